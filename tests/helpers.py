@@ -1,0 +1,59 @@
+"""Shared test helpers: golden fixture -> checkpoint / oracle Scene, error metrics."""
+import numpy as np
+import torch
+
+from oracle import tensoir_oracle as O
+
+
+def golden_checkpoint(g):
+    """Rebuild the reference-format checkpoint stored in tests/golden/small_scene.npz."""
+    sd = {k[3:]: torch.from_numpy(np.array(g[k])) for k in g.files if k.startswith("sd/")}
+    rot = [int(r) for r in g["scene/light_rotation"]]
+    kwargs = {
+        "aabb": torch.from_numpy(np.array(g["scene/aabb"])), "gridSize": [int(x) for x in g["scene/grid"]],
+        "density_n_comp": [16, 16, 16], "appearance_n_comp": [48, 48, 48], "app_dim": 27,
+        "density_shift": -10, "alphaMask_thres": 0.001, "distance_scale": 25,
+        "rayMarch_weight_thres": 0.0001, "fea2denseAct": "softplus", "near_far": [2.0, 6.0],
+        "step_ratio": 0.5, "shadingMode": "MLP_Fea", "pos_pe": 2, "view_pe": 2, "fea_pe": 2,
+        "featureC": 128, "normals_kind": "derived_plus_predicted", "light_num": len(rot),
+        "light_kind": "sg", "numLgtSGs": 128, "light_rotation": rot,
+    }
+    vol = torch.from_numpy(np.array(g["scene/alpha_volume"]))
+    ckpt = {"kwargs": kwargs, "state_dict": sd,
+            "alphaMask.shape": tuple(vol.shape),
+            "alphaMask.mask": np.packbits(vol.bool().numpy().reshape(-1)),
+            "alphaMask.aabb": torch.from_numpy(np.array(g["scene/alpha_aabb"]))}
+    return ckpt
+
+
+def scene_from_checkpoint(ckpt, envmap_h, envmap_w):
+    vol = aabb = None
+    if "alphaMask.aabb" in ckpt:
+        n = int(np.prod(ckpt["alphaMask.shape"]))
+        vol = torch.from_numpy(np.unpackbits(ckpt["alphaMask.mask"])[:n].reshape(ckpt["alphaMask.shape"])).float()
+        aabb = ckpt["alphaMask.aabb"]
+    return O.scene_from_state_dict(ckpt["state_dict"], ckpt["kwargs"], vol, aabb, envmap_h, envmap_w)
+
+
+def golden_scene(g):
+    h, w = [int(x) for x in g["scene/envmap_hw"]]
+    return scene_from_checkpoint(golden_checkpoint(g), h, w)
+
+
+def T(g, key):
+    return torch.from_numpy(np.array(g[key]))
+
+
+def max_err(a, b):
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    return float((a - b).abs().max()) if a.numel() else 0.0
+
+
+def rel_err(a, b, floor=1.0):
+    """max |a-b| / max(|b|, floor): the parity metric (north_star: 1e-4 relative)."""
+    a = torch.as_tensor(a).double().cpu()
+    b = torch.as_tensor(b).double().cpu()
+    if a.numel() == 0:
+        return 0.0
+    return float(((a - b).abs() / b.abs().clamp(min=floor)).max())
