@@ -1,0 +1,242 @@
+/*
+ * tensoir_hip.h -- C ABI of libtensoir_hip.so (MI355X / gfx950).
+ *
+ * The reference (Haian-Jin/TensoIR) has no FFI of its own: its hot path is a chain of ATen ops
+ * behind a Python call surface.  This header is the boundary a maintainer
+ * binds instead of those op chains; every entry point names the reference code it replaces
+ * (paths relative to the TensoIR repository root).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes, no framework types.  Every pointer is a DEVICE pointer unless it is
+ *     a `const Tir*` descriptor struct, which lives in HOST memory and is copied at launch.
+ *   - the caller owns every buffer (inputs, outputs, workspaces); the library allocates nothing
+ *     and keeps no state.  Calls are asynchronous on `stream` (a hipStream_t passed as void*);
+ *     no hipDeviceSynchronize inside; safe for hipGraph capture.
+ *   - fp32 I/O, int32 indices, int64 sizes.  Return 0 on success, a negative TIR_ERR_* /
+ *     -(hipError_t) on failure; nothing throws across the ABI.
+ *   - re-entrant; no internal threads.
+ */
+#ifndef TENSOIR_HIP_H
+#define TENSOIR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TIR_VERSION 100            /* 0.1.0 */
+
+#define TIR_OK               0
+#define TIR_ERR_ARG         -1001  /* null pointer / negative size / inconsistent descriptor      */
+#define TIR_ERR_UNSUPPORTED -1002  /* shape outside what the gfx950 kernels were built for        */
+#define TIR_ERR_NO_DEVICE   -1003  /* no HIP device / kernel image not loadable on this device    */
+
+/* ---------------------------------------------------------------------------------------------
+ * Packed VM field (device-resident shadow of TensorVMSplit's parameters).
+ * Reference layout: density_plane[i] [1,C,H_i,W_i], density_line[i] [1,C,R_i,1]
+ * (models/tensoRF_rotated_lights.py:19-29); here channel-last so one bilinear tap is one
+ * contiguous C*4-byte run (64 B for C=16, 192 B for C=48).
+ *   plane i: H_i = grid[matMode[i][1]], W_i = grid[matMode[i][0]]; line i: R_i = grid[vecMode[i]]
+ *   matMode = {{0,1},{0,2},{1,2}}, vecMode = {2,1,0}   (models/tensorBase_rotated_lights.py:398-399)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct TirField {
+    float aabb_min[3];
+    float aabb_max[3];
+    float inv_aabb[3];       /* 2/(max-min), fp32 as update_stepSize computes it (:611-612)        */
+    int32_t grid[3];         /* gridSize x,y,z                                                      */
+    float step_size;         /* stepSize (:615)                                                     */
+    float distance_scale;    /* 25  (opt.py:77)                                                     */
+    float density_shift;     /* -10 (opt.py:79)                                                     */
+    float weight_thres;      /* rayMarch_weight_thres 1e-4 (:354)                                   */
+    float near_, far_;       /* near_far (:385)                                                     */
+    int32_t act;             /* 0 = softplus, 1 = relu  (feature2density :813-817)                  */
+    int32_t n_dcomp;         /* density channels per plane (16), multiple of 4                      */
+    int32_t n_acomp;         /* appearance channels per plane (48), multiple of 4                   */
+    int32_t app_dim;         /* 27                                                                  */
+    int32_t n_lights;
+    const float* dplane[3];  /* [H_i][W_i][n_dcomp]                                                 */
+    const float* dline[3];   /* [R_i][n_dcomp]                                                      */
+    const float* aplane[3];  /* [H_i][W_i][n_acomp]                                                 */
+    const float* aline[3];   /* [R_i][n_acomp]                                                      */
+    const float* basis_t;    /* [3*n_acomp][32]: basis_mat^T, app_dim padded to 32 with zeros       */
+    const float* light_line; /* [n_lights][3*n_acomp]  (light_line.weight)                          */
+    const float* light_mean; /* [3*n_acomp] mean over lights (tensoRF_rotated_lights.py:160-161)    */
+    const uint32_t* occ_bits;/* bit-packed AlphaGridMask volume, bit (z*H+y)*W+x; NULL = no mask    */
+    int32_t occ_dim[3];      /* W,H,D of the mask volume                                            */
+    float occ_aabb_min[3];   /* the mask's own aabb (:105) ...                                      */
+    float occ_inv[3];        /* ... and (1/size)*2 (:107)                                           */
+} TirField;
+
+/* One 3-layer decoder (in -> hidden ReLU -> hidden ReLU -> out, then activation):
+ * MLPRender_Fea / MLPBRDF_PEandFeature (models/tensorBase_rotated_lights.py:122-146, :182-208).
+ * `packed` is produced by tir_pack_mlp. */
+typedef struct TirMlp {
+    const float* packed;
+    int32_t feat_dim;        /* 27                                                                  */
+    int32_t pe;              /* fea_pe == view_pe == pos_pe (2)                                     */
+    int32_t hidden;          /* 128                                                                 */
+    int32_t out_dim;         /* 3 (rgb, normal) or 4 (albedo+roughness)                             */
+    int32_t act;             /* 0 = sigmoid, 1 = tanh                                               */
+} TirMlp;
+
+/* Environment light as spherical Gaussians + per-light z-rotation
+ * (models/tensorBase_rotated_lights.py:461-488, :577-606). */
+typedef struct TirEnvSG {
+    const float* sgs;        /* [n_sg][7]  lobe xyz, lambda, mu rgb (raw parameters)                */
+    const float* rot;        /* [n_lights][9] row-major light_rotation_matrix                       */
+    int32_t n_sg;
+    int32_t n_lights;
+} TirEnvSG;
+
+int  tir_version(void);
+const char* tir_error_string(int code);
+/* 0 when a gfx950 device is present and the code object loads. */
+int  tir_device_check(void);
+
+/* ---- packing (build the shadow copies; re-run after any parameter update / upsample / shrink:
+ *      train_tensoIR.py:385-422) -------------------------------------------------------------- */
+/* [C,H,W] -> [H,W,C]   (also lines with W=1) */
+int tir_pack_plane(const float* src, float* dst, int32_t C, int32_t H, int32_t W, void* stream);
+/* float volume -> bits (value > 0.5); n voxels; bits must hold (n+31)/32 words, pre-zeroed not required */
+int tir_pack_occupancy(const float* vol, uint32_t* bits, int64_t n, void* stream);
+/* basis_mat.weight [app_dim][n_in] -> [n_in][32] */
+int tir_pack_basis(const float* w, float* dst, int32_t app_dim, int32_t n_in, void* stream);
+/* light_line.weight [L][n] -> mean over L [n] */
+int tir_light_mean(const float* light_line, float* mean, int32_t L, int32_t n, void* stream);
+int64_t tir_mlp_packed_floats(int32_t feat_dim, int32_t pe, int32_t hidden, int32_t out_dim);
+/* nn.Linear weights ([out][in] row-major) + biases of mlp.{0,2,4} -> packed blob */
+int tir_pack_mlp(const float* w0, const float* b0, const float* w1, const float* b1,
+                 const float* w2, const float* b2, int32_t feat_dim, int32_t pe, int32_t hidden,
+                 int32_t out_dim, float* packed, void* stream);
+
+/* ---- K2: compute_densityfeature + feature2density (models/tensoRF_rotated_lights.py:95-110,
+ *      models/tensorBase_rotated_lights.py:813-817).  xyz normalised to [-1,1]^3.
+ *      feat / sigma may each be NULL. */
+int tir_vm_density_fwd(const TirField* f, const float* xyz, float* feat, float* sigma,
+                       int64_t n, void* stream);
+
+/* ---- a2: AlphaGridMask.sample_alpha(xyz) > 0 (models/tensorBase_rotated_lights.py:112-119) at
+ *      world-space points; hit[n] = 1/0.  Needs f->occ_bits. */
+int tir_occupancy_query(const TirField* f, const float* xyz, uint8_t* hit, int64_t n, void* stream);
+
+/* ---- K6: analytic d sigma/d xyz and derived normal -normalize(grad, eps=1e-6)
+ *      (compute_derived_normals models/tensorBase_rotated_lights.py:839-856 ->
+ *       compute_densityfeature_with_xyz_grad models/tensoRF_rotated_lights.py:113-129 ->
+ *       models/relight_utils.py:57-107).  sigma/grad/normal may each be NULL. */
+int tir_density_grad_fwd(const TirField* f, const float* xyz, float* sigma, float* grad,
+                         float* normal, int64_t n, void* stream);
+
+/* ---- K4: compute_appfeature / compute_intrinfeature / compute_bothfeature
+ *      (models/tensoRF_rotated_lights.py:132-224).  light_idx (per point, or per `idx_map` entry when
+ *      idx_map != NULL: light_idx[idx_map[p]]) may be NULL when rad_feat is NULL.
+ *      rad_feat / int_feat [n][app_dim], either may be NULL. */
+int tir_vm_app_fwd(const TirField* f, const float* xyz, const int32_t* light_idx,
+                   const int32_t* idx_map, float* rad_feat, float* int_feat,
+                   int64_t n, void* stream);
+
+/* ---- K5: positional_encoding + 3-layer MLP + activation
+ *      (models/tensorBase_rotated_lights.py:12-17, :136-146, :198-208).
+ *      input row = [feat, aux, PE(feat), PE(aux)]; aux row p is aux[aux_map ? aux_map[p] : p]. */
+int tir_mlp_fwd(const TirMlp* m, const float* feat, const float* aux, const int32_t* aux_map,
+                float* out, int64_t n, void* stream);
+/* same contract, plain VALU kernel (any hidden size); used to cross-check the MFMA kernel */
+int tir_mlp_fwd_valu(const TirMlp* m, const float* feat, const float* aux, const int32_t* aux_map,
+                     float* out, int64_t n, void* stream);
+
+/* ---- K1+K2+K3 primary march: sample_ray + alpha-mask cull + density + raw2alpha
+ *      (models/tensorBase_rotated_lights.py:705-724, :892-921, :21-28).
+ *      rays [B][6]; ray_jitter [B] (is_train stratification, :717) or NULL.
+ *      Outputs: weight [B][S]; acc[B] = sum w; depth[B] = sum w*z; t_end[B] = prod(1-a+1e-10);
+ *      app_count[B] = #{w > weight_thres}.  t_stop: a ray stops marching once its running
+ *      transmittance drops below t_stop (remaining weights are written as 0; the error in acc is
+ *      < t_stop); pass 0 for the exact full march. */
+int tir_march_primary_fwd(const TirField* f, const float* rays, const float* ray_jitter,
+                          int32_t B, int32_t S, float t_stop, float* weight, float* acc,
+                          float* depth, float* t_end, int32_t* app_count, void* stream);
+
+/* exclusive scan of counts[n] -> offsets[n+1] (offsets[n] = total) */
+int tir_exclusive_scan(const int32_t* counts, int32_t* offsets, int32_t n, void* stream);
+
+/* Compact the samples with weight > thres into records ordered by (ray, sample) -- the order of
+ * the reference's boolean-mask indexing xyz_sampled[app_mask] (:924-926).
+ * rec_ray [A], rec_k [A], rec_w [A], rec_xyz [A][3] (normalised coords, :916). */
+int tir_compact_primary(const TirField* f, const float* rays, const float* ray_jitter,
+                        const float* weight, const int32_t* offsets, int32_t B, int32_t S,
+                        int32_t* rec_ray, int32_t* rec_k, float* rec_w, float* rec_xyz,
+                        void* stream);
+
+/* ---- compositing + tone mapping of the primary pass (models/tensorBase_rotated_lights.py:973-1031).
+ *      Per-record decoder outputs are summed per ray in sample order.  is_relight == 0 follows
+ *      the early-return branch (:978-986).  Any per-record pointer may be NULL (treated as 0).
+ *      out_maps [B][20]: rgb3 depth1 normal3 albedo3 rough1 fresnel3 acc1 ndiff1 norient1
+ *                        albcost1 rghcost1 (pad1). */
+#define TIR_MAP_STRIDE 20
+int tir_composite_primary(const float* rays, const int32_t* offsets, const float* rec_w,
+                          const float* rgb, const float* brdf, const float* brdf_jit,
+                          const float* pred_normal, const float* derived_normal,
+                          const float* acc, const float* depth, int32_t B, int32_t white_bg,
+                          int32_t is_relight, float fixed_fresnel, float* out_maps, void* stream);
+
+/* ---- K7 secondary march: sample_ray_equally + cull + density + raw2alpha
+ *      (models/relight_utils.py:707-722, :657-705, :777-834).
+ *      Ray p starts at origins[org_map ? org_map[p] : p] along dirs[dir_map ? dir_map[p] : p];
+ *      active[p] == 0 skips the ray (outputs 0).  n_sample <= 256.
+ *      z_vals [n_sample] (device) are the sample distances near*(1-t)+far*t, t = linspace(0,1,n)
+ *      (:716-717) -- passed in so that they are bit-identical to the caller framework's linspace.
+ *      vis[p] = T_end, one_minus_acc[p] = 1 - sum w (either may be NULL).
+ *      When rec_counter != NULL the samples with w > weight_thres are appended (contiguously per
+ *      ray, in sample order; ray segments in arbitrary order) to rec_* (capacity rec_cap records;
+ *      overflowing rays are dropped and *rec_counter still counts them) and
+ *      ray_rec_off[p] / ray_rec_cnt[p] locate ray p's segment. */
+int tir_march_secondary_fwd(const TirField* f, const float* origins, const int32_t* org_map,
+                            const float* dirs, const int32_t* dir_map, const uint8_t* active,
+                            int64_t n_rays, int32_t n_sample, const float* z_vals,
+                            float t_stop, float* vis, float* one_minus_acc,
+                            int32_t* rec_counter, int64_t rec_cap, int32_t* rec_ray,
+                            float* rec_w, float* rec_xyz, int32_t* ray_rec_off,
+                            int32_t* ray_rec_cnt, void* stream);
+
+/* indirect[p] = sum over ray p's records of w * rgb  (models/relight_utils.py:832) */
+int tir_accumulate_records(const int32_t* ray_rec_off, const int32_t* ray_rec_cnt,
+                           const float* rec_w, const float* rec_rgb, int64_t n_rays,
+                           float* indirect, void* stream);
+
+/* ---- a15: get_light_rgbs for spherical Gaussians (models/tensorBase_rotated_lights.py:577-588,
+ *      :70-86).  dirs [D][3] -> out [n_lights][D][3]. */
+int tir_env_sg_fwd(const TirEnvSG* e, const float* dirs, int32_t D, float* out, void* stream);
+
+/* ---- geometry of render_with_BRDF (models/relight_utils.py:417-435): surface point, view
+ *      vector and the cosine mask.  maps = [M][TIR_MAP_STRIDE] rows of the selected rays,
+ *      rays [M][6], dirs [D][3].  surf [M][3], active [M][D] (cosine > 1e-6). */
+int tir_shade_setup(const float* maps, const float* rays, const float* dirs, int32_t M,
+                    int32_t D, float* surf, uint8_t* active, void* stream);
+
+/* ---- K8: GGX_specular + rendering-equation sum + tone map
+ *      (models/relight_utils.py:17-50, :452-480, :489-515).
+ *      vis [M][D], indirect [M][D][3] (NULL = no indirect), env [n_lights][D][3],
+ *      weight_d [D] = light_area_weight (or NULL with equal_area != 0: mean * 4pi, :470-471).
+ *      out_rgb [M][3]. */
+int tir_shade_integrate(const float* maps, const float* rays, const float* dirs,
+                        const int32_t* light_idx, const float* vis, const float* indirect,
+                        const float* env, const float* weight_d, int32_t M, int32_t D,
+                        int32_t n_lights, int32_t equal_area, int32_t use_srgb, float* out_rgb,
+                        void* stream);
+
+/* ---- K9: importance-sampled HDR relighting, loop body of scripts/relight_importance.py:119-170.
+ *      Per surface point m and sample s: light_dir/rgb [M][Ns][3], pdf [M][Ns], vis [M][Ns].
+ *      albedo [M][3], rough [M], fresnel [M][3], normal [M][3], rays_d [M][3].  out [M][3]. */
+int tir_relight_importance(const float* normal, const float* albedo, const float* rough,
+                           const float* fresnel, const float* rays_d, const float* light_dir,
+                           const float* light_rgb, const float* light_pdf, const float* vis,
+                           int32_t M, int32_t Ns, float* out_rgb, void* stream);
+
+/* GGX_specular alone (models/relight_utils.py:17-50): normal/v [M][3], l [M][D][3],
+ * rough/fresnel [M][3] -> spec [M][D][3]. */
+int tir_ggx_specular(const float* normal, const float* v, const float* l, const float* rough,
+                     const float* fresnel, int32_t M, int32_t D, float* spec, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TENSOIR_HIP_H */

@@ -1,0 +1,205 @@
+// Shared device helpers for libtensoir_hip (gfx950 / CDNA4 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "tensoir_hip.h"
+
+#define TIR_WAVE 64
+
+#define TIR_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return -(int)e__;             \
+    } while (0)
+
+static inline hipStream_t tir_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// matMode / vecMode of the reference (models/tensorBase_rotated_lights.py:398-399)
+__device__ __constant__ const int kMat0[3] = {0, 0, 1};
+__device__ __constant__ const int kMat1[3] = {1, 2, 2};
+__device__ __constant__ const int kVec[3] = {2, 1, 0};
+
+namespace tir {
+
+// ---- exactly-rounded fp32 steps where the reference's decision points (floor / compare) depend on
+// them; everything else may contract to FMA.
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+
+// normalize_coord: (x - aabb0) * invaabbSize - 1   (models/tensorBase_rotated_lights.py:640-641)
+__device__ __forceinline__ float norm_coord(float x, float mn, float inv) {
+    return sub_rn(mul_rn(sub_rn(x, mn), inv), 1.0f);
+}
+
+// grid_sample unnormalise, align_corners=True: ((x+1)/2)*(size-1)  (models/relight_utils.py:64-65)
+__device__ __forceinline__ float unnorm(float x, int size) {
+    return mul_rn(mul_rn(add_rn(x, 1.0f), 0.5f), (float)(size - 1));
+}
+
+struct Tap1 {   // linear interpolation along one axis, zero padding
+    int i0, i1;     // clamped indices (always loadable)
+    float w0, w1;   // weights, 0 for out-of-range taps
+    float t;        // fractional position
+    float m0, m1;   // in-range masks (1/0) for derivative taps
+};
+
+__device__ __forceinline__ Tap1 make_tap(float x, int size) {
+    Tap1 r;
+    float ix = unnorm(x, size);
+    float f0 = floorf(ix);
+    r.t = ix - f0;
+    int i0 = (int)f0, i1 = i0 + 1;
+    bool ok0 = (i0 >= 0) & (i0 < size);
+    bool ok1 = (i1 >= 0) & (i1 < size);
+    r.m0 = ok0 ? 1.0f : 0.0f;
+    r.m1 = ok1 ? 1.0f : 0.0f;
+    r.w0 = ok0 ? (1.0f - r.t) : 0.0f;
+    r.w1 = ok1 ? r.t : 0.0f;
+    r.i0 = min(max(i0, 0), size - 1);
+    r.i1 = min(max(i1, 0), size - 1);
+    return r;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// sum_c bilinear(plane)[c] * linear(line)[c] for one VM component group
+// (one term of compute_densityfeature, models/tensoRF_rotated_lights.py:103-108)
+template <int C4>
+__device__ __forceinline__ float plane_line_dot(const float* __restrict__ plane,
+                                                const float* __restrict__ line, int H, int W,
+                                                int R, float u, float v, float w) {
+    Tap1 tx = make_tap(u, W), ty = make_tap(v, H), tl = make_tap(w, R);
+    const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
+    const float* p00 = plane + ((size_t)ty.i0 * W + tx.i0) * (C4 * 4);
+    const float* p01 = plane + ((size_t)ty.i0 * W + tx.i1) * (C4 * 4);
+    const float* p10 = plane + ((size_t)ty.i1 * W + tx.i0) * (C4 * 4);
+    const float* p11 = plane + ((size_t)ty.i1 * W + tx.i1) * (C4 * 4);
+    const float* l0 = line + (size_t)tl.i0 * (C4 * 4);
+    const float* l1 = line + (size_t)tl.i1 * (C4 * 4);
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C4; ++c) {
+        float4 a = ld4(p00 + 4 * c), b = ld4(p01 + 4 * c), cc = ld4(p10 + 4 * c), d = ld4(p11 + 4 * c);
+        float4 e = ld4(l0 + 4 * c), g = ld4(l1 + 4 * c);
+        float px = fmaf(d.x, w11, fmaf(cc.x, w10, fmaf(b.x, w01, a.x * w00)));
+        float py = fmaf(d.y, w11, fmaf(cc.y, w10, fmaf(b.y, w01, a.y * w00)));
+        float pz = fmaf(d.z, w11, fmaf(cc.z, w10, fmaf(b.z, w01, a.z * w00)));
+        float pw = fmaf(d.w, w11, fmaf(cc.w, w10, fmaf(b.w, w01, a.w * w00)));
+        acc = fmaf(px, fmaf(g.x, tl.w1, e.x * tl.w0), acc);
+        acc = fmaf(py, fmaf(g.y, tl.w1, e.y * tl.w0), acc);
+        acc = fmaf(pz, fmaf(g.z, tl.w1, e.z * tl.w0), acc);
+        acc = fmaf(pw, fmaf(g.w, tl.w1, e.w * tl.w0), acc);
+    }
+    return acc;
+}
+
+// density feature at a normalised point (compute_densityfeature, models/tensoRF_rotated_lights.py:95-110)
+template <int C4>
+__device__ __forceinline__ float density_feature(const TirField& f, float x, float y, float z) {
+    const float p[3] = {x, y, z};
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int m0 = (i == 2) ? 1 : 0, m1 = (i == 0) ? 1 : 2, vi = 2 - i;
+        acc += plane_line_dot<C4>(f.dplane[i], f.dline[i], f.grid[m1], f.grid[m0], f.grid[vi],
+                                  p[m0], p[m1], p[vi]);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ float density_feature_dyn(const TirField& f, float x, float y, float z) {
+    switch (f.n_dcomp) {
+        case 16: return density_feature<4>(f, x, y, z);
+        case 8:  return density_feature<2>(f, x, y, z);
+        case 32: return density_feature<8>(f, x, y, z);
+        default: return density_feature<1>(f, x, y, z);   // n_dcomp == 4
+    }
+}
+
+// feature2density (models/tensorBase_rotated_lights.py:813-817); torch softplus: threshold 20
+__device__ __forceinline__ float feature2density(const TirField& f, float feat) {
+    if (f.act == 1) return fmaxf(feat, 0.0f);
+    float x = feat + f.density_shift;
+    return (x > 20.0f) ? x : log1pf(expf(x));
+}
+
+// AlphaGridMask.sample_alpha(...) > 0  (models/tensorBase_rotated_lights.py:112-119, :893-894).
+// The volume is 0/1 and trilinear weights are >= 0, so "interpolated value > 0" == "some corner
+// with non-zero weight is set"; evaluated on the bit-packed volume.
+__device__ __forceinline__ bool occupancy_hit(const TirField& f, float px, float py, float pz) {
+    const int W = f.occ_dim[0], H = f.occ_dim[1], D = f.occ_dim[2];
+    float qx = sub_rn(mul_rn(sub_rn(px, f.occ_aabb_min[0]), f.occ_inv[0]), 1.0f);
+    float qy = sub_rn(mul_rn(sub_rn(py, f.occ_aabb_min[1]), f.occ_inv[1]), 1.0f);
+    float qz = sub_rn(mul_rn(sub_rn(pz, f.occ_aabb_min[2]), f.occ_inv[2]), 1.0f);
+    float ix = unnorm(qx, W), iy = unnorm(qy, H), iz = unnorm(qz, D);
+    float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    bool ux = (ix - fx) > 0.0f, uy = (iy - fy) > 0.0f, uz = (iz - fz) > 0.0f;
+    bool hit = false;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz) {
+        int zz = z0 + dz;
+        bool okz = (zz >= 0) & (zz < D) & (dz == 0 || uz);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            int yy = y0 + dy;
+            bool oky = okz & (yy >= 0) & (yy < H) & (dy == 0 || uy);
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                int xx = x0 + dx;
+                bool ok = oky & (xx >= 0) & (xx < W) & (dx == 0 || ux);
+                if (ok) {
+                    int64_t bit = ((int64_t)zz * H + yy) * W + xx;
+                    hit |= (f.occ_bits[bit >> 5] >> (bit & 31)) & 1u;
+                }
+            }
+        }
+    }
+    return hit;
+}
+
+// in-bbox test of sample_ray / sample_ray_equally: ~((aabb0 > p) | (p > aabb1)).any()
+__device__ __forceinline__ bool in_bbox(const TirField& f, float px, float py, float pz) {
+    return !((f.aabb_min[0] > px) | (px > f.aabb_max[0]) | (f.aabb_min[1] > py) |
+             (py > f.aabb_max[1]) | (f.aabb_min[2] > pz) | (pz > f.aabb_max[2]));
+}
+
+// sigma at a world-space sample (bbox test, occupancy cull, density, activation):
+// models/tensorBase_rotated_lights.py:892-919.  Returns 0 for culled samples.
+__device__ __forceinline__ float sigma_at(const TirField& f, float px, float py, float pz) {
+    if (!in_bbox(f, px, py, pz)) return 0.0f;
+    if (f.occ_bits != nullptr && !occupancy_hit(f, px, py, pz)) return 0.0f;
+    float x = norm_coord(px, f.aabb_min[0], f.inv_aabb[0]);
+    float y = norm_coord(py, f.aabb_min[1], f.inv_aabb[1]);
+    float z = norm_coord(pz, f.aabb_min[2], f.inv_aabb[2]);
+    return feature2density(f, density_feature_dyn(f, x, y, z));
+}
+
+// inclusive product scan across `width` (32 or 64) consecutive lanes
+template <int WIDTH>
+__device__ __forceinline__ float scan_prod(float v, int lane_in_group) {
+#pragma unroll
+    for (int d = 1; d < WIDTH; d <<= 1) {
+        float o = __shfl_up(v, d, WIDTH);
+        if (lane_in_group >= d) v *= o;
+    }
+    return v;
+}
+
+template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int d = WIDTH / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WIDTH);
+    return v;
+}
+
+// linear2srgb_torch after the [0,1] clip (models/relight_utils.py:489-515)
+__device__ __forceinline__ float linear2srgb(float x) {
+    x = fminf(fmaxf(x, 0.0f), 1.0f);
+    float lin = x * 12.92f;
+    float nonlin = 1.055f * powf(x + 1e-6f, 0.41666666666666667f) - 0.055f;   // python: 1/2.4, (1.055-1) as doubles -> fp32
+    return (x <= 0.0031308f) ? lin : nonlin;
+}
+
+}  // namespace tir

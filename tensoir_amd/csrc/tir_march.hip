@@ -1,0 +1,451 @@
+// Ray marching kernels: primary (K1+K2+K3), record compaction, compositing, secondary (K7).
+#include "tir_common.hpp"
+
+using namespace tir;
+
+// ------------------------------------------------------------------------------------------------
+// per-ray setup of sample_ray (models/tensorBase_rotated_lights.py:705-713)
+// ------------------------------------------------------------------------------------------------
+struct RaySetup {
+    float o[3], d[3];
+    float t_min;
+};
+
+__device__ __forceinline__ RaySetup ray_setup(const TirField& f, const float* __restrict__ rays, int r) {
+    RaySetup s;
+    float tm = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        s.o[a] = rays[6 * (size_t)r + a];
+        s.d[a] = rays[6 * (size_t)r + 3 + a];
+        float vec = (s.d[a] == 0.0f) ? 1e-6f : s.d[a];
+        float ra = __fdiv_rn(sub_rn(f.aabb_max[a], s.o[a]), vec);
+        float rb = __fdiv_rn(sub_rn(f.aabb_min[a], s.o[a]), vec);
+        tm = fmaxf(tm, fminf(ra, rb));
+    }
+    s.t_min = fminf(fmaxf(tm, f.near_), f.far_);
+    return s;
+}
+
+// z of sample k: t_min + stepSize * (k [+ jitter])   (:714-719)
+__device__ __forceinline__ float sample_z(const TirField& f, float t_min, int k, float jitter, bool has_jitter) {
+    float rng = (float)k;
+    if (has_jitter) rng = add_rn(rng, jitter);
+    return add_rn(t_min, mul_rn(f.step_size, rng));
+}
+
+// ------------------------------------------------------------------------------------------------
+// primary march: one wave64 per ray, 64 consecutive samples per step, transmittance carried
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_march_primary(TirField f, const float* __restrict__ rays, const float* __restrict__ ray_jitter,
+                int B, int S, float t_stop, float* __restrict__ weight, float* __restrict__ acc_out,
+                float* __restrict__ depth_out, float* __restrict__ tend_out, int32_t* __restrict__ app_count) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= B) return;
+    RaySetup rs = ray_setup(f, rays, ray);
+    const bool hj = ray_jitter != nullptr;
+    const float jit = hj ? ray_jitter[ray] : 0.0f;
+
+    float T = 1.0f;          // transmittance before the current step (wave-uniform)
+    float acc = 0.0f, depth = 0.0f;
+    int cnt = 0;
+    int k0 = 0;
+    for (; k0 < S; k0 += 64) {
+        const int k = k0 + lane;
+        float w = 0.0f, z = 0.0f, v = 1.0f;
+        if (k < S) {
+            z = sample_z(f, rs.t_min, k, jit, hj);
+            float px = add_rn(rs.o[0], mul_rn(rs.d[0], z));
+            float py = add_rn(rs.o[1], mul_rn(rs.d[1], z));
+            float pz = add_rn(rs.o[2], mul_rn(rs.d[2], z));
+            float sigma = sigma_at(f, px, py, pz);
+            // dists: z[k+1]-z[k], last 0 (:887); raw2alpha (:21-28) with dist * distance_scale (:921)
+            float dist = (k + 1 < S) ? sub_rn(sample_z(f, rs.t_min, k + 1, jit, hj), z) : 0.0f;
+            float alpha = 1.0f - expf(-sigma * mul_rn(dist, f.distance_scale));
+            v = add_rn(sub_rn(1.0f, alpha), 1e-10f);
+            w = alpha;   // multiplied by the exclusive transmittance below
+        }
+        float incl = scan_prod<64>(v, lane);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        w = w * (T * excl);
+        if (k < S) weight[(size_t)ray * S + k] = w;
+        acc += w;
+        depth = fmaf(w, z, depth);
+        cnt += __popcll(__ballot(w > f.weight_thres));
+        T = T * __shfl(incl, 63, 64);
+        if (T < t_stop) { k0 += 64; break; }
+    }
+    // early stop: remaining weights are zero
+    for (; k0 < S; k0 += 64) {
+        const int k = k0 + lane;
+        if (k < S) weight[(size_t)ray * S + k] = 0.0f;
+    }
+    acc = group_sum<64>(acc);
+    depth = group_sum<64>(depth);
+    if (lane == 0) {
+        acc_out[ray] = acc;
+        depth_out[ray] = depth;
+        if (tend_out) tend_out[ray] = T;
+        app_count[ray] = cnt;
+    }
+}
+
+extern "C" int tir_march_primary_fwd(const TirField* f, const float* rays, const float* ray_jitter,
+                                     int32_t B, int32_t S, float t_stop, float* weight, float* acc,
+                                     float* depth, float* t_end, int32_t* app_count, void* stream) {
+    if (!f || B < 0 || S <= 0) return TIR_ERR_ARG;
+    if (B == 0) return TIR_OK;
+    if (!rays || !weight || !acc || !depth || !app_count) return TIR_ERR_ARG;
+    if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_march_primary, dim3((B + 3) / 4), dim3(256), 0, tir_stream(stream), *f, rays,
+                       ray_jitter, B, S, t_stop, weight, acc, depth, t_end, app_count);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan of small int arrays (ray counts): single workgroup, chunked
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_exclusive_scan(const int32_t* __restrict__ counts, int32_t* __restrict__ offsets, int n) {
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        int i = base + tid;
+        int32_t v = (i < n) ? counts[i] : 0;
+        int32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int32_t o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int32_t woff = 0;
+        for (int q = 0; q < wv; ++q) woff += wsum[q];
+        int32_t carry = carry_s;
+        if (i < n) offsets[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) offsets[n] = carry_s;
+}
+
+extern "C" int tir_exclusive_scan(const int32_t* counts, int32_t* offsets, int32_t n, void* stream) {
+    if (!counts || !offsets || n < 0) return TIR_ERR_ARG;
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, tir_stream(stream), counts, offsets, n);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// compaction of weight > thres samples into (ray, sample)-ordered records
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_compact_primary(TirField f, const float* __restrict__ rays, const float* __restrict__ ray_jitter,
+                  const float* __restrict__ weight, const int32_t* __restrict__ offsets, int B, int S,
+                  int32_t* __restrict__ rec_ray, int32_t* __restrict__ rec_k, float* __restrict__ rec_w,
+                  float* __restrict__ rec_xyz) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= B) return;
+    int base = offsets[ray];
+    if (offsets[ray + 1] == base) return;
+    RaySetup rs = ray_setup(f, rays, ray);
+    const bool hj = ray_jitter != nullptr;
+    const float jit = hj ? ray_jitter[ray] : 0.0f;
+    for (int k0 = 0; k0 < S; k0 += 64) {
+        const int k = k0 + lane;
+        float w = (k < S) ? weight[(size_t)ray * S + k] : 0.0f;
+        bool keep = w > f.weight_thres;
+        unsigned long long m = __ballot(keep);
+        if (keep) {
+            int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+            float z = sample_z(f, rs.t_min, k, jit, hj);
+            rec_ray[slot] = ray;
+            rec_k[slot] = k;
+            rec_w[slot] = w;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float p = add_rn(rs.o[a], mul_rn(rs.d[a], z));
+                rec_xyz[3 * (size_t)slot + a] = norm_coord(p, f.aabb_min[a], f.inv_aabb[a]);
+            }
+        }
+        base += __popcll(m);
+    }
+}
+
+extern "C" int tir_compact_primary(const TirField* f, const float* rays, const float* ray_jitter,
+                                   const float* weight, const int32_t* offsets, int32_t B, int32_t S,
+                                   int32_t* rec_ray, int32_t* rec_k, float* rec_w, float* rec_xyz,
+                                   void* stream) {
+    if (!f || B < 0 || S <= 0) return TIR_ERR_ARG;
+    if (B == 0) return TIR_OK;
+    if (!rays || !weight || !offsets || !rec_ray || !rec_k || !rec_w || !rec_xyz) return TIR_ERR_ARG;
+    hipLaunchKernelGGL(k_compact_primary, dim3((B + 3) / 4), dim3(256), 0, tir_stream(stream), *f, rays,
+                       ray_jitter, weight, offsets, B, S, rec_ray, rec_k, rec_w, rec_xyz);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// compositing + tone mapping (models/tensorBase_rotated_lights.py:973-1031): one thread per ray walks
+// its records in sample order (deterministic sums).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_composite_primary(const float* __restrict__ rays, const int32_t* __restrict__ offsets,
+                    const float* __restrict__ rec_w, const float* __restrict__ rgb,
+                    const float* __restrict__ brdf, const float* __restrict__ brdf_jit,
+                    const float* __restrict__ pred_n, const float* __restrict__ der_n,
+                    const float* __restrict__ acc_in, const float* __restrict__ depth_in, int B, int white_bg,
+                    int is_relight, float fixed_fresnel, float* __restrict__ out) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B) return;
+    const int b = offsets[r], e = offsets[r + 1];
+    float c[3] = {0, 0, 0}, nm[3] = {0, 0, 0}, al[3] = {0, 0, 0};
+    float rough = 0, ndiff = 0, norient = 0, albc = 0, rghc = 0;
+    const float vd[3] = {rays[6 * (size_t)r + 3], rays[6 * (size_t)r + 4], rays[6 * (size_t)r + 5]};
+    for (int i = b; i < e; ++i) {
+        const float w = rec_w[i];
+        if (rgb) { c[0] = fmaf(w, rgb[3 * (size_t)i], c[0]); c[1] = fmaf(w, rgb[3 * (size_t)i + 1], c[1]); c[2] = fmaf(w, rgb[3 * (size_t)i + 2], c[2]); }
+        if (!is_relight) continue;
+        float a3[3] = {0, 0, 0}, rg = 0;
+        if (brdf) {
+            a3[0] = brdf[4 * (size_t)i]; a3[1] = brdf[4 * (size_t)i + 1]; a3[2] = brdf[4 * (size_t)i + 2];
+            rg = brdf[4 * (size_t)i + 3] * 0.9f + 0.09f;                         // :933
+            al[0] = fmaf(w, a3[0], al[0]); al[1] = fmaf(w, a3[1], al[1]); al[2] = fmaf(w, a3[2], al[2]);
+            rough = fmaf(w, rg, rough);
+        }
+        if (brdf && brdf_jit) {                                                  // :937-943, :858-863
+            float cost = 0.f;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                float aj = brdf_jit[4 * (size_t)i + q];
+                float base = fmaxf(fmaxf(a3[q], aj), 1e-6f);
+                float dlt = (a3[q] - aj) / base;
+                cost = fmaf(dlt, dlt, cost);
+            }
+            albc = fmaf(w, cost, albc);
+            float rj = brdf_jit[4 * (size_t)i + 3] * 0.9f + 0.09f;
+            float base = fmaxf(fmaxf(rg, rj), 1e-6f);
+            float dlt = (rg - rj) / base;
+            rghc = fmaf(w, dlt * dlt, rghc);
+        }
+        if (pred_n) {                                                            // :953-960
+            float p3[3] = {pred_n[3 * (size_t)i], pred_n[3 * (size_t)i + 1], pred_n[3 * (size_t)i + 2]};
+            nm[0] = fmaf(w, p3[0], nm[0]); nm[1] = fmaf(w, p3[1], nm[1]); nm[2] = fmaf(w, p3[2], nm[2]);
+            if (der_n) {
+                float d0 = p3[0] - der_n[3 * (size_t)i], d1 = p3[1] - der_n[3 * (size_t)i + 1], d2 = p3[2] - der_n[3 * (size_t)i + 2];
+                ndiff = fmaf(w, d0 * d0 + d1 * d1 + d2 * d2, ndiff);
+            }
+            float dot = vd[0] * p3[0] + vd[1] * p3[1] + vd[2] * p3[2];
+            norient = fmaf(w, fmaxf(dot, 0.f), norient);
+        }
+    }
+    const float acc = acc_in[r];
+    float depth = depth_in[r];
+    float* o = out + (size_t)r * TIR_MAP_STRIDE;
+    const float bg = 1.0f - acc;
+    if (!is_relight) {                                                           // :978-986
+        if (white_bg) { depth = depth + bg * rays[6 * (size_t)r + 5]; c[0] += bg; c[1] += bg; c[2] += bg; }
+        o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = depth;
+        for (int q = 4; q < TIR_MAP_STRIDE; ++q) o[q] = 0.f;
+        o[14] = acc;
+        return;
+    }
+    float fr = fixed_fresnel;
+    if (white_bg) {                                                              // :1004-1014
+        depth = depth + bg * rays[6 * (size_t)r + 5];                            // quirk: rays_d.z
+        c[0] += bg; c[1] += bg; c[2] += bg;
+        nm[2] += bg;                                                             // background normal (0,0,1)
+        al[0] += bg; al[1] += bg; al[2] += bg;
+        rough += bg;
+        fr += bg;
+    }
+    o[0] = linear2srgb(c[0]); o[1] = linear2srgb(c[1]); o[2] = linear2srgb(c[2]);  // :1017-1023
+    o[3] = depth;
+    float nn = fmaxf(sqrtf(nm[0] * nm[0] + nm[1] * nm[1] + nm[2] * nm[2]), 1e-6f); // :1028
+    o[4] = nm[0] / nn; o[5] = nm[1] / nn; o[6] = nm[2] / nn;
+    o[7] = fminf(fmaxf(al[0], 0.f), 1.f); o[8] = fminf(fmaxf(al[1], 0.f), 1.f); o[9] = fminf(fmaxf(al[2], 0.f), 1.f);
+    o[10] = fminf(fmaxf(rough, 0.f), 1.f);
+    fr = fminf(fmaxf(fr, 0.f), 1.f);
+    o[11] = fr; o[12] = fr; o[13] = fr;
+    o[14] = acc;
+    o[15] = ndiff; o[16] = norient; o[17] = albc; o[18] = rghc; o[19] = 0.f;
+}
+
+extern "C" int tir_composite_primary(const float* rays, const int32_t* offsets, const float* rec_w,
+                                     const float* rgb, const float* brdf, const float* brdf_jit,
+                                     const float* pred_normal, const float* derived_normal,
+                                     const float* acc, const float* depth, int32_t B, int32_t white_bg,
+                                     int32_t is_relight, float fixed_fresnel, float* out_maps, void* stream) {
+    if (B < 0) return TIR_ERR_ARG;
+    if (B == 0) return TIR_OK;
+    if (!rays || !offsets || !acc || !depth || !out_maps) return TIR_ERR_ARG;
+    hipLaunchKernelGGL(k_composite_primary, dim3((B + 63) / 64), dim3(64), 0, tir_stream(stream), rays, offsets,
+                       rec_w, rgb, brdf, brdf_jit, pred_normal, derived_normal, acc, depth, B, white_bg,
+                       is_relight, fixed_fresnel, out_maps);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7 secondary march: half a wave (32 lanes) per (surface point, direction) ray; n_sample/32 steps.
+// Weights of the ray are staged in LDS so that the w > thres records can be reserved with one atomic
+// and written contiguously in sample order.
+// ------------------------------------------------------------------------------------------------
+#define TIR_SEC_MAX_SAMPLES 256
+
+__global__ void __launch_bounds__(256)
+k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* __restrict__ org_map,
+                  const float* __restrict__ dirs, const int32_t* __restrict__ dir_map,
+                  const uint8_t* __restrict__ active, int64_t n_rays, int n_sample,
+                  const float* __restrict__ z_vals, float t_stop, float* __restrict__ vis,
+                  float* __restrict__ one_minus_acc, int32_t* __restrict__ rec_counter, int64_t rec_cap,
+                  int32_t* __restrict__ rec_ray, float* __restrict__ rec_w, float* __restrict__ rec_xyz,
+                  int32_t* __restrict__ ray_rec_off, int32_t* __restrict__ ray_rec_cnt) {
+    extern __shared__ float w_lds[];   // [8 half-waves][n_sample]
+    const int hl = threadIdx.x & 31;                 // lane within the half-wave
+    const int hw = threadIdx.x >> 5;                 // half-wave within the block
+    const int64_t ray = (int64_t)blockIdx.x * 8 + hw;
+    if (ray >= n_rays) return;
+    const bool want_rec = rec_counter != nullptr;
+    if (active && !active[ray]) {
+        if (hl == 0) {
+            if (vis) vis[ray] = 0.0f;
+            if (one_minus_acc) one_minus_acc[ray] = 0.0f;
+            if (want_rec) { ray_rec_off[ray] = 0; ray_rec_cnt[ray] = 0; }
+        }
+        return;
+    }
+    const size_t oi = org_map ? (size_t)org_map[ray] : (size_t)ray;
+    const size_t di = dir_map ? (size_t)dir_map[ray] : (size_t)ray;
+    const float o[3] = {origins[3 * oi], origins[3 * oi + 1], origins[3 * oi + 2]};
+    const float d[3] = {dirs[3 * di], dirs[3 * di + 1], dirs[3 * di + 2]};
+    float* wl = w_lds + (size_t)hw * n_sample;
+
+    float T = 1.0f, acc = 0.0f;
+    int cnt = 0;
+    int k0 = 0;
+    for (; k0 < n_sample; k0 += 32) {
+        const int k = k0 + hl;
+        float w = 0.0f, v = 1.0f;
+        if (k < n_sample) {
+            const float z = z_vals[k];
+            float px = add_rn(o[0], mul_rn(d[0], z));
+            float py = add_rn(o[1], mul_rn(d[1], z));
+            float pz = add_rn(o[2], mul_rn(d[2], z));
+            float sigma = sigma_at(f, px, py, pz);
+            float dist = (k + 1 < n_sample) ? sub_rn(z_vals[k + 1], z) : 0.0f;
+            float alpha = 1.0f - expf(-sigma * mul_rn(dist, f.distance_scale));
+            v = add_rn(sub_rn(1.0f, alpha), 1e-10f);
+            w = alpha;
+        }
+        float incl = scan_prod<32>(v, hl);
+        float excl = __shfl_up(incl, 1, 32);
+        if (hl == 0) excl = 1.0f;
+        w = w * (T * excl);
+        if (want_rec && k < n_sample) wl[k] = w;
+        acc += w;
+        const bool keep = w > f.weight_thres;
+        unsigned long long m = __ballot(keep);
+        cnt += __popc((unsigned)(m >> ((threadIdx.x & 32) ? 32 : 0)));
+        T = T * __shfl(incl, 31, 32);
+        if (T < t_stop) { k0 += 32; break; }
+    }
+    const int k_end = min(k0, n_sample);   // samples [k_end, n_sample) have zero weight
+    acc = group_sum<32>(acc);
+    if (hl == 0) {
+        if (vis) vis[ray] = T;
+        if (one_minus_acc) one_minus_acc[ray] = 1.0f - acc;
+    }
+    if (!want_rec) return;
+    int base = 0;
+    if (hl == 0) {
+        if (cnt > 0) base = atomicAdd(rec_counter, cnt);
+        bool fits = (int64_t)base + cnt <= rec_cap;
+        ray_rec_off[ray] = base;
+        ray_rec_cnt[ray] = (cnt > 0 && fits) ? cnt : 0;
+        if (!fits) base = -1;
+    }
+    base = __shfl(base, 0, 32);
+    if (cnt == 0 || base < 0) return;
+    for (int q0 = 0; q0 < k_end; q0 += 32) {
+        const int k = q0 + hl;
+        float w = (k < k_end) ? wl[k] : 0.0f;
+        const bool keep = w > f.weight_thres;
+        unsigned long long m = __ballot(keep);
+        unsigned hm = (unsigned)(m >> ((threadIdx.x & 32) ? 32 : 0));
+        if (keep) {
+            int slot = base + __popc(hm & ((1u << hl) - 1u));
+            const float z = z_vals[k];
+            rec_ray[slot] = (int32_t)ray;
+            rec_w[slot] = w;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float p = add_rn(o[a], mul_rn(d[a], z));
+                rec_xyz[3 * (size_t)slot + a] = norm_coord(p, f.aabb_min[a], f.inv_aabb[a]);
+            }
+        }
+        base += __popc(hm);
+    }
+}
+
+extern "C" int tir_march_secondary_fwd(const TirField* f, const float* origins, const int32_t* org_map,
+                                       const float* dirs, const int32_t* dir_map, const uint8_t* active,
+                                       int64_t n_rays, int32_t n_sample, const float* z_vals,
+                                       float t_stop, float* vis, float* one_minus_acc,
+                                       int32_t* rec_counter, int64_t rec_cap, int32_t* rec_ray,
+                                       float* rec_w, float* rec_xyz, int32_t* ray_rec_off,
+                                       int32_t* ray_rec_cnt, void* stream) {
+    if (!f || n_rays < 0 || n_sample <= 0) return TIR_ERR_ARG;
+    if (n_sample > TIR_SEC_MAX_SAMPLES) return TIR_ERR_UNSUPPORTED;
+    if (n_rays == 0) return TIR_OK;
+    if (!origins || !dirs || !z_vals) return TIR_ERR_ARG;
+    if (rec_counter && (!rec_ray || !rec_w || !rec_xyz || !ray_rec_off || !ray_rec_cnt || rec_cap < 0)) return TIR_ERR_ARG;
+    if (n_rays >= (int64_t)1 << 31) return TIR_ERR_UNSUPPORTED;
+    if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
+    size_t lds = rec_counter ? (size_t)8 * n_sample * sizeof(float) : 0;
+    hipLaunchKernelGGL(k_march_secondary, dim3((unsigned)((n_rays + 7) / 8)), dim3(256), lds, tir_stream(stream),
+                       *f, origins, org_map, dirs, dir_map, active, n_rays, n_sample, z_vals, t_stop, vis,
+                       one_minus_acc, rec_counter, rec_cap, rec_ray, rec_w, rec_xyz, ray_rec_off, ray_rec_cnt);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+// indirect[p] = sum_k w * rgb over ray p's records, in sample order (models/relight_utils.py:832)
+__global__ void __launch_bounds__(256)
+k_accumulate_records(const int32_t* __restrict__ off, const int32_t* __restrict__ cnt,
+                     const float* __restrict__ rec_w, const float* __restrict__ rec_rgb, int64_t n,
+                     float* __restrict__ indirect) {
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float c0 = 0, c1 = 0, c2 = 0;
+    const int b = off[p], e = b + cnt[p];
+    for (int i = b; i < e; ++i) {
+        float w = rec_w[i];
+        c0 = fmaf(w, rec_rgb[3 * (size_t)i], c0);
+        c1 = fmaf(w, rec_rgb[3 * (size_t)i + 1], c1);
+        c2 = fmaf(w, rec_rgb[3 * (size_t)i + 2], c2);
+    }
+    indirect[3 * p] = c0; indirect[3 * p + 1] = c1; indirect[3 * p + 2] = c2;
+}
+
+extern "C" int tir_accumulate_records(const int32_t* ray_rec_off, const int32_t* ray_rec_cnt,
+                                      const float* rec_w, const float* rec_rgb, int64_t n_rays,
+                                      float* indirect, void* stream) {
+    if (n_rays < 0) return TIR_ERR_ARG;
+    if (n_rays == 0) return TIR_OK;
+    if (!ray_rec_off || !ray_rec_cnt || !indirect) return TIR_ERR_ARG;
+    hipLaunchKernelGGL(k_accumulate_records, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0,
+                       tir_stream(stream), ray_rec_off, ray_rec_cnt, rec_w, rec_rgb, n_rays, indirect);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}

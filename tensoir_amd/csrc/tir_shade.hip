@@ -1,0 +1,302 @@
+// K8: environment light (spherical Gaussians), GGX specular, rendering-equation integration,
+// importance-sampled HDR relighting.
+#include "tir_common.hpp"
+
+using namespace tir;
+
+namespace {
+
+// F.normalize(x, dim=-1): x / max(||x||, 1e-12)
+__device__ __forceinline__ void normalize3(float& x, float& y, float& z, float eps) {
+    float n = fmaxf(sqrtf(x * x + y * y + z * z), eps);
+    x /= n; y /= n; z /= n;
+}
+
+struct Surface {     // per-surface-point quantities of GGX_specular (models/relight_utils.py:22-37)
+    float N[3], V[3];
+    float NoV;
+    float alpha2[3], k[3];
+    float fres[3];
+    float alb_pi[3];
+};
+
+__device__ __forceinline__ Surface make_surface(const float* normal, const float* view, const float* rough3,
+                                                const float* fres3, const float* albedo) {
+    Surface s;
+    s.N[0] = normal[0]; s.N[1] = normal[1]; s.N[2] = normal[2];
+    s.V[0] = view[0]; s.V[1] = view[1]; s.V[2] = view[2];
+    normalize3(s.V[0], s.V[1], s.V[2], 1e-12f);
+    normalize3(s.N[0], s.N[1], s.N[2], 1e-12f);
+    float nov = s.V[0] * s.N[0] + s.V[1] * s.N[1] + s.V[2] * s.N[2];
+    float sg = (nov > 0.f) ? 1.f : ((nov < 0.f) ? -1.f : 0.f);           // N = N * NoV.sign()  (:30)
+    s.N[0] *= sg; s.N[1] *= sg; s.N[2] *= sg;
+    nov = s.N[0] * s.V[0] + s.N[1] * s.V[1] + s.N[2] * s.V[2];
+    s.NoV = fminf(fmaxf(nov, 1e-6f), 1.f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float r = rough3[c];
+        float a = r * r;
+        s.alpha2[c] = a * a;
+        s.k[c] = (a + 2.f * r + 1.0f) / 8.0f;
+        s.fres[c] = fres3[c];
+        s.alb_pi[c] = albedo ? albedo[c] / 3.14159265358979323846f : 0.f;
+    }
+    return s;
+}
+
+// specular BRDF for one light direction (un-normalised l allowed), three channels (:22-49)
+__device__ __forceinline__ void ggx_dir(const Surface& s, float lx, float ly, float lz, float spec[3]) {
+    normalize3(lx, ly, lz, 1e-12f);
+    float hx = (lx + s.V[0]) / 2.0f, hy = (ly + s.V[1]) / 2.0f, hz = (lz + s.V[2]) / 2.0f;
+    normalize3(hx, hy, hz, 1e-12f);
+    float NoL = fminf(fmaxf(s.N[0] * lx + s.N[1] * ly + s.N[2] * lz, 1e-6f), 1.f);
+    float NoH = fminf(fmaxf(s.N[0] * hx + s.N[1] * hy + s.N[2] * hz, 1e-6f), 1.f);
+    float VoH = fminf(fmaxf(s.V[0] * hx + s.V[1] * hy + s.V[2] * hz, 1e-6f), 1.f);
+    float FMi = ((-5.55473f) * VoH - 6.98316f) * VoH;
+    float p2 = exp2f(FMi);
+    const float four_pi = 4.0f * 3.14159265358979323846f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float frac0 = s.fres[c] + (1.f - s.fres[c]) * p2;
+        float frac = frac0 * s.alpha2[c];
+        float nom0 = NoH * NoH * (s.alpha2[c] - 1.f) + 1.f;
+        float nom1 = s.NoV * (1.f - s.k[c]) + s.k[c];
+        float nom2 = NoL * (1.f - s.k[c]) + s.k[c];
+        float nom = fminf(fmaxf(four_pi * nom0 * nom0 * nom1 * nom2, 1e-6f), four_pi);
+        spec[c] = frac / nom;
+    }
+}
+
+// ---- a15: SG environment radiance per (light rotation, direction) ------------------------------
+__global__ void __launch_bounds__(128)
+k_env_sg(TirEnvSG e, const float* __restrict__ dirs, int D, float* __restrict__ out) {
+    // one block of 128 threads per (light, dir): thread k evaluates SG k, block-reduces
+    const int ld = blockIdx.x;
+    const int l = ld / D, d = ld % D;
+    const float v0 = dirs[3 * d], v1 = dirs[3 * d + 1], v2 = dirs[3 * d + 2];
+    const float* R = e.rot + 9 * l;
+    // torch.matmul(dirs[1,D,3], R[L,3,3]): row-vector times matrix  (models/tensorBase_rotated_lights.py:586)
+    const float r0 = v0 * R[0] + v1 * R[3] + v2 * R[6];
+    const float r1 = v0 * R[1] + v1 * R[4] + v2 * R[7];
+    const float r2 = v0 * R[2] + v1 * R[5] + v2 * R[8];
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    for (int k = threadIdx.x; k < e.n_sg; k += blockDim.x) {
+        const float* g = e.sgs + 7 * k;
+        float nrm = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+        float dot = r0 * (g[0] / nrm) + r1 * (g[1] / nrm) + r2 * (g[2] / nrm);
+        float ex = expf(fabsf(g[3]) * (dot - 1.0f));
+        c0 += fabsf(g[4]) * ex; c1 += fabsf(g[5]) * ex; c2 += fabsf(g[6]) * ex;
+    }
+    __shared__ float red[3][2];
+    c0 = group_sum<64>(c0); c1 = group_sum<64>(c1); c2 = group_sum<64>(c2);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wv] = c0; red[1][wv] = c1; red[2][wv] = c2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* o = out + 3 * (size_t)ld;
+        o[0] = red[0][0] + red[0][1]; o[1] = red[1][0] + red[1][1]; o[2] = red[2][0] + red[2][1];
+    }
+}
+
+// ---- render_with_BRDF geometry (models/relight_utils.py:417-435) -----------------------------------
+__global__ void __launch_bounds__(256)
+k_shade_setup(const float* __restrict__ maps, const float* __restrict__ rays, const float* __restrict__ dirs,
+              int M, int D, float* __restrict__ surf, uint8_t* __restrict__ active) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)M * D) return;
+    const int m = (int)(i / D), d = (int)(i % D);
+    const float* mp = maps + (size_t)m * TIR_MAP_STRIDE;
+    const float* r = rays + 6 * (size_t)m;
+    if (d == 0) {
+        const float depth = mp[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) surf[3 * (size_t)m + a] = add_rn(r[a], mul_rn(depth, r[3 + a]));   // :422
+    }
+    // cosine = clamp(einsum(surf2l, normal_map), 0); mask = cosine > 1e-6   (:433-435)
+    float cs = dirs[3 * d] * mp[4] + dirs[3 * d + 1] * mp[5] + dirs[3 * d + 2] * mp[6];
+    active[i] = fmaxf(cs, 0.f) > 1e-6f ? 1 : 0;
+}
+
+// ---- K8: one wave per surface point, lanes over light directions -----------------------------------
+__global__ void __launch_bounds__(256)
+k_shade_integrate(const float* __restrict__ maps, const float* __restrict__ rays, const float* __restrict__ dirs,
+                  const int32_t* __restrict__ light_idx, const float* __restrict__ vis,
+                  const float* __restrict__ indirect, const float* __restrict__ env,
+                  const float* __restrict__ weight_d, int M, int D, int n_lights, int equal_area, int use_srgb,
+                  float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* mp = maps + (size_t)m * TIR_MAP_STRIDE;
+    const float* r = rays + 6 * (size_t)m;
+    float view[3] = {-r[3], -r[4], -r[5]};
+    normalize3(view[0], view[1], view[2], 1e-6f);                   // safe_l2_normalize(-rays_d)  (:429-430)
+    const float rough3[3] = {mp[10], mp[10], mp[10]};                // roughness.repeat(1,3)  (renderer.py:91)
+    Surface s = make_surface(mp + 4, view, rough3, mp + 11, mp + 7);
+    int li = light_idx ? light_idx[m] : 0;
+    li = min(max(li, 0), n_lights - 1);
+    const float* envl = env + (size_t)li * D * 3;
+    float c[3] = {0.f, 0.f, 0.f};
+    for (int d = lane; d < D; d += 64) {
+        const float lx = dirs[3 * d], ly = dirs[3 * d + 1], lz = dirs[3 * d + 2];
+        const float cosine = fmaxf(lx * mp[4] + ly * mp[5] + lz * mp[6], 0.f);
+        float spec[3];
+        ggx_dir(s, lx, ly, lz, spec);
+        const size_t md = (size_t)m * D + d;
+        const float v = vis[md];
+        const float wd = equal_area ? 1.0f : weight_d[d];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float light = v * envl[3 * d + q] + (indirect ? indirect[3 * md + q] : 0.f);   // :462
+            float brdf = s.alb_pi[q] + spec[q];                                               // :455
+            if (equal_area) c[q] += 4.0f * 3.14159265358979323846f * brdf * light * cosine;   // :470-471
+            else c[q] += brdf * light * cosine * wd;                                          // :474-475
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        float t = group_sum<64>(c[q]);
+        if (equal_area) t /= (float)D;
+        t = fminf(fmaxf(t, 0.f), 1.f);                                                        // :477
+        if (use_srgb) t = linear2srgb(t);
+        if (lane == 0) out[3 * (size_t)m + q] = t;
+    }
+}
+
+// ---- K9: importance-sampled relighting (scripts/relight_importance.py:154-170) ----------------------
+__global__ void __launch_bounds__(256)
+k_relight_importance(const float* __restrict__ normal, const float* __restrict__ albedo,
+                     const float* __restrict__ rough, const float* __restrict__ fresnel,
+                     const float* __restrict__ rays_d, const float* __restrict__ ldir,
+                     const float* __restrict__ lrgb, const float* __restrict__ lpdf,
+                     const float* __restrict__ vis, int M, int Ns, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float view[3] = {-rays_d[3 * (size_t)m], -rays_d[3 * (size_t)m + 1], -rays_d[3 * (size_t)m + 2]};
+    normalize3(view[0], view[1], view[2], 1e-6f);
+    const float rough3[3] = {rough[m], rough[m], rough[m]};          // [M,1] broadcast against [M,3]
+    const float* nm = normal + 3 * (size_t)m;
+    Surface s = make_surface(nm, view, rough3, fresnel + 3 * (size_t)m, albedo + 3 * (size_t)m);
+    float c[3] = {0.f, 0.f, 0.f};
+    for (int j = lane; j < Ns; j += 64) {
+        const size_t mj = (size_t)m * Ns + j;
+        const float lx = ldir[3 * mj], ly = ldir[3 * mj + 1], lz = ldir[3 * mj + 2];
+        const float cosine = lx * nm[0] + ly * nm[1] + lz * nm[2];   // not clamped (:125); vis is 0 below 1e-6
+        float spec[3];
+        ggx_dir(s, lx, ly, lz, spec);
+        const float v = vis[mj], pdf = lpdf[mj];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            c[q] += (s.alb_pi[q] + spec[q]) * (v * lrgb[3 * mj + q]) * cosine / pdf;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        float t = group_sum<64>(c[q]) / (float)Ns;
+        t = linear2srgb(fminf(fmaxf(t, 0.f), 1.f));
+        if (lane == 0) out[3 * (size_t)m + q] = t;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_ggx(const float* __restrict__ normal, const float* __restrict__ v, const float* __restrict__ l,
+      const float* __restrict__ rough, const float* __restrict__ fresnel, int M, int D, float* __restrict__ spec) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)M * D) return;
+    const int m = (int)(i / D);
+    Surface s = make_surface(normal + 3 * (size_t)m, v + 3 * (size_t)m, rough + 3 * (size_t)m,
+                             fresnel + 3 * (size_t)m, nullptr);
+    float sp[3];
+    ggx_dir(s, l[3 * i], l[3 * i + 1], l[3 * i + 2], sp);
+    spec[3 * i] = sp[0]; spec[3 * i + 1] = sp[1]; spec[3 * i + 2] = sp[2];
+}
+
+}  // namespace
+
+extern "C" int tir_env_sg_fwd(const TirEnvSG* e, const float* dirs, int32_t D, float* out, void* stream) {
+    if (!e || !e->sgs || !e->rot || e->n_sg <= 0 || e->n_lights <= 0 || D < 0) return TIR_ERR_ARG;
+    if (D == 0) return TIR_OK;
+    if (!dirs || !out) return TIR_ERR_ARG;
+    hipLaunchKernelGGL(k_env_sg, dim3(e->n_lights * D), dim3(128), 0, tir_stream(stream), *e, dirs, D, out);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_shade_setup(const float* maps, const float* rays, const float* dirs, int32_t M,
+                               int32_t D, float* surf, uint8_t* active, void* stream) {
+    if (M < 0 || D <= 0) return TIR_ERR_ARG;
+    if (M == 0) return TIR_OK;
+    if (!maps || !rays || !dirs || !surf || !active) return TIR_ERR_ARG;
+    int64_t n = (int64_t)M * D;
+    hipLaunchKernelGGL(k_shade_setup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tir_stream(stream), maps,
+                       rays, dirs, M, D, surf, active);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_shade_integrate(const float* maps, const float* rays, const float* dirs,
+                                   const int32_t* light_idx, const float* vis, const float* indirect,
+                                   const float* env, const float* weight_d, int32_t M, int32_t D,
+                                   int32_t n_lights, int32_t equal_area, int32_t use_srgb, float* out_rgb,
+                                   void* stream) {
+    if (M < 0 || D <= 0 || n_lights <= 0) return TIR_ERR_ARG;
+    if (M == 0) return TIR_OK;
+    if (!maps || !rays || !dirs || !vis || !env || !out_rgb || (!equal_area && !weight_d)) return TIR_ERR_ARG;
+    hipLaunchKernelGGL(k_shade_integrate, dim3((M + 3) / 4), dim3(256), 0, tir_stream(stream), maps, rays, dirs,
+                       light_idx, vis, indirect, env, weight_d, M, D, n_lights, equal_area, use_srgb, out_rgb);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_relight_importance(const float* normal, const float* albedo, const float* rough,
+                                      const float* fresnel, const float* rays_d, const float* light_dir,
+                                      const float* light_rgb, const float* light_pdf, const float* vis,
+                                      int32_t M, int32_t Ns, float* out_rgb, void* stream) {
+    if (M < 0 || Ns <= 0) return TIR_ERR_ARG;
+    if (M == 0) return TIR_OK;
+    if (!normal || !albedo || !rough || !fresnel || !rays_d || !light_dir || !light_rgb || !light_pdf || !vis || !out_rgb)
+        return TIR_ERR_ARG;
+    hipLaunchKernelGGL(k_relight_importance, dim3((M + 3) / 4), dim3(256), 0, tir_stream(stream), normal, albedo,
+                       rough, fresnel, rays_d, light_dir, light_rgb, light_pdf, vis, M, Ns, out_rgb);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_ggx_specular(const float* normal, const float* v, const float* l, const float* rough,
+                                const float* fresnel, int32_t M, int32_t D, float* spec, void* stream) {
+    if (M < 0 || D <= 0) return TIR_ERR_ARG;
+    if (M == 0) return TIR_OK;
+    if (!normal || !v || !l || !rough || !fresnel || !spec) return TIR_ERR_ARG;
+    int64_t n = (int64_t)M * D;
+    hipLaunchKernelGGL(k_ggx, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tir_stream(stream), normal, v, l,
+                       rough, fresnel, M, D, spec);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+// ---- misc API ---------------------------------------------------------------------------------------
+extern "C" int tir_version(void) { return TIR_VERSION; }
+
+extern "C" const char* tir_error_string(int code) {
+    switch (code) {
+        case TIR_OK: return "ok";
+        case TIR_ERR_ARG: return "invalid argument (null pointer, negative size or inconsistent descriptor)";
+        case TIR_ERR_UNSUPPORTED: return "shape not supported by the gfx950 kernels";
+        case TIR_ERR_NO_DEVICE: return "no usable HIP device";
+        default: return code < 0 ? hipGetErrorString((hipError_t)(-code)) : "unknown";
+    }
+}
+
+__global__ void k_probe(int* x) { if (threadIdx.x == 0) *x = 950; }
+
+extern "C" int tir_device_check(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return TIR_ERR_NO_DEVICE;
+    int* d = nullptr;
+    if (hipMalloc(&d, sizeof(int)) != hipSuccess) return TIR_ERR_NO_DEVICE;
+    hipLaunchKernelGGL(k_probe, dim3(1), dim3(64), 0, 0, d);
+    int h = 0;
+    hipError_t e = hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost);
+    hipFree(d);
+    return (e == hipSuccess && h == 950) ? TIR_OK : TIR_ERR_NO_DEVICE;
+}

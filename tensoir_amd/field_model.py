@@ -1,0 +1,677 @@
+"""Host-side mirror of the reference's field model for the hot path.
+
+Same class names, constructor kwargs, parameter names/shapes (reference checkpoints load unchanged)
+and method signatures as ``models/tensoRF_rotated_lights.py`` + ``models/tensorBase_rotated_lights.py``;
+every per-sample computation is dispatched to libtensoir_hip.so (see tensoir_amd/ops.py).  What stays
+in PyTorch is what SURVEY.md section 8 leaves there: parameter containers, regularisers,
+up-sampling / shrinking, checkpoint I/O.
+"""
+from __future__ import annotations
+
+import math
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import TensoirHipError, TirField
+
+MAT_MODE = [[0, 1], [0, 2], [1, 2]]
+VEC_MODE = [2, 1, 0]
+
+
+def raw2alpha(sigma, dist):
+    """models/tensorBase_rotated_lights.py:21-28 (kept for `from models... import raw2alpha` callers;
+    the kernels implement the same recurrence with a wavefront prefix product)."""
+    alpha = 1.0 - torch.exp(-sigma * dist)
+    T = torch.cumprod(torch.cat([torch.ones(alpha.shape[0], 1).to(alpha.device), 1.0 - alpha + 1e-10], -1), -1)
+    weights = alpha * T[:, :-1]
+    return alpha, weights, T[:, -1:]
+
+
+def safe_l2_normalize(x, dim=None, eps=1e-6):
+    return F.normalize(x, p=2, dim=dim, eps=eps)
+
+
+def _no_grad_only(what, *tensors):
+    if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors):
+        raise NotImplementedError(
+            f"{what}: backward kernels are not implemented yet (SURVEY.md section 8f-1); "
+            "call under torch.no_grad() -- tensoir_amd never falls back to eager PyTorch")
+
+
+class AlphaGridMask(nn.Module):
+    """models/tensorBase_rotated_lights.py:100-119."""
+
+    def __init__(self, device, aabb, alpha_volume):
+        super().__init__()
+        self.device = device
+        self.aabb = aabb.to(self.device)
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invgridSize = 1.0 / self.aabbSize * 2
+        self.alpha_volume = alpha_volume.view(1, 1, *alpha_volume.shape[-3:])
+        self.gridSize = torch.LongTensor([alpha_volume.shape[-1], alpha_volume.shape[-2],
+                                          alpha_volume.shape[-3]]).to(self.device)
+        self._bits = None
+
+    def bits(self):
+        if self._bits is None:
+            self._bits = ops.pack_occupancy(self.alpha_volume.to(torch.float32))
+        return self._bits
+
+    def _descriptor(self):
+        f = TirField()
+        f.occ_bits = self.bits().data_ptr()
+        D, H, W = self.alpha_volume.shape[-3:]
+        f.occ_dim[:] = [W, H, D]
+        f.occ_aabb_min[:] = self.aabb[0].tolist()
+        f.occ_inv[:] = self.invgridSize.tolist()
+        return f
+
+    def sample_alpha(self, xyz_sampled):
+        """Returns 1.0 where the reference's trilinear lookup is > 0 and 0.0 elsewhere (callers only
+        ever test ``> 0``: :804, :823, :893-894)."""
+        hit = ops.occupancy_query(self._descriptor(), xyz_sampled.reshape(-1, 3))
+        return hit.to(torch.float32)
+
+    def normalize_coord(self, xyz_sampled):
+        return (xyz_sampled - self.aabb[0]) * self.invgridSize - 1
+
+
+class _Decoder(nn.Module):
+    """Parameter container of one 150->128->128->out MLP with the reference's module layout
+    (``.mlp.{0,2,4}``), evaluated by tir_mlp_fwd."""
+
+    def __init__(self, in_chanel, pe_aux, feape, feature_c, outc, act):
+        super().__init__()
+        self.in_mlpC = 2 * pe_aux * 3 + 2 * feape * in_chanel + 3 + in_chanel
+        self.feape = feape
+        self.pe_aux = pe_aux
+        self.outc = outc
+        self.in_chanel = in_chanel
+        self._act = act
+        l1 = nn.Linear(self.in_mlpC, feature_c)
+        l2 = nn.Linear(feature_c, feature_c)
+        l3 = nn.Linear(feature_c, outc)
+        self.mlp = nn.Sequential(l1, nn.ReLU(inplace=True), l2, nn.ReLU(inplace=True), l3)
+        nn.init.constant_(self.mlp[-1].bias, 0)
+        self._packed = None
+        self._key = None
+
+    def packed(self):
+        ps = [self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias,
+              self.mlp[4].weight, self.mlp[4].bias]
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if key != self._key:
+            if self.feape != self.pe_aux:
+                raise TensoirHipError("the gfx950 decoder kernel needs fea_pe == view_pe == pos_pe")
+            self._packed = ops.PackedMlp(self.mlp, self.in_chanel, self.feape, self._act)
+            self._key = key
+        return self._packed
+
+    def run(self, feat, aux, aux_map=None):
+        _no_grad_only(type(self).__name__, feat, aux, *self.parameters())
+        return ops.mlp(self.packed(), feat, aux, aux_map)
+
+
+class MLPRender_Fea(_Decoder):
+    """models/tensorBase_rotated_lights.py:122-146."""
+
+    def __init__(self, inChanel, viewpe=6, feape=6, featureC=128):
+        super().__init__(inChanel, viewpe, feape, featureC, 3, 0)
+        self.viewpe = viewpe
+
+    def forward(self, pts, viewdirs, features):
+        return self.run(features, viewdirs)
+
+
+class MLPBRDF_PEandFeature(_Decoder):
+    """models/tensorBase_rotated_lights.py:182-208."""
+
+    def __init__(self, inChanel, pospe=6, feape=6, featureC=128, outc=1, act_net=None):
+        act = 1 if isinstance(act_net, nn.Tanh) else 0
+        super().__init__(inChanel, pospe, feape, featureC, outc, act)
+        self.pospe = pospe
+        self.act_net = act_net if act_net is not None else nn.Sigmoid()
+
+    def forward(self, pts, features):
+        return self.run(features, pts)
+
+
+def fibonacci_sphere(samples=1):
+    """models/tensorBase_rotated_lights.py:49-67."""
+    i = np.arange(samples, dtype=np.float64)
+    z = 1 - (i / float(samples - 1)) * 2
+    r = np.sqrt(1 - z * z)
+    th = np.pi * (3.0 - np.sqrt(5.0)) * i
+    return np.stack([np.cos(th) * r, np.sin(th) * r, z], axis=-1)
+
+
+def compute_energy(lgtSGs):
+    lam = torch.abs(lgtSGs[:, 3:4])
+    mu = torch.abs(lgtSGs[:, 4:])
+    return mu * 2.0 * np.pi / lam * (1.0 - torch.exp(-2.0 * lam))
+
+
+class TensorVMSplit(nn.Module):
+    """TensorVMSplit (models/tensoRF_rotated_lights.py:6) on top of TensorBase
+    (models/tensorBase_rotated_lights.py:343-403): same kwargs, same state_dict."""
+
+    def __init__(self, aabb, gridSize, device, density_n_comp=8, appearance_n_comp=24, app_dim=27,
+                 shadingMode="MLP_PE", alphaMask=None, near_far=[2.0, 6.0], density_shift=-10,
+                 alphaMask_thres=0.001, distance_scale=25, rayMarch_weight_thres=0.0001,
+                 pos_pe=2, view_pe=2, fea_pe=2, featureC=128, step_ratio=2.0, fea2denseAct="softplus",
+                 normals_kind="purely_predicted", light_rotation=["000", "120", "240"],
+                 envmap_w=32, envmap_h=16, light_kind="pixel", dataset=None, numLgtSGs=128,
+                 fixed_fresnel=0.04, **kwargs):
+        super().__init__()
+        if isinstance(density_n_comp, int):
+            density_n_comp = [density_n_comp] * 3
+        if isinstance(appearance_n_comp, int):
+            appearance_n_comp = [appearance_n_comp] * 3
+        self.density_n_comp = list(density_n_comp)
+        self.app_n_comp = list(appearance_n_comp)
+        self.app_dim = app_dim
+        self.aabb = torch.as_tensor(aabb, dtype=torch.float32).to(device)
+        self.alphaMask = alphaMask
+        self.device = device
+        self.density_shift = density_shift
+        self.alphaMask_thres = alphaMask_thres
+        self.distance_scale = distance_scale
+        self.rayMarch_weight_thres = rayMarch_weight_thres
+        self.fea2denseAct = fea2denseAct
+        self.near_far = near_far
+        self.step_ratio = step_ratio
+        self.shadingMode, self.normals_kind = shadingMode, normals_kind
+        self.pos_pe, self.view_pe, self.fea_pe, self.featureC = pos_pe, view_pe, fea_pe, featureC
+        self.light_num = len(light_rotation)
+        self.light_rotation = [int(r) for r in light_rotation]
+        self.envmap_w, self.envmap_h = envmap_w, envmap_h
+        self.dataset = dataset
+        self.light_kind = light_kind
+        self.numLgtSGs = numLgtSGs
+        self.fixed_fresnel = fixed_fresnel
+        # transmittance below which a primary / secondary ray stops marching (error in acc < this)
+        self.march_t_stop = 1e-6
+        self.matMode = MAT_MODE
+        self.vecMode = VEC_MODE
+        self.comp_w = [1, 1, 1]
+        self._field_cache = None
+        self._field_key = None
+        self.update_stepSize(gridSize)
+        self.init_svd_volume(gridSize[0], device)
+        self.init_render_func(shadingMode, pos_pe, view_pe, fea_pe, featureC, device)
+        self.init_light()
+
+    # ---- construction ----------------------------------------------------------------------------
+    def init_svd_volume(self, res, device):
+        """models/tensoRF_rotated_lights.py:11-29."""
+        self.density_plane, self.density_line = self.init_one_svd(self.density_n_comp, self.gridSize, 0.1, device)
+        self.app_plane, self.app_line = self.init_one_svd(self.app_n_comp, self.gridSize, 0.1, device)
+        self.basis_mat = nn.Linear(sum(self.app_n_comp), self.app_dim, bias=False).to(device)
+        self.light_line = nn.Embedding(self.light_num, sum(self.app_n_comp)).to(device)
+
+    def init_one_svd(self, n_component, gridSize, scale, device):
+        planes, lines = [], []
+        for i in range(3):
+            vec_id = self.vecMode[i]
+            m0, m1 = self.matMode[i]
+            planes.append(nn.Parameter(scale * torch.randn((1, n_component[i], int(gridSize[m1]), int(gridSize[m0])))))
+            lines.append(nn.Parameter(scale * torch.randn((1, n_component[i], int(gridSize[vec_id]), 1))))
+        return nn.ParameterList(planes).to(device), nn.ParameterList(lines).to(device)
+
+    def init_render_func(self, shadingMode, pos_pe, view_pe, fea_pe, featureC, device):
+        """models/tensorBase_rotated_lights.py:405-431.  Only the configuration every shipped config
+        uses is implemented in HIP: shadingMode 'MLP_Fea', normals 'derived_plus_predicted' /
+        'purely_predicted' / 'purely_derived'."""
+        if shadingMode != "MLP_Fea":
+            raise NotImplementedError(f"shadingMode={shadingMode!r}: only 'MLP_Fea' has gfx950 kernels")
+        if self.normals_kind not in ("derived_plus_predicted", "purely_predicted", "purely_derived"):
+            raise NotImplementedError(f"normals_kind={self.normals_kind!r} has no gfx950 kernels")
+        self.renderModule = MLPRender_Fea(self.app_dim, view_pe, fea_pe, featureC).to(device)
+        if self.normals_kind in ("purely_predicted", "derived_plus_predicted"):
+            self.renderModule_normal = MLPBRDF_PEandFeature(self.app_dim, pos_pe, fea_pe, featureC, outc=3,
+                                                            act_net=nn.Tanh()).to(device)
+        self.renderModule_brdf = MLPBRDF_PEandFeature(self.app_dim, pos_pe, fea_pe, featureC, outc=4,
+                                                      act_net=nn.Sigmoid()).to(device)
+
+    def generate_envir_map_dir(self, envmap_h, envmap_w, is_jittor=False):
+        """models/tensorBase_rotated_lights.py:435-453 (host side, tiny)."""
+        lat = np.pi / envmap_h
+        lng = 2 * np.pi / envmap_w
+        phi, theta = torch.meshgrid([torch.linspace(np.pi / 2 - 0.5 * lat, -np.pi / 2 + 0.5 * lat, envmap_h),
+                                     torch.linspace(np.pi - 0.5 * lng, -np.pi + 0.5 * lng, envmap_w)], indexing="ij")
+        sin_phi = torch.sin(torch.pi / 2 - phi)
+        light_area_weight = 4 * torch.pi * sin_phi / torch.sum(sin_phi)
+        assert 0 not in light_area_weight, "There shouldn't be light pixel that doesn't contribute"
+        light_area_weight = light_area_weight.to(torch.float32).reshape(-1)
+        if is_jittor:
+            pj, tj = lat * (torch.rand_like(phi) - 0.5), lng * (torch.rand_like(theta) - 0.5)
+            phi, theta = phi + pj, theta + tj
+        view_dirs = torch.stack([torch.cos(theta) * torch.cos(phi), torch.sin(theta) * torch.cos(phi),
+                                 torch.sin(phi)], dim=-1).view(-1, 3)
+        return light_area_weight, view_dirs
+
+    def init_light(self):
+        """models/tensorBase_rotated_lights.py:455-488."""
+        self.light_area_weight, self.fixed_viewdirs = self.generate_envir_map_dir(self.envmap_h, self.envmap_w)
+        if self.light_kind != "sg":
+            raise NotImplementedError(f"light_kind={self.light_kind!r}: only 'sg' has gfx950 kernels")
+        self.lgtSGs = nn.Parameter(torch.randn(self.numLgtSGs, 7), requires_grad=True)
+        self.lgtSGs.data[:, -2:] = self.lgtSGs.data[:, -3:-2].expand((-1, 2))
+        self.lgtSGs.data[:, 3:4] = 10.0 + torch.abs(self.lgtSGs.data[:, 3:4] * 20.0)
+        energy = compute_energy(self.lgtSGs.data)
+        self.lgtSGs.data[:, 4:] = torch.abs(self.lgtSGs.data[:, 4:]) / torch.sum(energy, dim=0, keepdim=True) * 2.0 * np.pi * 0.8
+        lobes = fibonacci_sphere(self.numLgtSGs // 2).astype(np.float32)
+        self.lgtSGs.data[:self.numLgtSGs // 2, :3] = torch.from_numpy(lobes)
+        self.lgtSGs.data[self.numLgtSGs // 2:, :3] = torch.from_numpy(lobes)
+        self.lgtSGs.data = self.lgtSGs.data.to(self.device)
+        mats = []
+        for i in range(self.light_num):
+            a = torch.tensor(self.light_rotation[i] / 180 * torch.pi).to(torch.float32)
+            mats.append(torch.tensor([[torch.cos(a), -torch.sin(a), 0], [torch.sin(a), torch.cos(a), 0],
+                                      [0, 0, 1]]).to(torch.float32))
+        self.light_rotation_matrix = torch.stack(mats, dim=0)
+
+    def gen_light_incident_dirs(self, sample_number=-1, method="fixed_envirmap", device="cuda"):
+        """models/tensorBase_rotated_lights.py:492-574 (host-side direction tables)."""
+        if method == "fixed_envirmap":
+            dirs = self.fixed_viewdirs
+        elif method == "stratified_sampling":
+            lat, lng = np.pi / self.envmap_h, 2 * np.pi / self.envmap_w
+            pb, tb = torch.meshgrid([torch.linspace(np.pi / 2 - 0.5 * lat, -np.pi / 2 + 0.5 * lat, self.envmap_h),
+                                     torch.linspace(np.pi - 0.5 * lng, -np.pi + 0.5 * lng, self.envmap_w)], indexing="ij")
+            pj, tj = lat * (torch.rand_like(pb) - 0.5), lng * (torch.rand_like(tb) - 0.5)
+            phi, theta = pb + pj, tb + tj
+            dirs = torch.stack([torch.cos(theta) * torch.cos(phi), torch.sin(theta) * torch.cos(phi),
+                                torch.sin(phi)], dim=-1)
+        elif method == "stratifed_sample_equal_areas":
+            sps, lng = 2 / self.envmap_h, 2 * np.pi / self.envmap_w
+            sb, tb = torch.meshgrid([torch.linspace(1 - 0.5 * sps, -1 + 0.5 * sps, self.envmap_h),
+                                     torch.linspace(np.pi - 0.5 * lng, -np.pi + 0.5 * lng, self.envmap_w)], indexing="ij")
+            sj, tj = sps * (torch.rand_like(sb) - 0.5), lng * (torch.rand_like(tb) - 0.5)
+            phi, theta = torch.asin(sb + sj), tb + tj
+            dirs = torch.stack([torch.cos(theta) * torch.cos(phi), torch.sin(theta) * torch.cos(phi),
+                                torch.sin(phi)], dim=-1)
+        elif method == "importance_sample":
+            _, view_dirs = self.generate_envir_map_dir(128, 256, is_jittor=True)
+            envir_map = self.get_light_rgbs(view_dirs.reshape(-1, 3).to(device), device=device)[0]
+            with torch.no_grad():
+                envir_map = envir_map.reshape(128, 256, 3)
+                inten = torch.sum(envir_map, dim=2, keepdim=True)
+                h, w, _ = inten.shape
+                sin_theta = torch.sin(torch.linspace(0 + 0.5 / h, np.pi - 0.5 / h, h)).to(device)
+                pdf = inten * sin_theta.view(-1, 1, 1)
+                pdf_s = pdf / torch.sum(pdf)
+                pdf_c = pdf_s * h * w / (2 * np.pi * np.pi * sin_theta.view(-1, 1, 1))
+                idx = torch.multinomial(pdf_s.view(-1), sample_number, replacement=True)
+                d = view_dirs.view(-1, 3).to(device)[idx]
+                return d, envir_map.view(-1, 3)[idx], pdf_c.view(-1, 1)[idx]
+        else:
+            raise ValueError(f"unknown light sampling method {method!r}")
+        return dirs.reshape(-1, 3)
+
+    def get_light_rgbs(self, incident_light_directions=None, device="cuda"):
+        """models/tensorBase_rotated_lights.py:577-606 (sg): dirs [D,3] -> [L,D,3] via tir_env_sg_fwd."""
+        _no_grad_only("get_light_rgbs", self.lgtSGs)
+        dirs = incident_light_directions.to(device).reshape(-1, 3).to(torch.float32)
+        return ops.env_sg(self.lgtSGs.to(device), self.light_rotation_matrix.to(device), dirs)
+
+    def update_stepSize(self, gridSize):
+        """models/tensorBase_rotated_lights.py:608-619."""
+        self.aabbSize = self.aabb[1] - self.aabb[0]
+        self.invaabbSize = 2.0 / self.aabbSize
+        self.gridSize = torch.LongTensor([int(g) for g in gridSize]).to(self.device)
+        self.units = self.aabbSize / (self.gridSize - 1)
+        self.stepSize = torch.mean(self.units) * self.step_ratio
+        self.aabbDiag = torch.sqrt(torch.sum(torch.square(self.aabbSize)))
+        self.nSamples = int((self.aabbDiag / self.stepSize).item()) + 1
+        self._field_key = None
+
+    def normalize_coord(self, xyz_sampled):
+        return (xyz_sampled - self.aabb[0]) * self.invaabbSize - 1
+
+    # ---- optimiser groups / regularisers (PyTorch, off the hot path) --------------------------------
+    def get_optparam_groups(self, lr_init_spatialxyz=0.02, lr_init_network=0.001):
+        """models/tensoRF_rotated_lights.py:33-57."""
+        g = [{"params": self.density_line, "lr": lr_init_spatialxyz},
+             {"params": self.density_plane, "lr": lr_init_spatialxyz},
+             {"params": self.app_line, "lr": lr_init_spatialxyz},
+             {"params": self.app_plane, "lr": lr_init_spatialxyz},
+             {"params": self.basis_mat.parameters(), "lr": lr_init_network},
+             {"params": self.light_line.parameters(), "lr": 0.001},
+             {"params": self.lgtSGs, "lr": 0.001},
+             {"params": self.renderModule.parameters(), "lr": lr_init_network},
+             {"params": self.renderModule_brdf.parameters(), "lr": lr_init_network}]
+        if hasattr(self, "renderModule_normal"):
+            g.append({"params": self.renderModule_normal.parameters(), "lr": lr_init_network})
+        return g
+
+    def vectorDiffs(self, vector_comps):
+        total = 0
+        for idx in range(len(vector_comps)):
+            n_comp, n_size = vector_comps[idx].shape[1:-1]
+            v = vector_comps[idx].view(n_comp, n_size)
+            dotp = torch.matmul(v, v.transpose(-1, -2))
+            non_diag = dotp.view(-1)[1:].view(n_comp - 1, n_comp + 1)[..., :-1]
+            total = total + torch.mean(torch.abs(non_diag))
+        return total
+
+    def vector_comp_diffs(self):
+        return self.vectorDiffs(self.density_line) + self.vectorDiffs(self.app_line)
+
+    def density_L1(self):
+        total = 0
+        for idx in range(len(self.density_plane)):
+            total = total + torch.mean(torch.abs(self.density_plane[idx])) + torch.mean(torch.abs(self.density_line[idx]))
+        return total
+
+    def TV_loss_density(self, reg):
+        total = 0
+        for idx in range(len(self.density_plane)):
+            total = total + reg(self.density_plane[idx]) * 1e-2
+        return total
+
+    def TV_loss_app(self, reg):
+        total = 0
+        for idx in range(len(self.app_plane)):
+            total = total + reg(self.app_plane[idx]) * 1e-2
+        return total
+
+    # ---- packed shadow of the parameters -----------------------------------------------------------
+    def _field_params(self):
+        return (list(self.density_plane) + list(self.density_line) + list(self.app_plane) +
+                list(self.app_line) + [self.basis_mat.weight, self.light_line.weight])
+
+    def packed_field(self) -> TirField:
+        """Channel-last / bit-packed shadow copies + the TirField descriptor; rebuilt whenever a
+        parameter's storage or version changes (optimizer step, upsample, shrink, load)."""
+        ps = self._field_params()
+        mask = self.alphaMask
+        key = (tuple((p.data_ptr(), p._version, tuple(p.shape)) for p in ps), id(mask),
+               self.stepSize.data_ptr())
+        if key == self._field_key and self._field_cache is not None:
+            return self._field_cache["desc"]
+        if len(set(self.density_n_comp)) != 1 or len(set(self.app_n_comp)) != 1:
+            raise TensoirHipError("per-plane component counts must be equal for the gfx950 kernels")
+        keep = {}
+        f = TirField()
+        f.aabb_min[:] = self.aabb[0].tolist()
+        f.aabb_max[:] = self.aabb[1].tolist()
+        f.inv_aabb[:] = self.invaabbSize.tolist()
+        f.grid[:] = [int(g) for g in self.gridSize.tolist()]
+        f.step_size = float(self.stepSize)
+        f.distance_scale = float(self.distance_scale)
+        f.density_shift = float(self.density_shift)
+        f.weight_thres = float(self.rayMarch_weight_thres)
+        f.near_, f.far_ = float(self.near_far[0]), float(self.near_far[1])
+        f.act = {"softplus": 0, "relu": 1}[self.fea2denseAct]
+        f.n_dcomp, f.n_acomp = self.density_n_comp[0], self.app_n_comp[0]
+        f.app_dim, f.n_lights = self.app_dim, self.light_num
+        for i in range(3):
+            for name, src, dst in (("dp", self.density_plane, f.dplane), ("dl", self.density_line, f.dline),
+                                   ("ap", self.app_plane, f.aplane), ("al", self.app_line, f.aline)):
+                t = ops.pack_plane(src[i])
+                keep[f"{name}{i}"] = t
+                dst[i] = t.data_ptr()
+        keep["basis"] = ops.pack_basis(self.basis_mat.weight)
+        keep["ll"] = self.light_line.weight.detach().to(torch.float32).contiguous()
+        keep["lm"] = ops.light_mean(keep["ll"])
+        f.basis_t, f.light_line, f.light_mean = keep["basis"].data_ptr(), keep["ll"].data_ptr(), keep["lm"].data_ptr()
+        if mask is not None:
+            keep["bits"] = mask.bits()
+            f.occ_bits = keep["bits"].data_ptr()
+            D, H, W = mask.alpha_volume.shape[-3:]
+            f.occ_dim[:] = [W, H, D]
+            f.occ_aabb_min[:] = mask.aabb[0].tolist()
+            f.occ_inv[:] = mask.invgridSize.tolist()
+        keep["desc"] = f
+        self._field_cache, self._field_key = keep, key
+        return f
+
+    # ---- per-point field functions (reference signatures) ---------------------------------------------
+    def compute_densityfeature(self, xyz_sampled):
+        """models/tensoRF_rotated_lights.py:95-110 -> tir_vm_density_fwd."""
+        _no_grad_only("compute_densityfeature", *self._field_params())
+        return ops.vm_density(self.packed_field(), xyz_sampled.reshape(-1, 3))[0]
+
+    def feature2density(self, density_features):
+        if self.fea2denseAct == "softplus":
+            return F.softplus(density_features + self.density_shift)
+        return F.relu(density_features)
+
+    def compute_appfeature(self, xyz_sampled, light_idx):
+        """models/tensoRF_rotated_lights.py:197-224 -> tir_vm_app_fwd."""
+        _no_grad_only("compute_appfeature", *self._field_params())
+        li = light_idx.reshape(-1).to(xyz_sampled.device, torch.int32)
+        return ops.vm_app(self.packed_field(), xyz_sampled.reshape(-1, 3), li, None, True, False)[0]
+
+    def compute_bothfeature(self, xyz_sampled, light_idx):
+        """models/tensoRF_rotated_lights.py:132-165."""
+        _no_grad_only("compute_bothfeature", *self._field_params())
+        li = light_idx.reshape(-1).to(xyz_sampled.device, torch.int32)
+        return ops.vm_app(self.packed_field(), xyz_sampled.reshape(-1, 3), li, None, True, True)
+
+    def compute_intrinfeature(self, xyz_sampled):
+        """models/tensoRF_rotated_lights.py:167-195."""
+        _no_grad_only("compute_intrinfeature", *self._field_params())
+        return ops.vm_app(self.packed_field(), xyz_sampled.reshape(-1, 3), None, None, False, True)[1]
+
+    def compute_derived_normals(self, xyz_locs):
+        """models/tensorBase_rotated_lights.py:839-856 -> tir_density_grad_fwd (closed form)."""
+        _no_grad_only("compute_derived_normals", *self._field_params())
+        return ops.density_grad(self.packed_field(), xyz_locs.reshape(-1, 3))[2]
+
+    def compute_alpha(self, xyz_locs, length=1):
+        """models/tensorBase_rotated_lights.py:819-837 (occupancy cull + density on the GPU)."""
+        f = self.packed_field()
+        xyz = xyz_locs.reshape(-1, 3).to(torch.float32)
+        sigma = ops.vm_density(f, self.normalize_coord(xyz), False, True)[1]
+        if self.alphaMask is not None:
+            sigma = sigma * ops.occupancy_query(f, xyz).to(sigma.dtype)
+        return (1 - torch.exp(-sigma * length)).view(xyz_locs.shape[:-1])
+
+    # ---- occupancy maintenance (models/tensorBase_rotated_lights.py:737-811) ----------------------------
+    @torch.no_grad()
+    def getDenseAlpha(self, gridSize=None):
+        gridSize = self.gridSize if gridSize is None else gridSize
+        samples = torch.stack(torch.meshgrid(torch.linspace(0, 1, int(gridSize[0])), torch.linspace(0, 1, int(gridSize[1])),
+                                             torch.linspace(0, 1, int(gridSize[2])), indexing="ij"), -1).to(self.device)
+        dense_xyz = self.aabb[0] * (1 - samples) + self.aabb[1] * samples
+        alpha = self.compute_alpha(dense_xyz.view(-1, 3), self.stepSize).view(dense_xyz.shape[:-1])
+        return alpha, dense_xyz
+
+    @torch.no_grad()
+    def updateAlphaMask(self, gridSize=(200, 200, 200)):
+        alpha, dense_xyz = self.getDenseAlpha(gridSize)
+        dense_xyz = dense_xyz.transpose(0, 2).contiguous()
+        alpha = alpha.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
+        total_voxels = gridSize[0] * gridSize[1] * gridSize[2]
+        alpha = F.max_pool3d(alpha, kernel_size=3, padding=1, stride=1).view(tuple(gridSize)[::-1])
+        alpha[alpha >= self.alphaMask_thres] = 1
+        alpha[alpha < self.alphaMask_thres] = 0
+        self.alphaMask = AlphaGridMask(self.device, self.aabb, alpha)
+        self._field_key = None
+        valid_xyz = dense_xyz[alpha > 0.5]
+        xyz_min, xyz_max = valid_xyz.amin(0), valid_xyz.amax(0)
+        print(f"bbox: {xyz_min, xyz_max} alpha rest %%%f" % (torch.sum(alpha) / total_voxels * 100))
+        return torch.stack((xyz_min, xyz_max))
+
+    @torch.no_grad()
+    def filtering_rays(self, all_rays, N_samples=256, chunk=10240 * 5, bbox_only=False):
+        tt = time.time()
+        N = torch.tensor(all_rays.shape[:-1]).prod()
+        masks = []
+        for idx in torch.split(torch.arange(N), chunk):
+            rays_chunk = all_rays[idx].to(self.device)
+            rays_o, rays_d = rays_chunk[..., :3], rays_chunk[..., 3:6]
+            if bbox_only:
+                vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+                rate_a = (self.aabb[1] - rays_o) / vec
+                rate_b = (self.aabb[0] - rays_o) / vec
+                t_min = torch.minimum(rate_a, rate_b).amax(-1)
+                t_max = torch.maximum(rate_a, rate_b).amin(-1)
+                m = t_max > t_min
+            else:
+                xyz, _, _ = self.sample_ray(rays_o, rays_d, N_samples=N_samples, is_train=False)
+                m = (self.alphaMask.sample_alpha(xyz).view(xyz.shape[:-1]) > 0).any(-1)
+            masks.append(m.cpu())
+        mask = torch.cat(masks).view(all_rays.shape[:-1])
+        print(f"Ray filtering done! takes {time.time() - tt} s. ray mask ratio: {torch.sum(mask) / N}")
+        return all_rays[mask], mask
+
+    def sample_ray(self, rays_o, rays_d, is_train=True, N_samples=-1):
+        """models/tensorBase_rotated_lights.py:705-724 (kept for filtering_rays; the march kernels
+        generate the same samples on the fly and never materialise them)."""
+        N_samples = N_samples if N_samples > 0 else self.nSamples
+        near, far = self.near_far
+        vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+        rate_a = (self.aabb[1] - rays_o) / vec
+        rate_b = (self.aabb[0] - rays_o) / vec
+        t_min = torch.minimum(rate_a, rate_b).amax(-1).clamp(min=near, max=far)
+        rng = torch.arange(N_samples)[None].float()
+        if is_train:
+            rng = rng.repeat(rays_d.shape[-2], 1)
+            rng += torch.rand_like(rng[:, [0]])
+        step = self.stepSize * rng.to(rays_o.device)
+        interpx = t_min[..., None] + step
+        rays_pts = rays_o[..., None, :] + rays_d[..., None, :] * interpx[..., None]
+        mask_outbbox = ((self.aabb[0] > rays_pts) | (rays_pts > self.aabb[1])).any(dim=-1)
+        return rays_pts, interpx, ~mask_outbbox
+
+    # ---- resolution changes (models/tensoRF_rotated_lights.py:227-288) ---------------------------------
+    @torch.no_grad()
+    def up_sampling_VM(self, plane_coef, line_coef, res_target):
+        for i in range(3):
+            vec_id = self.vecMode[i]
+            m0, m1 = self.matMode[i]
+            plane_coef[i] = nn.Parameter(F.interpolate(plane_coef[i].data, size=(res_target[m1], res_target[m0]),
+                                                       mode="bilinear", align_corners=True))
+            line_coef[i] = nn.Parameter(F.interpolate(line_coef[i].data, size=(res_target[vec_id], 1),
+                                                      mode="bilinear", align_corners=True))
+        return plane_coef, line_coef
+
+    @torch.no_grad()
+    def upsample_volume_grid(self, res_target):
+        self.app_plane, self.app_line = self.up_sampling_VM(self.app_plane, self.app_line, res_target)
+        self.density_plane, self.density_line = self.up_sampling_VM(self.density_plane, self.density_line, res_target)
+        self.update_stepSize(res_target)
+        print(f"upsamping to {res_target}")
+
+    @torch.no_grad()
+    def shrink(self, new_aabb):
+        xyz_min, xyz_max = new_aabb
+        t_l, b_r = (xyz_min - self.aabb[0]) / self.units, (xyz_max - self.aabb[0]) / self.units
+        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
+        b_r = torch.stack([b_r, self.gridSize]).amin(0)
+        for i in range(3):
+            mode0 = self.vecMode[i]
+            self.density_line[i] = nn.Parameter(self.density_line[i].data[..., t_l[mode0]:b_r[mode0], :])
+            self.app_line[i] = nn.Parameter(self.app_line[i].data[..., t_l[mode0]:b_r[mode0], :])
+            mode0, mode1 = self.matMode[i]
+            self.density_plane[i] = nn.Parameter(self.density_plane[i].data[..., t_l[mode1]:b_r[mode1], t_l[mode0]:b_r[mode0]])
+            self.app_plane[i] = nn.Parameter(self.app_plane[i].data[..., t_l[mode1]:b_r[mode1], t_l[mode0]:b_r[mode0]])
+        if not torch.all(self.alphaMask.gridSize == self.gridSize):
+            t_l_r, b_r_r = t_l / (self.gridSize - 1), (b_r - 1) / (self.gridSize - 1)
+            correct_aabb = torch.zeros_like(new_aabb)
+            correct_aabb[0] = (1 - t_l_r) * self.aabb[0] + t_l_r * self.aabb[1]
+            correct_aabb[1] = (1 - b_r_r) * self.aabb[0] + b_r_r * self.aabb[1]
+            new_aabb = correct_aabb
+        newSize = b_r - t_l
+        self.aabb = new_aabb
+        self.update_stepSize((newSize[0], newSize[1], newSize[2]))
+
+    # ---- checkpoint I/O (models/tensorBase_rotated_lights.py:646-692) ---------------------------------
+    def get_kwargs(self):
+        return {
+            "aabb": self.aabb, "gridSize": self.gridSize.tolist(), "density_n_comp": self.density_n_comp,
+            "appearance_n_comp": self.app_n_comp, "app_dim": self.app_dim, "density_shift": self.density_shift,
+            "alphaMask_thres": self.alphaMask_thres, "distance_scale": self.distance_scale,
+            "rayMarch_weight_thres": self.rayMarch_weight_thres, "fea2denseAct": self.fea2denseAct,
+            "near_far": self.near_far, "step_ratio": self.step_ratio, "shadingMode": self.shadingMode,
+            "pos_pe": self.pos_pe, "view_pe": self.view_pe, "fea_pe": self.fea_pe, "featureC": self.featureC,
+            "normals_kind": self.normals_kind, "light_num": self.light_num, "light_kind": self.light_kind,
+            "numLgtSGs": self.numLgtSGs, "light_rotation": self.light_rotation,
+        }
+
+    def save(self, path):
+        ckpt = {"kwargs": self.get_kwargs(), "state_dict": self.state_dict()}
+        if self.alphaMask is not None:
+            alpha_volume = self.alphaMask.alpha_volume.bool().cpu().numpy()
+            ckpt.update({"alphaMask.shape": alpha_volume.shape})
+            ckpt.update({"alphaMask.mask": np.packbits(alpha_volume.reshape(-1))})
+            ckpt.update({"alphaMask.aabb": self.alphaMask.aabb.cpu()})
+        torch.save(ckpt, path)
+
+    def load(self, ckpt):
+        if "alphaMask.aabb" in ckpt.keys():
+            length = int(np.prod(ckpt["alphaMask.shape"]))
+            alpha_volume = torch.from_numpy(np.unpackbits(ckpt["alphaMask.mask"])[:length].reshape(ckpt["alphaMask.shape"]))
+            self.alphaMask = AlphaGridMask(self.device, ckpt["alphaMask.aabb"].to(self.device),
+                                           alpha_volume.float().to(self.device))
+        self.load_state_dict(ckpt["state_dict"])
+        self._field_key = None
+
+    # ---- the primary pass ----------------------------------------------------------------------------
+    def forward(self, rays_chunk, light_idx, white_bg=True, is_train=False, ndc_ray=False, is_relight=True,
+                N_samples=-1, _brdf_jitter_dense=None, _return_maps=False):
+        """TensorBase.forward (models/tensorBase_rotated_lights.py:868-1036) as a chain of HIP launches:
+        march -> scan -> compact -> appearance gather -> decoders -> analytic normals -> composite.
+
+        Returns the reference's 12-tuple.  ``_brdf_jitter_dense`` ([B,S,3] N(0,1), tests only) replaces
+        the torch.randn_like draw of :937 so different implementations see identical noise.
+        """
+        if ndc_ray:
+            raise NotImplementedError("ndc_ray=True is not on the TensoIR hot path (no shipped config uses it)")
+        _no_grad_only("TensorVMSplit.forward", *self.parameters())
+        dev = rays_chunk.device
+        rays = rays_chunk.to(torch.float32).contiguous()
+        B = rays.shape[0]
+        S = N_samples if N_samples > 0 else self.nSamples
+        f = self.packed_field()
+        lidx = light_idx.reshape(-1).to(dev, torch.int32).contiguous()
+        # RNG draws in the reference's order and on the reference's devices (:717 CPU, :937 device, :1004 CPU)
+        jitter = torch.rand(B, 1).to(dev) if is_train else None
+        weight, acc, depth, _tend, cnt = ops.march_primary(f, rays, jitter, S, self.march_t_stop)
+        offsets = ops.exclusive_scan(cnt)
+        A = int(offsets[-1].item())                      # the one host sync of the pass
+        rec_ray, rec_k, rec_w, rec_xyz = ops.compact_primary(f, rays, jitter, weight, offsets, A)
+        rgb = brdf = brdf_j = pred = derived = None
+        if A > 0:
+            viewdirs = rays[:, 3:6].contiguous()
+            rad, intr = ops.vm_app(f, rec_xyz, lidx, rec_ray, True, bool(is_relight))
+            rgb = self.renderModule.run(rad, viewdirs, rec_ray)
+            if is_relight:
+                brdf = self.renderModule_brdf.run(intr, rec_xyz)
+                if _brdf_jitter_dense is not None:
+                    noise = _brdf_jitter_dense.to(dev, torch.float32)[rec_ray.long(), rec_k.long()]
+                else:
+                    noise = torch.randn((A, 3), device=dev, dtype=torch.float32)
+                xyz_j = rec_xyz + noise * 0.01
+                intr_j = ops.vm_app(f, xyz_j, None, None, False, True)[1]
+                brdf_j = self.renderModule_brdf.run(intr_j, xyz_j)
+                if self.normals_kind == "purely_derived":
+                    pred = ops.density_grad(f, rec_xyz)[2]
+                else:
+                    pred = self.renderModule_normal.run(intr, rec_xyz)
+                    if self.normals_kind == "derived_plus_predicted":
+                        derived = ops.density_grad(f, rec_xyz)[2]
+        bg = bool(white_bg or (is_train and torch.rand((1,)) < 0.5))
+        maps = ops.composite_primary(rays, offsets, rec_w, rgb, brdf, brdf_j, pred, derived, acc, depth,
+                                     bg, is_relight, self.fixed_fresnel)
+        if self.normals_kind == "purely_derived" and is_relight:
+            maps[:, 16] = 0.0        # orientation loss only exists for predicted normals (:953-960)
+        out = self.unpack_maps(maps, is_relight)
+        return (out, maps) if _return_maps else out
+
+    @staticmethod
+    def unpack_maps(maps, is_relight=True):
+        """[B,20] map rows -> the reference's 12-tuple (:1033-1036 / :983-986)."""
+        if not is_relight:
+            return (maps[:, 0:3], maps[:, 3], None, None, None, None, maps[:, 14], None, None, None, None, None)
+        acc = maps[:, 14]
+        return (maps[:, 0:3], maps[:, 3], maps[:, 4:7], maps[:, 7:10], maps[:, 10:11], maps[:, 11:14], acc,
+                maps[:, 15:16], maps[:, 16:17], acc > 0.5, torch.mean(maps[:, 17:18]), torch.mean(maps[:, 18:19]))

@@ -1,0 +1,339 @@
+"""torch-tensor front end of the C ABI: argument checking, output allocation, stream plumbing.
+
+PyTorch is used for device memory and streams only; every arithmetic step of the hot path runs in
+libtensoir_hip.so.  All functions require CUDA(HIP) tensors and raise otherwise -- no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import TirEnvSG, TirField, TirMlp, check, lib
+
+MAP_STRIDE = 20
+
+
+def _stream(t=None):
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _req(t, dtype, name, last=None):
+    if not torch.is_tensor(t):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise _lib.TensoirHipError(f"{name}: tensor must live on the GPU (got {t.device}); "
+                                   "tensoir_amd has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if last is not None and (t.dim() < 1 or t.shape[-1] != last):
+        raise ValueError(f"{name}: last dim must be {last}, got {tuple(t.shape)}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def f32(t, name, last=None):
+    return _req(t, torch.float32, name, last)
+
+
+def i32(t, name):
+    return _req(t, torch.int32, name)
+
+
+# ---- packing ------------------------------------------------------------------------------------
+def pack_plane(src):
+    """[1,C,H,W] (or [C,H,W]) -> channel-last [H,W,C]."""
+    src = f32(src.detach(), "plane")
+    c, h, w = src.shape[-3:]
+    dst = torch.empty((h, w, c), dtype=torch.float32, device=src.device)
+    check(lib().tir_pack_plane(_ptr(src), _ptr(dst), c, h, w, _stream()), "tir_pack_plane")
+    return dst
+
+
+def pack_occupancy(vol):
+    vol = f32(vol.detach(), "alpha_volume")
+    n = vol.numel()
+    bits = torch.empty(((n + 31) // 32,), dtype=torch.int32, device=vol.device)
+    check(lib().tir_pack_occupancy(_ptr(vol), _ptr(bits), n, _stream()), "tir_pack_occupancy")
+    return bits
+
+
+def pack_basis(w):
+    w = f32(w.detach(), "basis_mat.weight")
+    app_dim, n_in = w.shape
+    dst = torch.empty((n_in, 32), dtype=torch.float32, device=w.device)
+    check(lib().tir_pack_basis(_ptr(w), _ptr(dst), app_dim, n_in, _stream()), "tir_pack_basis")
+    return dst
+
+
+def light_mean(ll):
+    ll = f32(ll.detach(), "light_line.weight")
+    L, n = ll.shape
+    out = torch.empty((n,), dtype=torch.float32, device=ll.device)
+    check(lib().tir_light_mean(_ptr(ll), _ptr(out), L, n, _stream()), "tir_light_mean")
+    return out
+
+
+def pack_mlp(w0, b0, w1, b1, w2, b2, feat_dim, pe):
+    ws = [f32(t.detach(), "mlp weight") for t in (w0, b0, w1, b1, w2, b2)]
+    hidden, out_dim = w1.shape[0], w2.shape[0]
+    n = lib().tir_mlp_packed_floats(feat_dim, pe, hidden, out_dim)
+    if n < 0:
+        check(int(n), f"tir_mlp_packed_floats(feat={feat_dim}, pe={pe}, hidden={hidden}, out={out_dim})")
+    if tuple(w0.shape) != (hidden, feat_dim + 3 + 2 * pe * feat_dim + 2 * pe * 3):
+        raise ValueError(f"mlp.0.weight has shape {tuple(w0.shape)}")
+    packed = torch.empty((int(n),), dtype=torch.float32, device=w0.device)
+    check(lib().tir_pack_mlp(*[_ptr(t) for t in ws], feat_dim, pe, hidden, out_dim, _ptr(packed),
+                             _stream()), "tir_pack_mlp")
+    return packed
+
+
+class PackedMlp:
+    def __init__(self, seq, feat_dim, pe, act):
+        """seq: the reference's nn.Sequential(Linear, ReLU, Linear, ReLU, Linear)."""
+        self.packed = pack_mlp(seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias,
+                               seq[4].weight, seq[4].bias, feat_dim, pe)
+        self.out_dim = seq[4].weight.shape[0]
+        self.desc = TirMlp(self.packed.data_ptr(), feat_dim, pe, seq[2].weight.shape[0],
+                           self.out_dim, act)
+
+
+# ---- field kernels --------------------------------------------------------------------------------
+def vm_density(field: TirField, xyz, want_feat=True, want_sigma=False):
+    xyz = f32(xyz, "xyz", 3).view(-1, 3)
+    n = xyz.shape[0]
+    feat = torch.empty((n,), dtype=torch.float32, device=xyz.device) if want_feat else None
+    sigma = torch.empty((n,), dtype=torch.float32, device=xyz.device) if want_sigma else None
+    check(lib().tir_vm_density_fwd(C.byref(field), _ptr(xyz), _ptr(feat), _ptr(sigma), n, _stream()),
+          "tir_vm_density_fwd")
+    return feat, sigma
+
+
+def occupancy_query(field: TirField, xyz):
+    xyz = f32(xyz, "xyz", 3).view(-1, 3)
+    n = xyz.shape[0]
+    hit = torch.empty((n,), dtype=torch.uint8, device=xyz.device)
+    check(lib().tir_occupancy_query(C.byref(field), _ptr(xyz), _ptr(hit), n, _stream()), "tir_occupancy_query")
+    return hit
+
+
+def density_grad(field: TirField, xyz, want_sigma=False, want_grad=False, want_normal=True):
+    xyz = f32(xyz, "xyz", 3).view(-1, 3)
+    n = xyz.shape[0]
+    mk = lambda on, *s: torch.empty(s, dtype=torch.float32, device=xyz.device) if on else None
+    sigma, grad, normal = mk(want_sigma, n), mk(want_grad, n, 3), mk(want_normal, n, 3)
+    check(lib().tir_density_grad_fwd(C.byref(field), _ptr(xyz), _ptr(sigma), _ptr(grad), _ptr(normal),
+                                     n, _stream()), "tir_density_grad_fwd")
+    return sigma, grad, normal
+
+
+def vm_app(field: TirField, xyz, light_idx=None, idx_map=None, want_rad=True, want_int=False):
+    xyz = f32(xyz, "xyz", 3).view(-1, 3)
+    n = xyz.shape[0]
+    ad = field.app_dim
+    if want_rad:
+        if light_idx is None:
+            raise ValueError("light_idx is required for the radiance feature")
+        light_idx = i32(light_idx, "light_idx").view(-1)
+        if idx_map is not None:
+            idx_map = i32(idx_map, "idx_map").view(-1)
+            if idx_map.numel() != n:
+                raise ValueError("idx_map must have one entry per point")
+        elif light_idx.numel() != n:
+            raise ValueError("light_idx must have one entry per point")
+    rad = torch.empty((n, ad), dtype=torch.float32, device=xyz.device) if want_rad else None
+    intr = torch.empty((n, ad), dtype=torch.float32, device=xyz.device) if want_int else None
+    check(lib().tir_vm_app_fwd(C.byref(field), _ptr(xyz), _ptr(light_idx) if want_rad else None,
+                               _ptr(idx_map) if want_rad else None, _ptr(rad), _ptr(intr), n, _stream()),
+          "tir_vm_app_fwd")
+    return rad, intr
+
+
+def mlp(m: PackedMlp, feat, aux, aux_map=None, impl="mfma"):
+    feat = f32(feat, "feat", m.desc.feat_dim)
+    aux = f32(aux, "aux", 3)
+    n = feat.shape[0]
+    if aux_map is not None:
+        aux_map = i32(aux_map, "aux_map").view(-1)
+        if aux_map.numel() != n:
+            raise ValueError("aux_map must have one entry per row")
+    elif aux.shape[0] != n:
+        raise ValueError("aux must have one row per feature row")
+    out = torch.empty((n, m.out_dim), dtype=torch.float32, device=feat.device)
+    fn = lib().tir_mlp_fwd if impl == "mfma" else lib().tir_mlp_fwd_valu
+    check(fn(C.byref(m.desc), _ptr(feat), _ptr(aux), _ptr(aux_map), _ptr(out), n, _stream()), "tir_mlp_fwd")
+    return out
+
+
+# ---- primary march --------------------------------------------------------------------------------
+def march_primary(field: TirField, rays, ray_jitter, n_samples, t_stop):
+    rays = f32(rays, "rays", 6)
+    B = rays.shape[0]
+    dev = rays.device
+    if ray_jitter is not None:
+        ray_jitter = f32(ray_jitter, "ray_jitter").view(-1)
+        if ray_jitter.numel() != B:
+            raise ValueError("ray_jitter must be [B] / [B,1]")
+    weight = torch.empty((B, n_samples), dtype=torch.float32, device=dev)
+    acc = torch.empty((B,), dtype=torch.float32, device=dev)
+    depth = torch.empty((B,), dtype=torch.float32, device=dev)
+    tend = torch.empty((B,), dtype=torch.float32, device=dev)
+    cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+    check(lib().tir_march_primary_fwd(C.byref(field), _ptr(rays), _ptr(ray_jitter), B, n_samples,
+                                      float(t_stop), _ptr(weight), _ptr(acc), _ptr(depth), _ptr(tend),
+                                      _ptr(cnt), _stream()), "tir_march_primary_fwd")
+    return weight, acc, depth, tend, cnt
+
+
+def exclusive_scan(counts):
+    counts = i32(counts, "counts").view(-1)
+    n = counts.numel()
+    off = torch.empty((n + 1,), dtype=torch.int32, device=counts.device)
+    check(lib().tir_exclusive_scan(_ptr(counts), _ptr(off), n, _stream()), "tir_exclusive_scan")
+    return off
+
+
+def compact_primary(field: TirField, rays, ray_jitter, weight, offsets, total):
+    rays = f32(rays, "rays", 6)
+    B, S = weight.shape
+    dev = rays.device
+    if ray_jitter is not None:
+        ray_jitter = f32(ray_jitter, "ray_jitter").view(-1)
+    rec_ray = torch.empty((total,), dtype=torch.int32, device=dev)
+    rec_k = torch.empty((total,), dtype=torch.int32, device=dev)
+    rec_w = torch.empty((total,), dtype=torch.float32, device=dev)
+    rec_xyz = torch.empty((total, 3), dtype=torch.float32, device=dev)
+    if total > 0:
+        check(lib().tir_compact_primary(C.byref(field), _ptr(rays), _ptr(ray_jitter), _ptr(weight),
+                                        _ptr(offsets), B, S, _ptr(rec_ray), _ptr(rec_k), _ptr(rec_w),
+                                        _ptr(rec_xyz), _stream()), "tir_compact_primary")
+    return rec_ray, rec_k, rec_w, rec_xyz
+
+
+def composite_primary(rays, offsets, rec_w, rgb, brdf, brdf_jit, pred_n, der_n, acc, depth,
+                      white_bg, is_relight, fixed_fresnel):
+    rays = f32(rays, "rays", 6)
+    B = rays.shape[0]
+    out = torch.empty((B, MAP_STRIDE), dtype=torch.float32, device=rays.device)
+    check(lib().tir_composite_primary(_ptr(rays), _ptr(offsets), _ptr(rec_w), _ptr(rgb), _ptr(brdf),
+                                      _ptr(brdf_jit), _ptr(pred_n), _ptr(der_n), _ptr(acc), _ptr(depth),
+                                      B, int(bool(white_bg)), int(bool(is_relight)),
+                                      float(fixed_fresnel), _ptr(out), _stream()), "tir_composite_primary")
+    return out
+
+
+# ---- secondary march ------------------------------------------------------------------------------
+def march_secondary(field: TirField, origins, dirs, z_vals, n_rays, org_map=None, dir_map=None,
+                    active=None, t_stop=0.0, want_records=False, rec_cap=0, want_nerfactor=True):
+    origins = f32(origins, "origins", 3)
+    dirs = f32(dirs, "dirs", 3)
+    z_vals = f32(z_vals, "z_vals").view(-1)
+    dev = origins.device
+    n_sample = z_vals.numel()
+    org_map = None if org_map is None else i32(org_map, "org_map")
+    dir_map = None if dir_map is None else i32(dir_map, "dir_map")
+    if active is not None:
+        active = _req(active, torch.uint8, "active")
+    vis = torch.empty((n_rays,), dtype=torch.float32, device=dev)
+    oma = torch.empty((n_rays,), dtype=torch.float32, device=dev) if want_nerfactor else None
+    rec = None
+    if want_records:
+        rec = {
+            "counter": torch.zeros((1,), dtype=torch.int32, device=dev),
+            "ray": torch.empty((rec_cap,), dtype=torch.int32, device=dev),
+            "w": torch.empty((rec_cap,), dtype=torch.float32, device=dev),
+            "xyz": torch.empty((rec_cap, 3), dtype=torch.float32, device=dev),
+            "off": torch.empty((n_rays,), dtype=torch.int32, device=dev),
+            "cnt": torch.empty((n_rays,), dtype=torch.int32, device=dev),
+            "cap": rec_cap,
+        }
+    r = rec or {}
+    check(lib().tir_march_secondary_fwd(
+        C.byref(field), _ptr(origins), _ptr(org_map), _ptr(dirs), _ptr(dir_map), _ptr(active),
+        n_rays, n_sample, _ptr(z_vals), float(t_stop), _ptr(vis), _ptr(oma),
+        _ptr(r.get("counter")), int(rec_cap), _ptr(r.get("ray")), _ptr(r.get("w")), _ptr(r.get("xyz")),
+        _ptr(r.get("off")), _ptr(r.get("cnt")), _stream()), "tir_march_secondary_fwd")
+    return vis, oma, rec
+
+
+def accumulate_records(off, cnt, rec_w, rec_rgb, n_rays):
+    out = torch.empty((n_rays, 3), dtype=torch.float32, device=off.device)
+    check(lib().tir_accumulate_records(_ptr(off), _ptr(cnt), _ptr(rec_w), _ptr(rec_rgb), n_rays,
+                                       _ptr(out), _stream()), "tir_accumulate_records")
+    return out
+
+
+# ---- shading --------------------------------------------------------------------------------------
+def env_sg(lgtSGs, rot, dirs):
+    sgs = f32(lgtSGs.detach(), "lgtSGs", 7)
+    rot = f32(rot, "light_rotation_matrix").view(-1, 9)
+    dirs = f32(dirs, "dirs", 3).view(-1, 3)
+    L, D = rot.shape[0], dirs.shape[0]
+    out = torch.empty((L, D, 3), dtype=torch.float32, device=dirs.device)
+    desc = TirEnvSG(sgs.data_ptr(), rot.data_ptr(), sgs.shape[0], L)
+    check(lib().tir_env_sg_fwd(C.byref(desc), _ptr(dirs), D, _ptr(out), _stream()), "tir_env_sg_fwd")
+    return out
+
+
+def shade_setup(maps, rays, dirs):
+    maps = f32(maps, "maps", MAP_STRIDE)
+    rays = f32(rays, "rays", 6)
+    dirs = f32(dirs, "dirs", 3)
+    M, D = maps.shape[0], dirs.shape[0]
+    surf = torch.empty((M, 3), dtype=torch.float32, device=maps.device)
+    active = torch.empty((M, D), dtype=torch.uint8, device=maps.device)
+    check(lib().tir_shade_setup(_ptr(maps), _ptr(rays), _ptr(dirs), M, D, _ptr(surf), _ptr(active),
+                                _stream()), "tir_shade_setup")
+    return surf, active
+
+
+def shade_integrate(maps, rays, dirs, light_idx, vis, indirect, env, weight_d, equal_area=False,
+                    use_srgb=True):
+    maps = f32(maps, "maps", MAP_STRIDE)
+    rays = f32(rays, "rays", 6)
+    dirs = f32(dirs, "dirs", 3)
+    M, D = maps.shape[0], dirs.shape[0]
+    light_idx = i32(light_idx, "light_idx").view(-1)
+    vis = f32(vis, "vis")
+    env = f32(env, "env", 3)
+    if indirect is not None:
+        indirect = f32(indirect, "indirect", 3)
+    if weight_d is not None:
+        weight_d = f32(weight_d, "light_area_weight")
+    out = torch.empty((M, 3), dtype=torch.float32, device=maps.device)
+    check(lib().tir_shade_integrate(_ptr(maps), _ptr(rays), _ptr(dirs), _ptr(light_idx), _ptr(vis),
+                                    _ptr(indirect), _ptr(env), _ptr(weight_d), M, D, env.shape[0],
+                                    int(bool(equal_area)), int(bool(use_srgb)), _ptr(out), _stream()),
+          "tir_shade_integrate")
+    return out
+
+
+def relight_importance(normal, albedo, rough, fresnel, rays_d, light_dir, light_rgb, light_pdf, vis):
+    normal, albedo = f32(normal, "normal", 3), f32(albedo, "albedo", 3)
+    rough = f32(rough, "roughness").view(-1)
+    fresnel, rays_d = f32(fresnel, "fresnel", 3), f32(rays_d, "rays_d", 3)
+    light_dir, light_rgb = f32(light_dir, "light_dir", 3), f32(light_rgb, "light_rgb", 3)
+    M, Ns = light_dir.shape[0], light_dir.shape[1]
+    light_pdf = f32(light_pdf, "light_pdf").view(M, Ns)
+    vis = f32(vis, "vis").view(M, Ns)
+    out = torch.empty((M, 3), dtype=torch.float32, device=normal.device)
+    check(lib().tir_relight_importance(_ptr(normal), _ptr(albedo), _ptr(rough), _ptr(fresnel), _ptr(rays_d),
+                                       _ptr(light_dir), _ptr(light_rgb), _ptr(light_pdf), _ptr(vis), M, Ns,
+                                       _ptr(out), _stream()), "tir_relight_importance")
+    return out
+
+
+def ggx_specular(normal, v, l, rough, fresnel):
+    normal, v = f32(normal, "normal", 3), f32(v, "pts2c", 3)
+    l = f32(l, "pts2l", 3)
+    M, D = l.shape[0], l.shape[1]
+    rough = f32(rough.expand(M, 3) if rough.shape[-1] == 1 else rough, "roughness", 3)
+    fresnel = f32(fresnel.expand(M, 3) if fresnel.shape[-1] == 1 else fresnel, "fresnel", 3)
+    out = torch.empty((M, D, 3), dtype=torch.float32, device=l.device)
+    check(lib().tir_ggx_specular(_ptr(normal), _ptr(v), _ptr(l), _ptr(rough), _ptr(fresnel), M, D,
+                                 _ptr(out), _stream()), "tir_ggx_specular")
+    return out

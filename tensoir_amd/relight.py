@@ -1,0 +1,245 @@
+"""Host-side mirror of ``models/relight_utils.py`` (live functions only): same names, argument
+meaning and return shapes; per-sample work runs in libtensoir_hip.so."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+from .field_model import safe_l2_normalize  # noqa: F401  (re-exported, as the reference module does)
+
+MAP_STRIDE = ops.MAP_STRIDE
+
+
+def _z_table(n_sample, near, far, device):
+    """sample_ray_equally's distances (models/relight_utils.py:716-717), computed by the same torch ops
+    on the same device as the reference would."""
+    t = torch.linspace(0.0, 1.0, n_sample, device=device)
+    return (near * (1.0 - t) + far * t).contiguous()
+
+
+def _rec_capacity(n_rays):
+    return int(min(max(1 << 20, 16 * n_rays), 1 << 28))
+
+
+def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, light_idx, light_map,
+               want_indirect, want_nerfactor=False):
+    """Shared driver of compute_transmittance / compute_radiance / render_with_BRDF:
+    march (+ record the w > thres samples) -> appearance gather -> radiance decoder -> per-ray sum."""
+    f = tensoIR.packed_field()
+    dev = origins.device
+    if not want_indirect:
+        vis, oma, _ = ops.march_secondary(f, origins, dirs, z, n_rays, org_map, dir_map, active,
+                                          tensoIR.march_t_stop, False, 0, want_nerfactor)
+        return vis, oma, None
+    cap = getattr(tensoIR, "_rec_cap_hint", 0) or _rec_capacity(n_rays)
+    while True:
+        vis, oma, rec = ops.march_secondary(f, origins, dirs, z, n_rays, org_map, dir_map, active,
+                                            tensoIR.march_t_stop, True, cap, want_nerfactor)
+        total = int(rec["counter"].item())              # host sync (the reference syncs per chunk too)
+        if total <= cap:
+            break
+        cap = int(total * 1.25) + 1024                  # rare: re-march with room for every record
+    tensoIR._rec_cap_hint = max(int(total * 1.5) + 4096, 1 << 16)
+    indirect = torch.zeros((n_rays, 3), dtype=torch.float32, device=dev)
+    if total > 0:
+        rec_ray, rec_w, rec_xyz = rec["ray"][:total], rec["w"][:total], rec["xyz"][:total]
+        # light index / view direction of a record = those of its ray
+        if light_map is not None:
+            li_map = light_map[rec_ray.long()].contiguous()
+        else:
+            li_map = rec_ray
+        feat = ops.vm_app(f, rec_xyz, light_idx, li_map, True, False)[0]
+        if dir_map is not None:
+            aux_map = dir_map[rec_ray.long()].contiguous()
+        else:
+            aux_map = rec_ray
+        rgb = tensoIR.renderModule.run(feat, dirs, aux_map)
+        indirect = ops.accumulate_records(rec["off"], rec["cnt"], rec_w, rgb, n_rays)
+    return vis, oma, indirect
+
+
+@torch.no_grad()
+def compute_transmittance(tensoIR, surf_pts, light_in_dir, nSample=128, vis_near=0.1, vis_far=2, device="cuda"):
+    """models/relight_utils.py:657-705 -> (nerv_vis [N], nerfactor_vis [N])."""
+    surf_pts = surf_pts.to(torch.float32).contiguous()
+    light_in_dir = light_in_dir.to(torch.float32).contiguous()
+    z = _z_table(nSample, vis_near, vis_far, surf_pts.device)
+    vis, oma, _ = _secondary(tensoIR, surf_pts, light_in_dir, surf_pts.shape[0], z, None, None, None,
+                             None, None, False, True)
+    return vis, oma
+
+
+@torch.no_grad()
+def compute_radiance(tensoIR, surf_pts, light_in_dir, light_idx, nSample=128, vis_near=0.05, vis_far=1.5,
+                     device=None):
+    """models/relight_utils.py:777-834 -> (nerv_vis [N], nerfactor_vis [N], indirect [N,3])."""
+    surf_pts = surf_pts.to(torch.float32).contiguous()
+    light_in_dir = light_in_dir.to(torch.float32).contiguous()
+    li = light_idx.reshape(-1).to(surf_pts.device, torch.int32).contiguous()
+    z = _z_table(nSample, vis_near, vis_far, surf_pts.device)
+    return _secondary(tensoIR, surf_pts, light_in_dir, surf_pts.shape[0], z, None, None, None, li, None,
+                      True, True)
+
+
+@torch.no_grad()
+def compute_secondary_shading_effects(tensoIR, surface_pts, surf2light, light_idx, nSample=96, vis_near=0.05,
+                                      vis_far=1.5, chunk_size=15000, device="cuda"):
+    """models/relight_utils.py:344-399 -> (visibility [N,1], indirect [N,3]).  chunk_size only bounded
+    the reference's intermediates; the fused march needs no chunking."""
+    vis, _, ind = compute_radiance(tensoIR, surface_pts, surf2light, light_idx, nSample, vis_near, vis_far)
+    return vis.reshape(-1, 1), ind.reshape(-1, 3)
+
+
+def GGX_specular(normal, pts2c, pts2l, roughness, fresnel):
+    """models/relight_utils.py:17-50 -> tir_ggx_specular."""
+    return ops.ggx_specular(normal, pts2c, pts2l, roughness, fresnel)
+
+
+brdf_specular = GGX_specular
+
+
+def linear2srgb_torch(tensor_0to1):
+    """models/relight_utils.py:489-515 (elementwise glue for callers outside the fused kernels)."""
+    if isinstance(tensor_0to1, np.ndarray):
+        x = np.clip(tensor_0to1, 0, 1)
+        return np.where(x <= 0.0031308, x * 12.92, 1.055 * np.power(x + 1e-6, 1 / 2.4) - (1.055 - 1))
+    x = tensor_0to1.clamp(0, 1)
+    return torch.where(x <= 0.0031308, x * 12.92, 1.055 * torch.pow(x + 1e-6, 1 / 2.4) - (1.055 - 1))
+
+
+def _maps_from_parts(depth_map, normal_map, albedo_map, roughness_map, fresnel_map):
+    M = depth_map.shape[0]
+    maps = torch.zeros((M, MAP_STRIDE), dtype=torch.float32, device=depth_map.device)
+    maps[:, 3] = depth_map.reshape(-1)
+    maps[:, 4:7] = normal_map
+    maps[:, 7:10] = albedo_map
+    maps[:, 10] = roughness_map.reshape(M, -1)[:, 0]
+    maps[:, 11:14] = fresnel_map
+    return maps
+
+
+def shade_from_maps(tensoIR, maps, rays, light_idx, sample_method="fixed_envirmap", args=None,
+                    use_linear2srgb=True, _dir_override=None, return_aux=False):
+    """The body of render_with_BRDF (models/relight_utils.py:417-480) on packed [M,20] map rows."""
+    dev = maps.device
+    M = maps.shape[0]
+    rays = rays.to(dev, torch.float32).contiguous()
+    li = light_idx.reshape(-1).to(dev, torch.int32).contiguous()
+    if _dir_override is not None:
+        dirs = _dir_override
+    else:
+        dirs = tensoIR.gen_light_incident_dirs(method=sample_method)
+    dirs = dirs.to(dev, torch.float32).contiguous()
+    D = dirs.shape[0]
+    area = tensoIR.light_area_weight.to(dev, torch.float32).contiguous()
+    n_sample = int(args.second_nSample)
+    z = _z_table(n_sample, args.second_near, args.second_far, dev)
+    if M == 0:
+        out = torch.zeros((0, 3), dtype=torch.float32, device=dev)
+        return (out, None) if return_aux else out
+    surf, active = ops.shade_setup(maps, rays, dirs)
+    n_pairs = M * D
+    pair = torch.arange(n_pairs, dtype=torch.int32, device=dev)
+    org_map = torch.div(pair, D, rounding_mode="floor").to(torch.int32)
+    dir_map = (pair - org_map * D).to(torch.int32)
+    vis, _, ind = _secondary(tensoIR, surf, dirs, n_pairs, z, org_map, dir_map, active.view(-1), li,
+                             org_map, True, False)
+    env = tensoIR.get_light_rgbs(dirs, device=dev)
+    equal_area = sample_method == "stratifed_sample_equal_areas"
+    rgb = ops.shade_integrate(maps, rays, dirs, li, vis.view(M, D), ind.view(M, D, 3), env,
+                              None if equal_area else area, equal_area, use_linear2srgb)
+    if return_aux:
+        return rgb, {"vis": vis.view(M, D), "indirect": ind.view(M, D, 3), "env": env, "surf": surf,
+                     "active": active}
+    return rgb
+
+
+@torch.no_grad()
+def render_with_BRDF(depth_map, normal_map, albedo_map, roughness_map, fresnel_map, rays, tensoIR, light_idx,
+                     sample_method="fixed_envirmap", chunk_size=15000, device="cuda", use_linear2srgb=True,
+                     args=None):
+    """models/relight_utils.py:403-483 (same positional arguments; roughness_map is [M,3] or [M,1])."""
+    maps = _maps_from_parts(depth_map.to(torch.float32), normal_map, albedo_map, roughness_map, fresnel_map)
+    return shade_from_maps(tensoIR, maps, rays, light_idx, sample_method, args, use_linear2srgb)
+
+
+class Environment_Light:
+    """models/relight_utils.py:110-205 with the HDR maps handed in as arrays (the reference reads
+    ``*.hdr`` files with OpenCV, which is I/O outside the hot path)."""
+
+    def __init__(self, hdr_path=None, device="cuda", hdr_maps=None):
+        self.hdr_rgbs, self.hdr_pdf_sample, self.hdr_pdf_return, self.hdr_dir = {}, {}, {}, {}
+        maps = dict(hdr_maps or {})
+        if hdr_path is not None:
+            import os
+            for file in os.listdir(hdr_path):
+                if file.endswith(".hdr"):
+                    maps[file.split(".")[0]] = torch.from_numpy(read_hdr(os.path.join(hdr_path, file)))
+        for name, rgbs in maps.items():
+            rgbs = torch.as_tensor(rgbs, dtype=torch.float32).cpu()
+            H, W, _ = rgbs.shape
+            inten = torch.sum(rgbs, dim=2, keepdim=True)
+            sin_theta = torch.sin(torch.linspace(0 + 0.5 / H, np.pi - 0.5 / H, H))
+            pdf = inten * sin_theta.view(-1, 1, 1)
+            pdf = pdf / torch.sum(pdf)
+            pdf_ret = pdf * H * W / (2 * np.pi * np.pi * sin_theta.view(-1, 1, 1))
+            lat, lng = np.pi / H, 2 * np.pi / W
+            phi, theta = torch.meshgrid([torch.linspace(np.pi / 2 - 0.5 * lat, -np.pi / 2 + 0.5 * lat, H),
+                                         torch.linspace(np.pi - 0.5 * lng, -np.pi + 0.5 * lng, W)], indexing="ij")
+            dirs = torch.stack([torch.cos(theta) * torch.cos(phi), torch.sin(theta) * torch.cos(phi),
+                                torch.sin(phi)], dim=-1).view(H, W, 3)
+            self.hdr_rgbs[name] = rgbs.to(device)
+            self.hdr_pdf_sample[name] = pdf.to(device)
+            self.hdr_pdf_return[name] = pdf_ret.to(device)
+            self.hdr_dir[name] = dirs.to(device)
+
+    @torch.no_grad()
+    def sample_light(self, light_name, bs, num_samples, sample_type="importance"):
+        """:150-188.  The reference draws torch.multinomial over an expanded [bs, H*W] pdf; sampling bs*num
+        indices from the 1-D pdf is the same distribution without materialising bs copies."""
+        if sample_type != "importance":
+            raise NotImplementedError("only importance sampling is used by scripts/relight_importance.py")
+        pdf = self.hdr_pdf_sample[light_name].view(-1)
+        idx = torch.multinomial(pdf, bs * num_samples, replacement=True).view(bs, num_samples)
+        d = self.hdr_dir[light_name].view(-1, 3)[idx]
+        rgb = self.hdr_rgbs[light_name].view(-1, 3)[idx]
+        p = self.hdr_pdf_return[light_name].view(-1)[idx].unsqueeze(-1)
+        return d, rgb, p
+
+    def get_light(self, light_name, incident_dir):
+        """:191-205 (background lookup, bilinear, align_corners=True)."""
+        import torch.nn.functional as F
+        env = self.hdr_rgbs[light_name].permute(2, 0, 1).unsqueeze(0)
+        phi = torch.arccos(incident_dir[:, 2]).reshape(-1) - 1e-6
+        theta = torch.atan2(incident_dir[:, 1], incident_dir[:, 0]).reshape(-1)
+        grid = torch.stack((-theta / np.pi, (phi / np.pi) * 2 - 1)).permute(1, 0).unsqueeze(0).unsqueeze(0)
+        return F.grid_sample(env, grid, align_corners=True).squeeze().permute(1, 0).reshape(-1, 3)
+
+
+def read_hdr(path):
+    import cv2
+    with open(path, "rb") as h:
+        buf = np.frombuffer(h.read(), np.uint8)
+    return cv2.cvtColor(cv2.imdecode(buf, cv2.IMREAD_UNCHANGED), cv2.COLOR_BGR2RGB)
+
+
+@torch.no_grad()
+def relight_with_envmap(tensoIR, surface_xyz, normal, albedo, roughness, fresnel, rays_d, light_dir,
+                        light_rgb, light_pdf, nSample=96, vis_near=0.05, vis_far=1.5):
+    """Loop body of scripts/relight_importance.py:119-170 for one environment map, given the samples
+    drawn by Environment_Light.sample_light: cosine mask -> visibility march -> BRDF*L*cos/pdf mean -> sRGB."""
+    dev = surface_xyz.device
+    M, Ns = light_dir.shape[:2]
+    light_dir = light_dir.to(torch.float32).contiguous()
+    normal = normal.to(torch.float32).contiguous()
+    cosine = torch.einsum("ijk,ik->ij", light_dir, normal)
+    active = (cosine > 1e-6).to(torch.uint8).contiguous()
+    pair = torch.arange(M * Ns, dtype=torch.int32, device=dev)
+    org_map = torch.div(pair, Ns, rounding_mode="floor").to(torch.int32)
+    z = _z_table(nSample, vis_near, vis_far, dev)
+    vis, _, _ = ops.march_secondary(tensoIR.packed_field(), surface_xyz.to(torch.float32).contiguous(),
+                                    light_dir.view(-1, 3), z, M * Ns, org_map, None, active.view(-1),
+                                    tensoIR.march_t_stop, False, 0, False)
+    return ops.relight_importance(normal, albedo, roughness, fresnel, rays_d, light_dir, light_rgb,
+                                  light_pdf, vis.view(M, Ns))

@@ -1,0 +1,35 @@
+"""Host-side mirror of the hot-path part of ``renderer.py`` (reference lines 57-127)."""
+from __future__ import annotations
+
+import torch
+
+from . import relight
+
+
+def Renderer_TensoIR_train(rays=None, normal_gt=None, light_idx=None, tensoIR=None, N_samples=-1, ndc_ray=False,
+                           white_bg=True, is_train=False, is_relight=True, sample_method="fixed_envirmap",
+                           chunk_size=15000, device="cuda", args=None):
+    """renderer.py:57-127: primary pass + physically-based re-render of the rays with acc > 0.5.
+    Same signature and the same 12-key dict."""
+    rays = rays.to(device)
+    light_idx = light_idx.to(device, torch.int32)
+    (rgb_map, depth_map, normal_map, albedo_map, roughness_map, fresnel_map, acc_map, normals_diff_map,
+     normals_orientation_loss_map, acc_mask, albedo_smoothness_loss, roughness_smoothness_loss), maps = \
+        tensoIR(rays, light_idx, is_train=is_train, white_bg=white_bg, is_relight=is_relight, ndc_ray=ndc_ray,
+                N_samples=N_samples, _return_maps=True)
+    if tensoIR.normals_kind == "gt_normals" and normal_gt is not None:
+        normal_map = normal_gt.to(device)
+    if is_relight:
+        masked = relight.shade_from_maps(tensoIR, maps[acc_mask], rays[acc_mask], light_idx[acc_mask],
+                                         sample_method, args)
+        rgb_with_brdf = torch.ones_like(rgb_map)          # background defaults to white (renderer.py:105)
+        rgb_with_brdf[acc_mask] = masked
+    else:
+        rgb_with_brdf = torch.ones_like(rgb_map)
+    return {
+        "rgb_map": rgb_map, "depth_map": depth_map, "normal_map": normal_map, "albedo_map": albedo_map,
+        "acc_map": acc_map, "roughness_map": roughness_map, "fresnel_map": fresnel_map,
+        "rgb_with_brdf_map": rgb_with_brdf, "normals_diff_map": normals_diff_map,
+        "normals_orientation_loss_map": normals_orientation_loss_map,
+        "albedo_smoothness_loss": albedo_smoothness_loss, "roughness_smoothness_loss": roughness_smoothness_loss,
+    }
