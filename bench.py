@@ -1,0 +1,271 @@
+#!/usr/bin/env python
+"""Headline benchmark: primary+secondary rays/s at 4096 rays x 512 samples (BASELINE.json), one
+MI355X per rank.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of 4096 synthetic rays per rank:
+``Renderer_TensoIR_train`` = primary march + appearance gather + 3 decoders + analytic normals +
+compositing, then for every ray with acc > 0.5 the secondary march over 8x16 = 128 light directions x
+96 samples (visibility + indirect radiance) and the GGX x SG-environment integration.  Rays and the
+field are resident in HBM before the timed region.  With N > 1 every rank renders its own 4096 rays
+(weak scaling; rays are independent) and the per-ray output records are all-gathered over RCCL once
+per step.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
+# algorithmic bytes per unit of work ("gather-bytes model")
+B_DENSITY_SAMPLE = 1184        # occupancy 8x4 + planes 3x4x16x4 + lines 3x2x16x4
+B_APP_GATHER = 3456            # planes 3x4x48x4 + lines 3x2x48x4
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--samples", type=int, default=512)
+    ap.add_argument("--grid", type=int, default=300)
+    ap.add_argument("--env-h", type=int, default=8)
+    ap.add_argument("--env-w", type=int, default=16)
+    ap.add_argument("--second-samples", type=int, default=96)
+    ap.add_argument("--cpu-rays", type=int, default=256, help="rays in the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--breakdown", type=str, default="", help="write the per-kernel table to this file")
+    return ap.parse_args()
+
+
+def build_scene(a, device, rank):
+    import tensoir_amd
+    from tensoir_amd import synth
+    ckpt = synth.make_checkpoint(grid=(a.grid,) * 3, seed=20211202)
+    model = tensoir_amd.model_from_checkpoint(ckpt, device, envmap_h=a.env_h, envmap_w=a.env_w)
+    with torch.no_grad():
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            model.updateAlphaMask((128, 128, 128))
+    side = int(round(a.rays ** 0.5))
+    rays = synth.make_rays(side, a.rays // side)
+    if rank > 0:   # same ray distribution on every rank, different rays
+        gen = torch.Generator().manual_seed(1000 + rank)
+        d = rays[:, 3:] + 1e-3 * torch.randn(rays.shape[0], 3, generator=gen)
+        rays = torch.cat([rays[:, :3], d / d.norm(dim=-1, keepdim=True)], dim=-1)
+    rays = rays.to(device).contiguous()
+    lidx = torch.zeros(rays.shape[0], 1, dtype=torch.int32, device=device)
+    return ckpt, model, rays, lidx
+
+
+def kernel_table(timing, stats, steps, shapes):
+    """Aggregate (name, e0, e1) event pairs into per-kernel totals and roofline figures."""
+    agg = {}
+    for name, e0, e1 in timing:
+        ms = e0.elapsed_time(e1)
+        k = agg.setdefault(name, {"ms": 0.0, "launches": 0})
+        k["ms"] += ms
+        k["launches"] += 1
+    rows = []
+    for name, k in agg.items():
+        avg_ms = k["ms"] / k["launches"]
+        row = {"kernel": name, "launches_per_step": k["launches"] / steps, "avg_ms": avg_ms,
+               "ms_per_step": k["ms"] / steps}
+        units = shapes.get(name)
+        if name in ("tir_march_primary_fwd", "tir_march_secondary_fwd") and stats and name in stats:
+            gathered = int(stats[name].item()) / k["launches"]
+            extra = units["io_bytes"] if units else 0
+            by = gathered * B_DENSITY_SAMPLE + extra
+            row.update(bound="hbm", units=gathered, unit="valid density samples/launch",
+                       achieved=by / (avg_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, runit="GB/s")
+        elif name == "tir_vm_app_fwd" and units:
+            by = units["n"] / k["launches"] * (B_APP_GATHER + units["out_bytes"])
+            row.update(bound="hbm", units=units["n"] / k["launches"], unit="appearance gathers/launch",
+                       achieved=by / (avg_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, runit="GB/s")
+        elif name == "tir_mlp_fwd" and units:
+            fl = units["flops"] / k["launches"]
+            row.update(bound="mfma", units=units["n"] / k["launches"], unit="decoder rows/launch",
+                       achieved=fl / (avg_ms * 1e-3) / 1e12, peak=F32_MFMA_PEAK_TF, runit="TFLOP/s")
+        if "achieved" in row:
+            row["frac"] = row["achieved"] / row["peak"]
+        rows.append(row)
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: tensoir_amd has no CPU path")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    n_gpus = world
+
+    from tensoir_amd import Renderer_TensoIR_train, _lib, ops
+    from tensoir_amd import dist as tdist
+    assert _lib.lib().tir_device_check() == 0
+    ckpt, model, rays, lidx = build_scene(a, device, rank)
+    args = types.SimpleNamespace(second_nSample=a.second_samples, second_near=0.05, second_far=1.5)
+    B = rays.shape[0]
+    gathered = torch.empty((world * B, tdist.RECORD), dtype=torch.float32, device=device) if world > 1 else None
+
+    def step():
+        with torch.no_grad():
+            ret = Renderer_TensoIR_train(rays, None, lidx, model, N_samples=a.samples, white_bg=True,
+                                         is_train=False, is_relight=True, sample_method="fixed_envirmap",
+                                         chunk_size=160000, device=device, args=args)
+            if world > 1:   # the one exchange step: all-gather of the rendered per-ray records
+                dist.all_gather_into_tensor(gathered, tdist.pack_records(ret))
+        return ret
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ret = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel attribution (separate, instrumented pass; events on the launch stream) ----------
+    ops.TIMING, ops.STATS = [], {}
+    shapes_acc = {"app_n": 0, "app_out": 0, "mlp_n": 0, "mlp_flops": 0}
+    orig_app, orig_mlp = ops.vm_app, ops.mlp
+
+    def app_wrap(field, xyz, light_idx=None, idx_map=None, want_rad=True, want_int=False):
+        n = xyz.shape[0]
+        shapes_acc["app_n"] += n
+        shapes_acc["app_out"] += n * 27 * 4 * (int(want_rad) + int(want_int))
+        return orig_app(field, xyz, light_idx, idx_map, want_rad, want_int)
+
+    def mlp_wrap(m, feat, aux, aux_map=None, impl="mfma"):
+        n = feat.shape[0]
+        shapes_acc["mlp_n"] += n
+        shapes_acc["mlp_flops"] += n * 2 * (150 * 128 + 128 * 128 + 128 * m.out_dim)
+        return orig_mlp(m, feat, aux, aux_map, impl)
+
+    ops.vm_app, ops.mlp = app_wrap, mlp_wrap
+    import tensoir_amd.field_model as FM
+    import tensoir_amd.relight as RL
+    psteps = max(1, min(a.profile_steps, a.steps))
+    for _ in range(psteps):
+        step()
+    torch.cuda.synchronize()
+    ops.vm_app, ops.mlp = orig_app, orig_mlp
+    timing, stats = ops.TIMING, ops.STATS
+    ops.TIMING, ops.STATS = None, None
+    M = int((ret["acc_map"] > 0.5).sum())
+    D = a.env_h * a.env_w
+    shapes = {
+        "tir_march_primary_fwd": {"io_bytes": B * (24 + 4 + 12) + B * a.samples * 4},
+        "tir_march_secondary_fwd": {"io_bytes": M * D * (24 + 16)},
+        "tir_vm_app_fwd": {"n": shapes_acc["app_n"], "out_bytes": shapes_acc["app_out"] / max(1, shapes_acc["app_n"])},
+        "tir_mlp_fwd": {"n": shapes_acc["mlp_n"], "flops": shapes_acc["mlp_flops"]},
+    }
+    rows = kernel_table(timing, stats, psteps, shapes)
+    gpu_ms = sum(r["ms_per_step"] for r in rows)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    dom = next((r for r in rows if "achieved" in r), None)
+    roofline = None
+    if dom:
+        roofline = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": round(dom["achieved"], 2),
+                    "peak": dom["peak"], "unit": dom["runit"], "frac": round(dom["frac"], 4), "traffic": None,
+                    "avg_launch_ms": round(dom["avg_ms"], 4), "units_per_launch": round(dom["units"], 1),
+                    "unit_of_work": dom["unit"]}
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # filled from rocprofv3 --pmc passes
+        if os.path.exists(pmc):
+            try:
+                roofline["traffic"] = json.load(open(pmc)).get(dom["kernel"])
+            except Exception:
+                pass
+
+    # ---- CPU baseline: the oracle (same algorithm, ATen CPU ops) on a bounded sample ------------------
+    cpu = None
+    if world == 1 and not a.no_cpu_baseline:
+        from oracle import tensoir_oracle as O          # checker / CPU baseline only
+        from tests.helpers import scene_from_checkpoint
+        ck = dict(ckpt)
+        vol = model.alphaMask.alpha_volume[0, 0].bool().cpu()
+        ck["alphaMask.shape"] = tuple(vol.shape)
+        ck["alphaMask.mask"] = np.packbits(vol.numpy().reshape(-1))
+        ck["alphaMask.aabb"] = model.alphaMask.aabb.cpu()
+        sc = scene_from_checkpoint(ck, a.env_h, a.env_w)
+        stride = max(1, B // a.cpu_rays)
+        r_cpu, l_cpu = rays.cpu()[::stride][: a.cpu_rays], lidx.cpu()[::stride][: a.cpu_rays]
+        times = []
+        with torch.no_grad():
+            for i in range(3):
+                t1 = time.perf_counter()
+                O.renderer_train(sc, r_cpu, l_cpu, n_samples=a.samples, second_n_sample=a.second_samples)
+                times.append(time.perf_counter() - t1)
+        med = sorted(times[1:])[len(times[1:]) // 2] if len(times) > 1 else times[0]
+        cpu = {"value": round(r_cpu.shape[0] / med, 2), "unit": "rays/s", "cores": torch.get_num_threads(),
+               "kind": "port",
+               "sample": f"every {stride}th ray of the batch ({r_cpu.shape[0]} rays x {a.samples} samples, "
+                         f"{D} dirs x {a.second_samples}), 1 warm-up + 2 timed calls, median; host nproc={os.cpu_count()}"}
+
+    value = n_gpus * B * a.steps / elapsed
+    out = {
+        "metric": "primary+secondary rays/sec at 4096 rays x 512 samples",
+        "value": round(value, 1), "unit": "rays/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C2+C3: Renderer_TensoIR_train, {B} rays x {a.samples} samples per GPU, VM grid "
+                               f"{a.grid}^3 (16/48 comps), occupancy 128^3, 3 decoders 150-128-128, secondary "
+                               f"{D} dirs x {a.second_samples} samples on {M} surface points, SG env light",
+                   "rays_per_gpu": B, "samples": a.samples, "grid": a.grid, "light_dirs": D,
+                   "second_samples": a.second_samples, "surface_points": M,
+                   "sharding": f"dp{n_gpus} over rays, all-gather of {tdist.RECORD * 4} B/ray records"},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "gpu_kernel_ms_per_step": round(gpu_ms, 4),
+        "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:8]],
+    }
+    if cpu:
+        out["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+    if a.breakdown:
+        with open(a.breakdown, "w") as fh:
+            json.dump({"rows": rows, "elapsed_s": elapsed, "steps": a.steps}, fh, indent=1)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -150,10 +150,13 @@ int tir_mlp_fwd_valu(const TirMlp* m, const float* feat, const float* aux, const
  *      Outputs: weight [B][S]; acc[B] = sum w; depth[B] = sum w*z; t_end[B] = prod(1-a+1e-10);
  *      app_count[B] = #{w > weight_thres}.  t_stop: a ray stops marching once its running
  *      transmittance drops below t_stop (remaining weights are written as 0; the error in acc is
- *      < t_stop); pass 0 for the exact full march. */
+ *      < t_stop); pass 0 for the exact full march.
+ *      stats (optional, NULL to skip): *stats += number of samples whose density was gathered
+ *      (in bbox and not culled by the occupancy mask) -- the unit of the roofline accounting. */
 int tir_march_primary_fwd(const TirField* f, const float* rays, const float* ray_jitter,
                           int32_t B, int32_t S, float t_stop, float* weight, float* acc,
-                          float* depth, float* t_end, int32_t* app_count, void* stream);
+                          float* depth, float* t_end, int32_t* app_count,
+                          unsigned long long* stats, void* stream);
 
 /* exclusive scan of counts[n] -> offsets[n+1] (offsets[n] = total) */
 int tir_exclusive_scan(const int32_t* counts, int32_t* offsets, int32_t n, void* stream);
@@ -188,14 +191,14 @@ int tir_composite_primary(const float* rays, const int32_t* offsets, const float
  *      When rec_counter != NULL the samples with w > weight_thres are appended (contiguously per
  *      ray, in sample order; ray segments in arbitrary order) to rec_* (capacity rec_cap records;
  *      overflowing rays are dropped and *rec_counter still counts them) and
- *      ray_rec_off[p] / ray_rec_cnt[p] locate ray p's segment. */
+ *      ray_rec_off[p] / ray_rec_cnt[p] locate ray p's segment.  stats: as tir_march_primary_fwd. */
 int tir_march_secondary_fwd(const TirField* f, const float* origins, const int32_t* org_map,
                             const float* dirs, const int32_t* dir_map, const uint8_t* active,
                             int64_t n_rays, int32_t n_sample, const float* z_vals,
                             float t_stop, float* vis, float* one_minus_acc,
                             int32_t* rec_counter, int64_t rec_cap, int32_t* rec_ray,
                             float* rec_w, float* rec_xyz, int32_t* ray_rec_off,
-                            int32_t* ray_rec_cnt, void* stream);
+                            int32_t* ray_rec_cnt, unsigned long long* stats, void* stream);
 
 /* indirect[p] = sum over ray p's records of w * rgb  (models/relight_utils.py:832) */
 int tir_accumulate_records(const int32_t* ray_rec_off, const int32_t* ray_rec_cnt,

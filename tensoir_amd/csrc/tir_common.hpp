@@ -167,9 +167,11 @@ __device__ __forceinline__ bool in_bbox(const TirField& f, float px, float py, f
 
 // sigma at a world-space sample (bbox test, occupancy cull, density, activation):
 // models/tensorBase_rotated_lights.py:892-919.  Returns 0 for culled samples.
-__device__ __forceinline__ float sigma_at(const TirField& f, float px, float py, float pz) {
+__device__ __forceinline__ float sigma_at(const TirField& f, float px, float py, float pz, bool& gathered) {
+    gathered = false;
     if (!in_bbox(f, px, py, pz)) return 0.0f;
     if (f.occ_bits != nullptr && !occupancy_hit(f, px, py, pz)) return 0.0f;
+    gathered = true;
     float x = norm_coord(px, f.aabb_min[0], f.inv_aabb[0]);
     float y = norm_coord(py, f.aabb_min[1], f.inv_aabb[1]);
     float z = norm_coord(pz, f.aabb_min[2], f.inv_aabb[2]);

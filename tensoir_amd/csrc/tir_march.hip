@@ -40,7 +40,8 @@ __device__ __forceinline__ float sample_z(const TirField& f, float t_min, int k,
 __global__ void __launch_bounds__(256)
 k_march_primary(TirField f, const float* __restrict__ rays, const float* __restrict__ ray_jitter,
                 int B, int S, float t_stop, float* __restrict__ weight, float* __restrict__ acc_out,
-                float* __restrict__ depth_out, float* __restrict__ tend_out, int32_t* __restrict__ app_count) {
+                float* __restrict__ depth_out, float* __restrict__ tend_out, int32_t* __restrict__ app_count,
+                unsigned long long* __restrict__ stats) {
     const int lane = threadIdx.x & 63;
     const int ray = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (ray >= B) return;
@@ -52,15 +53,17 @@ k_march_primary(TirField f, const float* __restrict__ rays, const float* __restr
     float acc = 0.0f, depth = 0.0f;
     int cnt = 0;
     int k0 = 0;
+    unsigned n_gather = 0;
     for (; k0 < S; k0 += 64) {
         const int k = k0 + lane;
         float w = 0.0f, z = 0.0f, v = 1.0f;
+        bool gathered = false;
         if (k < S) {
             z = sample_z(f, rs.t_min, k, jit, hj);
             float px = add_rn(rs.o[0], mul_rn(rs.d[0], z));
             float py = add_rn(rs.o[1], mul_rn(rs.d[1], z));
             float pz = add_rn(rs.o[2], mul_rn(rs.d[2], z));
-            float sigma = sigma_at(f, px, py, pz);
+            float sigma = sigma_at(f, px, py, pz, gathered);
             // dists: z[k+1]-z[k], last 0 (:887); raw2alpha (:21-28) with dist * distance_scale (:921)
             float dist = (k + 1 < S) ? sub_rn(sample_z(f, rs.t_min, k + 1, jit, hj), z) : 0.0f;
             float alpha = 1.0f - expf(-sigma * mul_rn(dist, f.distance_scale));
@@ -75,6 +78,7 @@ k_march_primary(TirField f, const float* __restrict__ rays, const float* __restr
         acc += w;
         depth = fmaf(w, z, depth);
         cnt += __popcll(__ballot(w > f.weight_thres));
+        if (stats) n_gather += __popcll(__ballot(gathered));
         T = T * __shfl(incl, 63, 64);
         if (T < t_stop) { k0 += 64; break; }
     }
@@ -90,18 +94,20 @@ k_march_primary(TirField f, const float* __restrict__ rays, const float* __restr
         depth_out[ray] = depth;
         if (tend_out) tend_out[ray] = T;
         app_count[ray] = cnt;
+        if (stats) atomicAdd(stats, (unsigned long long)n_gather);
     }
 }
 
 extern "C" int tir_march_primary_fwd(const TirField* f, const float* rays, const float* ray_jitter,
                                      int32_t B, int32_t S, float t_stop, float* weight, float* acc,
-                                     float* depth, float* t_end, int32_t* app_count, void* stream) {
+                                     float* depth, float* t_end, int32_t* app_count,
+                                     unsigned long long* stats, void* stream) {
     if (!f || B < 0 || S <= 0) return TIR_ERR_ARG;
     if (B == 0) return TIR_OK;
     if (!rays || !weight || !acc || !depth || !app_count) return TIR_ERR_ARG;
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_march_primary, dim3((B + 3) / 4), dim3(256), 0, tir_stream(stream), *f, rays,
-                       ray_jitter, B, S, t_stop, weight, acc, depth, t_end, app_count);
+                       ray_jitter, B, S, t_stop, weight, acc, depth, t_end, app_count, stats);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
@@ -310,7 +316,8 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
                   const float* __restrict__ z_vals, float t_stop, float* __restrict__ vis,
                   float* __restrict__ one_minus_acc, int32_t* __restrict__ rec_counter, int64_t rec_cap,
                   int32_t* __restrict__ rec_ray, float* __restrict__ rec_w, float* __restrict__ rec_xyz,
-                  int32_t* __restrict__ ray_rec_off, int32_t* __restrict__ ray_rec_cnt) {
+                  int32_t* __restrict__ ray_rec_off, int32_t* __restrict__ ray_rec_cnt,
+                  unsigned long long* __restrict__ stats) {
     extern __shared__ float w_lds[];   // [8 half-waves][n_sample]
     const int hl = threadIdx.x & 31;                 // lane within the half-wave
     const int hw = threadIdx.x >> 5;                 // half-wave within the block
@@ -334,15 +341,17 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
     float T = 1.0f, acc = 0.0f;
     int cnt = 0;
     int k0 = 0;
+    unsigned n_gather = 0;
     for (; k0 < n_sample; k0 += 32) {
         const int k = k0 + hl;
         float w = 0.0f, v = 1.0f;
+        bool gathered = false;
         if (k < n_sample) {
             const float z = z_vals[k];
             float px = add_rn(o[0], mul_rn(d[0], z));
             float py = add_rn(o[1], mul_rn(d[1], z));
             float pz = add_rn(o[2], mul_rn(d[2], z));
-            float sigma = sigma_at(f, px, py, pz);
+            float sigma = sigma_at(f, px, py, pz, gathered);
             float dist = (k + 1 < n_sample) ? sub_rn(z_vals[k + 1], z) : 0.0f;
             float alpha = 1.0f - expf(-sigma * mul_rn(dist, f.distance_scale));
             v = add_rn(sub_rn(1.0f, alpha), 1e-10f);
@@ -357,6 +366,7 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
         const bool keep = w > f.weight_thres;
         unsigned long long m = __ballot(keep);
         cnt += __popc((unsigned)(m >> ((threadIdx.x & 32) ? 32 : 0)));
+        if (stats) n_gather += __popc((unsigned)(__ballot(gathered) >> ((threadIdx.x & 32) ? 32 : 0)));
         T = T * __shfl(incl, 31, 32);
         if (T < t_stop) { k0 += 32; break; }
     }
@@ -365,6 +375,7 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
     if (hl == 0) {
         if (vis) vis[ray] = T;
         if (one_minus_acc) one_minus_acc[ray] = 1.0f - acc;
+        if (stats) atomicAdd(stats, (unsigned long long)n_gather);
     }
     if (!want_rec) return;
     int base = 0;
@@ -404,7 +415,7 @@ extern "C" int tir_march_secondary_fwd(const TirField* f, const float* origins, 
                                        float t_stop, float* vis, float* one_minus_acc,
                                        int32_t* rec_counter, int64_t rec_cap, int32_t* rec_ray,
                                        float* rec_w, float* rec_xyz, int32_t* ray_rec_off,
-                                       int32_t* ray_rec_cnt, void* stream) {
+                                       int32_t* ray_rec_cnt, unsigned long long* stats, void* stream) {
     if (!f || n_rays < 0 || n_sample <= 0) return TIR_ERR_ARG;
     if (n_sample > TIR_SEC_MAX_SAMPLES) return TIR_ERR_UNSUPPORTED;
     if (n_rays == 0) return TIR_OK;
@@ -415,7 +426,7 @@ extern "C" int tir_march_secondary_fwd(const TirField* f, const float* origins, 
     size_t lds = rec_counter ? (size_t)8 * n_sample * sizeof(float) : 0;
     hipLaunchKernelGGL(k_march_secondary, dim3((unsigned)((n_rays + 7) / 8)), dim3(256), lds, tir_stream(stream),
                        *f, origins, org_map, dirs, dir_map, active, n_rays, n_sample, z_vals, t_stop, vis,
-                       one_minus_acc, rec_counter, rec_cap, rec_ray, rec_w, rec_xyz, ray_rec_off, ray_rec_cnt);
+                       one_minus_acc, rec_counter, rec_cap, rec_ray, rec_w, rec_xyz, ray_rec_off, ray_rec_cnt, stats);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

@@ -1,0 +1,103 @@
+"""Ray-sharded rendering across the GPUs of one node.
+
+Rays are independent units: the field (70-190 MB) is replicated on every GPU, each rank renders its
+shard with the same kernels, and ONE collective at the end -- an all-gather of the per-ray output
+records over RCCL/xGMI -- assembles the image on every rank.  The reference has no data-path
+collective at all (it only calls init_process_group + barrier, train_tensoIR.py:22-27); this is the
+MI355X-native replacement for its sequential per-chunk loop (renderer.py:225-249).
+
+One process per GPU; ``backend='nccl'`` is RCCL on ROCm; the same code runs on ``gloo`` for CPU tests.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+RECORD = 24          # floats per ray in the exchanged record: 20 map floats + rgb_with_brdf 3 + pad
+
+
+def shard_rows(n_rays: int, rank: int, world: int, tile: int = 0):
+    """Index tensor (int64, ascending) of the rays rank `rank` renders.
+
+    tile == 0: contiguous row-tiles (rank r gets [r*ceil(n/world), ...)), the 800x800 -> 8 x 100-row
+    layout of SURVEY 8e.  tile > 0: interleaved tiles of `tile` rays (ray i -> rank (i // tile) % world)
+    for load balance when background rows terminate early.
+    """
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    if tile <= 0:
+        per = (n_rays + world - 1) // world
+        lo, hi = min(rank * per, n_rays), min((rank + 1) * per, n_rays)
+        return torch.arange(lo, hi, dtype=torch.int64)
+    idx = torch.arange(n_rays, dtype=torch.int64)
+    return idx[(idx // tile) % world == rank]
+
+
+def shard_capacity(n_rays: int, world: int, tile: int = 0) -> int:
+    """Largest shard over ranks (every rank pads its record buffer to this for the all-gather)."""
+    return max(int(shard_rows(n_rays, r, world, tile).numel()) for r in range(world))
+
+
+def pack_records(ret: dict) -> torch.Tensor:
+    """12-key dict of Renderer_TensoIR_train -> [n, RECORD] record rows."""
+    n = ret["rgb_map"].shape[0]
+    rec = torch.zeros((n, RECORD), dtype=torch.float32, device=ret["rgb_map"].device)
+    rec[:, 0:3] = ret["rgb_map"]
+    rec[:, 3] = ret["depth_map"]
+    rec[:, 4:7] = ret["normal_map"]
+    rec[:, 7:10] = ret["albedo_map"]
+    rec[:, 10:11] = ret["roughness_map"]
+    rec[:, 11:14] = ret["fresnel_map"]
+    rec[:, 14] = ret["acc_map"]
+    rec[:, 15:16] = ret["normals_diff_map"]
+    rec[:, 16:17] = ret["normals_orientation_loss_map"]
+    rec[:, 20:23] = ret["rgb_with_brdf_map"]
+    return rec
+
+
+def unpack_records(rec: torch.Tensor) -> dict:
+    return {"rgb_map": rec[:, 0:3], "depth_map": rec[:, 3], "normal_map": rec[:, 4:7],
+            "albedo_map": rec[:, 7:10], "roughness_map": rec[:, 10:11], "fresnel_map": rec[:, 11:14],
+            "acc_map": rec[:, 14], "normals_diff_map": rec[:, 15:16],
+            "normals_orientation_loss_map": rec[:, 16:17], "rgb_with_brdf_map": rec[:, 20:23]}
+
+
+def gather_records(local: torch.Tensor, n_rays: int, rank: int, world: int, tile: int = 0, group=None):
+    """All-gather the per-rank record rows and put them back in image order.  local: [n_local, RECORD]."""
+    cap = shard_capacity(n_rays, world, tile)
+    buf = torch.zeros((cap, local.shape[1]), dtype=local.dtype, device=local.device)
+    buf[: local.shape[0]] = local
+    if world == 1:
+        gathered = buf.unsqueeze(0)
+    else:
+        gathered = torch.empty((world, cap, local.shape[1]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(gathered.view(world * cap, -1), buf, group=group)
+    out = torch.empty((n_rays, local.shape[1]), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        idx = shard_rows(n_rays, r, world, tile).to(local.device)
+        out[idx] = gathered[r, : idx.numel()]
+    return out
+
+
+def render_sharded(render_fn, rays, light_idx, rank=None, world=None, chunk=4096, tile=0, group=None):
+    """Render `rays` ([N,6], identical on every rank) data-parallel over ranks.
+
+    render_fn(rays_chunk, light_idx_chunk) -> dict with the keys of Renderer_TensoIR_train.
+    Every rank returns the full-image dict (one all-gather per image, not per chunk).
+    """
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = rays.shape[0]
+    mine = shard_rows(n, rank, world, tile).to(rays.device)
+    parts = []
+    for c in torch.split(mine, chunk):
+        if c.numel() == 0:
+            continue
+        parts.append(pack_records(render_fn(rays[c], light_idx[c])))
+    if parts:
+        local = torch.cat(parts, dim=0)
+    else:
+        local = torch.zeros((0, RECORD), dtype=torch.float32, device=rays.device)
+    return unpack_records(gather_records(local, n, rank, world, tile, group))

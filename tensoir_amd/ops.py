@@ -14,6 +14,44 @@ from ._lib import TirEnvSG, TirField, TirMlp, check, lib
 
 MAP_STRIDE = 20
 
+# Optional instrumentation used by bench.py: when STATS is a dict, the march wrappers accumulate the
+# number of gathered density samples per kernel (device-side counter, read back by the caller), and
+# when TIMING is a list every C call is bracketed by events on the launch stream.
+STATS = None
+TIMING = None
+
+
+def _stats_ptr(name, dev):
+    if STATS is None:
+        return None
+    if name not in STATS:
+        STATS[name] = torch.zeros((1,), dtype=torch.int64, device=dev)
+    return C.c_void_p(STATS[name].data_ptr())
+
+
+def _call(name, *args):
+    with _timed(name):
+        rc = getattr(lib(), name)(*args)
+    check(rc, name)
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if TIMING is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if TIMING is not None:
+            self.e1.record()
+            TIMING.append((self.name, self.e0, self.e1))
+        return False
+
 
 def _stream(t=None):
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -50,7 +88,7 @@ def pack_plane(src):
     src = f32(src.detach(), "plane")
     c, h, w = src.shape[-3:]
     dst = torch.empty((h, w, c), dtype=torch.float32, device=src.device)
-    check(lib().tir_pack_plane(_ptr(src), _ptr(dst), c, h, w, _stream()), "tir_pack_plane")
+    _call("tir_pack_plane", _ptr(src), _ptr(dst), c, h, w, _stream())
     return dst
 
 
@@ -58,7 +96,7 @@ def pack_occupancy(vol):
     vol = f32(vol.detach(), "alpha_volume")
     n = vol.numel()
     bits = torch.empty(((n + 31) // 32,), dtype=torch.int32, device=vol.device)
-    check(lib().tir_pack_occupancy(_ptr(vol), _ptr(bits), n, _stream()), "tir_pack_occupancy")
+    _call("tir_pack_occupancy", _ptr(vol), _ptr(bits), n, _stream())
     return bits
 
 
@@ -66,7 +104,7 @@ def pack_basis(w):
     w = f32(w.detach(), "basis_mat.weight")
     app_dim, n_in = w.shape
     dst = torch.empty((n_in, 32), dtype=torch.float32, device=w.device)
-    check(lib().tir_pack_basis(_ptr(w), _ptr(dst), app_dim, n_in, _stream()), "tir_pack_basis")
+    _call("tir_pack_basis", _ptr(w), _ptr(dst), app_dim, n_in, _stream())
     return dst
 
 
@@ -74,7 +112,7 @@ def light_mean(ll):
     ll = f32(ll.detach(), "light_line.weight")
     L, n = ll.shape
     out = torch.empty((n,), dtype=torch.float32, device=ll.device)
-    check(lib().tir_light_mean(_ptr(ll), _ptr(out), L, n, _stream()), "tir_light_mean")
+    _call("tir_light_mean", _ptr(ll), _ptr(out), L, n, _stream())
     return out
 
 
@@ -87,8 +125,8 @@ def pack_mlp(w0, b0, w1, b1, w2, b2, feat_dim, pe):
     if tuple(w0.shape) != (hidden, feat_dim + 3 + 2 * pe * feat_dim + 2 * pe * 3):
         raise ValueError(f"mlp.0.weight has shape {tuple(w0.shape)}")
     packed = torch.empty((int(n),), dtype=torch.float32, device=w0.device)
-    check(lib().tir_pack_mlp(*[_ptr(t) for t in ws], feat_dim, pe, hidden, out_dim, _ptr(packed),
-                             _stream()), "tir_pack_mlp")
+    _call("tir_pack_mlp", *[_ptr(t) for t in ws], feat_dim, pe, hidden, out_dim, _ptr(packed),
+                             _stream())
     return packed
 
 
@@ -108,8 +146,7 @@ def vm_density(field: TirField, xyz, want_feat=True, want_sigma=False):
     n = xyz.shape[0]
     feat = torch.empty((n,), dtype=torch.float32, device=xyz.device) if want_feat else None
     sigma = torch.empty((n,), dtype=torch.float32, device=xyz.device) if want_sigma else None
-    check(lib().tir_vm_density_fwd(C.byref(field), _ptr(xyz), _ptr(feat), _ptr(sigma), n, _stream()),
-          "tir_vm_density_fwd")
+    _call("tir_vm_density_fwd", C.byref(field), _ptr(xyz), _ptr(feat), _ptr(sigma), n, _stream())
     return feat, sigma
 
 
@@ -117,7 +154,7 @@ def occupancy_query(field: TirField, xyz):
     xyz = f32(xyz, "xyz", 3).view(-1, 3)
     n = xyz.shape[0]
     hit = torch.empty((n,), dtype=torch.uint8, device=xyz.device)
-    check(lib().tir_occupancy_query(C.byref(field), _ptr(xyz), _ptr(hit), n, _stream()), "tir_occupancy_query")
+    _call("tir_occupancy_query", C.byref(field), _ptr(xyz), _ptr(hit), n, _stream())
     return hit
 
 
@@ -126,8 +163,8 @@ def density_grad(field: TirField, xyz, want_sigma=False, want_grad=False, want_n
     n = xyz.shape[0]
     mk = lambda on, *s: torch.empty(s, dtype=torch.float32, device=xyz.device) if on else None
     sigma, grad, normal = mk(want_sigma, n), mk(want_grad, n, 3), mk(want_normal, n, 3)
-    check(lib().tir_density_grad_fwd(C.byref(field), _ptr(xyz), _ptr(sigma), _ptr(grad), _ptr(normal),
-                                     n, _stream()), "tir_density_grad_fwd")
+    _call("tir_density_grad_fwd", C.byref(field), _ptr(xyz), _ptr(sigma), _ptr(grad), _ptr(normal),
+                                     n, _stream())
     return sigma, grad, normal
 
 
@@ -147,9 +184,8 @@ def vm_app(field: TirField, xyz, light_idx=None, idx_map=None, want_rad=True, wa
             raise ValueError("light_idx must have one entry per point")
     rad = torch.empty((n, ad), dtype=torch.float32, device=xyz.device) if want_rad else None
     intr = torch.empty((n, ad), dtype=torch.float32, device=xyz.device) if want_int else None
-    check(lib().tir_vm_app_fwd(C.byref(field), _ptr(xyz), _ptr(light_idx) if want_rad else None,
-                               _ptr(idx_map) if want_rad else None, _ptr(rad), _ptr(intr), n, _stream()),
-          "tir_vm_app_fwd")
+    _call("tir_vm_app_fwd", C.byref(field), _ptr(xyz), _ptr(light_idx) if want_rad else None,
+                               _ptr(idx_map) if want_rad else None, _ptr(rad), _ptr(intr), n, _stream())
     return rad, intr
 
 
@@ -164,8 +200,8 @@ def mlp(m: PackedMlp, feat, aux, aux_map=None, impl="mfma"):
     elif aux.shape[0] != n:
         raise ValueError("aux must have one row per feature row")
     out = torch.empty((n, m.out_dim), dtype=torch.float32, device=feat.device)
-    fn = lib().tir_mlp_fwd if impl == "mfma" else lib().tir_mlp_fwd_valu
-    check(fn(C.byref(m.desc), _ptr(feat), _ptr(aux), _ptr(aux_map), _ptr(out), n, _stream()), "tir_mlp_fwd")
+    _call("tir_mlp_fwd" if impl == "mfma" else "tir_mlp_fwd_valu", C.byref(m.desc), _ptr(feat), _ptr(aux),
+          _ptr(aux_map), _ptr(out), n, _stream())
     return out
 
 
@@ -183,9 +219,9 @@ def march_primary(field: TirField, rays, ray_jitter, n_samples, t_stop):
     depth = torch.empty((B,), dtype=torch.float32, device=dev)
     tend = torch.empty((B,), dtype=torch.float32, device=dev)
     cnt = torch.empty((B,), dtype=torch.int32, device=dev)
-    check(lib().tir_march_primary_fwd(C.byref(field), _ptr(rays), _ptr(ray_jitter), B, n_samples,
+    _call("tir_march_primary_fwd", C.byref(field), _ptr(rays), _ptr(ray_jitter), B, n_samples,
                                       float(t_stop), _ptr(weight), _ptr(acc), _ptr(depth), _ptr(tend),
-                                      _ptr(cnt), _stream()), "tir_march_primary_fwd")
+                                      _ptr(cnt), _stats_ptr("tir_march_primary_fwd", dev), _stream())
     return weight, acc, depth, tend, cnt
 
 
@@ -193,7 +229,7 @@ def exclusive_scan(counts):
     counts = i32(counts, "counts").view(-1)
     n = counts.numel()
     off = torch.empty((n + 1,), dtype=torch.int32, device=counts.device)
-    check(lib().tir_exclusive_scan(_ptr(counts), _ptr(off), n, _stream()), "tir_exclusive_scan")
+    _call("tir_exclusive_scan", _ptr(counts), _ptr(off), n, _stream())
     return off
 
 
@@ -208,9 +244,9 @@ def compact_primary(field: TirField, rays, ray_jitter, weight, offsets, total):
     rec_w = torch.empty((total,), dtype=torch.float32, device=dev)
     rec_xyz = torch.empty((total, 3), dtype=torch.float32, device=dev)
     if total > 0:
-        check(lib().tir_compact_primary(C.byref(field), _ptr(rays), _ptr(ray_jitter), _ptr(weight),
+        _call("tir_compact_primary", C.byref(field), _ptr(rays), _ptr(ray_jitter), _ptr(weight),
                                         _ptr(offsets), B, S, _ptr(rec_ray), _ptr(rec_k), _ptr(rec_w),
-                                        _ptr(rec_xyz), _stream()), "tir_compact_primary")
+                                        _ptr(rec_xyz), _stream())
     return rec_ray, rec_k, rec_w, rec_xyz
 
 
@@ -219,10 +255,10 @@ def composite_primary(rays, offsets, rec_w, rgb, brdf, brdf_jit, pred_n, der_n, 
     rays = f32(rays, "rays", 6)
     B = rays.shape[0]
     out = torch.empty((B, MAP_STRIDE), dtype=torch.float32, device=rays.device)
-    check(lib().tir_composite_primary(_ptr(rays), _ptr(offsets), _ptr(rec_w), _ptr(rgb), _ptr(brdf),
+    _call("tir_composite_primary", _ptr(rays), _ptr(offsets), _ptr(rec_w), _ptr(rgb), _ptr(brdf),
                                       _ptr(brdf_jit), _ptr(pred_n), _ptr(der_n), _ptr(acc), _ptr(depth),
                                       B, int(bool(white_bg)), int(bool(is_relight)),
-                                      float(fixed_fresnel), _ptr(out), _stream()), "tir_composite_primary")
+                                      float(fixed_fresnel), _ptr(out), _stream())
     return out
 
 
@@ -252,18 +288,18 @@ def march_secondary(field: TirField, origins, dirs, z_vals, n_rays, org_map=None
             "cap": rec_cap,
         }
     r = rec or {}
-    check(lib().tir_march_secondary_fwd(
+    _call("tir_march_secondary_fwd", 
         C.byref(field), _ptr(origins), _ptr(org_map), _ptr(dirs), _ptr(dir_map), _ptr(active),
         n_rays, n_sample, _ptr(z_vals), float(t_stop), _ptr(vis), _ptr(oma),
         _ptr(r.get("counter")), int(rec_cap), _ptr(r.get("ray")), _ptr(r.get("w")), _ptr(r.get("xyz")),
-        _ptr(r.get("off")), _ptr(r.get("cnt")), _stream()), "tir_march_secondary_fwd")
+        _ptr(r.get("off")), _ptr(r.get("cnt")), _stats_ptr("tir_march_secondary_fwd", dev), _stream())
     return vis, oma, rec
 
 
 def accumulate_records(off, cnt, rec_w, rec_rgb, n_rays):
     out = torch.empty((n_rays, 3), dtype=torch.float32, device=off.device)
-    check(lib().tir_accumulate_records(_ptr(off), _ptr(cnt), _ptr(rec_w), _ptr(rec_rgb), n_rays,
-                                       _ptr(out), _stream()), "tir_accumulate_records")
+    _call("tir_accumulate_records", _ptr(off), _ptr(cnt), _ptr(rec_w), _ptr(rec_rgb), n_rays,
+                                       _ptr(out), _stream())
     return out
 
 
@@ -275,7 +311,7 @@ def env_sg(lgtSGs, rot, dirs):
     L, D = rot.shape[0], dirs.shape[0]
     out = torch.empty((L, D, 3), dtype=torch.float32, device=dirs.device)
     desc = TirEnvSG(sgs.data_ptr(), rot.data_ptr(), sgs.shape[0], L)
-    check(lib().tir_env_sg_fwd(C.byref(desc), _ptr(dirs), D, _ptr(out), _stream()), "tir_env_sg_fwd")
+    _call("tir_env_sg_fwd", C.byref(desc), _ptr(dirs), D, _ptr(out), _stream())
     return out
 
 
@@ -286,8 +322,8 @@ def shade_setup(maps, rays, dirs):
     M, D = maps.shape[0], dirs.shape[0]
     surf = torch.empty((M, 3), dtype=torch.float32, device=maps.device)
     active = torch.empty((M, D), dtype=torch.uint8, device=maps.device)
-    check(lib().tir_shade_setup(_ptr(maps), _ptr(rays), _ptr(dirs), M, D, _ptr(surf), _ptr(active),
-                                _stream()), "tir_shade_setup")
+    _call("tir_shade_setup", _ptr(maps), _ptr(rays), _ptr(dirs), M, D, _ptr(surf), _ptr(active),
+                                _stream())
     return surf, active
 
 
@@ -305,10 +341,9 @@ def shade_integrate(maps, rays, dirs, light_idx, vis, indirect, env, weight_d, e
     if weight_d is not None:
         weight_d = f32(weight_d, "light_area_weight")
     out = torch.empty((M, 3), dtype=torch.float32, device=maps.device)
-    check(lib().tir_shade_integrate(_ptr(maps), _ptr(rays), _ptr(dirs), _ptr(light_idx), _ptr(vis),
+    _call("tir_shade_integrate", _ptr(maps), _ptr(rays), _ptr(dirs), _ptr(light_idx), _ptr(vis),
                                     _ptr(indirect), _ptr(env), _ptr(weight_d), M, D, env.shape[0],
-                                    int(bool(equal_area)), int(bool(use_srgb)), _ptr(out), _stream()),
-          "tir_shade_integrate")
+                                    int(bool(equal_area)), int(bool(use_srgb)), _ptr(out), _stream())
     return out
 
 
@@ -321,9 +356,9 @@ def relight_importance(normal, albedo, rough, fresnel, rays_d, light_dir, light_
     light_pdf = f32(light_pdf, "light_pdf").view(M, Ns)
     vis = f32(vis, "vis").view(M, Ns)
     out = torch.empty((M, 3), dtype=torch.float32, device=normal.device)
-    check(lib().tir_relight_importance(_ptr(normal), _ptr(albedo), _ptr(rough), _ptr(fresnel), _ptr(rays_d),
+    _call("tir_relight_importance", _ptr(normal), _ptr(albedo), _ptr(rough), _ptr(fresnel), _ptr(rays_d),
                                        _ptr(light_dir), _ptr(light_rgb), _ptr(light_pdf), _ptr(vis), M, Ns,
-                                       _ptr(out), _stream()), "tir_relight_importance")
+                                       _ptr(out), _stream())
     return out
 
 
@@ -334,6 +369,6 @@ def ggx_specular(normal, v, l, rough, fresnel):
     rough = f32(rough.expand(M, 3) if rough.shape[-1] == 1 else rough, "roughness", 3)
     fresnel = f32(fresnel.expand(M, 3) if fresnel.shape[-1] == 1 else fresnel, "fresnel", 3)
     out = torch.empty((M, D, 3), dtype=torch.float32, device=l.device)
-    check(lib().tir_ggx_specular(_ptr(normal), _ptr(v), _ptr(l), _ptr(rough), _ptr(fresnel), M, D,
-                                 _ptr(out), _stream()), "tir_ggx_specular")
+    _call("tir_ggx_specular", _ptr(normal), _ptr(v), _ptr(l), _ptr(rough), _ptr(fresnel), M, D,
+                                 _ptr(out), _stream())
     return out

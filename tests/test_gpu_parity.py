@@ -1,0 +1,285 @@
+"""Parity tests proper: the HIP path (through the C ABI) against (a) the golden vectors produced by the
+imported reference and (b) the CPU oracle on seeded inputs; plus size-independent properties at
+BASELINE.json's full size.  Tolerance: north_star's 1e-4 relative on rendered maps, measured as
+|hip - ref| / max(|ref|, 1)  (the maps live in [0,1] / unit normals / depth ~4)."""
+import ctypes as C
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+NAMES = ["rgb_map", "depth_map", "normal_map", "albedo_map", "roughness_map", "fresnel_map", "acc_map",
+         "normals_diff_map", "normals_orientation_loss_map", "acc_mask", "albedo_smoothness_loss",
+         "roughness_smoothness_loss"]
+
+
+def rel(a, b, floor=1.0):
+    a, b = a.detach().double().cpu(), torch.as_tensor(b).double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(((a - b).abs() / b.abs().clamp(min=floor)).max()) if a.numel() else 0.0
+
+
+@pytest.fixture(scope="module")
+def env(golden):
+    import tensoir_amd
+    from tests.helpers import golden_checkpoint, scene_from_checkpoint
+    assert torch.cuda.is_available()
+    from tensoir_amd import _lib
+    assert _lib.lib().tir_device_check() == 0           # fails loudly if the HIP library cannot run
+    ckpt = golden_checkpoint(golden)
+    eh, ew = [int(x) for x in golden["scene/envmap_hw"]]
+    model = tensoir_amd.model_from_checkpoint(ckpt, "cuda", envmap_h=eh, envmap_w=ew)
+    model.march_t_stop = 0.0
+    sc = scene_from_checkpoint(ckpt, eh, ew)
+    return types.SimpleNamespace(model=model, sc=sc, g=golden, dev="cuda",
+                                 args=types.SimpleNamespace(second_nSample=24, second_near=0.05, second_far=1.5))
+
+
+def G(env, key):
+    return torch.from_numpy(np.array(env.g[key])).to(env.dev)
+
+
+# ---------------------------------------------------------------- golden vectors (reference outputs)
+@torch.no_grad()
+def test_density_and_app_features_vs_reference(env):
+    m = env.model
+    xyz, li = G(env, "feat/xyz"), G(env, "feat/light_idx")
+    assert rel(m.compute_densityfeature(xyz), env.g["feat/density"]) < 2e-5
+    assert rel(m.compute_appfeature(xyz, li), env.g["feat/app"]) < 2e-5
+    r, i = m.compute_bothfeature(xyz, li)
+    assert rel(r, env.g["feat/both_rad"]) < 2e-5 and rel(i, env.g["feat/both_int"]) < 2e-5
+    assert rel(m.compute_intrinfeature(xyz), env.g["feat/intrin"]) < 2e-5
+    hit = m.alphaMask.sample_alpha(G(env, "occ/xyz_world")) > 0
+    assert bool((hit.cpu() == (torch.from_numpy(env.g["occ/alpha"]) > 0)).all())
+    assert rel(m.compute_derived_normals(G(env, "normals/xyz")), env.g["normals/derived"]) < TOL
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("impl", ["mfma", "valu"])
+def test_decoders_vs_reference(env, impl):
+    from tensoir_amd import ops
+    m = env.model
+    xyz, vd = G(env, "feat/xyz"), G(env, "mlp/viewdirs")
+    r, i = G(env, "feat/both_rad"), G(env, "feat/both_int")
+    assert rel(ops.mlp(m.renderModule.packed(), r, vd, None, impl), env.g["mlp/rgb"]) < 1e-5
+    assert rel(ops.mlp(m.renderModule_brdf.packed(), i, xyz, None, impl), env.g["mlp/brdf"]) < 1e-5
+    assert rel(ops.mlp(m.renderModule_normal.packed(), i, xyz, None, impl), env.g["mlp/normal"]) < 1e-5
+
+
+@torch.no_grad()
+def test_forward_vs_reference(env):
+    rays, lidx = G(env, "rays/rays"), G(env, "rays/light_idx")
+    out = env.model(rays, lidx)
+    for n, a in zip(NAMES, out):
+        if n == "acc_mask":
+            assert bool((a.cpu().numpy() == env.g["fwd/acc_mask"]).all())
+        elif not n.endswith("smoothness_loss"):        # those depend on the (device) jitter noise draw
+            assert rel(a, env.g["fwd/" + n]) < TOL, n
+    o = env.model(rays, lidx, is_relight=False)
+    assert rel(o[0], env.g["fwd_norelight/rgb_map"]) < TOL and rel(o[1], env.g["fwd_norelight/depth_map"]) < TOL
+    assert all(x is None for k, x in enumerate(o) if k not in (0, 1, 6))
+    o = env.model(rays, lidx, white_bg=False, N_samples=57)
+    for n, a in zip(NAMES, o):
+        if n not in ("acc_mask", "albedo_smoothness_loss", "roughness_smoothness_loss"):
+            assert rel(a, env.g["fwd_blackbg57/" + n]) < TOL, n
+
+
+@torch.no_grad()
+def test_secondary_env_ggx_vs_reference(env):
+    from tensoir_amd import relight
+    m = env.model
+    p, d, l = G(env, "sec/pts"), G(env, "sec/dirs"), G(env, "sec/light_idx")
+    v, nf = relight.compute_transmittance(m, p, d, nSample=96, vis_near=0.05, vis_far=1.5)
+    assert rel(v, env.g["sec/trans_vis"]) < TOL and rel(nf, env.g["sec/trans_nerfactor"]) < TOL
+    v, nf, ind = relight.compute_radiance(m, p, d, l, nSample=96, vis_near=0.05, vis_far=1.5)
+    assert rel(v, env.g["sec/rad_vis"]) < TOL and rel(ind, env.g["sec/rad_indirect"]) < TOL
+    assert rel(m.get_light_rgbs(G(env, "env/dirs"), device=env.dev), env.g["env/light_rgbs"]) < 1e-5
+    spec = relight.GGX_specular(G(env, "ggx/normal"), G(env, "ggx/v"), G(env, "ggx/l"), G(env, "ggx/rough"),
+                                G(env, "ggx/fresnel"))
+    assert rel(spec, env.g["ggx/spec"], 1e-3) < 1e-4
+
+
+@torch.no_grad()
+def test_renderer_boundary_vs_reference(env):
+    from tensoir_amd import Renderer_TensoIR_train
+    rays, lidx = G(env, "rays/rays").cpu(), G(env, "rays/light_idx").cpu()   # host tensors, as the reference passes
+    ret = Renderer_TensoIR_train(rays, None, lidx, env.model, args=env.args, device=env.dev)
+    assert sorted(ret) == sorted(k.split("/")[1] for k in env.g.files if k.startswith("render_fixed/"))
+    for k, v in ret.items():
+        if not k.endswith("smoothness_loss"):
+            assert rel(v, env.g["render_fixed/" + k]) < TOL, k
+    # stratified light directions: same CPU generator draws as the reference (randn on device differs,
+    # it only feeds the smoothness losses)
+    torch.manual_seed(20211202 + 5)
+    ret = Renderer_TensoIR_train(rays, None, lidx, env.model, args=env.args, device=env.dev,
+                                 sample_method="stratified_sampling")
+    assert rel(ret["rgb_with_brdf_map"], env.g["render_strat/rgb_with_brdf_map"]) < TOL
+
+
+@torch.no_grad()
+def test_hdr_relight_vs_reference(env):
+    from tensoir_amd import relight
+    out = relight.relight_with_envmap(env.model, G(env, "hdr/surf"), G(env, "hdr/normal"), G(env, "hdr/albedo"),
+                                      G(env, "hdr/rough"), G(env, "hdr/fresnel"), G(env, "hdr/rays_d"),
+                                      G(env, "hdr/light_dir"), G(env, "hdr/light_rgb"), G(env, "hdr/light_pdf"))
+    assert rel(out, env.g["hdr/relit"]) < TOL
+    el = relight.Environment_Light(hdr_maps={"syn": env.g["hdr/map"]}, device=env.dev)
+    assert rel(el.hdr_pdf_return["syn"], env.g["hdr/pdf_return"], 1e-3) < 1e-4
+    d, rgb, pdf = el.sample_light("syn", 7, 64)
+    assert d.shape == (7, 64, 3) and rgb.shape == (7, 64, 3) and pdf.shape == (7, 64, 1)
+    assert rel(el.get_light("syn", G(env, "rays/rays")[:, 3:]), env.g["hdr/bg"], 1e-2) < 1e-4
+
+
+# ---------------------------------------------------------------- oracle on seeded inputs (mid size)
+@pytest.fixture(scope="module")
+def mid():
+    import tensoir_amd
+    from oracle import tensoir_oracle as O
+    from tensoir_amd import synth
+    from tests.helpers import scene_from_checkpoint
+    ck = synth.make_checkpoint(grid=(96, 96, 96), seed=11, light_rotation=("000", "120", "240"))
+    sc = scene_from_checkpoint(ck, 8, 16)
+    O.update_alpha_mask(sc, (48, 48, 48))
+    vol = sc.alpha_volume
+    ck["alphaMask.shape"] = tuple(vol.shape)
+    ck["alphaMask.mask"] = np.packbits(vol.bool().numpy().reshape(-1))
+    ck["alphaMask.aabb"] = sc.alpha_aabb
+    model = tensoir_amd.model_from_checkpoint(ck, "cuda", envmap_h=8, envmap_w=16)
+    return types.SimpleNamespace(model=model, sc=sc, O=O, synth=synth)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("t_stop", [0.0, 1e-6])
+def test_renderer_vs_oracle_mid_size(mid, t_stop):
+    """Ragged batch (B not a multiple of 4, S not a multiple of 64), three lights, with and without
+    early ray termination."""
+    from tensoir_amd import Renderer_TensoIR_train, relight
+    m = mid.model
+    m.march_t_stop = t_stop
+    rays = mid.synth.make_rays(21, 19)
+    lidx = (torch.arange(rays.shape[0]) % 3).view(-1, 1).int()
+    S = 200
+    noise = torch.randn(rays.shape[0], S, 3, generator=torch.Generator().manual_seed(5))
+    args = types.SimpleNamespace(second_nSample=96, second_near=0.05, second_far=1.5)
+    out, maps = m(rays.cuda(), lidx.cuda(), N_samples=S, _brdf_jitter_dense=noise, _return_maps=True)
+    mask = out[9]
+    brdf = relight.shade_from_maps(m, maps[mask], rays.cuda()[mask], lidx.cuda()[mask], "fixed_envirmap", args)
+    ref = mid.O.renderer_train(mid.sc, rays, lidx, n_samples=S, brdf_jitter=noise)
+    for n, a in zip(NAMES, out):
+        if n == "acc_mask":
+            assert bool((a.cpu() == (ref["acc_map"] > 0.5)).all())
+        elif n.endswith("smoothness_loss"):
+            assert rel(a, ref[n], 1e-9) < 1e-2
+        else:
+            assert rel(a, ref[n]) < TOL, n
+    assert rel(brdf, ref["rgb_with_brdf_map"][ref["acc_map"] > 0.5]) < TOL
+    m.march_t_stop = 1e-6
+
+
+# ---------------------------------------------------------------- edge cases
+@torch.no_grad()
+def test_edge_cases(env):
+    from tensoir_amd import Renderer_TensoIR_train, relight
+    m, dev = env.model, env.dev
+    # empty batch
+    ret = Renderer_TensoIR_train(torch.zeros(0, 6), None, torch.zeros(0, 1, dtype=torch.int32), m, args=env.args, device=dev)
+    assert ret["rgb_map"].shape == (0, 3) and ret["rgb_with_brdf_map"].shape == (0, 3)
+    # rays that miss the volume: white background everywhere, no surface points, no records
+    rays = torch.tensor([[0.0, 0.0, 4.0, 0.0, 0.0, 1.0], [5.0, 5.0, 5.0, 1.0, 0.0, 0.0], [0, 0, 4.0, 0.0, 1.0, 0.0]])
+    ret = Renderer_TensoIR_train(rays, None, torch.zeros(3, 1, dtype=torch.int32), m, args=env.args, device=dev)
+    assert torch.all(ret["acc_map"] == 0) and torch.allclose(ret["rgb_map"], torch.ones(3, 3, device=dev))
+    assert torch.all(ret["rgb_with_brdf_map"] == 1) and torch.allclose(ret["normal_map"][:, 2], torch.ones(3, device=dev))
+    # zero direction component (the vec==0 -> 1e-6 substitution of sample_ray) stays finite
+    r = G(env, "rays/rays")[:5].clone(); r[:, 3] = 0.0
+    out = m(r, torch.zeros(5, 1, dtype=torch.int32, device=dev))
+    assert all(torch.isfinite(o).all() for o in out if torch.is_tensor(o) and o.dtype.is_floating_point)
+    # secondary march limits: n_sample 1, 256 (max) and 257 (rejected)
+    p, d = G(env, "sec/pts")[:9], G(env, "sec/dirs")[:9]
+    for n in (1, 33, 256):
+        v, nf = relight.compute_transmittance(m, p, d, nSample=n, vis_near=0.05, vis_far=1.5)
+        assert v.shape == (9,) and torch.isfinite(v).all() and (v <= 1.0 + 1e-6).all()
+    from tensoir_amd._lib import TensoirHipError
+    with pytest.raises(TensoirHipError):
+        relight.compute_transmittance(m, p, d, nSample=257, vis_near=0.05, vis_far=1.5)
+    with pytest.raises(TensoirHipError):
+        m.compute_densityfeature(torch.zeros(4, 3))          # CPU tensor: no fallback
+
+
+@torch.no_grad()
+def test_record_overflow_recovers(env):
+    """Secondary records larger than the first capacity guess trigger a re-march, not a wrong answer."""
+    from tensoir_amd import relight
+    m = env.model
+    p, d, l = G(env, "sec/pts"), G(env, "sec/dirs"), G(env, "sec/light_idx")
+    m._rec_cap_hint = 1
+    v, nf, ind = relight.compute_radiance(m, p, d, l, nSample=96, vis_near=0.05, vis_far=1.5)
+    assert rel(ind, env.g["sec/rad_indirect"]) < TOL
+
+
+# ---------------------------------------------------------------- full size (BASELINE C2/C3) properties
+@pytest.fixture(scope="module")
+def full():
+    import tensoir_amd
+    from tensoir_amd import synth
+    ck = synth.make_checkpoint(grid=(300, 300, 300), seed=20211202)
+    model = tensoir_amd.model_from_checkpoint(ck, "cuda", envmap_h=8, envmap_w=16)
+    with torch.no_grad():
+        model.updateAlphaMask((128, 128, 128))
+    rays = synth.make_rays(64, 64).cuda()
+    return types.SimpleNamespace(model=model, rays=rays, lidx=torch.zeros(4096, 1, dtype=torch.int32, device="cuda"),
+                                 args=types.SimpleNamespace(second_nSample=96, second_near=0.05, second_far=1.5))
+
+
+@torch.no_grad()
+def test_full_size_properties(full):
+    """4096 rays x 512 samples, R=300: conservation, sharding invariance, determinism, decoder cross-check."""
+    from tensoir_amd import Renderer_TensoIR_train, ops
+    m, rays, lidx = full.model, full.rays, full.lidx
+    f = m.packed_field()
+    # (1) sum of weights + final transmittance == 1 (telescoping product; 1e-10 fudge aside)
+    w, acc, depth, tend, cnt = ops.march_primary(f, rays, None, 512, 0.0)
+    assert float((acc + tend - 1.0).abs().max()) < 2e-5
+    assert float((w.sum(-1) - acc).abs().max()) < 2e-5
+    assert int((cnt != (w > m.rayMarch_weight_thres).sum(-1)).sum()) == 0
+    # (2) early termination changes nothing above its bound
+    w2, acc2, depth2, _, cnt2 = ops.march_primary(f, rays, None, 512, 1e-6)
+    assert float((acc2 - acc).abs().max()) < 3e-6 and float((depth2 - depth).abs().max()) < 2e-5
+    assert torch.equal(cnt, cnt2)
+    # (3) rays are independent: rendering two halves == rendering the batch, bit for bit; and repeatable
+    noise = torch.randn(4096, 512, 3, generator=torch.Generator().manual_seed(1)).cuda()
+    kw = dict(N_samples=512, args=full.args, device="cuda")
+    import tensoir_amd.field_model as FM
+    orig = FM.TensorVMSplit.forward
+    def fwd(self, r, l, **k):
+        sel = k.pop("_sel")
+        return orig(self, r, l, _brdf_jitter_dense=noise[sel], **k)
+    whole = orig(m, rays, lidx, N_samples=512, _brdf_jitter_dense=noise)
+    again = orig(m, rays, lidx, N_samples=512, _brdf_jitter_dense=noise)
+    lo = orig(m, rays[:2048], lidx[:2048], N_samples=512, _brdf_jitter_dense=noise[:2048])
+    hi = orig(m, rays[2048:], lidx[2048:], N_samples=512, _brdf_jitter_dense=noise[2048:])
+    for k in range(10):
+        if whole[k] is None or whole[k].dim() == 0:
+            continue
+        assert torch.equal(whole[k], again[k]), NAMES[k]
+        assert torch.equal(whole[k], torch.cat([lo[k], hi[k]])), NAMES[k]
+    # (4) MFMA decoder == VALU decoder on the real sample set
+    offsets = ops.exclusive_scan(cnt)
+    A = int(offsets[-1])
+    assert A > 100000
+    rec_ray, rec_k, rec_w, rec_xyz = ops.compact_primary(f, rays, None, w, offsets, A)
+    assert bool((rec_ray[1:] >= rec_ray[:-1]).all())                       # (ray, sample) order
+    rad, intr = ops.vm_app(f, rec_xyz[:20000], lidx.view(-1), rec_ray[:20000], True, True)
+    a = ops.mlp(m.renderModule_brdf.packed(), intr, rec_xyz[:20000], None, "mfma")
+    b = ops.mlp(m.renderModule_brdf.packed(), intr, rec_xyz[:20000], None, "valu")
+    assert float((a - b).abs().max()) < 2e-6
+    # (5) full boundary call: finite, in range, background white
+    ret = Renderer_TensoIR_train(rays, None, lidx, m, **kw)
+    for k, v in ret.items():
+        assert torch.isfinite(v).all(), k
+    assert float(ret["rgb_with_brdf_map"].min()) >= 0 and float(ret["rgb_with_brdf_map"].max()) <= 1.0 + 1e-6
+    n = ret["normal_map"].norm(dim=-1)
+    assert float((n[ret["acc_map"] > 0.5] - 1).abs().max()) < 1e-4

@@ -1,0 +1,113 @@
+"""Host-side mirror of the reference interface: construction, checkpoint compatibility, light tables,
+grid maintenance.  CPU only (no kernel launches)."""
+import io
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import tensoir_amd
+from tensoir_amd import synth
+from tensoir_amd.field_model import TensorVMSplit
+from tests.helpers import T, golden_checkpoint
+
+SEED = 20211202
+
+
+@pytest.fixture(scope="module")
+def model(golden):
+    eh, ew = [int(x) for x in golden["scene/envmap_hw"]]
+    return tensoir_amd.model_from_checkpoint(golden_checkpoint(golden), "cpu", envmap_h=eh, envmap_w=ew)
+
+
+def test_state_dict_is_reference_compatible(golden, model):
+    ref_keys = sorted(k[3:] for k in golden.files if k.startswith("sd/"))
+    sd = model.state_dict()
+    assert sorted(sd.keys()) == ref_keys
+    for k in ref_keys:
+        assert tuple(sd[k].shape) == golden["sd/" + k].shape, k
+        assert torch.equal(sd[k], T(golden, "sd/" + k))
+
+
+def test_step_geometry_matches_reference(golden, model):
+    assert model.nSamples == int(golden["scene/nSamples"][0])
+    assert float(model.stepSize) == float(golden["scene/stepSize"][0])
+    assert model.alphaMask.alpha_volume.shape[-3:] == golden["scene/alpha_volume"].shape
+
+
+def test_kwargs_roundtrip(tmp_path, model):
+    path = tmp_path / "ckpt.th"
+    model.save(str(path))
+    ckpt = torch.load(str(path), weights_only=False)
+    assert set(ckpt) == {"kwargs", "state_dict", "alphaMask.shape", "alphaMask.mask", "alphaMask.aabb"}
+    m2 = tensoir_amd.model_from_checkpoint(ckpt, "cpu", envmap_h=model.envmap_h, envmap_w=model.envmap_w)
+    for (k1, v1), (k2, v2) in zip(model.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    assert torch.equal(m2.alphaMask.alpha_volume, model.alphaMask.alpha_volume)
+    kw = model.get_kwargs()
+    assert kw["light_rotation"] == [0, 120, 240] and kw["light_num"] == 3 and kw["gridSize"] == [20, 24, 28]
+
+
+def test_light_tables_match_reference(golden, model):
+    area, dirs = model.generate_envir_map_dir(model.envmap_h, model.envmap_w)
+    assert torch.allclose(area, T(golden, "env/area"), atol=1e-7)
+    assert torch.allclose(dirs, T(golden, "env/dirs"), atol=1e-7)
+    assert torch.equal(model.gen_light_incident_dirs(method="fixed_envirmap"), model.fixed_viewdirs)
+    torch.manual_seed(SEED + 4)
+    strat = model.gen_light_incident_dirs(method="stratified_sampling")
+    assert torch.allclose(strat, T(golden, "env/strat_dirs"), atol=1e-6)
+    assert model.light_rotation_matrix.shape == (3, 3, 3)
+    with pytest.raises(ValueError):
+        model.gen_light_incident_dirs(method="nope")
+
+
+def test_sample_ray_matches_reference(golden, model):
+    rays = T(golden, "rays/rays")
+    pts, z, valid = model.sample_ray(rays[:, :3], rays[:, 3:6], is_train=False)
+    assert torch.equal(pts, T(golden, "march/pts")) and torch.equal(z, T(golden, "march/z"))
+    assert torch.equal(valid, T(golden, "march/valid"))
+    torch.manual_seed(SEED + 2)
+    _, zt, vt = model.sample_ray(rays[:, :3], rays[:, 3:6], is_train=True, N_samples=40)
+    assert torch.equal(zt, T(golden, "march/train_z")) and torch.equal(vt, T(golden, "march/train_valid"))
+
+
+def test_upsample_and_optimizer_groups():
+    ck = synth.make_checkpoint(grid=(12, 14, 16), seed=3)
+    m = tensoir_amd.model_from_checkpoint(ck, "cpu", envmap_h=4, envmap_w=8)
+    groups = m.get_optparam_groups(0.02, 0.001)
+    n_group_params = sum(len(list(g["params"])) if not isinstance(g["params"], torch.nn.Parameter) else 1 for g in groups)
+    assert n_group_params == len(list(m.parameters()))
+    m.upsample_volume_grid([20, 22, 24])
+    assert m.gridSize.tolist() == [20, 22, 24]
+    assert tuple(m.density_plane[0].shape) == (1, 16, 22, 20) and tuple(m.app_line[0].shape) == (1, 48, 24, 1)
+    assert m._field_key is None                       # packed shadow invalidated
+    reg = lambda x: (x[..., 1:, :] - x[..., :-1, :]).pow(2).mean()
+    for v in (m.vector_comp_diffs(), m.density_L1(), m.TV_loss_density(reg), m.TV_loss_app(reg)):
+        assert torch.isfinite(v)
+
+
+def test_unsupported_configurations_fail_loudly():
+    aabb = torch.tensor([[-1.5] * 3, [1.5] * 3])
+    with pytest.raises(NotImplementedError):
+        TensorVMSplit(aabb, [8, 8, 8], "cpu", shadingMode="SH", light_kind="sg", density_n_comp=[16] * 3,
+                      appearance_n_comp=[48] * 3)
+    with pytest.raises(NotImplementedError):
+        TensorVMSplit(aabb, [8, 8, 8], "cpu", shadingMode="MLP_Fea", light_kind="pixel", density_n_comp=[16] * 3,
+                      appearance_n_comp=[48] * 3)
+
+
+def test_no_silent_fallbacks(model, golden):
+    rays, lidx = T(golden, "rays/rays"), T(golden, "rays/light_idx")
+    with pytest.raises(NotImplementedError):           # autograd requested, no backward kernels yet
+        model(rays, lidx)
+    if not torch.cuda.is_available():
+        from tensoir_amd._lib import TensoirHipError
+        with torch.no_grad(), pytest.raises(TensoirHipError):
+            model(rays, lidx)                          # CPU tensors never run
+
+
+def test_synth_rays():
+    r = synth.make_rays(4, 6)
+    assert r.shape == (24, 6) and torch.allclose(r[:, 3:].norm(dim=-1), torch.ones(24), atol=1e-6)
+    assert torch.all(r[:, 2] == 4.0)
