@@ -114,7 +114,12 @@ def test_renderer_boundary_vs_reference(env):
             assert rel(v, env.g["render_fixed/" + k]) < TOL, k
     # stratified light directions: same CPU generator draws as the reference (randn on device differs,
     # it only feeds the smoothness losses)
+    # The golden run had the reference on the CPU, where its randn_like [A,3] (:937) also consumed the
+    # CPU generator before the two rand_like draws of gen_light_incident_dirs (:520); replay that.
+    from tensoir_amd import ops
+    cnt = ops.march_primary(env.model.packed_field(), rays.to(env.dev), None, env.model.nSamples, 0.0)[4]
     torch.manual_seed(20211202 + 5)
+    torch.randn(int(cnt.sum()), 3)
     ret = Renderer_TensoIR_train(rays, None, lidx, env.model, args=env.args, device=env.dev,
                                  sample_method="stratified_sampling")
     assert rel(ret["rgb_with_brdf_map"], env.g["render_strat/rgb_with_brdf_map"]) < TOL
