@@ -145,7 +145,7 @@ k_exclusive_scan(const int32_t* __restrict__ counts, int32_t* __restrict__ offse
 }
 
 extern "C" int tir_exclusive_scan(const int32_t* counts, int32_t* offsets, int32_t n, void* stream) {
-    if (!counts || !offsets || n < 0) return TIR_ERR_ARG;
+    if (!offsets || n < 0 || (n > 0 && !counts)) return TIR_ERR_ARG;
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, tir_stream(stream), counts, offsets, n);
     TIR_CHECK_LAUNCH();
     return TIR_OK;

@@ -78,6 +78,7 @@ def test_version_and_errors(lib):
     assert lib.tir_pack_plane(None, None, 16, 8, 8, None) == -1001
     assert lib.tir_vm_density_fwd(None, None, None, None, 10, None) == -1001
     assert lib.tir_exclusive_scan(None, None, 4, None) == -1001
+    assert lib.tir_exclusive_scan(None, None, 0, None) == -1001   # offsets is always required
     assert lib.tir_mlp_packed_floats(27, 2, 128, 4) > 36000
     assert lib.tir_mlp_packed_floats(27, 6, 128, 4) == -1002      # only pe=2 / 27 / 128 are built
     assert lib.tir_mlp_packed_floats(27, 2, 64, 3) == -1002

@@ -9,9 +9,9 @@ def find(pattern):
 
 
 def short(name):
-    name = name.split("(")[0]
     for p in ("void ", "(anonymous namespace)::"):
         name = name.replace(p, "")
+    name = name.split("(")[0]
     return name[:60]
 
 
@@ -39,3 +39,7 @@ for f in find("*counter_collection.csv"):
             continue
         parts = [f"{c}={sum(v)/len(v):.4g} (n={len(v)})" for c, v in sorted(cs.items())]
         print(f"  {k:40s} " + "  ".join(parts))
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and "SQ_BUSY_CU_CYCLES" in cs and sum(cs["SQ_BUSY_CU_CYCLES"]) > 0:
+            # MFMA busy cycles are summed over the 4 SIMDs of every CU
+            util = sum(cs["SQ_VALU_MFMA_BUSY_CYCLES"]) / (4.0 * sum(cs["SQ_BUSY_CU_CYCLES"]))
+            print(f"  {'':40s} MFMA pipe utilisation = MFMA_BUSY / (4 SIMD x BUSY_CU_CYCLES) = {util:.3f}")
