@@ -1,0 +1,61 @@
+"""Launcher that runs an UNMODIFIED TensoIR script on top of the HIP path:
+
+    python -m tensoir_amd.run /path/to/TensoIR/train_tensoIR.py --config configs/single_light/armadillo.txt --render_only 1 --ckpt ...
+
+It puts the TensoIR checkout on sys.path, imports the reference modules, rebinds the hot-path symbols
+ to the tensoir_amd implementations and then runs the script with runpy.  The
+script's own imports (`from renderer import *`, `from models.tensoRF_rotated_lights import raw2alpha,
+TensorVMSplit, AlphaGridMask`, train_tensoIR.py:6-14) then resolve to ours.
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import runpy
+import sys
+
+PATCHES = {
+    "models.tensoRF_rotated_lights": ["TensorVMSplit", "AlphaGridMask", "raw2alpha"],
+    "models.tensorBase_rotated_lights": ["AlphaGridMask", "raw2alpha"],
+    "models.relight_utils": ["render_with_BRDF", "compute_radiance", "compute_transmittance",
+                             "compute_secondary_shading_effects", "GGX_specular", "brdf_specular",
+                             "Environment_Light"],
+    "renderer": ["Renderer_TensoIR_train", "render_with_BRDF"],
+}
+
+
+def install(reference_root: str):
+    """Import the reference modules from `reference_root` and rebind the hot path.  Returns the
+    {module: [symbols]} actually patched."""
+    import tensoir_amd
+    from tensoir_amd import field_model, relight, renderer
+    ours = {}
+    for mod in (field_model, relight, renderer):
+        ours.update({k: getattr(mod, k) for k in dir(mod) if not k.startswith("_")})
+    ours["brdf_specular"] = relight.GGX_specular
+    if reference_root not in sys.path:
+        sys.path.insert(0, reference_root)
+    done = {}
+    for name, symbols in PATCHES.items():
+        m = importlib.import_module(name)
+        for s in symbols:
+            setattr(m, s, ours[s])
+        done[name] = list(symbols)
+    return done
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv:
+        raise SystemExit(__doc__)
+    script = os.path.abspath(argv[0])
+    root = os.path.dirname(script)
+    if os.path.basename(root) == "scripts":
+        root = os.path.dirname(root)
+    install(root)
+    sys.argv = [script] + argv[1:]
+    runpy.run_path(script, run_name="__main__")
+
+
+if __name__ == "__main__":
+    main()

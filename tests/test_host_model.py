@@ -111,3 +111,21 @@ def test_synth_rays():
     r = synth.make_rays(4, 6)
     assert r.shape == (24, 6) and torch.allclose(r[:, 3:].norm(dim=-1), torch.ones(24), atol=1e-6)
     assert torch.all(r[:, 2] == 4.0)
+
+
+def test_launcher_rebinds_reference_symbols():
+    """tensoir_amd.run.install: the reference's own modules end up pointing at our hot path."""
+    from oracle import ref_loader
+    if not ref_loader.available():
+        pytest.skip("reference checkout not present (GPU box)")
+    ref_loader.load()                                    # stubs for cv2/loguru/... + sys.path
+    from tensoir_amd import run
+    done = run.install(ref_loader.REF_ROOT)
+    import importlib
+    r = importlib.import_module("renderer")
+    ru = importlib.import_module("models.relight_utils")
+    tf = importlib.import_module("models.tensoRF_rotated_lights")
+    assert r.Renderer_TensoIR_train is tensoir_amd.Renderer_TensoIR_train
+    assert ru.render_with_BRDF is tensoir_amd.render_with_BRDF and ru.compute_radiance is tensoir_amd.compute_radiance
+    assert tf.TensorVMSplit is tensoir_amd.TensorVMSplit and tf.AlphaGridMask is tensoir_amd.AlphaGridMask
+    assert set(done) == set(run.PATCHES)
