@@ -62,7 +62,7 @@ typedef struct TirField {
     const float* basis_t;    /* [3*n_acomp][32]: basis_mat^T, app_dim padded to 32 with zeros       */
     const float* light_line; /* [n_lights][3*n_acomp]  (light_line.weight)                          */
     const float* light_mean; /* [3*n_acomp] mean over lights (tensoRF_rotated_lights.py:160-161)    */
-    const uint32_t* occ_bits;/* bit-packed AlphaGridMask volume, bit (z*H+y)*W+x; NULL = no mask    */
+    const uint8_t* occ_nbr;  /* AlphaGridMask as 2x2x2 neighbourhood bytes (tir_pack_occupancy); NULL = no mask */
     int32_t occ_dim[3];      /* W,H,D of the mask volume                                            */
     float occ_aabb_min[3];   /* the mask's own aabb (:105) ...                                      */
     float occ_inv[3];        /* ... and (1/size)*2 (:107)                                           */
@@ -98,8 +98,10 @@ int  tir_device_check(void);
  *      train_tensoIR.py:385-422) -------------------------------------------------------------- */
 /* [C,H,W] -> [H,W,C]   (also lines with W=1) */
 int tir_pack_plane(const float* src, float* dst, int32_t C, int32_t H, int32_t W, void* stream);
-/* float volume -> bits (value > 0.5); n voxels; bits must hold (n+31)/32 words, pre-zeroed not required */
-int tir_pack_occupancy(const float* vol, uint32_t* bits, int64_t n, void* stream);
+/* float volume [D][H][W] -> (D+1)*(H+1)*(W+1) neighbourhood bytes: byte (z0+1,y0+1,x0+1), bit dx+2dy+4dz =
+ * voxel (x0+dx,y0+dy,z0+dz) inside the grid and > 0.5.  The trilinear "sample_alpha(...) > 0" test of a
+ * point then needs one byte. */
+int tir_pack_occupancy(const float* vol, uint8_t* nbr, int32_t W, int32_t H, int32_t D, void* stream);
 /* basis_mat.weight [app_dim][n_in] -> [n_in][32] */
 int tir_pack_basis(const float* w, float* dst, int32_t app_dim, int32_t n_in, void* stream);
 /* light_line.weight [L][n] -> mean over L [n] */
@@ -117,7 +119,7 @@ int tir_vm_density_fwd(const TirField* f, const float* xyz, float* feat, float* 
                        int64_t n, void* stream);
 
 /* ---- a2: AlphaGridMask.sample_alpha(xyz) > 0 (models/tensorBase_rotated_lights.py:112-119) at
- *      world-space points; hit[n] = 1/0.  Needs f->occ_bits. */
+ *      world-space points; hit[n] = 1/0.  Needs f->occ_nbr. */
 int tir_occupancy_query(const TirField* f, const float* xyz, uint8_t* hit, int64_t n, void* stream);
 
 /* ---- K6: analytic d sigma/d xyz and derived normal -normalize(grad, eps=1e-6)
@@ -130,19 +132,33 @@ int tir_density_grad_fwd(const TirField* f, const float* xyz, float* sigma, floa
 /* ---- K4: compute_appfeature / compute_intrinfeature / compute_bothfeature
  *      (models/tensoRF_rotated_lights.py:132-224).  light_idx (per point, or per `idx_map` entry when
  *      idx_map != NULL: light_idx[idx_map[p]]) may be NULL when rad_feat is NULL.
- *      rad_feat / int_feat [n][app_dim], either may be NULL. */
+ *      rad_feat / int_feat [n][out_stride] (app_dim <= out_stride <= 32; columns >= app_dim are written
+ *      as 0; 32 gives aligned 128-byte rows), either may be NULL. */
 int tir_vm_app_fwd(const TirField* f, const float* xyz, const int32_t* light_idx,
-                   const int32_t* idx_map, float* rad_feat, float* int_feat,
+                   const int32_t* idx_map, float* rad_feat, float* int_feat, int32_t out_stride,
                    int64_t n, void* stream);
+/* same contract, one-sample-per-lane VALU kernel (cross-check of the matrix-core kernel) */
+int tir_vm_app_fwd_valu(const TirField* f, const float* xyz, const int32_t* light_idx,
+                        const int32_t* idx_map, float* rad_feat, float* int_feat, int32_t out_stride,
+                        int64_t n, void* stream);
 
 /* ---- K5: positional_encoding + 3-layer MLP + activation
  *      (models/tensorBase_rotated_lights.py:12-17, :136-146, :198-208).
- *      input row = [feat, aux, PE(feat), PE(aux)]; aux row p is aux[aux_map ? aux_map[p] : p]. */
-int tir_mlp_fwd(const TirMlp* m, const float* feat, const float* aux, const int32_t* aux_map,
-                float* out, int64_t n, void* stream);
+ *      input row = [feat, aux, PE(feat), PE(aux)]; aux row p is aux[aux_map ? aux_map[p] : p];
+ *      feat rows are feat_stride floats apart (>= feat_dim). */
+int tir_mlp_fwd(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
+                const int32_t* aux_map, float* out, int64_t n, void* stream);
+/* same contract on v_mfma_f32_32x32x16_bf16 with every operand split x = hi + lo in bf16 and the three
+ * products hi*hi + hi*lo + lo*hi accumulated in fp32 (~16 mantissa bits; measured <= 2e-6 abs on the
+ * decoder outputs): the parity-grade fast path. */
+int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
+                       const int32_t* aux_map, float* out, int64_t n, void* stream);
+/* single bf16 product (8 mantissa bits): reduced-precision mode, NOT parity grade (normals ~5e-3). */
+int tir_mlp_fwd_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
+                     const int32_t* aux_map, float* out, int64_t n, void* stream);
 /* same contract, plain VALU kernel (any hidden size); used to cross-check the MFMA kernel */
-int tir_mlp_fwd_valu(const TirMlp* m, const float* feat, const float* aux, const int32_t* aux_map,
-                     float* out, int64_t n, void* stream);
+int tir_mlp_fwd_valu(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
+                     const int32_t* aux_map, float* out, int64_t n, void* stream);
 
 /* ---- K1+K2+K3 primary march: sample_ray + alpha-mask cull + density + raw2alpha
  *      (models/tensorBase_rotated_lights.py:705-724, :892-921, :21-28).

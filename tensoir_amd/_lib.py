@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtensoir_hip.so")
+LIB_PATH = os.environ.get("TENSOIR_HIP_LIB", os.path.join(_HERE, "libtensoir_hip.so"))
 
 c_float_p = C.c_void_p   # device pointers are passed as integers
 c_int_p = C.c_void_p
@@ -26,7 +26,7 @@ class TirField(C.Structure):
         ("dplane", C.c_void_p * 3), ("dline", C.c_void_p * 3),
         ("aplane", C.c_void_p * 3), ("aline", C.c_void_p * 3),
         ("basis_t", C.c_void_p), ("light_line", C.c_void_p), ("light_mean", C.c_void_p),
-        ("occ_bits", C.c_void_p),
+        ("occ_nbr", C.c_void_p),
         ("occ_dim", C.c_int32 * 3), ("occ_aabb_min", C.c_float * 3), ("occ_inv", C.c_float * 3),
     ]
 
@@ -51,7 +51,7 @@ SIGNATURES = {
     "tir_error_string": (C.c_char_p, [C.c_int]),
     "tir_device_check": (C.c_int, []),
     "tir_pack_plane": (C.c_int, [P, P, I32, I32, I32, P]),
-    "tir_pack_occupancy": (C.c_int, [P, P, I64, P]),
+    "tir_pack_occupancy": (C.c_int, [P, P, I32, I32, I32, P]),
     "tir_pack_basis": (C.c_int, [P, P, I32, I32, P]),
     "tir_light_mean": (C.c_int, [P, P, I32, I32, P]),
     "tir_mlp_packed_floats": (I64, [I32, I32, I32, I32]),
@@ -59,9 +59,12 @@ SIGNATURES = {
     "tir_vm_density_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, I64, P]),
     "tir_occupancy_query": (C.c_int, [C.POINTER(TirField), P, P, I64, P]),
     "tir_density_grad_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, I64, P]),
-    "tir_vm_app_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I64, P]),
-    "tir_mlp_fwd": (C.c_int, [C.POINTER(TirMlp), P, P, P, P, I64, P]),
-    "tir_mlp_fwd_valu": (C.c_int, [C.POINTER(TirMlp), P, P, P, P, I64, P]),
+    "tir_vm_app_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I64, P]),
+    "tir_vm_app_fwd_valu": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I64, P]),
+    "tir_mlp_fwd": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, P, I64, P]),
+    "tir_mlp_fwd_bf16x3": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, P, I64, P]),
+    "tir_mlp_fwd_bf16": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, P, I64, P]),
+    "tir_mlp_fwd_valu": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, P, I64, P]),
     "tir_march_primary_fwd": (C.c_int, [C.POINTER(TirField), P, P, I32, I32, F32, P, P, P, P, P, P, P]),
     "tir_exclusive_scan": (C.c_int, [P, P, I32, P]),
     "tir_compact_primary": (C.c_int, [C.POINTER(TirField), P, P, P, P, I32, I32, P, P, P, P, P]),

@@ -125,8 +125,10 @@ __device__ __forceinline__ float feature2density(const TirField& f, float feat) 
 }
 
 // AlphaGridMask.sample_alpha(...) > 0  (models/tensorBase_rotated_lights.py:112-119, :893-894).
-// The volume is 0/1 and trilinear weights are >= 0, so "interpolated value > 0" == "some corner
-// with non-zero weight is set"; evaluated on the bit-packed volume.
+// The volume is 0/1 and trilinear weights are >= 0, so "interpolated value > 0" == "some corner with
+// non-zero weight is set".  occ_nbr holds, per base voxel (x0,y0,z0) in [-1,W-1]x[-1,H-1]x[-1,D-1], one byte
+// whose bit dx+2dy+4dz is the occupancy of corner (x0+dx,y0+dy,z0+dz) (0 outside the grid): ONE scattered
+// byte load per sample instead of eight word loads.
 __device__ __forceinline__ bool occupancy_hit(const TirField& f, float px, float py, float pz) {
     const int W = f.occ_dim[0], H = f.occ_dim[1], D = f.occ_dim[2];
     float qx = sub_rn(mul_rn(sub_rn(px, f.occ_aabb_min[0]), f.occ_inv[0]), 1.0f);
@@ -134,29 +136,16 @@ __device__ __forceinline__ bool occupancy_hit(const TirField& f, float px, float
     float qz = sub_rn(mul_rn(sub_rn(pz, f.occ_aabb_min[2]), f.occ_inv[2]), 1.0f);
     float ix = unnorm(qx, W), iy = unnorm(qy, H), iz = unnorm(qz, D);
     float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-    int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
-    bool ux = (ix - fx) > 0.0f, uy = (iy - fy) > 0.0f, uz = (iz - fz) > 0.0f;
-    bool hit = false;
-#pragma unroll
-    for (int dz = 0; dz < 2; ++dz) {
-        int zz = z0 + dz;
-        bool okz = (zz >= 0) & (zz < D) & (dz == 0 || uz);
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-            int yy = y0 + dy;
-            bool oky = okz & (yy >= 0) & (yy < H) & (dy == 0 || uy);
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                int xx = x0 + dx;
-                bool ok = oky & (xx >= 0) & (xx < W) & (dx == 0 || ux);
-                if (ok) {
-                    int64_t bit = ((int64_t)zz * H + yy) * W + xx;
-                    hit |= (f.occ_bits[bit >> 5] >> (bit & 31)) & 1u;
-                }
-            }
-        }
-    }
-    return hit;
+    // clamp before the int conversion (far-away points would overflow); out-of-range cells hold 0 anyway
+    fx = fminf(fmaxf(fx, -2.0f), (float)W); fy = fminf(fmaxf(fy, -2.0f), (float)H); fz = fminf(fmaxf(fz, -2.0f), (float)D);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    if ((x0 < -1) | (x0 >= W) | (y0 < -1) | (y0 >= H) | (z0 < -1) | (z0 >= D)) return false;
+    const uint32_t b = f.occ_nbr[((size_t)(z0 + 1) * (H + 1) + (y0 + 1)) * (W + 1) + (x0 + 1)];
+    // corners with a zero interpolation weight (fraction exactly 0) do not count
+    const uint32_t mx = (ix - fx) > 0.0f ? 0xFFu : 0x55u;
+    const uint32_t my = (iy - fy) > 0.0f ? 0xFFu : 0x33u;
+    const uint32_t mz = (iz - fz) > 0.0f ? 0xFFu : 0x0Fu;
+    return (b & mx & my & mz) != 0u;
 }
 
 // in-bbox test of sample_ray / sample_ray_equally: ~((aabb0 > p) | (p > aabb1)).any()
@@ -165,28 +154,58 @@ __device__ __forceinline__ bool in_bbox(const TirField& f, float px, float py, f
              (py > f.aabb_max[1]) | (f.aabb_min[2] > pz) | (pz > f.aabb_max[2]));
 }
 
-// sigma at a world-space sample (bbox test, occupancy cull, density, activation):
-// models/tensorBase_rotated_lights.py:892-919.  Returns 0 for culled samples.
-__device__ __forceinline__ float sigma_at(const TirField& f, float px, float py, float pz, bool& gathered) {
-    gathered = false;
-    if (!in_bbox(f, px, py, pz)) return 0.0f;
-    if (f.occ_bits != nullptr && !occupancy_hit(f, px, py, pz)) return 0.0f;
-    gathered = true;
-    float x = norm_coord(px, f.aabb_min[0], f.inv_aabb[0]);
-    float y = norm_coord(py, f.aabb_min[1], f.inv_aabb[1]);
-    float z = norm_coord(pz, f.aabb_min[2], f.inv_aabb[2]);
-    return feature2density(f, density_feature_dyn(f, x, y, z));
+// partial density feature: this lane's 16-byte chunk `c` of every tap (4 of the 4*C4 channels)
+template <int C4>
+__device__ __forceinline__ float density_feature_chunk(const TirField& f, float x, float y, float z, int c) {
+    const float p[3] = {x, y, z};
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int m0 = (i == 2) ? 1 : 0, m1 = (i == 0) ? 1 : 2, vi = 2 - i;
+        const int H = f.grid[m1], W = f.grid[m0], R = f.grid[vi];
+        Tap1 tx = make_tap(p[m0], W), ty = make_tap(p[m1], H), tl = make_tap(p[vi], R);
+        const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
+        const float* pl = f.dplane[i] + 4 * c;
+        const float4 a = ld4(pl + ((size_t)ty.i0 * W + tx.i0) * (C4 * 4));
+        const float4 b = ld4(pl + ((size_t)ty.i0 * W + tx.i1) * (C4 * 4));
+        const float4 cc = ld4(pl + ((size_t)ty.i1 * W + tx.i0) * (C4 * 4));
+        const float4 d = ld4(pl + ((size_t)ty.i1 * W + tx.i1) * (C4 * 4));
+        const float4 e = ld4(f.dline[i] + (size_t)tl.i0 * (C4 * 4) + 4 * c);
+        const float4 g = ld4(f.dline[i] + (size_t)tl.i1 * (C4 * 4) + 4 * c);
+        acc = fmaf(fmaf(d.x, w11, fmaf(cc.x, w10, fmaf(b.x, w01, a.x * w00))), fmaf(g.x, tl.w1, e.x * tl.w0), acc);
+        acc = fmaf(fmaf(d.y, w11, fmaf(cc.y, w10, fmaf(b.y, w01, a.y * w00))), fmaf(g.y, tl.w1, e.y * tl.w0), acc);
+        acc = fmaf(fmaf(d.z, w11, fmaf(cc.z, w10, fmaf(b.z, w01, a.z * w00))), fmaf(g.z, tl.w1, e.z * tl.w0), acc);
+        acc = fmaf(fmaf(d.w, w11, fmaf(cc.w, w10, fmaf(b.w, w01, a.w * w00))), fmaf(g.w, tl.w1, e.w * tl.w0), acc);
+    }
+    return acc;
 }
 
-// inclusive product scan across `width` (32 or 64) consecutive lanes
+// DPP helper: value of lane (l - shift) within a 16-lane row, `ident` where that lane is outside the row
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float ident, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident),
+                                                                 __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+
+// inclusive product scan across `width` (32 or 64) consecutive lanes, VALU only (DPP row shifts +
+// row broadcasts; no LDS round trips): row_shr:1/2/4/8 inside 16-lane rows, row_bcast:15 into rows 1 and 3,
+// row_bcast:31 into rows 2-3 (64-wide only).
 template <int WIDTH>
-__device__ __forceinline__ float scan_prod(float v, int lane_in_group) {
-#pragma unroll
-    for (int d = 1; d < WIDTH; d <<= 1) {
-        float o = __shfl_up(v, d, WIDTH);
-        if (lane_in_group >= d) v *= o;
-    }
+__device__ __forceinline__ float scan_prod(float v, int /*lane_in_group*/) {
+    v *= dpp_f<0x111, 0xf>(1.0f, v);
+    v *= dpp_f<0x112, 0xf>(1.0f, v);
+    v *= dpp_f<0x114, 0xf>(1.0f, v);
+    v *= dpp_f<0x118, 0xf>(1.0f, v);
+    v *= dpp_f<0x142, 0xa>(1.0f, v);
+    if (WIDTH == 64) v *= dpp_f<0x143, 0xc>(1.0f, v);
     return v;
+}
+
+// exclusive version: value of the previous lane of the group (1 for the group's first lane)
+template <int WIDTH>
+__device__ __forceinline__ float shift_up1(float incl, int lane_in_group) {
+    float o = dpp_f<0x138, 0xf>(1.0f, incl);        // wave_shr:1
+    return lane_in_group == 0 ? 1.0f : o;
 }
 
 template <int WIDTH>
@@ -194,6 +213,62 @@ __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
     for (int d = WIDTH / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, WIDTH);
     return v;
+}
+
+// Wave-collective density evaluation.  Every lane brings one sample (valid flag + normalised coordinates);
+// the valid samples of the wave are compacted (ballot rank) through a small per-wave LDS list and gathered
+// with C4 adjacent lanes per sample, each lane owning 16 bytes of every 16*C4-byte tap, so a lane group
+// reads whole runs (the L1/TA handles about one lane-address per clock: one-sample-per-lane costs 18*C4
+// address cycles per sample, this costs 18) and no gather instruction is spent on culled samples.
+// All 64 lanes must call it together.  wl: this wave's LDS scratch, 64*4 floats.
+template <int C4>
+__device__ __forceinline__ float wave_sigma_t(const TirField& f, bool valid, float x, float y, float z, float* wl) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long m = __ballot(valid);
+    const int n = __popcll(m);
+    if (n == 0) return 0.0f;
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (valid) { wl[rank * 4] = x; wl[rank * 4 + 1] = y; wl[rank * 4 + 2] = z; }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int PER = 64 / C4;               // samples per pass
+    const int slot_in = lane / C4, c = lane % C4;
+    for (int base = 0; base < n; base += PER) {
+        const int slot = base + slot_in;
+        float part = 0.0f;
+        if (slot < n) {
+            const float4 p = *reinterpret_cast<const float4*>(wl + slot * 4);
+            part = density_feature_chunk<C4>(f, p.x, p.y, p.z, c);
+        }
+        if (C4 >= 2) part += dpp_f<0xB1, 0xf>(0.0f, part);        // quad_perm [1,0,3,2]
+        if (C4 >= 4) part += dpp_f<0x4E, 0xf>(0.0f, part);        // quad_perm [2,3,0,1]
+        if (C4 >= 8) part += dpp_f<0x141, 0xf>(0.0f, part);       // row_half_mirror (values are quad-uniform)
+        if (slot < n && c == 0) wl[slot * 4 + 3] = part;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float sig = 0.0f;
+    if (valid) sig = feature2density(f, wl[rank * 4 + 3]);
+    __builtin_amdgcn_wave_barrier();
+    return sig;
+}
+
+__device__ __forceinline__ float wave_sigma(const TirField& f, bool valid, float x, float y, float z, float* wl) {
+    switch (f.n_dcomp) {
+        case 16: return wave_sigma_t<4>(f, valid, x, y, z, wl);
+        case 8:  return wave_sigma_t<2>(f, valid, x, y, z, wl);
+        case 32: return wave_sigma_t<8>(f, valid, x, y, z, wl);
+        default: return wave_sigma_t<1>(f, valid, x, y, z, wl);
+    }
+}
+
+// cull of one world-space sample (bbox + occupancy, models/tensorBase_rotated_lights.py:892-897) and its
+// normalised coordinates (:916)
+__device__ __forceinline__ bool sample_valid(const TirField& f, float px, float py, float pz, float& x, float& y, float& z) {
+    x = norm_coord(px, f.aabb_min[0], f.inv_aabb[0]);
+    y = norm_coord(py, f.aabb_min[1], f.inv_aabb[1]);
+    z = norm_coord(pz, f.aabb_min[2], f.inv_aabb[2]);
+    if (!in_bbox(f, px, py, pz)) return false;
+    if (f.occ_nbr != nullptr && !occupancy_hit(f, px, py, pz)) return false;
+    return true;
 }
 
 // linear2srgb_torch after the [0,1] clip (models/relight_utils.py:489-515)

@@ -15,13 +15,19 @@ __global__ void k_pack_plane(const float* __restrict__ src, float* __restrict__ 
     dst[i] = src[(int64_t)c * HW + t];
 }
 
-__global__ void k_pack_occ(const float* __restrict__ vol, uint32_t* __restrict__ bits, int64_t n) {
-    int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t base = w * 32;
-    if (base >= n) return;
+// float 0/1 volume [D][H][W] -> neighbourhood bytes [(D+1)][(H+1)][(W+1)]: cell (z0+1,y0+1,x0+1) holds, in bit
+// dx+2dy+4dz, whether voxel (x0+dx,y0+dy,z0+dz) is inside the grid and occupied (> 0.5)
+__global__ void k_pack_occ(const float* __restrict__ vol, uint8_t* __restrict__ nbr, int W, int H, int D) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)(W + 1) * (H + 1) * (D + 1);
+    if (i >= n) return;
+    const int x0 = (int)(i % (W + 1)) - 1, y0 = (int)((i / (W + 1)) % (H + 1)) - 1, z0 = (int)(i / ((int64_t)(W + 1) * (H + 1))) - 1;
     uint32_t m = 0;
-    for (int b = 0; b < 32 && base + b < n; ++b) m |= (vol[base + b] > 0.5f ? 1u : 0u) << b;
-    bits[w] = m;
+    for (int c = 0; c < 8; ++c) {
+        const int xx = x0 + (c & 1), yy = y0 + ((c >> 1) & 1), zz = z0 + (c >> 2);
+        if (xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D && vol[((int64_t)zz * H + yy) * W + xx] > 0.5f) m |= 1u << c;
+    }
+    nbr[i] = (uint8_t)m;
 }
 
 __global__ void k_pack_basis(const float* __restrict__ w, float* __restrict__ dst, int app_dim, int n_in) {
@@ -49,11 +55,11 @@ extern "C" int tir_pack_plane(const float* src, float* dst, int32_t C, int32_t H
     return TIR_OK;
 }
 
-extern "C" int tir_pack_occupancy(const float* vol, uint32_t* bits, int64_t n, void* stream) {
-    if (!vol || !bits || n <= 0) return TIR_ERR_ARG;
-    int64_t words = (n + 31) / 32;
-    hipLaunchKernelGGL(k_pack_occ, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, tir_stream(stream),
-                       vol, bits, n);
+extern "C" int tir_pack_occupancy(const float* vol, uint8_t* nbr, int32_t W, int32_t H, int32_t D, void* stream) {
+    if (!vol || !nbr || W <= 0 || H <= 0 || D <= 0) return TIR_ERR_ARG;
+    int64_t n = (int64_t)(W + 1) * (H + 1) * (D + 1);
+    hipLaunchKernelGGL(k_pack_occ, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tir_stream(stream),
+                       vol, nbr, W, H, D);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
@@ -116,7 +122,7 @@ k_occupancy_query(TirField f, const float* __restrict__ xyz, uint8_t* __restrict
 }
 
 extern "C" int tir_occupancy_query(const TirField* f, const float* xyz, uint8_t* hit, int64_t n, void* stream) {
-    if (!f || !f->occ_bits || n < 0 || (n > 0 && (!xyz || !hit))) return TIR_ERR_ARG;
+    if (!f || !f->occ_nbr || n < 0 || (n > 0 && (!xyz || !hit))) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
     hipLaunchKernelGGL(k_occupancy_query, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tir_stream(stream),
                        *f, xyz, hit, n);
@@ -221,9 +227,9 @@ extern "C" int tir_density_grad_fwd(const TirField* f, const float* xyz, float* 
 // ------------------------------------------------------------------------------------------------
 template <int C4, bool RAD, bool INTR>
 __global__ void __launch_bounds__(256)
-k_vm_app(TirField f, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
+k_vm_app_valu(TirField f, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
          const int32_t* __restrict__ idx_map, float* __restrict__ rad_feat, float* __restrict__ int_feat,
-         int64_t n) {
+         int out_stride, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     constexpr int CA = C4 * 4;
@@ -276,37 +282,194 @@ k_vm_app(TirField f, const float* __restrict__ xyz, const int32_t* __restrict__ 
             }
         }
     }
-    if (RAD) for (int j = 0; j < AD; ++j) rad_feat[i * AD + j] = accr[j];
-    if (INTR) for (int j = 0; j < AD; ++j) int_feat[i * AD + j] = acci[j];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        if (j < out_stride) {
+            const float vr = (j < 27) ? accr[j < 27 ? j : 0] : 0.f, vi2 = (j < 27) ? acci[j < 27 ? j : 0] : 0.f;
+            if (RAD) rad_feat[i * out_stride + j] = (j < AD) ? vr : 0.f;
+            if (INTR) int_feat[i * out_stride + j] = (j < AD) ? vi2 : 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4 on the matrix cores.  Gather: 4 adjacent lanes share one sample, each owning 16 B of every 64 B
+// run of a tap, so a quad reads whole lines (the L1/TA handles ~1 lane-address per clock: a lane-per-sample
+// gather costs 216 address cycles per sample, this mapping 54).  Contraction: the plane*line*light products
+// of 16 samples go through a per-wave LDS tile [channel][sample] into v_mfma_f32_16x16x4_f32 (exact fp32)
+// against basis_mat^T held in LDS:  F^T[32 x 16] += W^T[32 x 4] * X[4 x 16], one plane group (CA channels)
+// at a time.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define TIR_XLD 17   // padded sample stride of the X tile (bank spread for the quad-strided writes)
+
+template <int C4, bool RAD, bool INTR>
+__global__ void __launch_bounds__(256)
+k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
+              const int32_t* __restrict__ idx_map, float* __restrict__ rad_feat, float* __restrict__ int_feat,
+              int out_stride, int64_t n) {
+    constexpr int CA = C4 * 4;
+    constexpr int NX = (RAD ? 1 : 0) + (INTR ? 1 : 0);
+    extern __shared__ __attribute__((aligned(16))) float lds_app[];
+    float* Wt = lds_app;                                   // [3*CA][32]
+    const int wave = threadIdx.x >> 6, L = threadIdx.x & 63;
+    float* X = lds_app + 3 * CA * 32 + wave * (NX * CA * TIR_XLD);   // [NX][CA][17]
+    for (int i = threadIdx.x * 4; i < 3 * CA * 32; i += 256 * 4)
+        *reinterpret_cast<float4*>(Wt + i) = *reinterpret_cast<const float4*>(f.basis_t + i);
+    __syncthreads();
+    const int j = L >> 2, c = L & 3;          // gather role: sample slot, 16-byte quarter
+    const int jj = L & 15, kq = L >> 4;       // MFMA role: sample column, k quarter / output row quarter
+    const int64_t n_pass = (n + 15) / 16;
+    for (int64_t pass = (int64_t)blockIdx.x * 4 + wave; pass < n_pass; pass += (int64_t)gridDim.x * 4) {
+        const int64_t s = pass * 16 + j;
+        const int64_t sc = s < n ? s : n - 1;
+        const float p[3] = {xyz[3 * sc], xyz[3 * sc + 1], xyz[3 * sc + 2]};
+        const float* lrow = nullptr;
+        if (RAD) {
+            int li = light_idx[idx_map ? idx_map[sc] : sc];
+            li = min(max(li, 0), f.n_lights - 1);
+            lrow = f.light_line + (size_t)li * (3 * CA);
+        }
+        f32x4 accr[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4 acci[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 1
+        for (int k = 0; k < 3; ++k) {
+            const int m0 = (k == 2) ? 1 : 0, m1 = (k == 0) ? 1 : 2, vi = 2 - k;
+            const int H = f.grid[m1], W = f.grid[m0], R = f.grid[vi];
+            const float u = (k == 2) ? p[1] : p[0], v = (k == 0) ? p[1] : p[2], w = (k == 0) ? p[2] : ((k == 1) ? p[1] : p[0]);
+            Tap1 tx = make_tap(u, W), ty = make_tap(v, H), tl = make_tap(w, R);
+            const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
+            const float* pl = f.aplane[k];
+            const float* p00 = pl + ((size_t)ty.i0 * W + tx.i0) * CA;
+            const float* p01 = pl + ((size_t)ty.i0 * W + tx.i1) * CA;
+            const float* p10 = pl + ((size_t)ty.i1 * W + tx.i0) * CA;
+            const float* p11 = pl + ((size_t)ty.i1 * W + tx.i1) * CA;
+            const float* l0 = f.aline[k] + (size_t)tl.i0 * CA;
+            const float* l1 = f.aline[k] + (size_t)tl.i1 * CA;
+#pragma unroll
+            for (int q = 0; q < (C4 + 3) / 4; ++q) {
+                const int ch4 = 4 * q + c;                 // this lane's 16-byte chunk of the 64-byte run q
+                if (ch4 < C4) {
+                    const float4 a = ld4(p00 + 4 * ch4), b = ld4(p01 + 4 * ch4), cc = ld4(p10 + 4 * ch4), d = ld4(p11 + 4 * ch4);
+                    const float4 e = ld4(l0 + 4 * ch4), g = ld4(l1 + 4 * ch4);
+                    float val[4];
+                    val[0] = fmaf(d.x, w11, fmaf(cc.x, w10, fmaf(b.x, w01, a.x * w00))) * fmaf(g.x, tl.w1, e.x * tl.w0);
+                    val[1] = fmaf(d.y, w11, fmaf(cc.y, w10, fmaf(b.y, w01, a.y * w00))) * fmaf(g.y, tl.w1, e.y * tl.w0);
+                    val[2] = fmaf(d.z, w11, fmaf(cc.z, w10, fmaf(b.z, w01, a.z * w00))) * fmaf(g.z, tl.w1, e.z * tl.w0);
+                    val[3] = fmaf(d.w, w11, fmaf(cc.w, w10, fmaf(b.w, w01, a.w * w00))) * fmaf(g.w, tl.w1, e.w * tl.w0);
+                    if (RAD) {
+                        const float4 lr = ld4(lrow + k * CA + 4 * ch4);
+                        float* xr = X + (4 * ch4) * TIR_XLD + j;
+                        xr[0] = val[0] * lr.x; xr[TIR_XLD] = val[1] * lr.y; xr[2 * TIR_XLD] = val[2] * lr.z; xr[3 * TIR_XLD] = val[3] * lr.w;
+                    }
+                    if (INTR) {
+                        const float4 lm = ld4(f.light_mean + k * CA + 4 * ch4);
+                        float* xi = X + ((RAD ? CA : 0) + 4 * ch4) * TIR_XLD + j;
+                        xi[0] = val[0] * lm.x; xi[TIR_XLD] = val[1] * lm.y; xi[2 * TIR_XLD] = val[2] * lm.z; xi[3 * TIR_XLD] = val[3] * lm.w;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();      // LDS ops of one wave complete in order; keep the compiler from reordering
+            const float* wk = Wt + (size_t)(k * CA) * 32;
+#pragma unroll 4
+            for (int t = 0; t < CA / 4; ++t) {
+                const float a0 = wk[(4 * t + kq) * 32 + jj], a1 = wk[(4 * t + kq) * 32 + 16 + jj];
+                if (RAD) {
+                    const float br = X[(4 * t + kq) * TIR_XLD + jj];
+                    accr[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, br, accr[0], 0, 0, 0);
+                    accr[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, br, accr[1], 0, 0, 0);
+                }
+                if (INTR) {
+                    const float bi = X[((RAD ? CA : 0) + 4 * t + kq) * TIR_XLD + jj];
+                    acci[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bi, acci[0], 0, 0, 0);
+                    acci[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bi, acci[1], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // D layout: column = sample jj, rows = kq*4 + reg within each 16-row tile
+        const int64_t so = pass * 16 + jj;
+        if (so < n) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int row0 = mt * 16 + kq * 4;
+                if (RAD) {
+                    float* o = rad_feat + so * out_stride + row0;
+                    if (row0 + 4 <= out_stride && (out_stride & 3) == 0) *reinterpret_cast<float4*>(o) = make_float4(accr[mt][0], accr[mt][1], accr[mt][2], accr[mt][3]);
+                    else for (int r = 0; r < 4; ++r) if (row0 + r < out_stride) o[r] = accr[mt][r];
+                }
+                if (INTR) {
+                    float* o = int_feat + so * out_stride + row0;
+                    if (row0 + 4 <= out_stride && (out_stride & 3) == 0) *reinterpret_cast<float4*>(o) = make_float4(acci[mt][0], acci[mt][1], acci[mt][2], acci[mt][3]);
+                    else for (int r = 0; r < 4; ++r) if (row0 + r < out_stride) o[r] = acci[mt][r];
+                }
+            }
+        }
+    }
 }
 
 template <int C4>
-static void launch_app(const TirField* f, const float* xyz, const int32_t* li, const int32_t* map,
-                       float* rad, float* intr, int64_t n, hipStream_t s) {
-    dim3 g((unsigned)((n + 255) / 256)), b(256);
-    if (rad && intr) hipLaunchKernelGGL((k_vm_app<C4, true, true>), g, b, 0, s, *f, xyz, li, map, rad, intr, n);
-    else if (rad)    hipLaunchKernelGGL((k_vm_app<C4, true, false>), g, b, 0, s, *f, xyz, li, map, rad, intr, n);
-    else             hipLaunchKernelGGL((k_vm_app<C4, false, true>), g, b, 0, s, *f, xyz, li, map, rad, intr, n);
+static int launch_app(const TirField* f, const float* xyz, const int32_t* li, const int32_t* map,
+                      float* rad, float* intr, int stride, int64_t n, hipStream_t s, bool valu) {
+    if (valu) {
+        dim3 g((unsigned)((n + 255) / 256)), b(256);
+        if (rad && intr) hipLaunchKernelGGL((k_vm_app_valu<C4, true, true>), g, b, 0, s, *f, xyz, li, map, rad, intr, stride, n);
+        else if (rad)    hipLaunchKernelGGL((k_vm_app_valu<C4, true, false>), g, b, 0, s, *f, xyz, li, map, rad, intr, stride, n);
+        else             hipLaunchKernelGGL((k_vm_app_valu<C4, false, true>), g, b, 0, s, *f, xyz, li, map, rad, intr, stride, n);
+        return TIR_OK;
+    }
+    constexpr int CA = C4 * 4;
+    const int nx = (rad ? 1 : 0) + (intr ? 1 : 0);
+    const size_t lds = (size_t)(3 * CA * 32 + 4 * nx * CA * TIR_XLD) * sizeof(float);
+    int64_t blocks = (n + 63) / 64;
+    if (blocks > 2048) blocks = 2048;
+    dim3 g((unsigned)blocks), b(256);
+    static bool attr_set = false;
+    if (!attr_set) {   // > 64 KB only for unusually wide fields; harmless otherwise
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_mfma<C4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_mfma<C4, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_mfma<C4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (lds > 160 * 1024) return TIR_ERR_UNSUPPORTED;
+    if (rad && intr) hipLaunchKernelGGL((k_vm_app_mfma<C4, true, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, n);
+    else if (rad)    hipLaunchKernelGGL((k_vm_app_mfma<C4, true, false>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, n);
+    else             hipLaunchKernelGGL((k_vm_app_mfma<C4, false, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, n);
+    return TIR_OK;
 }
 
-extern "C" int tir_vm_app_fwd(const TirField* f, const float* xyz, const int32_t* light_idx,
-                              const int32_t* idx_map, float* rad_feat, float* int_feat,
-                              int64_t n, void* stream) {
+static int app_fwd(const TirField* f, const float* xyz, const int32_t* light_idx, const int32_t* idx_map,
+                   float* rad_feat, float* int_feat, int32_t out_stride, int64_t n, void* stream, bool valu) {
     if (!f) return TIR_ERR_ARG;
     for (int i = 0; i < 3; ++i)
         if (f->grid[i] < 2 || !f->aplane[i] || !f->aline[i]) return TIR_ERR_ARG;
     if (!f->basis_t || !f->light_mean || !f->light_line) return TIR_ERR_ARG;
     if (f->app_dim < 1 || f->app_dim > 27) return TIR_ERR_UNSUPPORTED;
+    if (out_stride < f->app_dim || out_stride > 32) return TIR_ERR_ARG;
     if (n < 0 || (n > 0 && !xyz) || (!rad_feat && !int_feat) || (rad_feat && !light_idx)) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
     hipStream_t s = tir_stream(stream);
+    int rc;
     switch (f->n_acomp) {
-        case 48: launch_app<12>(f, xyz, light_idx, idx_map, rad_feat, int_feat, n, s); break;
-        case 24: launch_app<6>(f, xyz, light_idx, idx_map, rad_feat, int_feat, n, s); break;
-        case 16: launch_app<4>(f, xyz, light_idx, idx_map, rad_feat, int_feat, n, s); break;
-        case 96: launch_app<24>(f, xyz, light_idx, idx_map, rad_feat, int_feat, n, s); break;
+        case 48: rc = launch_app<12>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, n, s, valu); break;
+        case 24: rc = launch_app<6>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, n, s, valu); break;
+        case 16: rc = launch_app<4>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, n, s, valu); break;
+        case 96: rc = launch_app<24>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, n, s, valu); break;
         default: return TIR_ERR_UNSUPPORTED;
     }
+    if (rc) return rc;
     TIR_CHECK_LAUNCH();
     return TIR_OK;
+}
+
+extern "C" int tir_vm_app_fwd(const TirField* f, const float* xyz, const int32_t* light_idx,
+                              const int32_t* idx_map, float* rad_feat, float* int_feat, int32_t out_stride,
+                              int64_t n, void* stream) {
+    return app_fwd(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, n, stream, false);
+}
+
+extern "C" int tir_vm_app_fwd_valu(const TirField* f, const float* xyz, const int32_t* light_idx,
+                                   const int32_t* idx_map, float* rad_feat, float* int_feat, int32_t out_stride,
+                                   int64_t n, void* stream) {
+    return app_fwd(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, n, stream, true);
 }

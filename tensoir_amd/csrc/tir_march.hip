@@ -49,6 +49,8 @@ k_march_primary(TirField f, const float* __restrict__ rays, const float* __restr
     const bool hj = ray_jitter != nullptr;
     const float jit = hj ? ray_jitter[ray] : 0.0f;
 
+    __shared__ __attribute__((aligned(16))) float wl_all[4][256];
+    float* wl = wl_all[threadIdx.x >> 6];
     float T = 1.0f;          // transmittance before the current step (wave-uniform)
     float acc = 0.0f, depth = 0.0f;
     int cnt = 0;
@@ -56,14 +58,18 @@ k_march_primary(TirField f, const float* __restrict__ rays, const float* __restr
     unsigned n_gather = 0;
     for (; k0 < S; k0 += 64) {
         const int k = k0 + lane;
-        float w = 0.0f, z = 0.0f, v = 1.0f;
-        bool gathered = false;
+        float z = 0.0f, x = 0.f, y = 0.f, zz = 0.f;
+        bool valid = false;
         if (k < S) {
             z = sample_z(f, rs.t_min, k, jit, hj);
             float px = add_rn(rs.o[0], mul_rn(rs.d[0], z));
             float py = add_rn(rs.o[1], mul_rn(rs.d[1], z));
             float pz = add_rn(rs.o[2], mul_rn(rs.d[2], z));
-            float sigma = sigma_at(f, px, py, pz, gathered);
+            valid = sample_valid(f, px, py, pz, x, y, zz);
+        }
+        const float sigma = wave_sigma(f, valid, x, y, zz, wl);
+        float w = 0.0f, v = 1.0f;
+        if (k < S) {
             // dists: z[k+1]-z[k], last 0 (:887); raw2alpha (:21-28) with dist * distance_scale (:921)
             float dist = (k + 1 < S) ? sub_rn(sample_z(f, rs.t_min, k + 1, jit, hj), z) : 0.0f;
             float alpha = 1.0f - expf(-sigma * mul_rn(dist, f.distance_scale));
@@ -71,14 +77,13 @@ k_march_primary(TirField f, const float* __restrict__ rays, const float* __restr
             w = alpha;   // multiplied by the exclusive transmittance below
         }
         float incl = scan_prod<64>(v, lane);
-        float excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.0f;
+        float excl = shift_up1<64>(incl, lane);
         w = w * (T * excl);
         if (k < S) weight[(size_t)ray * S + k] = w;
         acc += w;
         depth = fmaf(w, z, depth);
         cnt += __popcll(__ballot(w > f.weight_thres));
-        if (stats) n_gather += __popcll(__ballot(gathered));
+        if (stats) n_gather += __popcll(__ballot(valid));
         T = T * __shfl(incl, 63, 64);
         if (T < t_stop) { k0 += 64; break; }
     }
@@ -308,7 +313,10 @@ extern "C" int tir_composite_primary(const float* rays, const int32_t* offsets, 
 // and written contiguously in sample order.
 // ------------------------------------------------------------------------------------------------
 #define TIR_SEC_MAX_SAMPLES 256
+#define TIR_SEC_RPB 32     // rays per block: 4 groups of 8 half-waves; ONE record reservation (atomic) per block
 
+// LDS layout (floats): [z table n_sample] [wave scratch 4 x 256] [ints: cnt[32], kstop[32], base[32]]
+//                      [weights 32 x n_sample (only when records are requested)]
 __global__ void __launch_bounds__(256)
 k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* __restrict__ org_map,
                   const float* __restrict__ dirs, const int32_t* __restrict__ dir_map,
@@ -318,94 +326,141 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
                   int32_t* __restrict__ rec_ray, float* __restrict__ rec_w, float* __restrict__ rec_xyz,
                   int32_t* __restrict__ ray_rec_off, int32_t* __restrict__ ray_rec_cnt,
                   unsigned long long* __restrict__ stats) {
-    extern __shared__ float w_lds[];   // [8 half-waves][n_sample]
+    extern __shared__ __attribute__((aligned(16))) float w_lds[];
     const int hl = threadIdx.x & 31;                 // lane within the half-wave
     const int hw = threadIdx.x >> 5;                 // half-wave within the block
-    const int64_t ray = (int64_t)blockIdx.x * 8 + hw;
-    if (ray >= n_rays) return;
+    const int nz = (n_sample + 3) & ~3;
+    float* zt = w_lds;
+    float* ws = w_lds + nz + (threadIdx.x >> 6) * 256;            // this wave's gather scratch (16-B aligned)
+    int* s_cnt = reinterpret_cast<int*>(w_lds + nz + 4 * 256);
+    int* s_kstop = s_cnt + TIR_SEC_RPB;
+    int* s_base = s_kstop + TIR_SEC_RPB;
+    float* w_all = w_lds + nz + 4 * 256 + 3 * TIR_SEC_RPB;        // [32][n_sample]
+    for (int i = threadIdx.x; i < n_sample; i += blockDim.x) zt[i] = z_vals[i];
+    __syncthreads();
     const bool want_rec = rec_counter != nullptr;
-    if (active && !active[ray]) {
-        if (hl == 0) {
-            if (vis) vis[ray] = 0.0f;
-            if (one_minus_acc) one_minus_acc[ray] = 0.0f;
-            if (want_rec) { ray_rec_off[ray] = 0; ray_rec_cnt[ray] = 0; }
-        }
-        return;
-    }
-    const size_t oi = org_map ? (size_t)org_map[ray] : (size_t)ray;
-    const size_t di = dir_map ? (size_t)dir_map[ray] : (size_t)ray;
-    const float o[3] = {origins[3 * oi], origins[3 * oi + 1], origins[3 * oi + 2]};
-    const float d[3] = {dirs[3 * di], dirs[3 * di + 1], dirs[3 * di + 2]};
-    float* wl = w_lds + (size_t)hw * n_sample;
-
-    float T = 1.0f, acc = 0.0f;
-    int cnt = 0;
-    int k0 = 0;
     unsigned n_gather = 0;
-    for (; k0 < n_sample; k0 += 32) {
-        const int k = k0 + hl;
-        float w = 0.0f, v = 1.0f;
-        bool gathered = false;
-        if (k < n_sample) {
-            const float z = z_vals[k];
-            float px = add_rn(o[0], mul_rn(d[0], z));
-            float py = add_rn(o[1], mul_rn(d[1], z));
-            float pz = add_rn(o[2], mul_rn(d[2], z));
-            float sigma = sigma_at(f, px, py, pz, gathered);
-            float dist = (k + 1 < n_sample) ? sub_rn(z_vals[k + 1], z) : 0.0f;
-            float alpha = 1.0f - expf(-sigma * mul_rn(dist, f.distance_scale));
-            v = add_rn(sub_rn(1.0f, alpha), 1e-10f);
-            w = alpha;
-        }
-        float incl = scan_prod<32>(v, hl);
-        float excl = __shfl_up(incl, 1, 32);
-        if (hl == 0) excl = 1.0f;
-        w = w * (T * excl);
-        if (want_rec && k < n_sample) wl[k] = w;
-        acc += w;
-        const bool keep = w > f.weight_thres;
-        unsigned long long m = __ballot(keep);
-        cnt += __popc((unsigned)(m >> ((threadIdx.x & 32) ? 32 : 0)));
-        if (stats) n_gather += __popc((unsigned)(__ballot(gathered) >> ((threadIdx.x & 32) ? 32 : 0)));
-        T = T * __shfl(incl, 31, 32);
-        if (T < t_stop) { k0 += 32; break; }
-    }
-    const int k_end = min(k0, n_sample);   // samples [k_end, n_sample) have zero weight
-    acc = group_sum<32>(acc);
-    if (hl == 0) {
-        if (vis) vis[ray] = T;
-        if (one_minus_acc) one_minus_acc[ray] = 1.0f - acc;
-        if (stats) atomicAdd(stats, (unsigned long long)n_gather);
-    }
-    if (!want_rec) return;
-    int base = 0;
-    if (hl == 0) {
-        if (cnt > 0) base = atomicAdd(rec_counter, cnt);
-        bool fits = (int64_t)base + cnt <= rec_cap;
-        ray_rec_off[ray] = base;
-        ray_rec_cnt[ray] = (cnt > 0 && fits) ? cnt : 0;
-        if (!fits) base = -1;
-    }
-    base = __shfl(base, 0, 32);
-    if (cnt == 0 || base < 0) return;
-    for (int q0 = 0; q0 < k_end; q0 += 32) {
-        const int k = q0 + hl;
-        float w = (k < k_end) ? wl[k] : 0.0f;
-        const bool keep = w > f.weight_thres;
-        unsigned long long m = __ballot(keep);
-        unsigned hm = (unsigned)(m >> ((threadIdx.x & 32) ? 32 : 0));
-        if (keep) {
-            int slot = base + __popc(hm & ((1u << hl) - 1u));
-            const float z = z_vals[k];
-            rec_ray[slot] = (int32_t)ray;
-            rec_w[slot] = w;
+
+    for (int g = 0; g < TIR_SEC_RPB / 8; ++g) {
+        const int rl = g * 8 + hw;
+        const int64_t ray = (int64_t)blockIdx.x * TIR_SEC_RPB + rl;
+        const bool in_range = ray < n_rays;
+        const bool live = in_range && !(active && !active[ray]);
+        int cnt = 0, k_stop = n_sample;    // k_stop: first sample this ray did not march (zero weight from there)
+        if (__any(live)) {
+            float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+            if (live) {
+                const size_t oi = org_map ? (size_t)org_map[ray] : (size_t)ray;
+                const size_t di = dir_map ? (size_t)dir_map[ray] : (size_t)ray;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                float p = add_rn(o[a], mul_rn(d[a], z));
-                rec_xyz[3 * (size_t)slot + a] = norm_coord(p, f.aabb_min[a], f.inv_aabb[a]);
+                for (int a = 0; a < 3; ++a) { o[a] = origins[3 * oi + a]; d[a] = dirs[3 * di + a]; }
+            }
+            float* wl = w_all + (size_t)rl * n_sample;
+            float T = 1.0f, acc = 0.0f;
+            bool done = !live;                 // per half-wave (uniform inside a half)
+            for (int k0 = 0; k0 < n_sample; k0 += 32) {   // wave-uniform loop: the gather below is wave-collective
+                const int k = k0 + hl;
+                float z = 0.f, x = 0.f, y = 0.f, zz = 0.f;
+                bool valid = false;
+                const bool on = !done && k < n_sample;
+                if (on) {
+                    z = zt[k];
+                    float px = add_rn(o[0], mul_rn(d[0], z));
+                    float py = add_rn(o[1], mul_rn(d[1], z));
+                    float pz = add_rn(o[2], mul_rn(d[2], z));
+                    valid = sample_valid(f, px, py, pz, x, y, zz);
+                }
+                const float sigma = wave_sigma(f, valid, x, y, zz, ws);
+                float w = 0.0f, v = 1.0f;
+                if (on) {
+                    float dist = (k + 1 < n_sample) ? sub_rn(zt[k + 1], z) : 0.0f;
+                    float alpha = 1.0f - expf(-sigma * mul_rn(dist, f.distance_scale));
+                    v = add_rn(sub_rn(1.0f, alpha), 1e-10f);
+                    w = alpha;
+                }
+                float incl = scan_prod<32>(v, hl);
+                float excl = shift_up1<32>(incl, hl);
+                w = w * (T * excl);
+                if (want_rec && on) wl[k] = w;
+                acc += w;
+                const unsigned long long m = __ballot(w > f.weight_thres);
+                cnt += __popc((unsigned)(m >> ((threadIdx.x & 32) ? 32 : 0)));
+                if (stats) n_gather += __popc((unsigned)(__ballot(valid) >> ((threadIdx.x & 32) ? 32 : 0)));
+                T = T * __shfl(incl, 31, 32);
+                if (!done && T < t_stop) { done = true; k_stop = min(k0 + 32, n_sample); }
+                if (__all(done)) break;
+            }
+            acc = group_sum<32>(acc);
+            if (live && hl == 0) {
+                if (vis) vis[ray] = T;
+                if (one_minus_acc) one_minus_acc[ray] = 1.0f - acc;
             }
         }
-        base += __popc(hm);
+        if (hl == 0) {
+            if (in_range && !live) {
+                if (vis) vis[ray] = 0.0f;
+                if (one_minus_acc) one_minus_acc[ray] = 0.0f;
+            }
+            s_cnt[rl] = live ? cnt : 0;
+            s_kstop[rl] = k_stop;
+        }
+    }
+    if (stats && hl == 0 && n_gather) atomicAdd(stats, (unsigned long long)n_gather);
+    if (!want_rec) return;
+    __syncthreads();
+    // one reservation for the block's 32 rays: inclusive scan of the counts in the first half-wave
+    if (threadIdx.x < 32) {
+        const int c = s_cnt[hl];
+        int incl = c;
+#pragma unroll
+        for (int dd = 1; dd < 32; dd <<= 1) {
+            int oth = __shfl_up(incl, dd, 32);
+            if (hl >= dd) incl += oth;
+        }
+        const int total = __shfl(incl, 31, 32);
+        int base = 0;
+        if (hl == 31 && total > 0) base = atomicAdd(rec_counter, total);
+        base = __shfl(base, 31, 32);
+        const bool fits = (int64_t)base + total <= rec_cap;
+        const int64_t ray = (int64_t)blockIdx.x * TIR_SEC_RPB + hl;
+        if (ray < n_rays) {
+            ray_rec_off[ray] = base + incl - c;
+            ray_rec_cnt[ray] = fits ? c : 0;
+        }
+        s_base[hl] = (fits && c > 0) ? base + incl - c : -1;
+    }
+    __syncthreads();
+    for (int g = 0; g < TIR_SEC_RPB / 8; ++g) {
+        const int rl = g * 8 + hw;
+        int base = s_base[rl];
+        if (base < 0) continue;                    // uniform inside the half-wave
+        const int64_t ray = (int64_t)blockIdx.x * TIR_SEC_RPB + rl;
+        const size_t oi = org_map ? (size_t)org_map[ray] : (size_t)ray;
+        const size_t di = dir_map ? (size_t)dir_map[ray] : (size_t)ray;
+        float o[3], d[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { o[a] = origins[3 * oi + a]; d[a] = dirs[3 * di + a]; }
+        const float* wl = w_all + (size_t)rl * n_sample;
+        const int k_end = s_kstop[rl];
+        const unsigned half_shift = (threadIdx.x & 32) ? 32 : 0;
+        for (int q0 = 0; q0 < k_end; q0 += 32) {
+            const int k = q0 + hl;
+            float w = (k < k_end) ? wl[k] : 0.0f;
+            const bool keep = w > f.weight_thres;
+            const unsigned hm = (unsigned)(__ballot(keep) >> half_shift);
+            if (keep) {
+                const int slot = base + __popc(hm & ((1u << hl) - 1u));
+                const float z = zt[k];
+                rec_ray[slot] = (int32_t)ray;
+                rec_w[slot] = w;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    float p = add_rn(o[a], mul_rn(d[a], z));
+                    rec_xyz[3 * (size_t)slot + a] = norm_coord(p, f.aabb_min[a], f.inv_aabb[a]);
+                }
+            }
+            base += __popc(hm);
+        }
     }
 }
 
@@ -423,8 +478,9 @@ extern "C" int tir_march_secondary_fwd(const TirField* f, const float* origins, 
     if (rec_counter && (!rec_ray || !rec_w || !rec_xyz || !ray_rec_off || !ray_rec_cnt || rec_cap < 0)) return TIR_ERR_ARG;
     if (n_rays >= (int64_t)1 << 31) return TIR_ERR_UNSUPPORTED;
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
-    size_t lds = rec_counter ? (size_t)8 * n_sample * sizeof(float) : 0;
-    hipLaunchKernelGGL(k_march_secondary, dim3((unsigned)((n_rays + 7) / 8)), dim3(256), lds, tir_stream(stream),
+    size_t lds = ((size_t)((n_sample + 3) & ~3) + 4 * 256 + 3 * TIR_SEC_RPB +
+                  (rec_counter ? (size_t)TIR_SEC_RPB * n_sample : 0)) * sizeof(float);
+    hipLaunchKernelGGL(k_march_secondary, dim3((unsigned)((n_rays + TIR_SEC_RPB - 1) / TIR_SEC_RPB)), dim3(256), lds, tir_stream(stream),
                        *f, origins, org_map, dirs, dir_map, active, n_rays, n_sample, z_vals, t_stop, vis,
                        one_minus_acc, rec_counter, rec_cap, rec_ray, rec_w, rec_xyz, ray_rec_off, ray_rec_cnt, stats);
     TIR_CHECK_LAUNCH();

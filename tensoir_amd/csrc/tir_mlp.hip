@@ -39,7 +39,19 @@ constexpr int OFF_RW1 = OFF_RB0 + HID;          // [128][128]
 constexpr int OFF_RB1 = OFF_RW1 + HID * HID;
 constexpr int OFF_RW2 = OFF_RB1 + HID;          // [4][128]
 constexpr int OFF_RB2 = OFF_RW2 + 4 * HID;
-constexpr int TOTAL_FLOATS = OFF_RB2 + 4;
+constexpr int FP32_TOTAL = OFF_RB2 + 4;
+// split-bf16 image (one contiguous LDS image): fp32 header [b0p 128 | b1p 128 | W2p 512 | b2 4 | pad 4]
+// then bf16 operand tiles  W0hi | W0lo | W1hi | W1lo, each [kb][h][mt][i][8]  (8 bf16 = one ds_read_b128)
+constexpr int KB0 = (HALF + 7) / 8;             // 10 k-blocks of 16 for layer 1 (75 -> 80 per half)
+constexpr int KB1 = 64 / 8;                     // 8 k-blocks for layer 2
+constexpr int BH_B0 = 0, BH_B1 = 128, BH_W2 = 256, BH_B2 = 768, BH_FLOATS = 776;
+constexpr int BW0_ELEMS = KB0 * 2 * 4 * 32 * 8; // 20480 bf16
+constexpr int BW1_ELEMS = KB1 * 2 * 4 * 32 * 8; // 16384 bf16
+constexpr int BF_BYTES = BH_FLOATS * 4 + (2 * BW0_ELEMS + 2 * BW1_ELEMS) * 2;   // 150,560 B
+constexpr int BF_FLOATS = BF_BYTES / 4;
+constexpr int OFF_BF = FP32_TOTAL;              // float offset of the bf16 image inside the blob
+constexpr int TOTAL_FLOATS = OFF_BF + BF_FLOATS;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // reference input index (models/tensorBase_rotated_lights.py:137-142, :12-17) handled at step t by half h
 __host__ __device__ inline int kperm(int t, int h) {
@@ -91,7 +103,36 @@ __global__ void k_pack_mlp(const float* __restrict__ w0, const float* __restrict
     else if (i < OFF_RB1) v = w1[i - OFF_RW1];
     else if (i < OFF_RW2) v = b1[i - OFF_RB1];
     else if (i < OFF_RB2) { int j = i - OFF_RW2; v = (j / HID < out_dim) ? w2[j] : 0.0f; }
-    else { int o = i - OFF_RB2; v = (o < out_dim) ? b2[o] : 0.0f; }
+    else if (i < FP32_TOTAL) { int o = i - OFF_RB2; v = (o < out_dim) ? b2[o] : 0.0f; }
+    else {
+        int j = i - OFF_BF;                     // float slot inside the bf16 image
+        if (j < BH_FLOATS) {
+            if (j < BH_B1) v = b0[unit_of(j % 64, j / 64)];
+            else if (j < BH_W2) { int q = j - BH_B1; v = b1[unit_of(q % 64, q / 64)]; }
+            else if (j < BH_B2) { int q = j - BH_W2, h = q / 256, u = (q % 256) / 4, o = q % 4; v = (o < out_dim) ? w2[o * HID + unit_of(u, h)] : 0.0f; }
+            else { int o = j - BH_B2; v = (o < out_dim) ? b2[o] : 0.0f; }
+        } else {                                // two bf16 per float slot
+            unsigned short hw[2];
+            for (int t = 0; t < 2; ++t) {
+                int e_all = (j - BH_FLOATS) * 2 + t;
+                int sec, idx;
+                if (e_all < BW0_ELEMS) { sec = 0; idx = e_all; }
+                else if (e_all < 2 * BW0_ELEMS) { sec = 1; idx = e_all - BW0_ELEMS; }
+                else if (e_all < 2 * BW0_ELEMS + BW1_ELEMS) { sec = 2; idx = e_all - 2 * BW0_ELEMS; }
+                else { sec = 3; idx = e_all - 2 * BW0_ELEMS - BW1_ELEMS; }
+                int e = idx % 8, ii = (idx / 8) % 32, mt = (idx / 256) % 4, h = (idx / 1024) % 2, kb = idx / 2048;
+                int kk = kb * 8 + e;
+                float wv;
+                if (sec < 2) wv = (kk < HALF) ? w0[(mt * 32 + ii) * IN + kperm(kk, h)] : 0.0f;
+                else wv = w1[(mt * 32 + ii) * HID + unit_of(kk, h)];
+                __bf16 hi = (__bf16)wv;
+                __bf16 r = (sec & 1) ? (__bf16)(wv - (float)hi) : hi;
+                hw[t] = __builtin_bit_cast(unsigned short, r);
+            }
+            unsigned int packed2 = (unsigned int)hw[0] | ((unsigned int)hw[1] << 16);
+            v = __builtin_bit_cast(float, packed2);
+        }
+    }
     p[i] = v;
 }
 
@@ -103,7 +144,7 @@ __device__ __forceinline__ float act_out(float x, int act) {
 // MFMA kernel: 512 threads = 8 waves, 32 samples per wave, persistent over 256-sample tiles
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(512)
-k_mlp_mfma(const float* __restrict__ packed, const float* __restrict__ feat, const float* __restrict__ aux,
+k_mlp_mfma(const float* __restrict__ packed, const float* __restrict__ feat, int fstride, const float* __restrict__ aux,
            const int32_t* __restrict__ aux_map, float* __restrict__ out, int64_t n, int out_dim, int act) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     for (int i = threadIdx.x * 4; i < MFMA_FLOATS; i += 512 * 4)
@@ -120,7 +161,7 @@ k_mlp_mfma(const float* __restrict__ packed, const float* __restrict__ feat, con
         float x[HALF];
         {
             float ft[F];
-            const float* fr = feat + s * F;
+            const float* fr = feat + s * fstride;
 #pragma unroll
             for (int d = 0; d < F; ++d) ft[d] = fr[d];
             if (h == 0) {
@@ -218,16 +259,218 @@ k_mlp_mfma(const float* __restrict__ packed, const float* __restrict__ feat, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// split-bf16 kernel (v_mfma_f32_32x32x16_bf16): x = hi + lo in bf16, products hi*hi + hi*lo + lo*hi
+// accumulated in fp32 (NPROD = 3, ~1e-6 abs error on the outputs), or hi*hi only (NPROD = 1, fast mode).
+// Same wave/lane decomposition as the fp32 kernel; a lane supplies 8 consecutive k per MFMA.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        hi[e] = (__bf16)v[e];
+        lo[e] = (__bf16)(v[e] - (float)hi[e]);
+    }
+}
+
+// sin and cos of x with one shared Cody-Waite reduction and two minimax polynomials (<= 2 ulp for
+// |x| < 8192; larger arguments take the library path).  Branch-free, so both lane halves of a wave run the
+// same instruction stream; used by the split-bf16 decoders, whose own arithmetic error (~1e-5) dwarfs it.
+__device__ __forceinline__ void fast_sincos(float x, float& s, float& c) {
+    if (__builtin_expect(!(fabsf(x) < 8192.0f), 0)) { s = sinf(x); c = cosf(x); return; }
+    const float n = rintf(x * 0.636619772367581343f);
+    float r = fmaf(n, -1.57079637050628662109375f, x);
+    r = fmaf(n, 4.37113900018624283e-8f, r);
+    const float z = r * r;
+    const float sp = fmaf(r * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+    const float cp = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                          fmaf(z, -0.5f, 1.0f));
+    const int q = (int)n;
+    const float ss = (q & 1) ? cp : sp;
+    const float cc = (q & 1) ? sp : cp;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+}
+
+// This lane-half's positional encodings of value v: half 0 -> {sin v, sin 2v}, half 1 -> {cos v, cos 2v}
+// (double-angle identities: sin 2v = 2 s c, cos 2v = 1 - 2 s^2).
+__device__ __forceinline__ void pe_pair(float v, int h, float& p1, float& p2) {
+    float s, c;
+    fast_sincos(v, s, c);
+    p1 = h ? c : s;
+    p2 = h ? fmaf(-2.0f * s, s, 1.0f) : 2.0f * s * c;
+}
+
+struct AuxPE { float s[3], c[3], s2[3], c2[3]; };   // sin/cos of aux and of 2*aux
+
+// input t (>= NPF) of the tail for lane half h: half 0 -> feat[0..R0), half 1 -> feat[R0..F), aux, sin/cos PE(aux)
+template <int T>
+__device__ __forceinline__ float tail_input(const float (&ft)[F], const float (&ax)[3], const AuxPE& ap, int h) {
+    constexpr int q = T - NPF;
+    float a = 0.0f, b = 0.0f;
+    if constexpr (q < R0) a = ft[q];
+    if constexpr (q < F - R0) b = ft[R0 + q];
+    else if constexpr (q < F - R0 + 3) b = ax[q - (F - R0)];
+    else if constexpr (q < F - R0 + 3 + 3 * PE) {
+        constexpr int u = q - (F - R0 + 3);
+        b = (u & 1) ? ap.s2[u >> 1] : ap.s[u >> 1];
+    } else if constexpr (q < F - R0 + 3 + 6 * PE) {
+        constexpr int u = q - (F - R0 + 3 + 3 * PE);
+        b = (u & 1) ? ap.c2[u >> 1] : ap.c[u >> 1];
+    }
+    return h ? b : a;
+}
+
+template <int KB, int E>
+__device__ __forceinline__ void build_pair(const float (&ft)[F], const float (&ax)[3], const AuxPE& ap, int h, float (&v)[8]) {
+    constexpr int t = KB * 8 + E;
+    if constexpr (t + 1 < NPF) pe_pair(ft[t >> 1], h, v[E], v[E + 1]);
+    else {
+        v[E] = tail_input<t>(ft, ax, ap, h);
+        v[E + 1] = tail_input<t + 1>(ft, ax, ap, h);
+    }
+}
+
+// Build this lane-half's 80 padded inputs one k-block (8 values) at a time and split each block to bf16
+// hi/lo at once; template recursion keeps every array index a compile-time constant.
+template <int KB>
+__device__ __forceinline__ void build_inputs(const float (&ft)[F], const float (&ax)[3], const AuxPE& ap, int h,
+                                             bf16x8 (&xh)[KB0], bf16x8 (&xl)[KB0]) {
+    float v[8];
+    build_pair<KB, 0>(ft, ax, ap, h, v);
+    build_pair<KB, 2>(ft, ax, ap, h, v);
+    build_pair<KB, 4>(ft, ax, ap, h, v);
+    build_pair<KB, 6>(ft, ax, ap, h, v);
+    split8(v, xh[KB], xl[KB]);
+    if constexpr (KB + 1 < KB0) build_inputs<KB + 1>(ft, ax, ap, h, xh, xl);
+}
+
+template <int NPROD>
+__global__ void __launch_bounds__(512)
+k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int fstride, const float* __restrict__ aux,
+           const int32_t* __restrict__ aux_map, float* __restrict__ out, int64_t n, int out_dim, int act) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {
+        const float* src = packed + OFF_BF;
+        for (int i = threadIdx.x * 4; i < BF_FLOATS; i += 512 * 4)
+            *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(src + i);
+    }
+    __syncthreads();
+    const bf16x8* w0hi = reinterpret_cast<const bf16x8*>(lds + BH_FLOATS);
+    const bf16x8* w0lo = w0hi + BW0_ELEMS / 8;
+    const bf16x8* w1hi = w0lo + BW0_ELEMS / 8;
+    const bf16x8* w1lo = w1hi + BW1_ELEMS / 8;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sl = lane & 31, h = lane >> 5;
+    const int64_t n_tiles = (n + 255) / 256;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t s_raw = tile * 256 + wave * 32 + sl;
+        const int64_t s = s_raw < n ? s_raw : n - 1;
+        bf16x8 xh[KB0], xl[KB0];
+        {
+            float ft[F];
+            const float* fr = feat + s * fstride;
+#pragma unroll
+            for (int d = 0; d < F; ++d) ft[d] = fr[d];
+            const int64_t ai = aux_map ? (int64_t)aux_map[s] : s;
+            const float ax[3] = {aux[3 * ai], aux[3 * ai + 1], aux[3 * ai + 2]};
+            AuxPE ap;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                fast_sincos(ax[d], ap.s[d], ap.c[d]);
+                ap.s2[d] = 2.0f * ap.s[d] * ap.c[d];
+                ap.c2[d] = fmaf(-2.0f * ap.s[d], ap.s[d], 1.0f);
+            }
+            build_inputs<0>(ft, ax, ap, h, xh, xl);
+        }
+        // ---- layer 1 ----
+        f32x16 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const float* bp = lds + BH_B0 + (h * 4 + mt) * 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = bp[r];
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB0; ++kb) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int wi = ((kb * 2 + h) * 4 + mt) * 32 + sl;
+                const bf16x8 ah = w0hi[wi];
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[kb], acc[mt], 0, 0, 0);
+                if (NPROD == 3) {
+                    const bf16x8 al = w0lo[wi];
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[kb], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[kb], acc[mt], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- layer 2 ----
+        bf16x8 hh[KB1], hl[KB1];
+#pragma unroll
+        for (int kb = 0; kb < KB1; ++kb) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const int q = kb * 8 + e; v[e] = fmaxf(acc[q >> 4][q & 15], 0.0f); }
+            split8(v, hh[kb], hl[kb]);
+        }
+        f32x16 acc2[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const float* bp = lds + BH_B1 + (h * 4 + mt) * 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[mt][r] = bp[r];
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB1; ++kb) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int wi = ((kb * 2 + h) * 4 + mt) * 32 + sl;
+                const bf16x8 ah = w1hi[wi];
+                acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, hh[kb], acc2[mt], 0, 0, 0);
+                if (NPROD == 3) {
+                    const bf16x8 al = w1lo[wi];
+                    acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, hh[kb], acc2[mt], 0, 0, 0);
+                    acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, hl[kb], acc2[mt], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- layer 3 (fp32 VALU) ----
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+        {
+            const float* wp = lds + BH_W2 + h * 256;
+#pragma unroll
+            for (int q = 0; q < 64; ++q) {
+                const float hv = fmaxf(acc2[q >> 4][q & 15], 0.0f);
+                const float4 w = *reinterpret_cast<const float4*>(wp + q * 4);
+                o0 = fmaf(hv, w.x, o0); o1 = fmaf(hv, w.y, o1); o2 = fmaf(hv, w.z, o2); o3 = fmaf(hv, w.w, o3);
+            }
+        }
+        o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64);
+        o2 += __shfl_xor(o2, 32, 64); o3 += __shfl_xor(o3, 32, 64);
+        if (h == 0 && s_raw < n) {
+            const float* b2 = lds + BH_B2;
+            float* op = out + s_raw * out_dim;
+            op[0] = act_out(o0 + b2[0], act);
+            if (out_dim > 1) op[1] = act_out(o1 + b2[1], act);
+            if (out_dim > 2) op[2] = act_out(o2 + b2[2], act);
+            if (out_dim > 3) op[3] = act_out(o3 + b2[3], act);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // plain VALU kernel (one sample per lane, weights by wave-uniform scalar loads): cross-check only
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
-k_mlp_valu(const float* __restrict__ packed, const float* __restrict__ feat, const float* __restrict__ aux,
+k_mlp_valu(const float* __restrict__ packed, const float* __restrict__ feat, int fstride, const float* __restrict__ aux,
            const int32_t* __restrict__ aux_map, float* __restrict__ out, int64_t n, int out_dim, int act) {
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     float x[IN];
     const int64_t ai = aux_map ? (int64_t)aux_map[s] : s;
-    for (int d = 0; d < F; ++d) x[d] = feat[s * F + d];
+    for (int d = 0; d < F; ++d) x[d] = feat[s * fstride + d];
     for (int d = 0; d < 3; ++d) x[F + d] = aux[3 * ai + d];
     for (int d = 0; d < F; ++d)
         for (int f = 0; f < PE; ++f) {
@@ -287,11 +530,11 @@ extern "C" int tir_pack_mlp(const float* w0, const float* b0, const float* w1, c
     return TIR_OK;
 }
 
-extern "C" int tir_mlp_fwd(const TirMlp* m, const float* feat, const float* aux, const int32_t* aux_map,
+extern "C" int tir_mlp_fwd(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map,
                            float* out, int64_t n, void* stream) {
     int rc = check_mlp(m);
     if (rc) return rc;
-    if (n < 0 || (n > 0 && (!feat || !aux || !out))) return TIR_ERR_ARG;
+    if (n < 0 || feat_stride < F || (n > 0 && (!feat || !aux || !out))) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
     static bool attr_set = false;
     const size_t lds = (size_t)MFMA_FLOATS * sizeof(float);
@@ -303,20 +546,53 @@ extern "C" int tir_mlp_fwd(const TirMlp* m, const float* feat, const float* aux,
     }
     int64_t tiles = (n + 255) / 256;
     unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
-    hipLaunchKernelGGL(k_mlp_mfma, dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, aux,
+    hipLaunchKernelGGL(k_mlp_mfma, dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, feat_stride, aux,
                        aux_map, out, n, m->out_dim, m->act);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
 
-extern "C" int tir_mlp_fwd_valu(const TirMlp* m, const float* feat, const float* aux, const int32_t* aux_map,
+template <int NPROD>
+static int launch_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map,
+                       float* out, int64_t n, void* stream) {
+    int rc = check_mlp(m);
+    if (rc) return rc;
+    if (n < 0 || feat_stride < F || (n > 0 && (!feat || !aux || !out))) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    static bool attr_set = false;
+    const size_t lds = (size_t)BF_BYTES;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bf16<NPROD>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+        attr_set = true;
+    }
+    int64_t tiles = (n + 255) / 256;
+    unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    hipLaunchKernelGGL(k_mlp_bf16<NPROD>, dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, feat_stride, aux,
+                       aux_map, out, n, m->out_dim, m->act);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map,
+                                  float* out, int64_t n, void* stream) {
+    return launch_bf16<3>(m, feat, feat_stride, aux, aux_map, out, n, stream);
+}
+
+extern "C" int tir_mlp_fwd_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map,
+                                float* out, int64_t n, void* stream) {
+    return launch_bf16<1>(m, feat, feat_stride, aux, aux_map, out, n, stream);
+}
+
+extern "C" int tir_mlp_fwd_valu(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map,
                                 float* out, int64_t n, void* stream) {
     int rc = check_mlp(m);
     if (rc) return rc;
-    if (n < 0 || (n > 0 && (!feat || !aux || !out))) return TIR_ERR_ARG;
+    if (n < 0 || feat_stride < F || (n > 0 && (!feat || !aux || !out))) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
     hipLaunchKernelGGL(k_mlp_valu, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, tir_stream(stream), m->packed,
-                       feat, aux, aux_map, out, n, m->out_dim, m->act);
+                       feat, feat_stride, aux, aux_map, out, n, m->out_dim, m->act);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

@@ -64,7 +64,7 @@ class AlphaGridMask(nn.Module):
 
     def _descriptor(self):
         f = TirField()
-        f.occ_bits = self.bits().data_ptr()
+        f.occ_nbr = self.bits().data_ptr()
         D, H, W = self.alpha_volume.shape[-3:]
         f.occ_dim[:] = [W, H, D]
         f.occ_aabb_min[:] = self.aabb[0].tolist()
@@ -423,7 +423,7 @@ class TensorVMSplit(nn.Module):
         f.basis_t, f.light_line, f.light_mean = keep["basis"].data_ptr(), keep["ll"].data_ptr(), keep["lm"].data_ptr()
         if mask is not None:
             keep["bits"] = mask.bits()
-            f.occ_bits = keep["bits"].data_ptr()
+            f.occ_nbr = keep["bits"].data_ptr()
             D, H, W = mask.alpha_volume.shape[-3:]
             f.occ_dim[:] = [W, H, D]
             f.occ_aabb_min[:] = mask.aabb[0].tolist()
@@ -447,18 +447,19 @@ class TensorVMSplit(nn.Module):
         """models/tensoRF_rotated_lights.py:197-224 -> tir_vm_app_fwd."""
         _no_grad_only("compute_appfeature", *self._field_params())
         li = light_idx.reshape(-1).to(xyz_sampled.device, torch.int32)
-        return ops.vm_app(self.packed_field(), xyz_sampled.reshape(-1, 3), li, None, True, False)[0]
+        return ops.vm_app(self.packed_field(), xyz_sampled.reshape(-1, 3), li, None, True, False)[0][:, :self.app_dim].contiguous()
 
     def compute_bothfeature(self, xyz_sampled, light_idx):
         """models/tensoRF_rotated_lights.py:132-165."""
         _no_grad_only("compute_bothfeature", *self._field_params())
         li = light_idx.reshape(-1).to(xyz_sampled.device, torch.int32)
-        return ops.vm_app(self.packed_field(), xyz_sampled.reshape(-1, 3), li, None, True, True)
+        r, i = ops.vm_app(self.packed_field(), xyz_sampled.reshape(-1, 3), li, None, True, True)
+        return r[:, :self.app_dim].contiguous(), i[:, :self.app_dim].contiguous()
 
     def compute_intrinfeature(self, xyz_sampled):
         """models/tensoRF_rotated_lights.py:167-195."""
         _no_grad_only("compute_intrinfeature", *self._field_params())
-        return ops.vm_app(self.packed_field(), xyz_sampled.reshape(-1, 3), None, None, False, True)[1]
+        return ops.vm_app(self.packed_field(), xyz_sampled.reshape(-1, 3), None, None, False, True)[1][:, :self.app_dim].contiguous()
 
     def compute_derived_normals(self, xyz_locs):
         """models/tensorBase_rotated_lights.py:839-856 -> tir_density_grad_fwd (closed form)."""

@@ -6,6 +6,7 @@ libtensoir_hip.so.  All functions require CUDA(HIP) tensors and raise otherwise 
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -93,11 +94,12 @@ def pack_plane(src):
 
 
 def pack_occupancy(vol):
+    """[.., D, H, W] float 0/1 volume -> (D+1)(H+1)(W+1) neighbourhood bytes."""
     vol = f32(vol.detach(), "alpha_volume")
-    n = vol.numel()
-    bits = torch.empty(((n + 31) // 32,), dtype=torch.int32, device=vol.device)
-    _call("tir_pack_occupancy", _ptr(vol), _ptr(bits), n, _stream())
-    return bits
+    D, H, W = vol.shape[-3:]
+    nbr = torch.empty(((D + 1) * (H + 1) * (W + 1),), dtype=torch.uint8, device=vol.device)
+    _call("tir_pack_occupancy", _ptr(vol), _ptr(nbr), W, H, D, _stream())
+    return nbr
 
 
 def pack_basis(w):
@@ -168,10 +170,15 @@ def density_grad(field: TirField, xyz, want_sigma=False, want_grad=False, want_n
     return sigma, grad, normal
 
 
-def vm_app(field: TirField, xyz, light_idx=None, idx_map=None, want_rad=True, want_int=False):
+FEAT_STRIDE = 32     # feature rows are padded to 128 bytes (aligned float4 stores / loads)
+APP_IMPL = "mfma"    # "mfma" (matrix-core contraction, quad-coalesced gathers) or "valu" (cross-check)
+
+
+def vm_app(field: TirField, xyz, light_idx=None, idx_map=None, want_rad=True, want_int=False, impl=None):
+    """Returns padded feature buffers [n, FEAT_STRIDE]; columns >= app_dim are zero."""
     xyz = f32(xyz, "xyz", 3).view(-1, 3)
     n = xyz.shape[0]
-    ad = field.app_dim
+    ad = FEAT_STRIDE
     if want_rad:
         if light_idx is None:
             raise ValueError("light_idx is required for the radiance feature")
@@ -184,13 +191,26 @@ def vm_app(field: TirField, xyz, light_idx=None, idx_map=None, want_rad=True, wa
             raise ValueError("light_idx must have one entry per point")
     rad = torch.empty((n, ad), dtype=torch.float32, device=xyz.device) if want_rad else None
     intr = torch.empty((n, ad), dtype=torch.float32, device=xyz.device) if want_int else None
-    _call("tir_vm_app_fwd", C.byref(field), _ptr(xyz), _ptr(light_idx) if want_rad else None,
-                               _ptr(idx_map) if want_rad else None, _ptr(rad), _ptr(intr), n, _stream())
+    _call("tir_vm_app_fwd" if (impl or APP_IMPL) == "mfma" else "tir_vm_app_fwd_valu", C.byref(field), _ptr(xyz),
+          _ptr(light_idx) if want_rad else None, _ptr(idx_map) if want_rad else None, _ptr(rad), _ptr(intr),
+          ad, n, _stream())
     return rad, intr
 
 
-def mlp(m: PackedMlp, feat, aux, aux_map=None, impl="mfma"):
-    feat = f32(feat, "feat", m.desc.feat_dim)
+# decoder implementations: "mfma" = exact fp32 matrix cores, "bf16x3" = split-bf16 matrix cores (parity
+# grade, ~5x fewer MFMA cycles), "bf16" = single-product reduced precision, "valu" = cross-check kernel
+MLP_ENTRY = {"mfma": "tir_mlp_fwd", "bf16x3": "tir_mlp_fwd_bf16x3", "bf16": "tir_mlp_fwd_bf16",
+             "valu": "tir_mlp_fwd_valu"}
+MLP_IMPL = os.environ.get("TENSOIR_DECODER", "bf16x3")
+if MLP_IMPL not in MLP_ENTRY:
+    raise ValueError(f"TENSOIR_DECODER={MLP_IMPL!r}: expected one of {sorted(MLP_ENTRY)}")
+
+
+def mlp(m: PackedMlp, feat, aux, aux_map=None, impl=None):
+    impl = impl or MLP_IMPL
+    feat = f32(feat, "feat")
+    if feat.dim() != 2 or feat.shape[1] < m.desc.feat_dim:
+        raise ValueError(f"feat: expected [n, >= {m.desc.feat_dim}], got {tuple(feat.shape)}")
     aux = f32(aux, "aux", 3)
     n = feat.shape[0]
     if aux_map is not None:
@@ -200,7 +220,7 @@ def mlp(m: PackedMlp, feat, aux, aux_map=None, impl="mfma"):
     elif aux.shape[0] != n:
         raise ValueError("aux must have one row per feature row")
     out = torch.empty((n, m.out_dim), dtype=torch.float32, device=feat.device)
-    _call("tir_mlp_fwd" if impl == "mfma" else "tir_mlp_fwd_valu", C.byref(m.desc), _ptr(feat), _ptr(aux),
+    _call(MLP_ENTRY[impl], C.byref(m.desc), _ptr(feat), feat.shape[1], _ptr(aux),
           _ptr(aux_map), _ptr(out), n, _stream())
     return out
 

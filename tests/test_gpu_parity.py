@@ -39,6 +39,16 @@ def env(golden):
                                  args=types.SimpleNamespace(second_nSample=24, second_near=0.05, second_far=1.5))
 
 
+@pytest.fixture(params=["bf16x3", "mfma"])
+def decoder(request):
+    """Run a test once per decoder mode: split-bf16 matrix cores (product default) and exact fp32."""
+    from tensoir_amd import ops
+    old = ops.MLP_IMPL
+    ops.MLP_IMPL = request.param
+    yield request.param
+    ops.MLP_IMPL = old
+
+
 def G(env, key):
     return torch.from_numpy(np.array(env.g[key])).to(env.dev)
 
@@ -59,7 +69,7 @@ def test_density_and_app_features_vs_reference(env):
 
 
 @torch.no_grad()
-@pytest.mark.parametrize("impl", ["mfma", "valu"])
+@pytest.mark.parametrize("impl", ["mfma", "valu", "bf16x3"])
 def test_decoders_vs_reference(env, impl):
     from tensoir_amd import ops
     m = env.model
@@ -71,7 +81,7 @@ def test_decoders_vs_reference(env, impl):
 
 
 @torch.no_grad()
-def test_forward_vs_reference(env):
+def test_forward_vs_reference(env, decoder):
     rays, lidx = G(env, "rays/rays"), G(env, "rays/light_idx")
     out = env.model(rays, lidx)
     for n, a in zip(NAMES, out):
@@ -89,7 +99,7 @@ def test_forward_vs_reference(env):
 
 
 @torch.no_grad()
-def test_secondary_env_ggx_vs_reference(env):
+def test_secondary_env_ggx_vs_reference(env, decoder):
     from tensoir_amd import relight
     m = env.model
     p, d, l = G(env, "sec/pts"), G(env, "sec/dirs"), G(env, "sec/light_idx")
@@ -104,7 +114,7 @@ def test_secondary_env_ggx_vs_reference(env):
 
 
 @torch.no_grad()
-def test_renderer_boundary_vs_reference(env):
+def test_renderer_boundary_vs_reference(env, decoder):
     from tensoir_amd import Renderer_TensoIR_train
     rays, lidx = G(env, "rays/rays").cpu(), G(env, "rays/light_idx").cpu()   # host tensors, as the reference passes
     ret = Renderer_TensoIR_train(rays, None, lidx, env.model, args=env.args, device=env.dev)
@@ -159,7 +169,7 @@ def mid():
 
 @torch.no_grad()
 @pytest.mark.parametrize("t_stop", [0.0, 1e-6])
-def test_renderer_vs_oracle_mid_size(mid, t_stop):
+def test_renderer_vs_oracle_mid_size(mid, t_stop, decoder):
     """Ragged batch (B not a multiple of 4, S not a multiple of 64), three lights, with and without
     early ray termination."""
     from tensoir_amd import Renderer_TensoIR_train, relight
@@ -280,7 +290,12 @@ def test_full_size_properties(full):
     rad, intr = ops.vm_app(f, rec_xyz[:20000], lidx.view(-1), rec_ray[:20000], True, True)
     a = ops.mlp(m.renderModule_brdf.packed(), intr, rec_xyz[:20000], None, "mfma")
     b = ops.mlp(m.renderModule_brdf.packed(), intr, rec_xyz[:20000], None, "valu")
+    c3 = ops.mlp(m.renderModule_brdf.packed(), intr, rec_xyz[:20000], None, "bf16x3")
     assert float((a - b).abs().max()) < 2e-6
+    assert float((a - c3).abs().max()) < 2e-5          # split-bf16 matrix cores vs exact fp32
+    # appearance gather: matrix-core kernel == one-sample-per-lane kernel
+    r2, i2 = ops.vm_app(f, rec_xyz[:20000], lidx.view(-1), rec_ray[:20000], True, True, "valu")
+    assert float((rad - r2).abs().max()) < 2e-6 and float((intr - i2).abs().max()) < 2e-6
     # (5) full boundary call: finite, in range, background white
     ret = Renderer_TensoIR_train(rays, None, lidx, m, **kw)
     for k, v in ret.items():

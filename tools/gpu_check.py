@@ -38,7 +38,8 @@ def section(name, fn):
     log(f"== {name}")
     t0 = time.time()
     try:
-        fn()
+        with torch.no_grad():
+            fn()
     except Exception:
         log("  EXCEPTION\n" + traceback.format_exc())
     log(f"  ({time.time() - t0:.2f}s)")
@@ -70,10 +71,22 @@ def main():
         err("intrin", model.compute_intrinfeature(xyz), g["feat/intrin"])
     section("K4 app features", s_app)
 
+    def s_app_impl():
+        xyz, li = T(g, "feat/xyz").to(dev), T(g, "feat/light_idx").to(dev).view(-1).int()
+        with torch.no_grad():
+            for impl in ("valu", "mfma"):
+                r, i = ops.vm_app(model.packed_field(), xyz, li, None, True, True, impl)
+                err(f"both_rad[{impl}]", r[:, :27], g["feat/both_rad"]); err(f"both_int[{impl}]", i[:, :27], g["feat/both_int"])
+                log("   pad max", float(r[:, 27:].abs().max()), float(i[:, 27:].abs().max()))
+                r1 = ops.vm_app(model.packed_field(), xyz, li, None, True, False, impl)[0]
+                i1 = ops.vm_app(model.packed_field(), xyz, None, None, False, True, impl)[1]
+                err(f"rad-only[{impl}]", r1[:, :27], g["feat/both_rad"]); err(f"int-only[{impl}]", i1[:, :27], g["feat/both_int"])
+    section("K4 impls", s_app_impl)
+
     def s_mlp():
         xyz, vd = T(g, "feat/xyz").to(dev), T(g, "mlp/viewdirs").to(dev)
         r, i = T(g, "feat/both_rad").to(dev), T(g, "feat/both_int").to(dev)
-        for impl in ("valu", "mfma"):
+        for impl in ("valu", "mfma", "bf16x3", "bf16"):
             err(f"rgb[{impl}]", ops.mlp(model.renderModule.packed(), r, vd, None, impl), g["mlp/rgb"])
             err(f"brdf[{impl}]", ops.mlp(model.renderModule_brdf.packed(), i, xyz, None, impl), g["mlp/brdf"])
             err(f"normal[{impl}]", ops.mlp(model.renderModule_normal.packed(), i, xyz, None, impl), g["mlp/normal"])
