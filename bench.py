@@ -183,17 +183,20 @@ def main():
     shapes_acc = {"app_n": 0, "app_out": 0, "mlp_n": 0, "mlp_flops": 0}
     orig_app, orig_mlp = ops.vm_app, ops.mlp
 
-    def app_wrap(field, xyz, light_idx=None, idx_map=None, want_rad=True, want_int=False, impl=None):
-        n = xyz.shape[0]
-        shapes_acc["app_n"] += n
-        shapes_acc["app_out"] += n * 27 * 4 * (int(want_rad) + int(want_int))
-        return orig_app(field, xyz, light_idx, idx_map, want_rad, want_int, impl)
+    # rows actually processed: min(buffer rows, device-side count) -- the counts are read back after the pass
+    pending = []
 
-    def mlp_wrap(m, feat, aux, aux_map=None, impl=None):
-        n = feat.shape[0]
-        shapes_acc["mlp_n"] += n
-        shapes_acc["mlp_flops"] += n * 2 * (150 * 128 + 128 * 128 + 128 * m.out_dim)
-        return orig_mlp(m, feat, aux, aux_map, impl)
+    def app_wrap(field, xyz, *args, **kw):
+        n_dev = kw.get("n_dev", args[6] if len(args) > 6 else None)
+        want_rad = kw.get("want_rad", args[2] if len(args) > 2 else True)
+        want_int = kw.get("want_int", args[3] if len(args) > 3 else False)
+        pending.append(("app", xyz.shape[0], n_dev, int(want_rad) + int(want_int)))
+        return orig_app(field, xyz, *args, **kw)
+
+    def mlp_wrap(m, feat, *args, **kw):
+        n_dev = kw.get("n_dev", args[4] if len(args) > 4 else None)
+        pending.append(("mlp", feat.shape[0], n_dev, m.out_dim))
+        return orig_mlp(m, feat, *args, **kw)
 
     ops.vm_app, ops.mlp = app_wrap, mlp_wrap
     import tensoir_amd.field_model as FM
@@ -203,6 +206,14 @@ def main():
         step()
     torch.cuda.synchronize()
     ops.vm_app, ops.mlp = orig_app, orig_mlp
+    for kind, rows, n_dev, x in pending:
+        n = rows if n_dev is None else min(rows, int(n_dev.item()))
+        if kind == "app":
+            shapes_acc["app_n"] += n
+            shapes_acc["app_out"] += n * 27 * 4 * x
+        else:
+            shapes_acc["mlp_n"] += n
+            shapes_acc["mlp_flops"] += n * 2 * (150 * 128 + 128 * 128 + 128 * x)
     timing = ops.TIMING
     ops.TIMING, ops.STATS = None, {}
     step()

@@ -131,34 +131,42 @@ int tir_density_grad_fwd(const TirField* f, const float* xyz, float* sigma, floa
 
 /* ---- K4: compute_appfeature / compute_intrinfeature / compute_bothfeature
  *      (models/tensoRF_rotated_lights.py:132-224).  light_idx (per point, or per `idx_map` entry when
- *      idx_map != NULL: light_idx[idx_map[p]]) may be NULL when rad_feat is NULL.
+ *      idx_map != NULL: light_idx[idx_map[p]]; with idx_div > 1 the selector is divided by idx_div first, e.g.
+ *      pair id -> surface point) may be NULL when rad_feat is NULL.
  *      rad_feat / int_feat [n][out_stride] (app_dim <= out_stride <= 32; columns >= app_dim are written
- *      as 0; 32 gives aligned 128-byte rows), either may be NULL. */
+ *      as 0; 32 gives aligned 128-byte rows), either may be NULL.
+ *      n_dev (optional device pointer): the kernels process min(n, *n_dev) points, so a caller that sized its
+ *      buffers for n can launch before the producing kernel's count has reached the host. */
 int tir_vm_app_fwd(const TirField* f, const float* xyz, const int32_t* light_idx,
                    const int32_t* idx_map, float* rad_feat, float* int_feat, int32_t out_stride,
-                   int64_t n, void* stream);
+                   int32_t idx_div, int64_t n, const int32_t* n_dev, void* stream);
 /* same contract, one-sample-per-lane VALU kernel (cross-check of the matrix-core kernel) */
 int tir_vm_app_fwd_valu(const TirField* f, const float* xyz, const int32_t* light_idx,
                         const int32_t* idx_map, float* rad_feat, float* int_feat, int32_t out_stride,
-                        int64_t n, void* stream);
+                        int32_t idx_div, int64_t n, const int32_t* n_dev, void* stream);
 
 /* ---- K5: positional_encoding + 3-layer MLP + activation
  *      (models/tensorBase_rotated_lights.py:12-17, :136-146, :198-208).
  *      input row = [feat, aux, PE(feat), PE(aux)]; aux row p is aux[aux_map ? aux_map[p] : p];
- *      feat rows are feat_stride floats apart (>= feat_dim). */
+ *      feat rows are feat_stride floats apart (>= feat_dim).  aux_mod > 0: the aux row index is taken modulo
+ *      aux_mod (pair id -> direction).  n_dev: as tir_vm_app_fwd. */
 int tir_mlp_fwd(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
-                const int32_t* aux_map, float* out, int64_t n, void* stream);
+                const int32_t* aux_map, int32_t aux_mod, float* out, int64_t n, const int32_t* n_dev,
+        void* stream);
 /* same contract on v_mfma_f32_32x32x16_bf16 with every operand split x = hi + lo in bf16 and the three
  * products hi*hi + hi*lo + lo*hi accumulated in fp32 (~16 mantissa bits; measured <= 2e-6 abs on the
  * decoder outputs): the parity-grade fast path. */
 int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
-                       const int32_t* aux_map, float* out, int64_t n, void* stream);
+                       const int32_t* aux_map, int32_t aux_mod, float* out, int64_t n, const int32_t* n_dev,
+        void* stream);
 /* single bf16 product (8 mantissa bits): reduced-precision mode, NOT parity grade (normals ~5e-3). */
 int tir_mlp_fwd_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
-                     const int32_t* aux_map, float* out, int64_t n, void* stream);
+                     const int32_t* aux_map, int32_t aux_mod, float* out, int64_t n, const int32_t* n_dev,
+        void* stream);
 /* same contract, plain VALU kernel (any hidden size); used to cross-check the MFMA kernel */
 int tir_mlp_fwd_valu(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
-                     const int32_t* aux_map, float* out, int64_t n, void* stream);
+                     const int32_t* aux_map, int32_t aux_mod, float* out, int64_t n, const int32_t* n_dev,
+        void* stream);
 
 /* ---- K1+K2+K3 primary march: sample_ray + alpha-mask cull + density + raw2alpha
  *      (models/tensorBase_rotated_lights.py:705-724, :892-921, :21-28).
@@ -200,7 +208,8 @@ int tir_composite_primary(const float* rays, const int32_t* offsets, const float
 /* ---- K7 secondary march: sample_ray_equally + cull + density + raw2alpha
  *      (models/relight_utils.py:707-722, :657-705, :777-834).
  *      Ray p starts at origins[org_map ? org_map[p] : p] along dirs[dir_map ? dir_map[p] : p];
- *      active[p] == 0 skips the ray (outputs 0).  n_sample <= 256.
+ *      (with both maps NULL and n_dirs > 0: origin p / n_dirs, direction p % n_dirs -- the dense
+ *      [surface point][direction] pair grid);  active[p] == 0 skips the ray (outputs 0).  n_sample <= 256.
  *      z_vals [n_sample] (device) are the sample distances near*(1-t)+far*t, t = linspace(0,1,n)
  *      (:716-717) -- passed in so that they are bit-identical to the caller framework's linspace.
  *      vis[p] = T_end, one_minus_acc[p] = 1 - sum w (either may be NULL).
@@ -210,7 +219,7 @@ int tir_composite_primary(const float* rays, const int32_t* offsets, const float
  *      ray_rec_off[p] / ray_rec_cnt[p] locate ray p's segment.  stats: as tir_march_primary_fwd. */
 int tir_march_secondary_fwd(const TirField* f, const float* origins, const int32_t* org_map,
                             const float* dirs, const int32_t* dir_map, const uint8_t* active,
-                            int64_t n_rays, int32_t n_sample, const float* z_vals,
+                            int64_t n_rays, int32_t n_dirs, int32_t n_sample, const float* z_vals,
                             float t_stop, float* vis, float* one_minus_acc,
                             int32_t* rec_counter, int64_t rec_cap, int32_t* rec_ray,
                             float* rec_w, float* rec_xyz, int32_t* ray_rec_off,
@@ -227,20 +236,21 @@ int tir_env_sg_fwd(const TirEnvSG* e, const float* dirs, int32_t D, float* out, 
 
 /* ---- geometry of render_with_BRDF (models/relight_utils.py:417-435): surface point, view
  *      vector and the cosine mask.  maps = [M][TIR_MAP_STRIDE] rows of the selected rays,
- *      rays [M][6], dirs [D][3].  surf [M][3], active [M][D] (cosine > 1e-6). */
+ *      rays [M][6], dirs [D][3].  surf [M][3], active [M][D] = cosine > 1e-6 and acc > acc_thres
+ *      (acc_mask of :1031 / renderer.py:86; pass a large negative value to shade every row). */
 int tir_shade_setup(const float* maps, const float* rays, const float* dirs, int32_t M,
-                    int32_t D, float* surf, uint8_t* active, void* stream);
+                    int32_t D, float acc_thres, float* surf, uint8_t* active, void* stream);
 
 /* ---- K8: GGX_specular + rendering-equation sum + tone map
  *      (models/relight_utils.py:17-50, :452-480, :489-515).
  *      vis [M][D], indirect [M][D][3] (NULL = no indirect), env [n_lights][D][3],
  *      weight_d [D] = light_area_weight (or NULL with equal_area != 0: mean * 4pi, :470-471).
- *      out_rgb [M][3]. */
+ *      out_rgb [M][3]; rows with acc <= acc_thres get the white background (renderer.py:105-106). */
 int tir_shade_integrate(const float* maps, const float* rays, const float* dirs,
                         const int32_t* light_idx, const float* vis, const float* indirect,
                         const float* env, const float* weight_d, int32_t M, int32_t D,
-                        int32_t n_lights, int32_t equal_area, int32_t use_srgb, float* out_rgb,
-                        void* stream);
+                        int32_t n_lights, int32_t equal_area, int32_t use_srgb, float acc_thres,
+                        float* out_rgb, void* stream);
 
 /* ---- K9: importance-sampled HDR relighting, loop body of scripts/relight_importance.py:119-170.
  *      Per surface point m and sample s: light_dir/rgb [M][Ns][3], pdf [M][Ns], vis [M][Ns].

@@ -59,22 +59,22 @@ SIGNATURES = {
     "tir_vm_density_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, I64, P]),
     "tir_occupancy_query": (C.c_int, [C.POINTER(TirField), P, P, I64, P]),
     "tir_density_grad_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, I64, P]),
-    "tir_vm_app_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I64, P]),
-    "tir_vm_app_fwd_valu": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I64, P]),
-    "tir_mlp_fwd": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, P, I64, P]),
-    "tir_mlp_fwd_bf16x3": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, P, I64, P]),
-    "tir_mlp_fwd_bf16": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, P, I64, P]),
-    "tir_mlp_fwd_valu": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, P, I64, P]),
+    "tir_vm_app_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I32, I64, P, P]),
+    "tir_vm_app_fwd_valu": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I32, I64, P, P]),
+    "tir_mlp_fwd": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P, P]),
+    "tir_mlp_fwd_bf16x3": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P, P]),
+    "tir_mlp_fwd_bf16": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P, P]),
+    "tir_mlp_fwd_valu": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P, P]),
     "tir_march_primary_fwd": (C.c_int, [C.POINTER(TirField), P, P, I32, I32, F32, P, P, P, P, P, P, P]),
     "tir_exclusive_scan": (C.c_int, [P, P, I32, P]),
     "tir_compact_primary": (C.c_int, [C.POINTER(TirField), P, P, P, P, I32, I32, P, P, P, P, P]),
     "tir_composite_primary": (C.c_int, [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, F32, P, P]),
-    "tir_march_secondary_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I64, I32, P, F32, P, P,
+    "tir_march_secondary_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I64, I32, I32, P, F32, P, P,
                                           P, I64, P, P, P, P, P, P, P]),
     "tir_accumulate_records": (C.c_int, [P, P, P, P, I64, P, P]),
     "tir_env_sg_fwd": (C.c_int, [C.POINTER(TirEnvSG), P, I32, P, P]),
-    "tir_shade_setup": (C.c_int, [P, P, P, I32, I32, P, P, P]),
-    "tir_shade_integrate": (C.c_int, [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P]),
+    "tir_shade_setup": (C.c_int, [P, P, P, I32, I32, F32, P, P, P]),
+    "tir_shade_integrate": (C.c_int, [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, P, P]),
     "tir_relight_importance": (C.c_int, [P, P, P, P, P, P, P, P, P, I32, I32, P, P]),
     "tir_ggx_specular": (C.c_int, [P, P, P, P, P, I32, I32, P, P]),
 }

@@ -229,14 +229,17 @@ template <int C4, bool RAD, bool INTR>
 __global__ void __launch_bounds__(256)
 k_vm_app_valu(TirField f, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
          const int32_t* __restrict__ idx_map, float* __restrict__ rad_feat, float* __restrict__ int_feat,
-         int out_stride, int64_t n) {
+         int out_stride, int idx_div, int64_t n, const int32_t* __restrict__ n_dev) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
     if (i >= n) return;
     constexpr int CA = C4 * 4;
     const float p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
     const float* lrow = nullptr;
     if (RAD) {
-        int li = light_idx[idx_map ? idx_map[i] : i];
+        int64_t lsel = idx_map ? (int64_t)idx_map[i] : i;
+        if (idx_div > 1) lsel /= idx_div;
+        int li = light_idx[lsel];
         li = min(max(li, 0), f.n_lights - 1);
         lrow = f.light_line + (size_t)li * (3 * CA);
     }
@@ -307,7 +310,8 @@ template <int C4, bool RAD, bool INTR>
 __global__ void __launch_bounds__(256)
 k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
               const int32_t* __restrict__ idx_map, float* __restrict__ rad_feat, float* __restrict__ int_feat,
-              int out_stride, int64_t n) {
+              int out_stride, int idx_div, int64_t n, const int32_t* __restrict__ n_dev) {
+    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));        // device-side point count (no host sync needed)
     constexpr int CA = C4 * 4;
     constexpr int NX = (RAD ? 1 : 0) + (INTR ? 1 : 0);
     extern __shared__ __attribute__((aligned(16))) float lds_app[];
@@ -326,7 +330,9 @@ k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restri
         const float p[3] = {xyz[3 * sc], xyz[3 * sc + 1], xyz[3 * sc + 2]};
         const float* lrow = nullptr;
         if (RAD) {
-            int li = light_idx[idx_map ? idx_map[sc] : sc];
+            int64_t lsel = idx_map ? (int64_t)idx_map[sc] : sc;
+            if (idx_div > 1) lsel /= idx_div;
+            int li = light_idx[lsel];
             li = min(max(li, 0), f.n_lights - 1);
             lrow = f.light_line + (size_t)li * (3 * CA);
         }
@@ -410,12 +416,12 @@ k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restri
 
 template <int C4>
 static int launch_app(const TirField* f, const float* xyz, const int32_t* li, const int32_t* map,
-                      float* rad, float* intr, int stride, int64_t n, hipStream_t s, bool valu) {
+                      float* rad, float* intr, int stride, int idx_div, int64_t n, const int32_t* n_dev, hipStream_t s, bool valu) {
     if (valu) {
         dim3 g((unsigned)((n + 255) / 256)), b(256);
-        if (rad && intr) hipLaunchKernelGGL((k_vm_app_valu<C4, true, true>), g, b, 0, s, *f, xyz, li, map, rad, intr, stride, n);
-        else if (rad)    hipLaunchKernelGGL((k_vm_app_valu<C4, true, false>), g, b, 0, s, *f, xyz, li, map, rad, intr, stride, n);
-        else             hipLaunchKernelGGL((k_vm_app_valu<C4, false, true>), g, b, 0, s, *f, xyz, li, map, rad, intr, stride, n);
+        if (rad && intr) hipLaunchKernelGGL((k_vm_app_valu<C4, true, true>), g, b, 0, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev);
+        else if (rad)    hipLaunchKernelGGL((k_vm_app_valu<C4, true, false>), g, b, 0, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev);
+        else             hipLaunchKernelGGL((k_vm_app_valu<C4, false, true>), g, b, 0, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev);
         return TIR_OK;
     }
     constexpr int CA = C4 * 4;
@@ -432,14 +438,15 @@ static int launch_app(const TirField* f, const float* xyz, const int32_t* li, co
         attr_set = true;
     }
     if (lds > 160 * 1024) return TIR_ERR_UNSUPPORTED;
-    if (rad && intr) hipLaunchKernelGGL((k_vm_app_mfma<C4, true, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, n);
-    else if (rad)    hipLaunchKernelGGL((k_vm_app_mfma<C4, true, false>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, n);
-    else             hipLaunchKernelGGL((k_vm_app_mfma<C4, false, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, n);
+    if (rad && intr) hipLaunchKernelGGL((k_vm_app_mfma<C4, true, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev);
+    else if (rad)    hipLaunchKernelGGL((k_vm_app_mfma<C4, true, false>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev);
+    else             hipLaunchKernelGGL((k_vm_app_mfma<C4, false, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev);
     return TIR_OK;
 }
 
 static int app_fwd(const TirField* f, const float* xyz, const int32_t* light_idx, const int32_t* idx_map,
-                   float* rad_feat, float* int_feat, int32_t out_stride, int64_t n, void* stream, bool valu) {
+                   float* rad_feat, float* int_feat, int32_t out_stride, int32_t idx_div, int64_t n, const int32_t* n_dev, void* stream,
+                   bool valu) {
     if (!f) return TIR_ERR_ARG;
     for (int i = 0; i < 3; ++i)
         if (f->grid[i] < 2 || !f->aplane[i] || !f->aline[i]) return TIR_ERR_ARG;
@@ -451,10 +458,10 @@ static int app_fwd(const TirField* f, const float* xyz, const int32_t* light_idx
     hipStream_t s = tir_stream(stream);
     int rc;
     switch (f->n_acomp) {
-        case 48: rc = launch_app<12>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, n, s, valu); break;
-        case 24: rc = launch_app<6>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, n, s, valu); break;
-        case 16: rc = launch_app<4>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, n, s, valu); break;
-        case 96: rc = launch_app<24>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, n, s, valu); break;
+        case 48: rc = launch_app<12>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, s, valu); break;
+        case 24: rc = launch_app<6>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, s, valu); break;
+        case 16: rc = launch_app<4>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, s, valu); break;
+        case 96: rc = launch_app<24>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, s, valu); break;
         default: return TIR_ERR_UNSUPPORTED;
     }
     if (rc) return rc;
@@ -464,12 +471,12 @@ static int app_fwd(const TirField* f, const float* xyz, const int32_t* light_idx
 
 extern "C" int tir_vm_app_fwd(const TirField* f, const float* xyz, const int32_t* light_idx,
                               const int32_t* idx_map, float* rad_feat, float* int_feat, int32_t out_stride,
-                              int64_t n, void* stream) {
-    return app_fwd(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, n, stream, false);
+                              int32_t idx_div, int64_t n, const int32_t* n_dev, void* stream) {
+    return app_fwd(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, stream, false);
 }
 
 extern "C" int tir_vm_app_fwd_valu(const TirField* f, const float* xyz, const int32_t* light_idx,
                                    const int32_t* idx_map, float* rad_feat, float* int_feat, int32_t out_stride,
-                                   int64_t n, void* stream) {
-    return app_fwd(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, n, stream, true);
+                                   int32_t idx_div, int64_t n, const int32_t* n_dev, void* stream) {
+    return app_fwd(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, stream, true);
 }

@@ -320,7 +320,7 @@ extern "C" int tir_composite_primary(const float* rays, const int32_t* offsets, 
 __global__ void __launch_bounds__(256)
 k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* __restrict__ org_map,
                   const float* __restrict__ dirs, const int32_t* __restrict__ dir_map,
-                  const uint8_t* __restrict__ active, int64_t n_rays, int n_sample,
+                  const uint8_t* __restrict__ active, int64_t n_rays, int n_dirs, int n_sample,
                   const float* __restrict__ z_vals, float t_stop, float* __restrict__ vis,
                   float* __restrict__ one_minus_acc, int32_t* __restrict__ rec_counter, int64_t rec_cap,
                   int32_t* __restrict__ rec_ray, float* __restrict__ rec_w, float* __restrict__ rec_xyz,
@@ -350,8 +350,8 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
         if (__any(live)) {
             float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
             if (live) {
-                const size_t oi = org_map ? (size_t)org_map[ray] : (size_t)ray;
-                const size_t di = dir_map ? (size_t)dir_map[ray] : (size_t)ray;
+                const size_t oi = org_map ? (size_t)org_map[ray] : (n_dirs > 0 ? (size_t)(ray / n_dirs) : (size_t)ray);
+                const size_t di = dir_map ? (size_t)dir_map[ray] : (n_dirs > 0 ? (size_t)(ray % n_dirs) : (size_t)ray);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) { o[a] = origins[3 * oi + a]; d[a] = dirs[3 * di + a]; }
             }
@@ -435,8 +435,8 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
         int base = s_base[rl];
         if (base < 0) continue;                    // uniform inside the half-wave
         const int64_t ray = (int64_t)blockIdx.x * TIR_SEC_RPB + rl;
-        const size_t oi = org_map ? (size_t)org_map[ray] : (size_t)ray;
-        const size_t di = dir_map ? (size_t)dir_map[ray] : (size_t)ray;
+        const size_t oi = org_map ? (size_t)org_map[ray] : (n_dirs > 0 ? (size_t)(ray / n_dirs) : (size_t)ray);
+        const size_t di = dir_map ? (size_t)dir_map[ray] : (n_dirs > 0 ? (size_t)(ray % n_dirs) : (size_t)ray);
         float o[3], d[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) { o[a] = origins[3 * oi + a]; d[a] = dirs[3 * di + a]; }
@@ -466,7 +466,7 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
 
 extern "C" int tir_march_secondary_fwd(const TirField* f, const float* origins, const int32_t* org_map,
                                        const float* dirs, const int32_t* dir_map, const uint8_t* active,
-                                       int64_t n_rays, int32_t n_sample, const float* z_vals,
+                                       int64_t n_rays, int32_t n_dirs, int32_t n_sample, const float* z_vals,
                                        float t_stop, float* vis, float* one_minus_acc,
                                        int32_t* rec_counter, int64_t rec_cap, int32_t* rec_ray,
                                        float* rec_w, float* rec_xyz, int32_t* ray_rec_off,
@@ -481,7 +481,7 @@ extern "C" int tir_march_secondary_fwd(const TirField* f, const float* origins, 
     size_t lds = ((size_t)((n_sample + 3) & ~3) + 4 * 256 + 3 * TIR_SEC_RPB +
                   (rec_counter ? (size_t)TIR_SEC_RPB * n_sample : 0)) * sizeof(float);
     hipLaunchKernelGGL(k_march_secondary, dim3((unsigned)((n_rays + TIR_SEC_RPB - 1) / TIR_SEC_RPB)), dim3(256), lds, tir_stream(stream),
-                       *f, origins, org_map, dirs, dir_map, active, n_rays, n_sample, z_vals, t_stop, vis,
+                       *f, origins, org_map, dirs, dir_map, active, n_rays, n_dirs, n_sample, z_vals, t_stop, vis,
                        one_minus_acc, rec_counter, rec_cap, rec_ray, rec_w, rec_xyz, ray_rec_off, ray_rec_cnt, stats);
     TIR_CHECK_LAUNCH();
     return TIR_OK;

@@ -145,11 +145,13 @@ __device__ __forceinline__ float act_out(float x, int act) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(512)
 k_mlp_mfma(const float* __restrict__ packed, const float* __restrict__ feat, int fstride, const float* __restrict__ aux,
-           const int32_t* __restrict__ aux_map, float* __restrict__ out, int64_t n, int out_dim, int act) {
+           const int32_t* __restrict__ aux_map, int aux_mod, float* __restrict__ out, int64_t n,
+           const int32_t* __restrict__ n_dev, int out_dim, int act) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     for (int i = threadIdx.x * 4; i < MFMA_FLOATS; i += 512 * 4)
         *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(packed + i);
     __syncthreads();
+    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));      // device-side row count (no host sync needed)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sl = lane & 31, h = lane >> 5;
@@ -173,7 +175,8 @@ k_mlp_mfma(const float* __restrict__ packed, const float* __restrict__ feat, int
 #pragma unroll
                 for (int q = 0; q < R0; ++q) x[NPF + q] = ft[q];
             } else {
-                const int64_t ai = aux_map ? (int64_t)aux_map[s] : s;
+                int64_t ai = aux_map ? (int64_t)aux_map[s] : s;
+            if (aux_mod > 0) ai %= aux_mod;
                 const float a0 = aux[3 * ai], a1 = aux[3 * ai + 1], a2 = aux[3 * ai + 2];
 #pragma unroll
                 for (int d = 0; d < F; ++d) {
@@ -346,7 +349,8 @@ __device__ __forceinline__ void build_inputs(const float (&ft)[F], const float (
 template <int NPROD>
 __global__ void __launch_bounds__(512)
 k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int fstride, const float* __restrict__ aux,
-           const int32_t* __restrict__ aux_map, float* __restrict__ out, int64_t n, int out_dim, int act) {
+           const int32_t* __restrict__ aux_map, int aux_mod, float* __restrict__ out, int64_t n,
+           const int32_t* __restrict__ n_dev, int out_dim, int act) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
         const float* src = packed + OFF_BF;
@@ -358,6 +362,7 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
     const bf16x8* w0lo = w0hi + BW0_ELEMS / 8;
     const bf16x8* w1hi = w0lo + BW0_ELEMS / 8;
     const bf16x8* w1lo = w1hi + BW1_ELEMS / 8;
+    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));      // device-side row count (no host sync needed)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sl = lane & 31, h = lane >> 5;
@@ -371,7 +376,8 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
             const float* fr = feat + s * fstride;
 #pragma unroll
             for (int d = 0; d < F; ++d) ft[d] = fr[d];
-            const int64_t ai = aux_map ? (int64_t)aux_map[s] : s;
+            int64_t ai = aux_map ? (int64_t)aux_map[s] : s;
+            if (aux_mod > 0) ai %= aux_mod;
             const float ax[3] = {aux[3 * ai], aux[3 * ai + 1], aux[3 * ai + 2]};
             AuxPE ap;
 #pragma unroll
@@ -465,11 +471,14 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
 k_mlp_valu(const float* __restrict__ packed, const float* __restrict__ feat, int fstride, const float* __restrict__ aux,
-           const int32_t* __restrict__ aux_map, float* __restrict__ out, int64_t n, int out_dim, int act) {
+           const int32_t* __restrict__ aux_map, int aux_mod, float* __restrict__ out, int64_t n,
+           const int32_t* __restrict__ n_dev, int out_dim, int act) {
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
     if (s >= n) return;
     float x[IN];
-    const int64_t ai = aux_map ? (int64_t)aux_map[s] : s;
+    int64_t ai = aux_map ? (int64_t)aux_map[s] : s;
+            if (aux_mod > 0) ai %= aux_mod;
     for (int d = 0; d < F; ++d) x[d] = feat[s * fstride + d];
     for (int d = 0; d < 3; ++d) x[F + d] = aux[3 * ai + d];
     for (int d = 0; d < F; ++d)
@@ -530,8 +539,8 @@ extern "C" int tir_pack_mlp(const float* w0, const float* b0, const float* w1, c
     return TIR_OK;
 }
 
-extern "C" int tir_mlp_fwd(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map,
-                           float* out, int64_t n, void* stream) {
+extern "C" int tir_mlp_fwd(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map, int32_t aux_mod,
+                           float* out, int64_t n, const int32_t* n_dev, void* stream) {
     int rc = check_mlp(m);
     if (rc) return rc;
     if (n < 0 || feat_stride < F || (n > 0 && (!feat || !aux || !out))) return TIR_ERR_ARG;
@@ -547,14 +556,14 @@ extern "C" int tir_mlp_fwd(const TirMlp* m, const float* feat, int32_t feat_stri
     int64_t tiles = (n + 255) / 256;
     unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
     hipLaunchKernelGGL(k_mlp_mfma, dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, feat_stride, aux,
-                       aux_map, out, n, m->out_dim, m->act);
+                       aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
 
 template <int NPROD>
-static int launch_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map,
-                       float* out, int64_t n, void* stream) {
+static int launch_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map, int32_t aux_mod,
+                       float* out, int64_t n, const int32_t* n_dev, void* stream) {
     int rc = check_mlp(m);
     if (rc) return rc;
     if (n < 0 || feat_stride < F || (n > 0 && (!feat || !aux || !out))) return TIR_ERR_ARG;
@@ -570,29 +579,29 @@ static int launch_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, 
     int64_t tiles = (n + 255) / 256;
     unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
     hipLaunchKernelGGL(k_mlp_bf16<NPROD>, dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, feat_stride, aux,
-                       aux_map, out, n, m->out_dim, m->act);
+                       aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
 
-extern "C" int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map,
-                                  float* out, int64_t n, void* stream) {
-    return launch_bf16<3>(m, feat, feat_stride, aux, aux_map, out, n, stream);
+extern "C" int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map, int32_t aux_mod,
+                                  float* out, int64_t n, const int32_t* n_dev, void* stream) {
+    return launch_bf16<3>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream);
 }
 
-extern "C" int tir_mlp_fwd_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map,
-                                float* out, int64_t n, void* stream) {
-    return launch_bf16<1>(m, feat, feat_stride, aux, aux_map, out, n, stream);
+extern "C" int tir_mlp_fwd_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map, int32_t aux_mod,
+                                float* out, int64_t n, const int32_t* n_dev, void* stream) {
+    return launch_bf16<1>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream);
 }
 
-extern "C" int tir_mlp_fwd_valu(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map,
-                                float* out, int64_t n, void* stream) {
+extern "C" int tir_mlp_fwd_valu(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map, int32_t aux_mod,
+                                float* out, int64_t n, const int32_t* n_dev, void* stream) {
     int rc = check_mlp(m);
     if (rc) return rc;
     if (n < 0 || feat_stride < F || (n > 0 && (!feat || !aux || !out))) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
     hipLaunchKernelGGL(k_mlp_valu, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, tir_stream(stream), m->packed,
-                       feat, feat_stride, aux, aux_map, out, n, m->out_dim, m->act);
+                       feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

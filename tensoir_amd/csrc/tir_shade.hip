@@ -101,7 +101,7 @@ k_env_sg(TirEnvSG e, const float* __restrict__ dirs, int D, float* __restrict__ 
 // ---- render_with_BRDF geometry (models/relight_utils.py:417-435) -----------------------------------
 __global__ void __launch_bounds__(256)
 k_shade_setup(const float* __restrict__ maps, const float* __restrict__ rays, const float* __restrict__ dirs,
-              int M, int D, float* __restrict__ surf, uint8_t* __restrict__ active) {
+              int M, int D, float acc_thres, float* __restrict__ surf, uint8_t* __restrict__ active) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)M * D) return;
     const int m = (int)(i / D), d = (int)(i % D);
@@ -114,7 +114,7 @@ k_shade_setup(const float* __restrict__ maps, const float* __restrict__ rays, co
     }
     // cosine = clamp(einsum(surf2l, normal_map), 0); mask = cosine > 1e-6   (:433-435)
     float cs = dirs[3 * d] * mp[4] + dirs[3 * d + 1] * mp[5] + dirs[3 * d + 2] * mp[6];
-    active[i] = fmaxf(cs, 0.f) > 1e-6f ? 1 : 0;
+    active[i] = (fmaxf(cs, 0.f) > 1e-6f && mp[14] > acc_thres) ? 1 : 0;   // acc_mask = acc > 0.5 (:1031, renderer.py:86)
 }
 
 // ---- K8: one wave per surface point, lanes over light directions -----------------------------------
@@ -123,11 +123,15 @@ k_shade_integrate(const float* __restrict__ maps, const float* __restrict__ rays
                   const int32_t* __restrict__ light_idx, const float* __restrict__ vis,
                   const float* __restrict__ indirect, const float* __restrict__ env,
                   const float* __restrict__ weight_d, int M, int D, int n_lights, int equal_area, int use_srgb,
-                  float* __restrict__ out) {
+                  float acc_thres, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (m >= M) return;
     const float* mp = maps + (size_t)m * TIR_MAP_STRIDE;
+    if (!(mp[14] > acc_thres)) {              // background ray: white (renderer.py:105-106)
+        if (lane < 3) out[3 * (size_t)m + lane] = 1.0f;
+        return;
+    }
     const float* r = rays + 6 * (size_t)m;
     float view[3] = {-r[3], -r[4], -r[5]};
     normalize3(view[0], view[1], view[2], 1e-6f);                   // safe_l2_normalize(-rays_d)  (:429-430)
@@ -223,13 +227,13 @@ extern "C" int tir_env_sg_fwd(const TirEnvSG* e, const float* dirs, int32_t D, f
 }
 
 extern "C" int tir_shade_setup(const float* maps, const float* rays, const float* dirs, int32_t M,
-                               int32_t D, float* surf, uint8_t* active, void* stream) {
+                               int32_t D, float acc_thres, float* surf, uint8_t* active, void* stream) {
     if (M < 0 || D <= 0) return TIR_ERR_ARG;
     if (M == 0) return TIR_OK;
     if (!maps || !rays || !dirs || !surf || !active) return TIR_ERR_ARG;
     int64_t n = (int64_t)M * D;
     hipLaunchKernelGGL(k_shade_setup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tir_stream(stream), maps,
-                       rays, dirs, M, D, surf, active);
+                       rays, dirs, M, D, acc_thres, surf, active);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
@@ -237,13 +241,13 @@ extern "C" int tir_shade_setup(const float* maps, const float* rays, const float
 extern "C" int tir_shade_integrate(const float* maps, const float* rays, const float* dirs,
                                    const int32_t* light_idx, const float* vis, const float* indirect,
                                    const float* env, const float* weight_d, int32_t M, int32_t D,
-                                   int32_t n_lights, int32_t equal_area, int32_t use_srgb, float* out_rgb,
-                                   void* stream) {
+                                   int32_t n_lights, int32_t equal_area, int32_t use_srgb, float acc_thres,
+                                   float* out_rgb, void* stream) {
     if (M < 0 || D <= 0 || n_lights <= 0) return TIR_ERR_ARG;
     if (M == 0) return TIR_OK;
     if (!maps || !rays || !dirs || !vis || !env || !out_rgb || (!equal_area && !weight_d)) return TIR_ERR_ARG;
     hipLaunchKernelGGL(k_shade_integrate, dim3((M + 3) / 4), dim3(256), 0, tir_stream(stream), maps, rays, dirs,
-                       light_idx, vis, indirect, env, weight_d, M, D, n_lights, equal_area, use_srgb, out_rgb);
+                       light_idx, vis, indirect, env, weight_d, M, D, n_lights, equal_area, use_srgb, acc_thres, out_rgb);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

@@ -318,7 +318,11 @@ class TensorVMSplit(nn.Module):
         """models/tensorBase_rotated_lights.py:577-606 (sg): dirs [D,3] -> [L,D,3] via tir_env_sg_fwd."""
         _no_grad_only("get_light_rgbs", self.lgtSGs)
         dirs = incident_light_directions.to(device).reshape(-1, 3).to(torch.float32)
-        return ops.env_sg(self.lgtSGs.to(device), self.light_rotation_matrix.to(device), dirs)
+        rot = self.__dict__.get("_rot_dev")
+        if rot is None or rot.device != dirs.device:
+            rot = self.light_rotation_matrix.to(dirs.device).contiguous()
+            self.__dict__["_rot_dev"] = rot
+        return ops.env_sg(self.lgtSGs.to(device), rot, dirs)
 
     def update_stepSize(self, gridSize):
         """models/tensorBase_rotated_lights.py:608-619."""

@@ -174,8 +174,10 @@ FEAT_STRIDE = 32     # feature rows are padded to 128 bytes (aligned float4 stor
 APP_IMPL = "mfma"    # "mfma" (matrix-core contraction, quad-coalesced gathers) or "valu" (cross-check)
 
 
-def vm_app(field: TirField, xyz, light_idx=None, idx_map=None, want_rad=True, want_int=False, impl=None):
-    """Returns padded feature buffers [n, FEAT_STRIDE]; columns >= app_dim are zero."""
+def vm_app(field: TirField, xyz, light_idx=None, idx_map=None, want_rad=True, want_int=False, impl=None,
+           idx_div=0, n_dev=None):
+    """Returns padded feature buffers [n, FEAT_STRIDE]; columns >= app_dim are zero.
+    n_dev (int32 device scalar): only the first min(n, n_dev) rows are computed (rest left uninitialised)."""
     xyz = f32(xyz, "xyz", 3).view(-1, 3)
     n = xyz.shape[0]
     ad = FEAT_STRIDE
@@ -187,13 +189,13 @@ def vm_app(field: TirField, xyz, light_idx=None, idx_map=None, want_rad=True, wa
             idx_map = i32(idx_map, "idx_map").view(-1)
             if idx_map.numel() != n:
                 raise ValueError("idx_map must have one entry per point")
-        elif light_idx.numel() != n:
+        elif light_idx.numel() != n and idx_div <= 1:
             raise ValueError("light_idx must have one entry per point")
     rad = torch.empty((n, ad), dtype=torch.float32, device=xyz.device) if want_rad else None
     intr = torch.empty((n, ad), dtype=torch.float32, device=xyz.device) if want_int else None
     _call("tir_vm_app_fwd" if (impl or APP_IMPL) == "mfma" else "tir_vm_app_fwd_valu", C.byref(field), _ptr(xyz),
           _ptr(light_idx) if want_rad else None, _ptr(idx_map) if want_rad else None, _ptr(rad), _ptr(intr),
-          ad, n, _stream())
+          ad, int(idx_div), n, _ptr(n_dev), _stream())
     return rad, intr
 
 
@@ -206,7 +208,7 @@ if MLP_IMPL not in MLP_ENTRY:
     raise ValueError(f"TENSOIR_DECODER={MLP_IMPL!r}: expected one of {sorted(MLP_ENTRY)}")
 
 
-def mlp(m: PackedMlp, feat, aux, aux_map=None, impl=None):
+def mlp(m: PackedMlp, feat, aux, aux_map=None, impl=None, aux_mod=0, n_dev=None):
     impl = impl or MLP_IMPL
     feat = f32(feat, "feat")
     if feat.dim() != 2 or feat.shape[1] < m.desc.feat_dim:
@@ -217,11 +219,11 @@ def mlp(m: PackedMlp, feat, aux, aux_map=None, impl=None):
         aux_map = i32(aux_map, "aux_map").view(-1)
         if aux_map.numel() != n:
             raise ValueError("aux_map must have one entry per row")
-    elif aux.shape[0] != n:
+    elif aux.shape[0] != n and aux_mod <= 0:
         raise ValueError("aux must have one row per feature row")
     out = torch.empty((n, m.out_dim), dtype=torch.float32, device=feat.device)
     _call(MLP_ENTRY[impl], C.byref(m.desc), _ptr(feat), feat.shape[1], _ptr(aux),
-          _ptr(aux_map), _ptr(out), n, _stream())
+          _ptr(aux_map), int(aux_mod), _ptr(out), n, _ptr(n_dev), _stream())
     return out
 
 
@@ -284,7 +286,7 @@ def composite_primary(rays, offsets, rec_w, rgb, brdf, brdf_jit, pred_n, der_n, 
 
 # ---- secondary march ------------------------------------------------------------------------------
 def march_secondary(field: TirField, origins, dirs, z_vals, n_rays, org_map=None, dir_map=None,
-                    active=None, t_stop=0.0, want_records=False, rec_cap=0, want_nerfactor=True):
+                    active=None, t_stop=0.0, want_records=False, rec_cap=0, want_nerfactor=True, n_dirs=0):
     origins = f32(origins, "origins", 3)
     dirs = f32(dirs, "dirs", 3)
     z_vals = f32(z_vals, "z_vals").view(-1)
@@ -310,7 +312,7 @@ def march_secondary(field: TirField, origins, dirs, z_vals, n_rays, org_map=None
     r = rec or {}
     _call("tir_march_secondary_fwd", 
         C.byref(field), _ptr(origins), _ptr(org_map), _ptr(dirs), _ptr(dir_map), _ptr(active),
-        n_rays, n_sample, _ptr(z_vals), float(t_stop), _ptr(vis), _ptr(oma),
+        n_rays, int(n_dirs), n_sample, _ptr(z_vals), float(t_stop), _ptr(vis), _ptr(oma),
         _ptr(r.get("counter")), int(rec_cap), _ptr(r.get("ray")), _ptr(r.get("w")), _ptr(r.get("xyz")),
         _ptr(r.get("off")), _ptr(r.get("cnt")), _stats_ptr("tir_march_secondary_fwd", dev), _stream())
     return vis, oma, rec
@@ -335,20 +337,20 @@ def env_sg(lgtSGs, rot, dirs):
     return out
 
 
-def shade_setup(maps, rays, dirs):
+def shade_setup(maps, rays, dirs, acc_thres=-1e30):
     maps = f32(maps, "maps", MAP_STRIDE)
     rays = f32(rays, "rays", 6)
     dirs = f32(dirs, "dirs", 3)
     M, D = maps.shape[0], dirs.shape[0]
     surf = torch.empty((M, 3), dtype=torch.float32, device=maps.device)
     active = torch.empty((M, D), dtype=torch.uint8, device=maps.device)
-    _call("tir_shade_setup", _ptr(maps), _ptr(rays), _ptr(dirs), M, D, _ptr(surf), _ptr(active),
+    _call("tir_shade_setup", _ptr(maps), _ptr(rays), _ptr(dirs), M, D, float(acc_thres), _ptr(surf), _ptr(active),
                                 _stream())
     return surf, active
 
 
 def shade_integrate(maps, rays, dirs, light_idx, vis, indirect, env, weight_d, equal_area=False,
-                    use_srgb=True):
+                    use_srgb=True, acc_thres=-1e30):
     maps = f32(maps, "maps", MAP_STRIDE)
     rays = f32(rays, "rays", 6)
     dirs = f32(dirs, "dirs", 3)
@@ -363,7 +365,7 @@ def shade_integrate(maps, rays, dirs, light_idx, vis, indirect, env, weight_d, e
     out = torch.empty((M, 3), dtype=torch.float32, device=maps.device)
     _call("tir_shade_integrate", _ptr(maps), _ptr(rays), _ptr(dirs), _ptr(light_idx), _ptr(vis),
                                     _ptr(indirect), _ptr(env), _ptr(weight_d), M, D, env.shape[0],
-                                    int(bool(equal_area)), int(bool(use_srgb)), _ptr(out), _stream())
+                                    int(bool(equal_area)), int(bool(use_srgb)), float(acc_thres), _ptr(out), _stream())
     return out
 
 

@@ -11,51 +11,87 @@ from .field_model import safe_l2_normalize  # noqa: F401  (re-exported, as the r
 MAP_STRIDE = ops.MAP_STRIDE
 
 
+_CONST_CACHE = {}
+
+
 def _z_table(n_sample, near, far, device):
     """sample_ray_equally's distances (models/relight_utils.py:716-717), computed by the same torch ops
-    on the same device as the reference would."""
-    t = torch.linspace(0.0, 1.0, n_sample, device=device)
-    return (near * (1.0 - t) + far * t).contiguous()
+    on the same device as the reference would; cached per (n, near, far, device)."""
+    key = ("z", int(n_sample), float(near), float(far), str(device))
+    z = _CONST_CACHE.get(key)
+    if z is None:
+        t = torch.linspace(0.0, 1.0, n_sample, device=device)
+        z = (near * (1.0 - t) + far * t).contiguous()
+        _CONST_CACHE[key] = z
+    return z
+
+
+def _on_device(tensoIR, name, src, device):
+    """Device-resident copy of a small host-side table of the model (direction grid, solid angles ...)."""
+    cache = tensoIR.__dict__.setdefault("_dev_tables", {})
+    key = (name, str(device), src.data_ptr(), src._version)
+    t = cache.get(name)
+    if t is None or t[0] != key:
+        t = (key, src.to(device, torch.float32).contiguous())
+        cache[name] = t
+    return t[1]
 
 
 def _rec_capacity(n_rays):
     return int(min(max(1 << 20, 16 * n_rays), 1 << 28))
 
 
-def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, light_idx, light_map,
-               want_indirect, want_nerfactor=False):
+def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, light_idx, light_div,
+               want_indirect, want_nerfactor=False, n_dirs=0):
     """Shared driver of compute_transmittance / compute_radiance / render_with_BRDF:
-    march (+ record the w > thres samples) -> appearance gather -> radiance decoder -> per-ray sum."""
+    march (+ record the w > thres samples) -> appearance gather -> radiance decoder -> per-ray sum.
+
+    No host synchronisation on the record count: the record buffers are sized from the previous call's
+    count (x1.5), the gather / decoder kernels read the actual count from device memory (n_dev), and the
+    count is checked once after everything has been queued; an overflow (rare) re-runs the stage."""
     f = tensoIR.packed_field()
     dev = origins.device
     if not want_indirect:
         vis, oma, _ = ops.march_secondary(f, origins, dirs, z, n_rays, org_map, dir_map, active,
-                                          tensoIR.march_t_stop, False, 0, want_nerfactor)
+                                          tensoIR.march_t_stop, False, 0, want_nerfactor, n_dirs)
         return vis, oma, None
-    cap = getattr(tensoIR, "_rec_cap_hint", 0) or _rec_capacity(n_rays)
+    hints = tensoIR.__dict__.setdefault("_rec_cap_hints", {})      # record capacity learnt per problem size
+    cap = hints.get(n_rays, 0)
+    first = cap <= 0
+    if first:
+        cap = _rec_capacity(n_rays)
     while True:
         vis, oma, rec = ops.march_secondary(f, origins, dirs, z, n_rays, org_map, dir_map, active,
-                                            tensoIR.march_t_stop, True, cap, want_nerfactor)
-        total = int(rec["counter"].item())              # host sync (the reference syncs per chunk too)
+                                            tensoIR.march_t_stop, True, cap, want_nerfactor, n_dirs)
+        n_dev = rec["counter"]
+        if first:                                      # no history yet: learn the count before sizing buffers
+            total = int(n_dev.item())
+            if total > cap:
+                cap = int(total * 1.25) + 1024
+                continue
+            n_rows = total
+        else:
+            n_rows = cap
+        indirect = None
+        if n_rows > 0:
+            rec_ray, rec_w, rec_xyz = rec["ray"][:n_rows], rec["w"][:n_rows], rec["xyz"][:n_rows]
+            # light index / view direction of a record = those of its ray (ray id -> point via idx_div,
+            # ray id -> direction via aux_mod on the dense [point][direction] grid)
+            feat = ops.vm_app(f, rec_xyz, light_idx, rec_ray, True, False, None, light_div, n_dev)[0]
+            rgb = ops.mlp(tensoIR.renderModule.packed(), feat, dirs, rec_ray if dir_map is None else
+                          dir_map[rec_ray.long()].contiguous(), None, n_dirs if dir_map is None else 0, n_dev)
+            indirect = ops.accumulate_records(rec["off"], rec["cnt"], rec_w, rgb, n_rays)
+        else:
+            indirect = torch.zeros((n_rays, 3), dtype=torch.float32, device=dev)
+        if first:
+            break
+        total = int(n_dev.item())                      # everything is queued: this wait costs no GPU idle time
         if total <= cap:
             break
-        cap = int(total * 1.25) + 1024                  # rare: re-march with room for every record
-    tensoIR._rec_cap_hint = max(int(total * 1.5) + 4096, 1 << 16)
-    indirect = torch.zeros((n_rays, 3), dtype=torch.float32, device=dev)
-    if total > 0:
-        rec_ray, rec_w, rec_xyz = rec["ray"][:total], rec["w"][:total], rec["xyz"][:total]
-        # light index / view direction of a record = those of its ray
-        if light_map is not None:
-            li_map = light_map[rec_ray.long()].contiguous()
-        else:
-            li_map = rec_ray
-        feat = ops.vm_app(f, rec_xyz, light_idx, li_map, True, False)[0]
-        if dir_map is not None:
-            aux_map = dir_map[rec_ray.long()].contiguous()
-        else:
-            aux_map = rec_ray
-        rgb = tensoIR.renderModule.run(feat, dirs, aux_map)
-        indirect = ops.accumulate_records(rec["off"], rec["cnt"], rec_w, rgb, n_rays)
+        cap = int(total * 1.25) + 1024                 # overflow: some rays were dropped -> redo with room
+    if len(hints) > 32:
+        hints.clear()
+    hints[n_rays] = max(int(total * 1.5) + 4096, 1 << 14)
     return vis, oma, indirect
 
 
@@ -66,7 +102,7 @@ def compute_transmittance(tensoIR, surf_pts, light_in_dir, nSample=128, vis_near
     light_in_dir = light_in_dir.to(torch.float32).contiguous()
     z = _z_table(nSample, vis_near, vis_far, surf_pts.device)
     vis, oma, _ = _secondary(tensoIR, surf_pts, light_in_dir, surf_pts.shape[0], z, None, None, None,
-                             None, None, False, True)
+                             None, 0, False, True)
     return vis, oma
 
 
@@ -78,7 +114,7 @@ def compute_radiance(tensoIR, surf_pts, light_in_dir, light_idx, nSample=128, vi
     light_in_dir = light_in_dir.to(torch.float32).contiguous()
     li = light_idx.reshape(-1).to(surf_pts.device, torch.int32).contiguous()
     z = _z_table(nSample, vis_near, vis_far, surf_pts.device)
-    return _secondary(tensoIR, surf_pts, light_in_dir, surf_pts.shape[0], z, None, None, None, li, None,
+    return _secondary(tensoIR, surf_pts, light_in_dir, surf_pts.shape[0], z, None, None, None, li, 0,
                       True, True)
 
 
@@ -120,35 +156,29 @@ def _maps_from_parts(depth_map, normal_map, albedo_map, roughness_map, fresnel_m
 
 
 def shade_from_maps(tensoIR, maps, rays, light_idx, sample_method="fixed_envirmap", args=None,
-                    use_linear2srgb=True, _dir_override=None, return_aux=False):
-    """The body of render_with_BRDF (models/relight_utils.py:417-480) on packed [M,20] map rows."""
+                    use_linear2srgb=True, acc_thres=-1e30, return_aux=False):
+    """The body of render_with_BRDF (models/relight_utils.py:417-480) on packed [M,20] map rows.
+    Rows with acc <= acc_thres are background: no secondary rays, white output (renderer.py:86-106)."""
     dev = maps.device
     M = maps.shape[0]
     rays = rays.to(dev, torch.float32).contiguous()
     li = light_idx.reshape(-1).to(dev, torch.int32).contiguous()
-    if _dir_override is not None:
-        dirs = _dir_override
+    if sample_method == "fixed_envirmap":
+        dirs = _on_device(tensoIR, "fixed_viewdirs", tensoIR.fixed_viewdirs, dev)
     else:
-        dirs = tensoIR.gen_light_incident_dirs(method=sample_method)
-    dirs = dirs.to(dev, torch.float32).contiguous()
+        dirs = tensoIR.gen_light_incident_dirs(method=sample_method).to(dev, torch.float32).contiguous()
     D = dirs.shape[0]
-    area = tensoIR.light_area_weight.to(dev, torch.float32).contiguous()
-    n_sample = int(args.second_nSample)
-    z = _z_table(n_sample, args.second_near, args.second_far, dev)
+    area = _on_device(tensoIR, "light_area_weight", tensoIR.light_area_weight, dev)
+    z = _z_table(int(args.second_nSample), args.second_near, args.second_far, dev)
     if M == 0:
         out = torch.zeros((0, 3), dtype=torch.float32, device=dev)
         return (out, None) if return_aux else out
-    surf, active = ops.shade_setup(maps, rays, dirs)
-    n_pairs = M * D
-    pair = torch.arange(n_pairs, dtype=torch.int32, device=dev)
-    org_map = torch.div(pair, D, rounding_mode="floor").to(torch.int32)
-    dir_map = (pair - org_map * D).to(torch.int32)
-    vis, _, ind = _secondary(tensoIR, surf, dirs, n_pairs, z, org_map, dir_map, active.view(-1), li,
-                             org_map, True, False)
+    surf, active = ops.shade_setup(maps, rays, dirs, acc_thres)
+    vis, _, ind = _secondary(tensoIR, surf, dirs, M * D, z, None, None, active.view(-1), li, D, True, False, D)
     env = tensoIR.get_light_rgbs(dirs, device=dev)
     equal_area = sample_method == "stratifed_sample_equal_areas"
     rgb = ops.shade_integrate(maps, rays, dirs, li, vis.view(M, D), ind.view(M, D, 3), env,
-                              None if equal_area else area, equal_area, use_linear2srgb)
+                              None if equal_area else area, equal_area, use_linear2srgb, acc_thres)
     if return_aux:
         return rgb, {"vis": vis.view(M, D), "indirect": ind.view(M, D, 3), "env": env, "surf": surf,
                      "active": active}
@@ -235,8 +265,14 @@ def relight_with_envmap(tensoIR, surface_xyz, normal, albedo, roughness, fresnel
     normal = normal.to(torch.float32).contiguous()
     cosine = torch.einsum("ijk,ik->ij", light_dir, normal)
     active = (cosine > 1e-6).to(torch.uint8).contiguous()
-    pair = torch.arange(M * Ns, dtype=torch.int32, device=dev)
-    org_map = torch.div(pair, Ns, rounding_mode="floor").to(torch.int32)
+    key = ("orgmap", M, Ns, str(dev))
+    org_map = _CONST_CACHE.get(key)
+    if org_map is None:
+        pair = torch.arange(M * Ns, dtype=torch.int32, device=dev)
+        org_map = torch.div(pair, Ns, rounding_mode="floor").to(torch.int32)
+        if len(_CONST_CACHE) > 64:
+            _CONST_CACHE.clear()
+        _CONST_CACHE[key] = org_map
     z = _z_table(nSample, vis_near, vis_far, dev)
     vis, _, _ = ops.march_secondary(tensoIR.packed_field(), surface_xyz.to(torch.float32).contiguous(),
                                     light_dir.view(-1, 3), z, M * Ns, org_map, None, active.view(-1),

@@ -20,10 +20,10 @@ def Renderer_TensoIR_train(rays=None, normal_gt=None, light_idx=None, tensoIR=No
     if tensoIR.normals_kind == "gt_normals" and normal_gt is not None:
         normal_map = normal_gt.to(device)
     if is_relight:
-        masked = relight.shade_from_maps(tensoIR, maps[acc_mask], rays[acc_mask], light_idx[acc_mask],
-                                         sample_method, args)
-        rgb_with_brdf = torch.ones_like(rgb_map)          # background defaults to white (renderer.py:105)
-        rgb_with_brdf[acc_mask] = masked
+        # all rays go through the shading kernels; rows with acc <= 0.5 (acc_mask, :1031) spawn no secondary
+        # rays and get the white background (renderer.py:86-106) -- no boolean-mask compaction, no host sync
+        rgb_with_brdf = relight.shade_from_maps(tensoIR, maps, rays, light_idx, sample_method, args,
+                                                acc_thres=0.5)
     else:
         rgb_with_brdf = torch.ones_like(rgb_map)
     return {

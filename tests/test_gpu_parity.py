@@ -182,7 +182,7 @@ def test_renderer_vs_oracle_mid_size(mid, t_stop, decoder):
     args = types.SimpleNamespace(second_nSample=96, second_near=0.05, second_far=1.5)
     out, maps = m(rays.cuda(), lidx.cuda(), N_samples=S, _brdf_jitter_dense=noise, _return_maps=True)
     mask = out[9]
-    brdf = relight.shade_from_maps(m, maps[mask], rays.cuda()[mask], lidx.cuda()[mask], "fixed_envirmap", args)
+    brdf = relight.shade_from_maps(m, maps, rays.cuda(), lidx.cuda(), "fixed_envirmap", args, acc_thres=0.5)[mask]
     ref = mid.O.renderer_train(mid.sc, rays, lidx, n_samples=S, brdf_jitter=noise)
     for n, a in zip(NAMES, out):
         if n == "acc_mask":
@@ -230,7 +230,7 @@ def test_record_overflow_recovers(env):
     from tensoir_amd import relight
     m = env.model
     p, d, l = G(env, "sec/pts"), G(env, "sec/dirs"), G(env, "sec/light_idx")
-    m._rec_cap_hint = 1
+    m._rec_cap_hints = {p.shape[0]: 1}
     v, nf, ind = relight.compute_radiance(m, p, d, l, nSample=96, vis_near=0.05, vis_far=1.5)
     assert rel(ind, env.g["sec/rad_indirect"]) < TOL
 

@@ -210,6 +210,7 @@ def main():
         for k, v in ret.items():
             err(k, v, ref[k], 1e-9 if k.endswith("loss") else 1.0)
     section("big scene renderer vs oracle", s_big)
+    section("big scene renderer vs oracle (2nd call, capacity-hint path)", s_big)
 
 
 if __name__ == "__main__":
