@@ -664,9 +664,10 @@ def render_with_brdf(sc, depth, normal, albedo, roughness3, fresnel, rays, light
     vis = torch.zeros(M, D, 1, dtype=rays.dtype)
     ind = torch.zeros(M, D, 3, dtype=rays.dtype)
     if cmask.any():
-        v, _, i = compute_radiance(
-            sc, surf.unsqueeze(1).expand(-1, D, -1)[cmask], surf2l[cmask],
-            light_idx.view(-1, 1, 1).expand(M, D, 1)[cmask], n_sample, near, far, backend)
+        with torch.no_grad():      # compute_secondary_shading_effects is @torch.no_grad (models/relight_utils.py:344)
+            v, _, i = compute_radiance(
+                sc, surf.unsqueeze(1).expand(-1, D, -1)[cmask], surf2l[cmask],
+                light_idx.view(-1, 1, 1).expand(M, D, 1)[cmask], n_sample, near, far, backend)
         vis[cmask] = v.reshape(-1, 1)
         ind[cmask] = i
     spec = ggx_specular(normal, surf2c, surf2l, roughness3, fresnel)
@@ -793,3 +794,69 @@ def update_alpha_mask(sc, grid_size=(200, 200, 200), thres=0.001, backend="aten"
     sc.alpha_aabb = sc.aabb.clone()
     valid = dense[alpha > 0.5]
     return torch.stack((valid.amin(0), valid.amax(0)))
+
+
+# --------------------------------------------------------------------------
+# training step: loss of train_tensoIR.py:262-311 and its parameter gradients (autograd on the
+# functional restatement above) -- the checker for the HIP backward kernels
+# --------------------------------------------------------------------------
+TRAIN_WEIGHTS = dict(rgb_brdf=0.2, normals_diff=0.05, normals_orientation=0.1,
+                     albedo_smoothness=0.1, roughness_smoothness=0.1)
+
+
+def scene_parameters(sc):
+    """name -> tensor for every trainable tensor of the scene, named like the reference's state_dict
+    (models/tensorBase_rotated_lights.py:675-692)."""
+    ps = {}
+    for i in range(3):
+        ps[f"density_plane.{i}"] = sc.density_plane[i]
+        ps[f"density_line.{i}"] = sc.density_line[i]
+        ps[f"app_plane.{i}"] = sc.app_plane[i]
+        ps[f"app_line.{i}"] = sc.app_line[i]
+    ps["basis_mat.weight"] = sc.basis_mat
+    ps["light_line.weight"] = sc.light_line
+    for prefix, m in (("renderModule", sc.mlp_rgb), ("renderModule_brdf", sc.mlp_brdf),
+                      ("renderModule_normal", sc.mlp_normal)):
+        for j, k in ((0, "0"), (1, "2"), (2, "4")):
+            ps[f"{prefix}.mlp.{k}.weight"] = m[f"w{j}"]
+            ps[f"{prefix}.mlp.{k}.bias"] = m[f"b{j}"]
+    ps["lgtSGs"] = sc.lgtSGs
+    return ps
+
+
+def training_loss(ret, rgb_gt, is_relight, weights=None):
+    """train_tensoIR.py:262-311 with the enhance ratios at 1 and the parameter regularisers off."""
+    w = dict(TRAIN_WEIGHTS if weights is None else weights)
+    loss = torch.mean((ret["rgb_map"] - rgb_gt) ** 2)
+    if is_relight:
+        loss = loss + w["rgb_brdf"] * torch.mean((ret["rgb_with_brdf_map"] - rgb_gt) ** 2)
+        loss = loss + w["normals_diff"] * ret["normals_diff_map"].mean()
+        loss = loss + w["normals_orientation"] * ret["normals_orientation_loss_map"].mean()
+        loss = loss + w["roughness_smoothness"] * ret["roughness_smoothness_loss"]
+        loss = loss + w["albedo_smoothness"] * ret["albedo_smoothness_loss"]
+    return loss
+
+
+def train_step_grads(sc, rays, light_idx, rgb_gt, is_relight=True, n_samples=-1, white_bg=True,
+                     ray_jitter=None, brdf_jitter=None, dir_jitter=None, second_n_sample=96,
+                     second_near=0.05, second_far=1.5, weights=None, backend="aten"):
+    """One training forward/backward on the oracle: returns (loss, {name: grad}, ret).  Leaves `sc` untouched."""
+    work = Scene(**sc.__dict__)
+    leaf = {}
+
+    def mk(t):
+        v = t.detach().clone().requires_grad_(True)
+        return v
+    for name in ("density_plane", "density_line", "app_plane", "app_line"):
+        setattr(work, name, [mk(t) for t in getattr(sc, name)])
+    work.basis_mat, work.light_line, work.lgtSGs = mk(sc.basis_mat), mk(sc.light_line), mk(sc.lgtSGs)
+    for name in ("mlp_rgb", "mlp_brdf", "mlp_normal"):
+        setattr(work, name, {k: mk(v) for k, v in getattr(sc, name).items()})
+    leaf = scene_parameters(work)
+    with torch.enable_grad():
+        ret = renderer_train(work, rays, light_idx, n_samples, white_bg, is_relight, second_n_sample,
+                             second_near, second_far, ray_jitter, brdf_jitter, dir_jitter, backend)
+        loss = training_loss(ret, rgb_gt, is_relight, weights)
+    grads = torch.autograd.grad(loss, list(leaf.values()), allow_unused=True)
+    out = {n: (torch.zeros_like(p) if g is None else g) for (n, p), g in zip(leaf.items(), grads)}
+    return loss.detach(), out, {k: (v.detach() if torch.is_tensor(v) else v) for k, v in ret.items()}
