@@ -265,6 +265,104 @@ int tir_relight_importance(const float* normal, const float* albedo, const float
 int tir_ggx_specular(const float* normal, const float* v, const float* l, const float* rough,
                      const float* fresnel, int32_t M, int32_t D, float* spec, void* stream);
 
+/* =============================================================================================
+ * Training (backward) entry points -- SURVEY.md section 8(f)-1.  The reference obtains these from
+ * torch.autograd over its op chain (train_tensoIR.py:315-317 `total_loss.backward()`); here every
+ * chain has a hand-written backward kernel.  Gradient buffers are caller-allocated and ACCUMULATED
+ * into (zero them first); field gradients are in the packed channel-last layout of TirField.
+ * Scatter-adds use hardware fp32 atomics (like ATen's grid_sampler backward), so the summation order --
+ * not the set of addends -- varies from run to run.
+ * ============================================================================================= */
+typedef struct TirFieldGrad {
+    float* dplane[3];        /* [H_i][W_i][n_dcomp]   d loss / d density_plane (channel-last)       */
+    float* dline[3];         /* [R_i][n_dcomp]                                                      */
+    float* aplane[3];        /* [H_i][W_i][n_acomp]                                                 */
+    float* aline[3];         /* [R_i][n_acomp]                                                      */
+    float* light_line;       /* [n_lights][3*n_acomp]  d loss / d light_line.weight                 */
+    float* light_mean;       /* [3*n_acomp]  d loss / d mean-over-lights row (caller adds /L to every light) */
+} TirFieldGrad;
+
+/* tir_march_primary_fwd that additionally stores the per-sample density sigma [B][S] (0 for culled
+ * samples) -- the only extra state the backward needs. */
+int tir_march_primary_train_fwd(const TirField* f, const float* rays, const float* ray_jitter,
+                                int32_t B, int32_t S, float t_stop, float* weight, float* sigma,
+                                float* acc, float* depth, float* t_end, int32_t* app_count, void* stream);
+
+/* Backward of tir_composite_primary (models/tensorBase_rotated_lights.py:973-1031).
+ * g_maps [B][20]: d loss / d out_maps.  Outputs (written, not accumulated): per-record gradients g_rgb [A][3],
+ * g_brdf [A][4] (w.r.t. the raw sigmoid outputs), g_brdf_jit [A][4], g_pred [A][3], g_der [A][3] (NULL where the
+ * forward input was NULL); g_weight [B][S] dense, MUST be zero-filled by the caller -- receives the record
+ * part of d loss / d weight at (ray, rec_k); g_acc [B], g_depth [B]: gradients of the dense sums
+ * acc = sum w, depth = sum w z. */
+int tir_composite_primary_bwd(const float* rays, const int32_t* offsets, const int32_t* rec_k,
+                              const float* rec_w, const float* rgb, const float* brdf,
+                              const float* brdf_jit, const float* pred_normal,
+                              const float* derived_normal, const float* acc, const float* depth,
+                              int32_t B, int32_t S, int32_t white_bg, int32_t is_relight,
+                              float fixed_fresnel, const float* g_maps, float* g_rgb, float* g_brdf,
+                              float* g_brdf_jit, float* g_pred, float* g_der, float* g_weight,
+                              float* g_acc, float* g_depth, void* stream);
+
+/* Backward of raw2alpha + feature2density + compute_densityfeature along the primary rays
+ * (models/tensorBase_rotated_lights.py:21-28, :813-817; models/tensoRF_rotated_lights.py:95-110):
+ * d loss / d weight[b][k] = g_weight[b][k] + g_acc[b] + z_k g_depth[b]  ->  d alpha -> d sigma -> d feature,
+ * scatter-added into g->dplane / g->dline.  g_feature (optional, NULL to skip): [B][S] receives d loss / d
+ * density feature per sample (what is scattered). */
+int tir_march_primary_bwd(const TirField* f, const TirFieldGrad* g, const float* rays,
+                          const float* ray_jitter, int32_t B, int32_t S, const float* sigma,
+                          const float* weight, const float* g_weight, const float* g_acc,
+                          const float* g_depth, float* g_feature, void* stream);
+
+/* Backward of tir_density_grad_fwd's derived normal w.r.t. the density planes/lines (the second-order
+ * path of compute_derived_normals, models/tensorBase_rotated_lights.py:839-856: create_graph=True). */
+int tir_density_grad_bwd(const TirField* f, const TirFieldGrad* g, const float* xyz,
+                         const float* g_normal, int64_t n, void* stream);
+
+/* Backward of tir_vm_app_fwd.  g_rad / g_int [n][stride] (either may be NULL).  Accumulates into g->aplane,
+ * g->aline, g->light_line, g->light_mean; writes y_rad / y_int [n][3*n_acomp] = (plane*line) (.) light row,
+ * the left operand of d basis_mat = g_feat^T y (tir_gemm_tn). */
+int tir_vm_app_bwd(const TirField* f, const TirFieldGrad* g, const float* xyz,
+                   const int32_t* light_idx, const int32_t* idx_map, const float* g_rad,
+                   const float* g_int, int32_t stride, int64_t n, float* y_rad, float* y_int,
+                   void* stream);
+
+/* Decoder forward that also stores the post-ReLU hidden activations h1, h2 [n][hidden] (exact fp32 MFMA). */
+int tir_mlp_train_fwd(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
+                      const int32_t* aux_map, int32_t aux_mod, float* out, float* h1, float* h2,
+                      int64_t n, void* stream);
+/* decoder input rows [n][160] = [feat, aux, PE(feat), PE(aux), 0-pad]  (right operand of d W0) */
+int tir_mlp_inputs(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
+                   const int32_t* aux_map, int32_t aux_mod, float* x, int64_t n, void* stream);
+int64_t tir_mlp_bwd_packed_floats(int32_t feat_dim, int32_t pe, int32_t hidden, int32_t out_dim);
+int tir_pack_mlp_bwd(const float* w0, const float* w1, const float* w2, int32_t feat_dim, int32_t pe,
+                     int32_t hidden, int32_t out_dim, float* packed, void* stream);
+/* Backward-data of one decoder: out / g_out [n][out_dim] (post-activation values and their gradients) ->
+ * g_feat [n][32] (through the positional encoding; columns >= feat_dim are 0), and the pre-activation
+ * gradients dz1, dz2 [n][hidden], dz3 [n][4] whose products with (x, h1, h2) are the weight gradients
+ * (tir_gemm_tn).  `packed_bwd` from tir_pack_mlp_bwd. */
+int tir_mlp_bwd(const TirMlp* m, const float* packed_bwd, const float* feat, int32_t feat_stride,
+                const float* out, const float* g_out, const float* h1, const float* h2, int64_t n,
+                float* g_feat, float* dz1, float* dz2, float* dz3, void* stream);
+
+/* C[M][ldc] += A^T B (+ column N = A^T 1 when ones_col != 0: the bias gradient); A [n][lda] (first M columns),
+ * B [n][ldb] (first N columns); M <= 128, N + ones_col <= 160.  fp32 MFMA, split over n. */
+int tir_gemm_tn(const float* A, int32_t lda, int32_t M, const float* B, int32_t ldb, int32_t N,
+                int32_t ones_col, int64_t n, float* C, int32_t ldc, void* stream);
+
+/* Backward of tir_shade_integrate w.r.t. the map rows (normal 4:7, albedo 7:10, roughness 10, fresnel 11:14)
+ * and the environment radiance.  g_out [M][3] -> g_maps [M][20] (written), g_env [n_lights][D][3] (accumulated).
+ * Visibility and indirect light are constants (compute_secondary_shading_effects is @torch.no_grad,
+ * models/relight_utils.py:344). */
+int tir_shade_integrate_bwd(const float* maps, const float* rays, const float* dirs,
+                            const int32_t* light_idx, const float* vis, const float* indirect,
+                            const float* env, const float* weight_d, int32_t M, int32_t D,
+                            int32_t n_lights, int32_t equal_area, int32_t use_srgb, float acc_thres,
+                            const float* g_out, float* g_maps, float* g_env, void* stream);
+
+/* Backward of tir_env_sg_fwd: g_env [n_lights][D][3] -> g_sgs [n_sg][7] (accumulated). */
+int tir_env_sg_bwd(const TirEnvSG* e, const float* dirs, int32_t D, const float* g_env, float* g_sgs,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,11 @@ class TirField(C.Structure):
     ]
 
 
+class TirFieldGrad(C.Structure):
+    _fields_ = [("dplane", C.c_void_p * 3), ("dline", C.c_void_p * 3), ("aplane", C.c_void_p * 3),
+                ("aline", C.c_void_p * 3), ("light_line", C.c_void_p), ("light_mean", C.c_void_p)]
+
+
 class TirMlp(C.Structure):
     _fields_ = [("packed", C.c_void_p), ("feat_dim", C.c_int32), ("pe", C.c_int32),
                 ("hidden", C.c_int32), ("out_dim", C.c_int32), ("act", C.c_int32)]
@@ -77,6 +82,20 @@ SIGNATURES = {
     "tir_shade_integrate": (C.c_int, [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, P, P]),
     "tir_relight_importance": (C.c_int, [P, P, P, P, P, P, P, P, P, I32, I32, P, P]),
     "tir_ggx_specular": (C.c_int, [P, P, P, P, P, I32, I32, P, P]),
+    # ---- training (backward) entry points ----
+    "tir_march_primary_train_fwd": (C.c_int, [C.POINTER(TirField), P, P, I32, I32, F32, P, P, P, P, P, P, P]),
+    "tir_composite_primary_bwd": (C.c_int, [P] * 11 + [I32, I32, I32, I32, F32] + [P] * 9 + [P]),
+    "tir_march_primary_bwd": (C.c_int, [C.POINTER(TirField), C.POINTER(TirFieldGrad), P, P, I32, I32, P, P, P, P, P, P, P]),
+    "tir_density_grad_bwd": (C.c_int, [C.POINTER(TirField), C.POINTER(TirFieldGrad), P, P, I64, P]),
+    "tir_vm_app_bwd": (C.c_int, [C.POINTER(TirField), C.POINTER(TirFieldGrad), P, P, P, P, P, I32, I64, P, P, P]),
+    "tir_mlp_train_fwd": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, P, P, I64, P]),
+    "tir_mlp_inputs": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P]),
+    "tir_mlp_bwd_packed_floats": (I64, [I32, I32, I32, I32]),
+    "tir_pack_mlp_bwd": (C.c_int, [P, P, P, I32, I32, I32, I32, P, P]),
+    "tir_mlp_bwd": (C.c_int, [C.POINTER(TirMlp), P, P, I32, P, P, P, P, I64, P, P, P, P, P]),
+    "tir_gemm_tn": (C.c_int, [P, I32, I32, P, I32, I32, I32, I64, P, I32, P]),
+    "tir_shade_integrate_bwd": (C.c_int, [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, P, P, P, P]),
+    "tir_env_sg_bwd": (C.c_int, [C.POINTER(TirEnvSG), P, I32, P, P, P]),
 }
 
 _lib = None

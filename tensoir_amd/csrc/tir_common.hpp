@@ -279,4 +279,36 @@ __device__ __forceinline__ float linear2srgb(float x) {
     return (x <= 0.0031308f) ? lin : nonlin;
 }
 
+// ------------------------------------------------------------------------------------------------
+// per-ray setup of sample_ray (models/tensorBase_rotated_lights.py:705-713)
+// ------------------------------------------------------------------------------------------------
+struct RaySetup {
+    float o[3], d[3];
+    float t_min;
+};
+
+__device__ __forceinline__ RaySetup ray_setup(const TirField& f, const float* __restrict__ rays, int r) {
+    RaySetup s;
+    float tm = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        s.o[a] = rays[6 * (size_t)r + a];
+        s.d[a] = rays[6 * (size_t)r + 3 + a];
+        float vec = (s.d[a] == 0.0f) ? 1e-6f : s.d[a];
+        float ra = __fdiv_rn(sub_rn(f.aabb_max[a], s.o[a]), vec);
+        float rb = __fdiv_rn(sub_rn(f.aabb_min[a], s.o[a]), vec);
+        tm = fmaxf(tm, fminf(ra, rb));
+    }
+    s.t_min = fminf(fmaxf(tm, f.near_), f.far_);
+    return s;
+}
+
+// z of sample k: t_min + stepSize * (k [+ jitter])   (:714-719)
+__device__ __forceinline__ float sample_z(const TirField& f, float t_min, int k, float jitter, bool has_jitter) {
+    float rng = (float)k;
+    if (has_jitter) rng = add_rn(rng, jitter);
+    return add_rn(t_min, mul_rn(f.step_size, rng));
+}
+
+
 }  // namespace tir

@@ -4,44 +4,13 @@
 using namespace tir;
 
 // ------------------------------------------------------------------------------------------------
-// per-ray setup of sample_ray (models/tensorBase_rotated_lights.py:705-713)
-// ------------------------------------------------------------------------------------------------
-struct RaySetup {
-    float o[3], d[3];
-    float t_min;
-};
-
-__device__ __forceinline__ RaySetup ray_setup(const TirField& f, const float* __restrict__ rays, int r) {
-    RaySetup s;
-    float tm = -INFINITY;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        s.o[a] = rays[6 * (size_t)r + a];
-        s.d[a] = rays[6 * (size_t)r + 3 + a];
-        float vec = (s.d[a] == 0.0f) ? 1e-6f : s.d[a];
-        float ra = __fdiv_rn(sub_rn(f.aabb_max[a], s.o[a]), vec);
-        float rb = __fdiv_rn(sub_rn(f.aabb_min[a], s.o[a]), vec);
-        tm = fmaxf(tm, fminf(ra, rb));
-    }
-    s.t_min = fminf(fmaxf(tm, f.near_), f.far_);
-    return s;
-}
-
-// z of sample k: t_min + stepSize * (k [+ jitter])   (:714-719)
-__device__ __forceinline__ float sample_z(const TirField& f, float t_min, int k, float jitter, bool has_jitter) {
-    float rng = (float)k;
-    if (has_jitter) rng = add_rn(rng, jitter);
-    return add_rn(t_min, mul_rn(f.step_size, rng));
-}
-
-// ------------------------------------------------------------------------------------------------
 // primary march: one wave64 per ray, 64 consecutive samples per step, transmittance carried
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_march_primary(TirField f, const float* __restrict__ rays, const float* __restrict__ ray_jitter,
                 int B, int S, float t_stop, float* __restrict__ weight, float* __restrict__ acc_out,
                 float* __restrict__ depth_out, float* __restrict__ tend_out, int32_t* __restrict__ app_count,
-                unsigned long long* __restrict__ stats) {
+                unsigned long long* __restrict__ stats, float* __restrict__ sigma_out) {
     const int lane = threadIdx.x & 63;
     const int ray = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (ray >= B) return;
@@ -80,6 +49,7 @@ k_march_primary(TirField f, const float* __restrict__ rays, const float* __restr
         float excl = shift_up1<64>(incl, lane);
         w = w * (T * excl);
         if (k < S) weight[(size_t)ray * S + k] = w;
+        if (sigma_out && k < S) sigma_out[(size_t)ray * S + k] = sigma;
         acc += w;
         depth = fmaf(w, z, depth);
         cnt += __popcll(__ballot(w > f.weight_thres));
@@ -91,6 +61,7 @@ k_march_primary(TirField f, const float* __restrict__ rays, const float* __restr
     for (; k0 < S; k0 += 64) {
         const int k = k0 + lane;
         if (k < S) weight[(size_t)ray * S + k] = 0.0f;
+        if (sigma_out && k < S) sigma_out[(size_t)ray * S + k] = 0.0f;
     }
     acc = group_sum<64>(acc);
     depth = group_sum<64>(depth);
@@ -112,7 +83,21 @@ extern "C" int tir_march_primary_fwd(const TirField* f, const float* rays, const
     if (!rays || !weight || !acc || !depth || !app_count) return TIR_ERR_ARG;
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_march_primary, dim3((B + 3) / 4), dim3(256), 0, tir_stream(stream), *f, rays,
-                       ray_jitter, B, S, t_stop, weight, acc, depth, t_end, app_count, stats);
+                       ray_jitter, B, S, t_stop, weight, acc, depth, t_end, app_count, stats, (float*)nullptr);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_march_primary_train_fwd(const TirField* f, const float* rays, const float* ray_jitter,
+                                           int32_t B, int32_t S, float t_stop, float* weight, float* sigma,
+                                           float* acc, float* depth, float* t_end, int32_t* app_count, void* stream) {
+    if (!f || B < 0 || S <= 0) return TIR_ERR_ARG;
+    if (B == 0) return TIR_OK;
+    if (!rays || !weight || !sigma || !acc || !depth || !app_count) return TIR_ERR_ARG;
+    if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_march_primary, dim3((B + 3) / 4), dim3(256), 0, tir_stream(stream), *f, rays,
+                       ray_jitter, B, S, t_stop, weight, acc, depth, t_end, app_count,
+                       (unsigned long long*)nullptr, sigma);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

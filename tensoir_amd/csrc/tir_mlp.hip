@@ -143,10 +143,11 @@ __device__ __forceinline__ float act_out(float x, int act) {
 // ------------------------------------------------------------------------------------------------
 // MFMA kernel: 512 threads = 8 waves, 32 samples per wave, persistent over 256-sample tiles
 // ------------------------------------------------------------------------------------------------
+template <bool SAVE>
 __global__ void __launch_bounds__(512)
 k_mlp_mfma(const float* __restrict__ packed, const float* __restrict__ feat, int fstride, const float* __restrict__ aux,
            const int32_t* __restrict__ aux_map, int aux_mod, float* __restrict__ out, int64_t n,
-           const int32_t* __restrict__ n_dev, int out_dim, int act) {
+           const int32_t* __restrict__ n_dev, int out_dim, int act, float* __restrict__ h1o, float* __restrict__ h2o) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     for (int i = threadIdx.x * 4; i < MFMA_FLOATS; i += 512 * 4)
         *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(packed + i);
@@ -216,6 +217,15 @@ k_mlp_mfma(const float* __restrict__ packed, const float* __restrict__ feat, int
                 if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep LDS reads from piling up in VGPRs
             }
         }
+        if (SAVE && s_raw < n) {      // post-ReLU hidden activations, natural [sample][unit] layout (training)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<float4*>(h1o + s_raw * HID + mt * 32 + 8 * i + 4 * h) =
+                        make_float4(fmaxf(acc[mt][4 * i], 0.f), fmaxf(acc[mt][4 * i + 1], 0.f),
+                                    fmaxf(acc[mt][4 * i + 2], 0.f), fmaxf(acc[mt][4 * i + 3], 0.f));
+        }
         // ---- layer 2 ----
         f32x16 acc2[4];
 #pragma unroll
@@ -236,6 +246,15 @@ k_mlp_mfma(const float* __restrict__ packed, const float* __restrict__ feat, int
                 acc2[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b, acc2[3], 0, 0, 0);
                 if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+        }
+        if (SAVE && s_raw < n) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<float4*>(h2o + s_raw * HID + mt * 32 + 8 * i + 4 * h) =
+                        make_float4(fmaxf(acc2[mt][4 * i], 0.f), fmaxf(acc2[mt][4 * i + 1], 0.f),
+                                    fmaxf(acc2[mt][4 * i + 2], 0.f), fmaxf(acc2[mt][4 * i + 3], 0.f));
         }
         // ---- layer 3 (out_dim <= 4): per-lane dot over its 64 hidden units, then add the halves ----
         float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
@@ -514,6 +533,214 @@ k_mlp_valu(const float* __restrict__ packed, const float* __restrict__ feat, int
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Training: decoder input rows, backward-data kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int XPAD = 160;                        // input row stride of tir_mlp_inputs / W0^T row count
+// backward blob (floats): W2 [2][64][4] | W1^T [64*2][128] | W0^T [64*2][160]
+constexpr int OFFB_W2 = 0;
+constexpr int OFFB_W1T = OFFB_W2 + 2 * 64 * 4;
+constexpr int OFFB_W0T = OFFB_W1T + 128 * HID;
+constexpr int BWD_FLOATS = OFFB_W0T + 128 * XPAD;          // 37376 floats = 149,504 B of LDS
+
+// MFMA output row R (0..159) of d x^T = W0^T dz1^T  ->  decoder input index it carries (or -1).
+// Rows are permuted so that lane half h ends up holding, for feature d = 16 h + u/5 (u = 16 mt + r its accumulator
+// slot), the 5 cotangents {raw, sin f0, sin f1, cos f0, cos f1} the positional-encoding chain rule needs.
+__host__ __device__ inline int bwd_inrow(int R) {
+    const int mt = R >> 5, within = R & 31;
+    const int hh = (within >> 2) & 1, r = (within & 3) + 4 * (within >> 3);
+    const int u = mt * 16 + r;
+    const int d = hh * 16 + u / 5, comp = u % 5;
+    if (d >= F) return -1;
+    switch (comp) {
+        case 0: return d;
+        case 1: return F + 3 + d * PE;
+        case 2: return F + 3 + d * PE + 1;
+        case 3: return F + 3 + NPF + d * PE;
+        default: return F + 3 + NPF + d * PE + 1;
+    }
+}
+
+__global__ void k_pack_mlp_bwd(const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2,
+                               int out_dim, float* __restrict__ p) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BWD_FLOATS) return;
+    float v = 0.0f;
+    if (i < OFFB_W1T) {
+        int j = i - OFFB_W2, h = j / 256, q = (j % 256) / 4, o = j % 4;
+        v = (o < out_dim) ? w2[o * HID + unit_of(q, h)] : 0.0f;
+    } else if (i < OFFB_W0T) {
+        int j = i - OFFB_W1T, th = j / 128, rem = j % 128, ii = rem / 4, mt = rem % 4;
+        v = w1[unit_of(th >> 1, th & 1) * HID + (mt * 32 + ii)];          // W1^T[row = mt*32+ii][k = unit]
+    } else {
+        int j = i - OFFB_W0T, th = j / XPAD, rem = j % XPAD, ii = rem / 5, mt = rem % 5;
+        int in = bwd_inrow(mt * 32 + ii);
+        v = (in >= 0) ? w0[unit_of(th >> 1, th & 1) * IN + in] : 0.0f;
+    }
+    p[i] = v;
+}
+
+__global__ void __launch_bounds__(256)
+k_mlp_inputs(const float* __restrict__ feat, int fstride, const float* __restrict__ aux, const int32_t* __restrict__ aux_map,
+             int aux_mod, float* __restrict__ x, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * XPAD) return;
+    const int64_t s = idx / XPAD;
+    const int col = (int)(idx % XPAD);
+    float v = 0.0f;
+    if (col < F) v = feat[s * fstride + col];
+    else if (col < F + 3 + 2 * NPF) {
+        if (col >= F + 3) {
+            const int q = col - (F + 3);
+            const bool is_cos = q >= NPF;
+            const int qq = is_cos ? q - NPF : q;
+            const float y = feat[s * fstride + qq / PE] * (float)(1 << (qq % PE));
+            v = is_cos ? cosf(y) : sinf(y);
+        } else {
+            int64_t ai = aux_map ? (int64_t)aux_map[s] : s;
+            if (aux_mod > 0) ai %= aux_mod;
+            v = aux[3 * ai + (col - F)];
+        }
+    } else if (col < IN) {
+        int64_t ai = aux_map ? (int64_t)aux_map[s] : s;
+        if (aux_mod > 0) ai %= aux_mod;
+        const int q = col - (F + 3 + 2 * NPF);
+        const bool is_cos = q >= 3 * PE;
+        const int qq = is_cos ? q - 3 * PE : q;
+        const float y = aux[3 * ai + qq / PE] * (float)(1 << (qq % PE));
+        v = is_cos ? cosf(y) : sinf(y);
+    }
+    x[idx] = v;
+}
+
+// Backward-data: 8 waves x 32 samples per 256-sample tile, same lane decomposition as the forward kernels
+// (lane = sample l&31, half h = l>>5 holds hidden units unit_of(q, h)).  d h^T = W^T dz^T has exactly the forward's
+// shape with the transposed weights as the A operand, so the lane that holds h[unit] receives d h[unit].
+__global__ void __launch_bounds__(512)
+k_mlp_bwd(const float* __restrict__ packed_bwd, const float* __restrict__ feat, int fstride, const float* __restrict__ out,
+          const float* __restrict__ g_out, const float* __restrict__ h1, const float* __restrict__ h2, int64_t n,
+          int out_dim, int act, float* __restrict__ g_feat, float* __restrict__ dz1o, float* __restrict__ dz2o,
+          float* __restrict__ dz3o) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int i = threadIdx.x * 4; i < BWD_FLOATS; i += 512 * 4)
+        *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(packed_bwd + i);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sl = lane & 31, h = lane >> 5;
+    const int64_t n_tiles = (n + 255) / 256;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t s_raw = tile * 256 + wave * 32 + sl;
+        const bool on = s_raw < n;
+        const int64_t s = on ? s_raw : n - 1;
+        // ---- output layer ----
+        float dz3[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float y = 0.f, gy = 0.f;
+            if (o < out_dim) { y = out[s * out_dim + o]; gy = on ? g_out[s * out_dim + o] : 0.f; }
+            dz3[o] = gy * (act == 1 ? (1.0f - y * y) : y * (1.0f - y));
+        }
+        if (on && h == 0) *reinterpret_cast<float4*>(dz3o + s * 4) = make_float4(dz3[0], dz3[1], dz3[2], dz3[3]);
+        float dz[64];
+        {
+            const float* wp = lds + OFFB_W2 + h * 256;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 hv = *reinterpret_cast<const float4*>(h2 + s * HID + mt * 32 + 8 * i + 4 * h);
+                    const float hvv[4] = {hv.x, hv.y, hv.z, hv.w};
+                    float o4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int q = mt * 16 + 4 * i + j;
+                        const float4 w = *reinterpret_cast<const float4*>(wp + q * 4);
+                        const float d = w.x * dz3[0] + w.y * dz3[1] + w.z * dz3[2] + w.w * dz3[3];
+                        o4[j] = hvv[j] > 0.f ? d : 0.f;
+                        dz[q] = o4[j];
+                    }
+                    if (on) *reinterpret_cast<float4*>(dz2o + s * HID + mt * 32 + 8 * i + 4 * h) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                }
+        }
+        // ---- d h1^T = W1^T dz2^T ----
+        f32x16 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        {
+            const float* wp = lds + OFFB_W1T + h * 128 + sl * 4;
+#pragma unroll
+            for (int t = 0; t < 64; ++t) {
+                const float4 a = *reinterpret_cast<const float4*>(wp + t * 256);
+                const float b = dz[t];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b, acc[3], 0, 0, 0);
+                if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 hv = *reinterpret_cast<const float4*>(h1 + s * HID + mt * 32 + 8 * i + 4 * h);
+                const float hvv[4] = {hv.x, hv.y, hv.z, hv.w};
+                float o4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o4[j] = hvv[j] > 0.f ? acc[mt][4 * i + j] : 0.f;
+                    dz[mt * 16 + 4 * i + j] = o4[j];
+                }
+                if (on) *reinterpret_cast<float4*>(dz1o + s * HID + mt * 32 + 8 * i + 4 * h) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            }
+        // ---- d x^T = W0^T dz1^T (rows permuted, see bwd_inrow) ----
+        f32x16 ax[5];
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ax[mt][r] = 0.f;
+        {
+            const float* wp = lds + OFFB_W0T + h * XPAD + sl * 5;
+#pragma unroll
+            for (int t = 0; t < 64; ++t) {
+                const float* a = wp + t * (2 * XPAD);
+                const float b = dz[t];
+                ax[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b, ax[0], 0, 0, 0);
+                ax[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b, ax[1], 0, 0, 0);
+                ax[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b, ax[2], 0, 0, 0);
+                ax[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b, ax[3], 0, 0, 0);
+                ax[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4], b, ax[4], 0, 0, 0);
+                if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- positional-encoding chain rule: x = [f, sin f, sin 2f, cos f, cos 2f] ----
+        float gf[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int d = h * 16 + j;
+            float v = 0.f;
+            if (d < F) {
+                const float xv = feat[s * fstride + d];
+                const float s1 = sinf(xv), c1 = cosf(xv), s2 = sinf(xv * 2.0f), c2 = cosf(xv * 2.0f);
+                const int u0 = 5 * j;
+                const float g_raw = ax[(u0) >> 4][(u0) & 15], g_s0 = ax[(u0 + 1) >> 4][(u0 + 1) & 15];
+                const float g_s1 = ax[(u0 + 2) >> 4][(u0 + 2) & 15], g_c0 = ax[(u0 + 3) >> 4][(u0 + 3) & 15];
+                const float g_c1 = ax[(u0 + 4) >> 4][(u0 + 4) & 15];
+                v = g_raw + c1 * g_s0 + 2.0f * c2 * g_s1 - s1 * g_c0 - 2.0f * s2 * g_c1;
+            }
+            gf[j] = v;
+        }
+        if (on) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<float4*>(g_feat + s * 32 + h * 16 + 4 * i) = make_float4(gf[4 * i], gf[4 * i + 1], gf[4 * i + 2], gf[4 * i + 3]);
+        }
+    }
+}
+
 int check_mlp(const TirMlp* m) {
     if (!m || !m->packed) return TIR_ERR_ARG;
     if (m->feat_dim != F || m->pe != PE || m->hidden != HID || m->out_dim < 1 || m->out_dim > 4)
@@ -548,15 +775,38 @@ extern "C" int tir_mlp_fwd(const TirMlp* m, const float* feat, int32_t feat_stri
     static bool attr_set = false;
     const size_t lds = (size_t)MFMA_FLOATS * sizeof(float);
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_mfma),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_mfma<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return -(int)e;
         attr_set = true;
     }
     int64_t tiles = (n + 255) / 256;
     unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
-    hipLaunchKernelGGL(k_mlp_mfma, dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, feat_stride, aux,
-                       aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act);
+    hipLaunchKernelGGL(k_mlp_mfma<false>, dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, feat_stride, aux,
+                       aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act, (float*)nullptr, (float*)nullptr);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_mlp_train_fwd(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
+                                 const int32_t* aux_map, int32_t aux_mod, float* out, float* h1, float* h2,
+                                 int64_t n, void* stream) {
+    int rc = check_mlp(m);
+    if (rc) return rc;
+    if (n < 0 || feat_stride < F || (n > 0 && (!feat || !aux || !out || !h1 || !h2))) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    static bool attr_set = false;
+    const size_t lds = (size_t)MFMA_FLOATS * sizeof(float);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_mfma<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+        attr_set = true;
+    }
+    int64_t tiles = (n + 255) / 256;
+    unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    hipLaunchKernelGGL(k_mlp_mfma<true>, dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, feat_stride, aux,
+                       aux_map, aux_mod, out, n, (const int32_t*)nullptr, m->out_dim, m->act, h1, h2);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
@@ -602,6 +852,58 @@ extern "C" int tir_mlp_fwd_valu(const TirMlp* m, const float* feat, int32_t feat
     if (n == 0) return TIR_OK;
     hipLaunchKernelGGL(k_mlp_valu, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, tir_stream(stream), m->packed,
                        feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_mlp_inputs(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
+                              const int32_t* aux_map, int32_t aux_mod, float* x, int64_t n, void* stream) {
+    int rc = check_mlp(m);
+    if (rc) return rc;
+    if (n < 0 || feat_stride < F || (n > 0 && (!feat || !aux || !x))) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    const int64_t total = n * XPAD;
+    hipLaunchKernelGGL(k_mlp_inputs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, tir_stream(stream), feat,
+                       feat_stride, aux, aux_map, aux_mod, x, n);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int64_t tir_mlp_bwd_packed_floats(int32_t feat_dim, int32_t pe, int32_t hidden, int32_t out_dim) {
+    if (feat_dim != F || pe != PE || hidden != HID || out_dim < 1 || out_dim > 4) return TIR_ERR_UNSUPPORTED;
+    return BWD_FLOATS;
+}
+
+extern "C" int tir_pack_mlp_bwd(const float* w0, const float* w1, const float* w2, int32_t feat_dim, int32_t pe,
+                                int32_t hidden, int32_t out_dim, float* packed, void* stream) {
+    if (!w0 || !w1 || !w2 || !packed) return TIR_ERR_ARG;
+    if (feat_dim != F || pe != PE || hidden != HID || out_dim < 1 || out_dim > 4) return TIR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_pack_mlp_bwd, dim3((BWD_FLOATS + 255) / 256), dim3(256), 0, tir_stream(stream), w0, w1, w2,
+                       out_dim, packed);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_mlp_bwd(const TirMlp* m, const float* packed_bwd, const float* feat, int32_t feat_stride,
+                           const float* out, const float* g_out, const float* h1, const float* h2, int64_t n,
+                           float* g_feat, float* dz1, float* dz2, float* dz3, void* stream) {
+    int rc = check_mlp(m);
+    if (rc) return rc;
+    if (!packed_bwd || n < 0 || feat_stride < F) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    if (!feat || !out || !g_out || !h1 || !h2 || !g_feat || !dz1 || !dz2 || !dz3) return TIR_ERR_ARG;
+    static bool attr_set = false;
+    const size_t lds = (size_t)BWD_FLOATS * sizeof(float);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+        attr_set = true;
+    }
+    int64_t tiles = (n + 255) / 256;
+    unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    hipLaunchKernelGGL(k_mlp_bwd, dim3(grid), dim3(512), lds, tir_stream(stream), packed_bwd, feat, feat_stride, out,
+                       g_out, h1, h2, n, m->out_dim, m->act, g_feat, dz1, dz2, dz3);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

@@ -1,0 +1,942 @@
+// Backward kernels of the training step: the reference gets these from
+// torch.autograd over its ATen op chain (train_tensoIR.py:315-317); here each chain has a closed-form
+// backward.  Scatter-adds into the (channel-last) parameter gradients use hardware fp32 atomics.
+#include "tir_common.hpp"
+
+using namespace tir;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// ------------------------------------------------------------------------------------------------
+// Scatter of one VM group (plane i + line i) for one 4-channel chunk `c` of every tap.
+// Value model:  feat = sum_ch P L,   du = sum_ch Pu L,  dv = sum_ch Pv L,  dw = sum_ch P Lw
+// with P the bilinear plane value, Pu/Pv its derivatives per texel, L the linear line value, Lw = l1 - l0.
+// Cotangents: F (feat) and -- NORMAL only -- Gu, Gv, Gw (of du, dv, dw; texel-scale factors already applied).
+// NORMAL == false uses grid_sample's zero-padding weights (compute_densityfeature, F.grid_sample);
+// NORMAL == true uses clamped indices + unclamped weights (models/relight_utils.py:82-92).
+// ------------------------------------------------------------------------------------------------
+template <int CH, bool NORMAL>
+__device__ __forceinline__ void scatter_group(const float* __restrict__ plane, const float* __restrict__ line,
+                                              float* __restrict__ gplane, float* __restrict__ gline, int H, int W,
+                                              int R, float u, float v, float w, int c, float F, float Gu,
+                                              float Gv, float Gw) {
+    Tap1 tx = make_tap(u, W), ty = make_tap(v, H), tl = make_tap(w, R);
+    float wx0, wx1, wy0, wy1, wl0, wl1;
+    if (NORMAL) { wx0 = 1.0f - tx.t; wx1 = tx.t; wy0 = 1.0f - ty.t; wy1 = ty.t; wl0 = 1.0f - tl.t; wl1 = tl.t; }
+    else { wx0 = tx.w0; wx1 = tx.w1; wy0 = ty.w0; wy1 = ty.w1; wl0 = tl.w0; wl1 = tl.w1; }
+    const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+    const size_t o00 = ((size_t)ty.i0 * W + tx.i0) * CH + 4 * c, o01 = ((size_t)ty.i0 * W + tx.i1) * CH + 4 * c;
+    const size_t o10 = ((size_t)ty.i1 * W + tx.i0) * CH + 4 * c, o11 = ((size_t)ty.i1 * W + tx.i1) * CH + 4 * c;
+    const size_t q0 = (size_t)tl.i0 * CH + 4 * c, q1 = (size_t)tl.i1 * CH + 4 * c;
+    const float4 a4 = ld4(plane + o00), b4 = ld4(plane + o01), c4 = ld4(plane + o10), d4 = ld4(plane + o11);
+    const float4 e4 = ld4(line + q0), g4 = ld4(line + q1);
+    // per-tap cotangent coefficients (Pu = (b-a) wy0 + (d-c) wy1,  Pv = (c-a) wx0 + (d-b) wx1)
+    float a00 = F * w00, a01 = F * w01, a10 = F * w10, a11 = F * w11;
+    if (NORMAL) {
+        a00 += -Gu * wy0 - Gv * wx0; a01 += Gu * wy0 - Gv * wx1;
+        a10 += -Gu * wy1 + Gv * wx0; a11 += Gu * wy1 + Gv * wx1;
+    }
+    const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+    const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+    const float ev[4] = {e4.x, e4.y, e4.z, e4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float L = fmaf(gv[q], wl1, ev[q] * wl0);
+        const float P = fmaf(dv[q], w11, fmaf(cv[q], w10, fmaf(bv[q], w01, av[q] * w00)));
+        float t00 = L * a00, t01 = L * a01, t10 = L * a10, t11 = L * a11;
+        float S = F * P;
+        if (NORMAL) {
+            const float Lw = gv[q] - ev[q];
+            t00 = fmaf(Lw, Gw * w00, t00); t01 = fmaf(Lw, Gw * w01, t01);
+            t10 = fmaf(Lw, Gw * w10, t10); t11 = fmaf(Lw, Gw * w11, t11);
+            const float Pu = fmaf(dv[q] - cv[q], wy1, (bv[q] - av[q]) * wy0);
+            const float Pv = fmaf(dv[q] - bv[q], wx1, (cv[q] - av[q]) * wx0);
+            S = fmaf(Gv, Pv, fmaf(Gu, Pu, S));
+        }
+        if (t00 != 0.0f) atomic_add_f32(gplane + o00 + q, t00);
+        if (t01 != 0.0f) atomic_add_f32(gplane + o01 + q, t01);
+        if (t10 != 0.0f) atomic_add_f32(gplane + o10 + q, t10);
+        if (t11 != 0.0f) atomic_add_f32(gplane + o11 + q, t11);
+        float s0 = S * wl0, s1 = S * wl1;
+        if (NORMAL) { s0 = fmaf(-Gw, P, s0); s1 = fmaf(Gw, P, s1); }
+        if (s0 != 0.0f) atomic_add_f32(gline + q0 + q, s0);
+        if (s1 != 0.0f) atomic_add_f32(gline + q1 + q, s1);
+    }
+}
+
+// the three VM groups of the density field for one sample chunk
+template <int C4, bool NORMAL>
+__device__ __forceinline__ void scatter_density(const TirField& f, const TirFieldGrad& g, float x, float y, float z,
+                                                int c, float F, float G0, float G1, float G2) {
+    const float p[3] = {x, y, z};
+    const float G[3] = {G0, G1, G2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int m0 = (i == 2) ? 1 : 0, m1 = (i == 0) ? 1 : 2, vi = 2 - i;
+        const int H = f.grid[m1], W = f.grid[m0], R = f.grid[vi];
+        float Gu = 0.f, Gv = 0.f, Gw = 0.f;
+        if (NORMAL) { Gu = G[m0] * (0.5f * (float)(W - 1)); Gv = G[m1] * (0.5f * (float)(H - 1)); Gw = G[vi] * (0.5f * (float)(R - 1)); }
+        scatter_group<C4 * 4, NORMAL>(f.dplane[i], f.dline[i], g.dplane[i], g.dline[i], H, W, R, p[m0], p[m1], p[vi],
+                                      c, F, Gu, Gv, Gw);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the primary march: one wave64 per ray.
+// ------------------------------------------------------------------------------------------------
+#define TIR_MAX_CHUNKS 64      // S <= 4096
+
+template <int C4>
+__global__ void __launch_bounds__(256)
+k_march_primary_bwd(TirField f, TirFieldGrad g, const float* __restrict__ rays, const float* __restrict__ ray_jitter,
+                    int B, int S, const float* __restrict__ sigma, const float* __restrict__ weight,
+                    const float* __restrict__ gw, const float* __restrict__ g_acc, const float* __restrict__ g_depth,
+                    float* __restrict__ g_feat_out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wv;
+    if (ray >= B) return;
+    __shared__ float tstart[4][TIR_MAX_CHUNKS];
+    __shared__ __attribute__((aligned(16))) float wl_all[4][256];
+    float* wl = wl_all[wv];
+    RaySetup rs = ray_setup(f, rays, ray);
+    const bool hj = ray_jitter != nullptr;
+    const float jit = hj ? ray_jitter[ray] : 0.0f;
+    const int nch = (S + 63) / 64;
+    // pass 1: transmittance at the start of every 64-sample chunk, with the forward's exact arithmetic
+    float T = 1.0f;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int k = ch * 64 + lane;
+        float v = 1.0f;
+        if (k < S) {
+            const float z = sample_z(f, rs.t_min, k, jit, hj);
+            const float dist = (k + 1 < S) ? sub_rn(sample_z(f, rs.t_min, k + 1, jit, hj), z) : 0.0f;
+            const float alpha = 1.0f - expf(-sigma[(size_t)ray * S + k] * mul_rn(dist, f.distance_scale));
+            v = add_rn(sub_rn(1.0f, alpha), 1e-10f);
+        }
+        if (lane == 0) tstart[wv][ch] = T;
+        const float incl = scan_prod<64>(v, lane);
+        T = T * __shfl(incl, 63, 64);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // pass 2: chunks in reverse, carrying  suffix = sum_{j in later chunks} g_j w_j
+    const float ga = g_acc[ray], gd = g_depth[ray];
+    float suffix = 0.0f;
+    for (int ch = nch - 1; ch >= 0; --ch) {
+        const int k = ch * 64 + lane;
+        float gk = 0.f, wk = 0.f, sig = 0.f, z = 0.f, dist = 0.f, alpha = 0.f, v = 1.0f;
+        if (k < S) {
+            z = sample_z(f, rs.t_min, k, jit, hj);
+            dist = (k + 1 < S) ? mul_rn(sub_rn(sample_z(f, rs.t_min, k + 1, jit, hj), z), f.distance_scale) : 0.0f;
+            sig = sigma[(size_t)ray * S + k];
+            wk = weight[(size_t)ray * S + k];
+            gk = gw[(size_t)ray * S + k] + ga + z * gd;
+            alpha = 1.0f - expf(-sig * dist);
+            v = add_rn(sub_rn(1.0f, alpha), 1e-10f);
+        }
+        const float a = gk * wk;
+        // sum of a over the lanes AFTER this one: a reverse scan of the shifted values (never `total - prefix`:
+        // deep inside an opaque region both are ~1e-8 while the true suffix is 0, and it is divided by v ~ 1e-10)
+        float rsum = __shfl_down(a, 1, 64);
+        if (lane == 63) rsum = 0.0f;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float o = __shfl_down(rsum, d, 64);
+            if (lane + d < 64) rsum += o;
+        }
+        const float total = __shfl(rsum, 0, 64) + __shfl(a, 0, 64);
+        const float sfx = suffix + rsum;
+        const float incl = scan_prod<64>(v, lane);
+        const float excl = shift_up1<64>(incl, lane);
+        const float Tk = tstart[wv][ch] * excl;
+        // w_k = alpha_k T_k, w_j (j > k) is proportional to (1 - alpha_k + 1e-10)
+        const float dalpha = gk * Tk - sfx / v;
+        const float dsig = dalpha * dist * expf(-sig * dist);              // d alpha / d sigma = dist exp(-sigma dist)
+        const float df = (f.act == 1) ? (sig > 0.f ? dsig : 0.f) : dsig * (-expm1f(-sig));      // softplus' = sigmoid = 1 - e^-sigma (expm1: no cancellation for small sigma)
+        suffix += total;
+        if (g_feat_out && k < S) g_feat_out[(size_t)ray * S + k] = df;
+        const bool on = (k < S) && (df != 0.0f);
+        float x = 0.f, y = 0.f, zz = 0.f;
+        if (on) {
+            x = norm_coord(add_rn(rs.o[0], mul_rn(rs.d[0], z)), f.aabb_min[0], f.inv_aabb[0]);
+            y = norm_coord(add_rn(rs.o[1], mul_rn(rs.d[1], z)), f.aabb_min[1], f.inv_aabb[1]);
+            zz = norm_coord(add_rn(rs.o[2], mul_rn(rs.d[2], z)), f.aabb_min[2], f.inv_aabb[2]);
+        }
+        // wave-collective scatter: compact the active samples, C4 lanes per sample, 16 B of every tap per lane
+        const unsigned long long m = __ballot(on);
+        const int n = __popcll(m);
+        if (n == 0) continue;
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (on) { wl[rank * 4] = x; wl[rank * 4 + 1] = y; wl[rank * 4 + 2] = zz; wl[rank * 4 + 3] = df; }
+        __builtin_amdgcn_wave_barrier();
+        constexpr int PER = 64 / C4;
+        const int slot_in = lane / C4, c = lane % C4;
+        for (int base = 0; base < n; base += PER) {
+            const int slot = base + slot_in;
+            if (slot < n) {
+                const float4 p = *reinterpret_cast<const float4*>(wl + slot * 4);
+                scatter_density<C4, false>(f, g, p.x, p.y, p.z, c, p.w, 0.f, 0.f, 0.f);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the derived normal n = -g / max(|g|, 1e-6), g = softplus'(feat + shift) * grad feat
+// C4 adjacent lanes per sample.
+// ------------------------------------------------------------------------------------------------
+template <int C4>
+__global__ void __launch_bounds__(256)
+k_density_grad_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, const float* __restrict__ g_normal, int64_t n) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = tid / C4;
+    const int c = (int)(tid % C4);
+    const bool on = i < n;
+    const int64_t ic = on ? i : n - 1;
+    const float p[3] = {xyz[3 * ic], xyz[3 * ic + 1], xyz[3 * ic + 2]};
+    // forward recompute: this lane's partial sums over its 4 channels
+    float feat = 0.f, gr[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int m0 = (k == 2) ? 1 : 0, m1 = (k == 0) ? 1 : 2, vi = 2 - k;
+        const int H = f.grid[m1], W = f.grid[m0], R = f.grid[vi];
+        Tap1 tx = make_tap(p[m0], W), ty = make_tap(p[m1], H), tl = make_tap(p[vi], R);
+        const float wx0 = 1.0f - tx.t, wx1 = tx.t, wy0 = 1.0f - ty.t, wy1 = ty.t;
+        const float* pl = f.dplane[k] + 4 * c;
+        const float4 a4 = ld4(pl + ((size_t)ty.i0 * W + tx.i0) * (C4 * 4)), b4 = ld4(pl + ((size_t)ty.i0 * W + tx.i1) * (C4 * 4));
+        const float4 c4 = ld4(pl + ((size_t)ty.i1 * W + tx.i0) * (C4 * 4)), d4 = ld4(pl + ((size_t)ty.i1 * W + tx.i1) * (C4 * 4));
+        const float4 e4 = ld4(f.dline[k] + (size_t)tl.i0 * (C4 * 4) + 4 * c), g4 = ld4(f.dline[k] + (size_t)tl.i1 * (C4 * 4) + 4 * c);
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+        const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+        const float ev[4] = {e4.x, e4.y, e4.z, e4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+        float s_val = 0.f, s_du = 0.f, s_dv = 0.f, s_dw = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float P = fmaf(dv[q], wx1 * wy1, fmaf(cv[q], wx0 * wy1, fmaf(bv[q], wx1 * wy0, av[q] * (wx0 * wy0))));
+            const float Pu = fmaf(dv[q] - cv[q], wy1, (bv[q] - av[q]) * wy0);
+            const float Pv = fmaf(dv[q] - bv[q], wx1, (cv[q] - av[q]) * wx0);
+            const float L = fmaf(gv[q], tl.t, ev[q] * (1.0f - tl.t));
+            s_val = fmaf(P, L, s_val); s_du = fmaf(Pu, L, s_du); s_dv = fmaf(Pv, L, s_dv);
+            s_dw = fmaf(P, gv[q] - ev[q], s_dw);
+        }
+        feat += s_val;
+        gr[m0] += s_du * (0.5f * (float)(W - 1));
+        gr[m1] += s_dv * (0.5f * (float)(H - 1));
+        gr[vi] += s_dw * (0.5f * (float)(R - 1));
+    }
+#pragma unroll
+    for (int d = 1; d < C4; d <<= 1) {
+        feat += __shfl_xor(feat, d, 64);
+        gr[0] += __shfl_xor(gr[0], d, 64); gr[1] += __shfl_xor(gr[1], d, 64); gr[2] += __shfl_xor(gr[2], d, 64);
+    }
+    if (!on) return;
+    float ds, dds;         // softplus' and softplus''
+    if (f.act == 1) { ds = feat > 0.f ? 1.f : 0.f; dds = 0.f; }
+    else {
+        const float x = feat + f.density_shift;
+        if (x > 20.f) { ds = 1.f; dds = 0.f; }
+        else { ds = 1.0f / (1.0f + expf(-x)); dds = ds * (1.0f - ds); }
+    }
+    const float gx = ds * gr[0], gy = ds * gr[1], gz = ds * gr[2];
+    const float nrm = sqrtf(gx * gx + gy * gy + gz * gz);
+    const float dn[3] = {g_normal[3 * i], g_normal[3 * i + 1], g_normal[3 * i + 2]};
+    float dg[3];
+    if (nrm > 1e-6f) {                     // n = -g/|g|:  dg = -(dn - n (n . dn)) / |g|
+        const float nx = -gx / nrm, ny = -gy / nrm, nz = -gz / nrm;
+        const float dot = nx * dn[0] + ny * dn[1] + nz * dn[2];
+        dg[0] = -(dn[0] - nx * dot) / nrm; dg[1] = -(dn[1] - ny * dot) / nrm; dg[2] = -(dn[2] - nz * dot) / nrm;
+    } else { dg[0] = -dn[0] / 1e-6f; dg[1] = -dn[1] / 1e-6f; dg[2] = -dn[2] / 1e-6f; }
+    const float F = (dg[0] * gr[0] + dg[1] * gr[1] + dg[2] * gr[2]) * dds;
+    scatter_density<C4, true>(f, g, p[0], p[1], p[2], c, F, ds * dg[0], ds * dg[1], ds * dg[2]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of compositing + tone mapping: one thread per ray walks its records (as the forward does).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float srgb_grad(float x) {       // d linear2srgb / dx incl. the [0,1] clip (pass-through inclusive)
+    if (!(x >= 0.0f && x <= 1.0f)) return 0.0f;
+    if (x <= 0.0031308f) return 12.92f;
+    return 1.055f * 0.41666666666666667f * powf(x + 1e-6f, 0.41666666666666667f - 1.0f);
+}
+__device__ __forceinline__ float clip01_grad(float x) { return (x >= 0.0f && x <= 1.0f) ? 1.0f : 0.0f; }
+
+// relative smoothness term ((a - b) / max(max(a, b), 1e-6))^2  (models/tensorBase_rotated_lights.py:858-863)
+__device__ __forceinline__ void rel_smooth_grad(float a, float b, float& da, float& db) {
+    const float mx = fmaxf(a, b);
+    const float base = fmaxf(mx, 1e-6f);
+    const float dlt = (a - b) / base;
+    // d base: through the clip only when mx >= 1e-6; torch.maximum sends the gradient to the larger (half each on ties)
+    float ba = 0.f, bb = 0.f;
+    if (mx >= 1e-6f) { if (a > b) ba = 1.f; else if (b > a) bb = 1.f; else { ba = 0.5f; bb = 0.5f; } }
+    const float ddlt = 2.0f * dlt;
+    const float dbase = -ddlt * (a - b) / (base * base);
+    da = ddlt / base + dbase * ba;
+    db = -ddlt / base + dbase * bb;
+}
+
+__global__ void __launch_bounds__(64)
+k_composite_primary_bwd(const float* __restrict__ rays, const int32_t* __restrict__ offsets,
+                        const int32_t* __restrict__ rec_k, const float* __restrict__ rec_w,
+                        const float* __restrict__ rgb, const float* __restrict__ brdf,
+                        const float* __restrict__ brdf_jit, const float* __restrict__ pred_n,
+                        const float* __restrict__ der_n, const float* __restrict__ acc_in,
+                        const float* __restrict__ depth_in, int B, int S, int white_bg, int is_relight,
+                        float fixed_fresnel, const float* __restrict__ g_maps, float* __restrict__ g_rgb,
+                        float* __restrict__ g_brdf, float* __restrict__ g_brdf_jit, float* __restrict__ g_pred,
+                        float* __restrict__ g_der, float* __restrict__ g_weight, float* __restrict__ g_acc_out,
+                        float* __restrict__ g_depth_out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= B) return;
+    const int b = offsets[r], e = offsets[r + 1];
+    const float* go = g_maps + (size_t)r * TIR_MAP_STRIDE;
+    const float vd[3] = {rays[6 * (size_t)r + 3], rays[6 * (size_t)r + 4], rays[6 * (size_t)r + 5]};
+    // ---- recompute the forward sums (same order as k_composite_primary) ----
+    float c[3] = {0, 0, 0}, nm[3] = {0, 0, 0}, al[3] = {0, 0, 0}, rough = 0;
+    for (int i = b; i < e; ++i) {
+        const float w = rec_w[i];
+        if (rgb) { c[0] = fmaf(w, rgb[3 * (size_t)i], c[0]); c[1] = fmaf(w, rgb[3 * (size_t)i + 1], c[1]); c[2] = fmaf(w, rgb[3 * (size_t)i + 2], c[2]); }
+        if (!is_relight) continue;
+        if (brdf) {
+            al[0] = fmaf(w, brdf[4 * (size_t)i], al[0]); al[1] = fmaf(w, brdf[4 * (size_t)i + 1], al[1]); al[2] = fmaf(w, brdf[4 * (size_t)i + 2], al[2]);
+            rough = fmaf(w, brdf[4 * (size_t)i + 3] * 0.9f + 0.09f, rough);
+        }
+        if (pred_n) { nm[0] = fmaf(w, pred_n[3 * (size_t)i], nm[0]); nm[1] = fmaf(w, pred_n[3 * (size_t)i + 1], nm[1]); nm[2] = fmaf(w, pred_n[3 * (size_t)i + 2], nm[2]); }
+    }
+    const float acc = acc_in[r];
+    const float bg = 1.0f - acc;
+    float g_acc = go[14];
+    const float g_depth = go[3];
+    float gc[3], gnm[3] = {0, 0, 0}, gal[3] = {0, 0, 0}, grough = 0.f;
+    float g15 = 0.f, g16 = 0.f, g17 = 0.f, g18 = 0.f;
+    if (white_bg) g_acc -= g_depth * rays[6 * (size_t)r + 5];
+    if (!is_relight) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { gc[q] = go[q]; if (white_bg) g_acc -= gc[q]; }
+    } else {
+        float fr = fixed_fresnel;
+        if (white_bg) { c[0] += bg; c[1] += bg; c[2] += bg; nm[2] += bg; al[0] += bg; al[1] += bg; al[2] += bg; rough += bg; fr += bg; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            gc[q] = go[q] * srgb_grad(c[q]);
+            gal[q] = go[7 + q] * clip01_grad(al[q]);
+        }
+        grough = go[10] * clip01_grad(rough);
+        const float gfr = (go[11] + go[12] + go[13]) * clip01_grad(fr);
+        // safe_l2_normalize(v) = v / max(|v|, 1e-6)
+        const float nn = sqrtf(nm[0] * nm[0] + nm[1] * nm[1] + nm[2] * nm[2]);
+        if (nn > 1e-6f) {
+            const float n0 = nm[0] / nn, n1 = nm[1] / nn, n2 = nm[2] / nn;
+            const float dot = n0 * go[4] + n1 * go[5] + n2 * go[6];
+            gnm[0] = (go[4] - n0 * dot) / nn; gnm[1] = (go[5] - n1 * dot) / nn; gnm[2] = (go[6] - n2 * dot) / nn;
+        } else { gnm[0] = go[4] / 1e-6f; gnm[1] = go[5] / 1e-6f; gnm[2] = go[6] / 1e-6f; }
+        if (white_bg) g_acc -= gc[0] + gc[1] + gc[2] + gnm[2] + gal[0] + gal[1] + gal[2] + grough + gfr;
+        g15 = go[15]; g16 = go[16]; g17 = go[17]; g18 = go[18];
+    }
+    g_acc_out[r] = g_acc;
+    g_depth_out[r] = g_depth;
+    // ---- per-record gradients ----
+    for (int i = b; i < e; ++i) {
+        const float w = rec_w[i];
+        float gw = 0.f;
+        if (rgb) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { gw = fmaf(rgb[3 * (size_t)i + q], gc[q], gw); g_rgb[3 * (size_t)i + q] = w * gc[q]; }
+        }
+        if (is_relight) {
+            float a3[3] = {0, 0, 0}, rg = 0.f;
+            float gb[4] = {0, 0, 0, 0}, gbj[4] = {0, 0, 0, 0};
+            if (brdf) {
+                a3[0] = brdf[4 * (size_t)i]; a3[1] = brdf[4 * (size_t)i + 1]; a3[2] = brdf[4 * (size_t)i + 2];
+                rg = brdf[4 * (size_t)i + 3] * 0.9f + 0.09f;
+                gw += a3[0] * gal[0] + a3[1] * gal[1] + a3[2] * gal[2] + rg * grough;
+                gb[0] = w * gal[0]; gb[1] = w * gal[1]; gb[2] = w * gal[2]; gb[3] = w * grough * 0.9f;
+            }
+            if (brdf && brdf_jit) {
+                float cost = 0.f;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float aj = brdf_jit[4 * (size_t)i + q];
+                    const float base = fmaxf(fmaxf(a3[q], aj), 1e-6f);
+                    const float dlt = (a3[q] - aj) / base;
+                    cost = fmaf(dlt, dlt, cost);
+                    float da, db;
+                    rel_smooth_grad(a3[q], aj, da, db);
+                    gb[q] = fmaf(w * g17, da, gb[q]);
+                    gbj[q] = w * g17 * db;
+                }
+                const float rj = brdf_jit[4 * (size_t)i + 3] * 0.9f + 0.09f;
+                const float base = fmaxf(fmaxf(rg, rj), 1e-6f);
+                const float dlt = (rg - rj) / base;
+                float da, db;
+                rel_smooth_grad(rg, rj, da, db);
+                gb[3] = fmaf(w * g18 * 0.9f, da, gb[3]);
+                gbj[3] = w * g18 * 0.9f * db;
+                gw += cost * g17 + dlt * dlt * g18;
+            }
+            if (g_brdf && brdf) { g_brdf[4 * (size_t)i] = gb[0]; g_brdf[4 * (size_t)i + 1] = gb[1]; g_brdf[4 * (size_t)i + 2] = gb[2]; g_brdf[4 * (size_t)i + 3] = gb[3]; }
+            if (g_brdf_jit && brdf_jit) { g_brdf_jit[4 * (size_t)i] = gbj[0]; g_brdf_jit[4 * (size_t)i + 1] = gbj[1]; g_brdf_jit[4 * (size_t)i + 2] = gbj[2]; g_brdf_jit[4 * (size_t)i + 3] = gbj[3]; }
+            if (pred_n) {
+                const float p3[3] = {pred_n[3 * (size_t)i], pred_n[3 * (size_t)i + 1], pred_n[3 * (size_t)i + 2]};
+                float gp[3] = {w * gnm[0], w * gnm[1], w * gnm[2]};
+                gw += p3[0] * gnm[0] + p3[1] * gnm[1] + p3[2] * gnm[2];
+                if (der_n) {
+                    const float d0 = p3[0] - der_n[3 * (size_t)i], d1 = p3[1] - der_n[3 * (size_t)i + 1], d2 = p3[2] - der_n[3 * (size_t)i + 2];
+                    gw += (d0 * d0 + d1 * d1 + d2 * d2) * g15;
+                    const float s = 2.0f * w * g15;
+                    gp[0] = fmaf(s, d0, gp[0]); gp[1] = fmaf(s, d1, gp[1]); gp[2] = fmaf(s, d2, gp[2]);
+                    if (g_der) { g_der[3 * (size_t)i] = -s * d0; g_der[3 * (size_t)i + 1] = -s * d1; g_der[3 * (size_t)i + 2] = -s * d2; }
+                }
+                const float dot = vd[0] * p3[0] + vd[1] * p3[1] + vd[2] * p3[2];
+                if (dot > 0.f) {                       // clamp(min=0): gradient passes for dot > 0
+                    gw += dot * g16;
+                    gp[0] = fmaf(w * g16, vd[0], gp[0]); gp[1] = fmaf(w * g16, vd[1], gp[1]); gp[2] = fmaf(w * g16, vd[2], gp[2]);
+                }
+                if (g_pred) { g_pred[3 * (size_t)i] = gp[0]; g_pred[3 * (size_t)i + 1] = gp[1]; g_pred[3 * (size_t)i + 2] = gp[2]; }
+            }
+        }
+        g_weight[(size_t)r * S + rec_k[i]] = gw;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the appearance feature (compute_bothfeature / compute_appfeature / compute_intrinfeature):
+// 4 adjacent lanes per sample, each lane owning 16 B of every 64 B run of a tap (as the forward gather).
+// ------------------------------------------------------------------------------------------------
+#define TIR_APP_MAX_L 16
+
+template <int C4, bool RAD, bool INTR>
+__global__ void __launch_bounds__(256)
+k_vm_app_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
+             const int32_t* __restrict__ idx_map, const float* __restrict__ g_rad, const float* __restrict__ g_int,
+             int stride, int64_t n, float* __restrict__ y_rad, float* __restrict__ y_int) {
+    constexpr int CA = C4 * 4;
+    extern __shared__ __attribute__((aligned(16))) float lds_ab[];
+    float* Wt = lds_ab;                              // [3*CA][32] basis_mat^T
+    float* gl = lds_ab + 3 * CA * 32;                // [(n_lights + 1)][3*CA] block-local light_line / light_mean gradient
+    const int nl = min(f.n_lights, TIR_APP_MAX_L);
+    for (int i = threadIdx.x * 4; i < 3 * CA * 32; i += 256 * 4)
+        *reinterpret_cast<float4*>(Wt + i) = *reinterpret_cast<const float4*>(f.basis_t + i);
+    for (int i = threadIdx.x; i < (nl + 1) * 3 * CA; i += 256) gl[i] = 0.0f;
+    __syncthreads();
+    const int L = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = L >> 2, c = L & 3;
+    const int64_t n_pass = (n + 15) / 16;
+    for (int64_t pass = (int64_t)blockIdx.x * 4 + wave; pass < n_pass; pass += (int64_t)gridDim.x * 4) {
+        const int64_t s = pass * 16 + j;
+        const bool on = s < n;
+        const int64_t sc = on ? s : n - 1;
+        const float p[3] = {xyz[3 * sc], xyz[3 * sc + 1], xyz[3 * sc + 2]};
+        int li = 0;
+        if (RAD) {
+            const int64_t lsel = idx_map ? (int64_t)idx_map[sc] : sc;
+            li = min(max(light_idx[lsel], 0), f.n_lights - 1);
+        }
+        float gr[27], gi[27];
+#pragma unroll
+        for (int q = 0; q < 27; ++q) {
+            gr[q] = (RAD && on && q < f.app_dim) ? g_rad[sc * stride + q] : 0.f;
+            gi[q] = (INTR && on && q < f.app_dim) ? g_int[sc * stride + q] : 0.f;
+        }
+#pragma unroll 1
+        for (int k = 0; k < 3; ++k) {
+            const int m0 = (k == 2) ? 1 : 0, m1 = (k == 0) ? 1 : 2, vi = 2 - k;
+            const int H = f.grid[m1], W = f.grid[m0], R = f.grid[vi];
+            Tap1 tx = make_tap(p[m0], W), ty = make_tap(p[m1], H), tl = make_tap(p[vi], R);
+            const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
+            const size_t o00 = ((size_t)ty.i0 * W + tx.i0) * CA, o01 = ((size_t)ty.i0 * W + tx.i1) * CA;
+            const size_t o10 = ((size_t)ty.i1 * W + tx.i0) * CA, o11 = ((size_t)ty.i1 * W + tx.i1) * CA;
+            const size_t q0 = (size_t)tl.i0 * CA, q1 = (size_t)tl.i1 * CA;
+            const float* pl = f.aplane[k];
+            const float* ln = f.aline[k];
+#pragma unroll 1
+            for (int q = 0; q < (C4 + 3) / 4; ++q) {
+                const int ch4 = 4 * q + c;
+                if (ch4 >= C4) continue;
+                const int ch = k * CA + 4 * ch4;               // first of this lane's 4 channels
+                const float4 a4 = ld4(pl + o00 + 4 * ch4), b4 = ld4(pl + o01 + 4 * ch4), c4 = ld4(pl + o10 + 4 * ch4), d4 = ld4(pl + o11 + 4 * ch4);
+                const float4 e4 = ld4(ln + q0 + 4 * ch4), g4 = ld4(ln + q1 + 4 * ch4);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+                const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+                const float ev[4] = {e4.x, e4.y, e4.z, e4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+                float lrv[4] = {0, 0, 0, 0}, lmv[4] = {0, 0, 0, 0};
+                if (RAD) { const float4 t = ld4(f.light_line + (size_t)li * (3 * CA) + ch); lrv[0] = t.x; lrv[1] = t.y; lrv[2] = t.z; lrv[3] = t.w; }
+                if (INTR) { const float4 t = ld4(f.light_mean + ch); lmv[0] = t.x; lmv[1] = t.y; lmv[2] = t.z; lmv[3] = t.w; }
+                float yr[4], yi[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    // d (pl (.) light)[ch+u] = basis_mat[:, ch+u] . g_feat
+                    const float* wr = Wt + (size_t)(ch + u) * 32;
+                    float dyr = 0.f, dyi = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 27; ++t) {
+                        const float bw = wr[t];
+                        if (RAD) dyr = fmaf(bw, gr[t], dyr);
+                        if (INTR) dyi = fmaf(bw, gi[t], dyi);
+                    }
+                    const float P = fmaf(dv[u], w11, fmaf(cv[u], w10, fmaf(bv[u], w01, av[u] * w00)));
+                    const float Ln = fmaf(gv[u], tl.w1, ev[u] * tl.w0);
+                    const float plv = P * Ln;
+                    yr[u] = plv * lrv[u]; yi[u] = plv * lmv[u];
+                    if (!on) continue;
+                    if (RAD && dyr != 0.f) {
+                        if (f.n_lights <= TIR_APP_MAX_L) atomicAdd(gl + li * (3 * CA) + ch + u, dyr * plv);
+                        else atomic_add_f32(g.light_line + (size_t)li * (3 * CA) + ch + u, dyr * plv);
+                    }
+                    if (INTR && dyi != 0.f) atomicAdd(gl + nl * (3 * CA) + ch + u, dyi * plv);
+                    const float dpl = dyr * lrv[u] + dyi * lmv[u];
+                    if (dpl == 0.f) continue;
+                    const float dP = dpl * Ln, dL = dpl * P;
+                    if (w00 != 0.f) atomic_add_f32(g.aplane[k] + o00 + 4 * ch4 + u, dP * w00);
+                    if (w01 != 0.f) atomic_add_f32(g.aplane[k] + o01 + 4 * ch4 + u, dP * w01);
+                    if (w10 != 0.f) atomic_add_f32(g.aplane[k] + o10 + 4 * ch4 + u, dP * w10);
+                    if (w11 != 0.f) atomic_add_f32(g.aplane[k] + o11 + 4 * ch4 + u, dP * w11);
+                    if (tl.w0 != 0.f) atomic_add_f32(g.aline[k] + q0 + 4 * ch4 + u, dL * tl.w0);
+                    if (tl.w1 != 0.f) atomic_add_f32(g.aline[k] + q1 + 4 * ch4 + u, dL * tl.w1);
+                }
+                if (on) {
+                    if (RAD && y_rad) *reinterpret_cast<float4*>(y_rad + s * (3 * CA) + ch) = make_float4(yr[0], yr[1], yr[2], yr[3]);
+                    if (INTR && y_int) *reinterpret_cast<float4*>(y_int + s * (3 * CA) + ch) = make_float4(yi[0], yi[1], yi[2], yi[3]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (nl + 1) * 3 * CA; i += 256) {
+        const float v = gl[i];
+        if (v == 0.f) continue;
+        if (i < nl * 3 * CA) { if (RAD && f.n_lights <= TIR_APP_MAX_L) atomic_add_f32(g.light_line + i, v); }
+        else if (INTR) atomic_add_f32(g.light_mean + (i - nl * 3 * CA), v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C[M][ldc] += A^T B  (A [n][lda], B [n][ldb]), fp32 MFMA 32x32x2, split over n, atomics into C.
+// 4 waves; wave w owns rows 32w..32w+31 of C and all (<= 5) column tiles.
+// ------------------------------------------------------------------------------------------------
+#define GT_AS 160      // LDS row strides == 32 mod 64 banks: the two k rows of an MFMA step hit disjoint banks
+#define GT_BS 224
+
+__global__ void __launch_bounds__(256)
+k_gemm_tn(const float* __restrict__ A, int lda, int M, const float* __restrict__ Bm, int ldb, int N, int ones_col,
+          int64_t n, float* __restrict__ C, int ldc, int64_t chunk) {
+    __shared__ __attribute__((aligned(16))) float As[32 * GT_AS];
+    __shared__ __attribute__((aligned(16))) float Bs[32 * GT_BS];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int NT = (N + ones_col + 31) / 32;
+    const int64_t s0 = (int64_t)blockIdx.x * chunk;
+    const int64_t s1 = min(n, s0 + chunk);
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int Mp = (M + 3) & ~3, Np = (N + 3) & ~3;
+    for (int64_t s = s0; s < s1; s += 32) {
+        for (int e = threadIdx.x; e < 32 * 32; e += 256) {          // A slab: 32 rows x 128 cols (float4 granules)
+            const int row = e >> 5, c4 = (e & 31) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s + row < s1 && c4 < Mp) v = *reinterpret_cast<const float4*>(A + (s + row) * lda + c4);
+            *reinterpret_cast<float4*>(As + row * GT_AS + c4) = v;
+        }
+        for (int e = threadIdx.x; e < 32 * 40; e += 256) {          // B slab: 32 rows x 160 cols
+            const int row = e / 40, c4 = (e % 40) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool live = s + row < s1;
+            if (live && c4 < Np) v = *reinterpret_cast<const float4*>(Bm + (s + row) * ldb + c4);
+            if (c4 >= N) { v.x = 0.f; v.y = 0.f; v.z = 0.f; v.w = 0.f; }
+            else if (c4 + 3 >= N) { if (c4 + 1 >= N) v.y = 0.f; if (c4 + 2 >= N) v.z = 0.f; v.w = 0.f; }
+            if (ones_col && live && N >= c4 && N < c4 + 4) { float* pv = &v.x; pv[N - c4] = 1.0f; }
+            *reinterpret_cast<float4*>(Bs + row * GT_BS + c4) = v;
+        }
+        __syncthreads();
+        if (32 * w < M) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int kk = 2 * t + h;
+                const float a = As[kk * GT_AS + 32 * w + li];
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt)
+                    if (nt < NT) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[kk * GT_BS + 32 * nt + li], acc[nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (32 * w >= M) return;
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) {
+        if (nt >= NT) continue;
+        const int jcol = 32 * nt + li;
+        if (jcol >= N + ones_col) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (i < M && acc[nt][r] != 0.f) atomic_add_f32(C + (size_t)i * ldc + jcol, acc[nt][r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shading backward: one wave per surface point, lanes over light directions.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void normalize3(float& x, float& y, float& z, float eps) {
+    const float n = fmaxf(sqrtf(x * x + y * y + z * z), eps);
+    x /= n; y /= n; z /= n;
+}
+__device__ __forceinline__ float clamp_pass(float raw, float lo, float hi) { return (raw >= lo && raw <= hi) ? 1.0f : 0.0f; }
+
+__global__ void __launch_bounds__(256)
+k_shade_integrate_bwd(const float* __restrict__ maps, const float* __restrict__ rays, const float* __restrict__ dirs,
+                      const int32_t* __restrict__ light_idx, const float* __restrict__ vis,
+                      const float* __restrict__ indirect, const float* __restrict__ env,
+                      const float* __restrict__ weight_d, int M, int D, int n_lights, int equal_area, int use_srgb,
+                      float acc_thres, const float* __restrict__ g_out, float* __restrict__ g_maps,
+                      float* __restrict__ g_env) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* mp = maps + (size_t)m * TIR_MAP_STRIDE;
+    float* gm = g_maps + (size_t)m * TIR_MAP_STRIDE;
+    if (lane < TIR_MAP_STRIDE) gm[lane] = 0.0f;
+    if (!(mp[14] > acc_thres)) return;                       // background row: constant output
+    const float PI = 3.14159265358979323846f, four_pi = 4.0f * PI;
+    const float* r = rays + 6 * (size_t)m;
+    float V[3] = {-r[3], -r[4], -r[5]};
+    normalize3(V[0], V[1], V[2], 1e-6f);                      // safe_l2_normalize(-rays_d)
+    normalize3(V[0], V[1], V[2], 1e-12f);                     // F.normalize inside GGX_specular
+    const float nraw[3] = {mp[4], mp[5], mp[6]};
+    const float nlen = fmaxf(sqrtf(nraw[0] * nraw[0] + nraw[1] * nraw[1] + nraw[2] * nraw[2]), 1e-12f);
+    const float Nn[3] = {nraw[0] / nlen, nraw[1] / nlen, nraw[2] / nlen};
+    const float nov0 = V[0] * Nn[0] + V[1] * Nn[1] + V[2] * Nn[2];
+    const float sg = (nov0 > 0.f) ? 1.f : ((nov0 < 0.f) ? -1.f : 0.f);
+    const float N[3] = {Nn[0] * sg, Nn[1] * sg, Nn[2] * sg};
+    const float nov_raw = N[0] * V[0] + N[1] * V[1] + N[2] * V[2];
+    const float NoV = fminf(fmaxf(nov_raw, 1e-6f), 1.f);
+    const float rr = mp[10];
+    const float a1 = rr * rr, a2 = a1 * a1, kk = (a1 + 2.f * rr + 1.0f) / 8.0f;
+    const float F0[3] = {mp[11], mp[12], mp[13]};
+    const float alb_pi[3] = {mp[7] / PI, mp[8] / PI, mp[9] / PI};
+    int li = light_idx ? light_idx[m] : 0;
+    li = min(max(li, 0), n_lights - 1);
+    const float* envl = env + (size_t)li * D * 3;
+    // pass 1: forward totals (for the clip / sRGB derivative)
+    float c[3] = {0.f, 0.f, 0.f};
+    for (int d = lane; d < D; d += 64) {
+        float lx = dirs[3 * d], ly = dirs[3 * d + 1], lz = dirs[3 * d + 2];
+        const float cosine = fmaxf(lx * nraw[0] + ly * nraw[1] + lz * nraw[2], 0.f);
+        normalize3(lx, ly, lz, 1e-12f);
+        float hx = (lx + V[0]) / 2.0f, hy = (ly + V[1]) / 2.0f, hz = (lz + V[2]) / 2.0f;
+        normalize3(hx, hy, hz, 1e-12f);
+        const float NoL = fminf(fmaxf(N[0] * lx + N[1] * ly + N[2] * lz, 1e-6f), 1.f);
+        const float NoH = fminf(fmaxf(N[0] * hx + N[1] * hy + N[2] * hz, 1e-6f), 1.f);
+        const float VoH = fminf(fmaxf(V[0] * hx + V[1] * hy + V[2] * hz, 1e-6f), 1.f);
+        const float p2 = exp2f(((-5.55473f) * VoH - 6.98316f) * VoH);
+        const size_t md = (size_t)m * D + d;
+        const float v = vis[md], wd = equal_area ? four_pi : weight_d[d];
+        const float nom0 = NoH * NoH * (a2 - 1.f) + 1.f, nom1 = NoV * (1.f - kk) + kk, nom2 = NoL * (1.f - kk) + kk;
+        const float nom = fminf(fmaxf(four_pi * nom0 * nom0 * nom1 * nom2, 1e-6f), four_pi);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float spec = (F0[q] + (1.f - F0[q]) * p2) * a2 / nom;
+            const float light = v * envl[3 * d + q] + (indirect ? indirect[3 * md + q] : 0.f);
+            c[q] += (alb_pi[q] + spec) * light * cosine * wd;
+        }
+    }
+    float gt[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        float t = group_sum<64>(c[q]);
+        if (equal_area) t /= (float)D;
+        const float go = g_out[3 * (size_t)m + q];
+        gt[q] = use_srgb ? go * srgb_grad(t) : go * clip01_grad(t);
+        if (equal_area) gt[q] /= (float)D;
+    }
+    // pass 2: per-direction chain rule
+    float gN[3] = {0, 0, 0}, gnraw[3] = {0, 0, 0}, galb[3] = {0, 0, 0}, gF0[3] = {0, 0, 0};
+    float gNoV = 0.f, grough = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float l0 = dirs[3 * d], l1 = dirs[3 * d + 1], l2 = dirs[3 * d + 2];
+        float lx = l0, ly = l1, lz = l2;
+        const float cos_raw = l0 * nraw[0] + l1 * nraw[1] + l2 * nraw[2];
+        const float cosine = fmaxf(cos_raw, 0.f);
+        normalize3(lx, ly, lz, 1e-12f);
+        float hx = (lx + V[0]) / 2.0f, hy = (ly + V[1]) / 2.0f, hz = (lz + V[2]) / 2.0f;
+        normalize3(hx, hy, hz, 1e-12f);
+        const float nol_raw = N[0] * lx + N[1] * ly + N[2] * lz, noh_raw = N[0] * hx + N[1] * hy + N[2] * hz;
+        const float NoL = fminf(fmaxf(nol_raw, 1e-6f), 1.f), NoH = fminf(fmaxf(noh_raw, 1e-6f), 1.f);
+        const float VoH = fminf(fmaxf(V[0] * hx + V[1] * hy + V[2] * hz, 1e-6f), 1.f);
+        const float p2 = exp2f(((-5.55473f) * VoH - 6.98316f) * VoH);
+        const size_t md = (size_t)m * D + d;
+        const float v = vis[md], wd = equal_area ? four_pi : weight_d[d];
+        const float nom0 = NoH * NoH * (a2 - 1.f) + 1.f, nom1 = NoV * (1.f - kk) + kk, nom2 = NoL * (1.f - kk) + kk;
+        const float nom_raw = four_pi * nom0 * nom0 * nom1 * nom2;
+        const float nom = fminf(fmaxf(nom_raw, 1e-6f), four_pi);
+        const float nom_pass = clamp_pass(nom_raw, 1e-6f, four_pi);
+        float dcos = 0.f, dNoH = 0.f, dNoL = 0.f, dNoVd = 0.f, da2 = 0.f, dk = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float frac0 = F0[q] + (1.f - F0[q]) * p2;
+            const float frac = frac0 * a2;
+            const float spec = frac / nom;
+            const float direct = envl[3 * d + q];
+            const float light = v * direct + (indirect ? indirect[3 * md + q] : 0.f);
+            const float brdf = alb_pi[q] + spec;
+            const float gterm = gt[q] * wd;                       // cotangent of brdf * light * cosine
+            galb[q] += gterm * light * cosine / PI;
+            dcos += gterm * brdf * light;
+            if (g_env && v != 0.f) atomic_add_f32(g_env + ((size_t)li * D + d) * 3 + q, gterm * brdf * cosine * v);
+            const float gs = gterm * light * cosine;               // cotangent of spec
+            const float dfrac = gs / nom;
+            const float dnomr = -gs * frac / (nom * nom) * nom_pass;
+            const float dnom0 = dnomr * four_pi * 2.f * nom0 * nom1 * nom2;
+            const float dnom1 = dnomr * four_pi * nom0 * nom0 * nom2;
+            const float dnom2 = dnomr * four_pi * nom0 * nom0 * nom1;
+            da2 += dfrac * frac0 + dnom0 * NoH * NoH;
+            gF0[q] += dfrac * a2 * (1.f - p2);
+            dNoH += dnom0 * 2.f * NoH * (a2 - 1.f);
+            dNoVd += dnom1 * (1.f - kk);
+            dNoL += dnom2 * (1.f - kk);
+            dk += dnom1 * (1.f - NoV) + dnom2 * (1.f - NoL);
+        }
+        grough += da2 * 4.f * a1 * rr + dk * (2.f * rr + 2.f) / 8.0f;
+        gNoV += dNoVd;
+        dNoH *= clamp_pass(noh_raw, 1e-6f, 1.f);
+        dNoL *= clamp_pass(nol_raw, 1e-6f, 1.f);
+        gN[0] += dNoH * hx + dNoL * lx; gN[1] += dNoH * hy + dNoL * ly; gN[2] += dNoH * hz + dNoL * lz;
+        if (cos_raw > 0.f) { gnraw[0] += dcos * l0; gnraw[1] += dcos * l1; gnraw[2] += dcos * l2; }
+    }
+    gNoV = group_sum<64>(gNoV) * clamp_pass(nov_raw, 1e-6f, 1.f);
+    grough = group_sum<64>(grough);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        gN[q] = group_sum<64>(gN[q]) + gNoV * V[q];
+        gnraw[q] = group_sum<64>(gnraw[q]);
+        galb[q] = group_sum<64>(galb[q]);
+        gF0[q] = group_sum<64>(gF0[q]);
+    }
+    if (lane == 0) {
+        // N = sg * normalize(nraw)
+        const float dNn[3] = {gN[0] * sg, gN[1] * sg, gN[2] * sg};
+        const float dot = Nn[0] * dNn[0] + Nn[1] * dNn[1] + Nn[2] * dNn[2];
+        gm[4] = gnraw[0] + (dNn[0] - Nn[0] * dot) / nlen;
+        gm[5] = gnraw[1] + (dNn[1] - Nn[1] * dot) / nlen;
+        gm[6] = gnraw[2] + (dNn[2] - Nn[2] * dot) / nlen;
+        gm[7] = galb[0]; gm[8] = galb[1]; gm[9] = galb[2];
+        gm[10] = grough;
+        gm[11] = gF0[0]; gm[12] = gF0[1]; gm[13] = gF0[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SG environment backward: one block per SG, threads over (light, direction) pairs.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_env_sg_bwd(TirEnvSG e, const float* __restrict__ dirs, int D, const float* __restrict__ g_env, float* __restrict__ g_sgs) {
+    const int k = blockIdx.x;
+    const float* s = e.sgs + 7 * k;
+    const float nrm = sqrtf(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]);
+    const float u0 = s[0] / nrm, u1 = s[1] / nrm, u2 = s[2] / nrm;
+    const float lam = fabsf(s[3]);
+    const float sl = (s[3] > 0.f) ? 1.f : ((s[3] < 0.f) ? -1.f : 0.f);
+    float acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int ld = threadIdx.x; ld < e.n_lights * D; ld += blockDim.x) {
+        const int l = ld / D, d = ld % D;
+        const float v0 = dirs[3 * d], v1 = dirs[3 * d + 1], v2 = dirs[3 * d + 2];
+        const float* R = e.rot + 9 * l;
+        const float r0 = v0 * R[0] + v1 * R[3] + v2 * R[6];
+        const float r1 = v0 * R[1] + v1 * R[4] + v2 * R[7];
+        const float r2 = v0 * R[2] + v1 * R[5] + v2 * R[8];
+        const float dot = r0 * u0 + r1 * u1 + r2 * u2;
+        const float ex = expf(lam * (dot - 1.0f));
+        const float* go = g_env + 3 * (size_t)ld;
+        float G = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float mu = s[4 + q];
+            const float sm = (mu > 0.f) ? 1.f : ((mu < 0.f) ? -1.f : 0.f);
+            acc[4 + q] += sm * ex * go[q];
+            G += fabsf(mu) * go[q];
+        }
+        const float gex = G * ex;
+        acc[3] += sl * (dot - 1.0f) * gex;
+        const float gdot = lam * gex;
+        // dot = r . lobe / |lobe|
+        acc[0] += gdot * (r0 - u0 * dot) / nrm; acc[1] += gdot * (r1 - u1 * dot) / nrm; acc[2] += gdot * (r2 - u2 * dot) / nrm;
+    }
+    __shared__ float red[4][7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) acc[q] = group_sum<64>(acc[q]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int q = 0; q < 7; ++q) red[threadIdx.x >> 6][q] = acc[q];
+    __syncthreads();
+    if (threadIdx.x < 7) g_sgs[7 * k + threadIdx.x] += red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+int check_grad_field(const TirField* f, const TirFieldGrad* g, bool density, bool app) {
+    if (!f || !g) return TIR_ERR_ARG;
+    for (int i = 0; i < 3; ++i) {
+        if (f->grid[i] < 2) return TIR_ERR_ARG;
+        if (density && (!f->dplane[i] || !f->dline[i] || !g->dplane[i] || !g->dline[i])) return TIR_ERR_ARG;
+        if (app && (!f->aplane[i] || !f->aline[i] || !g->aplane[i] || !g->aline[i])) return TIR_ERR_ARG;
+    }
+    return TIR_OK;
+}
+
+}  // namespace
+
+extern "C" int tir_march_primary_bwd(const TirField* f, const TirFieldGrad* g, const float* rays,
+                                     const float* ray_jitter, int32_t B, int32_t S, const float* sigma,
+                                     const float* weight, const float* g_weight, const float* g_acc,
+                                     const float* g_depth, float* g_feature, void* stream) {
+    int rc = check_grad_field(f, g, true, false);
+    if (rc) return rc;
+    if (B < 0 || S <= 0) return TIR_ERR_ARG;
+    if (S > 64 * TIR_MAX_CHUNKS) return TIR_ERR_UNSUPPORTED;
+    if (B == 0) return TIR_OK;
+    if (!rays || !sigma || !weight || !g_weight || !g_acc || !g_depth) return TIR_ERR_ARG;
+    dim3 grid((B + 3) / 4), blk(256);
+    hipStream_t s = tir_stream(stream);
+    switch (f->n_dcomp) {
+        case 16: hipLaunchKernelGGL(k_march_primary_bwd<4>, grid, blk, 0, s, *f, *g, rays, ray_jitter, B, S, sigma, weight, g_weight, g_acc, g_depth, g_feature); break;
+        case 8:  hipLaunchKernelGGL(k_march_primary_bwd<2>, grid, blk, 0, s, *f, *g, rays, ray_jitter, B, S, sigma, weight, g_weight, g_acc, g_depth, g_feature); break;
+        case 32: hipLaunchKernelGGL(k_march_primary_bwd<8>, grid, blk, 0, s, *f, *g, rays, ray_jitter, B, S, sigma, weight, g_weight, g_acc, g_depth, g_feature); break;
+        case 4:  hipLaunchKernelGGL(k_march_primary_bwd<1>, grid, blk, 0, s, *f, *g, rays, ray_jitter, B, S, sigma, weight, g_weight, g_acc, g_depth, g_feature); break;
+        default: return TIR_ERR_UNSUPPORTED;
+    }
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_density_grad_bwd(const TirField* f, const TirFieldGrad* g, const float* xyz,
+                                    const float* g_normal, int64_t n, void* stream) {
+    int rc = check_grad_field(f, g, true, false);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!xyz || !g_normal))) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    hipStream_t s = tir_stream(stream);
+    const int c4 = f->n_dcomp / 4;
+    dim3 grid((unsigned)((n * c4 + 255) / 256)), blk(256);
+    switch (f->n_dcomp) {
+        case 16: hipLaunchKernelGGL(k_density_grad_bwd<4>, grid, blk, 0, s, *f, *g, xyz, g_normal, n); break;
+        case 8:  hipLaunchKernelGGL(k_density_grad_bwd<2>, grid, blk, 0, s, *f, *g, xyz, g_normal, n); break;
+        case 32: hipLaunchKernelGGL(k_density_grad_bwd<8>, grid, blk, 0, s, *f, *g, xyz, g_normal, n); break;
+        case 4:  hipLaunchKernelGGL(k_density_grad_bwd<1>, grid, blk, 0, s, *f, *g, xyz, g_normal, n); break;
+        default: return TIR_ERR_UNSUPPORTED;
+    }
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_composite_primary_bwd(const float* rays, const int32_t* offsets, const int32_t* rec_k,
+                                         const float* rec_w, const float* rgb, const float* brdf,
+                                         const float* brdf_jit, const float* pred_normal,
+                                         const float* derived_normal, const float* acc, const float* depth,
+                                         int32_t B, int32_t S, int32_t white_bg, int32_t is_relight,
+                                         float fixed_fresnel, const float* g_maps, float* g_rgb, float* g_brdf,
+                                         float* g_brdf_jit, float* g_pred, float* g_der, float* g_weight,
+                                         float* g_acc, float* g_depth, void* stream) {
+    if (B < 0 || S <= 0) return TIR_ERR_ARG;
+    if (B == 0) return TIR_OK;
+    if (!rays || !offsets || !acc || !depth || !g_maps || !g_weight || !g_acc || !g_depth) return TIR_ERR_ARG;
+    if (rgb && !g_rgb) return TIR_ERR_ARG;
+    hipLaunchKernelGGL(k_composite_primary_bwd, dim3((B + 63) / 64), dim3(64), 0, tir_stream(stream), rays, offsets,
+                       rec_k, rec_w, rgb, brdf, brdf_jit, pred_normal, derived_normal, acc, depth, B, S, white_bg,
+                       is_relight, fixed_fresnel, g_maps, g_rgb, g_brdf, g_brdf_jit, g_pred, g_der, g_weight, g_acc,
+                       g_depth);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+template <int C4>
+static int launch_app_bwd(const TirField* f, const TirFieldGrad* g, const float* xyz, const int32_t* li,
+                          const int32_t* map, const float* g_rad, const float* g_int, int stride, int64_t n,
+                          float* y_rad, float* y_int, hipStream_t s) {
+    constexpr int CA = C4 * 4;
+    const int nl = f->n_lights < TIR_APP_MAX_L ? f->n_lights : TIR_APP_MAX_L;
+    const size_t lds = (size_t)(3 * CA * 32 + (nl + 1) * 3 * CA) * sizeof(float);
+    if (lds > 160 * 1024) return TIR_ERR_UNSUPPORTED;
+    int64_t blocks = (n + 63) / 64;
+    if (blocks > 1024) blocks = 1024;
+    dim3 grid((unsigned)blocks), blk(256);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_bwd<C4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_bwd<C4, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_bwd<C4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (g_rad && g_int) hipLaunchKernelGGL((k_vm_app_bwd<C4, true, true>), grid, blk, lds, s, *f, *g, xyz, li, map, g_rad, g_int, stride, n, y_rad, y_int);
+    else if (g_rad)     hipLaunchKernelGGL((k_vm_app_bwd<C4, true, false>), grid, blk, lds, s, *f, *g, xyz, li, map, g_rad, g_int, stride, n, y_rad, y_int);
+    else                hipLaunchKernelGGL((k_vm_app_bwd<C4, false, true>), grid, blk, lds, s, *f, *g, xyz, li, map, g_rad, g_int, stride, n, y_rad, y_int);
+    return TIR_OK;
+}
+
+extern "C" int tir_vm_app_bwd(const TirField* f, const TirFieldGrad* g, const float* xyz,
+                              const int32_t* light_idx, const int32_t* idx_map, const float* g_rad,
+                              const float* g_int, int32_t stride, int64_t n, float* y_rad, float* y_int,
+                              void* stream) {
+    int rc = check_grad_field(f, g, false, true);
+    if (rc) return rc;
+    if (!f->basis_t || !f->light_mean || !f->light_line || !g->light_line || !g->light_mean) return TIR_ERR_ARG;
+    if (f->app_dim < 1 || f->app_dim > 27) return TIR_ERR_UNSUPPORTED;
+    if (stride < f->app_dim) return TIR_ERR_ARG;
+    if (n < 0 || (n > 0 && !xyz) || (!g_rad && !g_int) || (g_rad && !light_idx)) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    hipStream_t s = tir_stream(stream);
+    switch (f->n_acomp) {
+        case 48: rc = launch_app_bwd<12>(f, g, xyz, light_idx, idx_map, g_rad, g_int, stride, n, y_rad, y_int, s); break;
+        case 24: rc = launch_app_bwd<6>(f, g, xyz, light_idx, idx_map, g_rad, g_int, stride, n, y_rad, y_int, s); break;
+        case 16: rc = launch_app_bwd<4>(f, g, xyz, light_idx, idx_map, g_rad, g_int, stride, n, y_rad, y_int, s); break;
+        case 96: rc = launch_app_bwd<24>(f, g, xyz, light_idx, idx_map, g_rad, g_int, stride, n, y_rad, y_int, s); break;
+        default: return TIR_ERR_UNSUPPORTED;
+    }
+    if (rc) return rc;
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_gemm_tn(const float* A, int32_t lda, int32_t M, const float* B, int32_t ldb, int32_t N,
+                           int32_t ones_col, int64_t n, float* C, int32_t ldc, void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || n < 0) return TIR_ERR_ARG;
+    ones_col = ones_col ? 1 : 0;
+    if (M > 128 || N + ones_col > 160) return TIR_ERR_UNSUPPORTED;
+    if ((lda & 3) || (ldb & 3) || lda < ((M + 3) & ~3) || ldb < ((N + 3) & ~3) || ldc < N + ones_col) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    int64_t chunk = (n + 511) / 512;
+    chunk = (chunk + 31) / 32 * 32;
+    if (chunk < 256) chunk = 256;
+    const unsigned blocks = (unsigned)((n + chunk - 1) / chunk);
+    hipLaunchKernelGGL(k_gemm_tn, dim3(blocks), dim3(256), 0, tir_stream(stream), A, lda, M, B, ldb, N, ones_col, n, C, ldc, chunk);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_shade_integrate_bwd(const float* maps, const float* rays, const float* dirs,
+                                       const int32_t* light_idx, const float* vis, const float* indirect,
+                                       const float* env, const float* weight_d, int32_t M, int32_t D,
+                                       int32_t n_lights, int32_t equal_area, int32_t use_srgb, float acc_thres,
+                                       const float* g_out, float* g_maps, float* g_env, void* stream) {
+    if (M < 0 || D <= 0 || n_lights <= 0) return TIR_ERR_ARG;
+    if (M == 0) return TIR_OK;
+    if (!maps || !rays || !dirs || !vis || !env || !g_out || !g_maps || (!equal_area && !weight_d)) return TIR_ERR_ARG;
+    hipLaunchKernelGGL(k_shade_integrate_bwd, dim3((M + 3) / 4), dim3(256), 0, tir_stream(stream), maps, rays, dirs,
+                       light_idx, vis, indirect, env, weight_d, M, D, n_lights, equal_area, use_srgb, acc_thres, g_out,
+                       g_maps, g_env);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_env_sg_bwd(const TirEnvSG* e, const float* dirs, int32_t D, const float* g_env, float* g_sgs,
+                              void* stream) {
+    if (!e || !e->sgs || !e->rot || e->n_sg <= 0 || e->n_lights <= 0 || D < 0) return TIR_ERR_ARG;
+    if (D == 0) return TIR_OK;
+    if (!dirs || !g_env || !g_sgs) return TIR_ERR_ARG;
+    hipLaunchKernelGGL(k_env_sg_bwd, dim3(e->n_sg), dim3(256), 0, tir_stream(stream), *e, dirs, D, g_env, g_sgs);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}

@@ -316,12 +316,14 @@ class TensorVMSplit(nn.Module):
 
     def get_light_rgbs(self, incident_light_directions=None, device="cuda"):
         """models/tensorBase_rotated_lights.py:577-606 (sg): dirs [D,3] -> [L,D,3] via tir_env_sg_fwd."""
-        _no_grad_only("get_light_rgbs", self.lgtSGs)
-        dirs = incident_light_directions.to(device).reshape(-1, 3).to(torch.float32)
+        dirs = incident_light_directions.to(device).reshape(-1, 3).to(torch.float32).contiguous()
         rot = self.__dict__.get("_rot_dev")
         if rot is None or rot.device != dirs.device:
             rot = self.light_rotation_matrix.to(dirs.device).contiguous()
             self.__dict__["_rot_dev"] = rot
+        if torch.is_grad_enabled() and self.lgtSGs.requires_grad:
+            from . import training
+            return training.EnvSGFn.apply(self.lgtSGs, rot, dirs)
         return ops.env_sg(self.lgtSGs.to(device), rot, dirs)
 
     def update_stepSize(self, gridSize):
@@ -631,7 +633,6 @@ class TensorVMSplit(nn.Module):
         """
         if ndc_ray:
             raise NotImplementedError("ndc_ray=True is not on the TensoIR hot path (no shipped config uses it)")
-        _no_grad_only("TensorVMSplit.forward", *self.parameters())
         dev = rays_chunk.device
         rays = rays_chunk.to(torch.float32).contiguous()
         B = rays.shape[0]
@@ -640,6 +641,15 @@ class TensorVMSplit(nn.Module):
         lidx = light_idx.reshape(-1).to(dev, torch.int32).contiguous()
         # RNG draws in the reference's order and on the reference's devices (:717 CPU, :937 device, :1004 CPU)
         jitter = torch.rand(B, 1).to(dev) if is_train else None
+        from . import training
+        if training.wants_grad(self):
+            # training step: the same launches with the activations kept, and a hand-written backward
+            # (tensoir_amd/training.py); torch.autograd only links the fused stages
+            bg = bool(white_bg or (is_train and torch.rand((1,)) < 0.5))
+            maps = training.PrimaryRenderFn.apply(self, rays, lidx, S, bg, bool(is_relight), jitter,
+                                                  _brdf_jitter_dense, *training.field_param_list(self))
+            out = self.unpack_maps(maps, is_relight)
+            return (out, maps) if _return_maps else out
         weight, acc, depth, _tend, cnt = ops.march_primary(f, rays, jitter, S, self.march_t_stop)
         offsets = ops.exclusive_scan(cnt)
         A = int(offsets[-1].item())                      # the one host sync of the pass

@@ -394,3 +394,165 @@ def ggx_specular(normal, v, l, rough, fresnel):
     _call("tir_ggx_specular", _ptr(normal), _ptr(v), _ptr(l), _ptr(rough), _ptr(fresnel), M, D,
                                  _ptr(out), _stream())
     return out
+
+
+# ---- training (backward) kernels: SURVEY.md section 8(f)-1 -------------------------------------------
+from ._lib import TirFieldGrad  # noqa: E402
+
+
+def march_primary_train(field: TirField, rays, ray_jitter, n_samples, t_stop):
+    """march_primary that also returns the per-sample density sigma [B,S] (needed by the backward)."""
+    rays = f32(rays, "rays", 6)
+    B, dev = rays.shape[0], rays.device
+    if ray_jitter is not None:
+        ray_jitter = f32(ray_jitter, "ray_jitter").view(-1)
+    weight = torch.empty((B, n_samples), dtype=torch.float32, device=dev)
+    sigma = torch.empty((B, n_samples), dtype=torch.float32, device=dev)
+    acc = torch.empty((B,), dtype=torch.float32, device=dev)
+    depth = torch.empty((B,), dtype=torch.float32, device=dev)
+    tend = torch.empty((B,), dtype=torch.float32, device=dev)
+    cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+    _call("tir_march_primary_train_fwd", C.byref(field), _ptr(rays), _ptr(ray_jitter), B, n_samples, float(t_stop),
+          _ptr(weight), _ptr(sigma), _ptr(acc), _ptr(depth), _ptr(tend), _ptr(cnt), _stream())
+    return weight, sigma, acc, depth, tend, cnt
+
+
+def composite_primary_bwd(rays, offsets, rec_k, rec_w, rgb, brdf, brdf_jit, pred_n, der_n, acc, depth, S,
+                          white_bg, is_relight, fixed_fresnel, g_maps):
+    rays = f32(rays, "rays", 6)
+    g_maps = f32(g_maps, "g_maps", MAP_STRIDE)
+    B, dev = rays.shape[0], rays.device
+    like = lambda t: None if t is None else torch.empty_like(t)
+    g_rgb, g_brdf, g_brdf_jit, g_pred, g_der = like(rgb), like(brdf), like(brdf_jit), like(pred_n), like(der_n)
+    g_weight = torch.zeros((B, S), dtype=torch.float32, device=dev)
+    g_acc = torch.empty((B,), dtype=torch.float32, device=dev)
+    g_depth = torch.empty((B,), dtype=torch.float32, device=dev)
+    _call("tir_composite_primary_bwd", _ptr(rays), _ptr(offsets), _ptr(rec_k), _ptr(rec_w), _ptr(rgb), _ptr(brdf),
+          _ptr(brdf_jit), _ptr(pred_n), _ptr(der_n), _ptr(acc), _ptr(depth), B, int(S), int(bool(white_bg)),
+          int(bool(is_relight)), float(fixed_fresnel), _ptr(g_maps), _ptr(g_rgb), _ptr(g_brdf), _ptr(g_brdf_jit),
+          _ptr(g_pred), _ptr(g_der), _ptr(g_weight), _ptr(g_acc), _ptr(g_depth), _stream())
+    return g_rgb, g_brdf, g_brdf_jit, g_pred, g_der, g_weight, g_acc, g_depth
+
+
+def march_primary_bwd(field: TirField, grad: TirFieldGrad, rays, ray_jitter, sigma, weight, g_weight, g_acc, g_depth,
+                      want_g_feature=False):
+    B, S = weight.shape
+    g_feature = torch.empty_like(weight) if want_g_feature else None
+    if ray_jitter is not None:
+        ray_jitter = f32(ray_jitter, "ray_jitter").view(-1)
+    _call("tir_march_primary_bwd", C.byref(field), C.byref(grad), _ptr(f32(rays, "rays", 6)), _ptr(ray_jitter), B, S,
+          _ptr(f32(sigma, "sigma")), _ptr(f32(weight, "weight")), _ptr(f32(g_weight, "g_weight")),
+          _ptr(f32(g_acc, "g_acc")), _ptr(f32(g_depth, "g_depth")), _ptr(g_feature), _stream())
+    return g_feature
+
+
+def density_grad_bwd(field: TirField, grad: TirFieldGrad, xyz, g_normal):
+    xyz = f32(xyz, "xyz", 3).view(-1, 3)
+    g_normal = f32(g_normal, "g_normal", 3).view(-1, 3)
+    _call("tir_density_grad_bwd", C.byref(field), C.byref(grad), _ptr(xyz), _ptr(g_normal), xyz.shape[0], _stream())
+
+
+def vm_app_bwd(field: TirField, grad: TirFieldGrad, xyz, light_idx, idx_map, g_rad, g_int, want_y=True):
+    """Scatter d feat into the appearance planes/lines + light rows; returns (y_rad, y_int) [n, 3*Ca]."""
+    xyz = f32(xyz, "xyz", 3).view(-1, 3)
+    n = xyz.shape[0]
+    nch = 3 * field.n_acomp
+    g_rad = None if g_rad is None else f32(g_rad, "g_rad")
+    g_int = None if g_int is None else f32(g_int, "g_int")
+    stride = (g_rad if g_rad is not None else g_int).shape[1]
+    y_rad = torch.empty((n, nch), dtype=torch.float32, device=xyz.device) if (g_rad is not None and want_y) else None
+    y_int = torch.empty((n, nch), dtype=torch.float32, device=xyz.device) if (g_int is not None and want_y) else None
+    if light_idx is not None:
+        light_idx = i32(light_idx, "light_idx").view(-1)
+    if idx_map is not None:
+        idx_map = i32(idx_map, "idx_map").view(-1)
+    _call("tir_vm_app_bwd", C.byref(field), C.byref(grad), _ptr(xyz), _ptr(light_idx), _ptr(idx_map), _ptr(g_rad),
+          _ptr(g_int), stride, n, _ptr(y_rad), _ptr(y_int), _stream())
+    return y_rad, y_int
+
+
+def mlp_train(m: "PackedMlp", feat, aux, aux_map=None, aux_mod=0):
+    """Exact-fp32 decoder forward that also returns the hidden activations (h1, h2) [n,128]."""
+    feat = f32(feat, "feat")
+    aux = f32(aux, "aux", 3)
+    n = feat.shape[0]
+    if aux_map is not None:
+        aux_map = i32(aux_map, "aux_map").view(-1)
+    out = torch.empty((n, m.out_dim), dtype=torch.float32, device=feat.device)
+    h1 = torch.empty((n, 128), dtype=torch.float32, device=feat.device)
+    h2 = torch.empty((n, 128), dtype=torch.float32, device=feat.device)
+    _call("tir_mlp_train_fwd", C.byref(m.desc), _ptr(feat), feat.shape[1], _ptr(aux), _ptr(aux_map), int(aux_mod),
+          _ptr(out), _ptr(h1), _ptr(h2), n, _stream())
+    return out, h1, h2
+
+
+def mlp_inputs(m: "PackedMlp", feat, aux, aux_map=None, aux_mod=0):
+    feat = f32(feat, "feat")
+    aux = f32(aux, "aux", 3)
+    n = feat.shape[0]
+    if aux_map is not None:
+        aux_map = i32(aux_map, "aux_map").view(-1)
+    x = torch.empty((n, 160), dtype=torch.float32, device=feat.device)
+    _call("tir_mlp_inputs", C.byref(m.desc), _ptr(feat), feat.shape[1], _ptr(aux), _ptr(aux_map), int(aux_mod),
+          _ptr(x), n, _stream())
+    return x
+
+
+def pack_mlp_bwd(w0, w1, w2, feat_dim, pe):
+    ws = [f32(t.detach(), "mlp weight") for t in (w0, w1, w2)]
+    hidden, out_dim = w1.shape[0], w2.shape[0]
+    n = lib().tir_mlp_bwd_packed_floats(feat_dim, pe, hidden, out_dim)
+    if n < 0:
+        check(int(n), "tir_mlp_bwd_packed_floats")
+    packed = torch.empty((int(n),), dtype=torch.float32, device=w0.device)
+    _call("tir_pack_mlp_bwd", *[_ptr(t) for t in ws], feat_dim, pe, hidden, out_dim, _ptr(packed), _stream())
+    return packed
+
+
+def mlp_bwd(m: "PackedMlp", packed_bwd, feat, out, g_out, h1, h2):
+    feat = f32(feat, "feat")
+    n = feat.shape[0]
+    dev = feat.device
+    g_feat = torch.empty((n, FEAT_STRIDE), dtype=torch.float32, device=dev)
+    dz1 = torch.empty((n, 128), dtype=torch.float32, device=dev)
+    dz2 = torch.empty((n, 128), dtype=torch.float32, device=dev)
+    dz3 = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    _call("tir_mlp_bwd", C.byref(m.desc), _ptr(packed_bwd), _ptr(feat), feat.shape[1], _ptr(f32(out, "out")),
+          _ptr(f32(g_out, "g_out")), _ptr(h1), _ptr(h2), n, _ptr(g_feat), _ptr(dz1), _ptr(dz2), _ptr(dz3), _stream())
+    return g_feat, dz1, dz2, dz3
+
+
+def gemm_tn(A, M, B, N, C_out, ones_col=False):
+    """C_out[M, N(+1)] += A[:, :M]^T @ B[:, :N]  (+ column N = A^T 1)."""
+    A, B = f32(A, "A"), f32(B, "B")
+    n = A.shape[0]
+    if B.shape[0] != n:
+        raise ValueError("gemm_tn: row counts differ")
+    _call("tir_gemm_tn", _ptr(A), A.shape[1], int(M), _ptr(B), B.shape[1], int(N), int(bool(ones_col)), n,
+          _ptr(C_out), C_out.shape[1], _stream())
+    return C_out
+
+
+def shade_integrate_bwd(maps, rays, dirs, light_idx, vis, indirect, env, weight_d, equal_area, use_srgb, acc_thres,
+                        g_out):
+    maps = f32(maps, "maps", MAP_STRIDE)
+    M, D = maps.shape[0], dirs.shape[0]
+    g_maps = torch.empty_like(maps)
+    g_env = torch.zeros_like(env)
+    _call("tir_shade_integrate_bwd", _ptr(maps), _ptr(f32(rays, "rays", 6)), _ptr(f32(dirs, "dirs", 3)),
+          _ptr(i32(light_idx, "light_idx").view(-1)), _ptr(f32(vis, "vis")),
+          _ptr(None if indirect is None else f32(indirect, "indirect", 3)), _ptr(f32(env, "env", 3)),
+          _ptr(None if weight_d is None else f32(weight_d, "light_area_weight")), M, D, env.shape[0],
+          int(bool(equal_area)), int(bool(use_srgb)), float(acc_thres), _ptr(f32(g_out, "g_out", 3)), _ptr(g_maps),
+          _ptr(g_env), _stream())
+    return g_maps, g_env
+
+
+def env_sg_bwd(lgtSGs, rot, dirs, g_env):
+    sgs = f32(lgtSGs.detach(), "lgtSGs", 7)
+    rot = f32(rot, "light_rotation_matrix").view(-1, 9)
+    dirs = f32(dirs, "dirs", 3).view(-1, 3)
+    g = torch.zeros_like(sgs)
+    desc = TirEnvSG(sgs.data_ptr(), rot.data_ptr(), sgs.shape[0], rot.shape[0])
+    _call("tir_env_sg_bwd", C.byref(desc), _ptr(dirs), dirs.shape[0], _ptr(f32(g_env, "g_env", 3)), _ptr(g), _stream())
+    return g

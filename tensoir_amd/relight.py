@@ -173,19 +173,25 @@ def shade_from_maps(tensoIR, maps, rays, light_idx, sample_method="fixed_envirma
     if M == 0:
         out = torch.zeros((0, 3), dtype=torch.float32, device=dev)
         return (out, None) if return_aux else out
-    surf, active = ops.shade_setup(maps, rays, dirs, acc_thres)
-    vis, _, ind = _secondary(tensoIR, surf, dirs, M * D, z, None, None, active.view(-1), li, D, True, False, D)
+    train = torch.is_grad_enabled() and (maps.requires_grad or tensoIR.lgtSGs.requires_grad)
+    with torch.no_grad():      # compute_secondary_shading_effects is @torch.no_grad (models/relight_utils.py:344)
+        surf, active = ops.shade_setup(maps.detach(), rays, dirs, acc_thres)
+        vis, _, ind = _secondary(tensoIR, surf, dirs, M * D, z, None, None, active.view(-1), li, D, True, False, D)
     env = tensoIR.get_light_rgbs(dirs, device=dev)
     equal_area = sample_method == "stratifed_sample_equal_areas"
-    rgb = ops.shade_integrate(maps, rays, dirs, li, vis.view(M, D), ind.view(M, D, 3), env,
-                              None if equal_area else area, equal_area, use_linear2srgb, acc_thres)
+    if train:
+        from . import training
+        rgb = training.ShadeFn.apply(maps, env, rays, dirs, li, vis.view(M, D), ind.view(M, D, 3),
+                                     None if equal_area else area, equal_area, use_linear2srgb, acc_thres)
+    else:
+        rgb = ops.shade_integrate(maps, rays, dirs, li, vis.view(M, D), ind.view(M, D, 3), env,
+                                  None if equal_area else area, equal_area, use_linear2srgb, acc_thres)
     if return_aux:
         return rgb, {"vis": vis.view(M, D), "indirect": ind.view(M, D, 3), "env": env, "surf": surf,
                      "active": active}
     return rgb
 
 
-@torch.no_grad()
 def render_with_BRDF(depth_map, normal_map, albedo_map, roughness_map, fresnel_map, rays, tensoIR, light_idx,
                      sample_method="fixed_envirmap", chunk_size=15000, device="cuda", use_linear2srgb=True,
                      args=None):

@@ -1,0 +1,236 @@
+"""Training path: autograd bridges whose forward AND backward are HIP launches.
+
+The reference differentiates its ATen op chain with torch.autograd (train_tensoIR.py:315-317).  Here
+torch.autograd only carries gradients *between* three fused stages -- each stage's backward is a chain
+of hand-written kernels (tir_*_bwd in include/tensoir_hip.h):
+
+  PrimaryRenderFn : rays -> [B,20] map rows   (TensorBase.forward, models/tensorBase_rotated_lights.py:868-1036)
+  EnvSGFn         : lgtSGs -> environment radiance [L,D,3]   (:577-588, :70-86)
+  ShadeFn         : map rows + environment -> rgb_with_brdf  (render_with_BRDF, models/relight_utils.py:403-483;
+                    visibility / indirect light are constants there: compute_secondary_shading_effects is no_grad)
+
+There is no eager-PyTorch fallback: every derivative below is produced by libtensoir_hip.so.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+from ._lib import TirFieldGrad
+
+
+def field_param_list(model):
+    """Parameters PrimaryRenderFn differentiates, in the order its backward returns their gradients."""
+    ps = list(model.density_plane) + list(model.density_line) + list(model.app_plane) + list(model.app_line)
+    ps += [model.basis_mat.weight, model.light_line.weight]
+    for dec in _decoders(model):
+        m = dec.mlp
+        ps += [m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias]
+    return ps
+
+
+def _decoders(model):
+    decs = [model.renderModule, model.renderModule_brdf]
+    if hasattr(model, "renderModule_normal"):
+        decs.append(model.renderModule_normal)
+    return decs
+
+
+def _packed_bwd(dec):
+    """Transposed decoder weights in MFMA operand order for tir_mlp_bwd (cached per parameter version)."""
+    ps = [dec.mlp[0].weight, dec.mlp[2].weight, dec.mlp[4].weight]
+    key = tuple((p.data_ptr(), p._version) for p in ps)
+    cache = dec.__dict__.get("_bwd_cache")
+    if cache is None or cache[0] != key:
+        cache = (key, ops.pack_mlp_bwd(ps[0], ps[1], ps[2], dec.in_chanel, dec.feape))
+        dec.__dict__["_bwd_cache"] = cache
+    return cache[1]
+
+
+def _grad_buffers(model, field):
+    """Zero-filled gradient buffers in the packed channel-last layout + their TirFieldGrad descriptor."""
+    keep = model._field_cache
+    bufs = {}
+    g = TirFieldGrad()
+    for i in range(3):
+        for name, dst in (("dp", g.dplane), ("dl", g.dline), ("ap", g.aplane), ("al", g.aline)):
+            t = torch.zeros_like(keep[f"{name}{i}"])
+            bufs[f"{name}{i}"] = t
+            dst[i] = t.data_ptr()
+    bufs["ll"] = torch.zeros_like(keep["ll"])
+    bufs["lm"] = torch.zeros_like(keep["lm"])
+    g.light_line, g.light_mean = bufs["ll"].data_ptr(), bufs["lm"].data_ptr()
+    bufs["desc"] = g
+    return bufs
+
+
+def _to_param_layout(g):
+    """packed [H,W,C] (or [R,1,C]) -> parameter layout [1,C,H,W]."""
+    return g.permute(2, 0, 1).unsqueeze(0)
+
+
+class _DecoderCall(SimpleNamespace):
+    pass
+
+
+def _decoder_backward(dec, calls):
+    """Backward of every recorded invocation of one decoder.  Returns ([g_feat per call], 6 parameter grads)."""
+    pm, pb = dec.packed(), _packed_bwd(dec)
+    dev = calls[0].feat.device
+    od = pm.out_dim
+    dW0 = torch.zeros((128, 152), dtype=torch.float32, device=dev)     # [.., :150] weight, [.., 150] bias
+    dW1 = torch.zeros((128, 132), dtype=torch.float32, device=dev)
+    dW2 = torch.zeros((4, 132), dtype=torch.float32, device=dev)
+    g_feats = []
+    for c in calls:
+        g_feat, dz1, dz2, dz3 = ops.mlp_bwd(pm, pb, c.feat, c.out, c.g_out, c.h1, c.h2)
+        x = ops.mlp_inputs(pm, c.feat, c.aux, c.aux_map)
+        ops.gemm_tn(dz1, 128, x, 150, dW0, True)
+        ops.gemm_tn(dz2, 128, c.h1, 128, dW1, True)
+        ops.gemm_tn(dz3, 4, c.h2, 128, dW2, True)
+        g_feats.append(g_feat)
+    grads = [dW0[:, :150], dW0[:, 150], dW1[:, :128], dW1[:, 128], dW2[:od, :128], dW2[:od, 128]]
+    return g_feats, grads
+
+
+class PrimaryRenderFn(torch.autograd.Function):
+    """march -> scan -> compact -> appearance gather -> decoders -> analytic normals -> composite, with a
+    hand-written backward for every link."""
+
+    @staticmethod
+    def forward(ctx, model, rays, lidx, S, white_bg, is_relight, jitter, noise_dense, *params):
+        f = model.packed_field()
+        dev = rays.device
+        weight, sigma, acc, depth, _tend, cnt = ops.march_primary_train(f, rays, jitter, S, model.march_t_stop)
+        offsets = ops.exclusive_scan(cnt)
+        A = int(offsets[-1].item())
+        rec_ray, rec_k, rec_w, rec_xyz = ops.compact_primary(f, rays, jitter, weight, offsets, A)
+        st = SimpleNamespace(model=model, rays=rays, lidx=lidx, S=S, white_bg=white_bg, is_relight=is_relight,
+                             jitter=jitter, weight=weight, sigma=sigma, acc=acc, depth=depth, offsets=offsets, A=A,
+                             rec_ray=rec_ray, rec_k=rec_k, rec_w=rec_w, rec_xyz=rec_xyz, calls={}, n_params=len(params))
+        rgb = brdf = brdf_j = pred = derived = None
+        if A > 0:
+            viewdirs = rays[:, 3:6].contiguous()
+            rad, intr = ops.vm_app(f, rec_xyz, lidx, rec_ray, True, bool(is_relight))
+            rgb, h1, h2 = ops.mlp_train(model.renderModule.packed(), rad, viewdirs, rec_ray)
+            st.calls["rgb"] = _DecoderCall(feat=rad, aux=viewdirs, aux_map=rec_ray, out=rgb, h1=h1, h2=h2)
+            if is_relight:
+                pb = model.renderModule_brdf.packed()
+                brdf, h1, h2 = ops.mlp_train(pb, intr, rec_xyz)
+                st.calls["brdf"] = _DecoderCall(feat=intr, aux=rec_xyz, aux_map=None, out=brdf, h1=h1, h2=h2)
+                if noise_dense is not None:
+                    noise = noise_dense.to(dev, torch.float32)[rec_ray.long(), rec_k.long()]
+                else:
+                    noise = torch.randn((A, 3), device=dev, dtype=torch.float32)
+                xyz_j = rec_xyz + noise * 0.01
+                intr_j = ops.vm_app(f, xyz_j, None, None, False, True)[1]
+                brdf_j, h1, h2 = ops.mlp_train(pb, intr_j, xyz_j)
+                st.calls["brdf_j"] = _DecoderCall(feat=intr_j, aux=xyz_j, aux_map=None, out=brdf_j, h1=h1, h2=h2)
+                st.xyz_j = xyz_j
+                if model.normals_kind == "purely_derived":
+                    pred = ops.density_grad(f, rec_xyz)[2]
+                else:
+                    pred, h1, h2 = ops.mlp_train(model.renderModule_normal.packed(), intr, rec_xyz)
+                    st.calls["normal"] = _DecoderCall(feat=intr, aux=rec_xyz, aux_map=None, out=pred, h1=h1, h2=h2)
+                    if model.normals_kind == "derived_plus_predicted":
+                        derived = ops.density_grad(f, rec_xyz)[2]
+        st.rgb, st.brdf, st.brdf_j, st.pred, st.derived = rgb, brdf, brdf_j, pred, derived
+        maps = ops.composite_primary(rays, offsets, rec_w, rgb, brdf, brdf_j, pred, derived, acc, depth,
+                                     white_bg, is_relight, model.fixed_fresnel)
+        if model.normals_kind == "purely_derived" and is_relight:
+            maps[:, 16] = 0.0
+        ctx.st = st
+        return maps
+
+    @staticmethod
+    def backward(ctx, g_maps):
+        st = ctx.st
+        model = st.model
+        f = model.packed_field()
+        g_maps = g_maps.contiguous().to(torch.float32)
+        if model.normals_kind == "purely_derived" and st.is_relight:
+            g_maps = g_maps.clone()
+            g_maps[:, 16] = 0.0
+        bufs = _grad_buffers(model, f)
+        gd = bufs["desc"]
+        dev = st.rays.device
+        (g_rgb, g_brdf, g_brdf_j, g_pred, g_der, g_weight, g_acc, g_depth) = ops.composite_primary_bwd(
+            st.rays, st.offsets, st.rec_k, st.rec_w, st.rgb, st.brdf, st.brdf_j, st.pred, st.derived, st.acc, st.depth,
+            st.S, st.white_bg, st.is_relight, model.fixed_fresnel, g_maps)
+        dec_grads = {}
+        d_basis = torch.zeros((model.app_dim, 3 * f.n_acomp), dtype=torch.float32, device=dev)
+        if st.A > 0:
+            c = st.calls["rgb"]
+            c.g_out = g_rgb
+            (g_rad,), dec_grads["rgb"] = _decoder_backward(model.renderModule, [c])
+            g_int = g_int_j = None
+            if st.is_relight:
+                cb, cj = st.calls["brdf"], st.calls["brdf_j"]
+                cb.g_out, cj.g_out = g_brdf, g_brdf_j
+                (g_int, g_int_j), dec_grads["brdf"] = _decoder_backward(model.renderModule_brdf, [cb, cj])
+                if "normal" in st.calls:
+                    cn = st.calls["normal"]
+                    cn.g_out = g_pred
+                    (g_n,), dec_grads["normal"] = _decoder_backward(model.renderModule_normal, [cn])
+                    g_int = g_int + g_n
+                    if g_der is not None:
+                        ops.density_grad_bwd(f, gd, st.rec_xyz, g_der)
+                else:                                   # purely_derived: the composited normal IS the derived one
+                    ops.density_grad_bwd(f, gd, st.rec_xyz, g_pred)
+            y_rad, y_int = ops.vm_app_bwd(f, gd, st.rec_xyz, st.lidx, st.rec_ray, g_rad, g_int)
+            ops.gemm_tn(g_rad, model.app_dim, y_rad, 3 * f.n_acomp, d_basis)
+            if g_int is not None:
+                ops.gemm_tn(g_int, model.app_dim, y_int, 3 * f.n_acomp, d_basis)
+                _, y_j = ops.vm_app_bwd(f, gd, st.xyz_j, None, None, None, g_int_j)
+                ops.gemm_tn(g_int_j, model.app_dim, y_j, 3 * f.n_acomp, d_basis)
+        ops.march_primary_bwd(f, gd, st.rays, st.jitter, st.sigma, st.weight, g_weight, g_acc, g_depth)
+        grads = []
+        for name in ("dp", "dl", "ap", "al"):
+            grads += [_to_param_layout(bufs[f"{name}{i}"]) for i in range(3)]
+        grads.append(d_basis)
+        grads.append(bufs["ll"] + bufs["lm"][None, :] / float(model.light_num))
+        for key, dec in zip(("rgb", "brdf", "normal"), _decoders(model)):
+            grads += dec_grads.get(key, [None] * 6)
+        assert len(grads) == st.n_params
+        ctx.st = None
+        return (None,) * 8 + tuple(grads)
+
+
+class EnvSGFn(torch.autograd.Function):
+    """get_light_rgbs for spherical Gaussians (models/tensorBase_rotated_lights.py:577-588, :70-86)."""
+
+    @staticmethod
+    def forward(ctx, lgtSGs, rot, dirs):
+        ctx.save_for_backward(lgtSGs, rot, dirs)
+        return ops.env_sg(lgtSGs, rot, dirs)
+
+    @staticmethod
+    def backward(ctx, g_env):
+        lgtSGs, rot, dirs = ctx.saved_tensors
+        return ops.env_sg_bwd(lgtSGs, rot, dirs, g_env.contiguous()), None, None
+
+
+class ShadeFn(torch.autograd.Function):
+    """GGX x (visibility * environment + indirect) x cosine integration + tone map
+    (models/relight_utils.py:452-480), differentiable w.r.t. the map rows and the environment radiance."""
+
+    @staticmethod
+    def forward(ctx, maps, env, rays, dirs, light_idx, vis, indirect, area, equal_area, use_srgb, acc_thres):
+        ctx.save_for_backward(maps, env, rays, dirs, light_idx, vis, indirect, area)
+        ctx.flags = (equal_area, use_srgb, acc_thres)
+        return ops.shade_integrate(maps, rays, dirs, light_idx, vis, indirect, env, area, equal_area, use_srgb,
+                                   acc_thres)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        maps, env, rays, dirs, light_idx, vis, indirect, area = ctx.saved_tensors
+        equal_area, use_srgb, acc_thres = ctx.flags
+        g_maps, g_env = ops.shade_integrate_bwd(maps, rays, dirs, light_idx, vis, indirect, env, area, equal_area,
+                                                use_srgb, acc_thres, g_out.contiguous())
+        return (g_maps, g_env) + (None,) * 9
+
+
+def wants_grad(model) -> bool:
+    return torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())

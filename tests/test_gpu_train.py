@@ -1,0 +1,299 @@
+"""Training path on the GPU: every backward kernel (through the C ABI) against the CPU oracle's autograd,
+which tests/test_oracle_train.py pins to the imported reference's own backward (tests/golden/train_grads.npz).
+
+Gradient tolerance: max |hip - ref| / max |ref| per tensor < 2e-3 (fp32 atomics reorder the sums; the
+reference's own CUDA grid_sampler backward has the same property), forward maps keep the 1e-4 bar."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GTOL = 2e-3
+
+
+def gerr(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-20))
+
+
+@pytest.fixture(scope="module")
+def env(golden):
+    import tensoir_amd
+    from oracle import tensoir_oracle as O
+    from tests.helpers import golden_checkpoint, scene_from_checkpoint
+    assert torch.cuda.is_available()
+    from tensoir_amd import _lib
+    assert _lib.lib().tir_device_check() == 0
+    ckpt = golden_checkpoint(golden)
+    eh, ew = [int(x) for x in golden["scene/envmap_hw"]]
+    model = tensoir_amd.model_from_checkpoint(ckpt, "cuda", envmap_h=eh, envmap_w=ew)
+    model.march_t_stop = 0.0
+    sc = scene_from_checkpoint(ckpt, eh, ew)
+    tg = np.load(os.path.join(ROOT, "tests", "golden", "train_grads.npz"))
+    return types.SimpleNamespace(model=model, sc=sc, g=golden, tg=tg, O=O, dev="cuda",
+                                 args=types.SimpleNamespace(second_nSample=24, second_near=0.05, second_far=1.5))
+
+
+def T(g, k):
+    return torch.from_numpy(np.array(g[k]))
+
+
+# ------------------------------------------------------------------ building blocks
+def test_gemm_tn(env):
+    from tensoir_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    for n, M, N, lda, ldb, ones in ((1000, 128, 150, 128, 160, True), (777, 27, 144, 32, 144, False),
+                                    (5, 4, 128, 4, 128, True), (70000, 128, 128, 128, 128, True)):
+        A = torch.randn(n, lda, generator=gen)
+        B = torch.randn(n, ldb, generator=gen)
+        C = torch.zeros(M, N + (1 if ones else 0) + 3).cuda()
+        ops.gemm_tn(A.cuda(), M, B.cuda(), N, C, ones)
+        ref = A[:, :M].double().T @ B[:, :N].double()
+        assert gerr(C[:, :N], ref) < 1e-5, (n, M, N)
+        if ones:
+            assert gerr(C[:, N], A[:, :M].double().sum(0)) < 1e-5
+        assert float(C[:, N + (1 if ones else 0):].abs().max()) == 0.0
+
+
+def _torch_decoder(w, feat, aux, act):
+    O_ = __import__("oracle.tensoir_oracle", fromlist=["x"])
+    x = O_.mlp_input(feat, aux, 2, 2)
+    y = O_.mlp3(w, x)
+    return torch.tanh(y) if act == 1 else torch.sigmoid(y)
+
+
+@pytest.mark.parametrize("which", ["rgb", "brdf", "normal"])
+def test_decoder_backward(env, which):
+    from tensoir_amd import ops, training
+    m, sc = env.model, env.sc
+    dec, w, act = {"rgb": (m.renderModule, sc.mlp_rgb, 0), "brdf": (m.renderModule_brdf, sc.mlp_brdf, 0),
+                   "normal": (m.renderModule_normal, sc.mlp_normal, 1)}[which]
+    gen = torch.Generator().manual_seed(7)
+    n = 700
+    feat = torch.randn(n, 27, generator=gen) * 0.7
+    aux = torch.randn(n, 3, generator=gen)
+    od = w["w2"].shape[0]
+    g_out = torch.randn(n, od, generator=gen)
+    wr = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    fr = feat.clone().requires_grad_(True)
+    y = _torch_decoder(wr, fr, aux, act)
+    (y * g_out).sum().backward()
+    fpad = torch.zeros(n, 32)
+    fpad[:, :27] = feat
+    call = training._DecoderCall(feat=fpad.cuda(), aux=aux.cuda(), aux_map=None, g_out=g_out.cuda())
+    call.out, call.h1, call.h2 = ops.mlp_train(dec.packed(), call.feat, call.aux)
+    assert gerr(call.out, y) < 1e-5
+    (g_feat,), grads = training._decoder_backward(dec, [call])
+    assert gerr(g_feat[:, :27], fr.grad) < 1e-4
+    assert float(g_feat[:, 27:].abs().max()) == 0.0
+    for got, name in zip(grads, ("w0", "b0", "w1", "b1", "w2", "b2")):
+        assert gerr(got, wr[name].grad) < 1e-4, name
+
+
+def _field_grads(env, fn_hip, fn_oracle, names):
+    """run fn_hip(field, grad_desc) / fn_oracle(scene with leaf params) and compare the named gradients"""
+    from tensoir_amd import training
+    O = env.O
+    m = env.model
+    f = m.packed_field()
+    bufs = training._grad_buffers(m, f)
+    extra = fn_hip(f, bufs["desc"])
+    work = O.Scene(**env.sc.__dict__)
+    for nm in ("density_plane", "density_line", "app_plane", "app_line"):
+        setattr(work, nm, [t.detach().clone().requires_grad_(True) for t in getattr(env.sc, nm)])
+    work.basis_mat = env.sc.basis_mat.detach().clone().requires_grad_(True)
+    work.light_line = env.sc.light_line.detach().clone().requires_grad_(True)
+    fn_oracle(work).backward()
+    ps = O.scene_parameters(work)
+    short = {"density_plane": "dp", "density_line": "dl", "app_plane": "ap", "app_line": "al"}
+    errs = {}
+    for nm in names:
+        ref = ps[nm].grad
+        if nm == "light_line.weight":
+            got = bufs["ll"] + bufs["lm"][None] / m.light_num
+        elif nm == "basis_mat.weight":
+            got = extra
+        else:
+            base, i = nm.split(".")
+            got = training._to_param_layout(bufs[f"{short[base]}{i}"])
+        errs[nm] = gerr(got, ref)
+    assert max(errs.values()) < GTOL, errs
+
+
+def test_density_normal_backward(env):
+    from tensoir_amd import ops
+    xyz = T(env.g, "normals/xyz")
+    gn = torch.randn(xyz.shape[0], 3, generator=torch.Generator().manual_seed(11))
+
+    def hip(f, gd):
+        ops.density_grad_bwd(f, gd, xyz.cuda(), gn.cuda())
+
+    def orc(work):
+        return (env.O.density_grad(work, xyz)[2] * gn).sum()
+    _field_grads(env, hip, orc, [f"density_plane.{i}" for i in range(3)] + [f"density_line.{i}" for i in range(3)])
+
+
+def test_march_backward(env):
+    """raw2alpha + softplus + density gather backward in isolation: random cotangents on weight / acc / depth."""
+    from tensoir_amd import ops
+    O, g = env.O, env.g
+    rays = T(g, "rays/rays")
+    B, S = rays.shape[0], 57
+    gen = torch.Generator().manual_seed(31)
+    jitter = torch.rand(B, 1, generator=gen)
+    gw = torch.randn(B, S, generator=gen)
+    ga, gd = torch.randn(B, generator=gen), torch.randn(B, generator=gen)
+
+    def hip(f, gdesc):
+        r = rays.cuda()
+        weight, sigma, acc, depth, _t, _c = ops.march_primary_train(f, r, jitter.cuda(), S, 0.0)
+        ops.march_primary_bwd(f, gdesc, r, jitter.cuda(), sigma, weight, gw.cuda(), ga.cuda(), gd.cuda())
+
+    def orc(work):
+        pts, z, valid = O.sample_ray(work, rays[:, :3], rays[:, 3:6], S, jitter)
+        z = z.expand(B, S)
+        dists = torch.cat((z[:, 1:] - z[:, :-1], torch.zeros_like(z[:, :1])), dim=-1)
+        sigma, valid, xyz = O.march_sigma(work, pts, valid, "explicit")
+        _, weight, _ = O.raw2alpha(sigma, dists * work.distance_scale)
+        return (weight * gw).sum() + (weight.sum(-1) * ga).sum() + ((weight * z).sum(-1) * gd).sum()
+    _field_grads(env, hip, orc, [f"density_plane.{i}" for i in range(3)] + [f"density_line.{i}" for i in range(3)])
+
+
+
+def test_app_feature_backward(env):
+    from tensoir_amd import ops
+    xyz, li = T(env.g, "feat/xyz"), T(env.g, "feat/light_idx").int()
+    gen = torch.Generator().manual_seed(12)
+    n = xyz.shape[0]
+    gr, gi = torch.zeros(n, 32), torch.zeros(n, 32)
+    gr[:, :27] = torch.randn(n, 27, generator=gen)
+    gi[:, :27] = torch.randn(n, 27, generator=gen)
+
+    def hip(f, gd):
+        y_rad, y_int = ops.vm_app_bwd(f, gd, xyz.cuda(), li.cuda().view(-1), None, gr.cuda(), gi.cuda())
+        dB = torch.zeros(27, 3 * f.n_acomp).cuda()
+        ops.gemm_tn(gr.cuda(), 27, y_rad, 3 * f.n_acomp, dB)
+        ops.gemm_tn(gi.cuda(), 27, y_int, 3 * f.n_acomp, dB)
+        return dB
+
+    def orc(work):
+        r, i = env.O.both_feature(work, xyz, li, "explicit")
+        return (r * gr[:, :27]).sum() + (i * gi[:, :27]).sum()
+    _field_grads(env, hip, orc, [f"app_plane.{i}" for i in range(3)] + [f"app_line.{i}" for i in range(3)] +
+                 ["basis_mat.weight", "light_line.weight"])
+
+
+def test_shading_backward(env):
+    """ShadeFn / EnvSGFn against autograd through the oracle's render_with_brdf on identical vis/indirect."""
+    from tensoir_amd import relight
+    O, m, g = env.O, env.model, env.g
+    rays, lidx = T(g, "rays/rays"), T(g, "rays/light_idx")
+    with torch.no_grad():
+        out = O.forward_primary(env.sc, rays, lidx.int(), brdf_jitter=torch.zeros(rays.shape[0], m.nSamples, 3))
+    depth, normal, albedo, rough, fres, acc = out[1], out[2], out[3], out[4], out[5], out[6]
+    mask = acc > 0.5
+    leaves = [t[mask].clone().requires_grad_(True) for t in (normal, albedo, rough, fres)]
+    sgs = env.sc.lgtSGs.clone().requires_grad_(True)
+    work = O.Scene(**env.sc.__dict__)
+    work.lgtSGs = sgs
+    gout = torch.randn(int(mask.sum()), 3, generator=torch.Generator().manual_seed(13))
+    ref = O.render_with_brdf(work, depth[mask], leaves[0], leaves[1], leaves[2].repeat(1, 3), leaves[3], rays[mask],
+                             lidx[mask].int(), 24, 0.05, 1.5)
+    (ref * gout).sum().backward()
+    hl = [t.detach().clone().cuda().requires_grad_(True) for t in leaves]
+    m.lgtSGs.grad = None
+    got = relight.render_with_BRDF(depth[mask].cuda(), hl[0], hl[1], hl[2].repeat(1, 3), hl[3], rays[mask].cuda(), m,
+                                   lidx[mask].cuda(), "fixed_envirmap", args=env.args)
+    assert gerr(got, ref) < 1e-4
+    (got * gout.cuda()).sum().backward()
+    for a, b, nm in zip(hl, leaves, ("normal", "albedo", "roughness", "fresnel")):
+        assert gerr(a.grad, b.grad) < GTOL, (nm, gerr(a.grad, b.grad))
+    assert gerr(m.lgtSGs.grad, sgs.grad) < GTOL
+    m.lgtSGs.grad = None
+
+
+# ------------------------------------------------------------------ whole training step
+@pytest.mark.parametrize("relight", [False, True])
+def test_training_step_vs_oracle(env, relight):
+    from tensoir_amd import Renderer_TensoIR_train
+    O, m, g, tg = env.O, env.model, env.g, env.tg
+    rays, lidx = T(g, "rays/rays"), T(g, "rays/light_idx")
+    S = int(tg["train/n_samples"][0])
+    gt = T(tg, "train/rgb_gt")
+    B = rays.shape[0]
+    gen = torch.Generator().manual_seed(21)
+    jitter = torch.rand(B, 1, generator=gen)
+    noise = torch.randn(B, S, 3, generator=gen)
+    loss_ref, grads_ref, ret_ref = O.train_step_grads(env.sc, rays, lidx, gt, is_relight=relight, n_samples=S,
+                                                      ray_jitter=jitter, brdf_jitter=noise, second_n_sample=24)
+    m.zero_grad(set_to_none=True)
+    # feed the same draws: forward() takes the ray jitter from torch.rand(B,1) on the CPU generator
+    state = torch.get_rng_state()
+    torch.manual_seed(0)
+    orig_rand = torch.rand
+
+    def fake_rand(*a, **k):
+        if tuple(a) == (B, 1) or (len(a) == 1 and tuple(a[0]) == (B, 1)):
+            return jitter.clone()
+        return orig_rand(*a, **k)
+    torch.rand = fake_rand
+    try:
+        orig_fwd = type(m).forward
+
+        def fwd(self, r, l, **k):
+            return orig_fwd(self, r, l, _brdf_jitter_dense=noise, **k)
+        type(m).forward = fwd
+        try:
+            ret = Renderer_TensoIR_train(rays, None, lidx, m, N_samples=S, white_bg=True, is_train=True,
+                                         is_relight=relight, sample_method="fixed_envirmap", device="cuda",
+                                         args=env.args)
+        finally:
+            type(m).forward = orig_fwd
+    finally:
+        torch.rand = orig_rand
+        torch.set_rng_state(state)
+    loss = O.training_loss(ret, gt.cuda(), relight)
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    for k in ("rgb_map", "acc_map", "depth_map") + (("rgb_with_brdf_map", "normal_map", "albedo_map") if relight else ()):
+        assert float((ret[k].detach().cpu() - ret_ref[k]).abs().max()) < 1e-4, k
+    loss.backward()
+    worst = {}
+    for name, p in m.named_parameters():
+        ref = grads_ref[name]
+        if float(ref.abs().max()) == 0.0:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, name
+        worst[name] = gerr(p.grad, ref)
+    bad = {k: round(v, 5) for k, v in worst.items() if v > GTOL}
+    assert not bad, (bad, {k: round(v, 6) for k, v in worst.items() if k.startswith("density") or k.startswith("app")})
+    assert len(worst) >= (18 if not relight else 30)
+    m.zero_grad(set_to_none=True)
+
+
+def test_optimizer_steps_reduce_loss(env):
+    """A few Adam steps on the HIP training path lower the image loss (end-to-end sanity of sign/scale)."""
+    import tensoir_amd
+    from tensoir_amd import Renderer_TensoIR_train
+    from tests.helpers import golden_checkpoint
+    eh, ew = [int(x) for x in env.g["scene/envmap_hw"]]
+    m = tensoir_amd.model_from_checkpoint(golden_checkpoint(env.g), "cuda", envmap_h=eh, envmap_w=ew)
+    rays, lidx = T(env.g, "rays/rays").cuda(), T(env.g, "rays/light_idx").cuda()
+    gt = torch.full((rays.shape[0], 3), 0.25, device="cuda")
+    opt = torch.optim.Adam(m.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99))
+    losses = []
+    for it in range(6):
+        ret = Renderer_TensoIR_train(rays, None, lidx, m, N_samples=64, white_bg=True, is_train=True,
+                                     is_relight=True, sample_method="stratified_sampling", device="cuda", args=env.args)
+        loss = env.O.training_loss(ret, gt, True)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

@@ -99,12 +99,14 @@ def test_unsupported_configurations_fail_loudly():
 
 def test_no_silent_fallbacks(model, golden):
     rays, lidx = T(golden, "rays/rays"), T(golden, "rays/light_idx")
-    with pytest.raises(NotImplementedError):           # autograd requested, no backward kernels yet
-        model(rays, lidx)
+    with pytest.raises(NotImplementedError):           # stand-alone per-point calls have no autograd bridge
+        model.compute_densityfeature(rays[:, :3])
     if not torch.cuda.is_available():
         from tensoir_amd._lib import TensoirHipError
         with torch.no_grad(), pytest.raises(TensoirHipError):
-            model(rays, lidx)                          # CPU tensors never run
+            model(rays, lidx)                          # CPU tensors never run (inference path) ...
+        with pytest.raises(TensoirHipError):
+            model(rays, lidx)                          # ... nor on the training path: no eager fallback
 
 
 def test_synth_rays():
