@@ -125,9 +125,9 @@ int tir_occupancy_query(const TirField* f, const float* xyz, uint8_t* hit, int64
 /* ---- K6: analytic d sigma/d xyz and derived normal -normalize(grad, eps=1e-6)
  *      (compute_derived_normals models/tensorBase_rotated_lights.py:839-856 ->
  *       compute_densityfeature_with_xyz_grad models/tensoRF_rotated_lights.py:113-129 ->
- *       models/relight_utils.py:57-107).  sigma/grad/normal may each be NULL. */
+ *       models/relight_utils.py:57-107).  sigma/grad/normal may each be NULL.  n_dev: as tir_vm_app_fwd. */
 int tir_density_grad_fwd(const TirField* f, const float* xyz, float* sigma, float* grad,
-                         float* normal, int64_t n, void* stream);
+                         float* normal, int64_t n, const int32_t* n_dev, void* stream);
 
 /* ---- K4: compute_appfeature / compute_intrinfeature / compute_bothfeature
  *      (models/tensoRF_rotated_lights.py:132-224).  light_idx (per point, or per `idx_map` entry when
@@ -184,6 +184,11 @@ int tir_march_primary_fwd(const TirField* f, const float* rays, const float* ray
 
 /* exclusive scan of counts[n] -> offsets[n+1] (offsets[n] = total) */
 int tir_exclusive_scan(const int32_t* counts, int32_t* offsets, int32_t n, void* stream);
+/* same, with every offset clamped to `cap` (a record capacity chosen before the counts are known on the host):
+ * consumers that index records through the offsets then stay inside buffers of `cap` records; *total (optional)
+ * receives the unclamped total so the caller can detect the overflow afterwards and redo the pass. */
+int tir_exclusive_scan_capped(const int32_t* counts, int32_t* offsets, int32_t n, int32_t cap,
+                              int32_t* total, void* stream);
 
 /* Compact the samples with weight > thres into records ordered by (ray, sample) -- the order of
  * the reference's boolean-mask indexing xyz_sampled[app_mask] (:924-926).

@@ -63,7 +63,7 @@ SIGNATURES = {
     "tir_pack_mlp": (C.c_int, [P, P, P, P, P, P, I32, I32, I32, I32, P, P]),
     "tir_vm_density_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, I64, P]),
     "tir_occupancy_query": (C.c_int, [C.POINTER(TirField), P, P, I64, P]),
-    "tir_density_grad_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, I64, P]),
+    "tir_density_grad_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, I64, P, P]),
     "tir_vm_app_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I32, I64, P, P]),
     "tir_vm_app_fwd_valu": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I32, I64, P, P]),
     "tir_mlp_fwd": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P, P]),
@@ -72,6 +72,7 @@ SIGNATURES = {
     "tir_mlp_fwd_valu": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P, P]),
     "tir_march_primary_fwd": (C.c_int, [C.POINTER(TirField), P, P, I32, I32, F32, P, P, P, P, P, P, P]),
     "tir_exclusive_scan": (C.c_int, [P, P, I32, P]),
+    "tir_exclusive_scan_capped": (C.c_int, [P, P, I32, I32, P, P]),
     "tir_compact_primary": (C.c_int, [C.POINTER(TirField), P, P, P, P, I32, I32, P, P, P, P, P]),
     "tir_composite_primary": (C.c_int, [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, F32, P, P]),
     "tir_march_secondary_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I64, I32, I32, P, F32, P, P,

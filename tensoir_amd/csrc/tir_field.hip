@@ -169,8 +169,9 @@ __device__ __forceinline__ void plane_line_grad(const float* __restrict__ plane,
 template <int C4>
 __global__ void __launch_bounds__(256)
 k_density_grad(TirField f, const float* __restrict__ xyz, float* __restrict__ sigma,
-               float* __restrict__ grad, float* __restrict__ normal, int64_t n) {
+               float* __restrict__ grad, float* __restrict__ normal, int64_t n, const int32_t* __restrict__ n_dev) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
     if (i >= n) return;
     const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;
@@ -205,17 +206,17 @@ k_density_grad(TirField f, const float* __restrict__ xyz, float* __restrict__ si
 }
 
 extern "C" int tir_density_grad_fwd(const TirField* f, const float* xyz, float* sigma, float* grad,
-                                    float* normal, int64_t n, void* stream) {
+                                    float* normal, int64_t n, const int32_t* n_dev, void* stream) {
     int rc = check_field(f);
     if (rc) return rc;
     if (n < 0 || (n > 0 && !xyz)) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
     dim3 g((unsigned)((n + 255) / 256)), b(256);
     switch (f->n_dcomp) {
-        case 16: hipLaunchKernelGGL(k_density_grad<4>, g, b, 0, tir_stream(stream), *f, xyz, sigma, grad, normal, n); break;
-        case 8:  hipLaunchKernelGGL(k_density_grad<2>, g, b, 0, tir_stream(stream), *f, xyz, sigma, grad, normal, n); break;
-        case 32: hipLaunchKernelGGL(k_density_grad<8>, g, b, 0, tir_stream(stream), *f, xyz, sigma, grad, normal, n); break;
-        default: hipLaunchKernelGGL(k_density_grad<1>, g, b, 0, tir_stream(stream), *f, xyz, sigma, grad, normal, n); break;
+        case 16: hipLaunchKernelGGL(k_density_grad<4>, g, b, 0, tir_stream(stream), *f, xyz, sigma, grad, normal, n, n_dev); break;
+        case 8:  hipLaunchKernelGGL(k_density_grad<2>, g, b, 0, tir_stream(stream), *f, xyz, sigma, grad, normal, n, n_dev); break;
+        case 32: hipLaunchKernelGGL(k_density_grad<8>, g, b, 0, tir_stream(stream), *f, xyz, sigma, grad, normal, n, n_dev); break;
+        default: hipLaunchKernelGGL(k_density_grad<1>, g, b, 0, tir_stream(stream), *f, xyz, sigma, grad, normal, n, n_dev); break;
     }
     TIR_CHECK_LAUNCH();
     return TIR_OK;

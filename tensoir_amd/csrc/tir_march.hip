@@ -106,7 +106,8 @@ extern "C" int tir_march_primary_train_fwd(const TirField* f, const float* rays,
 // exclusive scan of small int arrays (ray counts): single workgroup, chunked
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-k_exclusive_scan(const int32_t* __restrict__ counts, int32_t* __restrict__ offsets, int n) {
+k_exclusive_scan(const int32_t* __restrict__ counts, int32_t* __restrict__ offsets, int n, int cap,
+                 int32_t* __restrict__ total_out) {
     __shared__ int32_t wsum[16];
     __shared__ int32_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -126,17 +127,29 @@ k_exclusive_scan(const int32_t* __restrict__ counts, int32_t* __restrict__ offse
         int32_t woff = 0;
         for (int q = 0; q < wv; ++q) woff += wsum[q];
         int32_t carry = carry_s;
-        if (i < n) offsets[i] = carry + woff + incl - v;
+        if (i < n) offsets[i] = min(carry + woff + incl - v, cap);
         __syncthreads();
         if (tid == 1023) carry_s = carry + woff + incl;
         __syncthreads();
     }
-    if (tid == 0) offsets[n] = carry_s;
+    if (tid == 0) {
+        offsets[n] = min(carry_s, cap);
+        if (total_out) *total_out = carry_s;
+    }
 }
 
 extern "C" int tir_exclusive_scan(const int32_t* counts, int32_t* offsets, int32_t n, void* stream) {
     if (!offsets || n < 0 || (n > 0 && !counts)) return TIR_ERR_ARG;
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, tir_stream(stream), counts, offsets, n);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, tir_stream(stream), counts, offsets, n, 0x7fffffff,
+                       (int32_t*)nullptr);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_exclusive_scan_capped(const int32_t* counts, int32_t* offsets, int32_t n, int32_t cap,
+                                         int32_t* total, void* stream) {
+    if (!offsets || n < 0 || cap < 0 || (n > 0 && !counts)) return TIR_ERR_ARG;
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, tir_stream(stream), counts, offsets, n, cap, total);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
@@ -153,7 +166,8 @@ k_compact_primary(TirField f, const float* __restrict__ rays, const float* __res
     const int ray = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (ray >= B) return;
     int base = offsets[ray];
-    if (offsets[ray + 1] == base) return;
+    const int end = offsets[ray + 1];       // with capped offsets the records past the capacity are dropped
+    if (end == base) return;
     RaySetup rs = ray_setup(f, rays, ray);
     const bool hj = ray_jitter != nullptr;
     const float jit = hj ? ray_jitter[ray] : 0.0f;
@@ -162,8 +176,8 @@ k_compact_primary(TirField f, const float* __restrict__ rays, const float* __res
         float w = (k < S) ? weight[(size_t)ray * S + k] : 0.0f;
         bool keep = w > f.weight_thres;
         unsigned long long m = __ballot(keep);
-        if (keep) {
-            int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep && slot < end) {
             float z = sample_z(f, rs.t_min, k, jit, hj);
             rec_ray[slot] = ray;
             rec_k[slot] = k;
@@ -192,44 +206,49 @@ extern "C" int tir_compact_primary(const TirField* f, const float* rays, const f
 }
 
 // ------------------------------------------------------------------------------------------------
-// compositing + tone mapping (models/tensorBase_rotated_lights.py:973-1031): one thread per ray walks
-// its records in sample order (deterministic sums).
+// compositing + tone mapping (models/tensorBase_rotated_lights.py:973-1031): one wave per ray, lanes stride
+// over the ray's records, butterfly reduction (deterministic sums).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_composite_primary(const float* __restrict__ rays, const int32_t* __restrict__ offsets,
                     const float* __restrict__ rec_w, const float* __restrict__ rgb,
                     const float* __restrict__ brdf, const float* __restrict__ brdf_jit,
                     const float* __restrict__ pred_n, const float* __restrict__ der_n,
                     const float* __restrict__ acc_in, const float* __restrict__ depth_in, int B, int white_bg,
                     int is_relight, float fixed_fresnel, float* __restrict__ out) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    // one wave64 per ray: lane l takes records b+l, b+l+64, ...; fixed-shape butterfly reduction -> the sums
+    // depend only on the ray's own records (deterministic, invariant under ray sharding)
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= B) return;
     const int b = offsets[r], e = offsets[r + 1];
     float c[3] = {0, 0, 0}, nm[3] = {0, 0, 0}, al[3] = {0, 0, 0};
     float rough = 0, ndiff = 0, norient = 0, albc = 0, rghc = 0;
     const float vd[3] = {rays[6 * (size_t)r + 3], rays[6 * (size_t)r + 4], rays[6 * (size_t)r + 5]};
-    for (int i = b; i < e; ++i) {
+    for (int i = b + lane; i < e; i += 64) {
         const float w = rec_w[i];
         if (rgb) { c[0] = fmaf(w, rgb[3 * (size_t)i], c[0]); c[1] = fmaf(w, rgb[3 * (size_t)i + 1], c[1]); c[2] = fmaf(w, rgb[3 * (size_t)i + 2], c[2]); }
         if (!is_relight) continue;
         float a3[3] = {0, 0, 0}, rg = 0;
         if (brdf) {
-            a3[0] = brdf[4 * (size_t)i]; a3[1] = brdf[4 * (size_t)i + 1]; a3[2] = brdf[4 * (size_t)i + 2];
-            rg = brdf[4 * (size_t)i + 3] * 0.9f + 0.09f;                         // :933
+            const float4 bv = *reinterpret_cast<const float4*>(brdf + 4 * (size_t)i);
+            a3[0] = bv.x; a3[1] = bv.y; a3[2] = bv.z;
+            rg = bv.w * 0.9f + 0.09f;                                            // :933
             al[0] = fmaf(w, a3[0], al[0]); al[1] = fmaf(w, a3[1], al[1]); al[2] = fmaf(w, a3[2], al[2]);
             rough = fmaf(w, rg, rough);
         }
         if (brdf && brdf_jit) {                                                  // :937-943, :858-863
+            const float4 jv = *reinterpret_cast<const float4*>(brdf_jit + 4 * (size_t)i);
+            const float ajv[3] = {jv.x, jv.y, jv.z};
             float cost = 0.f;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                float aj = brdf_jit[4 * (size_t)i + q];
-                float base = fmaxf(fmaxf(a3[q], aj), 1e-6f);
-                float dlt = (a3[q] - aj) / base;
+                float base = fmaxf(fmaxf(a3[q], ajv[q]), 1e-6f);
+                float dlt = (a3[q] - ajv[q]) / base;
                 cost = fmaf(dlt, dlt, cost);
             }
             albc = fmaf(w, cost, albc);
-            float rj = brdf_jit[4 * (size_t)i + 3] * 0.9f + 0.09f;
+            float rj = jv.w * 0.9f + 0.09f;
             float base = fmaxf(fmaxf(rg, rj), 1e-6f);
             float dlt = (rg - rj) / base;
             rghc = fmaf(w, dlt * dlt, rghc);
@@ -245,6 +264,15 @@ k_composite_primary(const float* __restrict__ rays, const int32_t* __restrict__ 
             norient = fmaf(w, fmaxf(dot, 0.f), norient);
         }
     }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { c[q] = group_sum<64>(c[q]); }
+    if (is_relight) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { nm[q] = group_sum<64>(nm[q]); al[q] = group_sum<64>(al[q]); }
+        rough = group_sum<64>(rough); ndiff = group_sum<64>(ndiff); norient = group_sum<64>(norient);
+        albc = group_sum<64>(albc); rghc = group_sum<64>(rghc);
+    }
+    if (lane != 0) return;
     const float acc = acc_in[r];
     float depth = depth_in[r];
     float* o = out + (size_t)r * TIR_MAP_STRIDE;
@@ -285,7 +313,7 @@ extern "C" int tir_composite_primary(const float* rays, const int32_t* offsets, 
     if (B < 0) return TIR_ERR_ARG;
     if (B == 0) return TIR_OK;
     if (!rays || !offsets || !acc || !depth || !out_maps) return TIR_ERR_ARG;
-    hipLaunchKernelGGL(k_composite_primary, dim3((B + 63) / 64), dim3(64), 0, tir_stream(stream), rays, offsets,
+    hipLaunchKernelGGL(k_composite_primary, dim3((B + 3) / 4), dim3(256), 0, tir_stream(stream), rays, offsets,
                        rec_w, rgb, brdf, brdf_jit, pred_normal, derived_normal, acc, depth, B, white_bg,
                        is_relight, fixed_fresnel, out_maps);
     TIR_CHECK_LAUNCH();

@@ -11,6 +11,7 @@
 // operands of the next layer when its contraction order is permuted to k2(t,h) -- no cross-lane traffic
 // between layers.  Lane halves h=0/1 split every contraction's k range in two.
 #include "tir_common.hpp"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -293,11 +294,15 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
     }
 }
 
-// sin and cos of x with one shared Cody-Waite reduction and two minimax polynomials (<= 2 ulp for
-// |x| < 8192; larger arguments take the library path).  Branch-free, so both lane halves of a wave run the
-// same instruction stream; used by the split-bf16 decoders, whose own arithmetic error (~1e-5) dwarfs it.
+// sin and cos of x with one shared Cody-Waite reduction and two minimax polynomials (<= 2 ulp for |x| < 8192);
+// larger arguments are first reduced modulo 2 pi in double precision (a few v_fma_f64, inline: a library call
+// here would clobber the register file at 17 call sites).  Branch-free apart from that rare pre-reduction.
 __device__ __forceinline__ void fast_sincos(float x, float& s, float& c) {
-    if (__builtin_expect(!(fabsf(x) < 8192.0f), 0)) { s = sinf(x); c = cosf(x); return; }
+    if (__builtin_expect(!(fabsf(x) < 8192.0f), 0)) {
+        const double xd = (double)x;
+        const double k = rint(xd * 0.15915494309189533577);
+        x = (float)fma(k, -6.283185307179586476925, xd);       // |x| <= pi (NaN / inf stay NaN)
+    }
     const float n = rintf(x * 0.636619772367581343f);
     float r = fmaf(n, -1.57079637050628662109375f, x);
     r = fmaf(n, 4.37113900018624283e-8f, r);
@@ -314,6 +319,8 @@ __device__ __forceinline__ void fast_sincos(float x, float& s, float& c) {
 
 // This lane-half's positional encodings of value v: half 0 -> {sin v, sin 2v}, half 1 -> {cos v, cos 2v}
 // (double-angle identities: sin 2v = 2 s c, cos 2v = 1 - 2 s^2).
+// (Sharing the sincos between the two lane halves of a sample with v_permlane32_swap_b32 was tried: the builtin
+// returns a wrong second result with this compiler and the inline-asm form has unmodelled hazards.)
 __device__ __forceinline__ void pe_pair(float v, int h, float& p1, float& p2) {
     float s, c;
     fast_sincos(v, s, c);
@@ -325,7 +332,7 @@ struct AuxPE { float s[3], c[3], s2[3], c2[3]; };   // sin/cos of aux and of 2*a
 
 // input t (>= NPF) of the tail for lane half h: half 0 -> feat[0..R0), half 1 -> feat[R0..F), aux, sin/cos PE(aux)
 template <int T>
-__device__ __forceinline__ float tail_input(const float (&ft)[F], const float (&ax)[3], const AuxPE& ap, int h) {
+__device__ __forceinline__ float tail_input(const float (&ft)[F + 1], const float (&ax)[3], const AuxPE& ap, int h) {
     constexpr int q = T - NPF;
     float a = 0.0f, b = 0.0f;
     if constexpr (q < R0) a = ft[q];
@@ -342,7 +349,7 @@ __device__ __forceinline__ float tail_input(const float (&ft)[F], const float (&
 }
 
 template <int KB, int E>
-__device__ __forceinline__ void build_pair(const float (&ft)[F], const float (&ax)[3], const AuxPE& ap, int h, float (&v)[8]) {
+__device__ __forceinline__ void build_pair(const float (&ft)[F + 1], const float (&ax)[3], const AuxPE& ap, int h, float (&v)[8]) {
     constexpr int t = KB * 8 + E;
     if constexpr (t + 1 < NPF) pe_pair(ft[t >> 1], h, v[E], v[E + 1]);
     else {
@@ -354,7 +361,7 @@ __device__ __forceinline__ void build_pair(const float (&ft)[F], const float (&a
 // Build this lane-half's 80 padded inputs one k-block (8 values) at a time and split each block to bf16
 // hi/lo at once; template recursion keeps every array index a compile-time constant.
 template <int KB>
-__device__ __forceinline__ void build_inputs(const float (&ft)[F], const float (&ax)[3], const AuxPE& ap, int h,
+__device__ __forceinline__ void build_inputs(const float (&ft)[F + 1], const float (&ax)[3], const AuxPE& ap, int h,
                                              bf16x8 (&xh)[KB0], bf16x8 (&xl)[KB0]) {
     float v[8];
     build_pair<KB, 0>(ft, ax, ap, h, v);
@@ -365,11 +372,132 @@ __device__ __forceinline__ void build_inputs(const float (&ft)[F], const float (
     if constexpr (KB + 1 < KB0) build_inputs<KB + 1>(ft, ax, ap, h, xh, xl);
 }
 
+// one k-block of a layer: the A tiles of all four 32-row blocks, then the MFMAs product-major so that consecutive
+// MFMAs never share an accumulator (no dependent-issue stalls)
+template <int NPROD, bool PM>
+__device__ __forceinline__ void mfma_block(const bf16x8* __restrict__ whi, const bf16x8* __restrict__ wlo, int wi,
+                                           const bf16x8& bh, const bf16x8& bl, f32x16 (&acc)[4]) {
+    if (!PM) {        // accumulator-major: the three products of one 32-row block back to back
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const bf16x8 a_hi = whi[wi + mt * 32];
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bh, acc[mt], 0, 0, 0);
+            if (NPROD == 3) {
+                const bf16x8 a_lo = wlo[wi + mt * 32];
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bh, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bl, acc[mt], 0, 0, 0);
+            }
+        }
+        return;
+    }
+    bf16x8 ah[4], al[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        ah[mt] = whi[wi + mt * 32];
+        if (NPROD == 3) al[mt] = wlo[wi + mt * 32];
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh, acc[mt], 0, 0, 0);
+    if (NPROD == 3) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl, acc[mt], 0, 0, 0);
+    }
+}
+
+// ---- interleaved form: per k-block [issue the A-tile LDS reads] [build that block's 8 inputs on the VALU] [12 MFMAs].
+// The MFMAs of block kb execute on the matrix pipe while the wave's VALU already builds block kb+1 (intra-wave overlap
+// instead of "all inputs, then all MFMAs"), the input build covers the LDS latency, and only one block of inputs is live.
 template <int NPROD>
+__device__ __forceinline__ void mfma12(const bf16x8 (&ah)[4], const bf16x8 (&al)[4], const bf16x8& bh, const bf16x8& bl,
+                                       f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh, acc[mt], 0, 0, 0);
+    if (NPROD == 3) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl, acc[mt], 0, 0, 0);
+    }
+}
+
+template <int NPROD, int KB>
+__device__ __forceinline__ void layer1_interleaved(const bf16x8* __restrict__ whi, const bf16x8* __restrict__ wlo, int h, int sl,
+                                                   const float (&ft)[F + 1], const float (&ax)[3], const AuxPE& ap,
+                                                   f32x16 (&acc)[4]) {
+    bf16x8 ah[4], al[4];
+    const int wi = (KB * 2 + h) * 128 + sl;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        ah[mt] = whi[wi + mt * 32];
+        if (NPROD == 3) al[mt] = wlo[wi + mt * 32];
+    }
+    float v[8];
+    build_pair<KB, 0>(ft, ax, ap, h, v);
+    build_pair<KB, 2>(ft, ax, ap, h, v);
+    build_pair<KB, 4>(ft, ax, ap, h, v);
+    build_pair<KB, 6>(ft, ax, ap, h, v);
+    bf16x8 xh, xl;
+    split8(v, xh, xl);
+    mfma12<NPROD>(ah, al, xh, xl, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (KB + 1 < KB0) layer1_interleaved<NPROD, KB + 1>(whi, wlo, h, sl, ft, ax, ap, acc);
+}
+
+template <int NPROD, int KB>
+__device__ __forceinline__ void layer2_interleaved(const bf16x8* __restrict__ whi, const bf16x8* __restrict__ wlo, int h, int sl,
+                                                   const f32x16 (&hid)[4], f32x16 (&acc)[4]) {
+    bf16x8 ah[4], al[4];
+    const int wi = (KB * 2 + h) * 128 + sl;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        ah[mt] = whi[wi + mt * 32];
+        if (NPROD == 3) al[mt] = wlo[wi + mt * 32];
+    }
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { constexpr int q0 = KB * 8; v[e] = fmaxf(hid[(q0 + e) >> 4][(q0 + e) & 15], 0.0f); }
+    bf16x8 xh, xl;
+    split8(v, xh, xl);
+    mfma12<NPROD>(ah, al, xh, xl, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (KB + 1 < KB1) layer2_interleaved<NPROD, KB + 1>(whi, wlo, h, sl, hid, acc);
+}
+
+// one sample's decoder inputs as they come from memory: 27 features (+ zero pad) and the 3 aux values
+struct RowIn { float ft[F + 1]; float ax[3]; };
+
+template <bool VEC>
+__device__ __forceinline__ void load_row(const float* __restrict__ feat, int fstride, const float* __restrict__ aux,
+                                         int64_t s, int64_t ai, RowIn& r) {
+    const float* fr = feat + s * fstride;
+    if (VEC) {       // rows are 16-byte aligned and at least 28 floats long: 7 dwordx4 per lane instead of 27 dwords
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(fr + 4 * q);
+            r.ft[4 * q] = v.x; r.ft[4 * q + 1] = v.y; r.ft[4 * q + 2] = v.z; r.ft[4 * q + 3] = v.w;
+        }
+        r.ft[F] = 0.0f;
+    } else {
+#pragma unroll
+        for (int d = 0; d < F; ++d) r.ft[d] = fr[d];
+        r.ft[F] = 0.0f;
+    }
+    r.ax[0] = aux[3 * ai]; r.ax[1] = aux[3 * ai + 1]; r.ax[2] = aux[3 * ai + 2];
+}
+
+__device__ __forceinline__ int64_t aux_index(const int32_t* __restrict__ aux_map, int aux_mod, int64_t s) {
+    int64_t ai = aux_map ? (int64_t)aux_map[s] : s;
+    if (aux_mod > 0) ai %= aux_mod;
+    return ai;
+}
+
+template <int NPROD, bool VEC, bool PF, bool PM>
 __global__ void __launch_bounds__(512)
 k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int fstride, const float* __restrict__ aux,
            const int32_t* __restrict__ aux_map, int aux_mod, float* __restrict__ out, int64_t n,
-           const int32_t* __restrict__ n_dev, int out_dim, int act) {
+           const int32_t* __restrict__ n_dev, int out_dim, int act, int stagger) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
         const float* src = packed + OFF_BF;
@@ -377,6 +505,11 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
             *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(src + i);
     }
     __syncthreads();
+    // The two waves that share a SIMD (w and w+4) would otherwise run in lockstep -- both in the VALU input-build
+    // phase, then both in the MFMA phase -- leaving each pipe idle half of the time.  Delaying the upper four waves by
+    // about half a tile period puts one wave's MFMA phase under the other's VALU phase for the rest of the kernel.
+    if ((threadIdx.x >> 8) != 0)
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);
     const bf16x8* w0hi = reinterpret_cast<const bf16x8*>(lds + BH_FLOATS);
     const bf16x8* w0lo = w0hi + BW0_ELEMS / 8;
     const bf16x8* w1hi = w0lo + BW0_ELEMS / 8;
@@ -386,80 +519,63 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sl = lane & 31, h = lane >> 5;
     const int64_t n_tiles = (n + 255) / 256;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t G = gridDim.x;
+    if ((int64_t)blockIdx.x >= n_tiles) return;
+    auto row_of = [&](int64_t tile) { const int64_t sr = tile * 256 + wave * 32 + sl; return sr < n ? sr : n - 1; };
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += G) {
         const int64_t s_raw = tile * 256 + wave * 32 + sl;
-        const int64_t s = s_raw < n ? s_raw : n - 1;
-        bf16x8 xh[KB0], xl[KB0];
-        {
-            float ft[F];
-            const float* fr = feat + s * fstride;
+        RowIn cur;
+        { const int64_t sc = row_of(tile); load_row<VEC>(feat, fstride, aux, sc, aux_index(aux_map, aux_mod, sc), cur); }
+        AuxPE ap;
 #pragma unroll
-            for (int d = 0; d < F; ++d) ft[d] = fr[d];
-            int64_t ai = aux_map ? (int64_t)aux_map[s] : s;
-            if (aux_mod > 0) ai %= aux_mod;
-            const float ax[3] = {aux[3 * ai], aux[3 * ai + 1], aux[3 * ai + 2]};
-            AuxPE ap;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                fast_sincos(ax[d], ap.s[d], ap.c[d]);
-                ap.s2[d] = 2.0f * ap.s[d] * ap.c[d];
-                ap.c2[d] = fmaf(-2.0f * ap.s[d], ap.s[d], 1.0f);
-            }
-            build_inputs<0>(ft, ax, ap, h, xh, xl);
+        for (int d = 0; d < 3; ++d) {
+            fast_sincos(cur.ax[d], ap.s[d], ap.c[d]);
+            ap.s2[d] = 2.0f * ap.s[d] * ap.c[d];
+            ap.c2[d] = fmaf(-2.0f * ap.s[d], ap.s[d], 1.0f);
         }
-        // ---- layer 1 ----
-        f32x16 acc[4];
+        f32x16 acc[4], acc2[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const float* bp = lds + BH_B0 + (h * 4 + mt) * 16;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][r] = bp[r];
         }
-#pragma unroll
-        for (int kb = 0; kb < KB0; ++kb) {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int wi = ((kb * 2 + h) * 4 + mt) * 32 + sl;
-                const bf16x8 ah = w0hi[wi];
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[kb], acc[mt], 0, 0, 0);
-                if (NPROD == 3) {
-                    const bf16x8 al = w0lo[wi];
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[kb], acc[mt], 0, 0, 0);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[kb], acc[mt], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- layer 2 ----
-        bf16x8 hh[KB1], hl[KB1];
-#pragma unroll
-        for (int kb = 0; kb < KB1; ++kb) {
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const int q = kb * 8 + e; v[e] = fmaxf(acc[q >> 4][q & 15], 0.0f); }
-            split8(v, hh[kb], hl[kb]);
-        }
-        f32x16 acc2[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const float* bp = lds + BH_B1 + (h * 4 + mt) * 16;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[mt][r] = bp[r];
-        }
-#pragma unroll
-        for (int kb = 0; kb < KB1; ++kb) {
+        if (PF) {
+            layer1_interleaved<NPROD, 0>(w0hi, w0lo, h, sl, cur.ft, cur.ax, ap, acc);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const int wi = ((kb * 2 + h) * 4 + mt) * 32 + sl;
-                const bf16x8 ah = w1hi[wi];
-                acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, hh[kb], acc2[mt], 0, 0, 0);
-                if (NPROD == 3) {
-                    const bf16x8 al = w1lo[wi];
-                    acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, hh[kb], acc2[mt], 0, 0, 0);
-                    acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, hl[kb], acc2[mt], 0, 0, 0);
-                }
+                const float* bp = lds + BH_B1 + (h * 4 + mt) * 16;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[mt][r] = bp[r];
             }
-            __builtin_amdgcn_sched_barrier(0);
+            layer2_interleaved<NPROD, 0>(w1hi, w1lo, h, sl, acc, acc2);
+        } else {
+            bf16x8 xh[KB0], xl[KB0];
+            build_inputs<0>(cur.ft, cur.ax, ap, h, xh, xl);
+#pragma unroll
+            for (int kb = 0; kb < KB0; ++kb) {
+                mfma_block<NPROD, PM>(w0hi, w0lo, (kb * 2 + h) * 128 + sl, xh[kb], xl[kb], acc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            bf16x8 hh[KB1], hl[KB1];
+#pragma unroll
+            for (int kb = 0; kb < KB1; ++kb) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int q = kb * 8 + e; v[e] = fmaxf(acc[q >> 4][q & 15], 0.0f); }
+                split8(v, hh[kb], hl[kb]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float* bp = lds + BH_B1 + (h * 4 + mt) * 16;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[mt][r] = bp[r];
+            }
+#pragma unroll
+            for (int kb = 0; kb < KB1; ++kb) {
+                mfma_block<NPROD, PM>(w1hi, w1lo, (kb * 2 + h) * 128 + sl, hh[kb], hl[kb], acc2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         // ---- layer 3 (fp32 VALU) ----
         float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
@@ -811,6 +927,27 @@ extern "C" int tir_mlp_train_fwd(const TirMlp* m, const float* feat, int32_t fea
     return TIR_OK;
 }
 
+template <int NPROD, bool VEC, bool PF, bool PM>
+static int launch_bf16_v(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map, int32_t aux_mod,
+                         float* out, int64_t n, const int32_t* n_dev, void* stream) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)BF_BYTES;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bf16<NPROD, VEC, PF, PM>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+        attr_set = true;
+    }
+    int64_t tiles = (n + 255) / 256;
+    unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    int stagger = 0;                  // units of 32 x 64 clocks; TIR_MLP_STAGGER overrides (tuning; 0 with the interleaved build)
+    if (const char* e = getenv("TIR_MLP_STAGGER")) stagger = atoi(e) < 0 ? 0 : atoi(e);
+    hipLaunchKernelGGL((k_mlp_bf16<NPROD, VEC, PF, PM>), dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, feat_stride, aux,
+                       aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act, tiles > (int64_t)grid ? stagger : 0);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
 template <int NPROD>
 static int launch_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map, int32_t aux_mod,
                        float* out, int64_t n, const int32_t* n_dev, void* stream) {
@@ -818,20 +955,16 @@ static int launch_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, 
     if (rc) return rc;
     if (n < 0 || feat_stride < F || (n > 0 && (!feat || !aux || !out))) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
-    static bool attr_set = false;
-    const size_t lds = (size_t)BF_BYTES;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bf16<NPROD>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return -(int)e;
-        attr_set = true;
+    const bool vec = (feat_stride % 4 == 0) && feat_stride >= F + 1 && (reinterpret_cast<uintptr_t>(feat) % 16 == 0);
+    int variant = 3;                  // bit 0: interleaved input build (per k-block), bit 1: product-major MFMA order
+    if (const char* e = getenv("TIR_MLP_VARIANT")) variant = atoi(e) & 3;
+    if (!vec) return launch_bf16_v<NPROD, false, false, false>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream);
+    switch (variant) {
+        case 0: return launch_bf16_v<NPROD, true, false, false>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream);
+        case 1: return launch_bf16_v<NPROD, true, true, false>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream);
+        case 2: return launch_bf16_v<NPROD, true, false, true>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream);
+        default: return launch_bf16_v<NPROD, true, true, true>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream);
     }
-    int64_t tiles = (n + 255) / 256;
-    unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
-    hipLaunchKernelGGL(k_mlp_bf16<NPROD>, dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, feat_stride, aux,
-                       aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act);
-    TIR_CHECK_LAUNCH();
-    return TIR_OK;
 }
 
 extern "C" int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map, int32_t aux_mod,

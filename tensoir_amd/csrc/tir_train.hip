@@ -255,7 +255,7 @@ k_density_grad_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward of compositing + tone mapping: one thread per ray walks its records (as the forward does).
+// Backward of compositing + tone mapping: one wave per ray, lanes stride over the ray's records (as the forward does).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float srgb_grad(float x) {       // d linear2srgb / dx incl. the [0,1] clip (pass-through inclusive)
     if (!(x >= 0.0f && x <= 1.0f)) return 0.0f;
@@ -278,7 +278,7 @@ __device__ __forceinline__ void rel_smooth_grad(float a, float b, float& da, flo
     db = -ddlt / base + dbase * bb;
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_composite_primary_bwd(const float* __restrict__ rays, const int32_t* __restrict__ offsets,
                         const int32_t* __restrict__ rec_k, const float* __restrict__ rec_w,
                         const float* __restrict__ rgb, const float* __restrict__ brdf,
@@ -289,14 +289,15 @@ k_composite_primary_bwd(const float* __restrict__ rays, const int32_t* __restric
                         float* __restrict__ g_brdf, float* __restrict__ g_brdf_jit, float* __restrict__ g_pred,
                         float* __restrict__ g_der, float* __restrict__ g_weight, float* __restrict__ g_acc_out,
                         float* __restrict__ g_depth_out) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= B) return;
     const int b = offsets[r], e = offsets[r + 1];
     const float* go = g_maps + (size_t)r * TIR_MAP_STRIDE;
     const float vd[3] = {rays[6 * (size_t)r + 3], rays[6 * (size_t)r + 4], rays[6 * (size_t)r + 5]};
     // ---- recompute the forward sums (same order as k_composite_primary) ----
     float c[3] = {0, 0, 0}, nm[3] = {0, 0, 0}, al[3] = {0, 0, 0}, rough = 0;
-    for (int i = b; i < e; ++i) {
+    for (int i = b + lane; i < e; i += 64) {
         const float w = rec_w[i];
         if (rgb) { c[0] = fmaf(w, rgb[3 * (size_t)i], c[0]); c[1] = fmaf(w, rgb[3 * (size_t)i + 1], c[1]); c[2] = fmaf(w, rgb[3 * (size_t)i + 2], c[2]); }
         if (!is_relight) continue;
@@ -306,6 +307,9 @@ k_composite_primary_bwd(const float* __restrict__ rays, const int32_t* __restric
         }
         if (pred_n) { nm[0] = fmaf(w, pred_n[3 * (size_t)i], nm[0]); nm[1] = fmaf(w, pred_n[3 * (size_t)i + 1], nm[1]); nm[2] = fmaf(w, pred_n[3 * (size_t)i + 2], nm[2]); }
     }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { c[q] = group_sum<64>(c[q]); nm[q] = group_sum<64>(nm[q]); al[q] = group_sum<64>(al[q]); }
+    rough = group_sum<64>(rough);
     const float acc = acc_in[r];
     const float bg = 1.0f - acc;
     float g_acc = go[14];
@@ -336,10 +340,9 @@ k_composite_primary_bwd(const float* __restrict__ rays, const int32_t* __restric
         if (white_bg) g_acc -= gc[0] + gc[1] + gc[2] + gnm[2] + gal[0] + gal[1] + gal[2] + grough + gfr;
         g15 = go[15]; g16 = go[16]; g17 = go[17]; g18 = go[18];
     }
-    g_acc_out[r] = g_acc;
-    g_depth_out[r] = g_depth;
+    if (lane == 0) { g_acc_out[r] = g_acc; g_depth_out[r] = g_depth; }
     // ---- per-record gradients ----
-    for (int i = b; i < e; ++i) {
+    for (int i = b + lane; i < e; i += 64) {
         const float w = rec_w[i];
         float gw = 0.f;
         if (rgb) {
@@ -844,7 +847,7 @@ extern "C" int tir_composite_primary_bwd(const float* rays, const int32_t* offse
     if (B == 0) return TIR_OK;
     if (!rays || !offsets || !acc || !depth || !g_maps || !g_weight || !g_acc || !g_depth) return TIR_ERR_ARG;
     if (rgb && !g_rgb) return TIR_ERR_ARG;
-    hipLaunchKernelGGL(k_composite_primary_bwd, dim3((B + 63) / 64), dim3(64), 0, tir_stream(stream), rays, offsets,
+    hipLaunchKernelGGL(k_composite_primary_bwd, dim3((B + 3) / 4), dim3(256), 0, tir_stream(stream), rays, offsets,
                        rec_k, rec_w, rgb, brdf, brdf_jit, pred_normal, derived_normal, acc, depth, B, S, white_bg,
                        is_relight, fixed_fresnel, g_maps, g_rgb, g_brdf, g_brdf_jit, g_pred, g_der, g_weight, g_acc,
                        g_depth);

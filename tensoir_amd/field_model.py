@@ -624,7 +624,7 @@ class TensorVMSplit(nn.Module):
 
     # ---- the primary pass ----------------------------------------------------------------------------
     def forward(self, rays_chunk, light_idx, white_bg=True, is_train=False, ndc_ray=False, is_relight=True,
-                N_samples=-1, _brdf_jitter_dense=None, _return_maps=False):
+                N_samples=-1, _brdf_jitter_dense=None, _return_maps=False, _defer_check=False):
         """TensorBase.forward (models/tensorBase_rotated_lights.py:868-1036) as a chain of HIP launches:
         march -> scan -> compact -> appearance gather -> decoders -> analytic normals -> composite.
 
@@ -650,37 +650,70 @@ class TensorVMSplit(nn.Module):
                                                   _brdf_jitter_dense, *training.field_param_list(self))
             out = self.unpack_maps(maps, is_relight)
             return (out, maps) if _return_maps else out
+        # Record capacity: the number A of w > thres samples is only known on the device.  The first call per
+        # (B, S) reads it back (one host sync in the middle of the pass); later inference calls size their buffers
+        # from the previous count, bound every kernel by the device-side count (n_dev) and check for overflow
+        # once everything -- incl. the caller's shading stage when _defer_check -- has been queued.
+        hints = self.__dict__.setdefault("_app_cap_hints", {})
+        cap = hints.get((B, S)) if (not is_train and _brdf_jitter_dense is None) else None
         weight, acc, depth, _tend, cnt = ops.march_primary(f, rays, jitter, S, self.march_t_stop)
-        offsets = ops.exclusive_scan(cnt)
-        A = int(offsets[-1].item())                      # the one host sync of the pass
+        if cap is None:
+            offsets = ops.exclusive_scan(cnt)
+            A = int(offsets[-1].item())                  # the one host sync of the pass
+            n_dev = total_dev = None
+        else:
+            offsets, total_dev = ops.exclusive_scan_capped(cnt, cap)
+            A, n_dev = cap, offsets[B:]
         rec_ray, rec_k, rec_w, rec_xyz = ops.compact_primary(f, rays, jitter, weight, offsets, A)
         rgb = brdf = brdf_j = pred = derived = None
         if A > 0:
             viewdirs = rays[:, 3:6].contiguous()
-            rad, intr = ops.vm_app(f, rec_xyz, lidx, rec_ray, True, bool(is_relight))
-            rgb = self.renderModule.run(rad, viewdirs, rec_ray)
+            rad, intr = ops.vm_app(f, rec_xyz, lidx, rec_ray, True, bool(is_relight), None, 0, n_dev)
+            rgb = ops.mlp(self.renderModule.packed(), rad, viewdirs, rec_ray, None, 0, n_dev)
             if is_relight:
-                brdf = self.renderModule_brdf.run(intr, rec_xyz)
+                pb = self.renderModule_brdf.packed()
+                brdf = ops.mlp(pb, intr, rec_xyz, None, None, 0, n_dev)
                 if _brdf_jitter_dense is not None:
                     noise = _brdf_jitter_dense.to(dev, torch.float32)[rec_ray.long(), rec_k.long()]
                 else:
                     noise = torch.randn((A, 3), device=dev, dtype=torch.float32)
                 xyz_j = rec_xyz + noise * 0.01
-                intr_j = ops.vm_app(f, xyz_j, None, None, False, True)[1]
-                brdf_j = self.renderModule_brdf.run(intr_j, xyz_j)
+                intr_j = ops.vm_app(f, xyz_j, None, None, False, True, None, 0, n_dev)[1]
+                brdf_j = ops.mlp(pb, intr_j, xyz_j, None, None, 0, n_dev)
                 if self.normals_kind == "purely_derived":
-                    pred = ops.density_grad(f, rec_xyz)[2]
+                    pred = ops.density_grad(f, rec_xyz, n_dev=n_dev)[2]
                 else:
-                    pred = self.renderModule_normal.run(intr, rec_xyz)
+                    pred = ops.mlp(self.renderModule_normal.packed(), intr, rec_xyz, None, None, 0, n_dev)
                     if self.normals_kind == "derived_plus_predicted":
-                        derived = ops.density_grad(f, rec_xyz)[2]
+                        derived = ops.density_grad(f, rec_xyz, n_dev=n_dev)[2]
         bg = bool(white_bg or (is_train and torch.rand((1,)) < 0.5))
         maps = ops.composite_primary(rays, offsets, rec_w, rgb, brdf, brdf_j, pred, derived, acc, depth,
                                      bg, is_relight, self.fixed_fresnel)
         if self.normals_kind == "purely_derived" and is_relight:
             maps[:, 16] = 0.0        # orientation loss only exists for predicted normals (:953-960)
+
+        def finish():
+            """True when the pass is valid; False when the record capacity overflowed (the caller re-runs)."""
+            total = A if total_dev is None else int(total_dev.item())
+            if len(hints) > 64:
+                hints.clear()
+            hints[(B, S)] = min(max(int(total * 1.25) + 4096, 1 << 14), B * S)
+            if total_dev is not None and total > cap:
+                hints.pop((B, S), None)               # next call takes the exact (synchronising) route
+                return False
+            return True
+        if _defer_check:
+            self.__dict__["_pending_primary"] = finish
+        elif not finish():
+            return self.forward(rays_chunk, light_idx, white_bg, is_train, ndc_ray, is_relight, N_samples,
+                                _brdf_jitter_dense, _return_maps)
         out = self.unpack_maps(maps, is_relight)
         return (out, maps) if _return_maps else out
+
+    def _finish_primary(self):
+        """Deferred overflow check of the last forward(..., _defer_check=True); True = results are valid."""
+        fin = self.__dict__.pop("_pending_primary", None)
+        return True if fin is None else fin()
 
     @staticmethod
     def unpack_maps(maps, is_relight=True):

@@ -160,13 +160,13 @@ def occupancy_query(field: TirField, xyz):
     return hit
 
 
-def density_grad(field: TirField, xyz, want_sigma=False, want_grad=False, want_normal=True):
+def density_grad(field: TirField, xyz, want_sigma=False, want_grad=False, want_normal=True, n_dev=None):
     xyz = f32(xyz, "xyz", 3).view(-1, 3)
     n = xyz.shape[0]
     mk = lambda on, *s: torch.empty(s, dtype=torch.float32, device=xyz.device) if on else None
     sigma, grad, normal = mk(want_sigma, n), mk(want_grad, n, 3), mk(want_normal, n, 3)
     _call("tir_density_grad_fwd", C.byref(field), _ptr(xyz), _ptr(sigma), _ptr(grad), _ptr(normal),
-                                     n, _stream())
+                                     n, _ptr(n_dev), _stream())
     return sigma, grad, normal
 
 
@@ -253,6 +253,16 @@ def exclusive_scan(counts):
     off = torch.empty((n + 1,), dtype=torch.int32, device=counts.device)
     _call("tir_exclusive_scan", _ptr(counts), _ptr(off), n, _stream())
     return off
+
+
+def exclusive_scan_capped(counts, cap):
+    """offsets clamped to `cap` records + the true total (device int32 [1])."""
+    counts = i32(counts, "counts").view(-1)
+    n = counts.numel()
+    off = torch.empty((n + 1,), dtype=torch.int32, device=counts.device)
+    total = torch.empty((1,), dtype=torch.int32, device=counts.device)
+    _call("tir_exclusive_scan_capped", _ptr(counts), _ptr(off), n, int(cap), _ptr(total), _stream())
+    return off, total
 
 
 def compact_primary(field: TirField, rays, ray_jitter, weight, offsets, total):

@@ -303,3 +303,25 @@ def test_full_size_properties(full):
     assert float(ret["rgb_with_brdf_map"].min()) >= 0 and float(ret["rgb_with_brdf_map"].max()) <= 1.0 + 1e-6
     n = ret["normal_map"].norm(dim=-1)
     assert float((n[ret["acc_map"] > 0.5] - 1).abs().max()) < 1e-4
+
+
+@torch.no_grad()
+def test_record_capacity_hint_overflow_recovers(env):
+    """Inference calls size the record buffers from the previous call's count and check afterwards; a hint that
+    is too small must be detected and the pass redone (identical results, hint repaired)."""
+    from tensoir_amd import Renderer_TensoIR_train
+    m = env.model
+    rays, lidx = G(env, "rays/rays"), G(env, "rays/light_idx")
+    B, S = rays.shape[0], m.nSamples
+    m.__dict__.pop("_app_cap_hints", None)
+    kw = dict(N_samples=-1, white_bg=True, is_train=False, is_relight=True, sample_method="fixed_envirmap",
+              device="cuda", args=env.args)
+    first = Renderer_TensoIR_train(rays, None, lidx, m, **kw)            # exact route, learns the count
+    assert (B, S) in m._app_cap_hints
+    second = Renderer_TensoIR_train(rays, None, lidx, m, **kw)           # hinted route
+    m._app_cap_hints[(B, S)] = 8                                         # far too small
+    third = Renderer_TensoIR_train(rays, None, lidx, m, **kw)            # overflow -> redone
+    assert m._app_cap_hints[(B, S)] > 8
+    for k in ("rgb_map", "depth_map", "normal_map", "albedo_map", "acc_map", "rgb_with_brdf_map", "normals_diff_map"):
+        assert torch.equal(first[k], second[k]), k
+        assert torch.equal(first[k], third[k]), k
