@@ -237,19 +237,27 @@ def main():
             dist.destroy_process_group()
         return
 
+    pmc_traffic = {}
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # bytes per launch from separate rocprofv3 --pmc passes
+    if os.path.exists(pmc):                                      # (tools/profile_gpu.sh + tools/summarize_prof.py)
+        try:
+            pmc_traffic = json.load(open(pmc))
+        except Exception:
+            pmc_traffic = {}
+
+    def roof(r):
+        return {"kernel": r["kernel"], "bound": r["bound"], "achieved": round(r["achieved"], 2),
+                "peak": r["peak"], "unit": r["runit"], "frac": round(r["frac"], 4),
+                "traffic": pmc_traffic.get(r["kernel"]), "avg_launch_ms": round(r["avg_ms"], 4),
+                "units_per_launch": round(r["units"], 1), "unit_of_work": r["unit"]}
     dom = next((r for r in rows if "achieved" in r), None)
-    roofline = None
-    if dom:
-        roofline = {"kernel": dom["kernel"], "bound": dom["bound"], "achieved": round(dom["achieved"], 2),
-                    "peak": dom["peak"], "unit": dom["runit"], "frac": round(dom["frac"], 4), "traffic": None,
-                    "avg_launch_ms": round(dom["avg_ms"], 4), "units_per_launch": round(dom["units"], 1),
-                    "unit_of_work": dom["unit"]}
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # filled from rocprofv3 --pmc passes
-        if os.path.exists(pmc):
-            try:
-                roofline["traffic"] = json.load(open(pmc)).get(dom["kernel"])
-            except Exception:
-                pass
+    roofline = roof(dom) if dom else None
+    # the fused VM-sample (density gather + march) kernel the north star names, whatever its rank in the table
+    vm = next((r for r in rows if r["kernel"] == "tir_march_secondary_fwd" and "achieved" in r), None)
+    roofline_vm = roof(vm) if vm else None
+    if roofline_vm:
+        roofline_vm["note"] = ("algorithmic gather-bytes model (SURVEY 8d): the 70 MB field is resident in L2 / Infinity "
+                               "Cache, so achieved exceeds the HBM peak while `traffic` (PMC) stays small")
 
     # ---- CPU baseline: the oracle (same algorithm, ATen CPU ops) on a bounded sample ------------------
     cpu = None
@@ -292,6 +300,7 @@ def main():
                     if a.decoder == "bf16x3" else "exact fp32 MFMA"},
         "exact_fp32_decoders": exact,
         "roofline": roofline,
+        "roofline_vm_sample": roofline_vm,
         "cpu_baseline": cpu,
         "gpu_kernel_ms_per_step": round(gpu_ms, 4),
         "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:8]],

@@ -19,7 +19,7 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomic
 // NORMAL == false uses grid_sample's zero-padding weights (compute_densityfeature, F.grid_sample);
 // NORMAL == true uses clamped indices + unclamped weights (models/relight_utils.py:82-92).
 // ------------------------------------------------------------------------------------------------
-template <int CH, bool NORMAL>
+template <int CH, bool NORMAL, bool LL>
 __device__ __forceinline__ void scatter_group(const float* __restrict__ plane, const float* __restrict__ line,
                                               float* __restrict__ gplane, float* __restrict__ gline, int H, int W,
                                               int R, float u, float v, float w, int c, float F, float Gu,
@@ -63,14 +63,19 @@ __device__ __forceinline__ void scatter_group(const float* __restrict__ plane, c
         if (t11 != 0.0f) atomic_add_f32(gplane + o11 + q, t11);
         float s0 = S * wl0, s1 = S * wl1;
         if (NORMAL) { s0 = fmaf(-Gw, P, s0); s1 = fmaf(Gw, P, s1); }
-        if (s0 != 0.0f) atomic_add_f32(gline + q0 + q, s0);
-        if (s1 != 0.0f) atomic_add_f32(gline + q1 + q, s1);
+        if (LL) {                 // gline is a block-local LDS copy of the (small, heavily shared) line gradient
+            if (s0 != 0.0f) atomicAdd(gline + q0 + q, s0);
+            if (s1 != 0.0f) atomicAdd(gline + q1 + q, s1);
+        } else {
+            if (s0 != 0.0f) atomic_add_f32(gline + q0 + q, s0);
+            if (s1 != 0.0f) atomic_add_f32(gline + q1 + q, s1);
+        }
     }
 }
 
 // the three VM groups of the density field for one sample chunk
-template <int C4, bool NORMAL>
-__device__ __forceinline__ void scatter_density(const TirField& f, const TirFieldGrad& g, float x, float y, float z,
+template <int C4, bool NORMAL, bool LL>
+__device__ __forceinline__ void scatter_density(const TirField& f, const TirFieldGrad& g, float* lds_lines, float x, float y, float z,
                                                 int c, float F, float G0, float G1, float G2) {
     const float p[3] = {x, y, z};
     const float G[3] = {G0, G1, G2};
@@ -80,28 +85,49 @@ __device__ __forceinline__ void scatter_density(const TirField& f, const TirFiel
         const int H = f.grid[m1], W = f.grid[m0], R = f.grid[vi];
         float Gu = 0.f, Gv = 0.f, Gw = 0.f;
         if (NORMAL) { Gu = G[m0] * (0.5f * (float)(W - 1)); Gv = G[m1] * (0.5f * (float)(H - 1)); Gw = G[vi] * (0.5f * (float)(R - 1)); }
-        scatter_group<C4 * 4, NORMAL>(f.dplane[i], f.dline[i], g.dplane[i], g.dline[i], H, W, R, p[m0], p[m1], p[vi],
-                                      c, F, Gu, Gv, Gw);
+        // LDS layout of the three line gradients: line i at offset sum_{j<i} R_j * CH  (R_0 = grid z, R_1 = grid y)
+        float* gl = LL ? lds_lines + (size_t)(i == 0 ? 0 : (i == 1 ? f.grid[2] : f.grid[2] + f.grid[1])) * (C4 * 4) : g.dline[i];
+        scatter_group<C4 * 4, NORMAL, LL>(f.dplane[i], f.dline[i], g.dplane[i], gl, H, W, R, p[m0], p[m1], p[vi],
+                                          c, F, Gu, Gv, Gw);
+    }
+}
+
+// block-local LDS copy of the three density-line gradients ([R_z + R_y + R_x][CH]): zero / flush helpers
+template <int CH>
+__device__ __forceinline__ void lines_zero(const TirField& f, float* lds_lines) {
+    const int n = (f.grid[0] + f.grid[1] + f.grid[2]) * CH;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) lds_lines[i] = 0.0f;
+}
+template <int CH>
+__device__ __forceinline__ void lines_flush(const TirField& f, const TirFieldGrad& g, const float* lds_lines) {
+    const int n0 = f.grid[2] * CH, n1 = f.grid[1] * CH, n2 = f.grid[0] * CH;
+    for (int i = threadIdx.x; i < n0 + n1 + n2; i += blockDim.x) {
+        const float v = lds_lines[i];
+        if (v == 0.0f) continue;
+        if (i < n0) atomic_add_f32(g.dline[0] + i, v);
+        else if (i < n0 + n1) atomic_add_f32(g.dline[1] + (i - n0), v);
+        else atomic_add_f32(g.dline[2] + (i - n0 - n1), v);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward of the primary march: one wave64 per ray.
+// Backward of the primary march: one wave64 per ray, persistent blocks of 4 waves.
 // ------------------------------------------------------------------------------------------------
 #define TIR_MAX_CHUNKS 64      // S <= 4096
 
-template <int C4>
+template <int C4, bool LL>
 __global__ void __launch_bounds__(256)
 k_march_primary_bwd(TirField f, TirFieldGrad g, const float* __restrict__ rays, const float* __restrict__ ray_jitter,
                     int B, int S, const float* __restrict__ sigma, const float* __restrict__ weight,
                     const float* __restrict__ gw, const float* __restrict__ g_acc, const float* __restrict__ g_depth,
                     float* __restrict__ g_feat_out) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int ray = blockIdx.x * 4 + wv;
-    if (ray >= B) return;
     __shared__ float tstart[4][TIR_MAX_CHUNKS];
     __shared__ __attribute__((aligned(16))) float wl_all[4][256];
+    extern __shared__ __attribute__((aligned(16))) float lds_lines[];
     float* wl = wl_all[wv];
+    if (LL) { lines_zero<C4 * 4>(f, lds_lines); __syncthreads(); }
+  for (int ray = blockIdx.x * 4 + wv; ray < B; ray += gridDim.x * 4) {
     RaySetup rs = ray_setup(f, rays, ray);
     const bool hj = ray_jitter != nullptr;
     const float jit = hj ? ray_jitter[ray] : 0.0f;
@@ -178,21 +204,26 @@ k_march_primary_bwd(TirField f, TirFieldGrad g, const float* __restrict__ rays, 
             const int slot = base + slot_in;
             if (slot < n) {
                 const float4 p = *reinterpret_cast<const float4*>(wl + slot * 4);
-                scatter_density<C4, false>(f, g, p.x, p.y, p.z, c, p.w, 0.f, 0.f, 0.f);
+                scatter_density<C4, false, LL>(f, g, lds_lines, p.x, p.y, p.z, c, p.w, 0.f, 0.f, 0.f);
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
+  }
+    if (LL) { __syncthreads(); lines_flush<C4 * 4>(f, g, lds_lines); }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Backward of the derived normal n = -g / max(|g|, 1e-6), g = softplus'(feat + shift) * grad feat
 // C4 adjacent lanes per sample.
 // ------------------------------------------------------------------------------------------------
-template <int C4>
+template <int C4, bool LL>
 __global__ void __launch_bounds__(256)
 k_density_grad_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, const float* __restrict__ g_normal, int64_t n) {
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float lds_lines[];
+    if (LL) { lines_zero<C4 * 4>(f, lds_lines); __syncthreads(); }
+  const int64_t n_lanes = (n * C4 + 255) / 256 * 256;          // whole blocks: the shuffles below need full lane groups
+  for (int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tid < n_lanes; tid += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = tid / C4;
     const int c = (int)(tid % C4);
     const bool on = i < n;
@@ -233,7 +264,7 @@ k_density_grad_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, co
         feat += __shfl_xor(feat, d, 64);
         gr[0] += __shfl_xor(gr[0], d, 64); gr[1] += __shfl_xor(gr[1], d, 64); gr[2] += __shfl_xor(gr[2], d, 64);
     }
-    if (!on) return;
+    if (!on) continue;
     float ds, dds;         // softplus' and softplus''
     if (f.act == 1) { ds = feat > 0.f ? 1.f : 0.f; dds = 0.f; }
     else {
@@ -251,7 +282,9 @@ k_density_grad_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, co
         dg[0] = -(dn[0] - nx * dot) / nrm; dg[1] = -(dn[1] - ny * dot) / nrm; dg[2] = -(dn[2] - nz * dot) / nrm;
     } else { dg[0] = -dn[0] / 1e-6f; dg[1] = -dn[1] / 1e-6f; dg[2] = -dn[2] / 1e-6f; }
     const float F = (dg[0] * gr[0] + dg[1] * gr[1] + dg[2] * gr[2]) * dds;
-    scatter_density<C4, true>(f, g, p[0], p[1], p[2], c, F, ds * dg[0], ds * dg[1], ds * dg[2]);
+    scatter_density<C4, true, LL>(f, g, lds_lines, p[0], p[1], p[2], c, F, ds * dg[0], ds * dg[1], ds * dg[2]);
+  }
+    if (LL) { __syncthreads(); lines_flush<C4 * 4>(f, g, lds_lines); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -415,46 +448,51 @@ template <int C4, bool RAD, bool INTR>
 __global__ void __launch_bounds__(256)
 k_vm_app_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
              const int32_t* __restrict__ idx_map, const float* __restrict__ g_rad, const float* __restrict__ g_int,
-             int stride, int64_t n, float* __restrict__ y_rad, float* __restrict__ y_int) {
+             int stride, int64_t n, float* __restrict__ y_rad, float* __restrict__ y_int, int line_lds) {
     constexpr int CA = C4 * 4;
     extern __shared__ __attribute__((aligned(16))) float lds_ab[];
     float* Wt = lds_ab;                              // [3*CA][32] basis_mat^T
     float* gl = lds_ab + 3 * CA * 32;                // [(n_lights + 1)][3*CA] block-local light_line / light_mean gradient
     const int nl = min(f.n_lights, TIR_APP_MAX_L);
+    // block-local gradient of ONE appearance line ([R][CA], the current VM group's): the line has only R rows, so
+    // every sample of the batch lands on a few hundred addresses -- in L2 those atomics serialise; in LDS they are cheap
+    float* lg = gl + (nl + 1) * 3 * CA;
     for (int i = threadIdx.x * 4; i < 3 * CA * 32; i += 256 * 4)
         *reinterpret_cast<float4*>(Wt + i) = *reinterpret_cast<const float4*>(f.basis_t + i);
     for (int i = threadIdx.x; i < (nl + 1) * 3 * CA; i += 256) gl[i] = 0.0f;
-    __syncthreads();
     const int L = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = L >> 2, c = L & 3;
     const int64_t n_pass = (n + 15) / 16;
-    for (int64_t pass = (int64_t)blockIdx.x * 4 + wave; pass < n_pass; pass += (int64_t)gridDim.x * 4) {
-        const int64_t s = pass * 16 + j;
-        const bool on = s < n;
-        const int64_t sc = on ? s : n - 1;
-        const float p[3] = {xyz[3 * sc], xyz[3 * sc + 1], xyz[3 * sc + 2]};
-        int li = 0;
-        if (RAD) {
-            const int64_t lsel = idx_map ? (int64_t)idx_map[sc] : sc;
-            li = min(max(light_idx[lsel], 0), f.n_lights - 1);
-        }
-        float gr[27], gi[27];
-#pragma unroll
-        for (int q = 0; q < 27; ++q) {
-            gr[q] = (RAD && on && q < f.app_dim) ? g_rad[sc * stride + q] : 0.f;
-            gi[q] = (INTR && on && q < f.app_dim) ? g_int[sc * stride + q] : 0.f;
-        }
 #pragma unroll 1
-        for (int k = 0; k < 3; ++k) {
-            const int m0 = (k == 2) ? 1 : 0, m1 = (k == 0) ? 1 : 2, vi = 2 - k;
-            const int H = f.grid[m1], W = f.grid[m0], R = f.grid[vi];
+    for (int k = 0; k < 3; ++k) {                  // one VM group at a time over ALL of the block's samples
+        const int m0 = (k == 2) ? 1 : 0, m1 = (k == 0) ? 1 : 2, vi = 2 - k;
+        const int H = f.grid[m1], W = f.grid[m0], R = f.grid[vi];
+        if (line_lds)
+            for (int i = threadIdx.x; i < R * CA; i += 256) lg[i] = 0.0f;
+        __syncthreads();
+        const float* pl = f.aplane[k];
+        const float* ln = f.aline[k];
+        for (int64_t pass = (int64_t)blockIdx.x * 4 + wave; pass < n_pass; pass += (int64_t)gridDim.x * 4) {
+            const int64_t s = pass * 16 + j;
+            const bool on = s < n;
+            const int64_t sc = on ? s : n - 1;
+            const float p[3] = {xyz[3 * sc], xyz[3 * sc + 1], xyz[3 * sc + 2]};
+            int li = 0;
+            if (RAD) {
+                const int64_t lsel = idx_map ? (int64_t)idx_map[sc] : sc;
+                li = min(max(light_idx[lsel], 0), f.n_lights - 1);
+            }
+            float gr[27], gi[27];
+#pragma unroll
+            for (int q = 0; q < 27; ++q) {
+                gr[q] = (RAD && on && q < f.app_dim) ? g_rad[sc * stride + q] : 0.f;
+                gi[q] = (INTR && on && q < f.app_dim) ? g_int[sc * stride + q] : 0.f;
+            }
             Tap1 tx = make_tap(p[m0], W), ty = make_tap(p[m1], H), tl = make_tap(p[vi], R);
             const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
             const size_t o00 = ((size_t)ty.i0 * W + tx.i0) * CA, o01 = ((size_t)ty.i0 * W + tx.i1) * CA;
             const size_t o10 = ((size_t)ty.i1 * W + tx.i0) * CA, o11 = ((size_t)ty.i1 * W + tx.i1) * CA;
             const size_t q0 = (size_t)tl.i0 * CA, q1 = (size_t)tl.i1 * CA;
-            const float* pl = f.aplane[k];
-            const float* ln = f.aline[k];
 #pragma unroll 1
             for (int q = 0; q < (C4 + 3) / 4; ++q) {
                 const int ch4 = 4 * q + c;
@@ -497,8 +535,13 @@ k_vm_app_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, const in
                     if (w01 != 0.f) atomic_add_f32(g.aplane[k] + o01 + 4 * ch4 + u, dP * w01);
                     if (w10 != 0.f) atomic_add_f32(g.aplane[k] + o10 + 4 * ch4 + u, dP * w10);
                     if (w11 != 0.f) atomic_add_f32(g.aplane[k] + o11 + 4 * ch4 + u, dP * w11);
-                    if (tl.w0 != 0.f) atomic_add_f32(g.aline[k] + q0 + 4 * ch4 + u, dL * tl.w0);
-                    if (tl.w1 != 0.f) atomic_add_f32(g.aline[k] + q1 + 4 * ch4 + u, dL * tl.w1);
+                    if (line_lds) {
+                        if (tl.w0 != 0.f) atomicAdd(lg + q0 + 4 * ch4 + u, dL * tl.w0);
+                        if (tl.w1 != 0.f) atomicAdd(lg + q1 + 4 * ch4 + u, dL * tl.w1);
+                    } else {
+                        if (tl.w0 != 0.f) atomic_add_f32(g.aline[k] + q0 + 4 * ch4 + u, dL * tl.w0);
+                        if (tl.w1 != 0.f) atomic_add_f32(g.aline[k] + q1 + 4 * ch4 + u, dL * tl.w1);
+                    }
                 }
                 if (on) {
                     if (RAD && y_rad) *reinterpret_cast<float4*>(y_rad + s * (3 * CA) + ch) = make_float4(yr[0], yr[1], yr[2], yr[3]);
@@ -506,6 +549,12 @@ k_vm_app_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, const in
                 }
             }
         }
+        __syncthreads();
+        if (line_lds)
+            for (int i = threadIdx.x; i < R * CA; i += 256) {
+                const float v = lg[i];
+                if (v != 0.f) atomic_add_f32(g.aline[k] + i, v);
+            }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < (nl + 1) * 3 * CA; i += 256) {
@@ -802,15 +851,29 @@ extern "C" int tir_march_primary_bwd(const TirField* f, const TirFieldGrad* g, c
     if (S > 64 * TIR_MAX_CHUNKS) return TIR_ERR_UNSUPPORTED;
     if (B == 0) return TIR_OK;
     if (!rays || !sigma || !weight || !g_weight || !g_acc || !g_depth) return TIR_ERR_ARG;
-    dim3 grid((B + 3) / 4), blk(256);
     hipStream_t s = tir_stream(stream);
+    const size_t line_bytes = (size_t)(f->grid[0] + f->grid[1] + f->grid[2]) * f->n_dcomp * sizeof(float);
+    const bool ll = line_bytes <= 96 * 1024;          // density-line gradients block-local in LDS when they fit
+    const size_t lds = ll ? line_bytes : 0;
+    int blocks = (B + 3) / 4;
+    if (ll && blocks > 512) blocks = 512;             // persistent blocks amortise the LDS zero / flush
+    dim3 grid(blocks), blk(256);
+#define TIR_LAUNCH_MB(C4)                                                                                             \
+    do {                                                                                                              \
+        if (ll) {                                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_primary_bwd<C4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+            hipLaunchKernelGGL((k_march_primary_bwd<C4, true>), grid, blk, lds, s, *f, *g, rays, ray_jitter, B, S, sigma, weight, g_weight, g_acc, g_depth, g_feature); \
+        } else                                                                                                        \
+            hipLaunchKernelGGL((k_march_primary_bwd<C4, false>), grid, blk, 0, s, *f, *g, rays, ray_jitter, B, S, sigma, weight, g_weight, g_acc, g_depth, g_feature); \
+    } while (0)
     switch (f->n_dcomp) {
-        case 16: hipLaunchKernelGGL(k_march_primary_bwd<4>, grid, blk, 0, s, *f, *g, rays, ray_jitter, B, S, sigma, weight, g_weight, g_acc, g_depth, g_feature); break;
-        case 8:  hipLaunchKernelGGL(k_march_primary_bwd<2>, grid, blk, 0, s, *f, *g, rays, ray_jitter, B, S, sigma, weight, g_weight, g_acc, g_depth, g_feature); break;
-        case 32: hipLaunchKernelGGL(k_march_primary_bwd<8>, grid, blk, 0, s, *f, *g, rays, ray_jitter, B, S, sigma, weight, g_weight, g_acc, g_depth, g_feature); break;
-        case 4:  hipLaunchKernelGGL(k_march_primary_bwd<1>, grid, blk, 0, s, *f, *g, rays, ray_jitter, B, S, sigma, weight, g_weight, g_acc, g_depth, g_feature); break;
+        case 16: TIR_LAUNCH_MB(4); break;
+        case 8:  TIR_LAUNCH_MB(2); break;
+        case 32: TIR_LAUNCH_MB(8); break;
+        case 4:  TIR_LAUNCH_MB(1); break;
         default: return TIR_ERR_UNSUPPORTED;
     }
+#undef TIR_LAUNCH_MB
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
@@ -823,14 +886,28 @@ extern "C" int tir_density_grad_bwd(const TirField* f, const TirFieldGrad* g, co
     if (n == 0) return TIR_OK;
     hipStream_t s = tir_stream(stream);
     const int c4 = f->n_dcomp / 4;
-    dim3 grid((unsigned)((n * c4 + 255) / 256)), blk(256);
+    const size_t line_bytes = (size_t)(f->grid[0] + f->grid[1] + f->grid[2]) * f->n_dcomp * sizeof(float);
+    const bool ll = line_bytes <= 96 * 1024;
+    const size_t lds = ll ? line_bytes : 0;
+    int64_t blocks = (n * c4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    dim3 grid((unsigned)blocks), blk(256);
+#define TIR_LAUNCH_DG(C4)                                                                                             \
+    do {                                                                                                              \
+        if (ll) {                                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_density_grad_bwd<C4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+            hipLaunchKernelGGL((k_density_grad_bwd<C4, true>), grid, blk, lds, s, *f, *g, xyz, g_normal, n);          \
+        } else                                                                                                        \
+            hipLaunchKernelGGL((k_density_grad_bwd<C4, false>), grid, blk, 0, s, *f, *g, xyz, g_normal, n);           \
+    } while (0)
     switch (f->n_dcomp) {
-        case 16: hipLaunchKernelGGL(k_density_grad_bwd<4>, grid, blk, 0, s, *f, *g, xyz, g_normal, n); break;
-        case 8:  hipLaunchKernelGGL(k_density_grad_bwd<2>, grid, blk, 0, s, *f, *g, xyz, g_normal, n); break;
-        case 32: hipLaunchKernelGGL(k_density_grad_bwd<8>, grid, blk, 0, s, *f, *g, xyz, g_normal, n); break;
-        case 4:  hipLaunchKernelGGL(k_density_grad_bwd<1>, grid, blk, 0, s, *f, *g, xyz, g_normal, n); break;
+        case 16: TIR_LAUNCH_DG(4); break;
+        case 8:  TIR_LAUNCH_DG(2); break;
+        case 32: TIR_LAUNCH_DG(8); break;
+        case 4:  TIR_LAUNCH_DG(1); break;
         default: return TIR_ERR_UNSUPPORTED;
     }
+#undef TIR_LAUNCH_DG
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
@@ -861,10 +938,16 @@ static int launch_app_bwd(const TirField* f, const TirFieldGrad* g, const float*
                           float* y_rad, float* y_int, hipStream_t s) {
     constexpr int CA = C4 * 4;
     const int nl = f->n_lights < TIR_APP_MAX_L ? f->n_lights : TIR_APP_MAX_L;
-    const size_t lds = (size_t)(3 * CA * 32 + (nl + 1) * 3 * CA) * sizeof(float);
-    if (lds > 160 * 1024) return TIR_ERR_UNSUPPORTED;
+    const size_t base = (size_t)(3 * CA * 32 + (nl + 1) * 3 * CA) * sizeof(float);
+    if (base > 160 * 1024) return TIR_ERR_UNSUPPORTED;
+    int rmax = f->grid[0] > f->grid[1] ? f->grid[0] : f->grid[1];
+    if (f->grid[2] > rmax) rmax = f->grid[2];
+    const size_t line = (size_t)rmax * CA * sizeof(float);
+    const int line_lds = base + line <= 160 * 1024 ? 1 : 0;     // one line's gradient block-local in LDS when it fits
+    const size_t lds = base + (line_lds ? line : 0);
     int64_t blocks = (n + 63) / 64;
-    if (blocks > 1024) blocks = 1024;
+    const int64_t cap = line_lds ? 512 : 1024;                   // fewer, longer-lived blocks amortise the LDS flush
+    if (blocks > cap) blocks = cap;
     dim3 grid((unsigned)blocks), blk(256);
     static bool attr_set = false;
     if (!attr_set) {
@@ -873,9 +956,9 @@ static int launch_app_bwd(const TirField* f, const TirFieldGrad* g, const float*
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_bwd<C4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (g_rad && g_int) hipLaunchKernelGGL((k_vm_app_bwd<C4, true, true>), grid, blk, lds, s, *f, *g, xyz, li, map, g_rad, g_int, stride, n, y_rad, y_int);
-    else if (g_rad)     hipLaunchKernelGGL((k_vm_app_bwd<C4, true, false>), grid, blk, lds, s, *f, *g, xyz, li, map, g_rad, g_int, stride, n, y_rad, y_int);
-    else                hipLaunchKernelGGL((k_vm_app_bwd<C4, false, true>), grid, blk, lds, s, *f, *g, xyz, li, map, g_rad, g_int, stride, n, y_rad, y_int);
+    if (g_rad && g_int) hipLaunchKernelGGL((k_vm_app_bwd<C4, true, true>), grid, blk, lds, s, *f, *g, xyz, li, map, g_rad, g_int, stride, n, y_rad, y_int, line_lds);
+    else if (g_rad)     hipLaunchKernelGGL((k_vm_app_bwd<C4, true, false>), grid, blk, lds, s, *f, *g, xyz, li, map, g_rad, g_int, stride, n, y_rad, y_int, line_lds);
+    else                hipLaunchKernelGGL((k_vm_app_bwd<C4, false, true>), grid, blk, lds, s, *f, *g, xyz, li, map, g_rad, g_int, stride, n, y_rad, y_int, line_lds);
     return TIR_OK;
 }
 

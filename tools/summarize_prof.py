@@ -43,3 +43,40 @@ for f in find("*counter_collection.csv"):
             # MFMA busy cycles are summed over the 4 SIMDs of every CU
             util = sum(cs["SQ_VALU_MFMA_BUSY_CYCLES"]) / (4.0 * sum(cs["SQ_BUSY_CU_CYCLES"]))
             print(f"  {'':40s} MFMA pipe utilisation = MFMA_BUSY / (4 SIMD x BUSY_CU_CYCLES) = {util:.3f}")
+
+
+# ---- per-launch HBM-side traffic (bytes) per C-ABI entry point, for bench.py's roofline.traffic ----------------
+# FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md, HBM
+# section) -> doubled.  WRITE_SIZE is taken as reported (uncalibrated per the guide).  Collected in separate passes.
+import json
+OP_OF = (("k_mlp_bf16<3", "tir_mlp_fwd_bf16x3"), ("k_mlp_bf16<1", "tir_mlp_fwd_bf16"), ("k_mlp_mfma", "tir_mlp_fwd"),
+         ("k_vm_app_mfma", "tir_vm_app_fwd"), ("k_march_secondary", "tir_march_secondary_fwd"),
+         ("k_march_primary", "tir_march_primary_fwd"), ("k_composite_primary", "tir_composite_primary"),
+         ("k_density_grad", "tir_density_grad_fwd"), ("k_shade_integrate", "tir_shade_integrate"))
+tot = collections.defaultdict(lambda: {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
+for f in find("*counter_collection.csv"):
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            c = r["Counter_Name"]
+            if c not in ("FETCH_SIZE", "WRITE_SIZE"):
+                continue
+            k = short(r["Kernel_Name"])
+            for pat, op in OP_OF:
+                if pat in k:
+                    t = tot[op][c]
+                    t[0] += float(r["Counter_Value"]); t[1] += 1
+                    break
+traffic = {}
+for op, d in tot.items():
+    fe = d["FETCH_SIZE"][0] / max(1, d["FETCH_SIZE"][1]) * 1024.0 * 2.0
+    wr = d["WRITE_SIZE"][0] / max(1, d["WRITE_SIZE"][1]) * 1024.0
+    traffic[op] = round(fe + wr)
+    traffic[op + ":detail"] = {"fetch_bytes_x2_corrected": round(fe), "write_bytes": round(wr),
+                               "launches_sampled": d["FETCH_SIZE"][1]}
+if traffic:
+    with open(os.path.join(root, "pmc_traffic.json"), "w") as fh:
+        json.dump(traffic, fh, indent=1)
+    print("\n== pmc_traffic.json (bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE)")
+    for k, v in traffic.items():
+        if not k.endswith(":detail"):
+            print(f"  {k:32s} {v/1e6:10.2f} MB")

@@ -1,0 +1,70 @@
+"""Training-step benchmark (GPU box): forward + hand-written backward + Adam on the synthetic C2 scene.
+
+    python tools/train_bench.py [--steps 20] [--rays 4096] [--samples 512] [--grid 300] [--relight 1]
+
+Reports iterations/s, rays/s and a per-entry-point breakdown (events around every C call).  One step =
+Renderer_TensoIR_train(is_train=True) + the loss of train_tensoIR.py:262-311 + backward() + optimizer.step()."""
+import argparse, json, os, sys, time, types
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from tensoir_amd import Renderer_TensoIR_train, ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--warmup", type=int, default=3)
+ap.add_argument("--rays", type=int, default=4096)
+ap.add_argument("--samples", type=int, default=512)
+ap.add_argument("--grid", type=int, default=300)
+ap.add_argument("--relight", type=int, default=1)
+a = ap.parse_args()
+a.env_h, a.env_w, a.second_samples = 8, 16, 96
+dev = torch.device("cuda", 0)
+ckpt, model, rays, lidx = bench.build_scene(a, dev, 0)
+model.march_t_stop = 1e-6
+args = types.SimpleNamespace(second_nSample=96, second_near=0.05, second_far=1.5)
+gt = torch.rand(rays.shape[0], 3, device=dev)
+opt = torch.optim.Adam(model.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99))
+W = dict(rgb_brdf=0.2, normals_diff=0.0005, normals_orientation=0.001, albedo_smoothness=0.001, roughness_smoothness=0.001)
+
+
+def step():
+    ret = Renderer_TensoIR_train(rays, None, lidx, model, N_samples=a.samples, white_bg=True, is_train=True,
+                                 is_relight=bool(a.relight), sample_method="stratified_sampling", device=dev, args=args)
+    loss = torch.mean((ret["rgb_map"] - gt) ** 2)
+    if a.relight:
+        loss = loss + W["rgb_brdf"] * torch.mean((ret["rgb_with_brdf_map"] - gt) ** 2) \
+            + W["normals_diff"] * ret["normals_diff_map"].mean() \
+            + W["normals_orientation"] * ret["normals_orientation_loss_map"].mean() \
+            + W["roughness_smoothness"] * ret["roughness_smoothness_loss"] + W["albedo_smoothness"] * ret["albedo_smoothness_loss"]
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    opt.step()
+    return loss
+
+
+for _ in range(a.warmup):
+    l0 = step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.steps):
+    l1 = step()
+torch.cuda.synchronize()
+el = time.perf_counter() - t0
+ops.TIMING = []
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+agg = {}
+for name, e0, e1 in ops.TIMING:
+    k = agg.setdefault(name, [0.0, 0])
+    k[0] += e0.elapsed_time(e1); k[1] += 1
+ops.TIMING = None
+rows = sorted(((n, v[0] / 3, v[1] / 3) for n, v in agg.items()), key=lambda r: -r[1])
+out = {"it_per_s": round(a.steps / el, 2), "ms_per_step": round(1e3 * el / a.steps, 3),
+       "rays_per_s": round(a.steps * rays.shape[0] / el, 1), "loss_first": float(l0), "loss_last": float(l1),
+       "config": {"rays": rays.shape[0], "samples": a.samples, "grid": a.grid, "relight": bool(a.relight)},
+       "hip_ms_per_step": round(sum(r[1] for r in rows), 3),
+       "entry_points": [{"name": n, "ms_per_step": round(ms, 4), "launches": c} for n, ms, c in rows[:16]]}
+print(json.dumps(out))
