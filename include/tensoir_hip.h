@@ -122,6 +122,20 @@ int tir_vm_density_fwd(const TirField* f, const float* xyz, float* feat, float* 
  *      world-space points; hit[n] = 1/0.  Needs f->occ_nbr. */
 int tir_occupancy_query(const TirField* f, const float* xyz, uint8_t* hit, int64_t n, void* stream);
 
+/* ---- occupancy-grid maintenance (models/tensorBase_rotated_lights.py:737-811, :819-837).
+ *      tir_dense_alpha: getDenseAlpha + compute_alpha on a gx*gy*gz lattice spanning the aabb; lin_* are the
+ *      caller's linspace(0,1,g) tables (device), alpha [gx][gy][gz] = 1 - exp(-sigma * length), sigma = 0 where the
+ *      current mask (f->occ_nbr, may be NULL) culls the point.
+ *      tir_alpha_pool: updateAlphaMask's clamp -> transpose -> 3x3x3 max-pool -> threshold; vol [gz][gy][gx] float 0/1,
+ *      bbox (optional, 6 ints pre-set to {INT_MAX x3, -1 x3}) receives the index bounding box of the occupied voxels.
+ *      tir_filter_rays: filtering_rays; mask[i] = ray i may hit something (bbox_only: slab test only). */
+int tir_dense_alpha(const TirField* f, const float* lin_x, const float* lin_y, const float* lin_z,
+                    int32_t gx, int32_t gy, int32_t gz, float length, float* alpha, void* stream);
+int tir_alpha_pool(const float* alpha, int32_t gx, int32_t gy, int32_t gz, float thres, float* vol,
+                   int32_t* bbox, void* stream);
+int tir_filter_rays(const TirField* f, const float* rays, int64_t n, int32_t n_samples, int32_t bbox_only,
+                    uint8_t* mask, void* stream);
+
 /* ---- K6: analytic d sigma/d xyz and derived normal -normalize(grad, eps=1e-6)
  *      (compute_derived_normals models/tensorBase_rotated_lights.py:839-856 ->
  *       compute_densityfeature_with_xyz_grad models/tensoRF_rotated_lights.py:113-129 ->

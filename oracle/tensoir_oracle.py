@@ -573,7 +573,12 @@ def sg_radiance(lgtSGs, dirs):
 
 def light_rgbs(sc, dirs):
     """get_light_rgbs (light_kind == 'sg'): models/tensorBase_rotated_lights.py:577-606.
-    dirs [D,3] -> [L,D,3]."""
+    dirs [D,3] -> [L,D,3].  With ``sc.lgtSGs_list`` set: the general multi-light variant, one SG set per light and
+    no rotation (models/tensorBase_general_multi_lights.py:566-582)."""
+    sg_list = getattr(sc, "lgtSGs_list", None)
+    if sg_list is not None:
+        d = dirs.reshape(-1, 3)
+        return torch.stack([sg_radiance(sg.to(dirs.dtype), d) for sg in sg_list], dim=0)
     rot = light_rotation_matrices(sc.light_rotation).to(dirs.dtype)
     remapped = torch.matmul(dirs.reshape(1, -1, 3), rot).reshape(-1, 3)
     return sg_radiance(sc.lgtSGs.to(dirs.dtype), remapped).reshape(len(sc.light_rotation), -1, 3)

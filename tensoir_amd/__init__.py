@@ -8,6 +8,7 @@ from .relight import (Environment_Light, GGX_specular, compute_radiance,  # noqa
                       compute_secondary_shading_effects, compute_transmittance, render_with_BRDF,
                       relight_with_envmap)
 from .renderer import Renderer_TensoIR_train  # noqa: F401
+from . import general_multi_lights  # noqa: F401  (TensorVMSplit with one SG set per light)
 
 __version__ = "0.1.0"
 

@@ -63,6 +63,9 @@ SIGNATURES = {
     "tir_pack_mlp": (C.c_int, [P, P, P, P, P, P, I32, I32, I32, I32, P, P]),
     "tir_vm_density_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, I64, P]),
     "tir_occupancy_query": (C.c_int, [C.POINTER(TirField), P, P, I64, P]),
+    "tir_dense_alpha": (C.c_int, [C.POINTER(TirField), P, P, P, I32, I32, I32, F32, P, P]),
+    "tir_alpha_pool": (C.c_int, [P, I32, I32, I32, F32, P, P, P]),
+    "tir_filter_rays": (C.c_int, [C.POINTER(TirField), P, I64, I32, I32, P, P]),
     "tir_density_grad_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, I64, P, P]),
     "tir_vm_app_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I32, I64, P, P]),
     "tir_vm_app_fwd_valu": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I32, I64, P, P]),

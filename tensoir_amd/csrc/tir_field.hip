@@ -131,6 +131,130 @@ extern "C" int tir_occupancy_query(const TirField* f, const float* xyz, uint8_t*
 }
 
 // ------------------------------------------------------------------------------------------------
+// Occupancy-grid maintenance on the device: getDenseAlpha / compute_alpha,
+// the 3x3x3 max-pool + threshold of updateAlphaMask, filtering_rays
+// (models/tensorBase_rotated_lights.py:737-811, :819-837).
+// ------------------------------------------------------------------------------------------------
+// alpha[ix][iy][iz] = 1 - exp(-sigma(p) * length),  p = aabb0 * (1 - s) + aabb1 * s with s = (lin_x[ix], lin_y[iy], lin_z[iz])
+// (the caller's torch.linspace tables, so positions are bit-identical to the reference's meshgrid);
+// sigma = 0 where the current occupancy mask (if any) culls the point.
+__global__ void __launch_bounds__(256)
+k_dense_alpha(TirField f, const float* __restrict__ lin_x, const float* __restrict__ lin_y,
+              const float* __restrict__ lin_z, int gx, int gy, int gz, float length, float* __restrict__ alpha) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)gx * gy * gz) return;
+    const int iz = (int)(i % gz), iy = (int)((i / gz) % gy), ix = (int)(i / ((int64_t)gz * gy));
+    const float s[3] = {lin_x[ix], lin_y[iy], lin_z[iz]};
+    float p[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) p[a] = add_rn(mul_rn(f.aabb_min[a], sub_rn(1.0f, s[a])), mul_rn(f.aabb_max[a], s[a]));
+    float sigma = 0.0f;
+    if (f.occ_nbr == nullptr || occupancy_hit(f, p[0], p[1], p[2])) {
+        const float x = norm_coord(p[0], f.aabb_min[0], f.inv_aabb[0]);
+        const float y = norm_coord(p[1], f.aabb_min[1], f.inv_aabb[1]);
+        const float z = norm_coord(p[2], f.aabb_min[2], f.inv_aabb[2]);
+        sigma = feature2density(f, density_feature_dyn(f, x, y, z));
+    }
+    alpha[i] = 1.0f - expf(-sigma * length);
+}
+
+// vol[z][y][x] = max over the 3x3x3 neighbourhood of clamp(alpha[x'][y'][z'], 0, 1) >= thres ? 1 : 0
+// (alpha.clamp(0,1).transpose(0,2) -> F.max_pool3d(k=3, pad=1, stride=1) -> threshold, :757-765);
+// also the index bounding box of the occupied voxels (6 ints: min x,y,z, max x,y,z) for the new aabb (:770-777).
+__global__ void __launch_bounds__(256)
+k_alpha_pool(const float* __restrict__ alpha, int gx, int gy, int gz, float thres, float* __restrict__ vol,
+             int32_t* __restrict__ bbox) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)gx * gy * gz) return;
+    const int x = (int)(i % gx), y = (int)((i / gx) % gy), z = (int)(i / ((int64_t)gx * gy));
+    float m = -INFINITY;
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dz = -1; dz <= 1; ++dz) {
+                const int xx = x + dx, yy = y + dy, zz = z + dz;
+                if (xx < 0 || xx >= gx || yy < 0 || yy >= gy || zz < 0 || zz >= gz) continue;
+                const float a = alpha[((int64_t)xx * gy + yy) * gz + zz];
+                m = fmaxf(m, fminf(fmaxf(a, 0.0f), 1.0f));
+            }
+    const bool occ = m >= thres;
+    vol[i] = occ ? 1.0f : 0.0f;
+    if (occ && bbox) {
+        atomicMin(bbox + 0, x); atomicMin(bbox + 1, y); atomicMin(bbox + 2, z);
+        atomicMax(bbox + 3, x); atomicMax(bbox + 4, y); atomicMax(bbox + 5, z);
+    }
+}
+
+// filtering_rays (:781-811): one wave per ray.  bbox_only: t_max > t_min of the slab test; otherwise "some
+// sample of the ray (eval sampling, no jitter) has a positive occupancy lookup".
+__global__ void __launch_bounds__(256)
+k_filter_rays(TirField f, const float* __restrict__ rays, int64_t n, int n_samples, int bbox_only,
+              uint8_t* __restrict__ mask) {
+    const int lane = threadIdx.x & 63;
+    const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= n) return;
+    float o[3], d[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { o[a] = rays[6 * ray + a]; d[a] = rays[6 * ray + 3 + a]; }
+    float tmin = -INFINITY, tmax = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float vec = (d[a] == 0.0f) ? 1e-6f : d[a];
+        const float ra = __fdiv_rn(sub_rn(f.aabb_max[a], o[a]), vec), rb = __fdiv_rn(sub_rn(f.aabb_min[a], o[a]), vec);
+        tmin = fmaxf(tmin, fminf(ra, rb));
+        tmax = fminf(tmax, fmaxf(ra, rb));
+    }
+    if (bbox_only) {
+        if (lane == 0) mask[ray] = tmax > tmin ? 1 : 0;
+        return;
+    }
+    const float t0 = fminf(fmaxf(tmin, f.near_), f.far_);
+    bool any = false;
+    for (int k0 = 0; k0 < n_samples && !any; k0 += 64) {
+        const int k = k0 + lane;
+        bool hit = false;
+        if (k < n_samples) {
+            const float z = add_rn(t0, mul_rn(f.step_size, (float)k));
+            hit = occupancy_hit(f, add_rn(o[0], mul_rn(d[0], z)), add_rn(o[1], mul_rn(d[1], z)), add_rn(o[2], mul_rn(d[2], z)));
+        }
+        any = __any(hit);
+    }
+    if (lane == 0) mask[ray] = any ? 1 : 0;
+}
+
+extern "C" int tir_dense_alpha(const TirField* f, const float* lin_x, const float* lin_y, const float* lin_z,
+                               int32_t gx, int32_t gy, int32_t gz, float length, float* alpha, void* stream) {
+    int rc = check_field(f);
+    if (rc) return rc;
+    if (!lin_x || !lin_y || !lin_z || !alpha || gx <= 0 || gy <= 0 || gz <= 0) return TIR_ERR_ARG;
+    const int64_t n = (int64_t)gx * gy * gz;
+    hipLaunchKernelGGL(k_dense_alpha, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tir_stream(stream), *f, lin_x,
+                       lin_y, lin_z, gx, gy, gz, length, alpha);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_alpha_pool(const float* alpha, int32_t gx, int32_t gy, int32_t gz, float thres, float* vol,
+                              int32_t* bbox, void* stream) {
+    if (!alpha || !vol || gx <= 0 || gy <= 0 || gz <= 0) return TIR_ERR_ARG;
+    const int64_t n = (int64_t)gx * gy * gz;
+    hipLaunchKernelGGL(k_alpha_pool, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tir_stream(stream), alpha, gx, gy,
+                       gz, thres, vol, bbox);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_filter_rays(const TirField* f, const float* rays, int64_t n, int32_t n_samples, int32_t bbox_only,
+                               uint8_t* mask, void* stream) {
+    if (!f || n < 0 || (n > 0 && (!rays || !mask))) return TIR_ERR_ARG;
+    if (!bbox_only && (!f->occ_nbr || n_samples <= 0)) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    hipLaunchKernelGGL(k_filter_rays, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, tir_stream(stream), *f, rays, n,
+                       n_samples, bbox_only, mask);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K6: analytic gradient of sigma w.r.t. normalised xyz
 // ------------------------------------------------------------------------------------------------
 template <int C4>

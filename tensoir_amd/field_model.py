@@ -348,13 +348,15 @@ class TensorVMSplit(nn.Module):
              {"params": self.app_line, "lr": lr_init_spatialxyz},
              {"params": self.app_plane, "lr": lr_init_spatialxyz},
              {"params": self.basis_mat.parameters(), "lr": lr_init_network},
-             {"params": self.light_line.parameters(), "lr": 0.001},
-             {"params": self.lgtSGs, "lr": 0.001},
+             {"params": self.light_line.parameters(), "lr": 0.001}] + self._light_param_groups() + [
              {"params": self.renderModule.parameters(), "lr": lr_init_network},
              {"params": self.renderModule_brdf.parameters(), "lr": lr_init_network}]
         if hasattr(self, "renderModule_normal"):
             g.append({"params": self.renderModule_normal.parameters(), "lr": lr_init_network})
         return g
+
+    def _light_param_groups(self):
+        return [{"params": self.lgtSGs, "lr": 0.001}]
 
     def vectorDiffs(self, vector_comps):
         total = 0
@@ -484,49 +486,50 @@ class TensorVMSplit(nn.Module):
     # ---- occupancy maintenance (models/tensorBase_rotated_lights.py:737-811) ----------------------------
     @torch.no_grad()
     def getDenseAlpha(self, gridSize=None):
+        """models/tensorBase_rotated_lights.py:737-753 -> tir_dense_alpha (positions generated in the kernel from the
+        linspace tables; the [g^3, 3] lattice is only materialised for the return value the reference promises)."""
         gridSize = self.gridSize if gridSize is None else gridSize
-        samples = torch.stack(torch.meshgrid(torch.linspace(0, 1, int(gridSize[0])), torch.linspace(0, 1, int(gridSize[1])),
-                                             torch.linspace(0, 1, int(gridSize[2])), indexing="ij"), -1).to(self.device)
+        alpha, lins = ops.dense_alpha(self.packed_field(), [int(g) for g in gridSize], float(self.stepSize))
+        samples = torch.stack(torch.meshgrid(lins[0], lins[1], lins[2], indexing="ij"), -1)
         dense_xyz = self.aabb[0] * (1 - samples) + self.aabb[1] * samples
-        alpha = self.compute_alpha(dense_xyz.view(-1, 3), self.stepSize).view(dense_xyz.shape[:-1])
         return alpha, dense_xyz
 
     @torch.no_grad()
     def updateAlphaMask(self, gridSize=(200, 200, 200)):
-        alpha, dense_xyz = self.getDenseAlpha(gridSize)
-        dense_xyz = dense_xyz.transpose(0, 2).contiguous()
-        alpha = alpha.clamp(0, 1).transpose(0, 2).contiguous()[None, None]
+        """models/tensorBase_rotated_lights.py:755-779, entirely on the device: dense alpha lattice -> clamp,
+        3x3x3 max-pool, threshold (tir_alpha_pool) -> new AlphaGridMask; the new aabb is the position of the index
+        bounding box of the occupied voxels (positions are separable and monotonic per axis, so the min / max over
+        the occupied lattice points is attained at the min / max indices)."""
+        gridSize = [int(g) for g in gridSize]
+        alpha, lins = ops.dense_alpha(self.packed_field(), gridSize, float(self.stepSize))
+        vol, bbox = ops.alpha_pool(alpha, self.alphaMask_thres)
         total_voxels = gridSize[0] * gridSize[1] * gridSize[2]
-        alpha = F.max_pool3d(alpha, kernel_size=3, padding=1, stride=1).view(tuple(gridSize)[::-1])
-        alpha[alpha >= self.alphaMask_thres] = 1
-        alpha[alpha < self.alphaMask_thres] = 0
-        self.alphaMask = AlphaGridMask(self.device, self.aabb, alpha)
+        self.alphaMask = AlphaGridMask(self.device, self.aabb, vol)
         self._field_key = None
-        valid_xyz = dense_xyz[alpha > 0.5]
-        xyz_min, xyz_max = valid_xyz.amin(0), valid_xyz.amax(0)
-        print(f"bbox: {xyz_min, xyz_max} alpha rest %%%f" % (torch.sum(alpha) / total_voxels * 100))
+        b = bbox.tolist()
+        if b[3] < 0:
+            raise TensoirHipError("updateAlphaMask: no voxel passes alphaMask_thres (empty scene)")
+        lo = torch.stack([lins[a][b[a]] for a in range(3)])
+        hi = torch.stack([lins[a][b[3 + a]] for a in range(3)])
+        xyz_min = self.aabb[0] * (1 - lo) + self.aabb[1] * lo
+        xyz_max = self.aabb[0] * (1 - hi) + self.aabb[1] * hi
+        print(f"bbox: {xyz_min, xyz_max} alpha rest %%%f" % (torch.sum(vol) / total_voxels * 100))
         return torch.stack((xyz_min, xyz_max))
 
     @torch.no_grad()
     def filtering_rays(self, all_rays, N_samples=256, chunk=10240 * 5, bbox_only=False):
+        """models/tensorBase_rotated_lights.py:781-811 -> tir_filter_rays (one wave per ray; the [chunk, N, 3] sample
+        tensor of the reference is never built).  all_rays may live on the host (as in train_tensoIR.py:228)."""
         tt = time.time()
-        N = torch.tensor(all_rays.shape[:-1]).prod()
+        flat = all_rays.reshape(-1, all_rays.shape[-1])
+        N = flat.shape[0]
+        f = self.packed_field()
+        big = chunk * 64
         masks = []
-        for idx in torch.split(torch.arange(N), chunk):
-            rays_chunk = all_rays[idx].to(self.device)
-            rays_o, rays_d = rays_chunk[..., :3], rays_chunk[..., 3:6]
-            if bbox_only:
-                vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
-                rate_a = (self.aabb[1] - rays_o) / vec
-                rate_b = (self.aabb[0] - rays_o) / vec
-                t_min = torch.minimum(rate_a, rate_b).amax(-1)
-                t_max = torch.maximum(rate_a, rate_b).amin(-1)
-                m = t_max > t_min
-            else:
-                xyz, _, _ = self.sample_ray(rays_o, rays_d, N_samples=N_samples, is_train=False)
-                m = (self.alphaMask.sample_alpha(xyz).view(xyz.shape[:-1]) > 0).any(-1)
-            masks.append(m.cpu())
-        mask = torch.cat(masks).view(all_rays.shape[:-1])
+        for i in range(0, N, big):
+            rays_chunk = flat[i:i + big, :6].to(self.device, torch.float32).contiguous()
+            masks.append(ops.filter_rays(f, rays_chunk, N_samples, bbox_only).to(all_rays.device))
+        mask = torch.cat(masks).view(all_rays.shape[:-1]) if masks else torch.zeros(all_rays.shape[:-1], dtype=torch.bool)
         print(f"Ray filtering done! takes {time.time() - tt} s. ray mask ratio: {torch.sum(mask) / N}")
         return all_rays[mask], mask
 

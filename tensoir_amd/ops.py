@@ -160,6 +160,35 @@ def occupancy_query(field: TirField, xyz):
     return hit
 
 
+def dense_alpha(field: TirField, grid_size, length):
+    """getDenseAlpha: alpha [gx,gy,gz] on the lattice aabb0*(1-s)+aabb1*s, s = torch.linspace(0,1,g) per axis."""
+    gx, gy, gz = [int(g) for g in grid_size]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lins = [torch.linspace(0, 1, g).to(dev).contiguous() for g in (gx, gy, gz)]
+    alpha = torch.empty((gx, gy, gz), dtype=torch.float32, device=dev)
+    _call("tir_dense_alpha", C.byref(field), _ptr(lins[0]), _ptr(lins[1]), _ptr(lins[2]), gx, gy, gz, float(length),
+          _ptr(alpha), _stream())
+    return alpha, lins
+
+
+def alpha_pool(alpha, thres):
+    """updateAlphaMask's pool + threshold: alpha [gx,gy,gz] -> (volume [gz,gy,gx] float 0/1, index bbox int32[6])."""
+    alpha = f32(alpha, "alpha")
+    gx, gy, gz = alpha.shape
+    vol = torch.empty((gz, gy, gx), dtype=torch.float32, device=alpha.device)
+    bbox = torch.tensor([2 ** 31 - 1] * 3 + [-1] * 3, dtype=torch.int32, device=alpha.device)
+    _call("tir_alpha_pool", _ptr(alpha), gx, gy, gz, float(thres), _ptr(vol), _ptr(bbox), _stream())
+    return vol, bbox
+
+
+def filter_rays(field: TirField, rays, n_samples, bbox_only):
+    rays = f32(rays, "rays", 6)
+    n = rays.shape[0]
+    mask = torch.empty((n,), dtype=torch.uint8, device=rays.device)
+    _call("tir_filter_rays", C.byref(field), _ptr(rays), n, int(n_samples), int(bool(bbox_only)), _ptr(mask), _stream())
+    return mask.bool()
+
+
 def density_grad(field: TirField, xyz, want_sigma=False, want_grad=False, want_normal=True, n_dev=None):
     xyz = f32(xyz, "xyz", 3).view(-1, 3)
     n = xyz.shape[0]

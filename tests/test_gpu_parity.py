@@ -325,3 +325,47 @@ def test_record_capacity_hint_overflow_recovers(env):
     for k in ("rgb_map", "depth_map", "normal_map", "albedo_map", "acc_map", "rgb_with_brdf_map", "normals_diff_map"):
         assert torch.equal(first[k], second[k]), k
         assert torch.equal(first[k], third[k]), k
+
+
+@torch.no_grad()
+def test_occupancy_maintenance_on_device(env):
+    """getDenseAlpha / updateAlphaMask / filtering_rays as device kernels vs the oracle / the
+    reference's own formulation."""
+    import copy
+    import tensoir_amd
+    from tests.helpers import golden_checkpoint
+    O = __import__("oracle.tensoir_oracle", fromlist=["x"])
+    eh, ew = [int(x) for x in env.g["scene/envmap_hw"]]
+    m = tensoir_amd.model_from_checkpoint(golden_checkpoint(env.g), "cuda", envmap_h=eh, envmap_w=ew)
+    sc = O.Scene(**env.sc.__dict__)
+    grid = (22, 26, 30)
+    # dense alpha lattice (with the existing mask culling)
+    alpha, dense = m.getDenseAlpha(grid)
+    a_ref, d_ref = O.dense_alpha(sc, grid)
+    assert rel(dense, d_ref, 1.0) < 1e-6 and rel(alpha, a_ref, 1e-3) < 1e-3
+    # new mask + bounding box
+    aabb_new = m.updateAlphaMask(grid)
+    ref_aabb = O.update_alpha_mask(sc, grid, thres=m.alphaMask_thres)
+    vol = m.alphaMask.alpha_volume[0, 0].cpu()
+    mism = int((vol != sc.alpha_volume).sum())
+    assert mism <= max(2, vol.numel() // 2000), mism      # voxels within rounding of the 1e-3 threshold may flip
+    if mism == 0:
+        assert rel(aabb_new, ref_aabb, 1.0) < 1e-6
+    # filtering_rays: both modes, vs the reference's formulation on the same model
+    gen = torch.Generator().manual_seed(51)
+    o = torch.randn(3000, 3, generator=gen) * 0.5 + torch.tensor([0.0, 0.0, 4.0])
+    d = torch.nn.functional.normalize(torch.randn(3000, 3, generator=gen) * torch.tensor([0.6, 0.6, 0.3]) - torch.tensor([0, 0, 1.0]), dim=-1)
+    rays = torch.cat([o, d], -1)
+    rays[:5, 3] = 0.0                                      # zero direction components
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        kept, mask = m.filtering_rays(rays, N_samples=80, bbox_only=False)
+        kept_b, mask_b = m.filtering_rays(rays, bbox_only=True)
+    r = rays.cuda()
+    xyz, _, _ = m.sample_ray(r[:, :3], r[:, 3:6], N_samples=80, is_train=False)
+    ref = (m.alphaMask.sample_alpha(xyz).view(xyz.shape[:-1]) > 0).any(-1).cpu()
+    assert torch.equal(mask, ref) and kept.shape[0] == int(ref.sum())
+    vec = torch.where(r[:, 3:6] == 0, torch.full_like(r[:, 3:6], 1e-6), r[:, 3:6])
+    ra, rb = (m.aabb[1] - r[:, :3]) / vec, (m.aabb[0] - r[:, :3]) / vec
+    ref_b = (torch.maximum(ra, rb).amin(-1) > torch.minimum(ra, rb).amax(-1)).cpu()
+    assert torch.equal(mask_b, ref_b)

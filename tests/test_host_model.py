@@ -131,3 +131,19 @@ def test_launcher_rebinds_reference_symbols():
     assert ru.render_with_BRDF is tensoir_amd.render_with_BRDF and ru.compute_radiance is tensoir_amd.compute_radiance
     assert tf.TensorVMSplit is tensoir_amd.TensorVMSplit and tf.AlphaGridMask is tensoir_amd.AlphaGridMask
     assert set(done) == set(run.PATCHES)
+
+
+def test_general_multi_light_variant_host_side():
+    """models/tensoRF_general_multi_lights.py mirror: per-light SG sets in a plain list (optimised, not in the
+    state_dict -- as in the reference), light_name_list round-trips through get_kwargs."""
+    from tensoir_amd.general_multi_lights import TensorVMSplit as General
+    m = General(torch.tensor([[-1.5] * 3, [1.5] * 3]), [16, 16, 16], "cpu", density_n_comp=[16] * 3,
+                appearance_n_comp=[48] * 3, shadingMode="MLP_Fea", normals_kind="derived_plus_predicted",
+                light_kind="sg", step_ratio=0.5, light_name_list=["sunset", "snow"])
+    assert m.light_num == 2 and len(m.lgtSGs_list) == 2 and m.light_line.weight.shape[0] == 2
+    assert "lgtSGs" not in m.state_dict()
+    groups = m.get_optparam_groups()
+    flat = [p for g in groups for p in (g["params"] if isinstance(g["params"], (list, tuple)) else [g["params"]])]
+    assert sum(1 for p in flat if any(p is sg for sg in m.lgtSGs_list)) == 2
+    kw = m.get_kwargs()
+    assert kw["light_name_list"] == ["sunset", "snow"] and "light_rotation" not in kw
