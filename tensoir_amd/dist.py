@@ -101,3 +101,54 @@ def render_sharded(render_fn, rays, light_idx, rank=None, world=None, chunk=4096
     else:
         local = torch.zeros((0, RECORD), dtype=torch.float32, device=rays.device)
     return unpack_records(gather_records(local, n, rank, world, tile, group))
+
+
+# ---- data-parallel training (the reference itself never all-reduces: section 2.1) ----------
+def shard_batch(n_rays: int, rank: int, world: int):
+    """Training batches are split `rays[rank::world]` (SURVEY 8e): every rank marches batch/world rays."""
+    return torch.arange(rank, n_rays, world, dtype=torch.int64)
+
+
+def allreduce_gradients(params, group=None, bucket_mb: float = 64.0, average: bool = True):
+    """Bucketed all-reduce (RCCL over xGMI with backend 'nccl') of the .grad of `params`, in place.
+
+    Buckets are sized for per-link-bound ring collectives on point-to-point xGMI: 64 MB keeps the 17.4 M (300^3) /
+    30.8 M (400^3) parameter gradients to 2 collectives instead of ~40 per-tensor ones.  Buckets are launched
+    asynchronously in reverse parameter order (decoders first, the large planes last, matching the order the
+    hand-written backward produces them) and awaited together.  Parameters without a gradient contribute zeros so
+    that every rank issues the same collectives.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    ps = [p for p in params if p.requires_grad]
+    if world == 1 or not ps:
+        return 0
+    cap = max(1, int(bucket_mb * (1 << 20) / 4))
+    buckets, cur, cur_n = [], [], 0
+    for p in reversed(ps):
+        if cur and cur_n + p.numel() > cap:
+            buckets.append(cur)
+            cur, cur_n = [], 0
+        cur.append(p)
+        cur_n += p.numel()
+    if cur:
+        buckets.append(cur)
+    pending = []
+    for b in buckets:
+        dev = b[0].device
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in b])
+        flat = flat.to(dev)
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        pending.append((b, flat, work))
+    for b, flat, work in pending:
+        work.wait()
+        if average:
+            flat.div_(world)
+        off = 0
+        for p in b:
+            g = flat[off:off + p.numel()].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += p.numel()
+    return len(buckets)

@@ -76,3 +76,41 @@ def test_gloo_all_gather(world, tile):
         p.join(timeout=60)
     assert sorted(r for r, _ in res) == list(range(world))
     assert all(ok for _, ok in res)
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        ps = [torch.nn.Parameter(torch.randn(s)) for s in ((3, 5), (7,), (2, 2, 4), (50,))]
+        for i, p in enumerate(ps):
+            if i != 1 or rank == 0:                      # one parameter has no gradient on rank 1
+                p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+        n_buckets = tdist.allreduce_gradients(ps, bucket_mb=60 * 4 / (1 << 20))       # 60-float buckets
+        want = [sum((r + 1) * (i + 1) for r in range(world)) / world for i in range(len(ps))]
+        want[1] = 2.0 / world                           # only rank 0 contributed (value 1*2)
+        ok = all(torch.allclose(p.grad, torch.full_like(p, w)) for p, w in zip(ps, want))
+        q.put((rank, ok and n_buckets >= 2))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_gradient_allreduce_buckets():
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res)
+    idx = torch.cat([tdist.shard_batch(10, r, 3) for r in range(3)])
+    assert sorted(idx.tolist()) == list(range(10))
