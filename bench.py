@@ -55,6 +55,7 @@ def parse():
                     help="decoder matrix-core mode: bf16x3 = split-bf16 (parity grade), mfma = exact fp32")
     ap.add_argument("--no-exact-pass", action="store_true", help="skip the extra timed pass with the exact fp32 decoders")
     ap.add_argument("--breakdown", type=str, default="", help="write the per-kernel table to this file")
+    ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying the HIP graph")
     return ap.parse_args()
 
 
@@ -138,11 +139,20 @@ def main():
     B = rays.shape[0]
     gathered = torch.empty((world * B, tdist.RECORD), dtype=torch.float32, device=device) if world > 1 else None
 
-    def step():
+    from tensoir_amd.graph import GraphedRenderer
+    graphed = {}
+
+    def step(eager=False):
         with torch.no_grad():
-            ret = Renderer_TensoIR_train(rays, None, lidx, model, N_samples=a.samples, white_bg=True,
-                                         is_train=False, is_relight=True, sample_method="fixed_envirmap",
-                                         chunk_size=160000, device=device, args=args)
+            if a.no_graph or eager:
+                ret = Renderer_TensoIR_train(rays, None, lidx, model, N_samples=a.samples, white_bg=True,
+                                             is_train=False, is_relight=True, sample_method="fixed_envirmap",
+                                             chunk_size=160000, device=device, args=args)
+            else:           # the same launches, replayed as one HIP graph per decoder mode (tensoir_amd/graph.py)
+                gr = graphed.get(ops.MLP_IMPL)
+                if gr is None:
+                    gr = graphed[ops.MLP_IMPL] = GraphedRenderer(model, B, N_samples=a.samples, args=args, device=device)
+                ret = gr(rays, lidx)
             if world > 1:   # the one exchange step: all-gather of the rendered per-ray records
                 dist.all_gather_into_tensor(gathered, tdist.pack_records(ret))
         return ret
@@ -203,7 +213,7 @@ def main():
     import tensoir_amd.relight as RL
     psteps = max(1, min(a.profile_steps, a.steps))
     for _ in range(psteps):
-        step()
+        step(eager=True)
     torch.cuda.synchronize()
     ops.vm_app, ops.mlp = orig_app, orig_mlp
     for kind, rows, n_dev, x in pending:
@@ -216,7 +226,7 @@ def main():
             shapes_acc["mlp_flops"] += n * 2 * (150 * 128 + 128 * 128 + 128 * x)
     timing = ops.TIMING
     ops.TIMING, ops.STATS = None, {}
-    step()
+    step(eager=True)
     torch.cuda.synchronize()
     stats = {k: v for k, v in ops.STATS.items()}
     ops.STATS = None
@@ -295,7 +305,8 @@ def main():
                                f"{D} dirs x {a.second_samples} samples on {M} surface points, SG env light",
                    "rays_per_gpu": B, "samples": a.samples, "grid": a.grid, "light_dirs": D,
                    "second_samples": a.second_samples, "surface_points": M,
-                   "sharding": f"dp{n_gpus} over rays, all-gather of {tdist.RECORD * 4} B/ray records"},
+                   "sharding": f"dp{n_gpus} over rays, all-gather of {tdist.RECORD * 4} B/ray records",
+                   "launch": "eager" if a.no_graph else "hip-graph replay (one graph per step)"},
         "decoder": {"mode": a.decoder, "note": "bf16x3 = x=hi+lo bf16 split, 3 MFMA products, fp32 accumulate; parity-tested at 1e-4"
                     if a.decoder == "bf16x3" else "exact fp32 MFMA"},
         "exact_fp32_decoders": exact,

@@ -232,9 +232,10 @@ int tir_composite_primary(const float* rays, const int32_t* offsets, const float
  *      z_vals [n_sample] (device) are the sample distances near*(1-t)+far*t, t = linspace(0,1,n)
  *      (:716-717) -- passed in so that they are bit-identical to the caller framework's linspace.
  *      vis[p] = T_end, one_minus_acc[p] = 1 - sum w (either may be NULL).
- *      When rec_counter != NULL the samples with w > weight_thres are appended (contiguously per
- *      ray, in sample order; ray segments in arbitrary order) to rec_* (capacity rec_cap records;
- *      overflowing rays are dropped and *rec_counter still counts them) and
+ *      When rec_counter != NULL (TWO int32, zeroed by the caller) the samples with w > weight_thres are appended
+ *      (contiguously per ray, in sample order; ray segments in arbitrary order) to rec_* (capacity rec_cap records;
+ *      overflowing rays are dropped; rec_counter[0] still counts them = the capacity a re-run needs, rec_counter[1] =
+ *      length of the record prefix that was actually written -- the row count consumers may process) and
  *      ray_rec_off[p] / ray_rec_cnt[p] locate ray p's segment.  stats: as tir_march_primary_fwd. */
 int tir_march_secondary_fwd(const TirField* f, const float* origins, const int32_t* org_map,
                             const float* dirs, const int32_t* dir_map, const uint8_t* active,
@@ -270,6 +271,16 @@ int tir_shade_integrate(const float* maps, const float* rays, const float* dirs,
                         const float* env, const float* weight_d, int32_t M, int32_t D,
                         int32_t n_lights, int32_t equal_area, int32_t use_srgb, float acc_thres,
                         float* out_rgb, void* stream);
+
+/* Same as tir_shade_integrate with the indirect radiance of pair (m, d) summed inside the kernel from that ray's
+ * records (ray_rec_off / ray_rec_cnt of tir_march_secondary_fwd, rec_rgb [A][3] = decoder output per record), i.e.
+ * tir_accumulate_records fused into the integration: the [M][D][3] indirect buffer is never written. */
+int tir_shade_integrate_records(const float* maps, const float* rays, const float* dirs,
+                                const int32_t* light_idx, const float* vis, const int32_t* ray_rec_off,
+                                const int32_t* ray_rec_cnt, const float* rec_w, const float* rec_rgb,
+                                const float* env, const float* weight_d, int32_t M, int32_t D,
+                                int32_t n_lights, int32_t equal_area, int32_t use_srgb, float acc_thres,
+                                float* out_rgb, void* stream);
 
 /* ---- K9: importance-sampled HDR relighting, loop body of scripts/relight_importance.py:119-170.
  *      Per surface point m and sample s: light_dir/rgb [M][Ns][3], pdf [M][Ns], vis [M][Ns].

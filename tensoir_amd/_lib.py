@@ -84,6 +84,7 @@ SIGNATURES = {
     "tir_env_sg_fwd": (C.c_int, [C.POINTER(TirEnvSG), P, I32, P, P]),
     "tir_shade_setup": (C.c_int, [P, P, P, I32, I32, F32, P, P, P]),
     "tir_shade_integrate": (C.c_int, [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, P, P]),
+    "tir_shade_integrate_records": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, P, P]),
     "tir_relight_importance": (C.c_int, [P, P, P, P, P, P, P, P, P, I32, I32, P, P]),
     "tir_ggx_specular": (C.c_int, [P, P, P, P, P, I32, I32, P, P]),
     # ---- training (backward) entry points ----

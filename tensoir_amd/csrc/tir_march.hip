@@ -435,6 +435,9 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
         if (hl == 31 && total > 0) base = atomicAdd(rec_counter, total);
         base = __shfl(base, 31, 32);
         const bool fits = (int64_t)base + total <= rec_cap;
+        // rec_counter[1]: length of the fully written record prefix.  Reservations are handed out in increasing order,
+        // so once one block does not fit no later one does: the written slots are exactly [0, max fitting base+total).
+        if (hl == 31 && total > 0 && fits) atomicMax(rec_counter + 1, base + total);
         const int64_t ray = (int64_t)blockIdx.x * TIR_SEC_RPB + hl;
         if (ray < n_rays) {
             ray_rec_off[ray] = base + incl - c;

@@ -123,7 +123,8 @@ k_shade_integrate(const float* __restrict__ maps, const float* __restrict__ rays
                   const int32_t* __restrict__ light_idx, const float* __restrict__ vis,
                   const float* __restrict__ indirect, const float* __restrict__ env,
                   const float* __restrict__ weight_d, int M, int D, int n_lights, int equal_area, int use_srgb,
-                  float acc_thres, float* __restrict__ out) {
+                  float acc_thres, float* __restrict__ out, const int32_t* __restrict__ rec_off,
+                  const int32_t* __restrict__ rec_cnt, const float* __restrict__ rec_w, const float* __restrict__ rec_rgb) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (m >= M) return;
@@ -149,9 +150,20 @@ k_shade_integrate(const float* __restrict__ maps, const float* __restrict__ rays
         const size_t md = (size_t)m * D + d;
         const float v = vis[md];
         const float wd = equal_area ? 1.0f : weight_d[d];
+        float ind[3] = {0.f, 0.f, 0.f};
+        if (indirect) { ind[0] = indirect[3 * md]; ind[1] = indirect[3 * md + 1]; ind[2] = indirect[3 * md + 2]; }
+        else if (rec_off) {        // indirect radiance straight from the ray's records, in sample order (models/relight_utils.py:832)
+            const int b = rec_off[md], e = b + rec_cnt[md];
+            for (int i = b; i < e; ++i) {
+                const float w = rec_w[i];
+                ind[0] = fmaf(w, rec_rgb[3 * (size_t)i], ind[0]);
+                ind[1] = fmaf(w, rec_rgb[3 * (size_t)i + 1], ind[1]);
+                ind[2] = fmaf(w, rec_rgb[3 * (size_t)i + 2], ind[2]);
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            float light = v * envl[3 * d + q] + (indirect ? indirect[3 * md + q] : 0.f);   // :462
+            float light = v * envl[3 * d + q] + ind[q];                                       // :462
             float brdf = s.alb_pi[q] + spec[q];                                               // :455
             if (equal_area) c[q] += 4.0f * 3.14159265358979323846f * brdf * light * cosine;   // :470-471
             else c[q] += brdf * light * cosine * wd;                                          // :474-475
@@ -247,7 +259,25 @@ extern "C" int tir_shade_integrate(const float* maps, const float* rays, const f
     if (M == 0) return TIR_OK;
     if (!maps || !rays || !dirs || !vis || !env || !out_rgb || (!equal_area && !weight_d)) return TIR_ERR_ARG;
     hipLaunchKernelGGL(k_shade_integrate, dim3((M + 3) / 4), dim3(256), 0, tir_stream(stream), maps, rays, dirs,
-                       light_idx, vis, indirect, env, weight_d, M, D, n_lights, equal_area, use_srgb, acc_thres, out_rgb);
+                       light_idx, vis, indirect, env, weight_d, M, D, n_lights, equal_area, use_srgb, acc_thres, out_rgb,
+                       (const int32_t*)nullptr, (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_shade_integrate_records(const float* maps, const float* rays, const float* dirs,
+                                           const int32_t* light_idx, const float* vis, const int32_t* ray_rec_off,
+                                           const int32_t* ray_rec_cnt, const float* rec_w, const float* rec_rgb,
+                                           const float* env, const float* weight_d, int32_t M, int32_t D,
+                                           int32_t n_lights, int32_t equal_area, int32_t use_srgb, float acc_thres,
+                                           float* out_rgb, void* stream) {
+    if (M < 0 || D <= 0 || n_lights <= 0) return TIR_ERR_ARG;
+    if (M == 0) return TIR_OK;
+    if (!maps || !rays || !dirs || !vis || !env || !out_rgb || (!equal_area && !weight_d)) return TIR_ERR_ARG;
+    if (!ray_rec_off || !ray_rec_cnt || !rec_w || !rec_rgb) return TIR_ERR_ARG;
+    hipLaunchKernelGGL(k_shade_integrate, dim3((M + 3) / 4), dim3(256), 0, tir_stream(stream), maps, rays, dirs,
+                       light_idx, vis, (const float*)nullptr, env, weight_d, M, D, n_lights, equal_area, use_srgb,
+                       acc_thres, out_rgb, ray_rec_off, ray_rec_cnt, rec_w, rec_rgb);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

@@ -324,7 +324,13 @@ class TensorVMSplit(nn.Module):
         if torch.is_grad_enabled() and self.lgtSGs.requires_grad:
             from . import training
             return training.EnvSGFn.apply(self.lgtSGs, rot, dirs)
-        return ops.env_sg(self.lgtSGs.to(device), rot, dirs)
+        # inference: the radiance table only changes with the SGs or the direction set -> cached per version
+        key = (self.lgtSGs.data_ptr(), self.lgtSGs._version, dirs.data_ptr(), dirs._version, tuple(dirs.shape))
+        cached = self.__dict__.get("_env_cache")
+        if cached is None or cached[0] != key:
+            cached = (key, ops.env_sg(self.lgtSGs.to(device), rot, dirs), dirs)
+            self.__dict__["_env_cache"] = cached
+        return cached[1]
 
     def update_stepSize(self, gridSize):
         """models/tensorBase_rotated_lights.py:608-619."""
@@ -705,7 +711,12 @@ class TensorVMSplit(nn.Module):
                 hints.pop((B, S), None)               # next call takes the exact (synchronising) route
                 return False
             return True
-        if _defer_check:
+        capture = self.__dict__.get("_capture")
+        if capture is not None:                       # HIP-graph capture (tensoir_amd/graph.py): no host reads here;
+            if total_dev is None:                     # the owner of the graph checks the counters after each replay
+                raise TensoirHipError("graph capture needs a warmed-up record-capacity hint (run one eager call first)")
+            capture.append((total_dev, cap, ("primary", B, S)))
+        elif _defer_check:
             self.__dict__["_pending_primary"] = finish
         elif not finish():
             return self.forward(rays_chunk, light_idx, white_bg, is_train, ndc_ray, is_relight, N_samples,
@@ -724,5 +735,6 @@ class TensorVMSplit(nn.Module):
         if not is_relight:
             return (maps[:, 0:3], maps[:, 3], None, None, None, None, maps[:, 14], None, None, None, None, None)
         acc = maps[:, 14]
+        smooth = torch.mean(maps[:, 17:19], dim=0)        # both smoothness losses in one reduction launch
         return (maps[:, 0:3], maps[:, 3], maps[:, 4:7], maps[:, 7:10], maps[:, 10:11], maps[:, 11:14], acc,
-                maps[:, 15:16], maps[:, 16:17], acc > 0.5, torch.mean(maps[:, 17:18]), torch.mean(maps[:, 18:19]))
+                maps[:, 15:16], maps[:, 16:17], acc > 0.5, smooth[0], smooth[1])

@@ -340,7 +340,7 @@ def march_secondary(field: TirField, origins, dirs, z_vals, n_rays, org_map=None
     rec = None
     if want_records:
         rec = {
-            "counter": torch.zeros((1,), dtype=torch.int32, device=dev),
+            "counter": torch.zeros((2,), dtype=torch.int32, device=dev),      # [total, written prefix]
             "ray": torch.empty((rec_cap,), dtype=torch.int32, device=dev),
             "w": torch.empty((rec_cap,), dtype=torch.float32, device=dev),
             "xyz": torch.empty((rec_cap, 3), dtype=torch.float32, device=dev),
@@ -405,6 +405,25 @@ def shade_integrate(maps, rays, dirs, light_idx, vis, indirect, env, weight_d, e
     _call("tir_shade_integrate", _ptr(maps), _ptr(rays), _ptr(dirs), _ptr(light_idx), _ptr(vis),
                                     _ptr(indirect), _ptr(env), _ptr(weight_d), M, D, env.shape[0],
                                     int(bool(equal_area)), int(bool(use_srgb)), float(acc_thres), _ptr(out), _stream())
+    return out
+
+
+def shade_integrate_records(maps, rays, dirs, light_idx, vis, rec_off, rec_cnt, rec_w, rec_rgb, env, weight_d,
+                            equal_area=False, use_srgb=True, acc_thres=-1e30):
+    """shade_integrate with the per-ray indirect sum fused in (reads the secondary records directly)."""
+    maps = f32(maps, "maps", MAP_STRIDE)
+    rays = f32(rays, "rays", 6)
+    dirs = f32(dirs, "dirs", 3)
+    M, D = maps.shape[0], dirs.shape[0]
+    light_idx = i32(light_idx, "light_idx").view(-1)
+    env = f32(env, "env", 3)
+    if weight_d is not None:
+        weight_d = f32(weight_d, "light_area_weight")
+    out = torch.empty((M, 3), dtype=torch.float32, device=maps.device)
+    _call("tir_shade_integrate_records", _ptr(maps), _ptr(rays), _ptr(dirs), _ptr(light_idx), _ptr(f32(vis, "vis")),
+          _ptr(i32(rec_off, "rec_off")), _ptr(i32(rec_cnt, "rec_cnt")), _ptr(f32(rec_w, "rec_w")),
+          _ptr(f32(rec_rgb, "rec_rgb", 3)), _ptr(env), _ptr(weight_d), M, D, env.shape[0], int(bool(equal_area)),
+          int(bool(use_srgb)), float(acc_thres), _ptr(out), _stream())
     return out
 
 

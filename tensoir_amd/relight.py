@@ -42,7 +42,7 @@ def _rec_capacity(n_rays):
 
 
 def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, light_idx, light_div,
-               want_indirect, want_nerfactor=False, n_dirs=0):
+               want_indirect, want_nerfactor=False, n_dirs=0, keep_records=False):
     """Shared driver of compute_transmittance / compute_radiance / render_with_BRDF:
     march (+ record the w > thres samples) -> appearance gather -> radiance decoder -> per-ray sum.
 
@@ -58,14 +58,17 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
     hints = tensoIR.__dict__.setdefault("_rec_cap_hints", {})      # record capacity learnt per problem size
     cap = hints.get(n_rays, 0)
     first = cap <= 0
+    capture = tensoIR.__dict__.get("_capture")
+    if capture is not None and first:
+        raise ops._lib.TensoirHipError("graph capture needs a warmed-up secondary record-capacity hint")
     if first:
         cap = _rec_capacity(n_rays)
     while True:
         vis, oma, rec = ops.march_secondary(f, origins, dirs, z, n_rays, org_map, dir_map, active,
                                             tensoIR.march_t_stop, True, cap, want_nerfactor, n_dirs)
-        n_dev = rec["counter"]
+        n_total, n_dev = rec["counter"][0:1], rec["counter"][1:2]      # all records / the written prefix consumers may read
         if first:                                      # no history yet: learn the count before sizing buffers
-            total = int(n_dev.item())
+            total = int(n_total.item())
             if total > cap:
                 cap = int(total * 1.25) + 1024
                 continue
@@ -79,13 +82,19 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
             # ray id -> direction via aux_mod on the dense [point][direction] grid)
             feat = ops.vm_app(f, rec_xyz, light_idx, rec_ray, True, False, None, light_div, n_dev)[0]
             rgb = ops.mlp(tensoIR.renderModule.packed(), feat, dirs, rec_ray if dir_map is None else
-                          dir_map[rec_ray.long()].contiguous(), None, n_dirs if dir_map is None else 0, n_dev)
-            indirect = ops.accumulate_records(rec["off"], rec["cnt"], rec_w, rgb, n_rays)
+                          dir_map[rec_ray.long().clamp_(0, dir_map.numel() - 1)].contiguous(), None, n_dirs if dir_map is None else 0, n_dev)
+            if keep_records:       # the caller's integration kernel sums the records itself (tir_shade_integrate_records)
+                indirect = {"off": rec["off"], "cnt": rec["cnt"], "w": rec_w, "rgb": rgb}
+            else:
+                indirect = ops.accumulate_records(rec["off"], rec["cnt"], rec_w, rgb, n_rays)
         else:
             indirect = torch.zeros((n_rays, 3), dtype=torch.float32, device=dev)
         if first:
             break
-        total = int(n_dev.item())                      # everything is queued: this wait costs no GPU idle time
+        if capture is not None:                        # HIP-graph capture: the graph owner reads the counter after replay
+            capture.append((n_total, cap, ("secondary", n_rays)))
+            return vis, oma, indirect
+        total = int(n_total.item())                    # everything is queued: this wait costs no GPU idle time
         if total <= cap:
             break
         cap = int(total * 1.25) + 1024                 # overflow: some rays were dropped -> redo with room
@@ -174,18 +183,24 @@ def shade_from_maps(tensoIR, maps, rays, light_idx, sample_method="fixed_envirma
         out = torch.zeros((0, 3), dtype=torch.float32, device=dev)
         return (out, None) if return_aux else out
     train = torch.is_grad_enabled() and (maps.requires_grad or tensoIR.lgtSGs.requires_grad)
+    fuse = not train and not return_aux
     with torch.no_grad():      # compute_secondary_shading_effects is @torch.no_grad (models/relight_utils.py:344)
         surf, active = ops.shade_setup(maps.detach(), rays, dirs, acc_thres)
-        vis, _, ind = _secondary(tensoIR, surf, dirs, M * D, z, None, None, active.view(-1), li, D, True, False, D)
+        vis, _, ind = _secondary(tensoIR, surf, dirs, M * D, z, None, None, active.view(-1), li, D, True, False, D,
+                                 keep_records=fuse)
     env = tensoIR.get_light_rgbs(dirs, device=dev)
     equal_area = sample_method == "stratifed_sample_equal_areas"
+    w_d = None if equal_area else area
     if train:
         from . import training
-        rgb = training.ShadeFn.apply(maps, env, rays, dirs, li, vis.view(M, D), ind.view(M, D, 3),
-                                     None if equal_area else area, equal_area, use_linear2srgb, acc_thres)
+        rgb = training.ShadeFn.apply(maps, env, rays, dirs, li, vis.view(M, D), ind.view(M, D, 3), w_d, equal_area,
+                                     use_linear2srgb, acc_thres)
+    elif isinstance(ind, dict):
+        rgb = ops.shade_integrate_records(maps, rays, dirs, li, vis.view(M, D), ind["off"], ind["cnt"], ind["w"],
+                                          ind["rgb"], env, w_d, equal_area, use_linear2srgb, acc_thres)
     else:
-        rgb = ops.shade_integrate(maps, rays, dirs, li, vis.view(M, D), ind.view(M, D, 3), env,
-                                  None if equal_area else area, equal_area, use_linear2srgb, acc_thres)
+        rgb = ops.shade_integrate(maps, rays, dirs, li, vis.view(M, D), ind.view(M, D, 3), env, w_d, equal_area,
+                                  use_linear2srgb, acc_thres)
     if return_aux:
         return rgb, {"vis": vis.view(M, D), "indirect": ind.view(M, D, 3), "env": env, "surf": surf,
                      "active": active}

@@ -369,3 +369,29 @@ def test_occupancy_maintenance_on_device(env):
     ra, rb = (m.aabb[1] - r[:, :3]) / vec, (m.aabb[0] - r[:, :3]) / vec
     ref_b = (torch.maximum(ra, rb).amin(-1) > torch.minimum(ra, rb).amax(-1)).cpu()
     assert torch.equal(mask_b, ref_b)
+
+
+@torch.no_grad()
+def test_hip_graph_replay_matches_eager(env):
+    """GraphedRenderer: one captured HIP graph per batch shape; identical maps to the eager path, also for a second
+    batch of different rays, and an artificially small captured capacity is detected and re-captured."""
+    from tensoir_amd import Renderer_TensoIR_train
+    from tensoir_amd.graph import GraphedRenderer
+    m = env.model
+    rays, lidx = G(env, "rays/rays"), G(env, "rays/light_idx")
+    kw = dict(N_samples=-1, white_bg=True, is_train=False, is_relight=True, sample_method="fixed_envirmap",
+              device="cuda", args=env.args)
+    gr = GraphedRenderer(m, rays.shape[0], args=env.args)
+    keys = ("rgb_map", "depth_map", "normal_map", "albedo_map", "acc_map", "rgb_with_brdf_map", "normals_diff_map")
+    for trial in range(3):
+        r = rays.clone()
+        if trial == 1:
+            r[:, 3:6] = torch.nn.functional.normalize(r[:, 3:6] + 0.02 * torch.randn_like(r[:, 3:6]), dim=-1)
+        if trial == 2:                                   # capture with too small a capacity -> overflow -> re-capture
+            gr._test_shrink_capacity = 16
+            gr.invalidate()
+        want = Renderer_TensoIR_train(r, None, lidx, m, **kw)
+        got = gr(r, lidx)
+        for k in keys:
+            assert torch.equal(got[k], want[k]), (trial, k)
+    assert gr.captures >= 3
