@@ -152,7 +152,13 @@ def main():
                 gr = graphed.get(ops.MLP_IMPL)
                 if gr is None:
                     gr = graphed[ops.MLP_IMPL] = GraphedRenderer(model, B, N_samples=a.samples, args=args, device=device)
-                ret = gr(rays, lidx)
+                try:
+                    ret = gr(rays, lidx)
+                except Exception as e:      # capture refused on this box: the eager path is the same work
+                    print(f"[bench] HIP-graph replay unavailable ({type(e).__name__}: {e}); using eager launches",
+                          file=sys.stderr, flush=True)
+                    a.no_graph = True
+                    return step()
             if world > 1:   # the one exchange step: all-gather of the rendered per-ray records
                 dist.all_gather_into_tensor(gathered, tdist.pack_records(ret))
         return ret
@@ -177,6 +183,8 @@ def main():
             el = float(t.item())
         return el, r
 
+    if world > 1:
+        a.no_graph = True       # RCCL's watchdog thread may touch the device during a capture: keep multi-rank runs eager
     ops.MLP_IMPL = a.decoder
     elapsed, ret = timed(a.warmup, a.steps)
     exact = None
