@@ -154,6 +154,11 @@ int tir_density_grad_fwd(const TirField* f, const float* xyz, float* sigma, floa
 int tir_vm_app_fwd(const TirField* f, const float* xyz, const int32_t* light_idx,
                    const int32_t* idx_map, float* rad_feat, float* int_feat, int32_t out_stride,
                    int32_t idx_div, int64_t n, const int32_t* n_dev, void* stream);
+/* same contract with the 144 x 27 contraction on v_mfma_f32_16x16x32_bf16 and every operand split x = hi + lo in bf16
+ * (three products, fp32 accumulate: parity grade, features agree with the exact kernel to ~1e-6); n_acomp <= 64. */
+int tir_vm_app_fwd_bf16x3(const TirField* f, const float* xyz, const int32_t* light_idx,
+                          const int32_t* idx_map, float* rad_feat, float* int_feat, int32_t out_stride,
+                          int32_t idx_div, int64_t n, const int32_t* n_dev, void* stream);
 /* same contract, one-sample-per-lane VALU kernel (cross-check of the matrix-core kernel) */
 int tir_vm_app_fwd_valu(const TirField* f, const float* xyz, const int32_t* light_idx,
                         const int32_t* idx_map, float* rad_feat, float* int_feat, int32_t out_stride,

@@ -68,6 +68,7 @@ SIGNATURES = {
     "tir_filter_rays": (C.c_int, [C.POINTER(TirField), P, I64, I32, I32, P, P]),
     "tir_density_grad_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, I64, P, P]),
     "tir_vm_app_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I32, I64, P, P]),
+    "tir_vm_app_fwd_bf16x3": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I32, I64, P, P]),
     "tir_vm_app_fwd_valu": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I32, I64, P, P]),
     "tir_mlp_fwd": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P, P]),
     "tir_mlp_fwd_bf16x3": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P, P]),

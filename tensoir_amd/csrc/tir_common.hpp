@@ -14,6 +14,16 @@
 
 static inline hipStream_t tir_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// XCD-aware work mapping switch (see tir::xcd_range).  Measured on the bench scene (same box, A/B): contiguous
+// per-XCD ranges leave the appearance gather unchanged (0.615 ms) and slow the secondary march by 7 % (0.509 -> 0.544 ms:
+// the eighths of the image are not equally expensive, and the 70 MB field is Infinity-Cache resident anyway), so the
+// interleaved order is the default; TIR_XCD=1 enables the partitioned order.
+#include <stdlib.h>
+static inline int tir_xcd_mapping() {
+    const char* e = getenv("TIR_XCD");
+    return (e && e[0] == '1') ? 1 : 0;
+}
+
 // matMode / vecMode of the reference (models/tensorBase_rotated_lights.py:398-399)
 __device__ __constant__ const int kMat0[3] = {0, 0, 1};
 __device__ __constant__ const int kMat1[3] = {1, 2, 2};
@@ -310,5 +320,28 @@ __device__ __forceinline__ float sample_z(const TirField& f, float t_min, int k,
     return add_rn(t_min, mul_rn(f.step_size, rng));
 }
 
+
+
+// XCD-aware work mapping.  The dispatcher places block b on XCD b % 8 (observed, not contractual: a wrong guess is only
+// slower), and each XCD has its own 4 MiB L2.  Records / rays are ordered along the image, so giving every XCD ONE
+// contiguous eighth of the items (instead of interleaving items across XCDs) keeps each L2's working set to the part
+// of the factor planes its own image region touches.  Returns this block's first item and its stride so that
+//     for (i = first; i < end; i += stride)      visits every item of [0, n_items) exactly once over the whole grid.
+// `per` = items a block consumes per iteration (e.g. 4 waves x 1 pass).  gridDim.x must be a multiple of 8 when on.
+struct XcdRange { long long first, end, stride; };
+__device__ __forceinline__ XcdRange xcd_range(long long n_items, int per, bool on) {
+    XcdRange r;
+    if (!on || (gridDim.x & 7) != 0) {
+        r.first = (long long)blockIdx.x * per; r.end = n_items; r.stride = (long long)gridDim.x * per;
+        return r;
+    }
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const long long chunk = (n_items + 7) / 8;
+    const long long lo = chunk * xcd;
+    r.first = lo + (long long)local * per;
+    r.end = lo + chunk < n_items ? lo + chunk : n_items;
+    r.stride = (long long)per_xcd * per;
+    return r;
+}
 
 }  // namespace tir

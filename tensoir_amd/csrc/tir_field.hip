@@ -435,7 +435,7 @@ template <int C4, bool RAD, bool INTR>
 __global__ void __launch_bounds__(256)
 k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
               const int32_t* __restrict__ idx_map, float* __restrict__ rad_feat, float* __restrict__ int_feat,
-              int out_stride, int idx_div, int64_t n, const int32_t* __restrict__ n_dev) {
+              int out_stride, int idx_div, int64_t n, const int32_t* __restrict__ n_dev, int xcd_on) {
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));        // device-side point count (no host sync needed)
     constexpr int CA = C4 * 4;
     constexpr int NX = (RAD ? 1 : 0) + (INTR ? 1 : 0);
@@ -449,7 +449,8 @@ k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restri
     const int j = L >> 2, c = L & 3;          // gather role: sample slot, 16-byte quarter
     const int jj = L & 15, kq = L >> 4;       // MFMA role: sample column, k quarter / output row quarter
     const int64_t n_pass = (n + 15) / 16;
-    for (int64_t pass = (int64_t)blockIdx.x * 4 + wave; pass < n_pass; pass += (int64_t)gridDim.x * 4) {
+    const XcdRange xr = xcd_range(n_pass, 4, xcd_on != 0);
+    for (int64_t pass = xr.first + wave; pass < xr.end; pass += xr.stride) {
         const int64_t s = pass * 16 + j;
         const int64_t sc = s < n ? s : n - 1;
         const float p[3] = {xyz[3 * sc], xyz[3 * sc + 1], xyz[3 * sc + 2]};
@@ -539,6 +540,175 @@ k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K4 with the contraction on v_mfma_f32_16x16x32_bf16 and every operand split x = hi + lo in bf16 (hi*hi + lo*hi +
+// hi*lo, fp32 accumulate; ~2^-17 relative per product): 12 matrix instructions per VM group and feature instead of 24
+// four-wide fp32 ones (the exact-fp32 kernel above spends > 50 % of its wave time in MFMA issue stalls).
+// Same gather; the per-group X tile is [16 samples][64 channels] fp32 in LDS (channels >= CA stay zero), read back
+// 8 consecutive channels per lane and split on the fly; basis_mat^T is pre-split into bf16 operand tiles at kernel start.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 app_bf16x8 __attribute__((ext_vector_type(8)));
+#define TIR_XS 68      // sample stride of the X tile in floats (64 channels + 4: spreads the 16 rows over the banks)
+
+__device__ __forceinline__ void app_split8(const float4& v0, const float4& v1, app_bf16x8& hi, app_bf16x8& lo) {
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        hi[e] = (__bf16)v[e];
+        lo[e] = (__bf16)(v[e] - (float)hi[e]);
+    }
+}
+
+template <int C4, bool RAD, bool INTR>
+__global__ void __launch_bounds__(256)
+k_vm_app_bf16(TirField f, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
+              const int32_t* __restrict__ idx_map, float* __restrict__ rad_feat, float* __restrict__ int_feat,
+              int out_stride, int idx_div, int64_t n, const int32_t* __restrict__ n_dev, int xcd_on) {
+    static_assert(C4 * 4 <= 64, "one VM group must fit two 32-wide k-steps");
+    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
+    constexpr int CA = C4 * 4;
+    constexpr int NX = (RAD ? 1 : 0) + (INTR ? 1 : 0);
+    extern __shared__ __attribute__((aligned(16))) float lds_app[];
+    // W tiles: [group 3][k-step 2][row tile 2][k-group 4][row 16] x 8 bf16, hi then lo
+    app_bf16x8* Whi = reinterpret_cast<app_bf16x8*>(lds_app);
+    app_bf16x8* Wlo = Whi + 3 * 2 * 2 * 64;
+    const int wave = threadIdx.x >> 6, L = threadIdx.x & 63;
+    float* X = reinterpret_cast<float*>(Wlo + 3 * 2 * 2 * 64) + wave * (NX * 16 * TIR_XS);      // [NX][16][TIR_XS]
+    for (int e = threadIdx.x; e < 3 * 2 * 2 * 64; e += 256) {
+        const int row = e & 15, kg = (e >> 4) & 3, mt = (e >> 6) & 1, t = (e >> 7) & 1, k = e >> 8;
+        app_bf16x8 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int ch = 32 * t + 8 * kg + q;
+            const float w = (ch < CA) ? f.basis_t[(size_t)(k * CA + ch) * 32 + mt * 16 + row] : 0.0f;
+            hi[q] = (__bf16)w;
+            lo[q] = (__bf16)(w - (float)hi[q]);
+        }
+        Whi[e] = hi; Wlo[e] = lo;
+    }
+    for (int e = L; e < NX * 16 * TIR_XS; e += 64) X[e] = 0.0f;          // incl. the never-written pad channels
+    __syncthreads();
+    const int j = L >> 2, c = L & 3;          // gather role: sample slot, 16-byte quarter
+    const int jj = L & 15, kg = L >> 4;       // MFMA role: sample column, k-group / output row quarter
+    const int64_t n_pass = (n + 15) / 16;
+    const XcdRange xr = xcd_range(n_pass, 4, xcd_on != 0);
+    for (int64_t pass = xr.first + wave; pass < xr.end; pass += xr.stride) {
+        const int64_t s = pass * 16 + j;
+        const int64_t sc = s < n ? s : n - 1;
+        const float p[3] = {xyz[3 * sc], xyz[3 * sc + 1], xyz[3 * sc + 2]};
+        const float* lrow = nullptr;
+        if (RAD) {
+            int64_t lsel = idx_map ? (int64_t)idx_map[sc] : sc;
+            if (idx_div > 1) lsel /= idx_div;
+            int li = light_idx[lsel];
+            li = min(max(li, 0), f.n_lights - 1);
+            lrow = f.light_line + (size_t)li * (3 * CA);
+        }
+        f32x4 accr[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4 acci[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 1
+        for (int k = 0; k < 3; ++k) {
+            const int m0 = (k == 2) ? 1 : 0, m1 = (k == 0) ? 1 : 2, vi = 2 - k;
+            const int H = f.grid[m1], W = f.grid[m0], R = f.grid[vi];
+            const float u = (k == 2) ? p[1] : p[0], v = (k == 0) ? p[1] : p[2], w = (k == 0) ? p[2] : ((k == 1) ? p[1] : p[0]);
+            Tap1 tx = make_tap(u, W), ty = make_tap(v, H), tl = make_tap(w, R);
+            const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
+            const float* pl = f.aplane[k];
+            const float* p00 = pl + ((size_t)ty.i0 * W + tx.i0) * CA;
+            const float* p01 = pl + ((size_t)ty.i0 * W + tx.i1) * CA;
+            const float* p10 = pl + ((size_t)ty.i1 * W + tx.i0) * CA;
+            const float* p11 = pl + ((size_t)ty.i1 * W + tx.i1) * CA;
+            const float* l0 = f.aline[k] + (size_t)tl.i0 * CA;
+            const float* l1 = f.aline[k] + (size_t)tl.i1 * CA;
+#pragma unroll
+            for (int q = 0; q < (C4 + 3) / 4; ++q) {
+                const int ch4 = 4 * q + c;
+                if (ch4 < C4) {
+                    const float4 a = ld4(p00 + 4 * ch4), b = ld4(p01 + 4 * ch4), cc = ld4(p10 + 4 * ch4), d = ld4(p11 + 4 * ch4);
+                    const float4 e = ld4(l0 + 4 * ch4), g = ld4(l1 + 4 * ch4);
+                    float4 val;
+                    val.x = fmaf(d.x, w11, fmaf(cc.x, w10, fmaf(b.x, w01, a.x * w00))) * fmaf(g.x, tl.w1, e.x * tl.w0);
+                    val.y = fmaf(d.y, w11, fmaf(cc.y, w10, fmaf(b.y, w01, a.y * w00))) * fmaf(g.y, tl.w1, e.y * tl.w0);
+                    val.z = fmaf(d.z, w11, fmaf(cc.z, w10, fmaf(b.z, w01, a.z * w00))) * fmaf(g.z, tl.w1, e.z * tl.w0);
+                    val.w = fmaf(d.w, w11, fmaf(cc.w, w10, fmaf(b.w, w01, a.w * w00))) * fmaf(g.w, tl.w1, e.w * tl.w0);
+                    if (RAD) {
+                        const float4 lr = ld4(lrow + k * CA + 4 * ch4);
+                        *reinterpret_cast<float4*>(X + j * TIR_XS + 4 * ch4) = make_float4(val.x * lr.x, val.y * lr.y, val.z * lr.z, val.w * lr.w);
+                    }
+                    if (INTR) {
+                        const float4 lm = ld4(f.light_mean + k * CA + 4 * ch4);
+                        *reinterpret_cast<float4*>(X + (RAD ? 16 * TIR_XS : 0) + j * TIR_XS + 4 * ch4) =
+                            make_float4(val.x * lm.x, val.y * lm.y, val.z * lm.z, val.w * lm.w);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (32 * t >= CA) break;
+                const int wi = ((k * 2 + t) * 2) * 64 + kg * 16 + jj;
+                const app_bf16x8 ah0 = Whi[wi], ah1 = Whi[wi + 64], al0 = Wlo[wi], al1 = Wlo[wi + 64];
+                if (RAD) {
+                    const float* xr = X + jj * TIR_XS + 32 * t + 8 * kg;
+                    app_bf16x8 bh, bl;
+                    app_split8(*reinterpret_cast<const float4*>(xr), *reinterpret_cast<const float4*>(xr + 4), bh, bl);
+                    accr[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bh, accr[0], 0, 0, 0);
+                    accr[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bh, accr[1], 0, 0, 0);
+                    accr[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, bh, accr[0], 0, 0, 0);
+                    accr[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, bh, accr[1], 0, 0, 0);
+                    accr[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bl, accr[0], 0, 0, 0);
+                    accr[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bl, accr[1], 0, 0, 0);
+                }
+                if (INTR) {
+                    const float* xi = X + (RAD ? 16 * TIR_XS : 0) + jj * TIR_XS + 32 * t + 8 * kg;
+                    app_bf16x8 bh, bl;
+                    app_split8(*reinterpret_cast<const float4*>(xi), *reinterpret_cast<const float4*>(xi + 4), bh, bl);
+                    acci[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bh, acci[0], 0, 0, 0);
+                    acci[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bh, acci[1], 0, 0, 0);
+                    acci[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, bh, acci[0], 0, 0, 0);
+                    acci[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, bh, acci[1], 0, 0, 0);
+                    acci[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bl, acci[0], 0, 0, 0);
+                    acci[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bl, acci[1], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        const int64_t so = pass * 16 + jj;
+        if (so < n) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int row0 = mt * 16 + kg * 4;
+                if (RAD) {
+                    float* o = rad_feat + so * out_stride + row0;
+                    if (row0 + 4 <= out_stride && (out_stride & 3) == 0) *reinterpret_cast<float4*>(o) = make_float4(accr[mt][0], accr[mt][1], accr[mt][2], accr[mt][3]);
+                    else for (int r = 0; r < 4; ++r) if (row0 + r < out_stride) o[r] = accr[mt][r];
+                }
+                if (INTR) {
+                    float* o = int_feat + so * out_stride + row0;
+                    if (row0 + 4 <= out_stride && (out_stride & 3) == 0) *reinterpret_cast<float4*>(o) = make_float4(acci[mt][0], acci[mt][1], acci[mt][2], acci[mt][3]);
+                    else for (int r = 0; r < 4; ++r) if (row0 + r < out_stride) o[r] = acci[mt][r];
+                }
+            }
+        }
+    }
+}
+
+template <int C4>
+static int launch_app_bf16(const TirField* f, const float* xyz, const int32_t* li, const int32_t* map,
+                           float* rad, float* intr, int stride, int idx_div, int64_t n, const int32_t* n_dev, hipStream_t s) {
+    const int nx = (rad ? 1 : 0) + (intr ? 1 : 0);
+    const size_t lds = (size_t)2 * 3 * 2 * 2 * 64 * 16 + (size_t)4 * nx * 16 * TIR_XS * sizeof(float);
+    int64_t blocks = (n + 63) / 64;
+    if (blocks > 2048) blocks = 2048;
+    const int xcd_on = tir_xcd_mapping();
+    if (xcd_on) blocks = (blocks + 7) / 8 * 8;
+    dim3 g((unsigned)blocks), b(256);
+    if (rad && intr) hipLaunchKernelGGL((k_vm_app_bf16<C4, true, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on);
+    else if (rad)    hipLaunchKernelGGL((k_vm_app_bf16<C4, true, false>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on);
+    else             hipLaunchKernelGGL((k_vm_app_bf16<C4, false, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on);
+    return TIR_OK;
+}
+
 template <int C4>
 static int launch_app(const TirField* f, const float* xyz, const int32_t* li, const int32_t* map,
                       float* rad, float* intr, int stride, int idx_div, int64_t n, const int32_t* n_dev, hipStream_t s, bool valu) {
@@ -554,6 +724,8 @@ static int launch_app(const TirField* f, const float* xyz, const int32_t* li, co
     const size_t lds = (size_t)(3 * CA * 32 + 4 * nx * CA * TIR_XLD) * sizeof(float);
     int64_t blocks = (n + 63) / 64;
     if (blocks > 2048) blocks = 2048;
+    const int xcd_on = tir_xcd_mapping();
+    if (xcd_on) blocks = (blocks + 7) / 8 * 8;
     dim3 g((unsigned)blocks), b(256);
     static bool attr_set = false;
     if (!attr_set) {   // > 64 KB only for unusually wide fields; harmless otherwise
@@ -563,15 +735,15 @@ static int launch_app(const TirField* f, const float* xyz, const int32_t* li, co
         attr_set = true;
     }
     if (lds > 160 * 1024) return TIR_ERR_UNSUPPORTED;
-    if (rad && intr) hipLaunchKernelGGL((k_vm_app_mfma<C4, true, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev);
-    else if (rad)    hipLaunchKernelGGL((k_vm_app_mfma<C4, true, false>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev);
-    else             hipLaunchKernelGGL((k_vm_app_mfma<C4, false, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev);
+    if (rad && intr) hipLaunchKernelGGL((k_vm_app_mfma<C4, true, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on);
+    else if (rad)    hipLaunchKernelGGL((k_vm_app_mfma<C4, true, false>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on);
+    else             hipLaunchKernelGGL((k_vm_app_mfma<C4, false, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on);
     return TIR_OK;
 }
 
 static int app_fwd(const TirField* f, const float* xyz, const int32_t* light_idx, const int32_t* idx_map,
                    float* rad_feat, float* int_feat, int32_t out_stride, int32_t idx_div, int64_t n, const int32_t* n_dev, void* stream,
-                   bool valu) {
+                   bool valu, bool split_bf16 = false) {
     if (!f) return TIR_ERR_ARG;
     for (int i = 0; i < 3; ++i)
         if (f->grid[i] < 2 || !f->aplane[i] || !f->aline[i]) return TIR_ERR_ARG;
@@ -582,6 +754,17 @@ static int app_fwd(const TirField* f, const float* xyz, const int32_t* light_idx
     if (n == 0) return TIR_OK;
     hipStream_t s = tir_stream(stream);
     int rc;
+    if (split_bf16) {
+        switch (f->n_acomp) {
+            case 48: rc = launch_app_bf16<12>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, s); break;
+            case 24: rc = launch_app_bf16<6>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, s); break;
+            case 16: rc = launch_app_bf16<4>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, s); break;
+            default: return TIR_ERR_UNSUPPORTED;
+        }
+        if (rc) return rc;
+        TIR_CHECK_LAUNCH();
+        return TIR_OK;
+    }
     switch (f->n_acomp) {
         case 48: rc = launch_app<12>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, s, valu); break;
         case 24: rc = launch_app<6>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, s, valu); break;
@@ -604,4 +787,10 @@ extern "C" int tir_vm_app_fwd_valu(const TirField* f, const float* xyz, const in
                                    const int32_t* idx_map, float* rad_feat, float* int_feat, int32_t out_stride,
                                    int32_t idx_div, int64_t n, const int32_t* n_dev, void* stream) {
     return app_fwd(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, stream, true);
+}
+
+extern "C" int tir_vm_app_fwd_bf16x3(const TirField* f, const float* xyz, const int32_t* light_idx,
+                                     const int32_t* idx_map, float* rad_feat, float* int_feat, int32_t out_stride,
+                                     int32_t idx_div, int64_t n, const int32_t* n_dev, void* stream) {
+    return app_fwd(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, stream, false, true);
 }

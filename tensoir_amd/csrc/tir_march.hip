@@ -338,8 +338,12 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
                   float* __restrict__ one_minus_acc, int32_t* __restrict__ rec_counter, int64_t rec_cap,
                   int32_t* __restrict__ rec_ray, float* __restrict__ rec_w, float* __restrict__ rec_xyz,
                   int32_t* __restrict__ ray_rec_off, int32_t* __restrict__ ray_rec_cnt,
-                  unsigned long long* __restrict__ stats) {
+                  unsigned long long* __restrict__ stats, int xcd_on) {
     extern __shared__ __attribute__((aligned(16))) float w_lds[];
+    // XCD-aware block order: XCD x (= blockIdx % 8) takes the x-th contiguous eighth of the ray blocks
+    int64_t bid = blockIdx.x;
+    if (xcd_on && (gridDim.x & 7) == 0) bid = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (bid * TIR_SEC_RPB >= n_rays) return;
     const int hl = threadIdx.x & 31;                 // lane within the half-wave
     const int hw = threadIdx.x >> 5;                 // half-wave within the block
     const int nz = (n_sample + 3) & ~3;
@@ -356,7 +360,7 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
 
     for (int g = 0; g < TIR_SEC_RPB / 8; ++g) {
         const int rl = g * 8 + hw;
-        const int64_t ray = (int64_t)blockIdx.x * TIR_SEC_RPB + rl;
+        const int64_t ray = bid * TIR_SEC_RPB + rl;
         const bool in_range = ray < n_rays;
         const bool live = in_range && !(active && !active[ray]);
         int cnt = 0, k_stop = n_sample;    // k_stop: first sample this ray did not march (zero weight from there)
@@ -438,7 +442,7 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
         // rec_counter[1]: length of the fully written record prefix.  Reservations are handed out in increasing order,
         // so once one block does not fit no later one does: the written slots are exactly [0, max fitting base+total).
         if (hl == 31 && total > 0 && fits) atomicMax(rec_counter + 1, base + total);
-        const int64_t ray = (int64_t)blockIdx.x * TIR_SEC_RPB + hl;
+        const int64_t ray = bid * TIR_SEC_RPB + hl;
         if (ray < n_rays) {
             ray_rec_off[ray] = base + incl - c;
             ray_rec_cnt[ray] = fits ? c : 0;
@@ -450,7 +454,7 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
         const int rl = g * 8 + hw;
         int base = s_base[rl];
         if (base < 0) continue;                    // uniform inside the half-wave
-        const int64_t ray = (int64_t)blockIdx.x * TIR_SEC_RPB + rl;
+        const int64_t ray = bid * TIR_SEC_RPB + rl;
         const size_t oi = org_map ? (size_t)org_map[ray] : (n_dirs > 0 ? (size_t)(ray / n_dirs) : (size_t)ray);
         const size_t di = dir_map ? (size_t)dir_map[ray] : (n_dirs > 0 ? (size_t)(ray % n_dirs) : (size_t)ray);
         float o[3], d[3];
@@ -496,9 +500,12 @@ extern "C" int tir_march_secondary_fwd(const TirField* f, const float* origins, 
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
     size_t lds = ((size_t)((n_sample + 3) & ~3) + 4 * 256 + 3 * TIR_SEC_RPB +
                   (rec_counter ? (size_t)TIR_SEC_RPB * n_sample : 0)) * sizeof(float);
-    hipLaunchKernelGGL(k_march_secondary, dim3((unsigned)((n_rays + TIR_SEC_RPB - 1) / TIR_SEC_RPB)), dim3(256), lds, tir_stream(stream),
+    const int xcd_on = tir_xcd_mapping();
+    unsigned nblk = (unsigned)((n_rays + TIR_SEC_RPB - 1) / TIR_SEC_RPB);
+    if (xcd_on) nblk = (nblk + 7) / 8 * 8;
+    hipLaunchKernelGGL(k_march_secondary, dim3(nblk), dim3(256), lds, tir_stream(stream),
                        *f, origins, org_map, dirs, dir_map, active, n_rays, n_dirs, n_sample, z_vals, t_stop, vis,
-                       one_minus_acc, rec_counter, rec_cap, rec_ray, rec_w, rec_xyz, ray_rec_off, ray_rec_cnt, stats);
+                       one_minus_acc, rec_counter, rec_cap, rec_ray, rec_w, rec_xyz, ray_rec_off, ray_rec_cnt, stats, xcd_on);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

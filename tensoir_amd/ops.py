@@ -200,7 +200,9 @@ def density_grad(field: TirField, xyz, want_sigma=False, want_grad=False, want_n
 
 
 FEAT_STRIDE = 32     # feature rows are padded to 128 bytes (aligned float4 stores / loads)
-APP_IMPL = "mfma"    # "mfma" (matrix-core contraction, quad-coalesced gathers) or "valu" (cross-check)
+# "mfma" (exact fp32 matrix-core contraction), "bf16x3" (split-bf16 matrix cores, parity grade) or "valu" (cross-check)
+APP_ENTRY = {"mfma": "tir_vm_app_fwd", "bf16x3": "tir_vm_app_fwd_bf16x3", "valu": "tir_vm_app_fwd_valu"}
+APP_IMPL = os.environ.get("TENSOIR_APP", "mfma")
 
 
 def vm_app(field: TirField, xyz, light_idx=None, idx_map=None, want_rad=True, want_int=False, impl=None,
@@ -222,7 +224,7 @@ def vm_app(field: TirField, xyz, light_idx=None, idx_map=None, want_rad=True, wa
             raise ValueError("light_idx must have one entry per point")
     rad = torch.empty((n, ad), dtype=torch.float32, device=xyz.device) if want_rad else None
     intr = torch.empty((n, ad), dtype=torch.float32, device=xyz.device) if want_int else None
-    _call("tir_vm_app_fwd" if (impl or APP_IMPL) == "mfma" else "tir_vm_app_fwd_valu", C.byref(field), _ptr(xyz),
+    _call(APP_ENTRY[impl or APP_IMPL], C.byref(field), _ptr(xyz),
           _ptr(light_idx) if want_rad else None, _ptr(idx_map) if want_rad else None, _ptr(rad), _ptr(intr),
           ad, int(idx_div), n, _ptr(n_dev), _stream())
     return rad, intr

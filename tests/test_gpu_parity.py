@@ -398,6 +398,26 @@ def test_hip_graph_replay_matches_eager(env):
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("impl", ["mfma", "valu", "bf16x3"])
+def test_app_feature_implementations_vs_reference(env, impl):
+    """All three appearance-contraction kernels (exact fp32 MFMA, VALU, split-bf16 MFMA) against the golden features,
+    with both outputs, one output, an index map and ragged sizes."""
+    from tensoir_amd import ops
+    f = env.model.packed_field()
+    xyz, li = G(env, "feat/xyz"), G(env, "feat/light_idx").view(-1).int()
+    for n in (600, 599, 17, 1):
+        r, i = ops.vm_app(f, xyz[:n], li[:n], None, True, True, impl)
+        assert rel(r[:, :27], env.g["feat/both_rad"][:n]) < 2e-5 and rel(i[:, :27], env.g["feat/both_int"][:n]) < 2e-5
+        assert float(r[:, 27:].abs().max()) == 0.0
+    r = ops.vm_app(f, xyz, li, None, True, False, impl)[0]
+    i = ops.vm_app(f, xyz, None, None, False, True, impl)[1]
+    assert rel(r[:, :27], env.g["feat/app"]) < 2e-5 and rel(i[:, :27], env.g["feat/intrin"]) < 2e-5
+    perm = torch.randperm(600, generator=torch.Generator().manual_seed(3)).int().cuda()
+    r = ops.vm_app(f, xyz, li[perm.long()].contiguous(), torch.argsort(perm).int(), True, False, impl)[0]   # light_idx[idx_map[p]]
+    assert rel(r[:, :27], env.g["feat/app"]) < 2e-5
+
+
+@torch.no_grad()
 def test_split_bf16_decoder_large_arguments(env):
     """The split-bf16 decoder's own sincos (Cody-Waite + polynomials, double-precision pre-reduction beyond |x| = 8192)
     against the exact-fp32 kernel (library sinf/cosf) on features far outside the usual range."""
