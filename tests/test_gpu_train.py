@@ -219,8 +219,8 @@ def test_shading_backward(env):
 
 
 # ------------------------------------------------------------------ whole training step
-@pytest.mark.parametrize("relight", [False, True])
-def test_training_step_vs_oracle(env, relight):
+@pytest.mark.parametrize("relight,t_stop", [(False, 0.0), (True, 0.0), (True, 1e-6)])
+def test_training_step_vs_oracle(env, relight, t_stop):
     from tensoir_amd import Renderer_TensoIR_train
     O, m, g, tg = env.O, env.model, env.g, env.tg
     rays, lidx = T(g, "rays/rays"), T(g, "rays/light_idx")
@@ -233,6 +233,7 @@ def test_training_step_vs_oracle(env, relight):
     loss_ref, grads_ref, ret_ref = O.train_step_grads(env.sc, rays, lidx, gt, is_relight=relight, n_samples=S,
                                                       ray_jitter=jitter, brdf_jitter=noise, second_n_sample=24)
     m.zero_grad(set_to_none=True)
+    m.march_t_stop = t_stop          # 1e-6 = the product default: rays stop marching once T < 1e-6 (gradients there are < 1e-6)
     # feed the same draws: forward() takes the ray jitter from torch.rand(B,1) on the CPU generator
     state = torch.get_rng_state()
     torch.manual_seed(0)
@@ -274,6 +275,25 @@ def test_training_step_vs_oracle(env, relight):
     bad = {k: round(v, 5) for k, v in worst.items() if v > GTOL}
     assert not bad, (bad, {k: round(v, 6) for k, v in worst.items() if k.startswith("density") or k.startswith("app")})
     assert len(worst) >= (18 if not relight else 30)
+    m.zero_grad(set_to_none=True)
+    m.march_t_stop = 0.0
+
+
+def test_training_step_with_no_hits(env):
+    """Rays that miss the volume: no records, every stage of the backward must cope (zero / absent gradients)."""
+    from tensoir_amd import Renderer_TensoIR_train
+    m = env.model
+    m.zero_grad(set_to_none=True)
+    rays = torch.tensor([[0.0, 0.0, 4.0, 0.9, 0.0, -0.43589]] * 5)
+    rays[:, 3:] = rays[:, 3:] / rays[:, 3:].norm(dim=-1, keepdim=True)
+    lidx = torch.zeros(5, 1, dtype=torch.int32)
+    ret = Renderer_TensoIR_train(rays, None, lidx, m, N_samples=32, white_bg=True, is_train=True, is_relight=True,
+                                 sample_method="fixed_envirmap", device="cuda", args=env.args)
+    loss = env.O.training_loss(ret, torch.zeros(5, 3, device="cuda"), True)
+    loss.backward()
+    assert torch.isfinite(loss)
+    for name, p in m.named_parameters():
+        assert p.grad is None or bool(torch.isfinite(p.grad).all()), name
     m.zero_grad(set_to_none=True)
 
 
