@@ -286,12 +286,26 @@ k_mlp_mfma(const float* __restrict__ packed, const float* __restrict__ feat, int
 // accumulated in fp32 (NPROD = 3, ~1e-6 abs error on the outputs), or hi*hi only (NPROD = 1, fast mode).
 // Same wave/lane decomposition as the fp32 kernel; a lane supplies 8 consecutive k per MFMA.
 // ------------------------------------------------------------------------------------------------
+// x = hi + lo with hi = bf16(x) (RNE) and lo = bf16(x - hi), two values at a time: one packed conversion for the hi
+// pair, shift / mask to get the pair back as floats, one (packed) subtract, one packed conversion for the lo pair --
+// 2.5 VALU instructions per value instead of ~4 for the element-wise form.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
+    u32x4_t H, L;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        hi[e] = (__bf16)v[e];
-        lo[e] = (__bf16)(v[e] - (float)hi[e]);
+    for (int p = 0; p < 4; ++p) {
+        const f32x2_t x = {v[2 * p], v[2 * p + 1]};
+        const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));
+        const f32x2_t hf = {__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+        const f32x2_t r = x - hf;
+        H[p] = hb;
+        L[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
     }
+    hi = __builtin_bit_cast(bf16x8, H);
+    lo = __builtin_bit_cast(bf16x8, L);
 }
 
 // sin and cos of x with one shared Cody-Waite reduction and two minimax polynomials (<= 2 ulp for |x| < 8192);
@@ -372,6 +386,17 @@ __device__ __forceinline__ void build_inputs(const float (&ft)[F + 1], const flo
     if constexpr (KB + 1 < KB0) build_inputs<KB + 1>(ft, ax, ap, h, xh, xl);
 }
 
+// ReLU.  fmaxf(x, 0) (and med3(x, 0, inf), which the compiler folds back) lowers to a canonicalising v_max(x, x) plus
+// the real v_max; MFMA accumulators are never signalling NaNs, so the single instruction is the same function at half
+// the VALU issue slots -- and the decoder kernel is VALU-issue bound.
+template <bool ONE>
+__device__ __forceinline__ float relu(float x) {
+    if (!ONE) return fmaxf(x, 0.0f);
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // one k-block of a layer: the A tiles of all four 32-row blocks, then the MFMAs product-major so that consecutive
 // MFMAs never share an accumulator (no dependent-issue stalls)
 template <int NPROD, bool PM>
@@ -445,7 +470,7 @@ __device__ __forceinline__ void layer1_interleaved(const bf16x8* __restrict__ wh
     if constexpr (KB + 1 < KB0) layer1_interleaved<NPROD, KB + 1>(whi, wlo, h, sl, ft, ax, ap, acc);
 }
 
-template <int NPROD, int KB>
+template <int NPROD, int KB, bool MED3>
 __device__ __forceinline__ void layer2_interleaved(const bf16x8* __restrict__ whi, const bf16x8* __restrict__ wlo, int h, int sl,
                                                    const f32x16 (&hid)[4], f32x16 (&acc)[4]) {
     bf16x8 ah[4], al[4];
@@ -457,12 +482,12 @@ __device__ __forceinline__ void layer2_interleaved(const bf16x8* __restrict__ wh
     }
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { constexpr int q0 = KB * 8; v[e] = fmaxf(hid[(q0 + e) >> 4][(q0 + e) & 15], 0.0f); }
+    for (int e = 0; e < 8; ++e) { constexpr int q0 = KB * 8; v[e] = relu<MED3>(hid[(q0 + e) >> 4][(q0 + e) & 15]); }
     bf16x8 xh, xl;
     split8(v, xh, xl);
     mfma12<NPROD>(ah, al, xh, xl, acc);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (KB + 1 < KB1) layer2_interleaved<NPROD, KB + 1>(whi, wlo, h, sl, hid, acc);
+    if constexpr (KB + 1 < KB1) layer2_interleaved<NPROD, KB + 1, MED3>(whi, wlo, h, sl, hid, acc);
 }
 
 // one sample's decoder inputs as they come from memory: 27 features (+ zero pad) and the 3 aux values
@@ -548,7 +573,7 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[mt][r] = bp[r];
             }
-            layer2_interleaved<NPROD, 0>(w1hi, w1lo, h, sl, acc, acc2);
+            layer2_interleaved<NPROD, 0, PM>(w1hi, w1lo, h, sl, acc, acc2);
         } else {
             bf16x8 xh[KB0], xl[KB0];
             build_inputs<0>(cur.ft, cur.ax, ap, h, xh, xl);
@@ -583,7 +608,7 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
             const float* wp = lds + BH_W2 + h * 256;
 #pragma unroll
             for (int q = 0; q < 64; ++q) {
-                const float hv = fmaxf(acc2[q >> 4][q & 15], 0.0f);
+                const float hv = relu<PM>(acc2[q >> 4][q & 15]);
                 const float4 w = *reinterpret_cast<const float4*>(wp + q * 4);
                 o0 = fmaf(hv, w.x, o0); o1 = fmaf(hv, w.y, o1); o2 = fmaf(hv, w.z, o2); o3 = fmaf(hv, w.w, o3);
             }
