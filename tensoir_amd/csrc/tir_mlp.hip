@@ -11,7 +11,6 @@
 // operands of the next layer when its contraction order is permuted to k2(t,h) -- no cross-lane traffic
 // between layers.  Lane halves h=0/1 split every contraction's k range in two.
 #include "tir_common.hpp"
-#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -372,66 +371,16 @@ __device__ __forceinline__ void build_pair(const float (&ft)[F + 1], const float
     }
 }
 
-// Build this lane-half's 80 padded inputs one k-block (8 values) at a time and split each block to bf16
-// hi/lo at once; template recursion keeps every array index a compile-time constant.
-template <int KB>
-__device__ __forceinline__ void build_inputs(const float (&ft)[F + 1], const float (&ax)[3], const AuxPE& ap, int h,
-                                             bf16x8 (&xh)[KB0], bf16x8 (&xl)[KB0]) {
-    float v[8];
-    build_pair<KB, 0>(ft, ax, ap, h, v);
-    build_pair<KB, 2>(ft, ax, ap, h, v);
-    build_pair<KB, 4>(ft, ax, ap, h, v);
-    build_pair<KB, 6>(ft, ax, ap, h, v);
-    split8(v, xh[KB], xl[KB]);
-    if constexpr (KB + 1 < KB0) build_inputs<KB + 1>(ft, ax, ap, h, xh, xl);
-}
-
 // ReLU.  fmaxf(x, 0) (and med3(x, 0, inf), which the compiler folds back) lowers to a canonicalising v_max(x, x) plus
 // the real v_max; MFMA accumulators are never signalling NaNs, so the single instruction is the same function at half
 // the VALU issue slots -- and the decoder kernel is VALU-issue bound.
-template <bool ONE>
 __device__ __forceinline__ float relu(float x) {
-    if (!ONE) return fmaxf(x, 0.0f);
     float r;
     asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
     return r;
 }
 
-// one k-block of a layer: the A tiles of all four 32-row blocks, then the MFMAs product-major so that consecutive
-// MFMAs never share an accumulator (no dependent-issue stalls)
-template <int NPROD, bool PM>
-__device__ __forceinline__ void mfma_block(const bf16x8* __restrict__ whi, const bf16x8* __restrict__ wlo, int wi,
-                                           const bf16x8& bh, const bf16x8& bl, f32x16 (&acc)[4]) {
-    if (!PM) {        // accumulator-major: the three products of one 32-row block back to back
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const bf16x8 a_hi = whi[wi + mt * 32];
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bh, acc[mt], 0, 0, 0);
-            if (NPROD == 3) {
-                const bf16x8 a_lo = wlo[wi + mt * 32];
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo, bh, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, bl, acc[mt], 0, 0, 0);
-            }
-        }
-        return;
-    }
-    bf16x8 ah[4], al[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        ah[mt] = whi[wi + mt * 32];
-        if (NPROD == 3) al[mt] = wlo[wi + mt * 32];
-    }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh, acc[mt], 0, 0, 0);
-    if (NPROD == 3) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh, acc[mt], 0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl, acc[mt], 0, 0, 0);
-    }
-}
-
-// ---- interleaved form: per k-block [issue the A-tile LDS reads] [build that block's 8 inputs on the VALU] [12 MFMAs].
+// ---- per k-block: [issue the A-tile LDS reads] [build that block's 8 inputs on the VALU] [12 MFMAs].
 // The MFMAs of block kb execute on the matrix pipe while the wave's VALU already builds block kb+1 (intra-wave overlap
 // instead of "all inputs, then all MFMAs"), the input build covers the LDS latency, and only one block of inputs is live.
 template <int NPROD>
@@ -470,7 +419,7 @@ __device__ __forceinline__ void layer1_interleaved(const bf16x8* __restrict__ wh
     if constexpr (KB + 1 < KB0) layer1_interleaved<NPROD, KB + 1>(whi, wlo, h, sl, ft, ax, ap, acc);
 }
 
-template <int NPROD, int KB, bool MED3>
+template <int NPROD, int KB>
 __device__ __forceinline__ void layer2_interleaved(const bf16x8* __restrict__ whi, const bf16x8* __restrict__ wlo, int h, int sl,
                                                    const f32x16 (&hid)[4], f32x16 (&acc)[4]) {
     bf16x8 ah[4], al[4];
@@ -482,12 +431,12 @@ __device__ __forceinline__ void layer2_interleaved(const bf16x8* __restrict__ wh
     }
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { constexpr int q0 = KB * 8; v[e] = relu<MED3>(hid[(q0 + e) >> 4][(q0 + e) & 15]); }
+    for (int e = 0; e < 8; ++e) { constexpr int q0 = KB * 8; v[e] = relu(hid[(q0 + e) >> 4][(q0 + e) & 15]); }
     bf16x8 xh, xl;
     split8(v, xh, xl);
     mfma12<NPROD>(ah, al, xh, xl, acc);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (KB + 1 < KB1) layer2_interleaved<NPROD, KB + 1, MED3>(whi, wlo, h, sl, hid, acc);
+    if constexpr (KB + 1 < KB1) layer2_interleaved<NPROD, KB + 1>(whi, wlo, h, sl, hid, acc);
 }
 
 // one sample's decoder inputs as they come from memory: 27 features (+ zero pad) and the 3 aux values
@@ -518,11 +467,11 @@ __device__ __forceinline__ int64_t aux_index(const int32_t* __restrict__ aux_map
     return ai;
 }
 
-template <int NPROD, bool VEC, bool PF, bool PM>
+template <int NPROD, bool VEC>
 __global__ void __launch_bounds__(512)
 k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int fstride, const float* __restrict__ aux,
            const int32_t* __restrict__ aux_map, int aux_mod, float* __restrict__ out, int64_t n,
-           const int32_t* __restrict__ n_dev, int out_dim, int act, int stagger) {
+           const int32_t* __restrict__ n_dev, int out_dim, int act) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
         const float* src = packed + OFF_BF;
@@ -530,11 +479,6 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
             *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(src + i);
     }
     __syncthreads();
-    // The two waves that share a SIMD (w and w+4) would otherwise run in lockstep -- both in the VALU input-build
-    // phase, then both in the MFMA phase -- leaving each pipe idle half of the time.  Delaying the upper four waves by
-    // about half a tile period puts one wave's MFMA phase under the other's VALU phase for the rest of the kernel.
-    if ((threadIdx.x >> 8) != 0)
-        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(32);
     const bf16x8* w0hi = reinterpret_cast<const bf16x8*>(lds + BH_FLOATS);
     const bf16x8* w0lo = w0hi + BW0_ELEMS / 8;
     const bf16x8* w1hi = w0lo + BW0_ELEMS / 8;
@@ -565,50 +509,21 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][r] = bp[r];
         }
-        if (PF) {
-            layer1_interleaved<NPROD, 0>(w0hi, w0lo, h, sl, cur.ft, cur.ax, ap, acc);
+        layer1_interleaved<NPROD, 0>(w0hi, w0lo, h, sl, cur.ft, cur.ax, ap, acc);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const float* bp = lds + BH_B1 + (h * 4 + mt) * 16;
+        for (int mt = 0; mt < 4; ++mt) {
+            const float* bp = lds + BH_B1 + (h * 4 + mt) * 16;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[mt][r] = bp[r];
-            }
-            layer2_interleaved<NPROD, 0, PM>(w1hi, w1lo, h, sl, acc, acc2);
-        } else {
-            bf16x8 xh[KB0], xl[KB0];
-            build_inputs<0>(cur.ft, cur.ax, ap, h, xh, xl);
-#pragma unroll
-            for (int kb = 0; kb < KB0; ++kb) {
-                mfma_block<NPROD, PM>(w0hi, w0lo, (kb * 2 + h) * 128 + sl, xh[kb], xl[kb], acc);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            bf16x8 hh[KB1], hl[KB1];
-#pragma unroll
-            for (int kb = 0; kb < KB1; ++kb) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const int q = kb * 8 + e; v[e] = fmaxf(acc[q >> 4][q & 15], 0.0f); }
-                split8(v, hh[kb], hl[kb]);
-            }
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const float* bp = lds + BH_B1 + (h * 4 + mt) * 16;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[mt][r] = bp[r];
-            }
-#pragma unroll
-            for (int kb = 0; kb < KB1; ++kb) {
-                mfma_block<NPROD, PM>(w1hi, w1lo, (kb * 2 + h) * 128 + sl, hh[kb], hl[kb], acc2);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int r = 0; r < 16; ++r) acc2[mt][r] = bp[r];
         }
+        layer2_interleaved<NPROD, 0>(w1hi, w1lo, h, sl, acc, acc2);
         // ---- layer 3 (fp32 VALU) ----
         float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
         {
             const float* wp = lds + BH_W2 + h * 256;
 #pragma unroll
             for (int q = 0; q < 64; ++q) {
-                const float hv = relu<PM>(acc2[q >> 4][q & 15]);
+                const float hv = relu(acc2[q >> 4][q & 15]);
                 const float4 w = *reinterpret_cast<const float4*>(wp + q * 4);
                 o0 = fmaf(hv, w.x, o0); o1 = fmaf(hv, w.y, o1); o2 = fmaf(hv, w.z, o2); o3 = fmaf(hv, w.w, o3);
             }
@@ -952,23 +867,21 @@ extern "C" int tir_mlp_train_fwd(const TirMlp* m, const float* feat, int32_t fea
     return TIR_OK;
 }
 
-template <int NPROD, bool VEC, bool PF, bool PM>
+template <int NPROD, bool VEC>
 static int launch_bf16_v(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map, int32_t aux_mod,
                          float* out, int64_t n, const int32_t* n_dev, void* stream) {
     static bool attr_set = false;
     const size_t lds = (size_t)BF_BYTES;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bf16<NPROD, VEC, PF, PM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bf16<NPROD, VEC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return -(int)e;
         attr_set = true;
     }
     int64_t tiles = (n + 255) / 256;
     unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
-    int stagger = 0;                  // units of 32 x 64 clocks; TIR_MLP_STAGGER overrides (tuning; 0 with the interleaved build)
-    if (const char* e = getenv("TIR_MLP_STAGGER")) stagger = atoi(e) < 0 ? 0 : atoi(e);
-    hipLaunchKernelGGL((k_mlp_bf16<NPROD, VEC, PF, PM>), dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, feat_stride, aux,
-                       aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act, tiles > (int64_t)grid ? stagger : 0);
+    hipLaunchKernelGGL((k_mlp_bf16<NPROD, VEC>), dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, feat_stride, aux,
+                       aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
@@ -980,16 +893,10 @@ static int launch_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, 
     if (rc) return rc;
     if (n < 0 || feat_stride < F || (n > 0 && (!feat || !aux || !out))) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
+    // 16-byte aligned rows of >= 28 floats take the dwordx4 row loads
     const bool vec = (feat_stride % 4 == 0) && feat_stride >= F + 1 && (reinterpret_cast<uintptr_t>(feat) % 16 == 0);
-    int variant = 3;                  // bit 0: interleaved input build (per k-block), bit 1: product-major MFMA order
-    if (const char* e = getenv("TIR_MLP_VARIANT")) variant = atoi(e) & 3;
-    if (!vec) return launch_bf16_v<NPROD, false, false, false>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream);
-    switch (variant) {
-        case 0: return launch_bf16_v<NPROD, true, false, false>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream);
-        case 1: return launch_bf16_v<NPROD, true, true, false>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream);
-        case 2: return launch_bf16_v<NPROD, true, false, true>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream);
-        default: return launch_bf16_v<NPROD, true, true, true>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream);
-    }
+    return vec ? launch_bf16_v<NPROD, true>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream)
+               : launch_bf16_v<NPROD, false>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream);
 }
 
 extern "C" int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map, int32_t aux_mod,
