@@ -436,3 +436,110 @@ def test_split_bf16_decoder_large_arguments(env):
         assert float((a[100:] - b[100:]).abs().max()) < 5e-5
         # huge raw features: the hi+lo split itself (2^-17 relative on inputs of 1e5) bounds the agreement, not the sincos
         assert torch.isfinite(a).all() and float((a[:100] - b[:100]).abs().max()) < 0.2
+
+
+# ---------------------------------------------------------------- BASELINE configs C4 / C5 at full size (properties)
+@pytest.fixture(scope="module")
+def full3():
+    """300^3 field with the three light rotations of configs[3] (multi_light_rotated)."""
+    import tensoir_amd
+    from tensoir_amd import synth
+    ck = synth.make_checkpoint(grid=(300, 300, 300), seed=20211202, light_rotation=("000", "120", "240"))
+    model = tensoir_amd.model_from_checkpoint(ck, "cuda", envmap_h=8, envmap_w=16)
+    with torch.no_grad():
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            model.updateAlphaMask((128, 128, 128))
+    return types.SimpleNamespace(model=model, args=types.SimpleNamespace(second_nSample=96, second_near=0.05, second_far=1.5))
+
+
+@torch.no_grad()
+def test_c4_full_image_800x800_sharded_render(full3):
+    """configs[3]: 800x800 image = 640 000 rays in 157 chunks, light index = pixel mod 3, rendered through
+    dist.render_sharded (the per-image record path of the 8-GPU layout; world = 1 here).  Properties: every map
+    finite and in range, background white, the assembled image equals direct chunk renders bit for bit (first, a
+    middle and the last, ragged, chunk), rotating the light changes the relit colour but not the geometry maps."""
+    from tensoir_amd import Renderer_TensoIR_train, synth
+    from tensoir_amd import dist as tdist
+    m, args = full3.model, full3.args
+    rays = synth.make_rays(800, 800, narrow=1.0).cuda()          # full field of view: the corners miss the object
+    n = rays.shape[0]
+    lidx = (torch.arange(n, device="cuda") % 3).to(torch.int32).view(-1, 1)
+    kw = dict(N_samples=-1, white_bg=True, is_train=False, is_relight=True, sample_method="fixed_envirmap",
+              device="cuda", args=args)
+
+    def render(r, l):
+        return Renderer_TensoIR_train(r, None, l, m, **kw)
+    img = tdist.render_sharded(render, rays, lidx, rank=0, world=1, chunk=4096)
+    for k, v in img.items():
+        assert v.shape[0] == n and bool(torch.isfinite(v).all()), k
+    acc = img["acc_map"]
+    assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-5
+    for k in ("rgb_map", "rgb_with_brdf_map", "albedo_map"):
+        assert float(img[k].min()) >= 0.0 and float(img[k].max()) <= 1.0 + 1e-6, k
+    bgd = acc < 1e-6
+    assert int(bgd.sum()) > 1000 and float((img["rgb_map"][bgd] - 1.0).abs().max()) < 1e-6     # corners: white background
+    assert float((img["rgb_with_brdf_map"][acc <= 0.5] - 1.0).abs().max()) == 0.0
+    hit = acc > 0.5
+    assert int(hit.sum()) > 100000
+    assert float((img["normal_map"][hit].norm(dim=-1) - 1).abs().max()) < 1e-4
+    chunks = list(torch.split(torch.arange(n, device="cuda"), 4096))
+    assert len(chunks) == 157 and chunks[-1].numel() == 640000 - 156 * 4096
+    for ci in (0, 78, 156):
+        c = chunks[ci]
+        direct = render(rays[c], lidx[c])
+        for k in ("rgb_map", "depth_map", "normal_map", "acc_map", "rgb_with_brdf_map"):
+            assert torch.equal(img[k][c], direct[k]), (ci, k)
+    # a different light rotation: same geometry / material maps, different shading
+    c = chunks[78]
+    other = render(rays[c], (lidx[c] + 1) % 3)
+    for k in ("depth_map", "normal_map", "albedo_map", "roughness_map", "acc_map"):
+        assert torch.equal(img[k][c], other[k]), k
+    assert float((img["rgb_with_brdf_map"][c] - other["rgb_with_brdf_map"]).abs().max()) > 1e-4
+
+
+@torch.no_grad()
+def test_c5_hdr_relight_2048x1024_importance_512(full3):
+    """configs[4]: relighting with a 2048x1024 HDR environment map and 512 importance samples per surface point
+    (scripts/relight_importance.py:115-171) on a 4096-ray chunk.  Properties: pdf tables normalised, sampled
+    directions unit length and concentrated on the bright disc, output finite / in [0,1] / deterministic for fixed
+    samples, exactly black under a black map, non-decreasing when the map is scaled up."""
+    from tensoir_amd import relight, synth
+    m, args = full3.model, full3.args
+    gen = torch.Generator().manual_seed(71)
+    H, W = 1024, 2048
+    hdr = torch.exp(torch.randn(H // 8, W // 8, 3, generator=gen) * 1.5)
+    hdr = torch.nn.functional.interpolate(hdr.permute(2, 0, 1)[None], size=(H, W), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).contiguous()
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    sun = ((yy - 300) ** 2 + (xx - 700) ** 2) < 20 ** 2
+    hdr[sun] *= 100.0
+    env = relight.Environment_Light(hdr_maps={"syn": hdr, "black": torch.zeros_like(hdr), "dim": hdr * 0.25}, device="cuda")
+    assert abs(float(env.hdr_pdf_sample["syn"].sum()) - 1.0) < 1e-4
+    rays = synth.make_rays(64, 64).cuda()
+    lidx = torch.zeros(4096, 1, dtype=torch.int32, device="cuda")
+    out = m(rays, lidx, N_samples=512)
+    depth, normal, albedo, rough, fres, acc = out[1], out[2], out[3], out[4], out[5], out[6]
+    mask = acc > 0.5
+    M, Ns = int(mask.sum()), 512
+    assert M > 3000
+    surf = (rays[:, :3] + depth.unsqueeze(-1) * rays[:, 3:])[mask]
+    torch.manual_seed(5)
+    ldir, lrgb, lpdf = env.sample_light("syn", M, Ns)
+    assert ldir.shape == (M, Ns, 3) and float((ldir.norm(dim=-1) - 1).abs().max()) < 1e-5
+    # importance sampling: the sun disc holds ~1e-4 of the pixels but a large share of the energy
+    sun_dir = env.hdr_dir["syn"][300, 700]
+    frac_sun = float(((ldir * sun_dir).sum(-1) > 0.995).float().mean())
+    assert frac_sun > 0.02
+
+    def relit(rgb, pdf):
+        return relight.relight_with_envmap(m, surf, normal[mask], albedo[mask], rough[mask], fres[mask], rays[:, 3:][mask],
+                                           ldir, rgb, pdf, nSample=96, vis_near=0.05, vis_far=1.5)
+    a = relit(lrgb, lpdf)
+    b = relit(lrgb, lpdf)
+    assert a.shape == (M, 3) and bool(torch.isfinite(a).all()) and torch.equal(a, b)
+    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0 + 1e-6 and float(a.mean()) > 0.01
+    assert float(relit(torch.zeros_like(lrgb), lpdf).abs().max()) == 0.0          # black map -> black (linear2srgb(0) = 0)
+    dim = relit(lrgb * 0.25, lpdf)
+    assert bool((dim <= a + 1e-6).all()) and float((a - dim).max()) > 1e-3
+    bg = env.get_light("syn", rays[:, 3:])
+    assert bg.shape == (4096, 3) and bool(torch.isfinite(bg).all()) and float(bg.min()) >= 0.0
