@@ -467,11 +467,11 @@ __device__ __forceinline__ int64_t aux_index(const int32_t* __restrict__ aux_map
     return ai;
 }
 
-template <int NPROD, bool VEC>
+template <int NPROD, bool VEC, bool SAVE>
 __global__ void __launch_bounds__(512)
 k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int fstride, const float* __restrict__ aux,
            const int32_t* __restrict__ aux_map, int aux_mod, float* __restrict__ out, int64_t n,
-           const int32_t* __restrict__ n_dev, int out_dim, int act) {
+           const int32_t* __restrict__ n_dev, int out_dim, int act, float* __restrict__ h1o, float* __restrict__ h2o) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
         const float* src = packed + OFF_BF;
@@ -510,6 +510,14 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
             for (int r = 0; r < 16; ++r) acc[mt][r] = bp[r];
         }
         layer1_interleaved<NPROD, 0>(w0hi, w0lo, h, sl, cur.ft, cur.ax, ap, acc);
+        if (SAVE && s_raw < n) {      // post-ReLU hidden activations in natural [sample][unit] order (training)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<float4*>(h1o + s_raw * HID + mt * 32 + 8 * i + 4 * h) =
+                        make_float4(relu(acc[mt][4 * i]), relu(acc[mt][4 * i + 1]), relu(acc[mt][4 * i + 2]), relu(acc[mt][4 * i + 3]));
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const float* bp = lds + BH_B1 + (h * 4 + mt) * 16;
@@ -517,6 +525,14 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
             for (int r = 0; r < 16; ++r) acc2[mt][r] = bp[r];
         }
         layer2_interleaved<NPROD, 0>(w1hi, w1lo, h, sl, acc, acc2);
+        if (SAVE && s_raw < n) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<float4*>(h2o + s_raw * HID + mt * 32 + 8 * i + 4 * h) =
+                        make_float4(relu(acc2[mt][4 * i]), relu(acc2[mt][4 * i + 1]), relu(acc2[mt][4 * i + 2]), relu(acc2[mt][4 * i + 3]));
+        }
         // ---- layer 3 (fp32 VALU) ----
         float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
         {
@@ -867,21 +883,21 @@ extern "C" int tir_mlp_train_fwd(const TirMlp* m, const float* feat, int32_t fea
     return TIR_OK;
 }
 
-template <int NPROD, bool VEC>
+template <int NPROD, bool VEC, bool SAVE>
 static int launch_bf16_v(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map, int32_t aux_mod,
-                         float* out, int64_t n, const int32_t* n_dev, void* stream) {
+                         float* out, int64_t n, const int32_t* n_dev, void* stream, float* h1 = nullptr, float* h2 = nullptr) {
     static bool attr_set = false;
     const size_t lds = (size_t)BF_BYTES;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bf16<NPROD, VEC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bf16<NPROD, VEC, SAVE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return -(int)e;
         attr_set = true;
     }
     int64_t tiles = (n + 255) / 256;
     unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
-    hipLaunchKernelGGL((k_mlp_bf16<NPROD, VEC>), dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, feat_stride, aux,
-                       aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act);
+    hipLaunchKernelGGL((k_mlp_bf16<NPROD, VEC, SAVE>), dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, feat_stride, aux,
+                       aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act, h1, h2);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
@@ -895,8 +911,20 @@ static int launch_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, 
     if (n == 0) return TIR_OK;
     // 16-byte aligned rows of >= 28 floats take the dwordx4 row loads
     const bool vec = (feat_stride % 4 == 0) && feat_stride >= F + 1 && (reinterpret_cast<uintptr_t>(feat) % 16 == 0);
-    return vec ? launch_bf16_v<NPROD, true>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream)
-               : launch_bf16_v<NPROD, false>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream);
+    return vec ? launch_bf16_v<NPROD, true, false>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream)
+               : launch_bf16_v<NPROD, false, false>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream);
+}
+
+extern "C" int tir_mlp_train_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
+                                        const int32_t* aux_map, int32_t aux_mod, float* out, float* h1, float* h2,
+                                        int64_t n, void* stream) {
+    int rc = check_mlp(m);
+    if (rc) return rc;
+    if (n < 0 || feat_stride < F || (n > 0 && (!feat || !aux || !out || !h1 || !h2))) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    const bool vec = (feat_stride % 4 == 0) && feat_stride >= F + 1 && (reinterpret_cast<uintptr_t>(feat) % 16 == 0);
+    return vec ? launch_bf16_v<3, true, true>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, nullptr, stream, h1, h2)
+               : launch_bf16_v<3, false, true>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, nullptr, stream, h1, h2);
 }
 
 extern "C" int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map, int32_t aux_mod,

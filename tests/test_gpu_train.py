@@ -86,14 +86,27 @@ def test_decoder_backward(env, which):
     (y * g_out).sum().backward()
     fpad = torch.zeros(n, 32)
     fpad[:, :27] = feat
-    call = training._DecoderCall(feat=fpad.cuda(), aux=aux.cuda(), aux_map=None, g_out=g_out.cuda())
-    call.out, call.h1, call.h2 = ops.mlp_train(dec.packed(), call.feat, call.aux)
-    assert gerr(call.out, y) < 1e-5
-    (g_feat,), grads = training._decoder_backward(dec, [call])
-    assert gerr(g_feat[:, :27], fr.grad) < 1e-4
-    assert float(g_feat[:, 27:].abs().max()) == 0.0
-    for got, name in zip(grads, ("w0", "b0", "w1", "b1", "w2", "b2")):
-        assert gerr(got, wr[name].grad) < 1e-4, name
+    for impl in ("mfma", "bf16x3"):      # forward with saved activations: exact fp32 and split-bf16 matrix cores
+        call = training._DecoderCall(feat=fpad.cuda(), aux=aux.cuda(), aux_map=None, g_out=g_out.cuda())
+        call.out, call.h1, call.h2 = ops.mlp_train(dec.packed(), call.feat, call.aux, impl=impl)
+        assert gerr(call.out, y) < 2e-5, impl
+        (g_feat,), grads = training._decoder_backward(dec, [call])
+        if impl == "mfma":
+            assert gerr(g_feat[:, :27], fr.grad) < 1e-4, impl
+        else:
+            # the split-bf16 forward rounds pre-activations differently (~1e-6): a hidden unit sitting within that of
+            # zero flips its ReLU mask, which changes ONE sample's gradient by a few percent (the backward is exact for
+            # the forward that was run).  Everything else agrees to 1e-4.
+            d = (g_feat[:, :27].cpu().double() - fr.grad.double()).abs().amax(-1) / fr.grad.double().abs().max()
+            assert float((d > 1e-4).double().mean()) < 5e-3 and float(d.max()) < 0.2, impl
+        assert float(g_feat[:, 27:].abs().max()) == 0.0
+        for got, name in zip(grads, ("w0", "b0", "w1", "b1", "w2", "b2")):
+            if impl == "mfma":
+                assert gerr(got, wr[name].grad) < 1e-4, (impl, name)
+            else:      # a flipped unit moves one row of the 700-sample weight gradient by ~1 %; the bulk agrees to 1e-4
+                ref = wr[name].grad.double()
+                d = (got.detach().cpu().double() - ref).abs() / ref.abs().max()
+                assert float(d.max()) < 5e-2 and float((d > 1e-4).double().mean()) < 2e-2, (impl, name, float(d.max()))
 
 
 def _field_grads(env, fn_hip, fn_oracle, names):
