@@ -307,27 +307,19 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
     lo = __builtin_bit_cast(bf16x8, L);
 }
 
-// sin and cos of x with one shared Cody-Waite reduction and two minimax polynomials (<= 2 ulp for |x| < 8192);
-// larger arguments are first reduced modulo 2 pi in double precision (a few v_fma_f64, inline: a library call
-// here would clobber the register file at 17 call sites).  Branch-free apart from that rare pre-reduction.
+// sin and cos of x on the hardware transcendental unit.  v_sin_f32 / v_cos_f32 take the angle in REVOLUTIONS and are
+// accurate to 1.4e-7 for |angle| <= 1/8 revolution (measured on gfx950) but the naive x * (1/2pi) loses the fraction of
+// large arguments (2.8e-6 at |x| = 32).  So the fraction of x / 2pi is formed exactly: k = rint(x * c_hi);
+// t = fma(x, c_hi, -k) is the exact fractional part of the product (one rounding, |t| <= 1/2), and fma(x, c_lo, t) adds
+// the part of 1/2pi that c_hi misses.  Six instruction slots instead of ~30 for the polynomial form -- the decoder
+// kernel is VALU-issue bound -- with <= 4e-7 absolute error for |x| up to ~1e5 (NaN / inf give NaN like sinf).
 __device__ __forceinline__ void fast_sincos(float x, float& s, float& c) {
-    if (__builtin_expect(!(fabsf(x) < 8192.0f), 0)) {
-        const double xd = (double)x;
-        const double k = rint(xd * 0.15915494309189533577);
-        x = (float)fma(k, -6.283185307179586476925, xd);       // |x| <= pi (NaN / inf stay NaN)
-    }
-    const float n = rintf(x * 0.636619772367581343f);
-    float r = fmaf(n, -1.57079637050628662109375f, x);
-    r = fmaf(n, 4.37113900018624283e-8f, r);
-    const float z = r * r;
-    const float sp = fmaf(r * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
-    const float cp = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
-                          fmaf(z, -0.5f, 1.0f));
-    const int q = (int)n;
-    const float ss = (q & 1) ? cp : sp;
-    const float cc = (q & 1) ? sp : cp;
-    s = (q & 2) ? -ss : ss;
-    c = ((q + 1) & 2) ? -cc : cc;
+    const float c_hi = 0.15915493667125702f, c_lo = 6.4206382432985265e-09f;      // c_hi + c_lo = 1 / (2 pi)
+    const float k = rintf(x * c_hi);
+    float t = fmaf(x, c_hi, -k);
+    t = fmaf(x, c_lo, t);
+    s = __builtin_amdgcn_sinf(t);
+    c = __builtin_amdgcn_cosf(t);
 }
 
 // This lane-half's positional encodings of value v: half 0 -> {sin v, sin 2v}, half 1 -> {cos v, cos 2v}
