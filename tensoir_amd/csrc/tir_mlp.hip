@@ -660,7 +660,9 @@ k_mlp_inputs(const float* __restrict__ feat, int fstride, const float* __restric
             const bool is_cos = q >= NPF;
             const int qq = is_cos ? q - NPF : q;
             const float y = feat[s * fstride + qq / PE] * (float)(1 << (qq % PE));
-            v = is_cos ? cosf(y) : sinf(y);
+            float sv, cv;
+            fast_sincos(y, sv, cv);            // transcendental unit, <= 4e-7 abs (these rows only feed d W0 = dz1^T x)
+            v = is_cos ? cv : sv;
         } else {
             int64_t ai = aux_map ? (int64_t)aux_map[s] : s;
             if (aux_mod > 0) ai %= aux_mod;
@@ -673,7 +675,9 @@ k_mlp_inputs(const float* __restrict__ feat, int fstride, const float* __restric
         const bool is_cos = q >= 3 * PE;
         const int qq = is_cos ? q - 3 * PE : q;
         const float y = aux[3 * ai + qq / PE] * (float)(1 << (qq % PE));
-        v = is_cos ? cosf(y) : sinf(y);
+        float sv, cv;
+        fast_sincos(y, sv, cv);
+        v = is_cos ? cv : sv;
     }
     x[idx] = v;
 }
@@ -788,7 +792,9 @@ k_mlp_bwd(const float* __restrict__ packed_bwd, const float* __restrict__ feat, 
             float v = 0.f;
             if (d < F) {
                 const float xv = feat[s * fstride + d];
-                const float s1 = sinf(xv), c1 = cosf(xv), s2 = sinf(xv * 2.0f), c2 = cosf(xv * 2.0f);
+                float s1, c1;
+                fast_sincos(xv, s1, c1);
+                const float s2 = 2.0f * s1 * c1, c2 = fmaf(-2.0f * s1, s1, 1.0f);      // double-angle identities
                 const int u0 = 5 * j;
                 const float g_raw = ax[(u0) >> 4][(u0) & 15], g_s0 = ax[(u0 + 1) >> 4][(u0 + 1) & 15];
                 const float g_s1 = ax[(u0 + 2) >> 4][(u0 + 2) & 15], g_c0 = ax[(u0 + 3) >> 4][(u0 + 3) & 15];
