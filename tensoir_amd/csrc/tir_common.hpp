@@ -175,13 +175,17 @@ __device__ __forceinline__ float density_feature_chunk(const TirField& f, float 
         const int H = f.grid[m1], W = f.grid[m0], R = f.grid[vi];
         Tap1 tx = make_tap(p[m0], W), ty = make_tap(p[m1], H), tl = make_tap(p[vi], R);
         const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
-        const float* pl = f.dplane[i] + 4 * c;
-        const float4 a = ld4(pl + ((size_t)ty.i0 * W + tx.i0) * (C4 * 4));
-        const float4 b = ld4(pl + ((size_t)ty.i0 * W + tx.i1) * (C4 * 4));
-        const float4 cc = ld4(pl + ((size_t)ty.i1 * W + tx.i0) * (C4 * 4));
-        const float4 d = ld4(pl + ((size_t)ty.i1 * W + tx.i1) * (C4 * 4));
-        const float4 e = ld4(f.dline[i] + (size_t)tl.i0 * (C4 * 4) + 4 * c);
-        const float4 g = ld4(f.dline[i] + (size_t)tl.i1 * (C4 * 4) + 4 * c);
+        // 32-bit element offsets (a plane holds < 2^31 floats, checked at launch): scalar base + one VGPR offset per
+        // tap instead of 64-bit address arithmetic per lane
+        const float* pl = f.dplane[i];
+        const unsigned r0 = (unsigned)(ty.i0 * W) * (C4 * 4) + 4 * c, r1 = (unsigned)(ty.i1 * W) * (C4 * 4) + 4 * c;
+        const unsigned x0 = (unsigned)tx.i0 * (C4 * 4), x1 = (unsigned)tx.i1 * (C4 * 4);
+        const float4 a = ld4(pl + (r0 + x0));
+        const float4 b = ld4(pl + (r0 + x1));
+        const float4 cc = ld4(pl + (r1 + x0));
+        const float4 d = ld4(pl + (r1 + x1));
+        const float4 e = ld4(f.dline[i] + ((unsigned)tl.i0 * (C4 * 4) + 4 * c));
+        const float4 g = ld4(f.dline[i] + ((unsigned)tl.i1 * (C4 * 4) + 4 * c));
         acc = fmaf(fmaf(d.x, w11, fmaf(cc.x, w10, fmaf(b.x, w01, a.x * w00))), fmaf(g.x, tl.w1, e.x * tl.w0), acc);
         acc = fmaf(fmaf(d.y, w11, fmaf(cc.y, w10, fmaf(b.y, w01, a.y * w00))), fmaf(g.y, tl.w1, e.y * tl.w0), acc);
         acc = fmaf(fmaf(d.z, w11, fmaf(cc.z, w10, fmaf(b.z, w01, a.z * w00))), fmaf(g.z, tl.w1, e.z * tl.w0), acc);

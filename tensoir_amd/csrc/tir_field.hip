@@ -83,6 +83,10 @@ static int check_field(const TirField* f) {
     if (!f) return TIR_ERR_ARG;
     for (int i = 0; i < 3; ++i)
         if (f->grid[i] < 2 || !f->dplane[i] || !f->dline[i]) return TIR_ERR_ARG;
+    // the gathers index planes with 32-bit element offsets
+    for (int i = 0; i < 3; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if ((int64_t)f->grid[i] * f->grid[j] * (f->n_acomp > f->n_dcomp ? f->n_acomp : f->n_dcomp) >= ((int64_t)1 << 31)) return TIR_ERR_UNSUPPORTED;
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
     return TIR_OK;
 }
@@ -472,12 +476,14 @@ k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restri
             Tap1 tx = make_tap(u, W), ty = make_tap(v, H), tl = make_tap(w, R);
             const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
             const float* pl = f.aplane[k];
-            const float* p00 = pl + ((size_t)ty.i0 * W + tx.i0) * CA;
-            const float* p01 = pl + ((size_t)ty.i0 * W + tx.i1) * CA;
-            const float* p10 = pl + ((size_t)ty.i1 * W + tx.i0) * CA;
-            const float* p11 = pl + ((size_t)ty.i1 * W + tx.i1) * CA;
-            const float* l0 = f.aline[k] + (size_t)tl.i0 * CA;
-            const float* l1 = f.aline[k] + (size_t)tl.i1 * CA;
+            const unsigned r0 = (unsigned)(ty.i0 * W) * CA, r1 = (unsigned)(ty.i1 * W) * CA;     // 32-bit element offsets
+            const unsigned x0 = (unsigned)tx.i0 * CA, x1 = (unsigned)tx.i1 * CA;
+            const float* p00 = pl + (r0 + x0);
+            const float* p01 = pl + (r0 + x1);
+            const float* p10 = pl + (r1 + x0);
+            const float* p11 = pl + (r1 + x1);
+            const float* l0 = f.aline[k] + (unsigned)tl.i0 * CA;
+            const float* l1 = f.aline[k] + (unsigned)tl.i1 * CA;
 #pragma unroll
             for (int q = 0; q < (C4 + 3) / 4; ++q) {
                 const int ch4 = 4 * q + c;                 // this lane's 16-byte chunk of the 64-byte run q
@@ -614,12 +620,14 @@ k_vm_app_bf16(TirField f, const float* __restrict__ xyz, const int32_t* __restri
             Tap1 tx = make_tap(u, W), ty = make_tap(v, H), tl = make_tap(w, R);
             const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
             const float* pl = f.aplane[k];
-            const float* p00 = pl + ((size_t)ty.i0 * W + tx.i0) * CA;
-            const float* p01 = pl + ((size_t)ty.i0 * W + tx.i1) * CA;
-            const float* p10 = pl + ((size_t)ty.i1 * W + tx.i0) * CA;
-            const float* p11 = pl + ((size_t)ty.i1 * W + tx.i1) * CA;
-            const float* l0 = f.aline[k] + (size_t)tl.i0 * CA;
-            const float* l1 = f.aline[k] + (size_t)tl.i1 * CA;
+            const unsigned r0 = (unsigned)(ty.i0 * W) * CA, r1 = (unsigned)(ty.i1 * W) * CA;     // 32-bit element offsets
+            const unsigned x0 = (unsigned)tx.i0 * CA, x1 = (unsigned)tx.i1 * CA;
+            const float* p00 = pl + (r0 + x0);
+            const float* p01 = pl + (r0 + x1);
+            const float* p10 = pl + (r1 + x0);
+            const float* p11 = pl + (r1 + x1);
+            const float* l0 = f.aline[k] + (unsigned)tl.i0 * CA;
+            const float* l1 = f.aline[k] + (unsigned)tl.i1 * CA;
 #pragma unroll
             for (int q = 0; q < (C4 + 3) / 4; ++q) {
                 const int ch4 = 4 * q + c;
