@@ -861,7 +861,8 @@ extern "C" int tir_march_primary_bwd(const TirField* f, const TirFieldGrad* g, c
 #define TIR_LAUNCH_MB(C4)                                                                                             \
     do {                                                                                                              \
         if (ll) {                                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_primary_bwd<C4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+            static bool attr_set = false;                                                                             \
+            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_primary_bwd<C4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set = true; } \
             hipLaunchKernelGGL((k_march_primary_bwd<C4, true>), grid, blk, lds, s, *f, *g, rays, ray_jitter, B, S, sigma, weight, g_weight, g_acc, g_depth, g_feature); \
         } else                                                                                                        \
             hipLaunchKernelGGL((k_march_primary_bwd<C4, false>), grid, blk, 0, s, *f, *g, rays, ray_jitter, B, S, sigma, weight, g_weight, g_acc, g_depth, g_feature); \
@@ -895,7 +896,8 @@ extern "C" int tir_density_grad_bwd(const TirField* f, const TirFieldGrad* g, co
 #define TIR_LAUNCH_DG(C4)                                                                                             \
     do {                                                                                                              \
         if (ll) {                                                                                                     \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_density_grad_bwd<C4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+            static bool attr_set = false;                                                                             \
+            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_density_grad_bwd<C4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set = true; } \
             hipLaunchKernelGGL((k_density_grad_bwd<C4, true>), grid, blk, lds, s, *f, *g, xyz, g_normal, n);          \
         } else                                                                                                        \
             hipLaunchKernelGGL((k_density_grad_bwd<C4, false>), grid, blk, 0, s, *f, *g, xyz, g_normal, n);           \

@@ -75,8 +75,6 @@ class GraphedRenderer:
         """rays [n_rays, 6], light_idx [n_rays, 1] (any device) -> the 12-key dict (fresh tensors)."""
         if rays.shape[0] != self.n_rays:
             raise ValueError(f"GraphedRenderer was built for {self.n_rays} rays, got {rays.shape[0]}")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters()):
-            pass                                         # replay never records autograd: documented as inference only
         self.rays.copy_(rays.to(self.device, torch.float32), non_blocking=True)
         self.lidx.copy_(light_idx.to(self.device, torch.int32).view(-1, 1), non_blocking=True)
         for _ in range(3):
