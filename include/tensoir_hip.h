@@ -250,6 +250,19 @@ int tir_march_secondary_fwd(const TirField* f, const float* origins, const int32
                             float* rec_w, float* rec_xyz, int32_t* ray_rec_off,
                             int32_t* ray_rec_cnt, unsigned long long* stats, void* stream);
 
+/* tir_march_secondary_fwd over a LIST of rays: ray_ids[0 .. min(n_rays, *n_ids_dev)) are pair ids (as produced by
+ * tir_shade_setup_compact); origin / direction / active / every output (vis, one_minus_acc, ray_rec_off, ray_rec_cnt,
+ * rec_ray entries) are addressed by the pair id, so the per-pair arrays keep their dense [M*D] shape while no half-wave
+ * is spent on a masked pair.  ray_ids == n_ids_dev == NULL: identical to tir_march_secondary_fwd. */
+int tir_march_secondary_ids_fwd(const TirField* f, const float* origins, const int32_t* org_map,
+                                const float* dirs, const int32_t* dir_map, const uint8_t* active,
+                                int64_t n_rays, int32_t n_dirs, int32_t n_sample, const float* z_vals,
+                                float t_stop, float* vis, float* one_minus_acc,
+                                int32_t* rec_counter, int64_t rec_cap, int32_t* rec_ray,
+                                float* rec_w, float* rec_xyz, int32_t* ray_rec_off,
+                                int32_t* ray_rec_cnt, unsigned long long* stats, const int32_t* ray_ids,
+                                const int32_t* n_ids_dev, void* stream);
+
 /* indirect[p] = sum over ray p's records of w * rgb  (models/relight_utils.py:832) */
 int tir_accumulate_records(const int32_t* ray_rec_off, const int32_t* ray_rec_cnt,
                            const float* rec_w, const float* rec_rgb, int64_t n_rays,
@@ -266,6 +279,15 @@ int tir_env_sg_fwd(const TirEnvSG* e, const float* dirs, int32_t D, float* out, 
 int tir_shade_setup(const float* maps, const float* rays, const float* dirs, int32_t M,
                     int32_t D, float acc_thres, float* surf, uint8_t* active, void* stream);
 
+/* tir_shade_setup that also emits the compacted list of active pairs -- the reference's boolean-mask indexing
+ * surf2l[cosine_mask] (models/relight_utils.py:440-441): pair_ids[0 .. *n_active) = m * D + d of the pairs with
+ * active != 0 (order of wave-sized groups arbitrary), *n_active += their number (caller zeroes it, or lets
+ * tir_shade_integrate_records re-arm it); vis[pair] = 0 and ray_rec_cnt[pair] = 0 (either may be NULL) for the masked
+ * pairs, which then need no secondary ray at all (tir_march_secondary_ids_fwd). */
+int tir_shade_setup_compact(const float* maps, const float* rays, const float* dirs, int32_t M,
+                            int32_t D, float acc_thres, float* surf, uint8_t* active, int32_t* pair_ids,
+                            int32_t* n_active, float* vis, int32_t* ray_rec_cnt, void* stream);
+
 /* ---- K8: GGX_specular + rendering-equation sum + tone map
  *      (models/relight_utils.py:17-50, :452-480, :489-515).
  *      vis [M][D], indirect [M][D][3] (NULL = no indirect), env [n_lights][D][3],
@@ -279,13 +301,15 @@ int tir_shade_integrate(const float* maps, const float* rays, const float* dirs,
 
 /* Same as tir_shade_integrate with the indirect radiance of pair (m, d) summed inside the kernel from that ray's
  * records (ray_rec_off / ray_rec_cnt of tir_march_secondary_fwd, rec_rgb [A][3] = decoder output per record), i.e.
- * tir_accumulate_records fused into the integration: the [M][D][3] indirect buffer is never written. */
+ * tir_accumulate_records fused into the integration: the [M][D][3] indirect buffer is never written.
+ * reset_counter (optional): a device int the kernel sets to 0 -- the pair counter of tir_shade_setup_compact, re-armed by
+ * the last consumer of the step so that no separate fill launch is needed (also under HIP-graph replay). */
 int tir_shade_integrate_records(const float* maps, const float* rays, const float* dirs,
                                 const int32_t* light_idx, const float* vis, const int32_t* ray_rec_off,
                                 const int32_t* ray_rec_cnt, const float* rec_w, const float* rec_rgb,
                                 const float* env, const float* weight_d, int32_t M, int32_t D,
                                 int32_t n_lights, int32_t equal_area, int32_t use_srgb, float acc_thres,
-                                float* out_rgb, void* stream);
+                                float* out_rgb, int32_t* reset_counter, void* stream);
 
 /* ---- K9: importance-sampled HDR relighting, loop body of scripts/relight_importance.py:119-170.
  *      Per surface point m and sample s: light_dir/rgb [M][Ns][3], pdf [M][Ns], vis [M][Ns].

@@ -85,7 +85,10 @@ SIGNATURES = {
     "tir_env_sg_fwd": (C.c_int, [C.POINTER(TirEnvSG), P, I32, P, P]),
     "tir_shade_setup": (C.c_int, [P, P, P, I32, I32, F32, P, P, P]),
     "tir_shade_integrate": (C.c_int, [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, P, P]),
-    "tir_shade_integrate_records": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, P, P]),
+    "tir_shade_integrate_records": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, P, P, P]),
+    "tir_shade_setup_compact": (C.c_int, [P, P, P, I32, I32, F32, P, P, P, P, P, P, P]),
+    "tir_march_secondary_ids_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I64, I32, I32, P, F32, P, P,
+                                              P, I64, P, P, P, P, P, P, P, P, P]),
     "tir_relight_importance": (C.c_int, [P, P, P, P, P, P, P, P, P, I32, I32, P, P]),
     "tir_ggx_specular": (C.c_int, [P, P, P, P, P, I32, I32, P, P]),
     # ---- training (backward) entry points ----

@@ -338,11 +338,15 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
                   float* __restrict__ one_minus_acc, int32_t* __restrict__ rec_counter, int64_t rec_cap,
                   int32_t* __restrict__ rec_ray, float* __restrict__ rec_w, float* __restrict__ rec_xyz,
                   int32_t* __restrict__ ray_rec_off, int32_t* __restrict__ ray_rec_cnt,
-                  unsigned long long* __restrict__ stats, int xcd_on) {
+                  unsigned long long* __restrict__ stats, int xcd_on, const int32_t* __restrict__ ray_ids,
+                  const int32_t* __restrict__ n_ids_dev) {
     extern __shared__ __attribute__((aligned(16))) float w_lds[];
     // XCD-aware block order: XCD x (= blockIdx % 8) takes the x-th contiguous eighth of the ray blocks
     int64_t bid = blockIdx.x;
     if (xcd_on && (gridDim.x & 7) == 0) bid = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    // ray_ids: the rays of this launch are the listed pair ids (a compacted active list, *n_ids_dev of them); every
+    // per-ray input and output is addressed by the pair id, the loop index only spreads the work
+    if (ray_ids && n_ids_dev) n_rays = min(n_rays, (int64_t)max(*n_ids_dev, 0));
     if (bid * TIR_SEC_RPB >= n_rays) return;
     const int hl = threadIdx.x & 31;                 // lane within the half-wave
     const int hw = threadIdx.x >> 5;                 // half-wave within the block
@@ -352,7 +356,8 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
     int* s_cnt = reinterpret_cast<int*>(w_lds + nz + 4 * 256);
     int* s_kstop = s_cnt + TIR_SEC_RPB;
     int* s_base = s_kstop + TIR_SEC_RPB;
-    float* w_all = w_lds + nz + 4 * 256 + 3 * TIR_SEC_RPB;        // [32][n_sample]
+    int* s_pid = s_base + TIR_SEC_RPB;
+    float* w_all = w_lds + nz + 4 * 256 + 4 * TIR_SEC_RPB;        // [32][n_sample]
     for (int i = threadIdx.x; i < n_sample; i += blockDim.x) zt[i] = z_vals[i];
     __syncthreads();
     const bool want_rec = rec_counter != nullptr;
@@ -360,8 +365,9 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
 
     for (int g = 0; g < TIR_SEC_RPB / 8; ++g) {
         const int rl = g * 8 + hw;
-        const int64_t ray = bid * TIR_SEC_RPB + rl;
-        const bool in_range = ray < n_rays;
+        const int64_t slot_id = bid * TIR_SEC_RPB + rl;
+        const bool in_range = slot_id < n_rays;
+        const int64_t ray = in_range ? (ray_ids ? (int64_t)ray_ids[slot_id] : slot_id) : 0;      // pair id
         const bool live = in_range && !(active && !active[ray]);
         int cnt = 0, k_stop = n_sample;    // k_stop: first sample this ray did not march (zero weight from there)
         if (__any(live)) {
@@ -420,6 +426,7 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
             }
             s_cnt[rl] = live ? cnt : 0;
             s_kstop[rl] = k_stop;
+            s_pid[rl] = in_range ? (int)ray : -1;
         }
     }
     if (stats && hl == 0 && n_gather) atomicAdd(stats, (unsigned long long)n_gather);
@@ -442,10 +449,10 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
         // rec_counter[1]: length of the fully written record prefix.  Reservations are handed out in increasing order,
         // so once one block does not fit no later one does: the written slots are exactly [0, max fitting base+total).
         if (hl == 31 && total > 0 && fits) atomicMax(rec_counter + 1, base + total);
-        const int64_t ray = bid * TIR_SEC_RPB + hl;
-        if (ray < n_rays) {
-            ray_rec_off[ray] = base + incl - c;
-            ray_rec_cnt[ray] = fits ? c : 0;
+        const int pid = s_pid[hl];
+        if (pid >= 0) {
+            ray_rec_off[pid] = base + incl - c;
+            ray_rec_cnt[pid] = fits ? c : 0;
         }
         s_base[hl] = (fits && c > 0) ? base + incl - c : -1;
     }
@@ -454,7 +461,7 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
         const int rl = g * 8 + hw;
         int base = s_base[rl];
         if (base < 0) continue;                    // uniform inside the half-wave
-        const int64_t ray = bid * TIR_SEC_RPB + rl;
+        const int64_t ray = s_pid[rl];
         const size_t oi = org_map ? (size_t)org_map[ray] : (n_dirs > 0 ? (size_t)(ray / n_dirs) : (size_t)ray);
         const size_t di = dir_map ? (size_t)dir_map[ray] : (n_dirs > 0 ? (size_t)(ray % n_dirs) : (size_t)ray);
         float o[3], d[3];
@@ -491,21 +498,36 @@ extern "C" int tir_march_secondary_fwd(const TirField* f, const float* origins, 
                                        int32_t* rec_counter, int64_t rec_cap, int32_t* rec_ray,
                                        float* rec_w, float* rec_xyz, int32_t* ray_rec_off,
                                        int32_t* ray_rec_cnt, unsigned long long* stats, void* stream) {
+    return tir_march_secondary_ids_fwd(f, origins, org_map, dirs, dir_map, active, n_rays, n_dirs, n_sample, z_vals, t_stop,
+                                       vis, one_minus_acc, rec_counter, rec_cap, rec_ray, rec_w, rec_xyz, ray_rec_off,
+                                       ray_rec_cnt, stats, nullptr, nullptr, stream);
+}
+
+extern "C" int tir_march_secondary_ids_fwd(const TirField* f, const float* origins, const int32_t* org_map,
+                                           const float* dirs, const int32_t* dir_map, const uint8_t* active,
+                                           int64_t n_rays, int32_t n_dirs, int32_t n_sample, const float* z_vals,
+                                           float t_stop, float* vis, float* one_minus_acc,
+                                           int32_t* rec_counter, int64_t rec_cap, int32_t* rec_ray,
+                                           float* rec_w, float* rec_xyz, int32_t* ray_rec_off,
+                                           int32_t* ray_rec_cnt, unsigned long long* stats, const int32_t* ray_ids,
+                                           const int32_t* n_ids_dev, void* stream) {
     if (!f || n_rays < 0 || n_sample <= 0) return TIR_ERR_ARG;
+    if ((ray_ids == nullptr) != (n_ids_dev == nullptr)) return TIR_ERR_ARG;
     if (n_sample > TIR_SEC_MAX_SAMPLES) return TIR_ERR_UNSUPPORTED;
     if (n_rays == 0) return TIR_OK;
     if (!origins || !dirs || !z_vals) return TIR_ERR_ARG;
     if (rec_counter && (!rec_ray || !rec_w || !rec_xyz || !ray_rec_off || !ray_rec_cnt || rec_cap < 0)) return TIR_ERR_ARG;
     if (n_rays >= (int64_t)1 << 31) return TIR_ERR_UNSUPPORTED;
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
-    size_t lds = ((size_t)((n_sample + 3) & ~3) + 4 * 256 + 3 * TIR_SEC_RPB +
+    size_t lds = ((size_t)((n_sample + 3) & ~3) + 4 * 256 + 4 * TIR_SEC_RPB +
                   (rec_counter ? (size_t)TIR_SEC_RPB * n_sample : 0)) * sizeof(float);
     const int xcd_on = tir_xcd_mapping();
     unsigned nblk = (unsigned)((n_rays + TIR_SEC_RPB - 1) / TIR_SEC_RPB);
     if (xcd_on) nblk = (nblk + 7) / 8 * 8;
     hipLaunchKernelGGL(k_march_secondary, dim3(nblk), dim3(256), lds, tir_stream(stream),
                        *f, origins, org_map, dirs, dir_map, active, n_rays, n_dirs, n_sample, z_vals, t_stop, vis,
-                       one_minus_acc, rec_counter, rec_cap, rec_ray, rec_w, rec_xyz, ray_rec_off, ray_rec_cnt, stats, xcd_on);
+                       one_minus_acc, rec_counter, rec_cap, rec_ray, rec_w, rec_xyz, ray_rec_off, ray_rec_cnt, stats, xcd_on,
+                       ray_ids, n_ids_dev);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

@@ -99,22 +99,52 @@ k_env_sg(TirEnvSG e, const float* __restrict__ dirs, int D, float* __restrict__ 
 }
 
 // ---- render_with_BRDF geometry (models/relight_utils.py:417-435) -----------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_shade_setup(const float* __restrict__ maps, const float* __restrict__ rays, const float* __restrict__ dirs,
-              int M, int D, float acc_thres, float* __restrict__ surf, uint8_t* __restrict__ active) {
+              int M, int D, float acc_thres, float* __restrict__ surf, uint8_t* __restrict__ active,
+              int32_t* __restrict__ pair_ids, int32_t* __restrict__ n_active, float* __restrict__ vis,
+              int32_t* __restrict__ rec_cnt) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)M * D) return;
-    const int m = (int)(i / D), d = (int)(i % D);
-    const float* mp = maps + (size_t)m * TIR_MAP_STRIDE;
-    const float* r = rays + 6 * (size_t)m;
-    if (d == 0) {
-        const float depth = mp[3];
+    const bool in = i < (int64_t)M * D;
+    bool act = false;
+    if (in) {
+        const int m = (int)(i / D), d = (int)(i % D);
+        const float* mp = maps + (size_t)m * TIR_MAP_STRIDE;
+        const float* r = rays + 6 * (size_t)m;
+        if (d == 0) {
+            const float depth = mp[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) surf[3 * (size_t)m + a] = add_rn(r[a], mul_rn(depth, r[3 + a]));   // :422
+            for (int a = 0; a < 3; ++a) surf[3 * (size_t)m + a] = add_rn(r[a], mul_rn(depth, r[3 + a]));   // :422
+        }
+        // cosine = clamp(einsum(surf2l, normal_map), 0); mask = cosine > 1e-6   (:433-435)
+        float cs = dirs[3 * d] * mp[4] + dirs[3 * d + 1] * mp[5] + dirs[3 * d + 2] * mp[6];
+        act = fmaxf(cs, 0.f) > 1e-6f && mp[14] > acc_thres;       // acc_mask = acc > 0.5 (:1031, renderer.py:86)
+        active[i] = act ? 1 : 0;
     }
-    // cosine = clamp(einsum(surf2l, normal_map), 0); mask = cosine > 1e-6   (:433-435)
-    float cs = dirs[3 * d] * mp[4] + dirs[3 * d + 1] * mp[5] + dirs[3 * d + 2] * mp[6];
-    active[i] = (fmaxf(cs, 0.f) > 1e-6f && mp[14] > acc_thres) ? 1 : 0;   // acc_mask = acc > 0.5 (:1031, renderer.py:86)
+    if (!pair_ids) return;
+    // compacted list of the (surface point, direction) pairs that get a secondary ray -- the boolean-mask indexing
+    // surf2l[cosine_mask] of the reference (:440-441) -- so that the march kernel spends no half-wave on a masked pair;
+    // masked pairs get their zero visibility / empty record range here (:437-438)
+    // one reservation per 1024-pair block (not per wave: 8192 atomics on one address cost 100 us), wave offsets by a
+    // small scan of the per-wave counts in LDS
+    __shared__ int s_wcnt[16];
+    __shared__ int s_base;
+    const unsigned long long mask = __ballot(act);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) s_wcnt[wv] = __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int q = 0; q < nw; ++q) { const int c = s_wcnt[q]; s_wcnt[q] = tot; tot += c; }
+        s_base = tot ? atomicAdd(n_active, tot) : 0;
+    }
+    __syncthreads();
+    const int base = s_base + s_wcnt[wv];
+    if (act) pair_ids[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)i;
+    else if (in) {
+        if (vis) vis[i] = 0.0f;
+        if (rec_cnt) rec_cnt[i] = 0;
+    }
 }
 
 // ---- K8: one wave per surface point, lanes over light directions -----------------------------------
@@ -124,8 +154,11 @@ k_shade_integrate(const float* __restrict__ maps, const float* __restrict__ rays
                   const float* __restrict__ indirect, const float* __restrict__ env,
                   const float* __restrict__ weight_d, int M, int D, int n_lights, int equal_area, int use_srgb,
                   float acc_thres, float* __restrict__ out, const int32_t* __restrict__ rec_off,
-                  const int32_t* __restrict__ rec_cnt, const float* __restrict__ rec_w, const float* __restrict__ rec_rgb) {
+                  const int32_t* __restrict__ rec_cnt, const float* __restrict__ rec_w, const float* __restrict__ rec_rgb,
+                  int32_t* __restrict__ reset_counter) {
     const int lane = threadIdx.x & 63;
+    // the last consumer of a step re-arms the caller's pair counter for the next step (also under HIP-graph replay)
+    if (reset_counter && blockIdx.x == 0 && threadIdx.x == 0) *reset_counter = 0;
     const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (m >= M) return;
     const float* mp = maps + (size_t)m * TIR_MAP_STRIDE;
@@ -245,7 +278,22 @@ extern "C" int tir_shade_setup(const float* maps, const float* rays, const float
     if (!maps || !rays || !dirs || !surf || !active) return TIR_ERR_ARG;
     int64_t n = (int64_t)M * D;
     hipLaunchKernelGGL(k_shade_setup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tir_stream(stream), maps,
-                       rays, dirs, M, D, acc_thres, surf, active);
+                       rays, dirs, M, D, acc_thres, surf, active, (int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr,
+                       (int32_t*)nullptr);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_shade_setup_compact(const float* maps, const float* rays, const float* dirs, int32_t M,
+                                       int32_t D, float acc_thres, float* surf, uint8_t* active, int32_t* pair_ids,
+                                       int32_t* n_active, float* vis, int32_t* ray_rec_cnt, void* stream) {
+    if (M < 0 || D <= 0) return TIR_ERR_ARG;
+    if (M == 0) return TIR_OK;
+    if (!maps || !rays || !dirs || !surf || !active || !pair_ids || !n_active) return TIR_ERR_ARG;
+    int64_t n = (int64_t)M * D;
+    if (n >= ((int64_t)1 << 31)) return TIR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_shade_setup, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, tir_stream(stream), maps,
+                       rays, dirs, M, D, acc_thres, surf, active, pair_ids, n_active, vis, ray_rec_cnt);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
@@ -260,7 +308,8 @@ extern "C" int tir_shade_integrate(const float* maps, const float* rays, const f
     if (!maps || !rays || !dirs || !vis || !env || !out_rgb || (!equal_area && !weight_d)) return TIR_ERR_ARG;
     hipLaunchKernelGGL(k_shade_integrate, dim3((M + 3) / 4), dim3(256), 0, tir_stream(stream), maps, rays, dirs,
                        light_idx, vis, indirect, env, weight_d, M, D, n_lights, equal_area, use_srgb, acc_thres, out_rgb,
-                       (const int32_t*)nullptr, (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
+                       (const int32_t*)nullptr, (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (int32_t*)nullptr);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
@@ -270,14 +319,14 @@ extern "C" int tir_shade_integrate_records(const float* maps, const float* rays,
                                            const int32_t* ray_rec_cnt, const float* rec_w, const float* rec_rgb,
                                            const float* env, const float* weight_d, int32_t M, int32_t D,
                                            int32_t n_lights, int32_t equal_area, int32_t use_srgb, float acc_thres,
-                                           float* out_rgb, void* stream) {
+                                           float* out_rgb, int32_t* reset_counter, void* stream) {
     if (M < 0 || D <= 0 || n_lights <= 0) return TIR_ERR_ARG;
     if (M == 0) return TIR_OK;
     if (!maps || !rays || !dirs || !vis || !env || !out_rgb || (!equal_area && !weight_d)) return TIR_ERR_ARG;
     if (!ray_rec_off || !ray_rec_cnt || !rec_w || !rec_rgb) return TIR_ERR_ARG;
     hipLaunchKernelGGL(k_shade_integrate, dim3((M + 3) / 4), dim3(256), 0, tir_stream(stream), maps, rays, dirs,
                        light_idx, vis, (const float*)nullptr, env, weight_d, M, D, n_lights, equal_area, use_srgb,
-                       acc_thres, out_rgb, ray_rec_off, ray_rec_cnt, rec_w, rec_rgb);
+                       acc_thres, out_rgb, ray_rec_off, ray_rec_cnt, rec_w, rec_rgb, reset_counter);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

@@ -327,7 +327,10 @@ def composite_primary(rays, offsets, rec_w, rgb, brdf, brdf_jit, pred_n, der_n, 
 
 # ---- secondary march ------------------------------------------------------------------------------
 def march_secondary(field: TirField, origins, dirs, z_vals, n_rays, org_map=None, dir_map=None,
-                    active=None, t_stop=0.0, want_records=False, rec_cap=0, want_nerfactor=True, n_dirs=0):
+                    active=None, t_stop=0.0, want_records=False, rec_cap=0, want_nerfactor=True, n_dirs=0,
+                    ray_ids=None, n_ids_dev=None, vis=None, rec_cnt=None):
+    """ray_ids / n_ids_dev: march only the listed pair ids (tir_march_secondary_ids_fwd); vis / rec_cnt: pre-filled
+    per-pair buffers (shade_setup_compact wrote the masked pairs' zeros into them)."""
     origins = f32(origins, "origins", 3)
     dirs = f32(dirs, "dirs", 3)
     z_vals = f32(z_vals, "z_vals").view(-1)
@@ -337,7 +340,8 @@ def march_secondary(field: TirField, origins, dirs, z_vals, n_rays, org_map=None
     dir_map = None if dir_map is None else i32(dir_map, "dir_map")
     if active is not None:
         active = _req(active, torch.uint8, "active")
-    vis = torch.empty((n_rays,), dtype=torch.float32, device=dev)
+    if vis is None:
+        vis = torch.empty((n_rays,), dtype=torch.float32, device=dev)
     oma = torch.empty((n_rays,), dtype=torch.float32, device=dev) if want_nerfactor else None
     rec = None
     if want_records:
@@ -347,15 +351,18 @@ def march_secondary(field: TirField, origins, dirs, z_vals, n_rays, org_map=None
             "w": torch.empty((rec_cap,), dtype=torch.float32, device=dev),
             "xyz": torch.empty((rec_cap, 3), dtype=torch.float32, device=dev),
             "off": torch.empty((n_rays,), dtype=torch.int32, device=dev),
-            "cnt": torch.empty((n_rays,), dtype=torch.int32, device=dev),
+            "cnt": rec_cnt if rec_cnt is not None else torch.empty((n_rays,), dtype=torch.int32, device=dev),
             "cap": rec_cap,
         }
     r = rec or {}
-    _call("tir_march_secondary_fwd", 
-        C.byref(field), _ptr(origins), _ptr(org_map), _ptr(dirs), _ptr(dir_map), _ptr(active),
-        n_rays, int(n_dirs), n_sample, _ptr(z_vals), float(t_stop), _ptr(vis), _ptr(oma),
-        _ptr(r.get("counter")), int(rec_cap), _ptr(r.get("ray")), _ptr(r.get("w")), _ptr(r.get("xyz")),
-        _ptr(r.get("off")), _ptr(r.get("cnt")), _stats_ptr("tir_march_secondary_fwd", dev), _stream())
+    if ray_ids is not None:
+        ray_ids = i32(ray_ids, "ray_ids")
+    _call("tir_march_secondary_fwd" if ray_ids is None else "tir_march_secondary_ids_fwd",
+          C.byref(field), _ptr(origins), _ptr(org_map), _ptr(dirs), _ptr(dir_map), _ptr(active),
+          n_rays, int(n_dirs), n_sample, _ptr(z_vals), float(t_stop), _ptr(vis), _ptr(oma),
+          _ptr(r.get("counter")), int(rec_cap), _ptr(r.get("ray")), _ptr(r.get("w")), _ptr(r.get("xyz")),
+          _ptr(r.get("off")), _ptr(r.get("cnt")), _stats_ptr("tir_march_secondary_fwd", dev),
+          *(() if ray_ids is None else (_ptr(ray_ids), _ptr(n_ids_dev))), _stream())
     return vis, oma, rec
 
 
@@ -390,6 +397,24 @@ def shade_setup(maps, rays, dirs, acc_thres=-1e30):
     return surf, active
 
 
+def shade_setup_compact(maps, rays, dirs, acc_thres, n_active):
+    """shade_setup + compacted active-pair list.  n_active: zeroed int32 device scalar (re-armed by
+    shade_integrate_records).  Returns surf, active, pair_ids [M*D], vis [M*D] and rec_cnt [M*D] (zeros at masked pairs)."""
+    maps = f32(maps, "maps", MAP_STRIDE)
+    rays = f32(rays, "rays", 6)
+    dirs = f32(dirs, "dirs", 3)
+    M, D = maps.shape[0], dirs.shape[0]
+    dev = maps.device
+    surf = torch.empty((M, 3), dtype=torch.float32, device=dev)
+    active = torch.empty((M, D), dtype=torch.uint8, device=dev)
+    pair_ids = torch.empty((M * D,), dtype=torch.int32, device=dev)
+    vis = torch.empty((M * D,), dtype=torch.float32, device=dev)
+    rec_cnt = torch.empty((M * D,), dtype=torch.int32, device=dev)
+    _call("tir_shade_setup_compact", _ptr(maps), _ptr(rays), _ptr(dirs), M, D, float(acc_thres), _ptr(surf), _ptr(active),
+          _ptr(pair_ids), _ptr(n_active), _ptr(vis), _ptr(rec_cnt), _stream())
+    return surf, active, pair_ids, vis, rec_cnt
+
+
 def shade_integrate(maps, rays, dirs, light_idx, vis, indirect, env, weight_d, equal_area=False,
                     use_srgb=True, acc_thres=-1e30):
     maps = f32(maps, "maps", MAP_STRIDE)
@@ -411,7 +436,7 @@ def shade_integrate(maps, rays, dirs, light_idx, vis, indirect, env, weight_d, e
 
 
 def shade_integrate_records(maps, rays, dirs, light_idx, vis, rec_off, rec_cnt, rec_w, rec_rgb, env, weight_d,
-                            equal_area=False, use_srgb=True, acc_thres=-1e30):
+                            equal_area=False, use_srgb=True, acc_thres=-1e30, reset_counter=None):
     """shade_integrate with the per-ray indirect sum fused in (reads the secondary records directly)."""
     maps = f32(maps, "maps", MAP_STRIDE)
     rays = f32(rays, "rays", 6)
@@ -425,7 +450,7 @@ def shade_integrate_records(maps, rays, dirs, light_idx, vis, rec_off, rec_cnt, 
     _call("tir_shade_integrate_records", _ptr(maps), _ptr(rays), _ptr(dirs), _ptr(light_idx), _ptr(f32(vis, "vis")),
           _ptr(i32(rec_off, "rec_off")), _ptr(i32(rec_cnt, "rec_cnt")), _ptr(f32(rec_w, "rec_w")),
           _ptr(f32(rec_rgb, "rec_rgb", 3)), _ptr(env), _ptr(weight_d), M, D, env.shape[0], int(bool(equal_area)),
-          int(bool(use_srgb)), float(acc_thres), _ptr(out), _stream())
+          int(bool(use_srgb)), float(acc_thres), _ptr(out), _ptr(reset_counter), _stream())
     return out
 
 

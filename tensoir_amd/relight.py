@@ -42,7 +42,7 @@ def _rec_capacity(n_rays):
 
 
 def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, light_idx, light_div,
-               want_indirect, want_nerfactor=False, n_dirs=0, keep_records=False):
+               want_indirect, want_nerfactor=False, n_dirs=0, keep_records=False, ids=None):
     """Shared driver of compute_transmittance / compute_radiance / render_with_BRDF:
     march (+ record the w > thres samples) -> appearance gather -> radiance decoder -> per-ray sum.
 
@@ -64,8 +64,10 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
     if first:
         cap = _rec_capacity(n_rays)
     while True:
+        extra = {} if ids is None else dict(ray_ids=ids["pair_ids"], n_ids_dev=ids["n_active"], vis=ids["vis"],
+                                            rec_cnt=ids["rec_cnt"])
         vis, oma, rec = ops.march_secondary(f, origins, dirs, z, n_rays, org_map, dir_map, active,
-                                            tensoIR.march_t_stop, True, cap, want_nerfactor, n_dirs)
+                                            tensoIR.march_t_stop, True, cap, want_nerfactor, n_dirs, **extra)
         n_total, n_dev = rec["counter"][0:1], rec["counter"][1:2]      # all records / the written prefix consumers may read
         if first:                                      # no history yet: learn the count before sizing buffers
             total = int(n_total.item())
@@ -184,10 +186,22 @@ def shade_from_maps(tensoIR, maps, rays, light_idx, sample_method="fixed_envirma
         return (out, None) if return_aux else out
     train = torch.is_grad_enabled() and (maps.requires_grad or tensoIR.lgtSGs.requires_grad)
     fuse = not train and not return_aux
+    ids = None
     with torch.no_grad():      # compute_secondary_shading_effects is @torch.no_grad (models/relight_utils.py:344)
-        surf, active = ops.shade_setup(maps.detach(), rays, dirs, acc_thres)
-        vis, _, ind = _secondary(tensoIR, surf, dirs, M * D, z, None, None, active.view(-1), li, D, True, False, D,
-                                 keep_records=fuse)
+        if fuse:
+            # only the pairs that pass the cosine / acc masks get a secondary ray: compacted id list (the reference's
+            # boolean-mask indexing, :440-441); the pair counter is re-armed by the integration kernel at the end
+            n_active = tensoIR.__dict__.get("_pair_counter")
+            if n_active is None or n_active.device != dev:
+                n_active = tensoIR.__dict__["_pair_counter"] = torch.zeros((1,), dtype=torch.int32, device=dev)
+            surf, active, pair_ids, vis0, cnt0 = ops.shade_setup_compact(maps.detach(), rays, dirs, acc_thres, n_active)
+            ids = {"pair_ids": pair_ids, "n_active": n_active, "vis": vis0, "rec_cnt": cnt0}
+            vis, _, ind = _secondary(tensoIR, surf, dirs, M * D, z, None, None, None, li, D, True, False, D,
+                                     keep_records=True, ids=ids)
+        else:
+            surf, active = ops.shade_setup(maps.detach(), rays, dirs, acc_thres)
+            vis, _, ind = _secondary(tensoIR, surf, dirs, M * D, z, None, None, active.view(-1), li, D, True, False, D,
+                                     keep_records=False)
     env = tensoIR.get_light_rgbs(dirs, device=dev)
     equal_area = sample_method == "stratifed_sample_equal_areas"
     w_d = None if equal_area else area
@@ -197,10 +211,13 @@ def shade_from_maps(tensoIR, maps, rays, light_idx, sample_method="fixed_envirma
                                      use_linear2srgb, acc_thres)
     elif isinstance(ind, dict):
         rgb = ops.shade_integrate_records(maps, rays, dirs, li, vis.view(M, D), ind["off"], ind["cnt"], ind["w"],
-                                          ind["rgb"], env, w_d, equal_area, use_linear2srgb, acc_thres)
+                                          ind["rgb"], env, w_d, equal_area, use_linear2srgb, acc_thres,
+                                          reset_counter=None if ids is None else ids["n_active"])
     else:
         rgb = ops.shade_integrate(maps, rays, dirs, li, vis.view(M, D), ind.view(M, D, 3), env, w_d, equal_area,
                                   use_linear2srgb, acc_thres)
+        if ids is not None:
+            ids["n_active"].zero_()        # no records at all: the fused kernel that re-arms the pair counter did not run
     if return_aux:
         return rgb, {"vis": vis.view(M, D), "indirect": ind.view(M, D, 3), "env": env, "surf": surf,
                      "active": active}
