@@ -186,25 +186,21 @@ def shade_from_maps(tensoIR, maps, rays, light_idx, sample_method="fixed_envirma
         return (out, None) if return_aux else out
     train = torch.is_grad_enabled() and (maps.requires_grad or tensoIR.lgtSGs.requires_grad)
     fuse = not train and not return_aux
-    ids = None
     with torch.no_grad():      # compute_secondary_shading_effects is @torch.no_grad (models/relight_utils.py:344)
-        if fuse:
-            # only the pairs that pass the cosine / acc masks get a secondary ray: compacted id list (the reference's
-            # boolean-mask indexing, :440-441); the pair counter is re-armed by the integration kernel at the end
-            n_active = tensoIR.__dict__.get("_pair_counter")
-            if n_active is None or n_active.device != dev:
-                n_active = tensoIR.__dict__["_pair_counter"] = torch.zeros((1,), dtype=torch.int32, device=dev)
-            surf, active, pair_ids, vis0, cnt0 = ops.shade_setup_compact(maps.detach(), rays, dirs, acc_thres, n_active)
-            ids = {"pair_ids": pair_ids, "n_active": n_active, "vis": vis0, "rec_cnt": cnt0}
-            vis, _, ind = _secondary(tensoIR, surf, dirs, M * D, z, None, None, None, li, D, True, False, D,
-                                     keep_records=True, ids=ids)
-        else:
-            surf, active = ops.shade_setup(maps.detach(), rays, dirs, acc_thres)
-            vis, _, ind = _secondary(tensoIR, surf, dirs, M * D, z, None, None, active.view(-1), li, D, True, False, D,
-                                     keep_records=False)
+        # only the pairs that pass the cosine / acc masks get a secondary ray: compacted id list (the reference's
+        # boolean-mask indexing, :440-441); the pair counter is re-armed by the integration kernel at the end
+        n_active = tensoIR.__dict__.get("_pair_counter")
+        if n_active is None or n_active.device != dev:
+            n_active = tensoIR.__dict__["_pair_counter"] = torch.zeros((1,), dtype=torch.int32, device=dev)
+        surf, active, pair_ids, vis0, cnt0 = ops.shade_setup_compact(maps.detach(), rays, dirs, acc_thres, n_active)
+        ids = {"pair_ids": pair_ids, "n_active": n_active, "vis": vis0, "rec_cnt": cnt0}
+        vis, _, ind = _secondary(tensoIR, surf, dirs, M * D, z, None, None, None, li, D, True, False, D,
+                                 keep_records=fuse, ids=ids)
     env = tensoIR.get_light_rgbs(dirs, device=dev)
     equal_area = sample_method == "stratifed_sample_equal_areas"
     w_d = None if equal_area else area
+    if not isinstance(ind, dict):
+        ids["n_active"].zero_()            # the fused integration kernel (which re-arms the pair counter) is not on this route
     if train:
         from . import training
         rgb = training.ShadeFn.apply(maps, env, rays, dirs, li, vis.view(M, D), ind.view(M, D, 3), w_d, equal_area,
@@ -212,12 +208,10 @@ def shade_from_maps(tensoIR, maps, rays, light_idx, sample_method="fixed_envirma
     elif isinstance(ind, dict):
         rgb = ops.shade_integrate_records(maps, rays, dirs, li, vis.view(M, D), ind["off"], ind["cnt"], ind["w"],
                                           ind["rgb"], env, w_d, equal_area, use_linear2srgb, acc_thres,
-                                          reset_counter=None if ids is None else ids["n_active"])
+                                          reset_counter=ids["n_active"])
     else:
         rgb = ops.shade_integrate(maps, rays, dirs, li, vis.view(M, D), ind.view(M, D, 3), env, w_d, equal_area,
                                   use_linear2srgb, acc_thres)
-        if ids is not None:
-            ids["n_active"].zero_()        # no records at all: the fused kernel that re-arms the pair counter did not run
     if return_aux:
         return rgb, {"vis": vis.view(M, D), "indirect": ind.view(M, D, 3), "env": env, "surf": surf,
                      "active": active}
