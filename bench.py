@@ -79,10 +79,15 @@ def build_scene(a, device, rank):
     return ckpt, model, rays, lidx
 
 
+# entry points that launch the same kernel as another one (same roofline model, same PMC key)
+ALIAS = {"tir_march_secondary_ids_fwd": "tir_march_secondary_fwd", "tir_shade_integrate_records": "tir_shade_integrate"}
+
+
 def kernel_table(timing, stats, steps, shapes):
     """Aggregate (name, e0, e1) event pairs into per-kernel totals and roofline figures."""
     agg = {}
     for name, e0, e1 in timing:
+        name = ALIAS.get(name, name)
         ms = e0.elapsed_time(e1)
         k = agg.setdefault(name, {"ms": 0.0, "launches": 0})
         k["ms"] += ms

@@ -12,12 +12,17 @@ namespace {
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 
 // ------------------------------------------------------------------------------------------------
-// Scatter of one VM group (plane i + line i) for one 4-channel chunk `c` of every tap.
+// Scatter of one VM group (plane i + line i) for ONE channel `c` of every tap.
 // Value model:  feat = sum_ch P L,   du = sum_ch Pu L,  dv = sum_ch Pv L,  dw = sum_ch P Lw
 // with P the bilinear plane value, Pu/Pv its derivatives per texel, L the linear line value, Lw = l1 - l0.
 // Cotangents: F (feat) and -- NORMAL only -- Gu, Gv, Gw (of du, dv, dw; texel-scale factors already applied).
 // NORMAL == false uses grid_sample's zero-padding weights (compute_densityfeature, F.grid_sample);
 // NORMAL == true uses clamped indices + unclamped weights (models/relight_utils.py:82-92).
+//
+// Lane layout: min(CH, 16) ADJACENT lanes share a sample and own consecutive channels, so one wave atomic instruction
+// lands 16 consecutive dwords in each 64-B segment it touches.  The L2 atomic rate on gfx950 is per 64-B segment per
+// instruction (~20 G segments/s chip-wide, tools/atomic_bench.hip) whether 1 or 16 of its dwords are written: this
+// layout moves 4x the gradient per segment of the float4-per-lane layout the forward gathers use.
 // ------------------------------------------------------------------------------------------------
 template <int CH, bool NORMAL, bool LL>
 __device__ __forceinline__ void scatter_group(const float* __restrict__ plane, const float* __restrict__ line,
@@ -29,51 +34,49 @@ __device__ __forceinline__ void scatter_group(const float* __restrict__ plane, c
     if (NORMAL) { wx0 = 1.0f - tx.t; wx1 = tx.t; wy0 = 1.0f - ty.t; wy1 = ty.t; wl0 = 1.0f - tl.t; wl1 = tl.t; }
     else { wx0 = tx.w0; wx1 = tx.w1; wy0 = ty.w0; wy1 = ty.w1; wl0 = tl.w0; wl1 = tl.w1; }
     const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
-    const size_t o00 = ((size_t)ty.i0 * W + tx.i0) * CH + 4 * c, o01 = ((size_t)ty.i0 * W + tx.i1) * CH + 4 * c;
-    const size_t o10 = ((size_t)ty.i1 * W + tx.i0) * CH + 4 * c, o11 = ((size_t)ty.i1 * W + tx.i1) * CH + 4 * c;
-    const size_t q0 = (size_t)tl.i0 * CH + 4 * c, q1 = (size_t)tl.i1 * CH + 4 * c;
-    const float4 a4 = ld4(plane + o00), b4 = ld4(plane + o01), c4 = ld4(plane + o10), d4 = ld4(plane + o11);
-    const float4 e4 = ld4(line + q0), g4 = ld4(line + q1);
+    const int r0 = (ty.i0 * W + tx.i0) * CH, r1 = (ty.i0 * W + tx.i1) * CH;      // < 2^31 floats (check_grad_field)
+    const int r2 = (ty.i1 * W + tx.i0) * CH, r3 = (ty.i1 * W + tx.i1) * CH;
+    const int q0 = tl.i0 * CH, q1 = tl.i1 * CH;
     // per-tap cotangent coefficients (Pu = (b-a) wy0 + (d-c) wy1,  Pv = (c-a) wx0 + (d-b) wx1)
     float a00 = F * w00, a01 = F * w01, a10 = F * w10, a11 = F * w11;
     if (NORMAL) {
         a00 += -Gu * wy0 - Gv * wx0; a01 += Gu * wy0 - Gv * wx1;
         a10 += -Gu * wy1 + Gv * wx0; a11 += Gu * wy1 + Gv * wx1;
     }
-    const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
-    const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
-    const float ev[4] = {e4.x, e4.y, e4.z, e4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+    constexpr int LPS = CH < 16 ? CH : 16;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float L = fmaf(gv[q], wl1, ev[q] * wl0);
-        const float P = fmaf(dv[q], w11, fmaf(cv[q], w10, fmaf(bv[q], w01, av[q] * w00)));
+    for (int ch = c; ch < CH; ch += LPS) {
+        const float av = plane[r0 + ch], bv = plane[r1 + ch], cv = plane[r2 + ch], dv = plane[r3 + ch];
+        const float ev = line[q0 + ch], gv = line[q1 + ch];
+        const float L = fmaf(gv, wl1, ev * wl0);
+        const float P = fmaf(dv, w11, fmaf(cv, w10, fmaf(bv, w01, av * w00)));
         float t00 = L * a00, t01 = L * a01, t10 = L * a10, t11 = L * a11;
         float S = F * P;
         if (NORMAL) {
-            const float Lw = gv[q] - ev[q];
+            const float Lw = gv - ev;
             t00 = fmaf(Lw, Gw * w00, t00); t01 = fmaf(Lw, Gw * w01, t01);
             t10 = fmaf(Lw, Gw * w10, t10); t11 = fmaf(Lw, Gw * w11, t11);
-            const float Pu = fmaf(dv[q] - cv[q], wy1, (bv[q] - av[q]) * wy0);
-            const float Pv = fmaf(dv[q] - bv[q], wx1, (cv[q] - av[q]) * wx0);
+            const float Pu = fmaf(dv - cv, wy1, (bv - av) * wy0);
+            const float Pv = fmaf(dv - bv, wx1, (cv - av) * wx0);
             S = fmaf(Gv, Pv, fmaf(Gu, Pu, S));
         }
-        if (t00 != 0.0f) atomic_add_f32(gplane + o00 + q, t00);
-        if (t01 != 0.0f) atomic_add_f32(gplane + o01 + q, t01);
-        if (t10 != 0.0f) atomic_add_f32(gplane + o10 + q, t10);
-        if (t11 != 0.0f) atomic_add_f32(gplane + o11 + q, t11);
+        if (t00 != 0.0f) atomic_add_f32(gplane + r0 + ch, t00);
+        if (t01 != 0.0f) atomic_add_f32(gplane + r1 + ch, t01);
+        if (t10 != 0.0f) atomic_add_f32(gplane + r2 + ch, t10);
+        if (t11 != 0.0f) atomic_add_f32(gplane + r3 + ch, t11);
         float s0 = S * wl0, s1 = S * wl1;
         if (NORMAL) { s0 = fmaf(-Gw, P, s0); s1 = fmaf(Gw, P, s1); }
         if (LL) {                 // gline is a block-local LDS copy of the (small, heavily shared) line gradient
-            if (s0 != 0.0f) atomicAdd(gline + q0 + q, s0);
-            if (s1 != 0.0f) atomicAdd(gline + q1 + q, s1);
+            if (s0 != 0.0f) atomicAdd(gline + q0 + ch, s0);
+            if (s1 != 0.0f) atomicAdd(gline + q1 + ch, s1);
         } else {
-            if (s0 != 0.0f) atomic_add_f32(gline + q0 + q, s0);
-            if (s1 != 0.0f) atomic_add_f32(gline + q1 + q, s1);
+            if (s0 != 0.0f) atomic_add_f32(gline + q0 + ch, s0);
+            if (s1 != 0.0f) atomic_add_f32(gline + q1 + ch, s1);
         }
     }
 }
 
-// the three VM groups of the density field for one sample chunk
+// the three VM groups of the density field for one sample; c = this lane's first channel (lane % min(CH, 16))
 template <int C4, bool NORMAL, bool LL>
 __device__ __forceinline__ void scatter_density(const TirField& f, const TirFieldGrad& g, float* lds_lines, float x, float y, float z,
                                                 int c, float F, float G0, float G1, float G2) {
@@ -191,15 +194,15 @@ k_march_primary_bwd(TirField f, TirFieldGrad g, const float* __restrict__ rays, 
             y = norm_coord(add_rn(rs.o[1], mul_rn(rs.d[1], z)), f.aabb_min[1], f.inv_aabb[1]);
             zz = norm_coord(add_rn(rs.o[2], mul_rn(rs.d[2], z)), f.aabb_min[2], f.inv_aabb[2]);
         }
-        // wave-collective scatter: compact the active samples, C4 lanes per sample, 16 B of every tap per lane
+        // wave-collective scatter: compact the active samples, min(CH, 16) lanes per sample, one channel per lane
         const unsigned long long m = __ballot(on);
         const int n = __popcll(m);
         if (n == 0) continue;
         const int rank = __popcll(m & ((1ull << lane) - 1ull));
         if (on) { wl[rank * 4] = x; wl[rank * 4 + 1] = y; wl[rank * 4 + 2] = zz; wl[rank * 4 + 3] = df; }
         __builtin_amdgcn_wave_barrier();
-        constexpr int PER = 64 / C4;
-        const int slot_in = lane / C4, c = lane % C4;
+        constexpr int LPS = C4 * 4 < 16 ? C4 * 4 : 16, PER = 64 / LPS;
+        const int slot_in = lane / LPS, c = lane % LPS;
         for (int base = 0; base < n; base += PER) {
             const int slot = base + slot_in;
             if (slot < n) {
@@ -215,21 +218,22 @@ k_march_primary_bwd(TirField f, TirFieldGrad g, const float* __restrict__ rays, 
 
 // ------------------------------------------------------------------------------------------------
 // Backward of the derived normal n = -g / max(|g|, 1e-6), g = softplus'(feat + shift) * grad feat
-// C4 adjacent lanes per sample.
+// min(CH, 16) adjacent lanes per sample, one channel per lane (the scatter layout, see scatter_group).
 // ------------------------------------------------------------------------------------------------
 template <int C4, bool LL>
 __global__ void __launch_bounds__(256)
 k_density_grad_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, const float* __restrict__ g_normal, int64_t n) {
     extern __shared__ __attribute__((aligned(16))) float lds_lines[];
     if (LL) { lines_zero<C4 * 4>(f, lds_lines); __syncthreads(); }
-  const int64_t n_lanes = (n * C4 + 255) / 256 * 256;          // whole blocks: the shuffles below need full lane groups
+    constexpr int CH = C4 * 4, LPS = CH < 16 ? CH : 16;
+  const int64_t n_lanes = (n * LPS + 255) / 256 * 256;         // whole blocks: the shuffles below need full lane groups
   for (int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tid < n_lanes; tid += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = tid / C4;
-    const int c = (int)(tid % C4);
+    const int64_t i = tid / LPS;
+    const int c = (int)(tid % LPS);
     const bool on = i < n;
     const int64_t ic = on ? i : n - 1;
     const float p[3] = {xyz[3 * ic], xyz[3 * ic + 1], xyz[3 * ic + 2]};
-    // forward recompute: this lane's partial sums over its 4 channels
+    // forward recompute: this lane's partial sums over its channel(s)
     float feat = 0.f, gr[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -237,22 +241,22 @@ k_density_grad_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, co
         const int H = f.grid[m1], W = f.grid[m0], R = f.grid[vi];
         Tap1 tx = make_tap(p[m0], W), ty = make_tap(p[m1], H), tl = make_tap(p[vi], R);
         const float wx0 = 1.0f - tx.t, wx1 = tx.t, wy0 = 1.0f - ty.t, wy1 = ty.t;
-        const float* pl = f.dplane[k] + 4 * c;
-        const float4 a4 = ld4(pl + ((size_t)ty.i0 * W + tx.i0) * (C4 * 4)), b4 = ld4(pl + ((size_t)ty.i0 * W + tx.i1) * (C4 * 4));
-        const float4 c4 = ld4(pl + ((size_t)ty.i1 * W + tx.i0) * (C4 * 4)), d4 = ld4(pl + ((size_t)ty.i1 * W + tx.i1) * (C4 * 4));
-        const float4 e4 = ld4(f.dline[k] + (size_t)tl.i0 * (C4 * 4) + 4 * c), g4 = ld4(f.dline[k] + (size_t)tl.i1 * (C4 * 4) + 4 * c);
-        const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
-        const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
-        const float ev[4] = {e4.x, e4.y, e4.z, e4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+        const float* pl = f.dplane[k];
+        const float* ln = f.dline[k];
+        const int r0 = (ty.i0 * W + tx.i0) * CH, r1 = (ty.i0 * W + tx.i1) * CH;
+        const int r2 = (ty.i1 * W + tx.i0) * CH, r3 = (ty.i1 * W + tx.i1) * CH;
+        const int q0 = tl.i0 * CH, q1 = tl.i1 * CH;
         float s_val = 0.f, s_du = 0.f, s_dv = 0.f, s_dw = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float P = fmaf(dv[q], wx1 * wy1, fmaf(cv[q], wx0 * wy1, fmaf(bv[q], wx1 * wy0, av[q] * (wx0 * wy0))));
-            const float Pu = fmaf(dv[q] - cv[q], wy1, (bv[q] - av[q]) * wy0);
-            const float Pv = fmaf(dv[q] - bv[q], wx1, (cv[q] - av[q]) * wx0);
-            const float L = fmaf(gv[q], tl.t, ev[q] * (1.0f - tl.t));
+        for (int ch = c; ch < CH; ch += LPS) {
+            const float av = pl[r0 + ch], bv = pl[r1 + ch], cv = pl[r2 + ch], dv = pl[r3 + ch];
+            const float ev = ln[q0 + ch], gv = ln[q1 + ch];
+            const float P = fmaf(dv, wx1 * wy1, fmaf(cv, wx0 * wy1, fmaf(bv, wx1 * wy0, av * (wx0 * wy0))));
+            const float Pu = fmaf(dv - cv, wy1, (bv - av) * wy0);
+            const float Pv = fmaf(dv - bv, wx1, (cv - av) * wx0);
+            const float L = fmaf(gv, tl.t, ev * (1.0f - tl.t));
             s_val = fmaf(P, L, s_val); s_du = fmaf(Pu, L, s_du); s_dv = fmaf(Pv, L, s_dv);
-            s_dw = fmaf(P, gv[q] - ev[q], s_dw);
+            s_dw = fmaf(P, gv - ev, s_dw);
         }
         feat += s_val;
         gr[m0] += s_du * (0.5f * (float)(W - 1));
@@ -260,7 +264,7 @@ k_density_grad_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, co
         gr[vi] += s_dw * (0.5f * (float)(R - 1));
     }
 #pragma unroll
-    for (int d = 1; d < C4; d <<= 1) {
+    for (int d = 1; d < LPS; d <<= 1) {
         feat += __shfl_xor(feat, d, 64);
         gr[0] += __shfl_xor(gr[0], d, 64); gr[1] += __shfl_xor(gr[1], d, 64); gr[2] += __shfl_xor(gr[2], d, 64);
     }
@@ -440,40 +444,53 @@ k_composite_primary_bwd(const float* __restrict__ rays, const int32_t* __restric
 
 // ------------------------------------------------------------------------------------------------
 // Backward of the appearance feature (compute_bothfeature / compute_appfeature / compute_intrinfeature):
-// 4 adjacent lanes per sample, each lane owning 16 B of every 64 B run of a tap (as the forward gather).
+// 16 adjacent lanes per sample, lane c owning channels c, c+16, ... of every tap (the scatter layout of scatter_group:
+// every plane atomic instruction lands 16 consecutive dwords per 64-B segment).  The per-channel cotangent
+// d(plane (.) line (.) light)[ch] = basis_mat[:, ch] . g_feat reads basis_mat^T rows from LDS as float4s (row stride 36
+// floats: the 16 rows a wave reads at once start in distinct bank quads).
 // ------------------------------------------------------------------------------------------------
 #define TIR_APP_MAX_L 16
+#define TIR_APP_WS 36
+
+// one block per CU (the LDS line gradient is ~58 KB at a 300^3 grid): 12 or 16 waves, as the registers allow
+template <bool RAD, bool INTR> struct AppBwdThreads { static constexpr int value = (RAD && INTR) ? 768 : 1024; };
 
 template <int C4, bool RAD, bool INTR>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__((AppBwdThreads<RAD, INTR>::value))
 k_vm_app_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
              const int32_t* __restrict__ idx_map, const float* __restrict__ g_rad, const float* __restrict__ g_int,
              int stride, int64_t n, float* __restrict__ y_rad, float* __restrict__ y_int, int line_lds) {
-    constexpr int CA = C4 * 4;
+    constexpr int CA = C4 * 4, WS = TIR_APP_WS;
     extern __shared__ __attribute__((aligned(16))) float lds_ab[];
-    float* Wt = lds_ab;                              // [3*CA][32] basis_mat^T
-    float* gl = lds_ab + 3 * CA * 32;                // [(n_lights + 1)][3*CA] block-local light_line / light_mean gradient
+    float* Wt = lds_ab;                              // [3*CA][WS] basis_mat^T, columns >= app_dim zero
+    float* gl = lds_ab + 3 * CA * WS;                // [(n_lights + 1)][3*CA] block-local light_line / light_mean gradient
     const int nl = min(f.n_lights, TIR_APP_MAX_L);
     // block-local gradient of ONE appearance line ([R][CA], the current VM group's): the line has only R rows, so
     // every sample of the batch lands on a few hundred addresses -- in L2 those atomics serialise; in LDS they are cheap
     float* lg = gl + (nl + 1) * 3 * CA;
-    for (int i = threadIdx.x * 4; i < 3 * CA * 32; i += 256 * 4)
-        *reinterpret_cast<float4*>(Wt + i) = *reinterpret_cast<const float4*>(f.basis_t + i);
-    for (int i = threadIdx.x; i < (nl + 1) * 3 * CA; i += 256) gl[i] = 0.0f;
+    const int nthr = blockDim.x, nwave = nthr >> 6;
+    for (int i = threadIdx.x; i < 3 * CA * 32; i += nthr) {
+        const int t = i & 31;
+        if (t < 28) Wt[(i >> 5) * WS + t] = (t < f.app_dim) ? f.basis_t[i] : 0.0f;
+    }
+    for (int i = threadIdx.x; i < (nl + 1) * 3 * CA; i += nthr) gl[i] = 0.0f;
     const int L = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = L >> 2, c = L & 3;
-    const int64_t n_pass = (n + 15) / 16;
+    const int j = L >> 4, c = L & 15;
+    const int64_t n_pass = (n + 3) / 4;
+    const bool vec_g = (stride & 3) == 0 && ((RAD ? (reinterpret_cast<uintptr_t>(g_rad) & 15) : 0) == 0) &&
+                       ((INTR ? (reinterpret_cast<uintptr_t>(g_int) & 15) : 0) == 0);
 #pragma unroll 1
     for (int k = 0; k < 3; ++k) {                  // one VM group at a time over ALL of the block's samples
         const int m0 = (k == 2) ? 1 : 0, m1 = (k == 0) ? 1 : 2, vi = 2 - k;
         const int H = f.grid[m1], W = f.grid[m0], R = f.grid[vi];
         if (line_lds)
-            for (int i = threadIdx.x; i < R * CA; i += 256) lg[i] = 0.0f;
+            for (int i = threadIdx.x; i < R * CA; i += nthr) lg[i] = 0.0f;
         __syncthreads();
         const float* pl = f.aplane[k];
         const float* ln = f.aline[k];
-        for (int64_t pass = (int64_t)blockIdx.x * 4 + wave; pass < n_pass; pass += (int64_t)gridDim.x * 4) {
-            const int64_t s = pass * 16 + j;
+        float* gp = g.aplane[k];
+        for (int64_t pass = (int64_t)blockIdx.x * nwave + wave; pass < n_pass; pass += (int64_t)gridDim.x * nwave) {
+            const int64_t s = pass * 4 + j;
             const bool on = s < n;
             const int64_t sc = on ? s : n - 1;
             const float p[3] = {xyz[3 * sc], xyz[3 * sc + 1], xyz[3 * sc + 2]};
@@ -482,82 +499,85 @@ k_vm_app_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, const in
                 const int64_t lsel = idx_map ? (int64_t)idx_map[sc] : sc;
                 li = min(max(light_idx[lsel], 0), f.n_lights - 1);
             }
-            float gr[27], gi[27];
+            float gr[28], gi[28];
+            if (vec_g) {
 #pragma unroll
-            for (int q = 0; q < 27; ++q) {
-                gr[q] = (RAD && on && q < f.app_dim) ? g_rad[sc * stride + q] : 0.f;
-                gi[q] = (INTR && on && q < f.app_dim) ? g_int[sc * stride + q] : 0.f;
+                for (int q = 0; q < 7; ++q) {
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+                    if (RAD && on && 4 * q < stride) a = ld4(g_rad + sc * stride + 4 * q);
+                    if (INTR && on && 4 * q < stride) b = ld4(g_int + sc * stride + 4 * q);
+                    gr[4 * q] = a.x; gr[4 * q + 1] = a.y; gr[4 * q + 2] = a.z; gr[4 * q + 3] = a.w;
+                    gi[4 * q] = b.x; gi[4 * q + 1] = b.y; gi[4 * q + 2] = b.z; gi[4 * q + 3] = b.w;
+                }
+#pragma unroll
+                for (int q = 0; q < 28; ++q)            // row padding may hold anything (0 x NaN): mask it
+                    if (q >= f.app_dim) { gr[q] = 0.f; gi[q] = 0.f; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 28; ++q) {
+                    gr[q] = (RAD && on && q < f.app_dim) ? g_rad[sc * stride + q] : 0.f;
+                    gi[q] = (INTR && on && q < f.app_dim) ? g_int[sc * stride + q] : 0.f;
+                }
             }
             Tap1 tx = make_tap(p[m0], W), ty = make_tap(p[m1], H), tl = make_tap(p[vi], R);
             const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
-            const size_t o00 = ((size_t)ty.i0 * W + tx.i0) * CA, o01 = ((size_t)ty.i0 * W + tx.i1) * CA;
-            const size_t o10 = ((size_t)ty.i1 * W + tx.i0) * CA, o11 = ((size_t)ty.i1 * W + tx.i1) * CA;
-            const size_t q0 = (size_t)tl.i0 * CA, q1 = (size_t)tl.i1 * CA;
+            const int o00 = (ty.i0 * W + tx.i0) * CA, o01 = (ty.i0 * W + tx.i1) * CA;     // < 2^31 (check_grad_field)
+            const int o10 = (ty.i1 * W + tx.i0) * CA, o11 = (ty.i1 * W + tx.i1) * CA;
+            const int q0 = tl.i0 * CA, q1 = tl.i1 * CA;
 #pragma unroll 1
-            for (int q = 0; q < (C4 + 3) / 4; ++q) {
-                const int ch4 = 4 * q + c;
-                if (ch4 >= C4) continue;
-                const int ch = k * CA + 4 * ch4;               // first of this lane's 4 channels
-                const float4 a4 = ld4(pl + o00 + 4 * ch4), b4 = ld4(pl + o01 + 4 * ch4), c4 = ld4(pl + o10 + 4 * ch4), d4 = ld4(pl + o11 + 4 * ch4);
-                const float4 e4 = ld4(ln + q0 + 4 * ch4), g4 = ld4(ln + q1 + 4 * ch4);
-                const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
-                const float cv[4] = {c4.x, c4.y, c4.z, c4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
-                const float ev[4] = {e4.x, e4.y, e4.z, e4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
-                float lrv[4] = {0, 0, 0, 0}, lmv[4] = {0, 0, 0, 0};
-                if (RAD) { const float4 t = ld4(f.light_line + (size_t)li * (3 * CA) + ch); lrv[0] = t.x; lrv[1] = t.y; lrv[2] = t.z; lrv[3] = t.w; }
-                if (INTR) { const float4 t = ld4(f.light_mean + ch); lmv[0] = t.x; lmv[1] = t.y; lmv[2] = t.z; lmv[3] = t.w; }
-                float yr[4], yi[4];
+            for (int cq = 0; cq < (CA + 15) / 16; ++cq) {
+                const int cha = 16 * cq + c;               // channel inside the group
+                if (cha >= CA) continue;
+                const int ch = k * CA + cha;               // channel of the 3*CA feature
+                const float av = pl[o00 + cha], bv = pl[o01 + cha], cv = pl[o10 + cha], dv = pl[o11 + cha];
+                const float ev = ln[q0 + cha], gv = ln[q1 + cha];
+                const float lrv = RAD ? f.light_line[li * (3 * CA) + ch] : 0.f;
+                const float lmv = INTR ? f.light_mean[ch] : 0.f;
+                // d (pl (.) light)[ch] = basis_mat[:, ch] . g_feat
+                const float4* wr = reinterpret_cast<const float4*>(Wt + ch * WS);
+                float dyr = 0.f, dyi = 0.f;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    // d (pl (.) light)[ch+u] = basis_mat[:, ch+u] . g_feat
-                    const float* wr = Wt + (size_t)(ch + u) * 32;
-                    float dyr = 0.f, dyi = 0.f;
-#pragma unroll
-                    for (int t = 0; t < 27; ++t) {
-                        const float bw = wr[t];
-                        if (RAD) dyr = fmaf(bw, gr[t], dyr);
-                        if (INTR) dyi = fmaf(bw, gi[t], dyi);
-                    }
-                    const float P = fmaf(dv[u], w11, fmaf(cv[u], w10, fmaf(bv[u], w01, av[u] * w00)));
-                    const float Ln = fmaf(gv[u], tl.w1, ev[u] * tl.w0);
-                    const float plv = P * Ln;
-                    yr[u] = plv * lrv[u]; yi[u] = plv * lmv[u];
-                    if (!on) continue;
-                    if (RAD && dyr != 0.f) {
-                        if (f.n_lights <= TIR_APP_MAX_L) atomicAdd(gl + li * (3 * CA) + ch + u, dyr * plv);
-                        else atomic_add_f32(g.light_line + (size_t)li * (3 * CA) + ch + u, dyr * plv);
-                    }
-                    if (INTR && dyi != 0.f) atomicAdd(gl + nl * (3 * CA) + ch + u, dyi * plv);
-                    const float dpl = dyr * lrv[u] + dyi * lmv[u];
-                    if (dpl == 0.f) continue;
-                    const float dP = dpl * Ln, dL = dpl * P;
-                    if (w00 != 0.f) atomic_add_f32(g.aplane[k] + o00 + 4 * ch4 + u, dP * w00);
-                    if (w01 != 0.f) atomic_add_f32(g.aplane[k] + o01 + 4 * ch4 + u, dP * w01);
-                    if (w10 != 0.f) atomic_add_f32(g.aplane[k] + o10 + 4 * ch4 + u, dP * w10);
-                    if (w11 != 0.f) atomic_add_f32(g.aplane[k] + o11 + 4 * ch4 + u, dP * w11);
-                    if (line_lds) {
-                        if (tl.w0 != 0.f) atomicAdd(lg + q0 + 4 * ch4 + u, dL * tl.w0);
-                        if (tl.w1 != 0.f) atomicAdd(lg + q1 + 4 * ch4 + u, dL * tl.w1);
-                    } else {
-                        if (tl.w0 != 0.f) atomic_add_f32(g.aline[k] + q0 + 4 * ch4 + u, dL * tl.w0);
-                        if (tl.w1 != 0.f) atomic_add_f32(g.aline[k] + q1 + 4 * ch4 + u, dL * tl.w1);
-                    }
+                for (int t = 0; t < 7; ++t) {
+                    const float4 bw = wr[t];
+                    if (RAD) dyr = fmaf(bw.w, gr[4 * t + 3], fmaf(bw.z, gr[4 * t + 2], fmaf(bw.y, gr[4 * t + 1], fmaf(bw.x, gr[4 * t], dyr))));
+                    if (INTR) dyi = fmaf(bw.w, gi[4 * t + 3], fmaf(bw.z, gi[4 * t + 2], fmaf(bw.y, gi[4 * t + 1], fmaf(bw.x, gi[4 * t], dyi))));
                 }
-                if (on) {
-                    if (RAD && y_rad) *reinterpret_cast<float4*>(y_rad + s * (3 * CA) + ch) = make_float4(yr[0], yr[1], yr[2], yr[3]);
-                    if (INTR && y_int) *reinterpret_cast<float4*>(y_int + s * (3 * CA) + ch) = make_float4(yi[0], yi[1], yi[2], yi[3]);
+                const float P = fmaf(dv, w11, fmaf(cv, w10, fmaf(bv, w01, av * w00)));
+                const float Ln = fmaf(gv, tl.w1, ev * tl.w0);
+                const float plv = P * Ln;
+                if (!on) continue;
+                if (RAD && y_rad) y_rad[s * (3 * CA) + ch] = plv * lrv;
+                if (INTR && y_int) y_int[s * (3 * CA) + ch] = plv * lmv;
+                if (RAD && dyr != 0.f) {
+                    if (f.n_lights <= TIR_APP_MAX_L) atomicAdd(gl + li * (3 * CA) + ch, dyr * plv);
+                    else atomic_add_f32(g.light_line + (size_t)li * (3 * CA) + ch, dyr * plv);
+                }
+                if (INTR && dyi != 0.f) atomicAdd(gl + nl * (3 * CA) + ch, dyi * plv);
+                const float dpl = dyr * lrv + dyi * lmv;
+                if (dpl == 0.f) continue;
+                const float dP = dpl * Ln, dL = dpl * P;
+                if (w00 != 0.f) atomic_add_f32(gp + o00 + cha, dP * w00);
+                if (w01 != 0.f) atomic_add_f32(gp + o01 + cha, dP * w01);
+                if (w10 != 0.f) atomic_add_f32(gp + o10 + cha, dP * w10);
+                if (w11 != 0.f) atomic_add_f32(gp + o11 + cha, dP * w11);
+                if (line_lds) {
+                    if (tl.w0 != 0.f) atomicAdd(lg + q0 + cha, dL * tl.w0);
+                    if (tl.w1 != 0.f) atomicAdd(lg + q1 + cha, dL * tl.w1);
+                } else {
+                    if (tl.w0 != 0.f) atomic_add_f32(g.aline[k] + q0 + cha, dL * tl.w0);
+                    if (tl.w1 != 0.f) atomic_add_f32(g.aline[k] + q1 + cha, dL * tl.w1);
                 }
             }
         }
         __syncthreads();
         if (line_lds)
-            for (int i = threadIdx.x; i < R * CA; i += 256) {
+            for (int i = threadIdx.x; i < R * CA; i += nthr) {
                 const float v = lg[i];
                 if (v != 0.f) atomic_add_f32(g.aline[k] + i, v);
             }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < (nl + 1) * 3 * CA; i += 256) {
+    for (int i = threadIdx.x; i < (nl + 1) * 3 * CA; i += nthr) {
         const float v = gl[i];
         if (v == 0.f) continue;
         if (i < nl * 3 * CA) { if (RAD && f.n_lights <= TIR_APP_MAX_L) atomic_add_f32(g.light_line + i, v); }
@@ -567,11 +587,14 @@ k_vm_app_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, const in
 
 // ------------------------------------------------------------------------------------------------
 // C[M][ldc] += A^T B  (A [n][lda], B [n][ldb]), fp32 MFMA 32x32x2, split over n, atomics into C.
-// 4 waves; wave w owns rows 32w..32w+31 of C and all (<= 5) column tiles.
+// 4 waves; the (<= 4 x 5) 32x32 tiles of C are dealt round-robin to the waves (tile t = w + 4i, row tile t % MT:
+// with M = 128 a wave keeps one row tile; with M <= 32 the column tiles spread over all four waves).  The next
+// 32-row slab of A and B is fetched into registers while the current one is multiplied out of LDS.
 // ------------------------------------------------------------------------------------------------
 #define GT_AS 160      // LDS row strides == 32 mod 64 banks: the two k rows of an MFMA step hit disjoint banks
 #define GT_BS 224
 
+template <int TPW>                    // 32x32 tiles per wave: 4 * TPW >= MT * NT
 __global__ void __launch_bounds__(256)
 k_gemm_tn(const float* __restrict__ A, int lda, int M, const float* __restrict__ Bm, int ldb, int N, int ones_col,
           int64_t n, float* __restrict__ C, int ldc, int64_t chunk) {
@@ -579,55 +602,93 @@ k_gemm_tn(const float* __restrict__ A, int lda, int M, const float* __restrict__
     __shared__ __attribute__((aligned(16))) float Bs[32 * GT_BS];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int li = lane & 31, h = lane >> 5;
-    const int NT = (N + ones_col + 31) / 32;
+    const int MT = (M + 31) / 32, NT = (N + ones_col + 31) / 32, T = MT * NT;
     const int64_t s0 = (int64_t)blockIdx.x * chunk;
     const int64_t s1 = min(n, s0 + chunk);
-    f32x16 acc[5];
+    int ta[TPW], tb[TPW];                 // LDS column offsets of this wave's tiles (slots past T redo tile 0, unused)
 #pragma unroll
-    for (int t = 0; t < 5; ++t)
+    for (int i = 0; i < TPW; ++i) {
+        const int t = (w + 4 * i < T) ? w + 4 * i : 0;
+        ta[i] = 32 * (t % MT) + li; tb[i] = 32 * (t / MT) + li;
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const int Mp = (M + 3) & ~3, Np = (N + 3) & ~3;
+    const int Np = (N + 3) & ~3;
+    const int a4 = (M + 3) >> 2, b4 = (N + ones_col + 3) >> 2;     // float4 granules per slab row actually needed
+    // slab-invariant part of this thread's granules: row / column, global offsets, LDS offsets (-1: none)
+    int a_lds[4], b_lds[5], a_row[4], b_row[5], b_col[5];
+    int64_t a_off[4], b_off[5];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = threadIdx.x + 256 * q, row = e / a4, c4 = (e % a4) * 4;
+        a_row[q] = row; a_lds[q] = row < 32 ? row * GT_AS + c4 : -1; a_off[q] = (int64_t)row * lda + c4;
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int e = threadIdx.x + 256 * q, row = e / b4, c4 = (e % b4) * 4;
+        b_row[q] = row; b_col[q] = c4; b_lds[q] = row < 32 ? row * GT_BS + c4 : -1; b_off[q] = (int64_t)row * ldb + c4;
+    }
+    float4 ra[4], rb[5];
+    auto fetch = [&](int64_t s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_lds[q] >= 0 && s + a_row[q] < s1) ra[q] = *reinterpret_cast<const float4*>(A + s * lda + a_off[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            rb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b_lds[q] >= 0 && s + b_row[q] < s1 && b_col[q] < Np) rb[q] = *reinterpret_cast<const float4*>(Bm + s * ldb + b_off[q]);
+        }
+    };
+    auto stage = [&](int64_t s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (a_lds[q] >= 0) *reinterpret_cast<float4*>(As + a_lds[q]) = ra[q];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            if (b_lds[q] < 0) continue;
+            float4 v = rb[q];
+            const int d = N - b_col[q];             // columns >= N of the granule: padding -> 0, the ones column -> 1
+            const float one = (ones_col && s + b_row[q] < s1) ? 1.0f : 0.0f;
+            if (d <= 0) v.x = (d == 0) ? one : 0.f;
+            if (d <= 1) v.y = (d == 1) ? one : 0.f;
+            if (d <= 2) v.z = (d == 2) ? one : 0.f;
+            if (d <= 3) v.w = (d == 3) ? one : 0.f;
+            *reinterpret_cast<float4*>(Bs + b_lds[q]) = v;
+        }
+    };
+    // columns of the LDS tiles beyond a4 / b4 granules are read by the MFMAs of partial tiles: zero them once
+    for (int e = threadIdx.x; e < 32 * (GT_AS / 4); e += 256) *reinterpret_cast<float4*>(As + 4 * e) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = threadIdx.x; e < 32 * (GT_BS / 4); e += 256) *reinterpret_cast<float4*>(Bs + 4 * e) = make_float4(0.f, 0.f, 0.f, 0.f);
+    fetch(s0);
+    __syncthreads();
     for (int64_t s = s0; s < s1; s += 32) {
-        for (int e = threadIdx.x; e < 32 * 32; e += 256) {          // A slab: 32 rows x 128 cols (float4 granules)
-            const int row = e >> 5, c4 = (e & 31) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s + row < s1 && c4 < Mp) v = *reinterpret_cast<const float4*>(A + (s + row) * lda + c4);
-            *reinterpret_cast<float4*>(As + row * GT_AS + c4) = v;
-        }
-        for (int e = threadIdx.x; e < 32 * 40; e += 256) {          // B slab: 32 rows x 160 cols
-            const int row = e / 40, c4 = (e % 40) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const bool live = s + row < s1;
-            if (live && c4 < Np) v = *reinterpret_cast<const float4*>(Bm + (s + row) * ldb + c4);
-            if (c4 >= N) { v.x = 0.f; v.y = 0.f; v.z = 0.f; v.w = 0.f; }
-            else if (c4 + 3 >= N) { if (c4 + 1 >= N) v.y = 0.f; if (c4 + 2 >= N) v.z = 0.f; v.w = 0.f; }
-            if (ones_col && live && N >= c4 && N < c4 + 4) { float* pv = &v.x; pv[N - c4] = 1.0f; }
-            *reinterpret_cast<float4*>(Bs + row * GT_BS + c4) = v;
-        }
+        stage(s);
         __syncthreads();
-        if (32 * w < M) {
+        if (s + 32 < s1) fetch(s + 32);
+#pragma unroll 2
+        for (int t = 0; t < 16; ++t) {
+            const int kk = 2 * t + h;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int kk = 2 * t + h;
-                const float a = As[kk * GT_AS + 32 * w + li];
-#pragma unroll
-                for (int nt = 0; nt < 5; ++nt)
-                    if (nt < NT) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[kk * GT_BS + 32 * nt + li], acc[nt], 0, 0, 0);
-            }
+            for (int i = 0; i < TPW; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[kk * GT_AS + ta[i]], Bs[kk * GT_BS + tb[i]], acc[i], 0, 0, 0);
         }
         __syncthreads();
     }
-    if (32 * w >= M) return;
 #pragma unroll
-    for (int nt = 0; nt < 5; ++nt) {
-        if (nt >= NT) continue;
-        const int jcol = 32 * nt + li;
-        if (jcol >= N + ones_col) continue;
+    for (int i = 0; i < TPW; ++i) {
+        const int t = w + 4 * i;
+        const int jcol = 32 * (t / MT) + li;
+        const int row0 = 32 * (t % MT) + 4 * h;
+        const bool col_ok = t < T && jcol < N + ones_col;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int i = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (i < M && acc[nt][r] != 0.f) atomic_add_f32(C + (size_t)i * ldc + jcol, acc[nt][r]);
+            const int row = row0 + (r & 3) + 8 * (r >> 2);
+            if (col_ok && row < M) atomic_add_f32(C + (size_t)row * ldc + jcol, acc[i][r]);
         }
     }
 }
@@ -836,6 +897,13 @@ int check_grad_field(const TirField* f, const TirFieldGrad* g, bool density, boo
         if (density && (!f->dplane[i] || !f->dline[i] || !g->dplane[i] || !g->dline[i])) return TIR_ERR_ARG;
         if (app && (!f->aplane[i] || !f->aline[i] || !g->aplane[i] || !g->aline[i])) return TIR_ERR_ARG;
     }
+    // the kernels index planes with 32-bit float offsets
+    const int64_t g0 = f->grid[0], g1 = f->grid[1], g2 = f->grid[2];
+    int64_t cells = g0 * g1;
+    if (g0 * g2 > cells) cells = g0 * g2;
+    if (g1 * g2 > cells) cells = g1 * g2;
+    if (density && cells * f->n_dcomp >= (1ll << 31)) return TIR_ERR_UNSUPPORTED;
+    if (app && cells * f->n_acomp >= (1ll << 31)) return TIR_ERR_UNSUPPORTED;
     return TIR_OK;
 }
 
@@ -886,11 +954,11 @@ extern "C" int tir_density_grad_bwd(const TirField* f, const TirFieldGrad* g, co
     if (n < 0 || (n > 0 && (!xyz || !g_normal))) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
     hipStream_t s = tir_stream(stream);
-    const int c4 = f->n_dcomp / 4;
     const size_t line_bytes = (size_t)(f->grid[0] + f->grid[1] + f->grid[2]) * f->n_dcomp * sizeof(float);
     const bool ll = line_bytes <= 96 * 1024;
     const size_t lds = ll ? line_bytes : 0;
-    int64_t blocks = (n * c4 + 255) / 256;
+    const int lps = f->n_dcomp < 16 ? f->n_dcomp : 16;       // lanes per sample (k_density_grad_bwd)
+    int64_t blocks = (n * lps + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     dim3 grid((unsigned)blocks), blk(256);
 #define TIR_LAUNCH_DG(C4)                                                                                             \
@@ -940,17 +1008,18 @@ static int launch_app_bwd(const TirField* f, const TirFieldGrad* g, const float*
                           float* y_rad, float* y_int, hipStream_t s) {
     constexpr int CA = C4 * 4;
     const int nl = f->n_lights < TIR_APP_MAX_L ? f->n_lights : TIR_APP_MAX_L;
-    const size_t base = (size_t)(3 * CA * 32 + (nl + 1) * 3 * CA) * sizeof(float);
+    const size_t base = (size_t)(3 * CA * TIR_APP_WS + (nl + 1) * 3 * CA) * sizeof(float);
     if (base > 160 * 1024) return TIR_ERR_UNSUPPORTED;
     int rmax = f->grid[0] > f->grid[1] ? f->grid[0] : f->grid[1];
     if (f->grid[2] > rmax) rmax = f->grid[2];
     const size_t line = (size_t)rmax * CA * sizeof(float);
     const int line_lds = base + line <= 160 * 1024 ? 1 : 0;     // one line's gradient block-local in LDS when it fits
     const size_t lds = base + (line_lds ? line : 0);
-    int64_t blocks = (n + 63) / 64;
-    const int64_t cap = line_lds ? 512 : 1024;                   // fewer, longer-lived blocks amortise the LDS flush
+    const int threads = (g_rad && g_int) ? AppBwdThreads<true, true>::value : AppBwdThreads<true, false>::value;
+    int64_t blocks = (n * 16 + threads - 1) / threads;           // 4 samples per wave pass
+    const int64_t cap = 256;                                     // persistent blocks amortise the LDS zero / flush
     if (blocks > cap) blocks = cap;
-    dim3 grid((unsigned)blocks), blk(256);
+    dim3 grid((unsigned)blocks), blk(threads);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_bwd<C4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -997,9 +1066,12 @@ extern "C" int tir_gemm_tn(const float* A, int32_t lda, int32_t M, const float* 
     if (n == 0) return TIR_OK;
     int64_t chunk = (n + 511) / 512;
     chunk = (chunk + 31) / 32 * 32;
-    if (chunk < 256) chunk = 256;
+    if (chunk < 128) chunk = 128;
     const unsigned blocks = (unsigned)((n + chunk - 1) / chunk);
-    hipLaunchKernelGGL(k_gemm_tn, dim3(blocks), dim3(256), 0, tir_stream(stream), A, lda, M, B, ldb, N, ones_col, n, C, ldc, chunk);
+    const int tiles = ((M + 31) / 32) * ((N + ones_col + 31) / 32);
+    if (tiles <= 4)      hipLaunchKernelGGL(k_gemm_tn<1>, dim3(blocks), dim3(256), 0, tir_stream(stream), A, lda, M, B, ldb, N, ones_col, n, C, ldc, chunk);
+    else if (tiles <= 8) hipLaunchKernelGGL(k_gemm_tn<2>, dim3(blocks), dim3(256), 0, tir_stream(stream), A, lda, M, B, ldb, N, ones_col, n, C, ldc, chunk);
+    else                 hipLaunchKernelGGL(k_gemm_tn<5>, dim3(blocks), dim3(256), 0, tir_stream(stream), A, lda, M, B, ldb, N, ones_col, n, C, ldc, chunk);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
