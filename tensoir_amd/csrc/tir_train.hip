@@ -443,42 +443,108 @@ k_composite_primary_bwd(const float* __restrict__ rays, const int32_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward of the appearance feature (compute_bothfeature / compute_appfeature / compute_intrinfeature):
-// 16 adjacent lanes per sample, lane c owning channels c, c+16, ... of every tap (the scatter layout of scatter_group:
-// every plane atomic instruction lands 16 consecutive dwords per 64-B segment).  The per-channel cotangent
-// d(plane (.) line (.) light)[ch] = basis_mat[:, ch] . g_feat reads basis_mat^T rows from LDS as float4s (row stride 36
-// floats: the 16 rows a wave reads at once start in distinct bank quads).
+// Backward of the appearance feature (compute_bothfeature / compute_appfeature / compute_intrinfeature), two kernels:
+//
+//  k_app_dy        dY[n][3CA] = g_feat[n][app_dim] . basis_mat  -- the cotangent of the (plane (.) line (.) light) products,
+//                  an fp32-MFMA GEMM, written INTO the y_rad / y_int output buffers (no extra workspace);
+//  k_vm_app_bwd    the scatter: 16 adjacent lanes per sample, lane c owning channels c, c+16, ... of every tap (the
+//                  layout of scatter_group: every plane atomic instruction lands 16 consecutive dwords per 64-B
+//                  segment), reading dY in place and overwriting it with y = (plane (.) line) (.) light row.
+//                  The gathers of item i+1 (one 16-channel run of one sample group) are issued before the atomics of
+//                  item i, and every atomic is unconditional (zero-weight taps add 0.0), so the loop body is
+//                  straight-line code whose loads complete while the previous atomics are still in flight.
 // ------------------------------------------------------------------------------------------------
 #define TIR_APP_MAX_L 16
-#define TIR_APP_WS 36
+#define TIR_APP_BWD_THREADS 1024
 
-// one block per CU (the LDS line gradient is ~58 KB at a 300^3 grid): 12 or 16 waves, as the registers allow
-template <bool RAD, bool INTR> struct AppBwdThreads { static constexpr int value = (RAD && INTR) ? 768 : 1024; };
+template <int C4>
+__global__ void __launch_bounds__(256)
+k_app_dy(const float* __restrict__ basis_t, int app_dim, const float* __restrict__ gfeat, int stride, int64_t n,
+         float* __restrict__ y) {
+    constexpr int CA3 = 12 * C4, NT = (CA3 + 31) / 32;
+    constexpr int LDW = (NT & 1) ? NT * 32 : NT * 32 + 32;       // == 32 mod 64: the two k rows of a step hit disjoint banks
+    __shared__ float Wl[28 * LDW];                                // basis_mat rows (k) x product columns
+    for (int i = threadIdx.x; i < 28 * LDW; i += 256) {
+        const int kk = i / LDW, col = i % LDW;
+        Wl[i] = (kk < app_dim && col < CA3) ? basis_t[(size_t)col * 32 + kk] : 0.0f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, h = lane >> 5;
+    const int64_t n_tile = (n + 31) / 32;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tile; tile += (int64_t)gridDim.x * 4) {
+        const int64_t s0 = tile * 32, row = s0 + li;
+        float a[14];
+#pragma unroll
+        for (int t = 0; t < 14; ++t) a[t] = (row < n && 2 * t + h < app_dim) ? gfeat[row * stride + 2 * t + h] : 0.0f;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 14; ++t)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], Wl[(2 * t + h) * LDW + 32 * nt + li], acc[nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = 32 * nt + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t rr = s0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (rr < n && col < CA3) y[rr * CA3 + col] = acc[nt][r];
+            }
+        }
+    }
+}
+
+struct AppSamp { float x, y, z; int li; int64_t sc; bool on; };
+
+__device__ __forceinline__ float ld_b(const float* base, unsigned byte_off) {          // saddr + 32-bit voffset form
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void atomic_b(float* base, unsigned byte_off, float v) {
+    atomic_add_f32(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off), v);
+}
 
 template <int C4, bool RAD, bool INTR>
-__global__ void __launch_bounds__((AppBwdThreads<RAD, INTR>::value))
+__global__ void __launch_bounds__(TIR_APP_BWD_THREADS)
 k_vm_app_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
-             const int32_t* __restrict__ idx_map, const float* __restrict__ g_rad, const float* __restrict__ g_int,
-             int stride, int64_t n, float* __restrict__ y_rad, float* __restrict__ y_int, int line_lds) {
-    constexpr int CA = C4 * 4, WS = TIR_APP_WS;
+             const int32_t* __restrict__ idx_map, int64_t n, float* __restrict__ y_rad, float* __restrict__ y_int,
+             int line_lds) {
+    constexpr int CA = C4 * 4, CA3 = 3 * CA, NCQ = (CA + 15) / 16;
     extern __shared__ __attribute__((aligned(16))) float lds_ab[];
-    float* Wt = lds_ab;                              // [3*CA][WS] basis_mat^T, columns >= app_dim zero
-    float* gl = lds_ab + 3 * CA * WS;                // [(n_lights + 1)][3*CA] block-local light_line / light_mean gradient
     const int nl = min(f.n_lights, TIR_APP_MAX_L);
+    const bool lds_light = f.n_lights <= TIR_APP_MAX_L;
+    float* Lt = lds_ab;                              // [(nl + 1)][3*CA] light_line rows, then light_mean
+    float* gl = Lt + (nl + 1) * CA3;                 // same shape: block-local light_line / light_mean gradient
     // block-local gradient of ONE appearance line ([R][CA], the current VM group's): the line has only R rows, so
     // every sample of the batch lands on a few hundred addresses -- in L2 those atomics serialise; in LDS they are cheap
-    float* lg = gl + (nl + 1) * 3 * CA;
+    float* lg = gl + (nl + 1) * CA3;
     const int nthr = blockDim.x, nwave = nthr >> 6;
-    for (int i = threadIdx.x; i < 3 * CA * 32; i += nthr) {
-        const int t = i & 31;
-        if (t < 28) Wt[(i >> 5) * WS + t] = (t < f.app_dim) ? f.basis_t[i] : 0.0f;
+    for (int i = threadIdx.x; i < (nl + 1) * CA3; i += nthr) {
+        Lt[i] = (i < nl * CA3) ? (lds_light ? f.light_line[i] : 0.0f) : f.light_mean[i - nl * CA3];
+        gl[i] = 0.0f;
     }
-    for (int i = threadIdx.x; i < (nl + 1) * 3 * CA; i += nthr) gl[i] = 0.0f;
     const int L = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = L >> 4, c = L & 15;
-    const int64_t n_pass = (n + 3) / 4;
-    const bool vec_g = (stride & 3) == 0 && ((RAD ? (reinterpret_cast<uintptr_t>(g_rad) & 15) : 0) == 0) &&
-                       ((INTR ? (reinterpret_cast<uintptr_t>(g_int) & 15) : 0) == 0);
+    // A wave owns chunks of 4 x RUN consecutive samples; lane group j walks samples [RUN j, RUN j + RUN) of the chunk
+    // one after the other.  Consecutive records are consecutive samples of a ray (half a voxel apart), so a group
+    // usually stays in the same plane cell for 2-3 samples: the four tap gradients are summed in registers while
+    // the cell does not change and leave as atomics only when it does (run-length combining).
+    constexpr int RUN = 8;
+    const int64_t n_chunk = (n + 4 * RUN - 1) / (4 * RUN), cstride = (int64_t)gridDim.x * nwave;
+    // sample of this lane group at step i of a chunk (clamped to n-1 past the end), and its row in light_idx
+    auto samp_of = [&](int64_t chunk, int i) { const int64_t s = chunk * (4 * RUN) + RUN * j + i; return s < n ? s : n - 1; };
+    auto lsel_of = [&](int64_t sc) { return (RAD && idx_map) ? (int64_t)idx_map[sc] : sc; };
+    // position + light of a sample; lsel comes from lsel_of() one step earlier so the two loads do not chain
+    auto load_samp = [&](int64_t chunk, int i, int64_t lsel) {
+        AppSamp sm;
+        sm.on = chunk * (4 * RUN) + RUN * j + i < n;
+        sm.sc = samp_of(chunk, i);
+        sm.x = xyz[3 * sm.sc]; sm.y = xyz[3 * sm.sc + 1]; sm.z = xyz[3 * sm.sc + 2];
+        sm.li = RAD ? min(max(light_idx[lsel], 0), f.n_lights - 1) : 0;
+        return sm;
+    };
 #pragma unroll 1
     for (int k = 0; k < 3; ++k) {                  // one VM group at a time over ALL of the block's samples
         const int m0 = (k == 2) ? 1 : 0, m1 = (k == 0) ? 1 : 2, vi = 2 - k;
@@ -489,84 +555,128 @@ k_vm_app_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, const in
         const float* pl = f.aplane[k];
         const float* ln = f.aline[k];
         float* gp = g.aplane[k];
-        for (int64_t pass = (int64_t)blockIdx.x * nwave + wave; pass < n_pass; pass += (int64_t)gridDim.x * nwave) {
-            const int64_t s = pass * 4 + j;
-            const bool on = s < n;
-            const int64_t sc = on ? s : n - 1;
-            const float p[3] = {xyz[3 * sc], xyz[3 * sc + 1], xyz[3 * sc + 2]};
-            int li = 0;
-            if (RAD) {
-                const int64_t lsel = idx_map ? (int64_t)idx_map[sc] : sc;
-                li = min(max(light_idx[lsel], 0), f.n_lights - 1);
+        float* gln = g.aline[k];
+        for (int64_t chunk = (int64_t)blockIdx.x * nwave + wave; chunk < n_chunk; chunk += cstride) {
+            AppSamp sm = load_samp(chunk, 0, lsel_of(samp_of(chunk, 0)));
+            int64_t lsel_n = lsel_of(samp_of(chunk, 1));
+            // the open run: tap byte offsets and the summed tap gradients of every 16-channel run of this lane
+            unsigned r00 = 0xffffffffu, r01 = 0, r10 = 0, r11 = 0;
+            float a00[NCQ], a01[NCQ], a10[NCQ], a11[NCQ];
+            // ... the same for the line rows (runs are longer: one axis) and for the light row of the samples' light
+            unsigned rq0 = 0xffffffffu, rq1 = 0;
+            int rli = -1;
+            float b0[NCQ], b1[NCQ], lr_acc[NCQ], lm_acc[NCQ];
+#pragma unroll
+            for (int cq = 0; cq < NCQ; ++cq) {
+                a00[cq] = 0.f; a01[cq] = 0.f; a10[cq] = 0.f; a11[cq] = 0.f;
+                b0[cq] = 0.f; b1[cq] = 0.f; lr_acc[cq] = 0.f; lm_acc[cq] = 0.f;
             }
-            float gr[28], gi[28];
-            if (vec_g) {
+            auto flush = [&]() {
 #pragma unroll
-                for (int q = 0; q < 7; ++q) {
-                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-                    if (RAD && on && 4 * q < stride) a = ld4(g_rad + sc * stride + 4 * q);
-                    if (INTR && on && 4 * q < stride) b = ld4(g_int + sc * stride + 4 * q);
-                    gr[4 * q] = a.x; gr[4 * q + 1] = a.y; gr[4 * q + 2] = a.z; gr[4 * q + 3] = a.w;
-                    gi[4 * q] = b.x; gi[4 * q + 1] = b.y; gi[4 * q + 2] = b.z; gi[4 * q + 3] = b.w;
+                for (int cq = 0; cq < NCQ; ++cq) {
+                    const unsigned cb = (16 * cq + c < CA) ? 64u * cq : 0u;     // dead lanes of a partial run add 0.0
+                    atomic_b(gp, r00 + cb, a00[cq]); atomic_b(gp, r01 + cb, a01[cq]);
+                    atomic_b(gp, r10 + cb, a10[cq]); atomic_b(gp, r11 + cb, a11[cq]);
+                    a00[cq] = 0.f; a01[cq] = 0.f; a10[cq] = 0.f; a11[cq] = 0.f;
                 }
+            };
+            auto flush_line = [&]() {
 #pragma unroll
-                for (int q = 0; q < 28; ++q)            // row padding may hold anything (0 x NaN): mask it
-                    if (q >= f.app_dim) { gr[q] = 0.f; gi[q] = 0.f; }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 28; ++q) {
-                    gr[q] = (RAD && on && q < f.app_dim) ? g_rad[sc * stride + q] : 0.f;
-                    gi[q] = (INTR && on && q < f.app_dim) ? g_int[sc * stride + q] : 0.f;
+                for (int cq = 0; cq < NCQ; ++cq) {
+                    const unsigned cb = (16 * cq + c < CA) ? 64u * cq : 0u;
+                    if (line_lds) { atomicAdd(lg + (rq0 + cb) / 4u, b0[cq]); atomicAdd(lg + (rq1 + cb) / 4u, b1[cq]); }
+                    else { atomic_b(gln, rq0 + cb, b0[cq]); atomic_b(gln, rq1 + cb, b1[cq]); }
+                    b0[cq] = 0.f; b1[cq] = 0.f;
                 }
-            }
-            Tap1 tx = make_tap(p[m0], W), ty = make_tap(p[m1], H), tl = make_tap(p[vi], R);
-            const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
-            const int o00 = (ty.i0 * W + tx.i0) * CA, o01 = (ty.i0 * W + tx.i1) * CA;     // < 2^31 (check_grad_field)
-            const int o10 = (ty.i1 * W + tx.i0) * CA, o11 = (ty.i1 * W + tx.i1) * CA;
-            const int q0 = tl.i0 * CA, q1 = tl.i1 * CA;
+            };
+            auto flush_light = [&]() {
+#pragma unroll
+                for (int cq = 0; cq < NCQ; ++cq) {
+                    const int ch = k * CA + ((16 * cq + c < CA) ? 16 * cq : 0) + c;
+                    if (RAD) {
+                        if (lds_light) atomicAdd(gl + rli * CA3 + ch, lr_acc[cq]);
+                        else atomic_add_f32(g.light_line + (size_t)rli * CA3 + ch, lr_acc[cq]);
+                    }
+                    lr_acc[cq] = 0.f;
+                }
+            };
 #pragma unroll 1
-            for (int cq = 0; cq < (CA + 15) / 16; ++cq) {
-                const int cha = 16 * cq + c;               // channel inside the group
-                if (cha >= CA) continue;
-                const int ch = k * CA + cha;               // channel of the 3*CA feature
-                const float av = pl[o00 + cha], bv = pl[o01 + cha], cv = pl[o10 + cha], dv = pl[o11 + cha];
-                const float ev = ln[q0 + cha], gv = ln[q1 + cha];
-                const float lrv = RAD ? f.light_line[li * (3 * CA) + ch] : 0.f;
-                const float lmv = INTR ? f.light_mean[ch] : 0.f;
-                // d (pl (.) light)[ch] = basis_mat[:, ch] . g_feat
-                const float4* wr = reinterpret_cast<const float4*>(Wt + ch * WS);
-                float dyr = 0.f, dyi = 0.f;
+            for (int i = 0; i < RUN; ++i) {
+                const float p[3] = {sm.x, sm.y, sm.z};
+                Tap1 tx = make_tap(p[m0], W), ty = make_tap(p[m1], H), tl = make_tap(p[vi], R);
+                const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
+                // byte offsets of this lane's first channel in each tap: < 2^32 (check_grad_field)
+                const unsigned o00 = ((unsigned)(ty.i0 * W + tx.i0) * CA + c) * 4u, o01 = ((unsigned)(ty.i0 * W + tx.i1) * CA + c) * 4u;
+                const unsigned o10 = ((unsigned)(ty.i1 * W + tx.i0) * CA + c) * 4u, o11 = ((unsigned)(ty.i1 * W + tx.i1) * CA + c) * 4u;
+                const unsigned q0 = ((unsigned)tl.i0 * CA + c) * 4u, q1 = ((unsigned)tl.i1 * CA + c) * 4u;
+                const int li = sm.li;
+                const bool on = sm.on;
+                float* yr = RAD ? y_rad + sm.sc * CA3 + k * CA + c : nullptr;
+                float* yi = INTR ? y_int + sm.sc * CA3 + k * CA + c : nullptr;
+                // every gather of the step (and the next sample's position) in flight before anything is consumed: a
+                // wave waits on ALL of its outstanding loads and atomics at once (vmcnt is shared), so one round
+                // trip per step is what this costs
+                float ga[NCQ], gb[NCQ], gc[NCQ], gd[NCQ], ge[NCQ], gg[NCQ], dyr[NCQ], dyi[NCQ];
 #pragma unroll
-                for (int t = 0; t < 7; ++t) {
-                    const float4 bw = wr[t];
-                    if (RAD) dyr = fmaf(bw.w, gr[4 * t + 3], fmaf(bw.z, gr[4 * t + 2], fmaf(bw.y, gr[4 * t + 1], fmaf(bw.x, gr[4 * t], dyr))));
-                    if (INTR) dyi = fmaf(bw.w, gi[4 * t + 3], fmaf(bw.z, gi[4 * t + 2], fmaf(bw.y, gi[4 * t + 1], fmaf(bw.x, gi[4 * t], dyi))));
+                for (int cq = 0; cq < NCQ; ++cq) {
+                    const bool chan = 16 * cq + c < CA;            // CA = 24: the second run is half empty
+                    const unsigned cb = chan ? 64u * cq : 0u;
+                    ga[cq] = ld_b(pl, o00 + cb); gb[cq] = ld_b(pl, o01 + cb); gc[cq] = ld_b(pl, o10 + cb); gd[cq] = ld_b(pl, o11 + cb);
+                    ge[cq] = ld_b(ln, q0 + cb); gg[cq] = ld_b(ln, q1 + cb);
+                    dyr[cq] = RAD ? yr[chan ? 16 * cq : 0] : 0.0f;
+                    dyi[cq] = INTR ? yi[chan ? 16 * cq : 0] : 0.0f;
                 }
-                const float P = fmaf(dv, w11, fmaf(cv, w10, fmaf(bv, w01, av * w00)));
-                const float Ln = fmaf(gv, tl.w1, ev * tl.w0);
-                const float plv = P * Ln;
-                if (!on) continue;
-                if (RAD && y_rad) y_rad[s * (3 * CA) + ch] = plv * lrv;
-                if (INTR && y_int) y_int[s * (3 * CA) + ch] = plv * lmv;
-                if (RAD && dyr != 0.f) {
-                    if (f.n_lights <= TIR_APP_MAX_L) atomicAdd(gl + li * (3 * CA) + ch, dyr * plv);
-                    else atomic_add_f32(g.light_line + (size_t)li * (3 * CA) + ch, dyr * plv);
+                if (i + 1 < RUN) {
+                    sm = load_samp(chunk, i + 1, lsel_n);
+                    lsel_n = lsel_of(samp_of(chunk, i + 2 < RUN ? i + 2 : i + 1));
                 }
-                if (INTR && dyi != 0.f) atomicAdd(gl + nl * (3 * CA) + ch, dyi * plv);
-                const float dpl = dyr * lrv + dyi * lmv;
-                if (dpl == 0.f) continue;
-                const float dP = dpl * Ln, dL = dpl * P;
-                if (w00 != 0.f) atomic_add_f32(gp + o00 + cha, dP * w00);
-                if (w01 != 0.f) atomic_add_f32(gp + o01 + cha, dP * w01);
-                if (w10 != 0.f) atomic_add_f32(gp + o10 + cha, dP * w10);
-                if (w11 != 0.f) atomic_add_f32(gp + o11 + cha, dP * w11);
-                if (line_lds) {
-                    if (tl.w0 != 0.f) atomicAdd(lg + q0 + cha, dL * tl.w0);
-                    if (tl.w1 != 0.f) atomicAdd(lg + q1 + cha, dL * tl.w1);
-                } else {
-                    if (tl.w0 != 0.f) atomic_add_f32(g.aline[k] + q0 + cha, dL * tl.w0);
-                    if (tl.w1 != 0.f) atomic_add_f32(g.aline[k] + q1 + cha, dL * tl.w1);
+                if (o00 != r00 || o11 != r11) {                    // left the cell: the open run goes out
+                    if (r00 != 0xffffffffu) flush();
+                    r00 = o00; r01 = o01; r10 = o10; r11 = o11;
                 }
+                if (q0 != rq0 || q1 != rq1) {
+                    if (rq0 != 0xffffffffu) flush_line();
+                    rq0 = q0; rq1 = q1;
+                }
+                if (RAD && li != rli) {
+                    if (rli >= 0) flush_light();
+                    rli = li;
+                }
+#pragma unroll
+                for (int cq = 0; cq < NCQ; ++cq) {
+                    const bool chan = 16 * cq + c < CA;
+                    const bool live = on && chan;
+                    const unsigned cb = chan ? 64u * cq : 0u;
+                    const int ch = k * CA + (chan ? 16 * cq : 0) + c;      // channel of the 3*CA product vector
+                    float lrv = 0.f, lmv = 0.f;
+                    if (RAD) lrv = lds_light ? Lt[li * CA3 + ch] : f.light_line[(size_t)li * CA3 + ch];
+                    if (INTR) lmv = Lt[nl * CA3 + ch];
+                    const float er = live ? dyr[cq] : 0.f, ei = live ? dyi[cq] : 0.f;
+                    const float P = fmaf(gd[cq], w11, fmaf(gc[cq], w10, fmaf(gb[cq], w01, ga[cq] * w00)));
+                    const float Ln = fmaf(gg[cq], tl.w1, ge[cq] * tl.w0);
+                    const float plv = P * Ln;
+                    // lanes past CA redo run 0 of the same sample (same y); lanes past n redo sample n-1 and must
+                    // not touch its y row (another group may not have read dY there yet); both add zeros below
+                    if (on) {
+                        if (RAD) yr[chan ? 16 * cq : 0] = plv * lrv;
+                        if (INTR) yi[chan ? 16 * cq : 0] = plv * lmv;
+                    }
+                    if (RAD) lr_acc[cq] = fmaf(er, plv, lr_acc[cq]);
+                    if (INTR) lm_acc[cq] = fmaf(ei, plv, lm_acc[cq]);
+                    const float dpl = er * lrv + ei * lmv;
+                    const float dP = dpl * Ln, dL = dpl * P;
+                    a00[cq] = fmaf(dP, w00, a00[cq]); a01[cq] = fmaf(dP, w01, a01[cq]);
+                    a10[cq] = fmaf(dP, w10, a10[cq]); a11[cq] = fmaf(dP, w11, a11[cq]);
+                    b0[cq] = fmaf(dL, tl.w0, b0[cq]); b1[cq] = fmaf(dL, tl.w1, b1[cq]);
+                }
+            }
+            if (r00 != 0xffffffffu) flush();
+            if (rq0 != 0xffffffffu) flush_line();
+            if (RAD && rli >= 0) flush_light();
+            if (INTR) {
+#pragma unroll
+                for (int cq = 0; cq < NCQ; ++cq)
+                    atomicAdd(gl + nl * CA3 + k * CA + ((16 * cq + c < CA) ? 16 * cq : 0) + c, lm_acc[cq]);
             }
         }
         __syncthreads();
@@ -577,11 +687,11 @@ k_vm_app_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, const in
             }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < (nl + 1) * 3 * CA; i += nthr) {
+    for (int i = threadIdx.x; i < (nl + 1) * CA3; i += nthr) {
         const float v = gl[i];
         if (v == 0.f) continue;
-        if (i < nl * 3 * CA) { if (RAD && f.n_lights <= TIR_APP_MAX_L) atomic_add_f32(g.light_line + i, v); }
-        else if (INTR) atomic_add_f32(g.light_mean + (i - nl * 3 * CA), v);
+        if (i < nl * CA3) { if (RAD && lds_light) atomic_add_f32(g.light_line + i, v); }
+        else if (INTR) atomic_add_f32(g.light_mean + (i - nl * CA3), v);
     }
 }
 
@@ -903,7 +1013,7 @@ int check_grad_field(const TirField* f, const TirFieldGrad* g, bool density, boo
     if (g0 * g2 > cells) cells = g0 * g2;
     if (g1 * g2 > cells) cells = g1 * g2;
     if (density && cells * f->n_dcomp >= (1ll << 31)) return TIR_ERR_UNSUPPORTED;
-    if (app && cells * f->n_acomp >= (1ll << 31)) return TIR_ERR_UNSUPPORTED;
+    if (app && cells * f->n_acomp >= (1ll << 30)) return TIR_ERR_UNSUPPORTED;      // 32-bit BYTE offsets
     return TIR_OK;
 }
 
@@ -1008,17 +1118,21 @@ static int launch_app_bwd(const TirField* f, const TirFieldGrad* g, const float*
                           float* y_rad, float* y_int, hipStream_t s) {
     constexpr int CA = C4 * 4;
     const int nl = f->n_lights < TIR_APP_MAX_L ? f->n_lights : TIR_APP_MAX_L;
-    const size_t base = (size_t)(3 * CA * TIR_APP_WS + (nl + 1) * 3 * CA) * sizeof(float);
-    if (base > 160 * 1024) return TIR_ERR_UNSUPPORTED;
+    const size_t base = (size_t)(2 * (nl + 1) * 3 * CA) * sizeof(float);
     int rmax = f->grid[0] > f->grid[1] ? f->grid[0] : f->grid[1];
     if (f->grid[2] > rmax) rmax = f->grid[2];
     const size_t line = (size_t)rmax * CA * sizeof(float);
     const int line_lds = base + line <= 160 * 1024 ? 1 : 0;     // one line's gradient block-local in LDS when it fits
     const size_t lds = base + (line_lds ? line : 0);
-    const int threads = (g_rad && g_int) ? AppBwdThreads<true, true>::value : AppBwdThreads<true, false>::value;
-    int64_t blocks = (n * 16 + threads - 1) / threads;           // 4 samples per wave pass
-    const int64_t cap = 256;                                     // persistent blocks amortise the LDS zero / flush
-    if (blocks > cap) blocks = cap;
+    // dY = g_feat . basis_mat into the y buffers
+    int64_t dyb = (n + 127) / 128;
+    if (dyb > 2048) dyb = 2048;
+    if (g_rad) hipLaunchKernelGGL((k_app_dy<C4>), dim3((unsigned)dyb), dim3(256), 0, s, f->basis_t, f->app_dim, g_rad, stride, n, y_rad);
+    if (g_int) hipLaunchKernelGGL((k_app_dy<C4>), dim3((unsigned)dyb), dim3(256), 0, s, f->basis_t, f->app_dim, g_int, stride, n, y_int);
+    const int threads = TIR_APP_BWD_THREADS;
+    int64_t blocks = (n * 2 + threads - 1) / threads;            // 32 samples per wave chunk
+    const int64_t per_cu = (lds <= 80 * 1024) ? 2 : 1;           // persistent blocks amortise the LDS zero / flush
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     dim3 grid((unsigned)blocks), blk(threads);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1027,9 +1141,9 @@ static int launch_app_bwd(const TirField* f, const TirFieldGrad* g, const float*
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_bwd<C4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (g_rad && g_int) hipLaunchKernelGGL((k_vm_app_bwd<C4, true, true>), grid, blk, lds, s, *f, *g, xyz, li, map, g_rad, g_int, stride, n, y_rad, y_int, line_lds);
-    else if (g_rad)     hipLaunchKernelGGL((k_vm_app_bwd<C4, true, false>), grid, blk, lds, s, *f, *g, xyz, li, map, g_rad, g_int, stride, n, y_rad, y_int, line_lds);
-    else                hipLaunchKernelGGL((k_vm_app_bwd<C4, false, true>), grid, blk, lds, s, *f, *g, xyz, li, map, g_rad, g_int, stride, n, y_rad, y_int, line_lds);
+    if (g_rad && g_int) hipLaunchKernelGGL((k_vm_app_bwd<C4, true, true>), grid, blk, lds, s, *f, *g, xyz, li, map, n, y_rad, y_int, line_lds);
+    else if (g_rad)     hipLaunchKernelGGL((k_vm_app_bwd<C4, true, false>), grid, blk, lds, s, *f, *g, xyz, li, map, n, y_rad, y_int, line_lds);
+    else                hipLaunchKernelGGL((k_vm_app_bwd<C4, false, true>), grid, blk, lds, s, *f, *g, xyz, li, map, n, y_rad, y_int, line_lds);
     return TIR_OK;
 }
 
@@ -1043,6 +1157,7 @@ extern "C" int tir_vm_app_bwd(const TirField* f, const TirFieldGrad* g, const fl
     if (f->app_dim < 1 || f->app_dim > 27) return TIR_ERR_UNSUPPORTED;
     if (stride < f->app_dim) return TIR_ERR_ARG;
     if (n < 0 || (n > 0 && !xyz) || (!g_rad && !g_int) || (g_rad && !light_idx)) return TIR_ERR_ARG;
+    if ((g_rad && !y_rad) || (g_int && !y_int)) return TIR_ERR_ARG;      // the y buffers double as the dY workspace
     if (n == 0) return TIR_OK;
     hipStream_t s = tir_stream(stream);
     switch (f->n_acomp) {

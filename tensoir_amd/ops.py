@@ -537,7 +537,7 @@ def density_grad_bwd(field: TirField, grad: TirFieldGrad, xyz, g_normal):
     _call("tir_density_grad_bwd", C.byref(field), C.byref(grad), _ptr(xyz), _ptr(g_normal), xyz.shape[0], _stream())
 
 
-def vm_app_bwd(field: TirField, grad: TirFieldGrad, xyz, light_idx, idx_map, g_rad, g_int, want_y=True):
+def vm_app_bwd(field: TirField, grad: TirFieldGrad, xyz, light_idx, idx_map, g_rad, g_int):
     """Scatter d feat into the appearance planes/lines + light rows; returns (y_rad, y_int) [n, 3*Ca]."""
     xyz = f32(xyz, "xyz", 3).view(-1, 3)
     n = xyz.shape[0]
@@ -545,8 +545,8 @@ def vm_app_bwd(field: TirField, grad: TirFieldGrad, xyz, light_idx, idx_map, g_r
     g_rad = None if g_rad is None else f32(g_rad, "g_rad")
     g_int = None if g_int is None else f32(g_int, "g_int")
     stride = (g_rad if g_rad is not None else g_int).shape[1]
-    y_rad = torch.empty((n, nch), dtype=torch.float32, device=xyz.device) if (g_rad is not None and want_y) else None
-    y_int = torch.empty((n, nch), dtype=torch.float32, device=xyz.device) if (g_int is not None and want_y) else None
+    y_rad = torch.empty((n, nch), dtype=torch.float32, device=xyz.device) if g_rad is not None else None
+    y_int = torch.empty((n, nch), dtype=torch.float32, device=xyz.device) if g_int is not None else None
     if light_idx is not None:
         light_idx = i32(light_idx, "light_idx").view(-1)
     if idx_map is not None:
