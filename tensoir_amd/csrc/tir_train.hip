@@ -23,12 +23,52 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomic
 // lands 16 consecutive dwords in each 64-B segment it touches.  The L2 atomic rate on gfx950 is per 64-B segment per
 // instruction (~20 G segments/s chip-wide, tools/atomic_bench.hip) whether 1 or 16 of its dwords are written: this
 // layout moves 4x the gradient per segment of the float4-per-lane layout the forward gathers use.
+//
+// Run-length combining: a lane group walks CONSECUTIVE samples of a ray (half a voxel apart), which usually stay in
+// one plane cell / line row for a few steps.  The tap gradients are summed in registers (VmRun) while the cell does not
+// change and leave as atomics only when it does.
 // ------------------------------------------------------------------------------------------------
+template <int NIT>                      // NIT = channels per lane = CH / min(CH, 16)
+struct VmRun {
+    int r[4];                           // float offsets of the open plane cell's taps (r[0] < 0: closed)
+    int q[2];                           // ... of the open line rows (q[0] < 0: closed)
+    float a[NIT][4], b[NIT][2];
+};
+
+template <int NIT>
+__device__ __forceinline__ void run_init(VmRun<NIT>& u) {
+    u.r[0] = -1; u.q[0] = -1;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) { u.a[it][0] = u.a[it][1] = u.a[it][2] = u.a[it][3] = 0.f; u.b[it][0] = u.b[it][1] = 0.f; }
+}
+template <int CH, int NIT>
+__device__ __forceinline__ void run_flush_plane(VmRun<NIT>& u, float* __restrict__ gplane, int c) {
+    constexpr int LPS = CH < 16 ? CH : 16;
+    if (u.r[0] < 0) return;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { atomic_add_f32(gplane + u.r[t] + c + it * LPS, u.a[it][t]); u.a[it][t] = 0.f; }
+}
+template <int CH, bool LL, int NIT>
+__device__ __forceinline__ void run_flush_line(VmRun<NIT>& u, float* __restrict__ gline, int c) {
+    constexpr int LPS = CH < 16 ? CH : 16;
+    if (u.q[0] < 0) return;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (LL) atomicAdd(gline + u.q[t] + c + it * LPS, u.b[it][t]);      // block-local LDS copy of the line gradient
+            else atomic_add_f32(gline + u.q[t] + c + it * LPS, u.b[it][t]);
+            u.b[it][t] = 0.f;
+        }
+}
+
 template <int CH, bool NORMAL, bool LL>
-__device__ __forceinline__ void scatter_group(const float* __restrict__ plane, const float* __restrict__ line,
-                                              float* __restrict__ gplane, float* __restrict__ gline, int H, int W,
-                                              int R, float u, float v, float w, int c, float F, float Gu,
-                                              float Gv, float Gw) {
+__device__ __forceinline__ void scatter_group(VmRun<(CH + 15) / 16>& run, const float* __restrict__ plane,
+                                              const float* __restrict__ line, float* __restrict__ gplane,
+                                              float* __restrict__ gline, int H, int W, int R, float u, float v, float w,
+                                              int c, float F, float Gu, float Gv, float Gw) {
     Tap1 tx = make_tap(u, W), ty = make_tap(v, H), tl = make_tap(w, R);
     float wx0, wx1, wy0, wy1, wl0, wl1;
     if (NORMAL) { wx0 = 1.0f - tx.t; wx1 = tx.t; wy0 = 1.0f - ty.t; wy1 = ty.t; wl0 = 1.0f - tl.t; wl1 = tl.t; }
@@ -37,6 +77,14 @@ __device__ __forceinline__ void scatter_group(const float* __restrict__ plane, c
     const int r0 = (ty.i0 * W + tx.i0) * CH, r1 = (ty.i0 * W + tx.i1) * CH;      // < 2^31 floats (check_grad_field)
     const int r2 = (ty.i1 * W + tx.i0) * CH, r3 = (ty.i1 * W + tx.i1) * CH;
     const int q0 = tl.i0 * CH, q1 = tl.i1 * CH;
+    if (r0 != run.r[0] || r3 != run.r[3]) {                    // left the cell: the open run goes out
+        run_flush_plane<CH>(run, gplane, c);
+        run.r[0] = r0; run.r[1] = r1; run.r[2] = r2; run.r[3] = r3;
+    }
+    if (q0 != run.q[0] || q1 != run.q[1]) {
+        run_flush_line<CH, LL>(run, gline, c);
+        run.q[0] = q0; run.q[1] = q1;
+    }
     // per-tap cotangent coefficients (Pu = (b-a) wy0 + (d-c) wy1,  Pv = (c-a) wx0 + (d-b) wx1)
     float a00 = F * w00, a01 = F * w01, a10 = F * w10, a11 = F * w11;
     if (NORMAL) {
@@ -45,7 +93,8 @@ __device__ __forceinline__ void scatter_group(const float* __restrict__ plane, c
     }
     constexpr int LPS = CH < 16 ? CH : 16;
 #pragma unroll
-    for (int ch = c; ch < CH; ch += LPS) {
+    for (int it = 0; it < (CH + 15) / 16; ++it) {
+        const int ch = c + it * LPS;
         const float av = plane[r0 + ch], bv = plane[r1 + ch], cv = plane[r2 + ch], dv = plane[r3 + ch];
         const float ev = line[q0 + ch], gv = line[q1 + ch];
         const float L = fmaf(gv, wl1, ev * wl0);
@@ -60,26 +109,26 @@ __device__ __forceinline__ void scatter_group(const float* __restrict__ plane, c
             const float Pv = fmaf(dv - bv, wx1, (cv - av) * wx0);
             S = fmaf(Gv, Pv, fmaf(Gu, Pu, S));
         }
-        if (t00 != 0.0f) atomic_add_f32(gplane + r0 + ch, t00);
-        if (t01 != 0.0f) atomic_add_f32(gplane + r1 + ch, t01);
-        if (t10 != 0.0f) atomic_add_f32(gplane + r2 + ch, t10);
-        if (t11 != 0.0f) atomic_add_f32(gplane + r3 + ch, t11);
+        run.a[it][0] += t00; run.a[it][1] += t01; run.a[it][2] += t10; run.a[it][3] += t11;
         float s0 = S * wl0, s1 = S * wl1;
         if (NORMAL) { s0 = fmaf(-Gw, P, s0); s1 = fmaf(Gw, P, s1); }
-        if (LL) {                 // gline is a block-local LDS copy of the (small, heavily shared) line gradient
-            if (s0 != 0.0f) atomicAdd(gline + q0 + ch, s0);
-            if (s1 != 0.0f) atomicAdd(gline + q1 + ch, s1);
-        } else {
-            if (s0 != 0.0f) atomic_add_f32(gline + q0 + ch, s0);
-            if (s1 != 0.0f) atomic_add_f32(gline + q1 + ch, s1);
-        }
+        run.b[it][0] += s0; run.b[it][1] += s1;
     }
+}
+
+// the open runs of the three VM groups of the density field
+template <int C4> struct DensityRuns { VmRun<(C4 * 4 + 15) / 16> g[3]; };
+
+template <int C4, bool LL>
+__device__ __forceinline__ float* density_line_grad(const TirField& f, const TirFieldGrad& g, float* lds_lines, int i) {
+    // LDS layout of the three line gradients: line i at offset sum_{j<i} R_j * CH  (R_0 = grid z, R_1 = grid y)
+    return LL ? lds_lines + (size_t)(i == 0 ? 0 : (i == 1 ? f.grid[2] : f.grid[2] + f.grid[1])) * (C4 * 4) : g.dline[i];
 }
 
 // the three VM groups of the density field for one sample; c = this lane's first channel (lane % min(CH, 16))
 template <int C4, bool NORMAL, bool LL>
-__device__ __forceinline__ void scatter_density(const TirField& f, const TirFieldGrad& g, float* lds_lines, float x, float y, float z,
-                                                int c, float F, float G0, float G1, float G2) {
+__device__ __forceinline__ void scatter_density(DensityRuns<C4>& runs, const TirField& f, const TirFieldGrad& g, float* lds_lines,
+                                                float x, float y, float z, int c, float F, float G0, float G1, float G2) {
     const float p[3] = {x, y, z};
     const float G[3] = {G0, G1, G2};
 #pragma unroll
@@ -88,10 +137,23 @@ __device__ __forceinline__ void scatter_density(const TirField& f, const TirFiel
         const int H = f.grid[m1], W = f.grid[m0], R = f.grid[vi];
         float Gu = 0.f, Gv = 0.f, Gw = 0.f;
         if (NORMAL) { Gu = G[m0] * (0.5f * (float)(W - 1)); Gv = G[m1] * (0.5f * (float)(H - 1)); Gw = G[vi] * (0.5f * (float)(R - 1)); }
-        // LDS layout of the three line gradients: line i at offset sum_{j<i} R_j * CH  (R_0 = grid z, R_1 = grid y)
-        float* gl = LL ? lds_lines + (size_t)(i == 0 ? 0 : (i == 1 ? f.grid[2] : f.grid[2] + f.grid[1])) * (C4 * 4) : g.dline[i];
-        scatter_group<C4 * 4, NORMAL, LL>(f.dplane[i], f.dline[i], g.dplane[i], gl, H, W, R, p[m0], p[m1], p[vi],
+        scatter_group<C4 * 4, NORMAL, LL>(runs.g[i], f.dplane[i], f.dline[i], g.dplane[i],
+                                          density_line_grad<C4, LL>(f, g, lds_lines, i), H, W, R, p[m0], p[m1], p[vi],
                                           c, F, Gu, Gv, Gw);
+    }
+}
+template <int C4>
+__device__ __forceinline__ void density_runs_init(DensityRuns<C4>& runs) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) run_init(runs.g[i]);
+}
+template <int C4, bool LL>
+__device__ __forceinline__ void density_runs_flush(DensityRuns<C4>& runs, const TirField& f, const TirFieldGrad& g, float* lds_lines, int c) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        run_flush_plane<C4 * 4>(runs.g[i], g.dplane[i], c);
+        run_flush_line<C4 * 4, LL>(runs.g[i], density_line_grad<C4, LL>(f, g, lds_lines, i), c);
+        run_init(runs.g[i]);
     }
 }
 
@@ -130,8 +192,12 @@ k_march_primary_bwd(TirField f, TirFieldGrad g, const float* __restrict__ rays, 
     extern __shared__ __attribute__((aligned(16))) float lds_lines[];
     float* wl = wl_all[wv];
     if (LL) { lines_zero<C4 * 4>(f, lds_lines); __syncthreads(); }
+    constexpr int LPS = C4 * 4 < 16 ? C4 * 4 : 16, PER = 64 / LPS;
+    const int slot_in = lane / LPS, c = lane % LPS;
   for (int ray = blockIdx.x * 4 + wv; ray < B; ray += gridDim.x * 4) {
     RaySetup rs = ray_setup(f, rays, ray);
+    DensityRuns<C4> runs;
+    density_runs_init<C4>(runs);
     const bool hj = ray_jitter != nullptr;
     const float jit = hj ? ray_jitter[ray] : 0.0f;
     const int nch = (S + 63) / 64;
@@ -201,17 +267,20 @@ k_march_primary_bwd(TirField f, TirFieldGrad g, const float* __restrict__ rays, 
         const int rank = __popcll(m & ((1ull << lane) - 1ull));
         if (on) { wl[rank * 4] = x; wl[rank * 4 + 1] = y; wl[rank * 4 + 2] = zz; wl[rank * 4 + 3] = df; }
         __builtin_amdgcn_wave_barrier();
-        constexpr int LPS = C4 * 4 < 16 ? C4 * 4 : 16, PER = 64 / LPS;
-        const int slot_in = lane / LPS, c = lane % LPS;
-        for (int base = 0; base < n; base += PER) {
-            const int slot = base + slot_in;
-            if (slot < n) {
+        // lane group g walks the CONSECUTIVE slots [g per, (g + 1) per): its open runs (VmRun) carry over from sample
+        // to sample and from chunk to chunk of the ray
+        const int per = (n + PER - 1) / PER;
+        const int lo = slot_in * per, hi = min(n, lo + per);
+        for (int t = 0; t < per; ++t) {
+            const int slot = lo + t;
+            if (slot < hi) {
                 const float4 p = *reinterpret_cast<const float4*>(wl + slot * 4);
-                scatter_density<C4, false, LL>(f, g, lds_lines, p.x, p.y, p.z, c, p.w, 0.f, 0.f, 0.f);
+                scatter_density<C4, false, LL>(runs, f, g, lds_lines, p.x, p.y, p.z, c, p.w, 0.f, 0.f, 0.f);
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
+    density_runs_flush<C4, LL>(runs, f, g, lds_lines, c);
   }
     if (LL) { __syncthreads(); lines_flush<C4 * 4>(f, g, lds_lines); }
 }
@@ -226,10 +295,17 @@ k_density_grad_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, co
     extern __shared__ __attribute__((aligned(16))) float lds_lines[];
     if (LL) { lines_zero<C4 * 4>(f, lds_lines); __syncthreads(); }
     constexpr int CH = C4 * 4, LPS = CH < 16 ? CH : 16;
-  const int64_t n_lanes = (n * LPS + 255) / 256 * 256;         // whole blocks: the shuffles below need full lane groups
+    constexpr int RUN = 8;                 // consecutive samples per lane group (run-length combining, see VmRun)
+  const int64_t n_grp = (n + RUN - 1) / RUN;
+  const int64_t n_lanes = (n_grp * LPS + 255) / 256 * 256;     // whole blocks: the shuffles below need full lane groups
   for (int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tid < n_lanes; tid += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = tid / LPS;
+    const int64_t grp = tid / LPS;
     const int c = (int)(tid % LPS);
+    DensityRuns<C4> runs;
+    density_runs_init<C4>(runs);
+#pragma unroll 1
+   for (int step = 0; step < RUN; ++step) {
+    const int64_t i = grp * RUN + step;
     const bool on = i < n;
     const int64_t ic = on ? i : n - 1;
     const float p[3] = {xyz[3 * ic], xyz[3 * ic + 1], xyz[3 * ic + 2]};
@@ -286,7 +362,9 @@ k_density_grad_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, co
         dg[0] = -(dn[0] - nx * dot) / nrm; dg[1] = -(dn[1] - ny * dot) / nrm; dg[2] = -(dn[2] - nz * dot) / nrm;
     } else { dg[0] = -dn[0] / 1e-6f; dg[1] = -dn[1] / 1e-6f; dg[2] = -dn[2] / 1e-6f; }
     const float F = (dg[0] * gr[0] + dg[1] * gr[1] + dg[2] * gr[2]) * dds;
-    scatter_density<C4, true, LL>(f, g, lds_lines, p[0], p[1], p[2], c, F, ds * dg[0], ds * dg[1], ds * dg[2]);
+    scatter_density<C4, true, LL>(runs, f, g, lds_lines, p[0], p[1], p[2], c, F, ds * dg[0], ds * dg[1], ds * dg[2]);
+   }
+    density_runs_flush<C4, LL>(runs, f, g, lds_lines, c);
   }
     if (LL) { __syncthreads(); lines_flush<C4 * 4>(f, g, lds_lines); }
 }
@@ -1067,8 +1145,8 @@ extern "C" int tir_density_grad_bwd(const TirField* f, const TirFieldGrad* g, co
     const size_t line_bytes = (size_t)(f->grid[0] + f->grid[1] + f->grid[2]) * f->n_dcomp * sizeof(float);
     const bool ll = line_bytes <= 96 * 1024;
     const size_t lds = ll ? line_bytes : 0;
-    const int lps = f->n_dcomp < 16 ? f->n_dcomp : 16;       // lanes per sample (k_density_grad_bwd)
-    int64_t blocks = (n * lps + 255) / 256;
+    const int lps = f->n_dcomp < 16 ? f->n_dcomp : 16;       // lanes per sample, 8 consecutive samples per lane group
+    int64_t blocks = ((n + 7) / 8 * lps + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     dim3 grid((unsigned)blocks), blk(256);
 #define TIR_LAUNCH_DG(C4)                                                                                             \
