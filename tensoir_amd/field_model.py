@@ -36,6 +36,21 @@ def safe_l2_normalize(x, dim=None, eps=1e-6):
     return F.normalize(x, p=2, dim=dim, eps=eps)
 
 
+def channel_last(t):
+    """[1,C,H,W] values stored as [H,W,C] in memory -- the layout the kernels gather from.  VM plane / line
+    parameters are created like this, so a parameter IS its packed form: no shadow copy after every optimizer step,
+    and the scatter kernels' channel-last gradients satisfy autograd's layout contract without a transposing copy."""
+    return t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+def is_channel_last(p):
+    if p.dim() != 4 or p.shape[0] != 1 or p.dtype != torch.float32:
+        return False
+    _, c, h, w = p.shape
+    _, sc, sh, sw = p.stride()
+    return (c == 1 or sc == 1) and (w == 1 or sw == c) and (h == 1 or sh == w * c)
+
+
 def _no_grad_only(what, *tensors):
     if torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors):
         raise NotImplementedError(
@@ -219,8 +234,8 @@ class TensorVMSplit(nn.Module):
         for i in range(3):
             vec_id = self.vecMode[i]
             m0, m1 = self.matMode[i]
-            planes.append(nn.Parameter(scale * torch.randn((1, n_component[i], int(gridSize[m1]), int(gridSize[m0])))))
-            lines.append(nn.Parameter(scale * torch.randn((1, n_component[i], int(gridSize[vec_id]), 1))))
+            planes.append(nn.Parameter(channel_last(scale * torch.randn((1, n_component[i], int(gridSize[m1]), int(gridSize[m0]))))))
+            lines.append(nn.Parameter(channel_last(scale * torch.randn((1, n_component[i], int(gridSize[vec_id]), 1)))))
         return nn.ParameterList(planes).to(device), nn.ParameterList(lines).to(device)
 
     def init_render_func(self, shadingMode, pos_pe, view_pe, fea_pe, featureC, device):
@@ -401,8 +416,9 @@ class TensorVMSplit(nn.Module):
                 list(self.app_line) + [self.basis_mat.weight, self.light_line.weight])
 
     def packed_field(self) -> TirField:
-        """Channel-last / bit-packed shadow copies + the TirField descriptor; rebuilt whenever a
-        parameter's storage or version changes (optimizer step, upsample, shrink, load)."""
+        """The TirField descriptor (+ the small derived tables: basis_mat^T, mean light row, occupancy bits); rebuilt
+        whenever a parameter's storage or version changes (optimizer step, upsample, shrink, load).  The VM planes /
+        lines are channel-last parameters and are referenced in place."""
         ps = self._field_params()
         mask = self.alphaMask
         key = (tuple((p.data_ptr(), p._version, tuple(p.shape)) for p in ps), id(mask),
@@ -428,7 +444,9 @@ class TensorVMSplit(nn.Module):
         for i in range(3):
             for name, src, dst in (("dp", self.density_plane, f.dplane), ("dl", self.density_line, f.dline),
                                    ("ap", self.app_plane, f.aplane), ("al", self.app_line, f.aline)):
-                t = ops.pack_plane(src[i])
+                # a channel-last parameter is gathered in place; anything else (a tensor swapped in from outside)
+                # gets a packed shadow copy
+                t = src[i].detach() if is_channel_last(src[i]) else ops.pack_plane(src[i])
                 keep[f"{name}{i}"] = t
                 dst[i] = t.data_ptr()
         keep["basis"] = ops.pack_basis(self.basis_mat.weight)
@@ -564,10 +582,10 @@ class TensorVMSplit(nn.Module):
         for i in range(3):
             vec_id = self.vecMode[i]
             m0, m1 = self.matMode[i]
-            plane_coef[i] = nn.Parameter(F.interpolate(plane_coef[i].data, size=(res_target[m1], res_target[m0]),
-                                                       mode="bilinear", align_corners=True))
-            line_coef[i] = nn.Parameter(F.interpolate(line_coef[i].data, size=(res_target[vec_id], 1),
-                                                      mode="bilinear", align_corners=True))
+            plane_coef[i] = nn.Parameter(channel_last(F.interpolate(plane_coef[i].data, size=(res_target[m1], res_target[m0]),
+                                                                    mode="bilinear", align_corners=True)))
+            line_coef[i] = nn.Parameter(channel_last(F.interpolate(line_coef[i].data, size=(res_target[vec_id], 1),
+                                                                   mode="bilinear", align_corners=True)))
         return plane_coef, line_coef
 
     @torch.no_grad()
@@ -585,11 +603,11 @@ class TensorVMSplit(nn.Module):
         b_r = torch.stack([b_r, self.gridSize]).amin(0)
         for i in range(3):
             mode0 = self.vecMode[i]
-            self.density_line[i] = nn.Parameter(self.density_line[i].data[..., t_l[mode0]:b_r[mode0], :])
-            self.app_line[i] = nn.Parameter(self.app_line[i].data[..., t_l[mode0]:b_r[mode0], :])
+            self.density_line[i] = nn.Parameter(channel_last(self.density_line[i].data[..., t_l[mode0]:b_r[mode0], :]))
+            self.app_line[i] = nn.Parameter(channel_last(self.app_line[i].data[..., t_l[mode0]:b_r[mode0], :]))
             mode0, mode1 = self.matMode[i]
-            self.density_plane[i] = nn.Parameter(self.density_plane[i].data[..., t_l[mode1]:b_r[mode1], t_l[mode0]:b_r[mode0]])
-            self.app_plane[i] = nn.Parameter(self.app_plane[i].data[..., t_l[mode1]:b_r[mode1], t_l[mode0]:b_r[mode0]])
+            self.density_plane[i] = nn.Parameter(channel_last(self.density_plane[i].data[..., t_l[mode1]:b_r[mode1], t_l[mode0]:b_r[mode0]]))
+            self.app_plane[i] = nn.Parameter(channel_last(self.app_plane[i].data[..., t_l[mode1]:b_r[mode1], t_l[mode0]:b_r[mode0]]))
         if not torch.all(self.alphaMask.gridSize == self.gridSize):
             t_l_r, b_r_r = t_l / (self.gridSize - 1), (b_r - 1) / (self.gridSize - 1)
             correct_aabb = torch.zeros_like(new_aabb)

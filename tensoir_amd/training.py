@@ -67,8 +67,10 @@ def _grad_buffers(model, field):
 
 
 def _to_param_layout(g):
-    """packed [H,W,C] (or [R,1,C]) -> parameter layout [1,C,H,W]."""
-    return g.permute(2, 0, 1).unsqueeze(0)
+    """Gradient buffer -> parameter shape [1,C,H,W].  Buffers are zeros_like() of what the kernels gather from: the
+    channel-last parameter itself (already the right shape and strides: autograd takes it without a copy) or a packed
+    [H,W,C] shadow (a permuted view)."""
+    return g if g.dim() == 4 else g.permute(2, 0, 1).unsqueeze(0)
 
 
 class _DecoderCall(SimpleNamespace):

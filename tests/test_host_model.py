@@ -82,6 +82,18 @@ def test_upsample_and_optimizer_groups():
     assert m.gridSize.tolist() == [20, 22, 24]
     assert tuple(m.density_plane[0].shape) == (1, 16, 22, 20) and tuple(m.app_line[0].shape) == (1, 48, 24, 1)
     assert m._field_key is None                       # packed shadow invalidated
+    # VM parameters live in the kernels' channel-last layout (the parameter is its own packed form) ...
+    from tensoir_amd.field_model import is_channel_last
+    vm = list(m.density_plane) + list(m.density_line) + list(m.app_plane) + list(m.app_line)
+    assert all(is_channel_last(p) for p in vm)
+    # ... and stay there through load_state_dict from ordinary (NCHW-contiguous) reference tensors and Adam state
+    sd = {k: v.contiguous() for k, v in m.state_dict().items()}
+    assert not is_channel_last(sd["app_plane.0"])
+    vals = sd["app_plane.0"].clone()
+    m.load_state_dict(sd)
+    assert all(is_channel_last(p) for p in vm) and torch.equal(m.app_plane[0].detach(), vals)
+    assert is_channel_last(torch.zeros_like(m.app_plane[0], memory_format=torch.preserve_format))
+    assert m.app_plane[0].detach().permute(0, 2, 3, 1).is_contiguous()
     reg = lambda x: (x[..., 1:, :] - x[..., :-1, :]).pow(2).mean()
     for v in (m.vector_comp_diffs(), m.density_L1(), m.TV_loss_density(reg), m.TV_loss_app(reg)):
         assert torch.isfinite(v)
