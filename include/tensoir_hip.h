@@ -411,6 +411,10 @@ int tir_mlp_bwd(const TirMlp* m, const float* packed_bwd, const float* feat, int
  * B [n][ldb] (first N columns); M <= 128, N + ones_col <= 160.  fp32 MFMA, split over n. */
 int tir_gemm_tn(const float* A, int32_t lda, int32_t M, const float* B, int32_t ldb, int32_t N,
                 int32_t ones_col, int64_t n, float* C, int32_t ldc, void* stream);
+/* Same product on the bf16 matrix pipe with every operand split x = hi + lo (3 products, fp32 accumulation:
+ * ~2^-16 relative per product, the decoders' split-bf16 scheme). */
+int tir_gemm_tn_bf16x3(const float* A, int32_t lda, int32_t M, const float* B, int32_t ldb, int32_t N,
+                int32_t ones_col, int64_t n, float* C, int32_t ldc, void* stream);
 
 /* Backward of tir_shade_integrate w.r.t. the map rows (normal 4:7, albedo 7:10, roughness 10, fresnel 11:14)
  * and the environment radiance.  g_out [M][3] -> g_maps [M][20] (written), g_env [n_lights][D][3] (accumulated).

@@ -882,6 +882,142 @@ k_gemm_tn(const float* __restrict__ A, int lda, int M, const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same product on the bf16 matrix pipe: every element x = hi + lo (two bf16), three products hi*hi + lo*hi + hi*lo
+// with fp32 accumulation (|error| ~ 2^-16 per product, the scheme of the split-bf16 decoders).
+// v_mfma_f32_32x32x16_bf16 wants 8 CONSECUTIVE k (= rows of A / B) per lane, so the 32-row slab is transposed on its
+// way into LDS: At[col][k], Bt[col][k] as bf16, hi and lo planes, 80-B column stride (conflict-free ds_read_b128).
+// A thread stages (row pair, 4 columns) items -- one packed u32 per column and plane; lanes run over 8 row pairs x 8
+// column granules, so global loads fetch whole 128-B lines and the transposing LDS writes are at most 2-way conflicted.
+// 120 MFMAs of 32 cycles per slab and block instead of 320 of 64.
+// ------------------------------------------------------------------------------------------------
+#define GB_RS 40          // bf16 elements per LDS column (32 k + 8 pad)
+
+typedef __bf16 gb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gb_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float gb_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void gb_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const gb_f32x2 x = {x0, x1};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, gb_bf16x2));
+    const gb_f32x2 hf = {__builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(x - hf, gb_bf16x2));
+}
+
+template <int TPW, bool SHARE_A>      // SHARE_A: MT == 4, a wave's tiles all sit in row tile w
+__global__ void __launch_bounds__(256)
+k_gemm_tn_bf16(const float* __restrict__ A, int lda, int M, const float* __restrict__ Bm, int ldb, int N, int ones_col,
+               int64_t n, float* __restrict__ C, int ldc, int64_t chunk) {
+    __shared__ __attribute__((aligned(16))) unsigned short At[2][128 * GB_RS];      // [hi / lo][column][k]
+    __shared__ __attribute__((aligned(16))) unsigned short Bt[2][160 * GB_RS];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int MT = (M + 31) / 32, NT = (N + ones_col + 31) / 32, T = MT * NT;
+    const int64_t s0 = (int64_t)blockIdx.x * chunk;
+    const int64_t s1 = min(n, s0 + chunk);
+    int ta[TPW], tb[TPW];                 // LDS columns of this wave's tiles (slots past T redo tile 0, unused)
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int t = (w + 4 * i < T) ? w + 4 * i : 0;
+        ta[i] = 32 * (t % MT) + li; tb[i] = 32 * (t / MT) + li;
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int a4 = (M + 3) >> 2, b4 = (N + ones_col + 3) >> 2, Np4 = (N + 3) >> 2;
+    // staging items of this wave: item w + 4 q of 8 (A: 2 row-pair halves x 4 granule blocks) + 10 (B: 2 x 5)
+    const int rp_l = lane & 7, g_l = lane >> 3;
+    float4 r0[5], r1[5];
+    auto item = [&](int q, bool& isA, int& rp, int& g) {
+        const int wi = w + 4 * q;
+        isA = wi < 8;
+        const int v = isA ? wi : wi - 8;
+        rp = 8 * (v & 1) + rp_l;                     // row pair 0..15 -> slab rows 2 rp, 2 rp + 1
+        g = 8 * (v >> 1) + g_l;                      // float4 granule (4 columns)
+        return wi < 18 && (isA ? g < a4 : g < b4);
+    };
+    auto fetch = [&](int64_t s) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            bool isA; int rp, g;
+            r0[q] = make_float4(0.f, 0.f, 0.f, 0.f); r1[q] = r0[q];
+            if (!item(q, isA, rp, g)) continue;
+            if (!isA && g >= Np4) continue;          // the granule that only holds the ones column
+            const float* src = isA ? A + (s + 2 * rp) * lda + 4 * g : Bm + (s + 2 * rp) * ldb + 4 * g;
+            const int ld = isA ? lda : ldb;
+            if (s + 2 * rp < s1) r0[q] = *reinterpret_cast<const float4*>(src);
+            if (s + 2 * rp + 1 < s1) r1[q] = *reinterpret_cast<const float4*>(src + ld);
+        }
+    };
+    auto stage = [&](int64_t s) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            bool isA; int rp, g;
+            if (!item(q, isA, rp, g)) continue;
+            const float x0[4] = {r0[q].x, r0[q].y, r0[q].z, r0[q].w}, x1[4] = {r1[q].x, r1[q].y, r1[q].z, r1[q].w};
+            const float one0 = (ones_col && s + 2 * rp < s1) ? 1.0f : 0.0f, one1 = (ones_col && s + 2 * rp + 1 < s1) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = 4 * g + j;
+                float v0 = x0[j], v1 = x1[j];
+                if (!isA && col >= N) { v0 = (col == N) ? one0 : 0.f; v1 = (col == N) ? one1 : 0.f; }   // padding / ones column
+                if (isA && col >= M) { v0 = 0.f; v1 = 0.f; }
+                unsigned hi, lo;
+                gb_split2(v0, v1, hi, lo);
+                unsigned* dh = reinterpret_cast<unsigned*>(isA ? At[0] : Bt[0]) + (col * GB_RS) / 2 + rp;
+                unsigned* dl = reinterpret_cast<unsigned*>(isA ? At[1] : Bt[1]) + (col * GB_RS) / 2 + rp;
+                *dh = hi; *dl = lo;
+            }
+        }
+    };
+    // columns never staged (beyond a4 / b4 granules) are read by the MFMAs of partial tiles: zero everything once
+    for (int e = threadIdx.x; e < 2 * 128 * GB_RS / 8; e += 256) reinterpret_cast<float4*>(&At[0][0])[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = threadIdx.x; e < 2 * 160 * GB_RS / 8; e += 256) reinterpret_cast<float4*>(&Bt[0][0])[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    fetch(s0);
+    __syncthreads();
+    for (int64_t s = s0; s < s1; s += 32) {
+        stage(s);
+        __syncthreads();
+        if (s + 32 < s1) fetch(s + 32);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int kb = 16 * ks + 8 * h;
+            gb_bf16x8 ah[TPW], al[TPW], bh[TPW], bl[TPW];
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                if (!SHARE_A || i == 0) {
+                    ah[i] = *reinterpret_cast<const gb_bf16x8*>(&At[0][ta[i] * GB_RS + kb]);
+                    al[i] = *reinterpret_cast<const gb_bf16x8*>(&At[1][ta[i] * GB_RS + kb]);
+                } else { ah[i] = ah[0]; al[i] = al[0]; }
+                bh[i] = *reinterpret_cast<const gb_bf16x8*>(&Bt[0][tb[i] * GB_RS + kb]);
+                bl[i] = *reinterpret_cast<const gb_bf16x8*>(&Bt[1][tb[i] * GB_RS + kb]);
+            }
+            // product-major: never two consecutive MFMAs on one accumulator
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[i], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[i], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[i], acc[i], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int t = w + 4 * i;
+        const int jcol = 32 * (t / MT) + li;
+        const int row0 = 32 * (t % MT) + 4 * h;
+        const bool col_ok = t < T && jcol < N + ones_col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2);
+            if (col_ok && row < M) atomic_add_f32(C + (size_t)row * ldc + jcol, acc[i][r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Shading backward: one wave per surface point, lanes over light directions.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void normalize3(float& x, float& y, float& z, float eps) {
@@ -1250,8 +1386,8 @@ extern "C" int tir_vm_app_bwd(const TirField* f, const TirFieldGrad* g, const fl
     return TIR_OK;
 }
 
-extern "C" int tir_gemm_tn(const float* A, int32_t lda, int32_t M, const float* B, int32_t ldb, int32_t N,
-                           int32_t ones_col, int64_t n, float* C, int32_t ldc, void* stream) {
+static int gemm_tn_launch(bool bf16, const float* A, int32_t lda, int32_t M, const float* B, int32_t ldb, int32_t N,
+                          int32_t ones_col, int64_t n, float* C, int32_t ldc, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || n < 0) return TIR_ERR_ARG;
     ones_col = ones_col ? 1 : 0;
     if (M > 128 || N + ones_col > 160) return TIR_ERR_UNSUPPORTED;
@@ -1261,12 +1397,32 @@ extern "C" int tir_gemm_tn(const float* A, int32_t lda, int32_t M, const float* 
     chunk = (chunk + 31) / 32 * 32;
     if (chunk < 128) chunk = 128;
     const unsigned blocks = (unsigned)((n + chunk - 1) / chunk);
-    const int tiles = ((M + 31) / 32) * ((N + ones_col + 31) / 32);
-    if (tiles <= 4)      hipLaunchKernelGGL(k_gemm_tn<1>, dim3(blocks), dim3(256), 0, tir_stream(stream), A, lda, M, B, ldb, N, ones_col, n, C, ldc, chunk);
-    else if (tiles <= 8) hipLaunchKernelGGL(k_gemm_tn<2>, dim3(blocks), dim3(256), 0, tir_stream(stream), A, lda, M, B, ldb, N, ones_col, n, C, ldc, chunk);
-    else                 hipLaunchKernelGGL(k_gemm_tn<5>, dim3(blocks), dim3(256), 0, tir_stream(stream), A, lda, M, B, ldb, N, ones_col, n, C, ldc, chunk);
+    const int mt = (M + 31) / 32, tiles = mt * ((N + ones_col + 31) / 32);
+    hipStream_t s = tir_stream(stream);
+#define TIR_GEMM_ARGS A, lda, M, B, ldb, N, ones_col, n, C, ldc, chunk
+    if (bf16) {
+        if (tiles <= 4)      hipLaunchKernelGGL((k_gemm_tn_bf16<1, false>), dim3(blocks), dim3(256), 0, s, TIR_GEMM_ARGS);
+        else if (tiles <= 8) hipLaunchKernelGGL((k_gemm_tn_bf16<2, false>), dim3(blocks), dim3(256), 0, s, TIR_GEMM_ARGS);
+        else if (mt == 4)    hipLaunchKernelGGL((k_gemm_tn_bf16<5, true>), dim3(blocks), dim3(256), 0, s, TIR_GEMM_ARGS);
+        else                 hipLaunchKernelGGL((k_gemm_tn_bf16<5, false>), dim3(blocks), dim3(256), 0, s, TIR_GEMM_ARGS);
+    } else {
+        if (tiles <= 4)      hipLaunchKernelGGL(k_gemm_tn<1>, dim3(blocks), dim3(256), 0, s, TIR_GEMM_ARGS);
+        else if (tiles <= 8) hipLaunchKernelGGL(k_gemm_tn<2>, dim3(blocks), dim3(256), 0, s, TIR_GEMM_ARGS);
+        else                 hipLaunchKernelGGL(k_gemm_tn<5>, dim3(blocks), dim3(256), 0, s, TIR_GEMM_ARGS);
+    }
+#undef TIR_GEMM_ARGS
     TIR_CHECK_LAUNCH();
     return TIR_OK;
+}
+
+extern "C" int tir_gemm_tn(const float* A, int32_t lda, int32_t M, const float* B, int32_t ldb, int32_t N,
+                           int32_t ones_col, int64_t n, float* C, int32_t ldc, void* stream) {
+    return gemm_tn_launch(false, A, lda, M, B, ldb, N, ones_col, n, C, ldc, stream);
+}
+
+extern "C" int tir_gemm_tn_bf16x3(const float* A, int32_t lda, int32_t M, const float* B, int32_t ldb, int32_t N,
+                                  int32_t ones_col, int64_t n, float* C, int32_t ldc, void* stream) {
+    return gemm_tn_launch(true, A, lda, M, B, ldb, N, ones_col, n, C, ldc, stream);
 }
 
 extern "C" int tir_shade_integrate_bwd(const float* maps, const float* rays, const float* dirs,

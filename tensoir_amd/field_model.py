@@ -36,6 +36,20 @@ def safe_l2_normalize(x, dim=None, eps=1e-6):
     return F.normalize(x, p=2, dim=dim, eps=eps)
 
 
+def _host_values(owner, name, tensors, build):
+    """Host copies of small device tensors (aabb, grid size, step size ...) without a device round trip per call:
+    `.tolist()` / `float()` on a device tensor waits for everything queued before it, which stalls the launch queue
+    once per step.  The copy is redone only when a tensor object, its storage or its version counter changes."""
+    key = tuple((id(t), t.data_ptr(), t._version) for t in tensors)
+    cache = owner.__dict__.get("_host_cache")
+    if cache is None:
+        cache = owner.__dict__["_host_cache"] = {}
+    hit = cache.get(name)
+    if hit is None or hit[0] != key:
+        hit = cache[name] = (key, build(), tensors)      # keeps the tensors alive: ids stay unique
+    return hit[1]
+
+
 def channel_last(t):
     """[1,C,H,W] values stored as [H,W,C] in memory -- the layout the kernels gather from.  VM plane / line
     parameters are created like this, so a parameter IS its packed form: no shadow copy after every optimizer step,
@@ -82,9 +96,12 @@ class AlphaGridMask(nn.Module):
         f.occ_nbr = self.bits().data_ptr()
         D, H, W = self.alpha_volume.shape[-3:]
         f.occ_dim[:] = [W, H, D]
-        f.occ_aabb_min[:] = self.aabb[0].tolist()
-        f.occ_inv[:] = self.invgridSize.tolist()
+        f.occ_aabb_min[:], f.occ_inv[:] = self.host_geometry()
         return f
+
+    def host_geometry(self):
+        return _host_values(self, "geom", (self.aabb, self.invgridSize),
+                            lambda: (self.aabb[0].tolist(), self.invgridSize.tolist()))
 
     def sample_alpha(self, xyz_sampled):
         """Returns 1.0 where the reference's trilinear lookup is > 0 and 0.0 elsewhere (callers only
@@ -331,7 +348,7 @@ class TensorVMSplit(nn.Module):
 
     def get_light_rgbs(self, incident_light_directions=None, device="cuda"):
         """models/tensorBase_rotated_lights.py:577-606 (sg): dirs [D,3] -> [L,D,3] via tir_env_sg_fwd."""
-        dirs = incident_light_directions.to(device).reshape(-1, 3).to(torch.float32).contiguous()
+        dirs = ops.to_device(incident_light_directions, device, torch.float32).reshape(-1, 3).to(torch.float32).contiguous()
         rot = self.__dict__.get("_rot_dev")
         if rot is None or rot.device != dirs.device:
             rot = self.light_rotation_matrix.to(dirs.device).contiguous()
@@ -429,11 +446,10 @@ class TensorVMSplit(nn.Module):
             raise TensoirHipError("per-plane component counts must be equal for the gfx950 kernels")
         keep = {}
         f = TirField()
-        f.aabb_min[:] = self.aabb[0].tolist()
-        f.aabb_max[:] = self.aabb[1].tolist()
-        f.inv_aabb[:] = self.invaabbSize.tolist()
-        f.grid[:] = [int(g) for g in self.gridSize.tolist()]
-        f.step_size = float(self.stepSize)
+        g = _host_values(self, "geom", (self.aabb, self.invaabbSize, self.gridSize, self.stepSize),
+                         lambda: (self.aabb[0].tolist(), self.aabb[1].tolist(), self.invaabbSize.tolist(),
+                                  [int(v) for v in self.gridSize.tolist()], float(self.stepSize)))
+        f.aabb_min[:], f.aabb_max[:], f.inv_aabb[:], f.grid[:], f.step_size = g
         f.distance_scale = float(self.distance_scale)
         f.density_shift = float(self.density_shift)
         f.weight_thres = float(self.rayMarch_weight_thres)
@@ -458,8 +474,7 @@ class TensorVMSplit(nn.Module):
             f.occ_nbr = keep["bits"].data_ptr()
             D, H, W = mask.alpha_volume.shape[-3:]
             f.occ_dim[:] = [W, H, D]
-            f.occ_aabb_min[:] = mask.aabb[0].tolist()
-            f.occ_inv[:] = mask.invgridSize.tolist()
+            f.occ_aabb_min[:], f.occ_inv[:] = mask.host_geometry()
         keep["desc"] = f
         self._field_cache, self._field_key = keep, key
         return f
@@ -570,7 +585,7 @@ class TensorVMSplit(nn.Module):
         if is_train:
             rng = rng.repeat(rays_d.shape[-2], 1)
             rng += torch.rand_like(rng[:, [0]])
-        step = self.stepSize * rng.to(rays_o.device)
+        step = self.stepSize * ops.to_device(rng, rays_o.device)
         interpx = t_min[..., None] + step
         rays_pts = rays_o[..., None, :] + rays_d[..., None, :] * interpx[..., None]
         mask_outbbox = ((self.aabb[0] > rays_pts) | (rays_pts > self.aabb[1])).any(dim=-1)
@@ -665,9 +680,9 @@ class TensorVMSplit(nn.Module):
         B = rays.shape[0]
         S = N_samples if N_samples > 0 else self.nSamples
         f = self.packed_field()
-        lidx = light_idx.reshape(-1).to(dev, torch.int32).contiguous()
+        lidx = ops.to_device(light_idx.reshape(-1), dev, torch.int32).contiguous()
         # RNG draws in the reference's order and on the reference's devices (:717 CPU, :937 device, :1004 CPU)
-        jitter = torch.rand(B, 1).to(dev) if is_train else None
+        jitter = ops.to_device(torch.rand(B, 1), dev) if is_train else None
         from . import training
         if training.wants_grad(self):
             # training step: the same launches with the activations kept, and a hand-written backward

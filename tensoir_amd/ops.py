@@ -83,6 +83,17 @@ def i32(t, name):
     return _req(t, torch.int32, name)
 
 
+def to_device(t, device, dtype=None):
+    """`t.to(device, dtype)` that does not stall the launch queue: a host tensor goes through pinned memory and a
+    non-blocking copy (a pageable-memory copy waits for everything queued on the stream before it returns)."""
+    device = torch.device(device)
+    if t.device.type == "cpu" and device.type == "cuda":
+        if dtype is not None and t.dtype != dtype:
+            t = t.to(dtype)
+        return t.contiguous().pin_memory().to(device, non_blocking=True)
+    return t.to(device) if dtype is None else t.to(device, dtype)
+
+
 # ---- packing ------------------------------------------------------------------------------------
 def pack_plane(src):
     """[1,C,H,W] (or [C,H,W]) -> channel-last [H,W,C]."""
@@ -609,13 +620,15 @@ def mlp_bwd(m: "PackedMlp", packed_bwd, feat, out, g_out, h1, h2):
     return g_feat, dz1, dz2, dz3
 
 
-def gemm_tn(A, M, B, N, C_out, ones_col=False):
-    """C_out[M, N(+1)] += A[:, :M]^T @ B[:, :N]  (+ column N = A^T 1)."""
+def gemm_tn(A, M, B, N, C_out, ones_col=False, impl=None):
+    """C_out[M, N(+1)] += A[:, :M]^T @ B[:, :N]  (+ column N = A^T 1).  Split-bf16 matrix cores when the product's
+    decoder mode is bf16x3 (default), exact fp32 MFMA otherwise."""
+    impl = impl or MLP_IMPL
     A, B = f32(A, "A"), f32(B, "B")
     n = A.shape[0]
     if B.shape[0] != n:
         raise ValueError("gemm_tn: row counts differ")
-    _call("tir_gemm_tn", _ptr(A), A.shape[1], int(M), _ptr(B), B.shape[1], int(N), int(bool(ones_col)), n,
+    _call("tir_gemm_tn_bf16x3" if impl == "bf16x3" else "tir_gemm_tn", _ptr(A), A.shape[1], int(M), _ptr(B), B.shape[1], int(N), int(bool(ones_col)), n,
           _ptr(C_out), C_out.shape[1], _stream())
     return C_out
 

@@ -172,12 +172,12 @@ def shade_from_maps(tensoIR, maps, rays, light_idx, sample_method="fixed_envirma
     Rows with acc <= acc_thres are background: no secondary rays, white output (renderer.py:86-106)."""
     dev = maps.device
     M = maps.shape[0]
-    rays = rays.to(dev, torch.float32).contiguous()
-    li = light_idx.reshape(-1).to(dev, torch.int32).contiguous()
+    rays = ops.to_device(rays, dev, torch.float32).contiguous()
+    li = ops.to_device(light_idx.reshape(-1), dev, torch.int32).contiguous()
     if sample_method == "fixed_envirmap":
         dirs = _on_device(tensoIR, "fixed_viewdirs", tensoIR.fixed_viewdirs, dev)
     else:
-        dirs = tensoIR.gen_light_incident_dirs(method=sample_method).to(dev, torch.float32).contiguous()
+        dirs = ops.to_device(tensoIR.gen_light_incident_dirs(method=sample_method), dev, torch.float32).contiguous()
     D = dirs.shape[0]
     area = _on_device(tensoIR, "light_area_weight", tensoIR.light_area_weight, dev)
     z = _z_table(int(args.second_nSample), args.second_near, args.second_far, dev)

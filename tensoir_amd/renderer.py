@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import torch
 
-from . import relight
+from . import ops, relight
 
 
 def Renderer_TensoIR_train(rays=None, normal_gt=None, light_idx=None, tensoIR=None, N_samples=-1, ndc_ray=False,
@@ -11,8 +11,8 @@ def Renderer_TensoIR_train(rays=None, normal_gt=None, light_idx=None, tensoIR=No
                            chunk_size=15000, device="cuda", args=None):
     """renderer.py:57-127: primary pass + physically-based re-render of the rays with acc > 0.5.
     Same signature and the same 12-key dict."""
-    rays = rays.to(device)
-    light_idx = light_idx.to(device, torch.int32)
+    rays = ops.to_device(rays, device)
+    light_idx = ops.to_device(light_idx, device, torch.int32)
     from . import training
     infer = not training.wants_grad(tensoIR)
     for attempt in range(2):
@@ -21,7 +21,7 @@ def Renderer_TensoIR_train(rays=None, normal_gt=None, light_idx=None, tensoIR=No
             tensoIR(rays, light_idx, is_train=is_train, white_bg=white_bg, is_relight=is_relight, ndc_ray=ndc_ray,
                     N_samples=N_samples, _return_maps=True, _defer_check=infer and attempt == 0)
         if tensoIR.normals_kind == "gt_normals" and normal_gt is not None:
-            normal_map = normal_gt.to(device)
+            normal_map = ops.to_device(normal_gt, device)
         if is_relight:
             # all rays go through the shading kernels; rows with acc <= 0.5 (acc_mask, :1031) spawn no secondary
             # rays and get the white background (renderer.py:86-106) -- no boolean-mask compaction, no host sync

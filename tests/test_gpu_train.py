@@ -45,19 +45,25 @@ def T(g, k):
 
 
 # ------------------------------------------------------------------ building blocks
-def test_gemm_tn(env):
+@pytest.mark.parametrize("impl,tol", [("mfma", 1e-5), ("bf16x3", 3e-5)])
+def test_gemm_tn(env, impl, tol):
+    """Weight-gradient product C += A^T B: exact fp32 MFMA, and the split-bf16 (3-product) version whose error per
+    product is ~2^-16 (the tolerance is relative to max |C|)."""
     from tensoir_amd import ops
     gen = torch.Generator().manual_seed(3)
     for n, M, N, lda, ldb, ones in ((1000, 128, 150, 128, 160, True), (777, 27, 144, 32, 144, False),
-                                    (5, 4, 128, 4, 128, True), (70000, 128, 128, 128, 128, True)):
+                                    (5, 4, 128, 4, 128, True), (70000, 128, 128, 128, 128, True),
+                                    (33, 100, 7, 100, 8, True), (4097, 128, 150, 132, 152, False)):
         A = torch.randn(n, lda, generator=gen)
         B = torch.randn(n, ldb, generator=gen)
+        A[:, M:] = float("nan")                 # row padding must never leak into C
+        B[:, N:] = float("nan")
         C = torch.zeros(M, N + (1 if ones else 0) + 3).cuda()
-        ops.gemm_tn(A.cuda(), M, B.cuda(), N, C, ones)
+        ops.gemm_tn(A.cuda(), M, B.cuda(), N, C, ones, impl=impl)
         ref = A[:, :M].double().T @ B[:, :N].double()
-        assert gerr(C[:, :N], ref) < 1e-5, (n, M, N)
+        assert gerr(C[:, :N], ref) < tol, (n, M, N)
         if ones:
-            assert gerr(C[:, N], A[:, :M].double().sum(0)) < 1e-5
+            assert gerr(C[:, N], A[:, :M].double().sum(0)) < tol
         assert float(C[:, N + (1 if ones else 0):].abs().max()) == 0.0
 
 

@@ -18,6 +18,7 @@ ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--samples", type=int, default=512)
 ap.add_argument("--grid", type=int, default=300)
 ap.add_argument("--relight", type=int, default=1)
+ap.add_argument("--cprofile", type=int, default=0, help="print the N hottest host functions of 10 steps (stderr)")
 a = ap.parse_args()
 a.env_h, a.env_w, a.second_samples = 8, 16, 96
 dev = torch.device("cuda", 0)
@@ -52,6 +53,15 @@ for _ in range(a.steps):
     l1 = step()
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
+if a.cprofile:
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize(); pr.disable()
+    st = pstats.Stats(pr, stream=sys.stderr)
+    st.sort_stats("tottime").print_stats(a.cprofile)
+    st.sort_stats("cumtime").print_stats(a.cprofile)
 ops.TIMING = []
 for _ in range(3):
     step()
