@@ -388,11 +388,11 @@ int tir_vm_app_bwd(const TirField* f, const TirFieldGrad* g, const float* xyz,
 /* Decoder forward that also stores the post-ReLU hidden activations h1, h2 [n][hidden] (exact fp32 MFMA). */
 int tir_mlp_train_fwd(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
                       const int32_t* aux_map, int32_t aux_mod, float* out, float* h1, float* h2,
-                      int64_t n, void* stream);
+                      int64_t n, const int32_t* n_dev, void* stream);
 /* same on the split-bf16 matrix-core kernel (the product's default decoder precision; ~4x faster than exact fp32) */
 int tir_mlp_train_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
                              const int32_t* aux_map, int32_t aux_mod, float* out, float* h1, float* h2,
-                             int64_t n, void* stream);
+                             int64_t n, const int32_t* n_dev, void* stream);
 /* decoder input rows [n][160] = [feat, aux, PE(feat), PE(aux), 0-pad]  (right operand of d W0) */
 int tir_mlp_inputs(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
                    const int32_t* aux_map, int32_t aux_mod, float* x, int64_t n, void* stream);

@@ -97,8 +97,8 @@ SIGNATURES = {
     "tir_march_primary_bwd": (C.c_int, [C.POINTER(TirField), C.POINTER(TirFieldGrad), P, P, I32, I32, P, P, P, P, P, P, P]),
     "tir_density_grad_bwd": (C.c_int, [C.POINTER(TirField), C.POINTER(TirFieldGrad), P, P, I64, P]),
     "tir_vm_app_bwd": (C.c_int, [C.POINTER(TirField), C.POINTER(TirFieldGrad), P, P, P, P, P, I32, I64, P, P, P]),
-    "tir_mlp_train_fwd": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, P, P, I64, P]),
-    "tir_mlp_train_fwd_bf16x3": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, P, P, I64, P]),
+    "tir_mlp_train_fwd": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, P, P, I64, P, P]),
+    "tir_mlp_train_fwd_bf16x3": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, P, P, I64, P, P]),
     "tir_mlp_inputs": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P]),
     "tir_mlp_bwd_packed_floats": (I64, [I32, I32, I32, I32]),
     "tir_pack_mlp_bwd": (C.c_int, [P, P, P, I32, I32, I32, I32, P, P]),

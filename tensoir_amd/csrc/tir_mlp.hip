@@ -860,7 +860,7 @@ extern "C" int tir_mlp_fwd(const TirMlp* m, const float* feat, int32_t feat_stri
 
 extern "C" int tir_mlp_train_fwd(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
                                  const int32_t* aux_map, int32_t aux_mod, float* out, float* h1, float* h2,
-                                 int64_t n, void* stream) {
+                                 int64_t n, const int32_t* n_dev, void* stream) {
     int rc = check_mlp(m);
     if (rc) return rc;
     if (n < 0 || feat_stride < F || (n > 0 && (!feat || !aux || !out || !h1 || !h2))) return TIR_ERR_ARG;
@@ -876,7 +876,7 @@ extern "C" int tir_mlp_train_fwd(const TirMlp* m, const float* feat, int32_t fea
     int64_t tiles = (n + 255) / 256;
     unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
     hipLaunchKernelGGL(k_mlp_mfma<true>, dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, feat_stride, aux,
-                       aux_map, aux_mod, out, n, (const int32_t*)nullptr, m->out_dim, m->act, h1, h2);
+                       aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act, h1, h2);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
@@ -915,14 +915,14 @@ static int launch_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, 
 
 extern "C" int tir_mlp_train_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
                                         const int32_t* aux_map, int32_t aux_mod, float* out, float* h1, float* h2,
-                                        int64_t n, void* stream) {
+                                        int64_t n, const int32_t* n_dev, void* stream) {
     int rc = check_mlp(m);
     if (rc) return rc;
     if (n < 0 || feat_stride < F || (n > 0 && (!feat || !aux || !out || !h1 || !h2))) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
     const bool vec = (feat_stride % 4 == 0) && feat_stride >= F + 1 && (reinterpret_cast<uintptr_t>(feat) % 16 == 0);
-    return vec ? launch_bf16_v<3, true, true>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, nullptr, stream, h1, h2)
-               : launch_bf16_v<3, false, true>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, nullptr, stream, h1, h2);
+    return vec ? launch_bf16_v<3, true, true>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream, h1, h2)
+               : launch_bf16_v<3, false, true>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream, h1, h2);
 }
 
 extern "C" int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map, int32_t aux_mod,

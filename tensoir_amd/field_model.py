@@ -688,8 +688,15 @@ class TensorVMSplit(nn.Module):
             # training step: the same launches with the activations kept, and a hand-written backward
             # (tensoir_amd/training.py); torch.autograd only links the fused stages
             bg = bool(white_bg or (is_train and torch.rand((1,)) < 0.5))
-            maps = training.PrimaryRenderFn.apply(self, rays, lidx, S, bg, bool(is_relight), jitter,
-                                                  _brdf_jitter_dense, *training.field_param_list(self))
+            for attempt in range(2):
+                try:
+                    maps = training.PrimaryRenderFn.apply(self, rays, lidx, S, bg, bool(is_relight), jitter,
+                                                          _brdf_jitter_dense, bool(_defer_check),
+                                                          *training.field_param_list(self))
+                    break
+                except training._CapacityOverflow:     # hint dropped: the second attempt counts exactly
+                    if attempt:
+                        raise
             out = self.unpack_maps(maps, is_relight)
             return (out, maps) if _return_maps else out
         # Record capacity: the number A of w > thres samples is only known on the device.  The first call per

@@ -567,9 +567,10 @@ def vm_app_bwd(field: TirField, grad: TirFieldGrad, xyz, light_idx, idx_map, g_r
     return y_rad, y_int
 
 
-def mlp_train(m: "PackedMlp", feat, aux, aux_map=None, aux_mod=0, impl=None):
+def mlp_train(m: "PackedMlp", feat, aux, aux_map=None, aux_mod=0, impl=None, n_dev=None):
     """Decoder forward that also returns the hidden activations (h1, h2) [n,128]: split-bf16 matrix cores when the
-    product's decoder mode is bf16x3 (default), exact fp32 MFMA otherwise."""
+    product's decoder mode is bf16x3 (default), exact fp32 MFMA otherwise.  n_dev: device-side row count (rows past
+    it are left unwritten)."""
     impl = impl or MLP_IMPL
     feat = f32(feat, "feat")
     aux = f32(aux, "aux", 3)
@@ -580,7 +581,7 @@ def mlp_train(m: "PackedMlp", feat, aux, aux_map=None, aux_mod=0, impl=None):
     h1 = torch.empty((n, 128), dtype=torch.float32, device=feat.device)
     h2 = torch.empty((n, 128), dtype=torch.float32, device=feat.device)
     _call("tir_mlp_train_fwd_bf16x3" if impl == "bf16x3" else "tir_mlp_train_fwd", C.byref(m.desc), _ptr(feat),
-          feat.shape[1], _ptr(aux), _ptr(aux_map), int(aux_mod), _ptr(out), _ptr(h1), _ptr(h2), n, _stream())
+          feat.shape[1], _ptr(aux), _ptr(aux_map), int(aux_mod), _ptr(out), _ptr(h1), _ptr(h2), n, _ptr(n_dev), _stream())
     return out, h1, h2
 
 

@@ -42,7 +42,7 @@ def _rec_capacity(n_rays):
 
 
 def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, light_idx, light_div,
-               want_indirect, want_nerfactor=False, n_dirs=0, keep_records=False, ids=None):
+               want_indirect, want_nerfactor=False, n_dirs=0, keep_records=False, ids=None, defer=False):
     """Shared driver of compute_transmittance / compute_radiance / render_with_BRDF:
     march (+ record the w > thres samples) -> appearance gather -> radiance decoder -> per-ray sum.
 
@@ -95,6 +95,16 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
             break
         if capture is not None:                        # HIP-graph capture: the graph owner reads the counter after replay
             capture.append((n_total, cap, ("secondary", n_rays)))
+            return vis, oma, indirect
+        if defer:                                      # the caller checks after ITS remaining launches are queued too
+            def check(n_total=n_total, cap=cap):
+                total = int(n_total.item())
+                if total > cap:
+                    hints.pop(n_rays, None)            # the re-run learns the count first
+                    return False
+                hints[n_rays] = max(int(total * 1.5) + 4096, 1 << 14)
+                return True
+            tensoIR.__dict__.setdefault("_pending_checks", []).append(check)
             return vis, oma, indirect
         total = int(n_total.item())                    # everything is queued: this wait costs no GPU idle time
         if total <= cap:
@@ -166,8 +176,16 @@ def _maps_from_parts(depth_map, normal_map, albedo_map, roughness_map, fresnel_m
     return maps
 
 
+def finish_pending(tensoIR):
+    """Run the deferred record-capacity checks of the shading stage; False = something overflowed (re-run the pass)."""
+    ok = True
+    for check in tensoIR.__dict__.pop("_pending_checks", []):
+        ok = check() and ok
+    return ok
+
+
 def shade_from_maps(tensoIR, maps, rays, light_idx, sample_method="fixed_envirmap", args=None,
-                    use_linear2srgb=True, acc_thres=-1e30, return_aux=False):
+                    use_linear2srgb=True, acc_thres=-1e30, return_aux=False, _defer_check=False):
     """The body of render_with_BRDF (models/relight_utils.py:417-480) on packed [M,20] map rows.
     Rows with acc <= acc_thres are background: no secondary rays, white output (renderer.py:86-106)."""
     dev = maps.device
@@ -195,7 +213,7 @@ def shade_from_maps(tensoIR, maps, rays, light_idx, sample_method="fixed_envirma
         surf, active, pair_ids, vis0, cnt0 = ops.shade_setup_compact(maps.detach(), rays, dirs, acc_thres, n_active)
         ids = {"pair_ids": pair_ids, "n_active": n_active, "vis": vis0, "rec_cnt": cnt0}
         vis, _, ind = _secondary(tensoIR, surf, dirs, M * D, z, None, None, None, li, D, True, False, D,
-                                 keep_records=fuse, ids=ids)
+                                 keep_records=fuse, ids=ids, defer=_defer_check)
     env = tensoIR.get_light_rgbs(dirs, device=dev)
     equal_area = sample_method == "stratifed_sample_equal_areas"
     w_d = None if equal_area else area

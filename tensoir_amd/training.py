@@ -18,7 +18,7 @@ from types import SimpleNamespace
 import torch
 
 from . import ops
-from ._lib import TirFieldGrad
+from ._lib import TensoirHipError, TirFieldGrad
 
 
 def field_param_list(model):
@@ -97,52 +97,124 @@ def _decoder_backward(dec, calls):
     return g_feats, grads
 
 
+class _CapacityOverflow(RuntimeError):
+    """The record buffers sized from the previous step were too small: the forward is re-run with an exact count."""
+
+
+class _FinishOnce:
+    """Deferred end-of-forward bookkeeping of one PrimaryRenderFn pass (runs at most once)."""
+
+    def __init__(self, st):
+        self.st, self.result = st, None
+
+    def __call__(self):
+        if self.result is None:
+            fin, self.st.finish = self.st.finish, None
+            self.result = True if fin is None else fin()
+        return self.result
+
+
+def _trim_state(st, total):
+    """Capacity-sized saved buffers -> exact [:total] views for the backward."""
+    st.A = total
+    for name in ("rec_ray", "rec_k", "rec_w", "rec_xyz", "rgb", "brdf", "brdf_j", "pred", "derived", "xyz_j"):
+        t = getattr(st, name, None)
+        if t is not None:
+            setattr(st, name, t[:total])
+    for c in st.calls.values():
+        for name in ("feat", "aux", "out", "h1", "h2"):
+            t = getattr(c, name)
+            if t is not None and not (name == "aux" and c.aux_map is not None):
+                setattr(c, name, t[:total])
+        if c.aux_map is not None:
+            c.aux_map = c.aux_map[:total]
+
+
 class PrimaryRenderFn(torch.autograd.Function):
     """march -> scan -> compact -> appearance gather -> decoders -> analytic normals -> composite, with a
     hand-written backward for every link."""
 
     @staticmethod
-    def forward(ctx, model, rays, lidx, S, white_bg, is_relight, jitter, noise_dense, *params):
+    def forward(ctx, model, rays, lidx, S, white_bg, is_relight, jitter, noise_dense, defer, *params):
+        """Record capacity as in the inference forward (field_model.forward): the number A of w > thres samples lives
+        on the device.  With a capacity learnt from the previous step the buffers are sized cap rows, every kernel is
+        bounded by the device-side count, and A is read once everything has been queued (`finish`; when `defer` the
+        caller -- Renderer_TensoIR_train -- calls it after its shading stage is queued too).  The backward runs on
+        the exact [:A] views."""
         f = model.packed_field()
         dev = rays.device
+        B = rays.shape[0]
         weight, sigma, acc, depth, _tend, cnt = ops.march_primary_train(f, rays, jitter, S, model.march_t_stop)
-        offsets = ops.exclusive_scan(cnt)
-        A = int(offsets[-1].item())
+        hints = model.__dict__.setdefault("_train_cap_hints", {})
+        cap = hints.get((B, S)) if noise_dense is None else None
+        if cap is None:
+            offsets = ops.exclusive_scan(cnt)
+            A = int(offsets[-1].item())                    # first step of a batch shape: one host sync mid-pass
+            n_dev = total_dev = None
+        else:
+            offsets, total_dev = ops.exclusive_scan_capped(cnt, cap)
+            A, n_dev = cap, offsets[B:]
         rec_ray, rec_k, rec_w, rec_xyz = ops.compact_primary(f, rays, jitter, weight, offsets, A)
         st = SimpleNamespace(model=model, rays=rays, lidx=lidx, S=S, white_bg=white_bg, is_relight=is_relight,
                              jitter=jitter, weight=weight, sigma=sigma, acc=acc, depth=depth, offsets=offsets, A=A,
-                             rec_ray=rec_ray, rec_k=rec_k, rec_w=rec_w, rec_xyz=rec_xyz, calls={}, n_params=len(params))
+                             rec_ray=rec_ray, rec_k=rec_k, rec_w=rec_w, rec_xyz=rec_xyz, calls={}, n_params=len(params),
+                             xyz_j=None, valid=True)
         rgb = brdf = brdf_j = pred = derived = None
         if A > 0:
             viewdirs = rays[:, 3:6].contiguous()
-            rad, intr = ops.vm_app(f, rec_xyz, lidx, rec_ray, True, bool(is_relight))
-            rgb, h1, h2 = ops.mlp_train(model.renderModule.packed(), rad, viewdirs, rec_ray)
+            rad, intr = ops.vm_app(f, rec_xyz, lidx, rec_ray, True, bool(is_relight), None, 0, n_dev)
+            rgb, h1, h2 = ops.mlp_train(model.renderModule.packed(), rad, viewdirs, rec_ray, n_dev=n_dev)
             st.calls["rgb"] = _DecoderCall(feat=rad, aux=viewdirs, aux_map=rec_ray, out=rgb, h1=h1, h2=h2)
             if is_relight:
                 pb = model.renderModule_brdf.packed()
-                brdf, h1, h2 = ops.mlp_train(pb, intr, rec_xyz)
+                brdf, h1, h2 = ops.mlp_train(pb, intr, rec_xyz, n_dev=n_dev)
                 st.calls["brdf"] = _DecoderCall(feat=intr, aux=rec_xyz, aux_map=None, out=brdf, h1=h1, h2=h2)
                 if noise_dense is not None:
                     noise = noise_dense.to(dev, torch.float32)[rec_ray.long(), rec_k.long()]
                 else:
                     noise = torch.randn((A, 3), device=dev, dtype=torch.float32)
                 xyz_j = rec_xyz + noise * 0.01
-                intr_j = ops.vm_app(f, xyz_j, None, None, False, True)[1]
-                brdf_j, h1, h2 = ops.mlp_train(pb, intr_j, xyz_j)
+                intr_j = ops.vm_app(f, xyz_j, None, None, False, True, None, 0, n_dev)[1]
+                brdf_j, h1, h2 = ops.mlp_train(pb, intr_j, xyz_j, n_dev=n_dev)
                 st.calls["brdf_j"] = _DecoderCall(feat=intr_j, aux=xyz_j, aux_map=None, out=brdf_j, h1=h1, h2=h2)
                 st.xyz_j = xyz_j
                 if model.normals_kind == "purely_derived":
-                    pred = ops.density_grad(f, rec_xyz)[2]
+                    pred = ops.density_grad(f, rec_xyz, n_dev=n_dev)[2]
                 else:
-                    pred, h1, h2 = ops.mlp_train(model.renderModule_normal.packed(), intr, rec_xyz)
+                    pred, h1, h2 = ops.mlp_train(model.renderModule_normal.packed(), intr, rec_xyz, n_dev=n_dev)
                     st.calls["normal"] = _DecoderCall(feat=intr, aux=rec_xyz, aux_map=None, out=pred, h1=h1, h2=h2)
                     if model.normals_kind == "derived_plus_predicted":
-                        derived = ops.density_grad(f, rec_xyz)[2]
+                        derived = ops.density_grad(f, rec_xyz, n_dev=n_dev)[2]
         st.rgb, st.brdf, st.brdf_j, st.pred, st.derived = rgb, brdf, brdf_j, pred, derived
         maps = ops.composite_primary(rays, offsets, rec_w, rgb, brdf, brdf_j, pred, derived, acc, depth,
                                      white_bg, is_relight, model.fixed_fresnel)
         if model.normals_kind == "purely_derived" and is_relight:
             maps[:, 16] = 0.0
+
+        def finish():
+            """Read the record count; trim the saved rows to it.  False = the capacity overflowed (re-run the pass)."""
+            if total_dev is None:
+                total = A
+            else:
+                total = int(total_dev.item())
+                if total > cap:
+                    hints.pop((B, S), None)            # next call takes the exact (synchronising) route
+                    st.valid = False
+                    return False
+                _trim_state(st, total)
+            if len(hints) > 64:
+                hints.clear()
+            if noise_dense is None:
+                hints[(B, S)] = min(max(int(total * 1.25) + 4096, 1 << 14), B * S)
+            return True
+
+        st.finish = None if total_dev is None else finish
+        if total_dev is None:
+            finish()
+        elif defer:
+            model.__dict__["_pending_primary"] = _FinishOnce(st)
+        elif not _FinishOnce(st)():
+            raise _CapacityOverflow()
         ctx.st = st
         return maps
 
@@ -150,6 +222,13 @@ class PrimaryRenderFn(torch.autograd.Function):
     def backward(ctx, g_maps):
         st = ctx.st
         model = st.model
+        if st.finish is not None:                          # nobody ran the deferred check: do it now
+            pend = model.__dict__.get("_pending_primary")
+            ok = pend() if isinstance(pend, _FinishOnce) and pend.st is st else _FinishOnce(st)()
+            if not ok:
+                raise TensoirHipError("record capacity overflowed in the training forward and the pass was not re-run")
+        if not st.valid:
+            raise TensoirHipError("backward through a training forward whose record capacity overflowed")
         f = model.packed_field()
         g_maps = g_maps.contiguous().to(torch.float32)
         if model.normals_kind == "purely_derived" and st.is_relight:
@@ -197,7 +276,7 @@ class PrimaryRenderFn(torch.autograd.Function):
             grads += dec_grads.get(key, [None] * 6)
         assert len(grads) == st.n_params
         ctx.st = None
-        return (None,) * 8 + tuple(grads)
+        return (None,) * 9 + tuple(grads)
 
 
 class EnvSGFn(torch.autograd.Function):

@@ -397,3 +397,38 @@ def test_general_multi_light_variant(env):
     O.training_loss(ret, gt.cuda(), True).backward()
     for sg, ref in zip(m.lgtSGs_list, leaves):
         assert gerr(sg.grad, ref.grad) < GTOL
+
+
+def test_training_record_capacity_hints(env):
+    """Second and later training steps size their record buffers from the previous step (no mid-pass host read);
+    gradients equal those of the exact (first-call) route, also after a forced capacity overflow (pass re-run)."""
+    import tensoir_amd
+    from tensoir_amd import Renderer_TensoIR_train
+    from tests.helpers import golden_checkpoint
+    eh, ew = [int(x) for x in env.g["scene/envmap_hw"]]
+    m = tensoir_amd.model_from_checkpoint(golden_checkpoint(env.g), "cuda", envmap_h=eh, envmap_w=ew)
+    m.march_t_stop = 0.0
+    rays, lidx = T(env.g, "rays/rays").cuda(), T(env.g, "rays/light_idx").cuda()
+    B, S = rays.shape[0], 64
+    gt = torch.full((B, 3), 0.25, device="cuda")
+
+    def grads():
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(7)
+        ret = Renderer_TensoIR_train(rays, None, lidx, m, N_samples=S, white_bg=True, is_train=False, is_relight=False,
+                                     device="cuda", args=env.args)
+        loss = torch.mean((ret["rgb_map"] - gt) ** 2)
+        loss.backward()
+        return float(loss), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    l0, g0 = grads()                                   # exact route, learns the capacity
+    assert (B, S) in m._train_cap_hints
+    l1, g1 = grads()                                   # capacity-hint route
+    m._train_cap_hints[(B, S)] = 64                    # far too small: overflow -> the pass is re-run exactly
+    l2, g2 = grads()
+    assert (B, S) in m._train_cap_hints and m._train_cap_hints[(B, S)] > 64
+    for l, g in ((l1, g1), (l2, g2)):
+        assert abs(l - l0) < 1e-6
+        assert set(g) == set(g0)
+        for n in g0:
+            assert gerr(g[n], g0[n]) < 2e-5, n

@@ -30,7 +30,11 @@ opt = torch.optim.Adam(model.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99)
 W = dict(rgb_brdf=0.2, normals_diff=0.0005, normals_orientation=0.001, albedo_smoothness=0.001, roughness_smoothness=0.001)
 
 
+PHASE = None        # host seconds per phase (forward incl. its end-of-pass count read, loss, backward, optimizer)
+
+
 def step():
+    t0 = time.perf_counter()
     ret = Renderer_TensoIR_train(rays, None, lidx, model, N_samples=a.samples, white_bg=True, is_train=True,
                                  is_relight=bool(a.relight), sample_method="stratified_sampling", device=dev, args=args)
     loss = torch.mean((ret["rgb_map"] - gt) ** 2)
@@ -39,20 +43,27 @@ def step():
             + W["normals_diff"] * ret["normals_diff_map"].mean() \
             + W["normals_orientation"] * ret["normals_orientation_loss_map"].mean() \
             + W["roughness_smoothness"] * ret["roughness_smoothness_loss"] + W["albedo_smoothness"] * ret["albedo_smoothness_loss"]
+    t1 = time.perf_counter()
     opt.zero_grad(set_to_none=True)
     loss.backward()
+    t2 = time.perf_counter()
     opt.step()
+    t3 = time.perf_counter()
+    if PHASE is not None:
+        PHASE[0] += t1 - t0; PHASE[1] += t2 - t1; PHASE[2] += t3 - t2
     return loss
 
 
 for _ in range(a.warmup):
     l0 = step()
 torch.cuda.synchronize()
+PHASE = [0.0, 0.0, 0.0]
 t0 = time.perf_counter()
 for _ in range(a.steps):
     l1 = step()
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
+phase, PHASE = [round(1e3 * v / a.steps, 3) for v in PHASE], None
 if a.cprofile:
     import cProfile, pstats
     pr = cProfile.Profile(); pr.enable()
@@ -76,5 +87,6 @@ out = {"it_per_s": round(a.steps / el, 2), "ms_per_step": round(1e3 * el / a.ste
        "rays_per_s": round(a.steps * rays.shape[0] / el, 1), "loss_first": float(l0), "loss_last": float(l1),
        "config": {"rays": rays.shape[0], "samples": a.samples, "grid": a.grid, "relight": bool(a.relight)},
        "hip_ms_per_step": round(sum(r[1] for r in rows), 3),
+       "host_ms_per_step": {"forward_incl_count_read": phase[0], "loss_and_backward": phase[1], "optimizer": phase[2]},
        "entry_points": [{"name": n, "ms_per_step": round(ms, 4), "launches": c} for n, ms, c in rows[:16]]}
 print(json.dumps(out))
