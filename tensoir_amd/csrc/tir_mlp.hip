@@ -645,41 +645,37 @@ __global__ void k_pack_mlp_bwd(const float* __restrict__ w0, const float* __rest
     p[i] = v;
 }
 
-__global__ void __launch_bounds__(256)
+// one decoder-input column of one row (see the forward's input build for the layout)
+__device__ __forceinline__ float mlp_input_col(const float* __restrict__ frow, const float* __restrict__ arow, int col) {
+    if (col < F) return frow[col];
+    if (col < F + 3) return arow[col - F];
+    if (col >= IN) return 0.0f;
+    const bool from_aux = col >= F + 3 + 2 * NPF;
+    const int q = from_aux ? col - (F + 3 + 2 * NPF) : col - (F + 3);
+    const int half = from_aux ? 3 * PE : NPF;            // sin block, then cos block
+    const bool is_cos = q >= half;
+    const int qq = is_cos ? q - half : q;
+    const float base = from_aux ? arow[qq / PE] : frow[qq / PE];
+    float sv, cv;
+    fast_sincos(base * (float)(1 << (qq % PE)), sv, cv);  // transcendental unit, <= 4e-7 abs (these rows only feed d W0 = dz1^T x)
+    return is_cos ? cv : sv;
+}
+
+// 320 threads = 8 rows x 40 float4 granules: every row leaves as 640 contiguous bytes
+__global__ void __launch_bounds__(320)
 k_mlp_inputs(const float* __restrict__ feat, int fstride, const float* __restrict__ aux, const int32_t* __restrict__ aux_map,
              int aux_mod, float* __restrict__ x, int64_t n) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n * XPAD) return;
-    const int64_t s = idx / XPAD;
-    const int col = (int)(idx % XPAD);
-    float v = 0.0f;
-    if (col < F) v = feat[s * fstride + col];
-    else if (col < F + 3 + 2 * NPF) {
-        if (col >= F + 3) {
-            const int q = col - (F + 3);
-            const bool is_cos = q >= NPF;
-            const int qq = is_cos ? q - NPF : q;
-            const float y = feat[s * fstride + qq / PE] * (float)(1 << (qq % PE));
-            float sv, cv;
-            fast_sincos(y, sv, cv);            // transcendental unit, <= 4e-7 abs (these rows only feed d W0 = dz1^T x)
-            v = is_cos ? cv : sv;
-        } else {
-            int64_t ai = aux_map ? (int64_t)aux_map[s] : s;
-            if (aux_mod > 0) ai %= aux_mod;
-            v = aux[3 * ai + (col - F)];
-        }
-    } else if (col < IN) {
-        int64_t ai = aux_map ? (int64_t)aux_map[s] : s;
-        if (aux_mod > 0) ai %= aux_mod;
-        const int q = col - (F + 3 + 2 * NPF);
-        const bool is_cos = q >= 3 * PE;
-        const int qq = is_cos ? q - 3 * PE : q;
-        const float y = aux[3 * ai + qq / PE] * (float)(1 << (qq % PE));
-        float sv, cv;
-        fast_sincos(y, sv, cv);
-        v = is_cos ? cv : sv;
-    }
-    x[idx] = v;
+    const int r = threadIdx.x / (XPAD / 4), g = threadIdx.x % (XPAD / 4);
+    const int64_t s = (int64_t)blockIdx.x * 8 + r;
+    if (s >= n) return;
+    int64_t ai = aux_map ? (int64_t)aux_map[s] : s;
+    if (aux_mod > 0) ai %= aux_mod;
+    const float* frow = feat + s * fstride;
+    const float* arow = aux + 3 * ai;
+    float4 v;
+    v.x = mlp_input_col(frow, arow, 4 * g);     v.y = mlp_input_col(frow, arow, 4 * g + 1);
+    v.z = mlp_input_col(frow, arow, 4 * g + 2); v.w = mlp_input_col(frow, arow, 4 * g + 3);
+    *reinterpret_cast<float4*>(x + s * XPAD + 4 * g) = v;
 }
 
 // Backward-data: 8 waves x 32 samples per 256-sample tile, same lane decomposition as the forward kernels
@@ -953,8 +949,7 @@ extern "C" int tir_mlp_inputs(const TirMlp* m, const float* feat, int32_t feat_s
     if (rc) return rc;
     if (n < 0 || feat_stride < F || (n > 0 && (!feat || !aux || !x))) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
-    const int64_t total = n * XPAD;
-    hipLaunchKernelGGL(k_mlp_inputs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, tir_stream(stream), feat,
+    hipLaunchKernelGGL(k_mlp_inputs, dim3((unsigned)((n + 7) / 8)), dim3(8 * (XPAD / 4)), 0, tir_stream(stream), feat,
                        feat_stride, aux, aux_map, aux_mod, x, n);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
