@@ -432,3 +432,33 @@ def test_training_record_capacity_hints(env):
         assert set(g) == set(g0)
         for n in g0:
             assert gerr(g[n], g0[n]) < 2e-5, n
+
+
+def test_grid_400_training_and_inference_smoke(env):
+    """The largest shipped resolution (ficus: N_voxel_final = 400^3): one inference pass and one
+    training step run, agree with each other on the rendered maps, and give finite gradients for every parameter."""
+    import types
+    import tensoir_amd
+    from tensoir_amd import Renderer_TensoIR_train, synth
+    ck = synth.make_checkpoint(grid=(400, 400, 400), seed=11)
+    m = tensoir_amd.model_from_checkpoint(ck, "cuda", envmap_h=4, envmap_w=8)
+    rays = synth.make_rays(32, 32).cuda()
+    lidx = torch.zeros(rays.shape[0], 1, dtype=torch.int32, device="cuda")
+    args = types.SimpleNamespace(second_nSample=96, second_near=0.05, second_far=1.5)
+    with torch.no_grad():
+        ref = Renderer_TensoIR_train(rays, None, lidx, m, N_samples=256, white_bg=True, is_train=False, is_relight=True,
+                                     sample_method="fixed_envirmap", device="cuda", args=args)
+    ret = Renderer_TensoIR_train(rays, None, lidx, m, N_samples=256, white_bg=True, is_train=False, is_relight=True,
+                                 sample_method="fixed_envirmap", device="cuda", args=args)
+    for k in ("rgb_map", "acc_map", "normal_map", "albedo_map"):
+        assert gerr(ret[k], ref[k]) < 2e-5, k                    # training forward == inference forward
+    assert float(ref["acc_map"].max()) > 0.5                     # the scene is hit
+    loss = torch.mean((ret["rgb_map"] - 0.3) ** 2) + 0.2 * torch.mean((ret["rgb_with_brdf_map"] - 0.3) ** 2) \
+        + 1e-3 * ret["normals_diff_map"].mean()
+    loss.backward()
+    n_grad = 0
+    for name, p in m.named_parameters():
+        if p.grad is not None:
+            assert bool(torch.isfinite(p.grad).all()), name
+            n_grad += int(p.grad.abs().sum() > 0)
+    assert n_grad >= 18
