@@ -726,7 +726,7 @@ class TensorVMSplit(nn.Module):
                     noise = _brdf_jitter_dense.to(dev, torch.float32)[rec_ray.long(), rec_k.long()]
                 else:
                     noise = torch.randn((A, 3), device=dev, dtype=torch.float32)
-                xyz_j = rec_xyz + noise * 0.01
+                xyz_j = torch.add(rec_xyz, noise, alpha=0.01)
                 intr_j = ops.vm_app(f, xyz_j, None, None, False, True, None, 0, n_dev)[1]
                 brdf_j = ops.mlp(pb, intr_j, xyz_j, None, None, 0, n_dev)
                 if self.normals_kind == "purely_derived":

@@ -173,7 +173,7 @@ class PrimaryRenderFn(torch.autograd.Function):
                     noise = noise_dense.to(dev, torch.float32)[rec_ray.long(), rec_k.long()]
                 else:
                     noise = torch.randn((A, 3), device=dev, dtype=torch.float32)
-                xyz_j = rec_xyz + noise * 0.01
+                xyz_j = torch.add(rec_xyz, noise, alpha=0.01)
                 intr_j = ops.vm_app(f, xyz_j, None, None, False, True, None, 0, n_dev)[1]
                 brdf_j, h1, h2 = ops.mlp_train(pb, intr_j, xyz_j, n_dev=n_dev)
                 st.calls["brdf_j"] = _DecoderCall(feat=intr_j, aux=xyz_j, aux_map=None, out=brdf_j, h1=h1, h2=h2)
