@@ -103,9 +103,15 @@ __global__ void __launch_bounds__(1024)
 k_shade_setup(const float* __restrict__ maps, const float* __restrict__ rays, const float* __restrict__ dirs,
               int M, int D, float acc_thres, float* __restrict__ surf, uint8_t* __restrict__ active,
               int32_t* __restrict__ pair_ids, int32_t* __restrict__ n_active, float* __restrict__ vis,
-              int32_t* __restrict__ rec_cnt) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = i < (int64_t)M * D;
+              int32_t* __restrict__ rec_cnt, int dir_major) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = t < (int64_t)M * D;
+    // thread order = order of the compacted pair list.  dir_major: consecutive threads are consecutive surface points
+    // (neighbouring pixels) with the SAME light direction, so the 32 rays a march block takes are a bundle of nearly
+    // parallel rays from neighbouring points: they walk neighbouring plane cells in step (L1 / L2 hits) and end
+    // after similar step counts.  Point-major order hands a block one point's whole fan of directions.
+    int64_t i = t;
+    if (dir_major && in) i = (t % M) * D + t / M;
     bool act = false;
     if (in) {
         const int m = (int)(i / D), d = (int)(i % D);
@@ -279,7 +285,7 @@ extern "C" int tir_shade_setup(const float* maps, const float* rays, const float
     int64_t n = (int64_t)M * D;
     hipLaunchKernelGGL(k_shade_setup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tir_stream(stream), maps,
                        rays, dirs, M, D, acc_thres, surf, active, (int32_t*)nullptr, (int32_t*)nullptr, (float*)nullptr,
-                       (int32_t*)nullptr);
+                       (int32_t*)nullptr, 0);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
@@ -292,8 +298,11 @@ extern "C" int tir_shade_setup_compact(const float* maps, const float* rays, con
     if (!maps || !rays || !dirs || !surf || !active || !pair_ids || !n_active) return TIR_ERR_ARG;
     int64_t n = (int64_t)M * D;
     if (n >= ((int64_t)1 << 31)) return TIR_ERR_UNSUPPORTED;
+    // pair-list order: direction-major by default (+3.7 % on the whole step, -9 % on the secondary march);
+    // TIR_PAIR_ORDER=m restores point-major for A/B runs
+    static const int dir_major = [] { const char* e = getenv("TIR_PAIR_ORDER"); return (e && e[0] == 'm') ? 0 : 1; }();
     hipLaunchKernelGGL(k_shade_setup, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, tir_stream(stream), maps,
-                       rays, dirs, M, D, acc_thres, surf, active, pair_ids, n_active, vis, ray_rec_cnt);
+                       rays, dirs, M, D, acc_thres, surf, active, pair_ids, n_active, vis, ray_rec_cnt, dir_major);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
