@@ -379,7 +379,10 @@ int tir_density_grad_bwd(const TirField* f, const TirFieldGrad* g, const float* 
 
 /* Backward of tir_vm_app_fwd.  g_rad / g_int [n][stride] (either may be NULL).  Accumulates into g->aplane,
  * g->aline, g->light_line, g->light_mean; writes y_rad / y_int [n][3*n_acomp] = (plane*line) (.) light row,
- * the left operand of d basis_mat = g_feat^T y (tir_gemm_tn). */
+ * the left operand of d basis_mat = g_feat^T y (tir_gemm_tn).  y_rad (y_int) is REQUIRED whenever g_rad (g_int) is
+ * given: the buffer first holds dY = g_feat . basis_mat (an MFMA GEMM) and is then overwritten in place with y.
+ * Samples should arrive in (ray, sample-along-ray) order -- tir_compact_primary's order: consecutive samples that
+ * share a plane cell are summed in registers before they are scattered. */
 int tir_vm_app_bwd(const TirField* f, const TirFieldGrad* g, const float* xyz,
                    const int32_t* light_idx, const int32_t* idx_map, const float* g_rad,
                    const float* g_int, int32_t stride, int64_t n, float* y_rad, float* y_int,
