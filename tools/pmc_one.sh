@@ -6,7 +6,7 @@ OUT="$REPO/gpurun_out/$1"; shift
 CTRS="$1"; shift
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d "$OUT" -o pmc -- "$@" > "$OUT/log.txt" 2>&1
+timeout -k 5 ${PMC_TIMEOUT:-180} rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d "$OUT" -o pmc -- "$@" > "$OUT/log.txt" 2>&1
 python - "$OUT" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
