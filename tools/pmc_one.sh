@@ -1,5 +1,7 @@
 #!/bin/bash
 # usage: tools/pmc_one.sh <outdir-under-gpurun_out> "<counters>" <python cmd...>   (GPU box)
+# FETCH_SIZE and WRITE_SIZE (and the TCP_* sums) each need a pass of their own on gfx950: asking for two of them at once
+# fails with "Request exceeds the capabilities of the hardware to collect" and rocprofv3 then hangs -- hence the timeout.
 set -u
 REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 OUT="$REPO/gpurun_out/$1"; shift
