@@ -314,6 +314,15 @@ def test_training_step_with_no_hits(env):
     for name, p in m.named_parameters():
         assert p.grad is None or bool(torch.isfinite(p.grad).all()), name
     m.zero_grad(set_to_none=True)
+    # second call: the record buffers are now sized from the (empty) previous step -- the capacity-hint route
+    ret2 = Renderer_TensoIR_train(rays, None, lidx, m, N_samples=32, white_bg=True, is_train=True, is_relight=True,
+                                  sample_method="fixed_envirmap", device="cuda", args=env.args)
+    loss2 = env.O.training_loss(ret2, torch.zeros(5, 3, device="cuda"), True)
+    loss2.backward()
+    assert abs(float(loss2.detach()) - float(loss.detach())) < 1e-6
+    for name, p in m.named_parameters():
+        assert p.grad is None or bool(torch.isfinite(p.grad).all()), name
+    m.zero_grad(set_to_none=True)
 
 
 def test_optimizer_steps_reduce_loss(env):

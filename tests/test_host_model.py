@@ -159,3 +159,31 @@ def test_general_multi_light_variant_host_side():
     assert sum(1 for p in flat if any(p is sg for sg in m.lgtSGs_list)) == 2
     kw = m.get_kwargs()
     assert kw["light_name_list"] == ["sunset", "snow"] and "light_rotation" not in kw
+
+
+def test_host_value_cache_follows_tensor_changes():
+    """Geometry constants are mirrored on the host once per change (no `.tolist()` per call: it would drain the
+    launch queue); replacing the tensor, or writing into it, refreshes the mirror."""
+    from tensoir_amd.field_model import _host_values
+
+    class Owner:
+        pass
+    o, calls = Owner(), []
+    a = torch.tensor([1.0, 2.0])
+
+    def build():
+        calls.append(1)
+        return a.tolist()
+    assert _host_values(o, "k", (a,), build) == [1.0, 2.0] and len(calls) == 1
+    assert _host_values(o, "k", (a,), build) == [1.0, 2.0] and len(calls) == 1          # cached
+    a.mul_(2.0)                                                                           # in-place: version bump
+    assert _host_values(o, "k", (a,), build) == [2.0, 4.0] and len(calls) == 2
+    a = torch.tensor([5.0, 6.0])                                                          # new tensor object
+    assert _host_values(o, "k", (a,), build) == [5.0, 6.0] and len(calls) == 3
+
+
+def test_to_device_is_a_plain_to_on_cpu():
+    from tensoir_amd import ops
+    t = torch.arange(6).reshape(2, 3)
+    out = ops.to_device(t, "cpu", torch.int32)
+    assert out.dtype == torch.int32 and torch.equal(out.long(), t)
