@@ -109,6 +109,13 @@ def shard_batch(n_rays: int, rank: int, world: int):
     return torch.arange(rank, n_rays, world, dtype=torch.int64)
 
 
+def _memory_order(p):
+    """Dimension permutation that walks `p` in memory order (so that flattening a gradient that shares p's layout
+    -- e.g. the channel-last VM planes -- is a view, not a transposing copy).  Depends only on the parameter, hence
+    identical on every rank."""
+    return sorted(range(p.dim()), key=lambda d: (-p.stride(d), d))
+
+
 def allreduce_gradients(params, group=None, bucket_mb: float = 64.0, average: bool = True):
     """Bucketed all-reduce (RCCL over xGMI with backend 'nccl') of the .grad of `params`, in place.
 
@@ -135,7 +142,8 @@ def allreduce_gradients(params, group=None, bucket_mb: float = 64.0, average: bo
     pending = []
     for b in buckets:
         dev = b[0].device
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in b])
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).permute(_memory_order(p)).reshape(-1)
+                          .to(torch.float32) for p in b])
         flat = flat.to(dev)
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
         pending.append((b, flat, work))
@@ -145,10 +153,10 @@ def allreduce_gradients(params, group=None, bucket_mb: float = 64.0, average: bo
             flat.div_(world)
         off = 0
         for p in b:
-            g = flat[off:off + p.numel()].view_as(p)
+            perm = _memory_order(p)
             if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
+                p.grad = torch.empty_like(p)          # preserve_format: the parameter's own layout
+            dst = p.grad.permute(perm)
+            dst.copy_(flat[off:off + p.numel()].view(dst.shape))
             off += p.numel()
     return len(buckets)

@@ -88,10 +88,18 @@ def _grad_worker(rank, world, port, q):
         for i, p in enumerate(ps):
             if i != 1 or rank == 0:                      # one parameter has no gradient on rank 1
                 p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+        # a channel-last VM plane (values differ per element, so a wrong flattening order would show): its gradient
+        # is flattened in memory order -- a view -- and comes back in the parameter's own layout
+        from tensoir_amd.field_model import channel_last, is_channel_last
+        cl = torch.nn.Parameter(channel_last(torch.randn(1, 4, 3, 5)))
+        base = torch.arange(60, dtype=torch.float32).reshape(1, 4, 3, 5)
+        cl.grad = channel_last(base * (rank + 1))
+        ps.append(cl)
         n_buckets = tdist.allreduce_gradients(ps, bucket_mb=60 * 4 / (1 << 20))       # 60-float buckets
-        want = [sum((r + 1) * (i + 1) for r in range(world)) / world for i in range(len(ps))]
+        want = [sum((r + 1) * (i + 1) for r in range(world)) / world for i in range(len(ps) - 1)]
         want[1] = 2.0 / world                           # only rank 0 contributed (value 1*2)
-        ok = all(torch.allclose(p.grad, torch.full_like(p, w)) for p, w in zip(ps, want))
+        ok = all(torch.allclose(p.grad, torch.full_like(p, w)) for p, w in zip(ps[:-1], want))
+        ok = ok and torch.allclose(cl.grad, base * sum(r + 1 for r in range(world)) / world) and is_channel_last(cl.grad)
         q.put((rank, ok and n_buckets >= 2))
     finally:
         dist.destroy_process_group()
