@@ -1026,16 +1026,15 @@ __device__ __forceinline__ void normalize3(float& x, float& y, float& z, float e
 }
 __device__ __forceinline__ float clamp_pass(float raw, float lo, float hi) { return (raw >= lo && raw <= hi) ? 1.0f : 0.0f; }
 
-__global__ void __launch_bounds__(256)
-k_shade_integrate_bwd(const float* __restrict__ maps, const float* __restrict__ rays, const float* __restrict__ dirs,
-                      const int32_t* __restrict__ light_idx, const float* __restrict__ vis,
-                      const float* __restrict__ indirect, const float* __restrict__ env,
-                      const float* __restrict__ weight_d, int M, int D, int n_lights, int equal_area, int use_srgb,
-                      float acc_thres, const float* __restrict__ g_out, float* __restrict__ g_maps,
-                      float* __restrict__ g_env) {
-    const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (m >= M) return;
+// One surface point on one wave.  genv: where the environment-radiance gradient [n_lights][D][3] accumulates -- the
+// block's LDS copy (lds_env) or, when that does not fit, global memory.
+__device__ __forceinline__ void
+shade_bwd_point(int m, int lane, const float* __restrict__ maps, const float* __restrict__ rays, const float* __restrict__ dirs,
+                const int32_t* __restrict__ light_idx, const float* __restrict__ vis,
+                const float* __restrict__ indirect, const float* __restrict__ env,
+                const float* __restrict__ weight_d, int D, int n_lights, int equal_area, int use_srgb,
+                float acc_thres, const float* __restrict__ g_out, float* __restrict__ g_maps,
+                float* __restrict__ g_env, float* lds_env) {
     const float* mp = maps + (size_t)m * TIR_MAP_STRIDE;
     float* gm = g_maps + (size_t)m * TIR_MAP_STRIDE;
     if (lane < TIR_MAP_STRIDE) gm[lane] = 0.0f;
@@ -1125,7 +1124,11 @@ k_shade_integrate_bwd(const float* __restrict__ maps, const float* __restrict__ 
             const float gterm = gt[q] * wd;                       // cotangent of brdf * light * cosine
             galb[q] += gterm * light * cosine / PI;
             dcos += gterm * brdf * light;
-            if (g_env && v != 0.f) atomic_add_f32(g_env + ((size_t)li * D + d) * 3 + q, gterm * brdf * cosine * v);
+            if (g_env && v != 0.f) {
+                const float ge = gterm * brdf * cosine * v;
+                if (lds_env) atomicAdd(lds_env + (li * D + d) * 3 + q, ge);
+                else atomic_add_f32(g_env + ((size_t)li * D + d) * 3 + q, ge);
+            }
             const float gs = gterm * light * cosine;               // cotangent of spec
             const float dfrac = gs / nom;
             const float dnomr = -gs * frac / (nom * nom) * nom_pass;
@@ -1165,6 +1168,36 @@ k_shade_integrate_bwd(const float* __restrict__ maps, const float* __restrict__ 
         gm[7] = galb[0]; gm[8] = galb[1]; gm[9] = galb[2];
         gm[10] = grough;
         gm[11] = gF0[0]; gm[12] = gF0[1]; gm[13] = gF0[2];
+    }
+}
+
+// Persistent blocks of 4 waves, one surface point per wave at a time.  Every point adds to the SAME n_lights x D x 3
+// environment-gradient entries: left as global atomics that is an M-way collision per address (4096 waves serialise
+// on 384 words), so the block sums its points in LDS and flushes once.
+__global__ void __launch_bounds__(256)
+k_shade_integrate_bwd(const float* __restrict__ maps, const float* __restrict__ rays, const float* __restrict__ dirs,
+                      const int32_t* __restrict__ light_idx, const float* __restrict__ vis,
+                      const float* __restrict__ indirect, const float* __restrict__ env,
+                      const float* __restrict__ weight_d, int M, int D, int n_lights, int equal_area, int use_srgb,
+                      float acc_thres, const float* __restrict__ g_out, float* __restrict__ g_maps,
+                      float* __restrict__ g_env, int env_in_lds) {
+    extern __shared__ float lds_env_buf[];
+    float* lds_env = (g_env && env_in_lds) ? lds_env_buf : nullptr;
+    const int n_env = n_lights * D * 3;
+    if (lds_env) {
+        for (int i = threadIdx.x; i < n_env; i += blockDim.x) lds_env[i] = 0.0f;
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int m = blockIdx.x * nw + (threadIdx.x >> 6); m < M; m += gridDim.x * nw)
+        shade_bwd_point(m, lane, maps, rays, dirs, light_idx, vis, indirect, env, weight_d, D, n_lights, equal_area,
+                        use_srgb, acc_thres, g_out, g_maps, g_env, lds_env);
+    if (lds_env) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_env; i += blockDim.x) {
+            const float v = lds_env[i];
+            if (v != 0.0f) atomic_add_f32(g_env + i, v);
+        }
     }
 }
 
@@ -1433,9 +1466,13 @@ extern "C" int tir_shade_integrate_bwd(const float* maps, const float* rays, con
     if (M < 0 || D <= 0 || n_lights <= 0) return TIR_ERR_ARG;
     if (M == 0) return TIR_OK;
     if (!maps || !rays || !dirs || !vis || !env || !g_out || !g_maps || (!equal_area && !weight_d)) return TIR_ERR_ARG;
-    hipLaunchKernelGGL(k_shade_integrate_bwd, dim3((M + 3) / 4), dim3(256), 0, tir_stream(stream), maps, rays, dirs,
-                       light_idx, vis, indirect, env, weight_d, M, D, n_lights, equal_area, use_srgb, acc_thres, g_out,
-                       g_maps, g_env);
+    const size_t env_bytes = (size_t)n_lights * D * 3 * sizeof(float);
+    const int env_in_lds = env_bytes <= 64 * 1024 ? 1 : 0;
+    int blocks = (M + 3) / 4;
+    if (env_in_lds && blocks > 512) blocks = 512;             // persistent: one LDS flush per block
+    hipLaunchKernelGGL(k_shade_integrate_bwd, dim3(blocks), dim3(256), env_in_lds ? env_bytes : 0, tir_stream(stream),
+                       maps, rays, dirs, light_idx, vis, indirect, env, weight_d, M, D, n_lights, equal_area, use_srgb,
+                       acc_thres, g_out, g_maps, g_env, env_in_lds);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
