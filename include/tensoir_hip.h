@@ -409,6 +409,11 @@ int tir_pack_mlp_bwd(const float* w0, const float* w1, const float* w2, int32_t 
 int tir_mlp_bwd(const TirMlp* m, const float* packed_bwd, const float* feat, int32_t feat_stride,
                 const float* out, const float* g_out, const float* h1, const float* h2, int64_t n,
                 float* g_feat, float* dz1, float* dz2, float* dz3, void* stream);
+/* Same on the bf16 matrix pipe with split operands (3 products, fp32 accumulation; the blob of tir_pack_mlp_bwd
+ * carries both images). */
+int tir_mlp_bwd_bf16x3(const TirMlp* m, const float* packed_bwd, const float* feat, int32_t feat_stride,
+                const float* out, const float* g_out, const float* h1, const float* h2, int64_t n,
+                float* g_feat, float* dz1, float* dz2, float* dz3, void* stream);
 
 /* C[M][ldc] += A^T B (+ column N = A^T 1 when ones_col != 0: the bias gradient); A [n][lda] (first M columns),
  * B [n][ldb] (first N columns); M <= 128, N + ones_col <= 160.  fp32 MFMA, split over n. */

@@ -607,6 +607,15 @@ constexpr int OFFB_W2 = 0;
 constexpr int OFFB_W1T = OFFB_W2 + 2 * 64 * 4;
 constexpr int OFFB_W0T = OFFB_W1T + 128 * HID;
 constexpr int BWD_FLOATS = OFFB_W0T + 128 * XPAD;          // 37376 floats = 149,504 B of LDS
+// split-bf16 image appended to the blob (tir_mlp_bwd_bf16x3): W1^T hi | W1^T lo | W0^T hi | W0^T lo as bf16x8 operand
+// vectors [(kb*2 + h)*ROWS + row] -- the forward image's layout with the transposed matrices; k slot (kb, h, e) is the
+// hidden unit unit_of(8 kb + e, h), rows of W0^T permuted by bwd_inrow.
+constexpr int BB_W1T_ELEMS = HID * HID;                    // 16384 bf16 per plane
+constexpr int BB_W0T_ELEMS = XPAD * HID;                   // 20480
+constexpr int BB_ELEMS = 2 * BB_W1T_ELEMS + 2 * BB_W0T_ELEMS;
+constexpr int BWD_BF_FLOATS = BB_ELEMS / 2;                // 36864 float slots
+constexpr int BWD_TOTAL_FLOATS = BWD_FLOATS + BWD_BF_FLOATS;
+constexpr int BWD_BF_LDS_BYTES = (2 * 64 * 4) * 4 + BB_ELEMS * 2;      // W2 (fp32) + the bf16 image = 149,504 B
 
 // MFMA output row R (0..159) of d x^T = W0^T dz1^T  ->  decoder input index it carries (or -1).
 // Rows are permuted so that lane half h ends up holding, for feature d = 16 h + u/5 (u = 16 mt + r its accumulator
@@ -629,8 +638,31 @@ __host__ __device__ inline int bwd_inrow(int R) {
 __global__ void k_pack_mlp_bwd(const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2,
                                int out_dim, float* __restrict__ p) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= BWD_FLOATS) return;
+    if (i >= BWD_TOTAL_FLOATS) return;
     float v = 0.0f;
+    if (i >= BWD_FLOATS) {                          // two bf16 per float slot of the split-bf16 image
+        unsigned short hw[2];
+        for (int t = 0; t < 2; ++t) {
+            int e_all = (i - BWD_FLOATS) * 2 + t;
+            const bool is_w1 = e_all < 2 * BB_W1T_ELEMS;
+            const int plane_elems = is_w1 ? BB_W1T_ELEMS : BB_W0T_ELEMS;
+            const int rel = is_w1 ? e_all : e_all - 2 * BB_W1T_ELEMS;
+            const bool lo = rel >= plane_elems;
+            const int idx = lo ? rel - plane_elems : rel;
+            const int ntile = is_w1 ? 4 : 5;
+            const int e = idx % 8, ii = (idx / 8) % 32, mt = (idx / 256) % ntile, hh = (idx / (256 * ntile)) % 2,
+                      kb = idx / (512 * ntile);
+            const int unit = unit_of(kb * 8 + e, hh);
+            float wv;
+            if (is_w1) wv = w1[unit * HID + (mt * 32 + ii)];                      // W1^T[row][k = unit]
+            else { const int in = bwd_inrow(mt * 32 + ii); wv = (in >= 0) ? w0[unit * IN + in] : 0.0f; }
+            const __bf16 hi = (__bf16)wv;
+            const __bf16 r = lo ? (__bf16)(wv - (float)hi) : hi;
+            hw[t] = __builtin_bit_cast(unsigned short, r);
+        }
+        p[i] = __builtin_bit_cast(float, (unsigned int)hw[0] | ((unsigned int)hw[1] << 16));
+        return;
+    }
     if (i < OFFB_W1T) {
         int j = i - OFFB_W2, h = j / 256, q = (j % 256) / 4, o = j % 4;
         v = (o < out_dim) ? w2[o * HID + unit_of(q, h)] : 0.0f;
@@ -779,6 +811,150 @@ k_mlp_bwd(const float* __restrict__ packed_bwd, const float* __restrict__ feat, 
                 ax[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4], b, ax[4], 0, 0, 0);
                 if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+        }
+        // ---- positional-encoding chain rule: x = [f, sin f, sin 2f, cos f, cos 2f] ----
+        float gf[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int d = h * 16 + j;
+            float v = 0.f;
+            if (d < F) {
+                const float xv = feat[s * fstride + d];
+                float s1, c1;
+                fast_sincos(xv, s1, c1);
+                const float s2 = 2.0f * s1 * c1, c2 = fmaf(-2.0f * s1, s1, 1.0f);      // double-angle identities
+                const int u0 = 5 * j;
+                const float g_raw = ax[(u0) >> 4][(u0) & 15], g_s0 = ax[(u0 + 1) >> 4][(u0 + 1) & 15];
+                const float g_s1 = ax[(u0 + 2) >> 4][(u0 + 2) & 15], g_c0 = ax[(u0 + 3) >> 4][(u0 + 3) & 15];
+                const float g_c1 = ax[(u0 + 4) >> 4][(u0 + 4) & 15];
+                v = g_raw + c1 * g_s0 + 2.0f * c2 * g_s1 - s1 * g_c0 - 2.0f * s2 * g_c1;
+            }
+            gf[j] = v;
+        }
+        if (on) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<float4*>(g_feat + s * 32 + h * 16 + 4 * i) = make_float4(gf[4 * i], gf[4 * i + 1], gf[4 * i + 2], gf[4 * i + 3]);
+        }
+    }
+}
+
+// The same on the bf16 matrix pipe: both W^T dz^T products with split operands (x = hi + lo, 3 products, fp32
+// accumulation) on v_mfma_f32_32x32x16_bf16 -- 216 MFMAs of 32 cycles per 32-sample tile instead of 576 of 64.
+// Backward-data: 8 waves x 32 samples per 256-sample tile, same lane decomposition as the forward kernels
+// (lane = sample l&31, half h = l>>5 holds hidden units unit_of(q, h)).  d h^T = W^T dz^T has exactly the forward's
+// shape with the transposed weights as the A operand, so the lane that holds h[unit] receives d h[unit].
+__global__ void __launch_bounds__(512)
+k_mlp_bwd_bf16(const float* __restrict__ packed_bwd, const float* __restrict__ feat, int fstride, const float* __restrict__ out,
+          const float* __restrict__ g_out, const float* __restrict__ h1, const float* __restrict__ h2, int64_t n,
+          int out_dim, int act, float* __restrict__ g_feat, float* __restrict__ dz1o, float* __restrict__ dz2o,
+          float* __restrict__ dz3o) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // LDS: W2 (fp32, 512 floats) | bf16 image (W1^T hi, lo, W0^T hi, lo)
+    for (int i = threadIdx.x * 4; i < 2 * 64 * 4; i += 512 * 4)
+        *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(packed_bwd + OFFB_W2 + i);
+    for (int i = threadIdx.x * 4; i < BWD_BF_FLOATS; i += 512 * 4)
+        *reinterpret_cast<float4*>(lds + 2 * 64 * 4 + i) = *reinterpret_cast<const float4*>(packed_bwd + BWD_FLOATS + i);
+    __syncthreads();
+    const bf16x8* w1hi = reinterpret_cast<const bf16x8*>(lds + 2 * 64 * 4);
+    const bf16x8* w1lo = w1hi + BB_W1T_ELEMS / 8;
+    const bf16x8* w0hi = w1lo + BB_W1T_ELEMS / 8;
+    const bf16x8* w0lo = w0hi + BB_W0T_ELEMS / 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sl = lane & 31, h = lane >> 5;
+    const int64_t n_tiles = (n + 255) / 256;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t s_raw = tile * 256 + wave * 32 + sl;
+        const bool on = s_raw < n;
+        const int64_t s = on ? s_raw : n - 1;
+        // ---- output layer ----
+        float dz3[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float y = 0.f, gy = 0.f;
+            if (o < out_dim) { y = out[s * out_dim + o]; gy = on ? g_out[s * out_dim + o] : 0.f; }
+            dz3[o] = gy * (act == 1 ? (1.0f - y * y) : y * (1.0f - y));
+        }
+        if (on && h == 0) *reinterpret_cast<float4*>(dz3o + s * 4) = make_float4(dz3[0], dz3[1], dz3[2], dz3[3]);
+        float dz[64];
+        {
+            const float* wp = lds + OFFB_W2 + h * 256;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 hv = *reinterpret_cast<const float4*>(h2 + s * HID + mt * 32 + 8 * i + 4 * h);
+                    const float hvv[4] = {hv.x, hv.y, hv.z, hv.w};
+                    float o4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int q = mt * 16 + 4 * i + j;
+                        const float4 w = *reinterpret_cast<const float4*>(wp + q * 4);
+                        const float d = w.x * dz3[0] + w.y * dz3[1] + w.z * dz3[2] + w.w * dz3[3];
+                        o4[j] = hvv[j] > 0.f ? d : 0.f;
+                        dz[q] = o4[j];
+                    }
+                    if (on) *reinterpret_cast<float4*>(dz2o + s * HID + mt * 32 + 8 * i + 4 * h) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                }
+        }
+        // ---- d h1^T = W1^T dz2^T ----
+        f32x16 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            bf16x8 ah[4], al[4], xh, xl;
+            const int wi = (kb * 2 + h) * 128 + sl;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) { ah[mt] = w1hi[wi + mt * 32]; al[mt] = w1lo[wi + mt * 32]; }
+            split8(dz + kb * 8, xh, xl);
+            mfma12<3>(ah, al, xh, xl, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 hv = *reinterpret_cast<const float4*>(h1 + s * HID + mt * 32 + 8 * i + 4 * h);
+                const float hvv[4] = {hv.x, hv.y, hv.z, hv.w};
+                float o4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o4[j] = hvv[j] > 0.f ? acc[mt][4 * i + j] : 0.f;
+                    dz[mt * 16 + 4 * i + j] = o4[j];
+                }
+                if (on) *reinterpret_cast<float4*>(dz1o + s * HID + mt * 32 + 8 * i + 4 * h) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            }
+        // ---- d x^T = W0^T dz1^T (rows permuted, see bwd_inrow) ----
+        f32x16 ax[5];
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ax[mt][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {
+            bf16x8 xh, xl;
+            const int wi = (kb * 2 + h) * 160 + sl;
+            split8(dz + kb * 8, xh, xl);
+            // two groups of row tiles (3 + 2) keep the operand registers at 6 vectors; product-major inside a group:
+            // never two consecutive MFMAs on one accumulator
+#pragma unroll
+            for (int g0 = 0; g0 < 5; g0 += 3) {
+                const int gn = (g0 == 0) ? 3 : 2;
+                bf16x8 ah[3], al[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (u < gn) { ah[u] = w0hi[wi + (g0 + u) * 32]; al[u] = w0lo[wi + (g0 + u) * 32]; }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) if (u < gn) ax[g0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], xh, ax[g0 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 3; ++u) if (u < gn) ax[g0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u], xh, ax[g0 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 3; ++u) if (u < gn) ax[g0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], xl, ax[g0 + u], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- positional-encoding chain rule: x = [f, sin f, sin 2f, cos f, cos 2f] ----
         float gf[16];
@@ -957,14 +1133,14 @@ extern "C" int tir_mlp_inputs(const TirMlp* m, const float* feat, int32_t feat_s
 
 extern "C" int64_t tir_mlp_bwd_packed_floats(int32_t feat_dim, int32_t pe, int32_t hidden, int32_t out_dim) {
     if (feat_dim != F || pe != PE || hidden != HID || out_dim < 1 || out_dim > 4) return TIR_ERR_UNSUPPORTED;
-    return BWD_FLOATS;
+    return BWD_TOTAL_FLOATS;
 }
 
 extern "C" int tir_pack_mlp_bwd(const float* w0, const float* w1, const float* w2, int32_t feat_dim, int32_t pe,
                                 int32_t hidden, int32_t out_dim, float* packed, void* stream) {
     if (!w0 || !w1 || !w2 || !packed) return TIR_ERR_ARG;
     if (feat_dim != F || pe != PE || hidden != HID || out_dim < 1 || out_dim > 4) return TIR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_pack_mlp_bwd, dim3((BWD_FLOATS + 255) / 256), dim3(256), 0, tir_stream(stream), w0, w1, w2,
+    hipLaunchKernelGGL(k_pack_mlp_bwd, dim3((BWD_TOTAL_FLOATS + 255) / 256), dim3(256), 0, tir_stream(stream), w0, w1, w2,
                        out_dim, packed);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
@@ -989,6 +1165,30 @@ extern "C" int tir_mlp_bwd(const TirMlp* m, const float* packed_bwd, const float
     int64_t tiles = (n + 255) / 256;
     unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
     hipLaunchKernelGGL(k_mlp_bwd, dim3(grid), dim3(512), lds, tir_stream(stream), packed_bwd, feat, feat_stride, out,
+                       g_out, h1, h2, n, m->out_dim, m->act, g_feat, dz1, dz2, dz3);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_mlp_bwd_bf16x3(const TirMlp* m, const float* packed_bwd, const float* feat, int32_t feat_stride,
+                           const float* out, const float* g_out, const float* h1, const float* h2, int64_t n,
+                           float* g_feat, float* dz1, float* dz2, float* dz3, void* stream) {
+    int rc = check_mlp(m);
+    if (rc) return rc;
+    if (!packed_bwd || n < 0 || feat_stride < F) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    if (!feat || !out || !g_out || !h1 || !h2 || !g_feat || !dz1 || !dz2 || !dz3) return TIR_ERR_ARG;
+    static bool attr_set = false;
+    const size_t lds = (size_t)BWD_BF_LDS_BYTES;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_bf16),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+        attr_set = true;
+    }
+    int64_t tiles = (n + 255) / 256;
+    unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    hipLaunchKernelGGL(k_mlp_bwd_bf16, dim3(grid), dim3(512), lds, tir_stream(stream), packed_bwd, feat, feat_stride, out,
                        g_out, h1, h2, n, m->out_dim, m->act, g_feat, dz1, dz2, dz3);
     TIR_CHECK_LAUNCH();
     return TIR_OK;

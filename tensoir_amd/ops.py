@@ -608,7 +608,10 @@ def pack_mlp_bwd(w0, w1, w2, feat_dim, pe):
     return packed
 
 
-def mlp_bwd(m: "PackedMlp", packed_bwd, feat, out, g_out, h1, h2):
+def mlp_bwd(m: "PackedMlp", packed_bwd, feat, out, g_out, h1, h2, impl=None):
+    """Backward-data of one decoder (g_feat, dz1, dz2, dz3): split-bf16 matrix cores when the product's decoder mode
+    is bf16x3 (default), exact fp32 MFMA otherwise."""
+    impl = impl or MLP_IMPL
     feat = f32(feat, "feat")
     n = feat.shape[0]
     dev = feat.device
@@ -616,7 +619,8 @@ def mlp_bwd(m: "PackedMlp", packed_bwd, feat, out, g_out, h1, h2):
     dz1 = torch.empty((n, 128), dtype=torch.float32, device=dev)
     dz2 = torch.empty((n, 128), dtype=torch.float32, device=dev)
     dz3 = torch.empty((n, 4), dtype=torch.float32, device=dev)
-    _call("tir_mlp_bwd", C.byref(m.desc), _ptr(packed_bwd), _ptr(feat), feat.shape[1], _ptr(f32(out, "out")),
+    _call("tir_mlp_bwd_bf16x3" if impl == "bf16x3" else "tir_mlp_bwd", C.byref(m.desc), _ptr(packed_bwd), _ptr(feat),
+          feat.shape[1], _ptr(f32(out, "out")),
           _ptr(f32(g_out, "g_out")), _ptr(h1), _ptr(h2), n, _ptr(g_feat), _ptr(dz1), _ptr(dz2), _ptr(dz3), _stream())
     return g_feat, dz1, dz2, dz3
 

@@ -77,7 +77,7 @@ class _DecoderCall(SimpleNamespace):
     pass
 
 
-def _decoder_backward(dec, calls):
+def _decoder_backward(dec, calls, impl=None):
     """Backward of every recorded invocation of one decoder.  Returns ([g_feat per call], 6 parameter grads)."""
     pm, pb = dec.packed(), _packed_bwd(dec)
     dev = calls[0].feat.device
@@ -87,11 +87,11 @@ def _decoder_backward(dec, calls):
     dW2 = torch.zeros((4, 132), dtype=torch.float32, device=dev)
     g_feats = []
     for c in calls:
-        g_feat, dz1, dz2, dz3 = ops.mlp_bwd(pm, pb, c.feat, c.out, c.g_out, c.h1, c.h2)
+        g_feat, dz1, dz2, dz3 = ops.mlp_bwd(pm, pb, c.feat, c.out, c.g_out, c.h1, c.h2, impl=impl)
         x = ops.mlp_inputs(pm, c.feat, c.aux, c.aux_map)
-        ops.gemm_tn(dz1, 128, x, 150, dW0, True)
-        ops.gemm_tn(dz2, 128, c.h1, 128, dW1, True)
-        ops.gemm_tn(dz3, 4, c.h2, 128, dW2, True)
+        ops.gemm_tn(dz1, 128, x, 150, dW0, True, impl=impl)
+        ops.gemm_tn(dz2, 128, c.h1, 128, dW1, True, impl=impl)
+        ops.gemm_tn(dz3, 4, c.h2, 128, dW2, True, impl=impl)
         g_feats.append(g_feat)
     grads = [dW0[:, :150], dW0[:, 150], dW1[:, :128], dW1[:, 128], dW2[:od, :128], dW2[:od, 128]]
     return g_feats, grads

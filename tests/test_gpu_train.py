@@ -96,7 +96,7 @@ def test_decoder_backward(env, which):
         call = training._DecoderCall(feat=fpad.cuda(), aux=aux.cuda(), aux_map=None, g_out=g_out.cuda())
         call.out, call.h1, call.h2 = ops.mlp_train(dec.packed(), call.feat, call.aux, impl=impl)
         assert gerr(call.out, y) < 2e-5, impl
-        (g_feat,), grads = training._decoder_backward(dec, [call])
+        (g_feat,), grads = training._decoder_backward(dec, [call], impl=impl)     # exact fp32 / all split-bf16
         if impl == "mfma":
             assert gerr(g_feat[:, :27], fr.grad) < 1e-4, impl
         else:
