@@ -416,13 +416,14 @@ int tir_mlp_bwd_bf16x3(const TirMlp* m, const float* packed_bwd, const float* fe
                 float* g_feat, float* dz1, float* dz2, float* dz3, void* stream);
 
 /* C[M][ldc] += A^T B (+ column N = A^T 1 when ones_col != 0: the bias gradient); A [n][lda] (first M columns),
- * B [n][ldb] (first N columns); M <= 128, N + ones_col <= 160.  fp32 MFMA, split over n. */
+ * B [n][ldb] (first N columns); M <= 128, N + ones_col <= 160.  fp32 MFMA, split over n.  bias_out (may be NULL):
+ * A^T 1 is added to bias_out[M] instead of column N of C, so that C can be the exact [M][N] weight gradient. */
 int tir_gemm_tn(const float* A, int32_t lda, int32_t M, const float* B, int32_t ldb, int32_t N,
-                int32_t ones_col, int64_t n, float* C, int32_t ldc, void* stream);
+                int32_t ones_col, int64_t n, float* C, int32_t ldc, float* bias_out, void* stream);
 /* Same product on the bf16 matrix pipe with every operand split x = hi + lo (3 products, fp32 accumulation:
  * ~2^-16 relative per product, the decoders' split-bf16 scheme). */
 int tir_gemm_tn_bf16x3(const float* A, int32_t lda, int32_t M, const float* B, int32_t ldb, int32_t N,
-                int32_t ones_col, int64_t n, float* C, int32_t ldc, void* stream);
+                int32_t ones_col, int64_t n, float* C, int32_t ldc, float* bias_out, void* stream);
 
 /* Backward of tir_shade_integrate w.r.t. the map rows (normal 4:7, albedo 7:10, roughness 10, fresnel 11:14)
  * and the environment radiance.  g_out [M][3] -> g_maps [M][20] (written), g_env [n_lights][D][3] (accumulated).

@@ -785,7 +785,7 @@ k_vm_app_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, const in
 template <int TPW>                    // 32x32 tiles per wave: 4 * TPW >= MT * NT
 __global__ void __launch_bounds__(256)
 k_gemm_tn(const float* __restrict__ A, int lda, int M, const float* __restrict__ Bm, int ldb, int N, int ones_col,
-          int64_t n, float* __restrict__ C, int ldc, int64_t chunk) {
+          int64_t n, float* __restrict__ C, int ldc, int64_t chunk, float* __restrict__ bias_out) {
     __shared__ __attribute__((aligned(16))) float As[32 * GT_AS];
     __shared__ __attribute__((aligned(16))) float Bs[32 * GT_BS];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -876,7 +876,10 @@ k_gemm_tn(const float* __restrict__ A, int lda, int M, const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + (r & 3) + 8 * (r >> 2);
-            if (col_ok && row < M) atomic_add_f32(C + (size_t)row * ldc + jcol, acc[i][r]);
+            if (col_ok && row < M) {
+                if (bias_out && jcol == N) atomic_add_f32(bias_out + row, acc[i][r]);      // the ones column, kept apart
+                else atomic_add_f32(C + (size_t)row * ldc + jcol, acc[i][r]);
+            }
         }
     }
 }
@@ -906,7 +909,7 @@ __device__ __forceinline__ void gb_split2(float x0, float x1, unsigned& hi, unsi
 template <int TPW, bool SHARE_A>      // SHARE_A: MT == 4, a wave's tiles all sit in row tile w
 __global__ void __launch_bounds__(256)
 k_gemm_tn_bf16(const float* __restrict__ A, int lda, int M, const float* __restrict__ Bm, int ldb, int N, int ones_col,
-               int64_t n, float* __restrict__ C, int ldc, int64_t chunk) {
+               int64_t n, float* __restrict__ C, int ldc, int64_t chunk, float* __restrict__ bias_out) {
     __shared__ __attribute__((aligned(16))) unsigned short At[2][128 * GB_RS];      // [hi / lo][column][k]
     __shared__ __attribute__((aligned(16))) unsigned short Bt[2][160 * GB_RS];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1012,7 +1015,10 @@ k_gemm_tn_bf16(const float* __restrict__ A, int lda, int M, const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + (r & 3) + 8 * (r >> 2);
-            if (col_ok && row < M) atomic_add_f32(C + (size_t)row * ldc + jcol, acc[i][r]);
+            if (col_ok && row < M) {
+                if (bias_out && jcol == N) atomic_add_f32(bias_out + row, acc[i][r]);      // the ones column, kept apart
+                else atomic_add_f32(C + (size_t)row * ldc + jcol, acc[i][r]);
+            }
         }
     }
 }
@@ -1420,11 +1426,11 @@ extern "C" int tir_vm_app_bwd(const TirField* f, const TirFieldGrad* g, const fl
 }
 
 static int gemm_tn_launch(bool bf16, const float* A, int32_t lda, int32_t M, const float* B, int32_t ldb, int32_t N,
-                          int32_t ones_col, int64_t n, float* C, int32_t ldc, void* stream) {
+                          int32_t ones_col, int64_t n, float* C, int32_t ldc, float* bias_out, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || n < 0) return TIR_ERR_ARG;
-    ones_col = ones_col ? 1 : 0;
+    ones_col = (ones_col || bias_out) ? 1 : 0;
     if (M > 128 || N + ones_col > 160) return TIR_ERR_UNSUPPORTED;
-    if ((lda & 3) || (ldb & 3) || lda < ((M + 3) & ~3) || ldb < ((N + 3) & ~3) || ldc < N + ones_col) return TIR_ERR_ARG;
+    if ((lda & 3) || (ldb & 3) || lda < ((M + 3) & ~3) || ldb < ((N + 3) & ~3) || ldc < N + (bias_out ? 0 : ones_col)) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
     int64_t chunk = (n + 511) / 512;
     chunk = (chunk + 31) / 32 * 32;
@@ -1432,7 +1438,7 @@ static int gemm_tn_launch(bool bf16, const float* A, int32_t lda, int32_t M, con
     const unsigned blocks = (unsigned)((n + chunk - 1) / chunk);
     const int mt = (M + 31) / 32, tiles = mt * ((N + ones_col + 31) / 32);
     hipStream_t s = tir_stream(stream);
-#define TIR_GEMM_ARGS A, lda, M, B, ldb, N, ones_col, n, C, ldc, chunk
+#define TIR_GEMM_ARGS A, lda, M, B, ldb, N, ones_col, n, C, ldc, chunk, bias_out
     if (bf16) {
         if (tiles <= 4)      hipLaunchKernelGGL((k_gemm_tn_bf16<1, false>), dim3(blocks), dim3(256), 0, s, TIR_GEMM_ARGS);
         else if (tiles <= 8) hipLaunchKernelGGL((k_gemm_tn_bf16<2, false>), dim3(blocks), dim3(256), 0, s, TIR_GEMM_ARGS);
@@ -1449,13 +1455,13 @@ static int gemm_tn_launch(bool bf16, const float* A, int32_t lda, int32_t M, con
 }
 
 extern "C" int tir_gemm_tn(const float* A, int32_t lda, int32_t M, const float* B, int32_t ldb, int32_t N,
-                           int32_t ones_col, int64_t n, float* C, int32_t ldc, void* stream) {
-    return gemm_tn_launch(false, A, lda, M, B, ldb, N, ones_col, n, C, ldc, stream);
+                           int32_t ones_col, int64_t n, float* C, int32_t ldc, float* bias_out, void* stream) {
+    return gemm_tn_launch(false, A, lda, M, B, ldb, N, ones_col, n, C, ldc, bias_out, stream);
 }
 
 extern "C" int tir_gemm_tn_bf16x3(const float* A, int32_t lda, int32_t M, const float* B, int32_t ldb, int32_t N,
-                                  int32_t ones_col, int64_t n, float* C, int32_t ldc, void* stream) {
-    return gemm_tn_launch(true, A, lda, M, B, ldb, N, ones_col, n, C, ldc, stream);
+                                  int32_t ones_col, int64_t n, float* C, int32_t ldc, float* bias_out, void* stream) {
+    return gemm_tn_launch(true, A, lda, M, B, ldb, N, ones_col, n, C, ldc, bias_out, stream);
 }
 
 extern "C" int tir_shade_integrate_bwd(const float* maps, const float* rays, const float* dirs,

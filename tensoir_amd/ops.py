@@ -625,16 +625,16 @@ def mlp_bwd(m: "PackedMlp", packed_bwd, feat, out, g_out, h1, h2, impl=None):
     return g_feat, dz1, dz2, dz3
 
 
-def gemm_tn(A, M, B, N, C_out, ones_col=False, impl=None):
-    """C_out[M, N(+1)] += A[:, :M]^T @ B[:, :N]  (+ column N = A^T 1).  Split-bf16 matrix cores when the product's
-    decoder mode is bf16x3 (default), exact fp32 MFMA otherwise."""
+def gemm_tn(A, M, B, N, C_out, ones_col=False, impl=None, bias_out=None):
+    """C_out[M, N(+1)] += A[:, :M]^T @ B[:, :N]  (+ column N = A^T 1, or bias_out[M] += A^T 1 when given).  Split-bf16
+    matrix cores when the product's decoder mode is bf16x3 (default), exact fp32 MFMA otherwise."""
     impl = impl or MLP_IMPL
     A, B = f32(A, "A"), f32(B, "B")
     n = A.shape[0]
     if B.shape[0] != n:
         raise ValueError("gemm_tn: row counts differ")
     _call("tir_gemm_tn_bf16x3" if impl == "bf16x3" else "tir_gemm_tn", _ptr(A), A.shape[1], int(M), _ptr(B), B.shape[1], int(N), int(bool(ones_col)), n,
-          _ptr(C_out), C_out.shape[1], _stream())
+          _ptr(C_out), C_out.shape[1], _ptr(bias_out), _stream())
     return C_out
 
 

@@ -82,18 +82,20 @@ def _decoder_backward(dec, calls, impl=None):
     pm, pb = dec.packed(), _packed_bwd(dec)
     dev = calls[0].feat.device
     od = pm.out_dim
-    dW0 = torch.zeros((128, 152), dtype=torch.float32, device=dev)     # [.., :150] weight, [.., 150] bias
-    dW1 = torch.zeros((128, 132), dtype=torch.float32, device=dev)
-    dW2 = torch.zeros((4, 132), dtype=torch.float32, device=dev)
+    # one zeroed buffer, carved into the six exact-shape (contiguous) gradients: autograd takes them as they are
+    sizes = (128 * 150, 128, 128 * 128, 128, 4 * 128, 4)
+    flat = torch.zeros((sum(sizes),), dtype=torch.float32, device=dev)
+    dW0, db0, dW1, db1, dW2, db2 = (t.view(shape) for t, shape in zip(
+        torch.split(flat, sizes), ((128, 150), (128,), (128, 128), (128,), (4, 128), (4,))))
     g_feats = []
     for c in calls:
         g_feat, dz1, dz2, dz3 = ops.mlp_bwd(pm, pb, c.feat, c.out, c.g_out, c.h1, c.h2, impl=impl)
         x = ops.mlp_inputs(pm, c.feat, c.aux, c.aux_map)
-        ops.gemm_tn(dz1, 128, x, 150, dW0, True, impl=impl)
-        ops.gemm_tn(dz2, 128, c.h1, 128, dW1, True, impl=impl)
-        ops.gemm_tn(dz3, 4, c.h2, 128, dW2, True, impl=impl)
+        ops.gemm_tn(dz1, 128, x, 150, dW0, True, impl=impl, bias_out=db0)
+        ops.gemm_tn(dz2, 128, c.h1, 128, dW1, True, impl=impl, bias_out=db1)
+        ops.gemm_tn(dz3, 4, c.h2, 128, dW2, True, impl=impl, bias_out=db2)
         g_feats.append(g_feat)
-    grads = [dW0[:, :150], dW0[:, 150], dW1[:, :128], dW1[:, 128], dW2[:od, :128], dW2[:od, 128]]
+    grads = [dW0, db0, dW1, db1, dW2[:od], db2[:od]]
     return g_feats, grads
 
 
@@ -271,7 +273,7 @@ class PrimaryRenderFn(torch.autograd.Function):
         for name in ("dp", "dl", "ap", "al"):
             grads += [_to_param_layout(bufs[f"{name}{i}"]) for i in range(3)]
         grads.append(d_basis)
-        grads.append(bufs["ll"] + bufs["lm"][None, :] / float(model.light_num))
+        grads.append(torch.add(bufs["ll"], bufs["lm"][None, :], alpha=1.0 / float(model.light_num)))
         for key, dec in zip(("rgb", "brdf", "normal"), _decoders(model)):
             grads += dec_grads.get(key, [None] * 6)
         assert len(grads) == st.n_params

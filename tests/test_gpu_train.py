@@ -64,6 +64,10 @@ def test_gemm_tn(env, impl, tol):
         assert gerr(C[:, :N], ref) < tol, (n, M, N)
         if ones:
             assert gerr(C[:, N], A[:, :M].double().sum(0)) < tol
+            # the same with the bias column kept apart: C is the exact [M, N] weight gradient
+            Cw, cb = torch.zeros(M, N).cuda(), torch.zeros(M).cuda()
+            ops.gemm_tn(A.cuda(), M, B.cuda(), N, Cw, True, impl=impl, bias_out=cb)
+            assert gerr(Cw, ref) < tol and gerr(cb, A[:, :M].double().sum(0)) < tol, (n, M, N)
         assert float(C[:, N + (1 if ones else 0):].abs().max()) == 0.0
 
 
