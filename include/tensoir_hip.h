@@ -209,6 +209,12 @@ int tir_exclusive_scan(const int32_t* counts, int32_t* offsets, int32_t n, void*
 int tir_exclusive_scan_capped(const int32_t* counts, int32_t* offsets, int32_t n, int32_t cap,
                               int32_t* total, void* stream);
 
+/* Record-capacity check of a captured (HIP-graph) step: copies up to 4 device-side record counters to host_counts and
+ * mirrors a sticky overflow flag (set when counters[i] > caps[i]; cleared only by the caller) to host_flag.  host_counts /
+ * host_flag are pinned host allocations the device can write (hipHostMalloc); `counters` / `caps` are HOST arrays. */
+int tir_record_check(const int32_t* const* counters, const int64_t* caps, int32_t n, int32_t* sticky,
+                     int64_t* host_counts, int32_t* host_flag, void* stream);
+
 /* Compact the samples with weight > thres into records ordered by (ray, sample) -- the order of
  * the reference's boolean-mask indexing xyz_sampled[app_mask] (:924-926).
  * rec_ray [A], rec_k [A], rec_w [A], rec_xyz [A][3] (normalised coords, :916). */

@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import torch
 
-from . import relight  # noqa: F401  (imported for its caches being warmed by the eager call)
+from . import ops, relight  # noqa: F401  (relight: imported for its caches being warmed by the eager call)
 from ._lib import TensoirHipError
 from .renderer import Renderer_TensoIR_train
 
@@ -32,6 +32,11 @@ class GraphedRenderer:
         self.graph = None
         self.out = None
         self.checks = []
+        self._count_pin = torch.empty((8,), dtype=torch.int64, pin_memory=True)    # allocated outside any capture
+        self._sticky = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        self._sticky_pin = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        self._deferred = 0              # replays queued with defer_check=True since the last validate()
+        self.count_host = None          # pinned host mirror of the record counters, written by a copy node of the graph
         self.captures = 0
 
     def _eager(self):
@@ -52,6 +57,16 @@ class GraphedRenderer:
         try:
             with torch.no_grad(), torch.cuda.graph(g):
                 self.out = Renderer_TensoIR_train(self.rays, None, self.lidx, self.model, **self.kw)
+                # the record counters leave the device as part of the graph (one small copy node into pinned memory):
+                # after a replay the host only waits for the stream and reads them -- no extra launches between steps
+                if self.checks:
+                    # the record counters and a sticky overflow flag (never cleared by a replay) leave the device as
+                    # part of the graph: one single-thread kernel writing pinned host memory.  After a replay the host
+                    # only waits for the stream and reads them; a caller may also queue many replays and ask later
+                    # whether ANY of them overflowed (validate()).
+                    self.count_host = self._count_pin[:len(self.checks)]
+                    ops.record_check([t.reshape(1) for t, _, _ in self.checks], [c for _, c, _ in self.checks],
+                                     self._sticky, self.count_host, self._sticky_pin)
         finally:
             self.model.__dict__.pop("_capture", None)
         self.graph = g
@@ -60,7 +75,8 @@ class GraphedRenderer:
     def _overflowed(self):
         if not self.checks:
             return False
-        totals = torch.cat([t.reshape(1) for t, _, _ in self.checks]).tolist()       # the one host read per call
+        torch.cuda.current_stream(self.device).synchronize()                         # the one host wait per call
+        totals = self.count_host.tolist()
         bad = False
         for total, (_, cap, key) in zip(totals, self.checks):
             if total > cap:
@@ -71,18 +87,56 @@ class GraphedRenderer:
                     self.model._rec_cap_hints.pop(key[1], None)
         return bad
 
-    def __call__(self, rays, light_idx):
-        """rays [n_rays, 6], light_idx [n_rays, 1] (any device) -> the 12-key dict (fresh tensors)."""
-        if rays.shape[0] != self.n_rays:
-            raise ValueError(f"GraphedRenderer was built for {self.n_rays} rays, got {rays.shape[0]}")
-        self.rays.copy_(rays.to(self.device, torch.float32), non_blocking=True)
-        self.lidx.copy_(light_idx.to(self.device, torch.int32).view(-1, 1), non_blocking=True)
+    def validate(self):
+        """Wait for the queued replays and report whether all of them stayed within the captured record capacities.
+        False: the outputs of the deferred calls since the last validate() are not to be used -- render them again
+        (the next call re-captures with room)."""
+        torch.cuda.current_stream(self.device).synchronize()
+        self._deferred = 0
+        if int(self._sticky_pin[0]) != 0:
+            self._clear_sticky()
+            for _, _, key in self.checks:                # which replay overflowed is not recorded: relearn all capacities
+                if key[0] == "primary":
+                    self.model._app_cap_hints.pop((key[1], key[2]), None)
+                else:
+                    self.model._rec_cap_hints.pop(key[1], None)
+            self.graph = None
+            return False
+        return True
+
+    def _clear_sticky(self):
+        self._sticky.zero_()
+        torch.cuda.current_stream(self.device).synchronize()
+        self._sticky_pin.zero_()
+
+    def __call__(self, rays=None, light_idx=None, clone_outputs=True, defer_check=False):
+        """rays [n_rays, 6], light_idx [n_rays, 1] (any device) -> the 12-key dict.
+
+        The graph reads its inputs from the static buffers ``self.rays`` / ``self.lidx``: pass tensors to have them
+        copied in, or fill the buffers yourself and pass nothing.  ``clone_outputs=False`` returns the graph's own
+        output tensors (valid until the next call) instead of fresh copies -- a chunked image render that packs each
+        chunk's records right away (``dist.render_sharded``) needs no copies.  ``defer_check=True`` does not wait for
+        the replay: the capacity check is made by ``validate()`` later (a sticky device-side flag covers every replay
+        queued in between), so back-to-back calls keep the GPU busy without a host round trip per step."""
+        if rays is not None and rays is not self.rays:
+            if rays.shape[0] != self.n_rays:
+                raise ValueError(f"GraphedRenderer was built for {self.n_rays} rays, got {rays.shape[0]}")
+            self.rays.copy_(rays.to(self.device, torch.float32), non_blocking=True)
+        if light_idx is not None and light_idx is not self.lidx:
+            self.lidx.copy_(light_idx.to(self.device, torch.int32).view(-1, 1), non_blocking=True)
         for _ in range(3):
             if self.graph is None:
                 self._capture()
             self.graph.replay()
+            if defer_check:
+                self._deferred += 1
+                return dict(self.out) if not clone_outputs else {k: (v.clone() if torch.is_tensor(v) else v)
+                                                                 for k, v in self.out.items()}
             if not self._overflowed():
+                if not clone_outputs:
+                    return dict(self.out)
                 return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.out.items()}
+            self._clear_sticky()
             self.graph = None                            # capacity too small for this batch: re-capture with room
         raise TensoirHipError("record capacity kept overflowing while re-capturing the HIP graph")
 

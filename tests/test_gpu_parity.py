@@ -395,6 +395,28 @@ def test_hip_graph_replay_matches_eager(env):
         for k in keys:
             assert torch.equal(got[k], want[k]), (trial, k)
     assert gr.captures >= 3
+    # static-buffer use: inputs written straight into the graph's buffers, outputs returned without copies
+    gr.rays.copy_(rays)
+    gr.lidx.copy_(lidx.view(-1, 1))
+    want = Renderer_TensoIR_train(rays, None, lidx, m, **kw)
+    got = gr(clone_outputs=False)
+    assert got["rgb_map"].data_ptr() == gr.out["rgb_map"].data_ptr()
+    for k in keys:
+        assert torch.equal(got[k], want[k]), k
+    # deferred capacity check: replays are queued without a host wait, validate() reports on all of them
+    for _ in range(3):
+        got = gr(clone_outputs=False, defer_check=True)
+    assert gr.validate()
+    for k in keys:
+        assert torch.equal(got[k], want[k]), k
+    gr._test_shrink_capacity = 16                        # a capture whose capacity is too small: validate() must say so
+    gr.invalidate()
+    gr(clone_outputs=False, defer_check=True)
+    gr(clone_outputs=False, defer_check=True)
+    assert not gr.validate()
+    got = gr(clone_outputs=False)                        # re-captured with room
+    for k in keys:
+        assert torch.equal(got[k], want[k]), k
 
 
 @torch.no_grad()
