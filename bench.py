@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--no-exact-pass", action="store_true", help="skip the extra timed pass with the exact fp32 decoders")
     ap.add_argument("--breakdown", type=str, default="", help="write the per-kernel table to this file")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying the HIP graph")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="single process: create a 1-rank RCCL group anyway and run the multi-rank code path (all-gather per step)")
     return ap.parse_args()
 
 
@@ -131,10 +133,8 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
     n_gpus = world
+    use_dist = world > 1 or a.force_dist        # one process per GPU over RCCL (--force-dist: the same path on 1 rank)
 
     from tensoir_amd import Renderer_TensoIR_train, _lib, ops
     from tensoir_amd import dist as tdist
@@ -142,10 +142,35 @@ def main():
     ckpt, model, rays, lidx = build_scene(a, device, rank)
     args = types.SimpleNamespace(second_nSample=a.second_samples, second_near=0.05, second_far=1.5)
     B = rays.shape[0]
-    gathered = torch.empty((world * B, tdist.RECORD), dtype=torch.float32, device=device) if world > 1 else None
 
     from tensoir_amd.graph import GraphedRenderer
     graphed = {}
+
+    def make_graph(impl):
+        ops.MLP_IMPL = impl
+        gr = GraphedRenderer(model, B, N_samples=a.samples, args=args, device=device)
+        gr.rays.copy_(rays)                          # the batch is resident in HBM: it sits in the graph's input buffers
+        gr.lidx.copy_(lidx)
+        gr(clone_outputs=False)                      # capture + one checked replay
+        graphed[impl] = gr
+
+    # Every rank captures its step graph(s) BEFORE the process group exists: no RCCL thread is alive yet that could
+    # issue a call into the runtime while the stream is capturing.  Replays and the per-step all-gather then simply
+    # follow each other on the stream.
+    if not a.no_graph:
+        try:
+            for impl in dict.fromkeys([a.decoder] + (["mfma"] if a.decoder != "mfma" and not a.no_exact_pass else [])):
+                make_graph(impl)
+        except Exception as e:                       # capture refused on this box: the eager path is the same work
+            print(f"[bench] HIP-graph capture unavailable ({type(e).__name__}: {e}); using eager launches",
+                  file=sys.stderr, flush=True)
+            graphed.clear()
+            a.no_graph = True
+        ops.MLP_IMPL = a.decoder
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    gathered = torch.empty((world * B, tdist.RECORD), dtype=torch.float32, device=device) if use_dist else None
 
     def step(eager=False):
         with torch.no_grad():
@@ -154,12 +179,12 @@ def main():
                                              is_train=False, is_relight=True, sample_method="fixed_envirmap",
                                              chunk_size=160000, device=device, args=args)
             else:           # the same launches, replayed as one HIP graph per decoder mode (tensoir_amd/graph.py)
-                gr = graphed.get(ops.MLP_IMPL)
-                if gr is None:
-                    gr = graphed[ops.MLP_IMPL] = GraphedRenderer(model, B, N_samples=a.samples, args=args, device=device)
-                    gr.rays.copy_(rays)              # the batch is resident in HBM: it sits in the graph's input buffers
-                    gr.lidx.copy_(lidx)
                 try:
+                    if ops.MLP_IMPL not in graphed:
+                        if use_dist:
+                            raise RuntimeError("no graph was captured for this decoder mode before the process group was created")
+                        make_graph(ops.MLP_IMPL)
+                    gr = graphed[ops.MLP_IMPL]
                     # outputs stay in the graph's buffers (valid until the next step); the record-capacity check of all
                     # queued replays is made once, inside the timed region, by validate() below
                     ret = gr(clone_outputs=False, defer_check=not getattr(a, "no_defer", False))
@@ -168,14 +193,14 @@ def main():
                           file=sys.stderr, flush=True)
                     a.no_graph = True
                     return step()
-            if world > 1:   # the one exchange step: all-gather of the rendered per-ray records
+            if use_dist:   # the one exchange step: all-gather of the rendered per-ray records
                 dist.all_gather_into_tensor(gathered, tdist.pack_records(ret))
         return ret
 
     def timed(n_warm, n_steps):
         for _ in range(n_warm):
             step()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -184,21 +209,22 @@ def main():
             r = step()
         torch.cuda.synchronize()
         valid = all(g.validate() for g in graphed.values())        # sticky overflow flag of every replay queued above
-        if world > 1:
+        if use_dist:
             dist.barrier()
         el = time.perf_counter() - t0
         if not valid:                                              # a capacity overflowed: time again with per-step checks
             print("[bench] a deferred record-capacity check failed; re-timing with per-step checks", file=sys.stderr, flush=True)
-            a.no_defer = True
+            if use_dist:
+                a.no_graph = True          # a re-capture would run next to live RCCL threads: finish eagerly instead
+            else:
+                a.no_defer = True
             return timed(n_warm, n_steps)
-        if world > 1:
+        if use_dist:
             t = torch.tensor([el], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, r
 
-    if world > 1:
-        a.no_graph = True       # RCCL's watchdog thread may touch the device during a capture: keep multi-rank runs eager
     ops.MLP_IMPL = a.decoder
     elapsed, ret = timed(a.warmup, a.steps)
     exact = None
@@ -265,7 +291,7 @@ def main():
     gpu_ms = sum(r["ms_per_step"] for r in rows)
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -344,7 +370,7 @@ def main():
         with open(a.breakdown, "w") as fh:
             json.dump({"rows": rows, "elapsed_s": elapsed, "steps": a.steps}, fh, indent=1)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
