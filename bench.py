@@ -209,13 +209,13 @@ def main():
             r = step()
         torch.cuda.synchronize()
         valid = all(g.validate() for g in graphed.values())        # sticky overflow flag of every replay queued above
-        if use_dist:                                               # re-timing is a collective decision
-            ok = torch.tensor([1 if valid else 0], dtype=torch.int32, device=device)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            valid = bool(ok.item())
         if use_dist:
             dist.barrier()
         el = time.perf_counter() - t0
+        if use_dist:                                               # re-timing is a collective decision (taken off the clock)
+            ok = torch.tensor([1 if valid else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            valid = bool(ok.item())
         if not valid:                                              # a capacity overflowed: time again with per-step checks
             print("[bench] a deferred record-capacity check failed; re-timing with per-step checks", file=sys.stderr, flush=True)
             if use_dist:
