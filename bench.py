@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-exact-pass", action="store_true", help="skip the extra timed pass with the exact fp32 decoders")
     ap.add_argument("--breakdown", type=str, default="", help="write the per-kernel table to this file")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying the HIP graph")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--force-dist", action="store_true",
                     help="single process: create a 1-rank RCCL group anyway and run the multi-rank code path (all-gather per step)")
     return ap.parse_args()
@@ -169,7 +170,7 @@ def main():
         ops.MLP_IMPL = a.decoder
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group(a.backend, **({"device_id": device} if a.backend == "nccl" else {}))
     gathered = torch.empty((world * B, tdist.RECORD), dtype=torch.float32, device=device) if use_dist else None
 
     def step(eager=False):
