@@ -39,20 +39,15 @@ def shard_capacity(n_rays: int, world: int, tile: int = 0) -> int:
 
 
 def pack_records(ret: dict) -> torch.Tensor:
-    """12-key dict of Renderer_TensoIR_train -> [n, RECORD] record rows."""
-    n = ret["rgb_map"].shape[0]
-    rec = torch.zeros((n, RECORD), dtype=torch.float32, device=ret["rgb_map"].device)
-    rec[:, 0:3] = ret["rgb_map"]
-    rec[:, 3] = ret["depth_map"]
-    rec[:, 4:7] = ret["normal_map"]
-    rec[:, 7:10] = ret["albedo_map"]
-    rec[:, 10:11] = ret["roughness_map"]
-    rec[:, 11:14] = ret["fresnel_map"]
-    rec[:, 14] = ret["acc_map"]
-    rec[:, 15:16] = ret["normals_diff_map"]
-    rec[:, 16:17] = ret["normals_orientation_loss_map"]
-    rec[:, 20:23] = ret["rgb_with_brdf_map"]
-    return rec
+    """12-key dict of Renderer_TensoIR_train -> [n, RECORD] record rows (one concatenation kernel)."""
+    rgb = ret["rgb_map"]
+    n = rgb.shape[0]
+    col = lambda t: t.reshape(n, -1).to(torch.float32)
+    pad = rgb.new_zeros((n, 3), dtype=torch.float32)
+    return torch.cat([col(rgb), col(ret["depth_map"]), col(ret["normal_map"]), col(ret["albedo_map"]),
+                      col(ret["roughness_map"]), col(ret["fresnel_map"]), col(ret["acc_map"]),
+                      col(ret["normals_diff_map"]), col(ret["normals_orientation_loss_map"]), pad,
+                      col(ret["rgb_with_brdf_map"]), pad[:, :1]], dim=1)
 
 
 def unpack_records(rec: torch.Tensor) -> dict:
