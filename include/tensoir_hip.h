@@ -209,11 +209,12 @@ int tir_exclusive_scan(const int32_t* counts, int32_t* offsets, int32_t n, void*
 int tir_exclusive_scan_capped(const int32_t* counts, int32_t* offsets, int32_t n, int32_t cap,
                               int32_t* total, void* stream);
 
-/* Record-capacity check of a captured (HIP-graph) step: copies up to 4 device-side record counters to host_counts and
- * mirrors a sticky overflow flag (set when counters[i] > caps[i]; cleared only by the caller) to host_flag.  host_counts /
- * host_flag are pinned host allocations the device can write (hipHostMalloc); `counters` / `caps` are HOST arrays. */
-int tir_record_check(const int32_t* const* counters, const int64_t* caps, int32_t n, int32_t* sticky,
-                     int64_t* host_counts, int32_t* host_flag, void* stream);
+/* Record-capacity check of a captured (HIP-graph) step.  `state` (device, int64[5], zeroed by the caller, never cleared
+ * by the call): running maximum of each of up to 4 device-side record counters [0..3] and a sticky overflow flag [4]
+ * (set when counters[i] > caps[i]).  `host_out` (pinned host memory the device can write, int64[9]) receives this
+ * launch's counters [0..3], the running maxima [4..7] and the flag [8].  `counters` / `caps` are HOST arrays. */
+int tir_record_check(const int32_t* const* counters, const int64_t* caps, int32_t n, int64_t* state,
+                     int64_t* host_out, void* stream);
 
 /* Compact the samples with weight > thres into records ordered by (ray, sample) -- the order of
  * the reference's boolean-mask indexing xyz_sampled[app_mask] (:924-926).

@@ -155,34 +155,40 @@ extern "C" int tir_exclusive_scan_capped(const int32_t* counts, int32_t* offsets
 }
 
 // ------------------------------------------------------------------------------------------------
-// Record-capacity check of a captured step (tensoir_amd/graph.py): the device-side record counters go to (pinned,
-// device-mapped) host memory and a STICKY overflow flag -- set by any launch whose counter exceeded its capacity, never
-// cleared here -- is mirrored next to them.  One single-thread kernel instead of a handful of framework ops per replay.
+// Record-capacity check of a captured step (tensoir_amd/graph.py).  Device state (int64[5], kept by the caller, never
+// cleared here): running maximum of each counter over all launches [0..3] and a STICKY overflow flag [4], set by any
+// launch whose counter exceeded its capacity.  Every launch mirrors {this launch's counters [0..3], the running maxima
+// [4..7], the flag [8]} into pinned, device-mapped host memory.  One single-thread kernel instead of a handful of
+// framework ops per replay; a caller can queue many replays and later learn whether any overflowed and by how much.
 // ------------------------------------------------------------------------------------------------
 struct TirCheck4 { const int32_t* cnt[4]; int64_t cap[4]; int n; };
 
-__global__ void k_record_check(TirCheck4 c, int32_t* __restrict__ sticky, int64_t* __restrict__ host_counts,
-                               int32_t* __restrict__ host_flag) {
+__global__ void k_record_check(TirCheck4 c, int64_t* __restrict__ state, int64_t* __restrict__ host_out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int over = *sticky;
-    for (int i = 0; i < c.n; ++i) {
-        const int64_t v = *c.cnt[i];
-        host_counts[i] = v;
-        if (v > c.cap[i]) over = 1;
+    int64_t over = state[4];
+    for (int i = 0; i < 4; ++i) {
+        int64_t v = 0;
+        if (i < c.n) {
+            v = *c.cnt[i];
+            if (v > c.cap[i]) over = 1;
+            if (v > state[i]) state[i] = v;
+        }
+        host_out[i] = v;
+        host_out[4 + i] = state[i];
     }
-    *sticky = over;
-    *host_flag = over;
+    state[4] = over;
+    host_out[8] = over;
     __threadfence_system();
 }
 
-extern "C" int tir_record_check(const int32_t* const* counters, const int64_t* caps, int32_t n, int32_t* sticky,
-                                int64_t* host_counts, int32_t* host_flag, void* stream) {
-    if (n < 0 || n > 4 || !sticky || !host_counts || !host_flag || (n > 0 && (!counters || !caps))) return TIR_ERR_ARG;
+extern "C" int tir_record_check(const int32_t* const* counters, const int64_t* caps, int32_t n, int64_t* state,
+                                int64_t* host_out, void* stream) {
+    if (n < 0 || n > 4 || !state || !host_out || (n > 0 && (!counters || !caps))) return TIR_ERR_ARG;
     TirCheck4 c;
     c.n = n;
     for (int i = 0; i < 4; ++i) { c.cnt[i] = i < n ? counters[i] : nullptr; c.cap[i] = i < n ? caps[i] : 0; }
     for (int i = 0; i < n; ++i) if (!c.cnt[i]) return TIR_ERR_ARG;
-    hipLaunchKernelGGL(k_record_check, dim3(1), dim3(64), 0, tir_stream(stream), c, sticky, host_counts, host_flag);
+    hipLaunchKernelGGL(k_record_check, dim3(1), dim3(64), 0, tir_stream(stream), c, state, host_out);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

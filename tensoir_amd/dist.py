@@ -78,7 +78,9 @@ def render_sharded(render_fn, rays, light_idx, rank=None, world=None, chunk=4096
     """Render `rays` ([N,6], identical on every rank) data-parallel over ranks.
 
     render_fn(rays_chunk, light_idx_chunk) -> dict with the keys of Renderer_TensoIR_train.
-    Every rank returns the full-image dict (one all-gather per image, not per chunk).
+    Every rank returns the full-image dict (one all-gather per image, not per chunk).  A render_fn with a
+    ``validate()`` method (GraphedChunkRenderer) is asked once per image whether its deferred capacity checks held;
+    if not, this rank's chunks are rendered again (the renderer re-captures with room).
     """
     if world is None:
         world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -86,16 +88,48 @@ def render_sharded(render_fn, rays, light_idx, rank=None, world=None, chunk=4096
         rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = rays.shape[0]
     mine = shard_rows(n, rank, world, tile).to(rays.device)
-    parts = []
-    for c in torch.split(mine, chunk):
-        if c.numel() == 0:
-            continue
-        parts.append(pack_records(render_fn(rays[c], light_idx[c])))
+    for attempt in range(4):
+        parts = []
+        for c in torch.split(mine, chunk):
+            if c.numel() == 0:
+                continue
+            parts.append(pack_records(render_fn(rays[c], light_idx[c])))
+        validate = getattr(render_fn, "validate", None)
+        if validate is None or validate():
+            break
+    else:
+        raise RuntimeError("render_sharded: the renderer's record capacity kept overflowing")
     if parts:
         local = torch.cat(parts, dim=0)
     else:
         local = torch.zeros((0, RECORD), dtype=torch.float32, device=rays.device)
     return unpack_records(gather_records(local, n, rank, world, tile, group))
+
+
+class GraphedChunkRenderer:
+    """render_fn for render_sharded: full chunks replay ONE captured HIP graph with no host wait per chunk (inputs go
+    into the graph's static buffers, outputs are packed straight from them, the record-capacity check of all replays
+    is made once per image by validate()); a ragged last chunk takes the eager renderer."""
+
+    def __init__(self, tensoIR, chunk, args, N_samples=-1, white_bg=True, is_relight=True, device="cuda"):
+        from .graph import GraphedRenderer
+        from .renderer import Renderer_TensoIR_train
+        self.gr = GraphedRenderer(tensoIR, chunk, N_samples=N_samples, white_bg=white_bg, is_relight=is_relight,
+                                  args=args, device=device)
+        self._eager = lambda r, l: Renderer_TensoIR_train(r, None, l, tensoIR, N_samples=N_samples, white_bg=white_bg,
+                                                          is_train=False, is_relight=is_relight,
+                                                          sample_method="fixed_envirmap", device=device, args=args)
+
+    @torch.no_grad()
+    def __call__(self, rays, light_idx):
+        if rays.shape[0] != self.gr.n_rays:
+            return self._eager(rays, light_idx)
+        self.gr.rays.copy_(rays, non_blocking=True)
+        self.gr.lidx.copy_(light_idx.reshape(-1, 1), non_blocking=True)
+        return self.gr(clone_outputs=False, defer_check=True)
+
+    def validate(self):
+        return self.gr.validate()
 
 
 # ---- data-parallel training (SURVEY.md section 8(f)-4; the reference itself never all-reduces: section 2.1) ----------

@@ -32,11 +32,11 @@ class GraphedRenderer:
         self.graph = None
         self.out = None
         self.checks = []
-        self._count_pin = torch.empty((8,), dtype=torch.int64, pin_memory=True)    # allocated outside any capture
-        self._sticky = torch.zeros((1,), dtype=torch.int32, device=self.device)
-        self._sticky_pin = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        # written by the last node of the graph (tir_record_check): this replay's record counters [0:4], their running
+        # maxima over all replays [4:8], sticky overflow flag [8]; `_state` is the device side of maxima + flag
+        self._host = torch.zeros((9,), dtype=torch.int64).pin_memory()             # allocated outside any capture
+        self._state = torch.zeros((5,), dtype=torch.int64, device=self.device)
         self._deferred = 0              # replays queued with defer_check=True since the last validate()
-        self.count_host = None          # pinned host mirror of the record counters, written by a copy node of the graph
         self.captures = 0
 
     def _eager(self):
@@ -47,6 +47,13 @@ class GraphedRenderer:
         self._eager()                                     # learns the capacities, fills every cache, sets kernel attributes
         self._eager()                                     # and exercises the hinted (sync-free) route once
         torch.cuda.synchronize()
+        # never capture with less room than an earlier capture of this renderer had: a chunked image render walks
+        # through light and heavy chunks, and the capacity should converge to the heaviest instead of following the last
+        for (kind, *key), cap in self.__dict__.get("_cap_floor", {}).items():
+            hints = self.model._app_cap_hints if kind == "primary" else self.model._rec_cap_hints
+            k = tuple(key) if kind == "primary" else key[0]
+            if k in hints:
+                hints[k] = max(hints[k], cap)
         shrink = self.__dict__.pop("_test_shrink_capacity", None)      # tests: capture with a capacity that is too small
         if shrink:
             for k in list(self.model._app_cap_hints):
@@ -60,54 +67,66 @@ class GraphedRenderer:
                 # the record counters leave the device as part of the graph (one small copy node into pinned memory):
                 # after a replay the host only waits for the stream and reads them -- no extra launches between steps
                 if self.checks:
-                    # the record counters and a sticky overflow flag (never cleared by a replay) leave the device as
-                    # part of the graph: one single-thread kernel writing pinned host memory.  After a replay the host
-                    # only waits for the stream and reads them; a caller may also queue many replays and ask later
-                    # whether ANY of them overflowed (validate()).
-                    self.count_host = self._count_pin[:len(self.checks)]
+                    # the record counters, their running maxima and a sticky overflow flag (never cleared by a replay)
+                    # leave the device as part of the graph: one single-thread kernel writing pinned host memory.
+                    # After a replay the host only waits for the stream and reads them; a caller may also queue many
+                    # replays and ask later whether ANY of them overflowed, and how much room they need (validate()).
                     ops.record_check([t.reshape(1) for t, _, _ in self.checks], [c for _, c, _ in self.checks],
-                                     self._sticky, self.count_host, self._sticky_pin)
+                                     self._state, self._host)
         finally:
             self.model.__dict__.pop("_capture", None)
         self.graph = g
         self.captures += 1
+        if not shrink:
+            floor = self.__dict__.setdefault("_cap_floor", {})
+            for _, cap, key in self.checks:
+                floor[key] = max(floor.get(key, 0), cap)
 
     def _overflowed(self):
         if not self.checks:
             return False
         torch.cuda.current_stream(self.device).synchronize()                         # the one host wait per call
-        totals = self.count_host.tolist()
+        totals = self._host[:len(self.checks)].tolist()
         bad = False
         for total, (_, cap, key) in zip(totals, self.checks):
             if total > cap:
                 bad = True
-                if key[0] == "primary":
-                    self.model._app_cap_hints.pop((key[1], key[2]), None)             # relearnt by the next eager call
-                else:
-                    self.model._rec_cap_hints.pop(key[1], None)
+                self._need(key, total)
         return bad
+
+    def _need(self, key, total):
+        """A replay produced `total` records for `key`: the next capture gets room for it (and the eager call that
+        precedes the capture relearns the hint)."""
+        floor = self.__dict__.setdefault("_cap_floor", {})
+        need = int(total * 1.25) + 4096
+        if key[0] == "primary":
+            need = min(need, key[1] * key[2])              # never more than rays x samples
+        floor[key] = max(floor.get(key, 0), need)
+        if key[0] == "primary":
+            self.model._app_cap_hints.pop((key[1], key[2]), None)
+        else:
+            self.model._rec_cap_hints.pop(key[1], None)
 
     def validate(self):
         """Wait for the queued replays and report whether all of them stayed within the captured record capacities.
         False: the outputs of the deferred calls since the last validate() are not to be used -- render them again
-        (the next call re-captures with room)."""
+        (the next call re-captures with room for the largest count seen)."""
         torch.cuda.current_stream(self.device).synchronize()
         self._deferred = 0
-        if int(self._sticky_pin[0]) != 0:
-            self._clear_sticky()
-            for _, _, key in self.checks:                # which replay overflowed is not recorded: relearn all capacities
-                if key[0] == "primary":
-                    self.model._app_cap_hints.pop((key[1], key[2]), None)
-                else:
-                    self.model._rec_cap_hints.pop(key[1], None)
-            self.graph = None
-            return False
-        return True
+        if int(self._host[8]) == 0:
+            return True
+        maxima = self._host[4:4 + len(self.checks)].tolist()
+        for total, (_, cap, key) in zip(maxima, self.checks):
+            if total > cap:
+                self._need(key, total)
+        self._clear_sticky()
+        self.graph = None
+        return False
 
     def _clear_sticky(self):
-        self._sticky.zero_()
+        self._state.zero_()
         torch.cuda.current_stream(self.device).synchronize()
-        self._sticky_pin.zero_()
+        self._host.zero_()
 
     def __call__(self, rays=None, light_idx=None, clone_outputs=True, defer_check=False):
         """rays [n_rays, 6], light_idx [n_rays, 1] (any device) -> the 12-key dict.

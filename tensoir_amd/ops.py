@@ -94,18 +94,20 @@ def to_device(t, device, dtype=None):
     return t.to(device) if dtype is None else t.to(device, dtype)
 
 
-def record_check(counters, caps, sticky, host_counts, host_flag):
-    """One kernel: device record counters -> pinned host_counts, sticky overflow flag (device int32) -> pinned host_flag."""
+def record_check(counters, caps, state, host_out):
+    """One kernel: device record counters -> pinned host_out (counts [0:4], running maxima [4:8], sticky overflow flag
+    [8]); `state` = device int64[5] holding the maxima and the flag across launches."""
     n = len(counters)
-    ptrs = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in counters])
-    cap_arr = (C.c_int64 * max(n, 1))(*[int(c) for c in caps])
     for t in counters:
         if t.dtype != torch.int32 or not t.is_cuda:
             raise _lib.TensoirHipError("record_check: counters must be int32 device tensors")
-    if not (host_counts.is_pinned() and host_flag.is_pinned()):
-        raise _lib.TensoirHipError("record_check: host buffers must be pinned")
-    _call("tir_record_check", ptrs, cap_arr, n, _ptr(sticky), C.c_void_p(host_counts.data_ptr()),
-          C.c_void_p(host_flag.data_ptr()), _stream())
+    if not host_out.is_pinned() or host_out.dtype != torch.int64 or host_out.numel() < 9:
+        raise _lib.TensoirHipError("record_check: host_out must be a pinned int64[9] tensor")
+    if state.dtype != torch.int64 or state.numel() < 5 or not state.is_cuda:
+        raise _lib.TensoirHipError("record_check: state must be a device int64[5] tensor")
+    ptrs = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in counters])
+    cap_arr = (C.c_int64 * max(n, 1))(*[int(c) for c in caps])
+    _call("tir_record_check", ptrs, cap_arr, n, _ptr(state), C.c_void_p(host_out.data_ptr()), _stream())
 
 
 # ---- packing ------------------------------------------------------------------------------------

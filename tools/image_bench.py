@@ -18,6 +18,8 @@ for name, narrow in (("object fills the frame", 0.45), ("full field of view (cor
     lidx = (torch.arange(rays.shape[0], device="cuda") % 3).to(torch.int32).view(-1, 1)
     fn = lambda r, l: Renderer_TensoIR_train(r, None, l, m, N_samples=-1, white_bg=True, is_train=False, is_relight=True,
                                              sample_method="fixed_envirmap", device="cuda", args=args)
+    if os.environ.get("IMAGE_BENCH_EAGER") != "1":      # default: one captured graph per chunk shape, checks deferred per image
+        fn = tdist.GraphedChunkRenderer(m, 4096, args)
     with torch.no_grad():
         img = tdist.render_sharded(fn, rays, lidx, rank=0, world=1, chunk=4096)
         torch.cuda.synchronize()
@@ -26,6 +28,6 @@ for name, narrow in (("object fills the frame", 0.45), ("full field of view (cor
             img = tdist.render_sharded(fn, rays, lidx, rank=0, world=1, chunk=4096)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 3
-    out[name] = {"s_per_image": round(dt, 4), "rays_per_s": round(rays.shape[0] / dt, 1), "n_samples": m.nSamples,
+    out[name] = {"launch": "eager" if os.environ.get("IMAGE_BENCH_EAGER") == "1" else "hip-graph replay per chunk", "s_per_image": round(dt, 4), "rays_per_s": round(rays.shape[0] / dt, 1), "n_samples": m.nSamples,
                  "hit_fraction": round(float((img["acc_map"] > 0.5).float().mean()), 3)}
 print(json.dumps({"config": "C4: 800x800, 300^3 field, 3 light rotations, 128 dirs x 96 secondary samples, 1 GPU", "results": out}))
