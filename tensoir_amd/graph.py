@@ -3,9 +3,12 @@
 A step of ``Renderer_TensoIR_train`` is ~25 short kernel launches plus their buffer allocations; issued eagerly the
 host needs ~0.8 ms per step, which the primary stage (0.25 ms of GPU work) cannot hide, and the two record-capacity
 checks drain the queue.  ``GraphedRenderer`` captures the whole step once -- all launches go to the capture stream
-through the same C ABI, all buffers live in the graph's private pool -- and replays it with one launch; the two
-device-side record counters are read after the replay, and an overflow (more w > thres samples than the captured
-capacity) re-captures with larger buffers.  Results are identical to the eager path.
+through the same C ABI, all buffers live in the graph's private pool -- and replays it with one launch.  The last node
+of the graph writes the two device-side record counters, their running maxima and a sticky overflow flag into pinned
+host memory (tir_record_check), so NOTHING is launched between replays: the host waits for the stream and reads them
+(or, with ``defer_check``, queues replays back to back and asks ``validate()`` once); an overflow (more w > thres
+samples than the captured capacity) re-captures with room for the largest count seen.  Results are identical to the
+eager path.
 
 Constraints (checked): inference only (no autograd, ``is_train=False``), ``sample_method='fixed_envirmap'`` (the
 stratified direction jitter is a host-side RNG draw), fixed number of rays per call.
@@ -64,8 +67,6 @@ class GraphedRenderer:
         try:
             with torch.no_grad(), torch.cuda.graph(g):
                 self.out = Renderer_TensoIR_train(self.rays, None, self.lidx, self.model, **self.kw)
-                # the record counters leave the device as part of the graph (one small copy node into pinned memory):
-                # after a replay the host only waits for the stream and reads them -- no extra launches between steps
                 if self.checks:
                     # the record counters, their running maxima and a sticky overflow flag (never cleared by a replay)
                     # leave the device as part of the graph: one single-thread kernel writing pinned host memory.
