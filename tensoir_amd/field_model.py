@@ -666,7 +666,7 @@ class TensorVMSplit(nn.Module):
 
     # ---- the primary pass ----------------------------------------------------------------------------
     def forward(self, rays_chunk, light_idx, white_bg=True, is_train=False, ndc_ray=False, is_relight=True,
-                N_samples=-1, _brdf_jitter_dense=None, _return_maps=False, _defer_check=False):
+                N_samples=-1, _brdf_jitter_dense=None, _return_maps=False, _defer_check=False, _want_mask=True):
         """TensorBase.forward (models/tensorBase_rotated_lights.py:868-1036) as a chain of HIP launches:
         march -> scan -> compact -> appearance gather -> decoders -> analytic normals -> composite.
 
@@ -697,7 +697,7 @@ class TensorVMSplit(nn.Module):
                 except training._CapacityOverflow:     # hint dropped: the second attempt counts exactly
                     if attempt:
                         raise
-            out = self.unpack_maps(maps, is_relight)
+            out = self.unpack_maps(maps, is_relight, want_mask=_want_mask)
             return (out, maps) if _return_maps else out
         # Record capacity: the number A of w > thres samples is only known on the device.  The first call per
         # (B, S) reads it back (one host sync in the middle of the pass); later inference calls size their buffers
@@ -760,8 +760,8 @@ class TensorVMSplit(nn.Module):
             self.__dict__["_pending_primary"] = finish
         elif not finish():
             return self.forward(rays_chunk, light_idx, white_bg, is_train, ndc_ray, is_relight, N_samples,
-                                _brdf_jitter_dense, _return_maps)
-        out = self.unpack_maps(maps, is_relight)
+                                _brdf_jitter_dense, _return_maps, False, _want_mask)
+        out = self.unpack_maps(maps, is_relight, want_mask=_want_mask)
         return (out, maps) if _return_maps else out
 
     def _finish_primary(self):
@@ -770,11 +770,12 @@ class TensorVMSplit(nn.Module):
         return True if fin is None else fin()
 
     @staticmethod
-    def unpack_maps(maps, is_relight=True):
-        """[B,20] map rows -> the reference's 12-tuple (:1033-1036 / :983-986)."""
+    def unpack_maps(maps, is_relight=True, want_mask=True):
+        """[B,20] map rows -> the reference's 12-tuple (:1033-1036 / :983-986).  want_mask=False leaves acc_mask out
+        (None): Renderer_TensoIR_train shades from the map rows and never looks at it -- one launch less per step."""
         if not is_relight:
             return (maps[:, 0:3], maps[:, 3], None, None, None, None, maps[:, 14], None, None, None, None, None)
         acc = maps[:, 14]
         smooth = torch.mean(maps[:, 17:19], dim=0)        # both smoothness losses in one reduction launch
         return (maps[:, 0:3], maps[:, 3], maps[:, 4:7], maps[:, 7:10], maps[:, 10:11], maps[:, 11:14], acc,
-                maps[:, 15:16], maps[:, 16:17], acc > 0.5, smooth[0], smooth[1])
+                maps[:, 15:16], maps[:, 16:17], (acc > 0.5) if want_mask else None, smooth[0], smooth[1])

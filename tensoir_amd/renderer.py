@@ -20,7 +20,7 @@ def Renderer_TensoIR_train(rays=None, normal_gt=None, light_idx=None, tensoIR=No
         (rgb_map, depth_map, normal_map, albedo_map, roughness_map, fresnel_map, acc_map, normals_diff_map,
          normals_orientation_loss_map, acc_mask, albedo_smoothness_loss, roughness_smoothness_loss), maps = \
             tensoIR(rays, light_idx, is_train=is_train, white_bg=white_bg, is_relight=is_relight, ndc_ray=ndc_ray,
-                    N_samples=N_samples, _return_maps=True, _defer_check=attempt == 0)
+                    N_samples=N_samples, _return_maps=True, _defer_check=attempt == 0, _want_mask=False)
         if tensoIR.normals_kind == "gt_normals" and normal_gt is not None:
             normal_map = ops.to_device(normal_gt, device)
         if is_relight:
