@@ -475,3 +475,45 @@ def test_grid_400_training_and_inference_smoke(env):
             assert bool(torch.isfinite(p.grad).all()), name
             n_grad += int(p.grad.abs().sum() > 0)
     assert n_grad >= 18
+
+
+def test_full_size_training_properties():
+    """BASELINE size (4096 rays x 512 samples, R = 300, 128 directions x 96 secondary samples): size-independent
+    properties of the training step -- (1) the training forward renders the inference forward's maps, (2) the backward
+    is linear in the loss (gradients of 2 L are 2 x gradients of L up to the order of the atomic adds), (3) the
+    capacity-hint route (second call) reproduces the exact route (first call), (4) every gradient is finite and every
+    field parameter receives one."""
+    import types
+    import tensoir_amd
+    from tensoir_amd import Renderer_TensoIR_train, synth
+    ck = synth.make_checkpoint(grid=(300, 300, 300), seed=20211202)
+    m = tensoir_amd.model_from_checkpoint(ck, "cuda", envmap_h=8, envmap_w=16)
+    with torch.no_grad():
+        m.updateAlphaMask((128, 128, 128))
+    rays = synth.make_rays(64, 64).cuda()
+    lidx = torch.zeros(4096, 1, dtype=torch.int32, device="cuda")
+    args = types.SimpleNamespace(second_nSample=96, second_near=0.05, second_far=1.5)
+    kw = dict(N_samples=512, white_bg=True, is_train=False, is_relight=True, sample_method="fixed_envirmap",
+              device="cuda", args=args)
+    with torch.no_grad():
+        ref = Renderer_TensoIR_train(rays, None, lidx, m, **kw)
+
+    def run(scale):
+        m.zero_grad(set_to_none=True)
+        ret = Renderer_TensoIR_train(rays, None, lidx, m, **kw)
+        loss = scale * (torch.mean((ret["rgb_map"] - 0.3) ** 2) + 0.2 * torch.mean((ret["rgb_with_brdf_map"] - 0.3) ** 2)
+                        + 1e-3 * ret["normals_diff_map"].mean())
+        loss.backward()
+        return ret, float(loss.detach()), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    ret1, l1, g1 = run(1.0)                               # exact route (learns the record capacities)
+    for k in ("rgb_map", "depth_map", "normal_map", "albedo_map", "acc_map", "rgb_with_brdf_map"):
+        assert gerr(ret1[k], ref[k]) < 2e-5, k            # (1)
+    ret2, l2, g2 = run(2.0)                               # capacity-hint route, doubled loss
+    assert abs(l2 - 2.0 * l1) < 1e-6 * max(1.0, abs(l1))   # (3) same forward
+    assert set(g1) == set(g2) and len(g1) >= 30
+    for n in g1:
+        assert bool(torch.isfinite(g1[n]).all()), n       # (4)
+        assert gerr(g2[n], 2.0 * g1[n]) < 2e-4, n         # (2)
+    for n in ("density_plane.0", "density_line.2", "app_plane.1", "app_line.0", "basis_mat.weight"):
+        assert float(g1[n].abs().sum()) > 0.0, n
