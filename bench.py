@@ -30,6 +30,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L2_PEAK_GBS = 34500.0          # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate over the 8 XCDs
+GATHER_BENCH_TAPS = 157e9      # tools/gather_bench.hip (profiles/r01_v5_gather_bench.txt): 192-B taps/s when
+                               # consecutive samples share cells -- the measured ceiling of this access pattern
 F32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TF = 2500.0     # v_mfma_f32_32x32x16_bf16 dense peak
 # algorithmic bytes per unit of work ("gather-bytes model")
@@ -48,7 +51,9 @@ def parse():
     ap.add_argument("--env-h", type=int, default=8)
     ap.add_argument("--env-w", type=int, default=16)
     ap.add_argument("--second-samples", type=int, default=96)
-    ap.add_argument("--cpu-rays", type=int, default=256, help="rays in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-rays", type=int, default=1024, help="rays in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-calls", type=int, default=5, help="timed CPU-baseline calls (after 2 warm-ups)")
+    ap.add_argument("--boundary-calls", type=int, default=50, help="timed eager boundary calls (after 10 warm-ups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--decoder", type=str, default="bf16x3", choices=["mfma", "bf16x3"],
@@ -105,12 +110,13 @@ def kernel_table(timing, stats, steps, shapes):
             gathered = int(stats[name].item()) / (k["launches"] / steps)      # counters come from ONE step
             extra = units["io_bytes"] if units else 0
             by = gathered * B_DENSITY_SAMPLE + extra
-            row.update(bound="hbm", units=gathered, unit="valid density samples/launch",
-                       achieved=by / (avg_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, runit="GB/s")
+            row.update(bound="l2", units=gathered, unit="valid density samples/launch", gather_bytes=by,
+                       achieved=by / (avg_ms * 1e-3) / 1e9, peak=L2_PEAK_GBS, runit="GB/s")
         elif name == "tir_vm_app_fwd" and units:
             by = units["n"] / k["launches"] * (B_APP_GATHER + units["out_bytes"])
-            row.update(bound="hbm", units=units["n"] / k["launches"], unit="appearance gathers/launch",
-                       achieved=by / (avg_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, runit="GB/s")
+            row.update(bound="l2", units=units["n"] / k["launches"], unit="appearance gathers/launch", gather_bytes=by,
+                       achieved=by / (avg_ms * 1e-3) / 1e9, peak=L2_PEAK_GBS, runit="GB/s",
+                       taps_per_s=units["n"] / k["launches"] * 18 / (avg_ms * 1e-3))
         elif name.startswith("tir_mlp_fwd") and units:
             fl = units["flops"] / k["launches"]
             # split-bf16 issues 3 bf16 MFMAs per fp32-equivalent product: price it against the dense bf16 peak / 3
@@ -309,43 +315,112 @@ def main():
             pmc_traffic = {}
 
     def roof(r):
-        return {"kernel": r["kernel"], "bound": r["bound"], "achieved": round(r["achieved"], 2),
-                "peak": r["peak"], "unit": r["runit"], "frac": round(r["frac"], 4),
-                "traffic": pmc_traffic.get(r["kernel"]), "avg_launch_ms": round(r["avg_ms"], 4),
-                "units_per_launch": round(r["units"], 1), "unit_of_work": r["unit"]}
+        """One roofline object.  bound 'mfma': useful decoder FLOPs vs the matrix-core ceiling of the operand scheme.
+        bound 'l2': the VM gathers read a field that is resident in L2 / Infinity Cache (70 MB; PMC HBM traffic is
+        ~2 % of the gather bytes), so the bounding resource is the cache hierarchy, not HBM: gather bytes (SURVEY 8d
+        model) / launch time vs the guide's aggregate L2 bandwidth.  The SURVEY 8d gather-bytes-over-HBM-peak figure is
+        kept as the labelled `sec8d_hbm_model` (a ratio that exceeds 1 for a cache-resident field -- NOT a roofline
+        fraction), next to the counter-measured HBM traffic."""
+        t = pmc_traffic.get(r["kernel"])
+        o = {"kernel": r["kernel"], "bound": r["bound"], "achieved": round(r["achieved"], 2),
+             "peak": r["peak"], "unit": r["runit"], "frac": round(r["frac"], 4),
+             "traffic": t, "avg_launch_ms": round(r["avg_ms"], 4),
+             "units_per_launch": round(r["units"], 1), "unit_of_work": r["unit"]}
+        if r["bound"] == "l2":
+            o["peak_source"] = "MI355X_MICROARCH.md L2 aggregate 34.5 TB/s"
+            o["sec8d_hbm_model"] = {"gather_bytes_per_launch": round(r["gather_bytes"], 1),
+                                    "gather_GBps": round(r["achieved"], 2), "hbm_peak_GBps": HBM_PEAK_GBS,
+                                    "gather_GBps_over_hbm_peak": round(r["achieved"] / HBM_PEAK_GBS, 3),
+                                    "note": "SURVEY 8d gather-bytes model; the field is cache resident, so this ratio is "
+                                            "not bounded by 1 and is not a roofline fraction"}
+            if t:
+                o["hbm_traffic"] = {"bytes_per_launch": t, "GBps": round(t / (r["avg_ms"] * 1e-3) / 1e9, 2),
+                                    "frac_of_hbm_peak": round(t / (r["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/pmc_traffic.json"}
+            if "taps_per_s" in r:
+                o["gather_bench"] = {"taps_per_s": round(r["taps_per_s"], 1), "ceiling_taps_per_s": GATHER_BENCH_TAPS,
+                                     "frac": round(r["taps_per_s"] / GATHER_BENCH_TAPS, 4),
+                                     "source": "tools/gather_bench.hip, coherent 192-B taps"}
+        else:
+            o["frac_of_dense_bf16_peak"] = round(r["achieved"] / BF16_MFMA_PEAK_TF, 4)
+            o["peak_source"] = ("dense bf16 MFMA 2.5 PF / 3 products of the split-bf16 scheme" if r["kernel"].endswith("bf16x3")
+                                else "dense f32 MFMA 157.3 TF")
+        return o
     dom = next((r for r in rows if "achieved" in r), None)
     roofline = roof(dom) if dom else None
     # the fused VM-sample (density gather + march) kernel the north star names, whatever its rank in the table
     vm = next((r for r in rows if r["kernel"] == "tir_march_secondary_fwd" and "achieved" in r), None)
     roofline_vm = roof(vm) if vm else None
-    if roofline_vm:
-        roofline_vm["note"] = ("algorithmic gather-bytes model (SURVEY 8d): the 70 MB field is resident in L2 / Infinity "
-                               "Cache, so achieved exceeds the HBM peak while `traffic` (PMC) stays small")
+    vapp = next((r for r in rows if r["kernel"] == "tir_vm_app_fwd" and "achieved" in r), None)
+    roofline_app = roof(vapp) if vapp else None
 
-    # ---- CPU baseline: the oracle (same algorithm, ATen CPU ops) on a bounded sample ------------------
-    cpu = None
+    # ---- the reference's boundary call, eagerly, host rays in (renderer.py:74-75 does the H2D per call) ----------
+    boundary = None
+    if world == 1:
+        ops.MLP_IMPL = a.decoder
+        r_host, l_host = rays.cpu().pin_memory(), lidx.cpu().pin_memory()
+        stream = torch.cuda.current_stream()
+        ts = []
+        with torch.no_grad():
+            for i in range(10 + a.boundary_calls):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record(stream)
+                Renderer_TensoIR_train(r_host, None, l_host, model, N_samples=a.samples, white_bg=True, is_train=False,
+                                       is_relight=True, sample_method="fixed_envirmap", chunk_size=160000, device=device,
+                                       args=args)
+                e1.record(stream)
+                e1.synchronize()
+                if i >= 10:
+                    ts.append(e0.elapsed_time(e1))
+        med = sorted(ts)[len(ts) // 2]
+        boundary = {"rays_per_s": round(B / (med * 1e-3), 1), "ms": round(med, 4), "min_ms": round(min(ts), 4),
+                    "max_ms": round(max(ts), 4),
+                    "protocol": f"eager Renderer_TensoIR_train(host rays) incl. H2D of rays, hipEvent pair per call, "
+                                f"10 warm-ups, median of {len(ts)} (SURVEY 8d)"}
+
+    # ---- CPU baseline: the oracle (same algorithm, ATen CPU ops) on a bounded sample; its outputs double as a
+    #      full-size parity check of the HIP maps (rays are independent; sharding is bit-exact) --------------
+    cpu = parity = None
     if world == 1 and not a.no_cpu_baseline:
         from oracle import tensoir_oracle as O          # checker / CPU baseline only
-        from tests.helpers import scene_from_checkpoint
-        ck = dict(ckpt)
-        vol = model.alphaMask.alpha_volume[0, 0].bool().cpu()
-        ck["alphaMask.shape"] = tuple(vol.shape)
-        ck["alphaMask.mask"] = np.packbits(vol.numpy().reshape(-1))
-        ck["alphaMask.aabb"] = model.alphaMask.aabb.cpu()
-        sc = scene_from_checkpoint(ck, a.env_h, a.env_w)
+        from tests.helpers import parity_metrics, scene_from_model
+        sc = scene_from_model(ckpt, model, a.env_h, a.env_w)
         stride = max(1, B // a.cpu_rays)
         r_cpu, l_cpu = rays.cpu()[::stride][: a.cpu_rays], lidx.cpu()[::stride][: a.cpu_rays]
-        times = []
+        times, ref = [], None
         with torch.no_grad():
-            for i in range(3):
+            for i in range(2 + a.cpu_calls):
                 t1 = time.perf_counter()
-                O.renderer_train(sc, r_cpu, l_cpu, n_samples=a.samples, second_n_sample=a.second_samples)
-                times.append(time.perf_counter() - t1)
-        med = sorted(times[1:])[len(times[1:]) // 2] if len(times) > 1 else times[0]
+                ref = O.renderer_train(sc, r_cpu, l_cpu, n_samples=a.samples, second_n_sample=a.second_samples)
+                if i >= 2:
+                    times.append(time.perf_counter() - t1)
+        med = sorted(times)[len(times) // 2]
         cpu = {"value": round(r_cpu.shape[0] / med, 2), "unit": "rays/s", "cores": torch.get_num_threads(),
-               "kind": "port",
+               "kind": "port", "reference_checkout": False,
+               "note": "the reference checkout (/root/reference) does not exist on the GPU box; the timed code is the oracle, "
+                       "a functional restatement on the same ATen CPU ops (F.grid_sample, cumprod, F.linear), pinned to "
+                       "the imported reference by tests/golden/",
                "sample": f"every {stride}th ray of the batch ({r_cpu.shape[0]} rays x {a.samples} samples, "
-                         f"{D} dirs x {a.second_samples}), 1 warm-up + 2 timed calls, median; host nproc={os.cpu_count()}"}
+                         f"{D} dirs x {a.second_samples}), 2 warm-ups + {len(times)} timed calls, median "
+                         f"(min {min(times):.2f} s, max {max(times):.2f} s); host nproc={os.cpu_count()}"}
+        # parity of the timed HIP path (graph replay outputs `ret`) against those oracle rows
+        maps = ["rgb_map", "depth_map", "normal_map", "albedo_map", "roughness_map", "fresnel_map", "acc_map",
+                "rgb_with_brdf_map", "normals_diff_map", "normals_orientation_loss_map"]
+        worst = {"max_abs": 0.0, "max_rel_floor1": 0.0, "max_rel_pixel": 0.0}
+        per_map = {}
+        for k in maps:
+            m = parity_metrics(ret[k].detach().cpu()[::stride][: a.cpu_rays], ref[k])
+            per_map[k] = {kk: float(f"{vv:.3e}") for kk, vv in m.items()}
+            for kk in worst:
+                worst[kk] = max(worst[kk], m[kk])
+        parity = {"ok": worst["max_rel_floor1"] < 1e-4, "tolerance": 1e-4,
+                  "metric": "max |hip - oracle| / max(|oracle|, 1) per map (maps live in [0,1], unit normals, depth ~4); "
+                            "max_rel = true per-pixel relative error ||d|| / ||ref|| over pixels with ||ref|| > 1e-2",
+                  "max_abs": float(f"{worst['max_abs']:.3e}"), "max_rel_floor1": float(f"{worst['max_rel_floor1']:.3e}"),
+                  "max_rel": float(f"{worst['max_rel_pixel']:.3e}"), "rays_compared": int(r_cpu.shape[0]),
+                  "maps": maps, "per_map": per_map,
+                  "excluded": "albedo/roughness smoothness losses (depend on the device-side jitter draw)"}
 
     value = n_gpus * B * a.steps / elapsed
     out = {
@@ -365,7 +440,10 @@ def main():
         "exact_fp32_decoders": exact,
         "roofline": roofline,
         "roofline_vm_sample": roofline_vm,
+        "roofline_app_gather": roofline_app,
+        "boundary_call": boundary,
         "cpu_baseline": cpu,
+        "parity": parity,
         "gpu_kernel_ms_per_step": round(gpu_ms, 4),
         "kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:8]],
     }
@@ -377,6 +455,8 @@ def main():
     print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if parity is not None and not parity["ok"]:
+        raise SystemExit(f"[bench] PARITY FAILURE vs the oracle at the headline size: {parity}")
 
 
 if __name__ == "__main__":

@@ -101,7 +101,8 @@ def scene_from_state_dict(sd, kwargs, alpha_volume=None, alpha_aabb=None,
         light_line=sd["light_line.weight"],
         mlp_rgb=mlp("renderModule"),
         mlp_brdf=mlp("renderModule_brdf"),
-        mlp_normal=mlp("renderModule_normal"),
+        mlp_normal=mlp("renderModule_normal") if "renderModule_normal.mlp.0.weight" in sd else None,
+        normals_kind=str(kwargs.get("normals_kind", "derived_plus_predicted")),
         lgtSGs=sd["lgtSGs"],
         light_rotation=[int(r) for r in kwargs["light_rotation"]],
         density_shift=float(kwargs["density_shift"]),
@@ -477,12 +478,21 @@ def forward_primary(sc, rays, light_idx, n_samples=-1, white_bg=True, is_relight
             vaj, vrj = brdf_j[..., :3], brdf_j[..., 3:4] * 0.9 + 0.09
             alb_cost[app_mask] = relative_smoothness(va, vaj)
             rgh_cost[app_mask] = relative_smoothness(vr, vrj)
-            # normals_kind == 'derived_plus_predicted' (:953-960), the only kind the configs use
-            _, _, derived = density_grad(sc, xa)
-            pred = render_normal(sc, xa, int_f)
-            normal[app_mask] = pred
-            ndiff[app_mask] = torch.sum((pred - derived) ** 2, dim=-1, keepdim=True)
-            norient[app_mask] = torch.sum(vd[app_mask] * pred, dim=-1, keepdim=True).clamp(min=0)
+            # the three normals kinds with kernels (:946-960); normals_diff / orientation are only filled in the
+            # derived_plus_predicted branch and stay zero otherwise
+            kind = getattr(sc, "normals_kind", "derived_plus_predicted")
+            if kind == "purely_predicted":
+                normal[app_mask] = render_normal(sc, xa, int_f)
+            elif kind == "purely_derived":
+                normal[app_mask] = density_grad(sc, xa)[2]
+            elif kind == "derived_plus_predicted":
+                _, _, derived = density_grad(sc, xa)
+                pred = render_normal(sc, xa, int_f)
+                normal[app_mask] = pred
+                ndiff[app_mask] = torch.sum((pred - derived) ** 2, dim=-1, keepdim=True)
+                norient[app_mask] = torch.sum(vd[app_mask] * pred, dim=-1, keepdim=True).clamp(min=0)
+            else:
+                raise ValueError(f"normals_kind {kind!r}")
 
     acc = torch.sum(weight, -1)
     depth = torch.sum(weight * z, -1)
@@ -822,6 +832,8 @@ def scene_parameters(sc):
     ps["light_line.weight"] = sc.light_line
     for prefix, m in (("renderModule", sc.mlp_rgb), ("renderModule_brdf", sc.mlp_brdf),
                       ("renderModule_normal", sc.mlp_normal)):
+        if m is None:                     # normals_kind == 'purely_derived' has no normal decoder (:417-419)
+            continue
         for j, k in ((0, "0"), (1, "2"), (2, "4")):
             ps[f"{prefix}.mlp.{k}.weight"] = m[f"w{j}"]
             ps[f"{prefix}.mlp.{k}.bias"] = m[f"b{j}"]
@@ -856,7 +868,8 @@ def train_step_grads(sc, rays, light_idx, rgb_gt, is_relight=True, n_samples=-1,
         setattr(work, name, [mk(t) for t in getattr(sc, name)])
     work.basis_mat, work.light_line, work.lgtSGs = mk(sc.basis_mat), mk(sc.light_line), mk(sc.lgtSGs)
     for name in ("mlp_rgb", "mlp_brdf", "mlp_normal"):
-        setattr(work, name, {k: mk(v) for k, v in getattr(sc, name).items()})
+        if getattr(sc, name) is not None:
+            setattr(work, name, {k: mk(v) for k, v in getattr(sc, name).items()})
     leaf = scene_parameters(work)
     with torch.enable_grad():
         ret = renderer_train(work, rays, light_idx, n_samples, white_bg, is_relight, second_n_sample,

@@ -738,8 +738,8 @@ class TensorVMSplit(nn.Module):
         bg = bool(white_bg or (is_train and torch.rand((1,)) < 0.5))
         maps = ops.composite_primary(rays, offsets, rec_w, rgb, brdf, brdf_j, pred, derived, acc, depth,
                                      bg, is_relight, self.fixed_fresnel)
-        if self.normals_kind == "purely_derived" and is_relight:
-            maps[:, 16] = 0.0        # orientation loss only exists for predicted normals (:953-960)
+        if self.normals_kind != "derived_plus_predicted" and is_relight:
+            maps[:, 16] = 0.0        # the orientation loss is only filled in the derived_plus_predicted branch (:953-960)
 
         def finish():
             """True when the pass is valid; False when the record capacity overflowed (the caller re-runs)."""

@@ -2,10 +2,13 @@
 
     python -m tensoir_amd.run /path/to/TensoIR/train_tensoIR.py --config configs/single_light/armadillo.txt --render_only 1 --ckpt ...
 
-It puts the TensoIR checkout on sys.path, imports the reference modules, rebinds the hot-path symbols
- to the tensoir_amd implementations and then runs the script with runpy.  The
-script's own imports (`from renderer import *`, `from models.tensoRF_rotated_lights import raw2alpha,
-TensorVMSplit, AlphaGridMask`, train_tensoIR.py:6-14) then resolve to ours.
+It puts the TensoIR checkout on sys.path, installs stand-ins for the third-party modules this image lacks
+(tensoir_amd/shims.py: cv2, loguru, kornia, torchvision, imageio, plyfile, skimage, lpips, configargparse,
+tensorboard -- image I/O / logging / CLI, none on the hot path), imports the reference modules, rebinds the
+hot-path symbols to the tensoir_amd implementations and then runs the script with runpy.
+The script's own imports (`from renderer import *`, `from models.tensoRF_rotated_lights import raw2alpha,
+TensorVMSplit, AlphaGridMask`, train_tensoIR.py:6-14) then resolve to ours.  With `datadir = synthetic:views=6,res=48`
+in the config the dataset is generated analytically (tensoir_amd/synth_dataset.py; no dataset exists offline).
 """
 from __future__ import annotations
 
@@ -30,7 +33,8 @@ def install(reference_root: str):
     """Import the reference modules from `reference_root` and rebind the hot path.  Returns the
     {module: [symbols]} actually patched."""
     import tensoir_amd
-    from tensoir_amd import field_model, general_multi_lights, relight, renderer
+    from tensoir_amd import field_model, general_multi_lights, relight, renderer, shims, synth_dataset
+    shims.install()
     ours = {}
     for mod in (field_model, relight, renderer):
         ours.update({k: getattr(mod, k) for k in dir(mod) if not k.startswith("_")})
@@ -47,6 +51,7 @@ def install(reference_root: str):
             else:
                 setattr(m, s, ours[s])
         done[name] = [s.split(":")[0] for s in symbols]
+    synth_dataset.wrap_dataset_dict(importlib.import_module("dataLoader").dataset_dict)
     return done
 
 

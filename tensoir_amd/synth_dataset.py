@@ -1,0 +1,126 @@
+"""A dataset with the interface ``train_tensoIR.py`` expects from ``dataLoader.dataset_dict[...]`` entries
+(dataLoader/tensoIR_rotation_setting.py:16-140), generated analytically: there is no dataset offline.
+
+Scene: a Lambert sphere of radius 0.8 with a banded albedo under one directional light per light rotation
+(rotated about z, as models/tensorBase_rotated_lights.py:478-488) plus ambient, composited on white.  Cameras sit on
+a ring of radius 4 looking at the origin; ray directions are L2-normalised (tensoIR_rotation_setting.py:105-106).
+
+Selected by ``datadir = synthetic:views=6,res=48`` in the config (tensoir_amd.run wraps every dataset_dict entry so
+that such a datadir builds this class and anything else goes to the reference's own loader).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+
+def parse_spec(root_dir):
+    spec = {"views": 6, "res": 48, "radius": 0.8, "fov": 0.6911, "cam": 4.0}
+    text = str(root_dir)
+    if ":" in text:
+        for item in text.split(":", 1)[1].split(","):
+            if "=" in item:
+                k, v = item.split("=", 1)
+                spec[k.strip()] = float(v) if "." in v else int(v)
+    return spec
+
+
+def is_synthetic(root_dir):
+    return str(root_dir).startswith("synthetic")
+
+
+class SyntheticDataset(torch.utils.data.Dataset):
+    def __init__(self, root_dir, hdr_dir=None, split="train", random_test=False, N_vis=-1, downsample=1.0, sub=0,
+                 light_rotation=("000",), light_name="sunset", light_name_list=None, is_stack=False, **unused):
+        spec = parse_spec(root_dir)
+        self.split = split
+        self.N_vis = N_vis
+        self.downsample = downsample
+        self.white_bg = True
+        self.near_far = [2.0, 6.0]
+        self.scene_bbox = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]]) * downsample
+        self.light_name = light_name
+        names = light_name_list if light_name_list else list(light_rotation or ["000"])
+        self.light_rotation = [str(r) for r in names]
+        self.light_num = len(self.light_rotation)
+        self.lights_probes = None
+        res = max(4, int(spec["res"] / downsample))
+        self.img_wh = (res, res)
+        n_views = int(spec["views"]) if split == "train" else max(1, int(spec["views"]) // 3)
+        if sub > 0:
+            n_views = min(n_views, sub)
+        self.n_views = n_views
+        self.radius, self.cam, self.fov = float(spec["radius"]), float(spec["cam"]), float(spec["fov"])
+        frames = [self._frame(v, l) for v in range(n_views) for l in range(self.light_num)]
+        self.frames = frames
+        self.all_rays = torch.cat([f["rays"] for f in frames], 0)                 # [N*H*W, 6]
+        self.all_rgbs = torch.cat([f["rgbs"] for f in frames], 0)                 # [N*H*W, 3]
+        self.all_masks = []                                                       # as the reference leaves it (:133)
+        self.all_light_idx = torch.cat([f["light_idx"] for f in frames], 0)       # [N*H*W, 1] int8 (:130)
+
+    # ---- geometry --------------------------------------------------------------------------------
+    def _camera(self, v):
+        phase = 0.0 if self.split == "train" else 0.5
+        az = 2 * math.pi * (v + phase) / max(self.n_views, 1)
+        el = 0.35 * math.sin(1.7 * v + 0.3)
+        eye = torch.tensor([math.cos(az) * math.cos(el), math.sin(az) * math.cos(el), math.sin(el)]) * self.cam
+        fwd = -eye / eye.norm()
+        right = torch.linalg.cross(fwd, torch.tensor([0.0, 0.0, 1.0]))
+        right = right / right.norm()
+        up = torch.linalg.cross(right, fwd)
+        return eye, fwd, right, up
+
+    def _frame(self, v, l):
+        W, H = self.img_wh
+        eye, fwd, right, up = self._camera(v)
+        focal = 0.5 * W / math.tan(0.5 * self.fov)
+        j, i = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+        d = ((i - W / 2 + 0.5) / focal)[..., None] * right - ((j - H / 2 + 0.5) / focal)[..., None] * up + fwd
+        d = (d / d.norm(dim=-1, keepdim=True)).reshape(-1, 3)
+        o = eye.expand_as(d)
+        # ray / sphere intersection
+        b = (o * d).sum(-1)
+        disc = b * b - ((o * o).sum(-1) - self.radius ** 2)
+        hit = disc > 0
+        t = -b - torch.sqrt(disc.clamp(min=0))
+        p = o + t[:, None] * d
+        n = p / self.radius
+        ang = math.radians(float(int(self.light_rotation[l]) if self.light_rotation[l].isdigit() else 40 * l))
+        light = torch.tensor([math.cos(ang) * 0.6, math.sin(ang) * 0.6, 0.8])
+        light = light / light.norm()
+        albedo = torch.stack([0.55 + 0.35 * torch.sin(6 * p[:, 2]), 0.5 + 0.3 * torch.sin(5 * p[:, 0] + 1.0),
+                              0.45 + 0.25 * torch.cos(4 * p[:, 1])], -1)
+        shade = (n * light).sum(-1).clamp(min=0)[:, None] * 0.8 + 0.2
+        rgb = torch.where(hit[:, None], (albedo * shade).clamp(0, 1), torch.ones_like(albedo))
+        normals = torch.where(hit[:, None], n, torch.tensor([0.0, 0.0, 1.0]).expand_as(n))
+        return {"rays": torch.cat([o, d], -1).contiguous(), "rgbs": rgb.contiguous(),
+                "light_idx": torch.full((d.shape[0], 1), l, dtype=torch.int8),
+                "rgbs_mask": hit[:, None], "normals": normals, "albedo": torch.where(hit[:, None], albedo, torch.ones_like(albedo))}
+
+    # ---- Dataset protocol (test-split consumers index whole frames) ----------------------------------
+    def __len__(self):
+        return self.n_views
+
+    def __getitem__(self, idx):
+        fs = self.frames[idx * self.light_num:(idx + 1) * self.light_num]
+        return {"img_wh": self.img_wh, "light_idx": torch.stack([f["light_idx"] for f in fs]),
+                "rgbs": torch.stack([f["rgbs"] for f in fs]), "rgbs_mask": fs[0]["rgbs_mask"],
+                "rays": fs[0]["rays"], "normals": fs[0]["normals"], "albedo": fs[0]["albedo"]}
+
+
+def wrap_dataset_dict(dataset_dict):
+    """Every entry keeps its reference class for real data directories and builds the analytic dataset when
+    ``datadir`` starts with ``synthetic``."""
+    for name, cls in list(dataset_dict.items()):
+        if getattr(cls, "__tensoir_wrapped__", False):
+            continue
+
+        def factory(root_dir, *a, _cls=cls, **k):
+            if is_synthetic(root_dir):
+                return SyntheticDataset(root_dir, *a, **k)
+            return _cls(root_dir, *a, **k)
+        factory.__tensoir_wrapped__ = True
+        factory.__name__ = getattr(cls, "__name__", name)
+        dataset_dict[name] = factory
+    return dataset_dict

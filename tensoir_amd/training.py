@@ -190,8 +190,8 @@ class PrimaryRenderFn(torch.autograd.Function):
         st.rgb, st.brdf, st.brdf_j, st.pred, st.derived = rgb, brdf, brdf_j, pred, derived
         maps = ops.composite_primary(rays, offsets, rec_w, rgb, brdf, brdf_j, pred, derived, acc, depth,
                                      white_bg, is_relight, model.fixed_fresnel)
-        if model.normals_kind == "purely_derived" and is_relight:
-            maps[:, 16] = 0.0
+        if model.normals_kind != "derived_plus_predicted" and is_relight:
+            maps[:, 16] = 0.0            # only the derived_plus_predicted branch fills it (tensorBase_rotated_lights.py:953-960)
 
         def finish():
             """Read the record count; trim the saved rows to it.  False = the capacity overflowed (re-run the pass)."""
@@ -233,7 +233,7 @@ class PrimaryRenderFn(torch.autograd.Function):
             raise TensoirHipError("backward through a training forward whose record capacity overflowed")
         f = model.packed_field()
         g_maps = g_maps.contiguous().to(torch.float32)
-        if model.normals_kind == "purely_derived" and st.is_relight:
+        if model.normals_kind != "derived_plus_predicted" and st.is_relight:
             g_maps = g_maps.clone()
             g_maps[:, 16] = 0.0
         bufs = _grad_buffers(model, f)

@@ -57,3 +57,32 @@ def rel_err(a, b, floor=1.0):
     if a.numel() == 0:
         return 0.0
     return float(((a - b).abs() / b.abs().clamp(min=floor)).max())
+
+
+def scene_from_model(ckpt, model, envmap_h, envmap_w):
+    """Oracle Scene of a synthetic checkpoint whose occupancy mask was built on the device
+    (model.updateAlphaMask): same parameters, same 0/1 volume, same mask aabb."""
+    ck = dict(ckpt)
+    if model.alphaMask is not None:
+        vol = model.alphaMask.alpha_volume[0, 0].bool().cpu()
+        ck["alphaMask.shape"] = tuple(vol.shape)
+        ck["alphaMask.mask"] = np.packbits(vol.numpy().reshape(-1))
+        ck["alphaMask.aabb"] = model.alphaMask.aabb.cpu()
+    return scene_from_checkpoint(ck, envmap_h, envmap_w)
+
+
+def parity_metrics(a, b):
+    """The three error figures reported for a rendered map (hip a vs reference b):
+    max_abs, max |d| / max(|ref|, 1) (the test metric; maps live in [0,1] / unit normals / depth ~4) and the
+    true per-pixel relative error ||d|| / ||ref|| over pixels with ||ref|| > 1e-2 (vector maps: L2 over channels)."""
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    if a.numel() == 0:
+        return {"max_abs": 0.0, "max_rel_floor1": 0.0, "max_rel_pixel": 0.0}
+    d = (a - b).abs()
+    a2, b2, d2 = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1), (a - b).reshape(a.shape[0], -1)
+    nb = b2.norm(dim=-1)
+    sel = nb > 1e-2
+    relpix = float((d2.norm(dim=-1)[sel] / nb[sel]).max()) if bool(sel.any()) else 0.0
+    return {"max_abs": float(d.max()), "max_rel_floor1": float((d / b.abs().clamp(min=1.0)).max()),
+            "max_rel_pixel": relpix}

@@ -244,8 +244,42 @@ def test_shading_backward(env):
 # ------------------------------------------------------------------ whole training step
 @pytest.mark.parametrize("relight,t_stop", [(False, 0.0), (True, 0.0), (True, 1e-6)])
 def test_training_step_vs_oracle(env, relight, t_stop):
+    _check_training_step(env, env.model, env.sc, relight, t_stop, 18 if not relight else 30)
+
+
+@pytest.mark.parametrize("kind", ["purely_predicted", "purely_derived"])
+def test_normals_kinds_vs_reference(env, kind):
+    """normals_kind 'purely_predicted' (the reference's class default) and 'purely_derived': forward maps against the
+    imported reference (tests/golden/normals_kinds.npz) -- normals_diff and normals_orientation_loss are ZERO in both
+    (only the derived_plus_predicted branch fills them, tensorBase_rotated_lights.py:946-960) -- and one training step
+    against the oracle (pinned to the reference's gradients for these kinds by tests/test_oracle_kinds.py)."""
+    import tensoir_amd
+    from tests.helpers import golden_checkpoint, scene_from_checkpoint
+    kg = np.load(os.path.join(ROOT, "tests", "golden", "normals_kinds.npz"))
+    ck = golden_checkpoint(env.g)
+    ck["kwargs"]["normals_kind"] = kind
+    if kind == "purely_derived":
+        ck["state_dict"] = {k: v for k, v in ck["state_dict"].items() if not k.startswith("renderModule_normal")}
+    eh, ew = [int(x) for x in env.g["scene/envmap_hw"]]
+    m = tensoir_amd.model_from_checkpoint(ck, "cuda", envmap_h=eh, envmap_w=ew)
+    m.march_t_stop = 0.0
+    sc = scene_from_checkpoint(ck, eh, ew)
+    assert sc.normals_kind == kind
+    rays, lidx = T(env.g, "rays/rays").cuda(), T(env.g, "rays/light_idx").cuda()
+    names = ["rgb_map", "depth_map", "normal_map", "albedo_map", "roughness_map", "fresnel_map", "acc_map",
+             "normals_diff_map", "normals_orientation_loss_map"]
+    with torch.no_grad():
+        out = m(rays, lidx)
+    for n, a in zip(names, out):
+        ref = torch.from_numpy(kg[f"{kind}/fwd/{n}"])
+        assert float((a.cpu() - ref).abs().max()) < 1e-4, (kind, n)
+    assert float(out[7].abs().max()) == 0.0 and float(out[8].abs().max()) == 0.0
+    _check_training_step(env, m, sc, True, 0.0, 25)
+
+
+def _check_training_step(env, m, sc, relight, t_stop, min_checked):
     from tensoir_amd import Renderer_TensoIR_train
-    O, m, g, tg = env.O, env.model, env.g, env.tg
+    O, g, tg = env.O, env.g, env.tg
     rays, lidx = T(g, "rays/rays"), T(g, "rays/light_idx")
     S = int(tg["train/n_samples"][0])
     gt = T(tg, "train/rgb_gt")
@@ -253,7 +287,7 @@ def test_training_step_vs_oracle(env, relight, t_stop):
     gen = torch.Generator().manual_seed(21)
     jitter = torch.rand(B, 1, generator=gen)
     noise = torch.randn(B, S, 3, generator=gen)
-    loss_ref, grads_ref, ret_ref = O.train_step_grads(env.sc, rays, lidx, gt, is_relight=relight, n_samples=S,
+    loss_ref, grads_ref, ret_ref = O.train_step_grads(sc, rays, lidx, gt, is_relight=relight, n_samples=S,
                                                       ray_jitter=jitter, brdf_jitter=noise, second_n_sample=24)
     m.zero_grad(set_to_none=True)
     m.march_t_stop = t_stop          # 1e-6 = the product default: rays stop marching once T < 1e-6 (gradients there are < 1e-6)
@@ -284,7 +318,8 @@ def test_training_step_vs_oracle(env, relight, t_stop):
         torch.set_rng_state(state)
     loss = O.training_loss(ret, gt.cuda(), relight)
     assert abs(float(loss) - float(loss_ref)) < 1e-5
-    for k in ("rgb_map", "acc_map", "depth_map") + (("rgb_with_brdf_map", "normal_map", "albedo_map") if relight else ()):
+    for k in ("rgb_map", "acc_map", "depth_map") + (("rgb_with_brdf_map", "normal_map", "albedo_map", "normals_diff_map",
+                                                     "normals_orientation_loss_map") if relight else ()):
         assert float((ret[k].detach().cpu() - ret_ref[k]).abs().max()) < 1e-4, k
     loss.backward()
     worst = {}
@@ -297,7 +332,7 @@ def test_training_step_vs_oracle(env, relight, t_stop):
         worst[name] = gerr(p.grad, ref)
     bad = {k: round(v, 5) for k, v in worst.items() if v > GTOL}
     assert not bad, (bad, {k: round(v, 6) for k, v in worst.items() if k.startswith("density") or k.startswith("app")})
-    assert len(worst) >= (18 if not relight else 30)
+    assert len(worst) >= min_checked
     m.zero_grad(set_to_none=True)
     m.march_t_stop = 0.0
 

@@ -1,0 +1,72 @@
+"""Pins the oracle's normals_kind branches ('purely_predicted' = the reference's class default, 'purely_derived')
+against tests/golden/normals_kinds.npz (imported reference, oracle/make_golden_kinds.py): forward maps and the
+parameter gradients of one training step.  In both kinds normals_diff / normals_orientation_loss are zero
+(models/tensorBase_rotated_lights.py:946-960).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tensoir_oracle as O
+from tests.helpers import T, golden_checkpoint, scene_from_checkpoint
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEED = 20211202
+NAMES = ["rgb_map", "depth_map", "normal_map", "albedo_map", "roughness_map", "fresnel_map",
+         "acc_map", "normals_diff_map", "normals_orientation_loss_map", "acc_mask",
+         "albedo_smoothness_loss", "roughness_smoothness_loss"]
+
+
+@pytest.fixture(scope="module")
+def kg():
+    return np.load(os.path.join(ROOT, "tests", "golden", "normals_kinds.npz"))
+
+
+def kind_scene(golden, kind):
+    ck = golden_checkpoint(golden)
+    ck["kwargs"]["normals_kind"] = kind
+    if kind == "purely_derived":
+        ck["state_dict"] = {k: v for k, v in ck["state_dict"].items() if not k.startswith("renderModule_normal")}
+    eh, ew = [int(x) for x in golden["scene/envmap_hw"]]
+    return scene_from_checkpoint(ck, eh, ew)
+
+
+@pytest.mark.parametrize("kind", ["purely_predicted", "purely_derived"])
+def test_forward_kinds_vs_reference(golden, kg, kind):
+    sc = kind_scene(golden, kind)
+    rays, lidx = T(golden, "rays/rays"), T(golden, "rays/light_idx")
+    torch.manual_seed(SEED + 3)
+    with torch.set_grad_enabled(kind == "purely_derived"):
+        out = O.forward_primary(sc, rays, lidx.int())
+    for n, v in zip(NAMES, out):
+        ref = kg[f"{kind}/fwd/{n}"]
+        if n == "acc_mask":
+            assert np.array_equal(v.numpy(), ref)
+        else:
+            assert float((v.detach() - torch.from_numpy(ref)).abs().max()) < 3e-5, n
+    assert float(np.abs(kg[f"{kind}/fwd/normals_orientation_loss_map"]).max()) == 0.0
+    assert float(np.abs(kg[f"{kind}/fwd/normals_diff_map"]).max()) == 0.0
+
+
+@pytest.mark.parametrize("kind", ["purely_predicted", "purely_derived"])
+def test_train_grads_kinds_vs_reference(golden, kg, kind):
+    sc = kind_scene(golden, kind)
+    rays, lidx = T(golden, "rays/rays"), T(golden, "rays/light_idx")
+    S = int(kg["n_samples"][0])
+    torch.manual_seed(SEED + 12)
+    jit = torch.rand(rays.shape[0], 1)
+    assert np.array_equal(jit.numpy(), kg[f"{kind}/train/ray_jitter"])
+    loss, grads, ret = O.train_step_grads(sc, rays, lidx, T(kg, "rgb_gt"), is_relight=True, n_samples=S,
+                                          ray_jitter=jit, second_n_sample=24, second_near=0.05, second_far=1.5)
+    assert abs(float(loss) - float(kg[f"{kind}/train/loss"][0])) < 2e-6
+    checked = 0
+    for name, gr in grads.items():
+        ref = torch.from_numpy(kg[f"{kind}/train/grad/{name}"]).double()
+        if float(ref.abs().max()) == 0:
+            assert float(gr.abs().max()) == 0, name
+            continue
+        err = float((gr.double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-3, (name, err)
+        checked += 1
+    assert checked >= 25
