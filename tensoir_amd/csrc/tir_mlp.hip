@@ -13,6 +13,7 @@
 #include "tir_common.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -40,11 +41,15 @@ constexpr int OFF_RB1 = OFF_RW1 + HID * HID;
 constexpr int OFF_RW2 = OFF_RB1 + HID;          // [4][128]
 constexpr int OFF_RB2 = OFF_RW2 + 4 * HID;
 constexpr int FP32_TOTAL = OFF_RB2 + 4;
-// split-bf16 image (one contiguous LDS image): fp32 header [b0p 128 | b1p 128 | W2p 512 | b2 4 | pad 4]
-// then bf16 operand tiles  W0hi | W0lo | W1hi | W1lo, each [kb][h][mt][i][8]  (8 bf16 = one ds_read_b128)
+// split-bf16 image (one contiguous LDS image): fp32 header [b0p 128 | b1p 128 | W2a 544 | b2 4 | pad 4]
+// then bf16 operand tiles  W0hi | W0lo | W1hi | W1lo, each [kb][h][mt][i][8]  (8 bf16 = one ds_read_b128).
+// W2a = layer-3 weights as the A operand of v_mfma_f32_4x4x1_16b_f32: [h][o][q] with a row stride of 68 floats (the 4
+// rows a 16-lane LDS group reads land on disjoint banks).  Layer 1's bias rides in the padded k slot HALF of half 0
+// (input 1.0), so the layer-1 accumulators start from the inline constant 0.
 constexpr int KB0 = (HALF + 7) / 8;             // 10 k-blocks of 16 for layer 1 (75 -> 80 per half)
 constexpr int KB1 = 64 / 8;                     // 8 k-blocks for layer 2
-constexpr int BH_B0 = 0, BH_B1 = 128, BH_W2 = 256, BH_B2 = 768, BH_FLOATS = 776;
+constexpr int W2A_STRIDE = 68;
+constexpr int BH_B0 = 0, BH_B1 = 128, BH_W2 = 256, BH_B2 = BH_W2 + 2 * 4 * W2A_STRIDE, BH_FLOATS = BH_B2 + 8;
 constexpr int BW0_ELEMS = KB0 * 2 * 4 * 32 * 8; // 20480 bf16
 constexpr int BW1_ELEMS = KB1 * 2 * 4 * 32 * 8; // 16384 bf16
 constexpr int BF_BYTES = BH_FLOATS * 4 + (2 * BW0_ELEMS + 2 * BW1_ELEMS) * 2;   // 150,560 B
@@ -109,7 +114,10 @@ __global__ void k_pack_mlp(const float* __restrict__ w0, const float* __restrict
         if (j < BH_FLOATS) {
             if (j < BH_B1) v = b0[unit_of(j % 64, j / 64)];
             else if (j < BH_W2) { int q = j - BH_B1; v = b1[unit_of(q % 64, q / 64)]; }
-            else if (j < BH_B2) { int q = j - BH_W2, h = q / 256, u = (q % 256) / 4, o = q % 4; v = (o < out_dim) ? w2[o * HID + unit_of(u, h)] : 0.0f; }
+            else if (j < BH_B2) {
+                int q = j - BH_W2, h = q / (4 * W2A_STRIDE), o = (q / W2A_STRIDE) % 4, u = q % W2A_STRIDE;
+                v = (o < out_dim && u < 64) ? 0.5f * w2[o * HID + unit_of(u, h)] : 0.0f;     // x 1/2: B operand is 2 relu(h)
+            }
             else { int o = j - BH_B2; v = (o < out_dim) ? b2[o] : 0.0f; }
         } else {                                // two bf16 per float slot
             unsigned short hw[2];
@@ -123,7 +131,8 @@ __global__ void k_pack_mlp(const float* __restrict__ w0, const float* __restrict
                 int e = idx % 8, ii = (idx / 8) % 32, mt = (idx / 256) % 4, h = (idx / 1024) % 2, kb = idx / 2048;
                 int kk = kb * 8 + e;
                 float wv;
-                if (sec < 2) wv = (kk < HALF) ? w0[(mt * 32 + ii) * IN + kperm(kk, h)] : 0.0f;
+                if (sec < 2) wv = (kk < HALF) ? w0[(mt * 32 + ii) * IN + kperm(kk, h)]
+                                              : ((kk == HALF && h == 0) ? b0[mt * 32 + ii] : 0.0f);   // bias slot (input = 1)
                 else wv = w1[(mt * 32 + ii) * HID + unit_of(kk, h)];
                 __bf16 hi = (__bf16)wv;
                 __bf16 r = (sec & 1) ? (__bf16)(wv - (float)hi) : hi;
@@ -322,15 +331,18 @@ __device__ __forceinline__ void fast_sincos(float x, float& s, float& c) {
     c = __builtin_amdgcn_cosf(t);
 }
 
-// This lane-half's positional encodings of value v: half 0 -> {sin v, sin 2v}, half 1 -> {cos v, cos 2v}
-// (double-angle identities: sin 2v = 2 s c, cos 2v = 1 - 2 s^2).
-// (Sharing the sincos between the two lane halves of a sample with v_permlane32_swap_b32 was tried: the builtin
-// returns a wrong second result with this compiler and the inline-asm form has unmodelled hazards.)
-__device__ __forceinline__ void pe_pair(float v, int h, float& p1, float& p2) {
-    float s, c;
-    fast_sincos(v, s, c);
-    p1 = h ? c : s;
-    p2 = h ? fmaf(-2.0f * s, s, 1.0f) : 2.0f * s * c;
+// This lane-half's positional encodings of value v: half 0 -> {sin v, sin 2v}, half 1 -> {cos v, cos 2v}.
+// cos x = sin(x + pi/2): with the angle in revolutions, both halves evaluate v_sin_f32 at t + q and 2t + q, q = 0 for
+// half 0 and 1/4 for half 1 -- two transcendental issues per value and no select, instead of sin + cos + double-angle
+// products + two selects (each half used to compute both functions and keep one).  t is the exact fraction of
+// v / 2pi (see fast_sincos), |t| <= 1/2, so 2t + q is exact up to one rounding at magnitude <= 1.25 (6e-8 rev).
+__device__ __forceinline__ void pe_pair(float v, float q, float& p1, float& p2) {
+    const float c_hi = 0.15915493667125702f, c_lo = 6.4206382432985265e-09f;      // c_hi + c_lo = 1 / (2 pi)
+    const float k = rintf(v * c_hi);
+    float t = fmaf(v, c_hi, -k);
+    t = fmaf(v, c_lo, t);
+    p1 = __builtin_amdgcn_sinf(t + q);
+    p2 = __builtin_amdgcn_sinf(fmaf(t, 2.0f, q));
 }
 
 struct AuxPE { float s[3], c[3], s2[3], c2[3]; };   // sin/cos of aux and of 2*aux
@@ -340,6 +352,7 @@ template <int T>
 __device__ __forceinline__ float tail_input(const float (&ft)[F + 1], const float (&ax)[3], const AuxPE& ap, int h) {
     constexpr int q = T - NPF;
     float a = 0.0f, b = 0.0f;
+    if constexpr (T == HALF) a = 1.0f;          // the constant input that carries layer 1's bias (half 0 only)
     if constexpr (q < R0) a = ft[q];
     if constexpr (q < F - R0) b = ft[R0 + q];
     else if constexpr (q < F - R0 + 3) b = ax[q - (F - R0)];
@@ -354,9 +367,10 @@ __device__ __forceinline__ float tail_input(const float (&ft)[F + 1], const floa
 }
 
 template <int KB, int E>
-__device__ __forceinline__ void build_pair(const float (&ft)[F + 1], const float (&ax)[3], const AuxPE& ap, int h, float (&v)[8]) {
+__device__ __forceinline__ void build_pair(const float (&ft)[F + 1], const float (&ax)[3], const AuxPE& ap, int h, float hq,
+                                           float (&v)[8]) {
     constexpr int t = KB * 8 + E;
-    if constexpr (t + 1 < NPF) pe_pair(ft[t >> 1], h, v[E], v[E + 1]);
+    if constexpr (t + 1 < NPF) pe_pair(ft[t >> 1], hq, v[E], v[E + 1]);
     else {
         v[E] = tail_input<t>(ft, ax, ap, h);
         v[E + 1] = tail_input<t + 1>(ft, ax, ap, h);
@@ -370,6 +384,19 @@ __device__ __forceinline__ float relu(float x) {
     float r;
     asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
     return r;
+}
+
+// LDS operand tiles are read through four per-lane byte bases (W0hi / W0lo / W1hi / W1lo section start + this lane's
+// offset) that the compiler cannot see through, plus compile-time offsets < 64 KB that fit the 16-bit ds offset field.
+// Left to itself (150 KB image, absolute addresses above the 64 KB offset range) the compiler hoists one address VGPR
+// PER READ out of the tile loop -- ~80 registers of a 256-register budget.
+typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
+__device__ __forceinline__ bf16x8 lds_tile(unsigned base, int byte_off) {
+    return *reinterpret_cast<lds_bf16x8*>(base + (unsigned)byte_off);
+}
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+    asm volatile("" : "+v"(v));
+    return v;
 }
 
 // ---- per k-block: [issue the A-tile LDS reads] [build that block's 8 inputs on the VALU] [12 MFMAs].
@@ -389,37 +416,35 @@ __device__ __forceinline__ void mfma12(const bf16x8 (&ah)[4], const bf16x8 (&al)
 }
 
 template <int NPROD, int KB>
-__device__ __forceinline__ void layer1_interleaved(const bf16x8* __restrict__ whi, const bf16x8* __restrict__ wlo, int h, int sl,
-                                                   const float (&ft)[F + 1], const float (&ax)[3], const AuxPE& ap,
+__device__ __forceinline__ void layer1_interleaved(unsigned whi, unsigned wlo, int h,
+                                                   const float (&ft)[F + 1], const float (&ax)[3], const AuxPE& ap, float hq,
                                                    f32x16 (&acc)[4]) {
     bf16x8 ah[4], al[4];
-    const int wi = (KB * 2 + h) * 128 + sl;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        ah[mt] = whi[wi + mt * 32];
-        if (NPROD == 3) al[mt] = wlo[wi + mt * 32];
+        ah[mt] = lds_tile(whi, KB * 4096 + mt * 512);
+        if (NPROD == 3) al[mt] = lds_tile(wlo, KB * 4096 + mt * 512);
     }
     float v[8];
-    build_pair<KB, 0>(ft, ax, ap, h, v);
-    build_pair<KB, 2>(ft, ax, ap, h, v);
-    build_pair<KB, 4>(ft, ax, ap, h, v);
-    build_pair<KB, 6>(ft, ax, ap, h, v);
+    build_pair<KB, 0>(ft, ax, ap, h, hq, v);
+    build_pair<KB, 2>(ft, ax, ap, h, hq, v);
+    build_pair<KB, 4>(ft, ax, ap, h, hq, v);
+    build_pair<KB, 6>(ft, ax, ap, h, hq, v);
     bf16x8 xh, xl;
     split8(v, xh, xl);
     mfma12<NPROD>(ah, al, xh, xl, acc);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (KB + 1 < KB0) layer1_interleaved<NPROD, KB + 1>(whi, wlo, h, sl, ft, ax, ap, acc);
+    if constexpr (KB + 1 < KB0) layer1_interleaved<NPROD, KB + 1>(whi, wlo, h, ft, ax, ap, hq, acc);
 }
 
 template <int NPROD, int KB>
-__device__ __forceinline__ void layer2_interleaved(const bf16x8* __restrict__ whi, const bf16x8* __restrict__ wlo, int h, int sl,
+__device__ __forceinline__ void layer2_interleaved(unsigned whi, unsigned wlo,
                                                    const f32x16 (&hid)[4], f32x16 (&acc)[4]) {
     bf16x8 ah[4], al[4];
-    const int wi = (KB * 2 + h) * 128 + sl;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        ah[mt] = whi[wi + mt * 32];
-        if (NPROD == 3) al[mt] = wlo[wi + mt * 32];
+        ah[mt] = lds_tile(whi, KB * 4096 + mt * 512);
+        if (NPROD == 3) al[mt] = lds_tile(wlo, KB * 4096 + mt * 512);
     }
     float v[8];
 #pragma unroll
@@ -428,7 +453,7 @@ __device__ __forceinline__ void layer2_interleaved(const bf16x8* __restrict__ wh
     split8(v, xh, xl);
     mfma12<NPROD>(ah, al, xh, xl, acc);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (KB + 1 < KB1) layer2_interleaved<NPROD, KB + 1>(whi, wlo, h, sl, hid, acc);
+    if constexpr (KB + 1 < KB1) layer2_interleaved<NPROD, KB + 1>(whi, wlo, hid, acc);
 }
 
 // one sample's decoder inputs as they come from memory: 27 features (+ zero pad) and the 3 aux values
@@ -471,22 +496,25 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
             *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(src + i);
     }
     __syncthreads();
-    const bf16x8* w0hi = reinterpret_cast<const bf16x8*>(lds + BH_FLOATS);
-    const bf16x8* w0lo = w0hi + BW0_ELEMS / 8;
-    const bf16x8* w1hi = w0lo + BW0_ELEMS / 8;
-    const bf16x8* w1lo = w1hi + BW1_ELEMS / 8;
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));      // device-side row count (no host sync needed)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sl = lane & 31, h = lane >> 5;
+    // tile element (kb, h, mt, i) sits at byte ((kb*2 + h)*128 + mt*32 + i) * 16 of its section
+    const unsigned lds0 = (unsigned)(size_t)lds;        // low 32 bits of a flat LDS-aperture address = the LDS byte address
+    const unsigned lane_off = lds0 + BH_FLOATS * 4 + (unsigned)(h * 128 + sl) * 16;
+    const unsigned w0hi = opaque(lane_off);
+    const unsigned w0lo = opaque(lane_off + BW0_ELEMS * 2);
+    const unsigned w1hi = opaque(lane_off + BW0_ELEMS * 4);
+    const unsigned w1lo = opaque(lane_off + BW0_ELEMS * 4 + BW1_ELEMS * 2);
     const int64_t n_tiles = (n + 255) / 256;
     const int64_t G = gridDim.x;
     if ((int64_t)blockIdx.x >= n_tiles) return;
     auto row_of = [&](int64_t tile) { const int64_t sr = tile * 256 + wave * 32 + sl; return sr < n ? sr : n - 1; };
+    RowIn cur;
+    { const int64_t sc = row_of(blockIdx.x); load_row<VEC>(feat, fstride, aux, sc, aux_index(aux_map, aux_mod, sc), cur); }
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += G) {
         const int64_t s_raw = tile * 256 + wave * 32 + sl;
-        RowIn cur;
-        { const int64_t sc = row_of(tile); load_row<VEC>(feat, fstride, aux, sc, aux_index(aux_map, aux_mod, sc), cur); }
         AuxPE ap;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
@@ -496,12 +524,16 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
         }
         f32x16 acc[4], acc2[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const float* bp = lds + BH_B0 + (h * 4 + mt) * 16;
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][r] = bp[r];
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;      // bias: the constant-1 input of k slot HALF
+        layer1_interleaved<NPROD, 0>(w0hi, w0lo, h, cur.ft, cur.ax, ap, 0.25f * (float)h, acc);
+        // the row registers are dead from here on: fetch the NEXT tile's row into them now, so that the global-load
+        // latency (the features were just written by the gather kernel: L2 / HBM) hides behind layers 2 and 3
+        if (tile + G < n_tiles) {
+            const int64_t sc = row_of(tile + G);
+            load_row<VEC>(feat, fstride, aux, sc, aux_index(aux_map, aux_mod, sc), cur);
         }
-        layer1_interleaved<NPROD, 0>(w0hi, w0lo, h, sl, cur.ft, cur.ax, ap, acc);
         if (SAVE && s_raw < n) {      // post-ReLU hidden activations in natural [sample][unit] order (training)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
@@ -516,7 +548,7 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[mt][r] = bp[r];
         }
-        layer2_interleaved<NPROD, 0>(w1hi, w1lo, h, sl, acc, acc2);
+        layer2_interleaved<NPROD, 0>(w1hi, w1lo, acc, acc2);
         if (SAVE && s_raw < n) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
@@ -525,17 +557,34 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
                     *reinterpret_cast<float4*>(h2o + s_raw * HID + mt * 32 + 8 * i + 4 * h) =
                         make_float4(relu(acc2[mt][4 * i]), relu(acc2[mt][4 * i + 1]), relu(acc2[mt][4 * i + 2]), relu(acc2[mt][4 * i + 3]));
         }
-        // ---- layer 3 (fp32 VALU) ----
-        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-        {
-            const float* wp = lds + BH_W2 + h * 256;
+        // ---- layer 3 (128 -> out <= 4) on the matrix pipe, exact fp32: v_mfma_f32_4x4x1_16b_f32 computes 16 independent
+        // 4x4 outer products per issue.  Block = 4 consecutive lanes (same half); lane 4b+j supplies B = its own sample's
+        // hidden value (column j) and A = W2[row j][that unit]; D register i of lane 4b+j = out_i of lane's sample.
+        // 64 issues of 8 cycles replace 256 FMAs + 64 LDS reads per lane; four accumulators break the dependency chain.
+        // (register layout probed on gfx950: D reg i of lane 4b+j = A(lane 4b+i) * B(lane 4b+j).)
+        f32x4 o4[4];
 #pragma unroll
-            for (int q = 0; q < 64; ++q) {
-                const float hv = relu(acc2[q >> 4][q & 15]);
-                const float4 w = *reinterpret_cast<const float4*>(wp + q * 4);
-                o0 = fmaf(hv, w.x, o0); o1 = fmaf(hv, w.y, o1); o2 = fmaf(hv, w.z, o2); o3 = fmaf(hv, w.w, o3);
+        for (int c = 0; c < 4; ++c) o4[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const float* wp = lds + BH_W2 + (h * 4 + (lane & 3)) * W2A_STRIDE;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float4 w = *reinterpret_cast<const float4*>(wp + 4 * g);
+                const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int q = 4 * g + e;
+                    const float x = acc2[q >> 4][q & 15];
+                    // 2 relu(x) = x + |x| (one VALU op the compiler can schedule and pad: an inline-asm v_max feeding an
+                    // MFMA operand would need its VALU->MFMA wait states by hand); W2a carries the exact factor 1/2
+                    o4[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], x + __builtin_fabsf(x), o4[e], 0, 0, 0);
+                }
             }
         }
+        float o0 = (o4[0][0] + o4[1][0]) + (o4[2][0] + o4[3][0]);
+        float o1 = (o4[0][1] + o4[1][1]) + (o4[2][1] + o4[3][1]);
+        float o2 = (o4[0][2] + o4[1][2]) + (o4[2][2] + o4[3][2]);
+        float o3 = (o4[0][3] + o4[1][3]) + (o4[2][3] + o4[3][3]);
         o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64);
         o2 += __shfl_xor(o2, 32, 64); o3 += __shfl_xor(o3, 32, 64);
         if (h == 0 && s_raw < n) {

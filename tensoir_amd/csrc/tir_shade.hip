@@ -146,8 +146,12 @@ k_shade_setup(const float* __restrict__ maps, const float* __restrict__ rays, co
     }
     __syncthreads();
     const int base = s_base + s_wcnt[wv];
-    if (act) pair_ids[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)i;
-    else if (in) {
+    if (act) {
+        // the shared pair counter must have been zero at entry (re-armed by the integration kernel); a stale count left by
+        // an interrupted earlier call must never turn into a write past the M*D slots
+        const int64_t slot = (int64_t)base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (slot < (int64_t)M * D) pair_ids[slot] = (int32_t)i;
+    } else if (in) {
         if (vis) vis[i] = 0.0f;
         if (rec_cnt) rec_cnt[i] = 0;
     }

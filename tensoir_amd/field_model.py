@@ -198,7 +198,7 @@ class TensorVMSplit(nn.Module):
                  pos_pe=2, view_pe=2, fea_pe=2, featureC=128, step_ratio=2.0, fea2denseAct="softplus",
                  normals_kind="purely_predicted", light_rotation=["000", "120", "240"],
                  envmap_w=32, envmap_h=16, light_kind="pixel", dataset=None, numLgtSGs=128,
-                 fixed_fresnel=0.04, **kwargs):
+                 fixed_fresnel=0.04, march_t_stop=1e-6, **kwargs):
         super().__init__()
         if isinstance(density_n_comp, int):
             density_n_comp = [density_n_comp] * 3
@@ -226,8 +226,9 @@ class TensorVMSplit(nn.Module):
         self.light_kind = light_kind
         self.numLgtSGs = numLgtSGs
         self.fixed_fresnel = fixed_fresnel
-        # transmittance below which a primary / secondary ray stops marching (error in acc < this)
-        self.march_t_stop = 1e-6
+        # transmittance below which a primary / secondary ray stops marching (error in acc, vis and gradients < this;
+        # the reference marches every ray to the end: march_t_stop=0 reproduces that exactly)
+        self.march_t_stop = float(march_t_stop)
         self.matMode = MAT_MODE
         self.vecMode = VEC_MODE
         self.comp_w = [1, 1, 1]
@@ -439,7 +440,8 @@ class TensorVMSplit(nn.Module):
         ps = self._field_params()
         mask = self.alphaMask
         key = (tuple((p.data_ptr(), p._version, tuple(p.shape)) for p in ps), id(mask),
-               self.stepSize.data_ptr())
+               self.stepSize.data_ptr(), float(self.distance_scale), float(self.density_shift),
+               float(self.rayMarch_weight_thres), float(self.near_far[0]), float(self.near_far[1]), self.fea2denseAct)
         if key == self._field_key and self._field_cache is not None:
             return self._field_cache["desc"]
         if len(set(self.density_n_comp)) != 1 or len(set(self.app_n_comp)) != 1:

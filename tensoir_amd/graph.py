@@ -41,6 +41,21 @@ class GraphedRenderer:
         self._state = torch.zeros((5,), dtype=torch.int64, device=self.device)
         self._deferred = 0              # replays queued with defer_check=True since the last validate()
         self.captures = 0
+        self._model_key = None          # what the captured descriptors were built from (see _stale)
+
+    def _key(self):
+        """Everything the by-value descriptors inside the graph point into: the field tables, the SGs, the decoder
+        blobs and the marching constants.  packed_field() refreshes the field key as a side effect."""
+        m = self.model
+        m.packed_field()
+        decs = [getattr(m, n) for n in ("renderModule", "renderModule_brdf", "renderModule_normal") if hasattr(m, n)]
+        for d in decs:
+            d.packed()
+        return (m._field_key, m.lgtSGs.data_ptr(), m.lgtSGs._version, tuple(d._key for d in decs),
+                float(m.march_t_stop), ops.MLP_IMPL)
+
+    def _stale(self):
+        return self.graph is not None and self._key() != self._model_key
 
     def _eager(self):
         with torch.no_grad():
@@ -77,6 +92,7 @@ class GraphedRenderer:
         finally:
             self.model.__dict__.pop("_capture", None)
         self.graph = g
+        self._model_key = self._key()
         self.captures += 1
         if not shrink:
             floor = self.__dict__.setdefault("_cap_floor", {})
@@ -144,6 +160,8 @@ class GraphedRenderer:
             self.rays.copy_(rays.to(self.device, torch.float32), non_blocking=True)
         if light_idx is not None and light_idx is not self.lidx:
             self.lidx.copy_(light_idx.to(self.device, torch.int32).view(-1, 1), non_blocking=True)
+        if self._stale():            # an optimizer step, upsample, shrink, new mask or decoder mode since the capture: the
+            self.graph = None        # graph's descriptors point at freed / outdated tables -> capture again
         for _ in range(3):
             if self.graph is None:
                 self._capture()
@@ -161,5 +179,6 @@ class GraphedRenderer:
         raise TensoirHipError("record capacity kept overflowing while re-capturing the HIP graph")
 
     def invalidate(self):
-        """Call after the model's parameters / grid / mask change (the graph holds the packed shadows' addresses)."""
+        """Drop the captured graph (also done automatically when the model's parameters / grid / mask / decoder mode
+        changed since the capture, see _stale)."""
         self.graph = None

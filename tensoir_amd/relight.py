@@ -212,8 +212,17 @@ def shade_from_maps(tensoIR, maps, rays, light_idx, sample_method="fixed_envirma
             n_active = tensoIR.__dict__["_pair_counter"] = torch.zeros((1,), dtype=torch.int32, device=dev)
         surf, active, pair_ids, vis0, cnt0 = ops.shade_setup_compact(maps.detach(), rays, dirs, acc_thres, n_active)
         ids = {"pair_ids": pair_ids, "n_active": n_active, "vis": vis0, "rec_cnt": cnt0}
-        vis, _, ind = _secondary(tensoIR, surf, dirs, M * D, z, None, None, None, li, D, True, False, D,
-                                 keep_records=fuse, ids=ids, defer=_defer_check)
+        try:
+            vis, _, ind = _secondary(tensoIR, surf, dirs, M * D, z, None, None, None, li, D, True, False, D,
+                                     keep_records=fuse, ids=ids, defer=_defer_check)
+        except BaseException:
+            # the pair counter is re-armed by the integration kernel at the end of the pass; if the pass is abandoned
+            # in between (capacity error under capture, OOM ...) it must not stay non-zero for the next call
+            if tensoIR.__dict__.get("_capture") is None:
+                n_active.zero_()
+            else:
+                tensoIR.__dict__.pop("_pair_counter", None)
+            raise
     env = tensoIR.get_light_rgbs(dirs, device=dev)
     equal_area = sample_method == "stratifed_sample_equal_areas"
     w_d = None if equal_area else area

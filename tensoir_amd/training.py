@@ -223,7 +223,13 @@ class PrimaryRenderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_maps):
         st = ctx.st
+        if st is None:
+            raise TensoirHipError("backward through the same primary render twice is not supported: the saved activations "
+                                  "are released after the first backward (combine the losses and call backward once)")
         model = st.model
+        pend = model.__dict__.get("_pending_primary")
+        if isinstance(pend, _FinishOnce) and pend.st is st and st.finish is None:
+            model.__dict__.pop("_pending_primary", None)       # nothing left to check: do not keep the activations alive
         if st.finish is not None:                          # nobody ran the deferred check: do it now
             pend = model.__dict__.get("_pending_primary")
             ok = pend() if isinstance(pend, _FinishOnce) and pend.st is st else _FinishOnce(st)()

@@ -202,4 +202,7 @@ def test_c5_hdr_2048x1024_importance_512_vs_oracle():
     r = _record("C5", "relit_rgb", c(got), ref)
     assert r["max_rel_floor1"] < TOL and r["max_rel_pixel"] < 5e-4, r
     bg = env.get_light("syn", rays[:, 3:])
-    assert _record("C5", "background", bg.cpu()[::16], O.envlight_lookup(hdr, rays[:, 3:].cpu()[::16]))["max_rel_floor1"] < 1e-4
+    # HDR radiance is unbounded (sun disc ~1e3): relative metric.  The lookup differentiates a 2048-wide map at a pixel
+    # coordinate that comes out of acos / atan2 -- 1 ulp of the angle is 1e-4 pixel
+    r = _record("C5", "background", bg.cpu()[::16], O.envlight_lookup(hdr, rays[:, 3:].cpu()[::16]))
+    assert r["max_rel_pixel"] < 2e-4, r

@@ -417,6 +417,23 @@ def test_hip_graph_replay_matches_eager(env):
     got = gr(clone_outputs=False)                        # re-captured with room
     for k in keys:
         assert torch.equal(got[k], want[k]), k
+    # staleness: a parameter update after the capture (optimizer step, upsample, new mask ...) is detected at the next
+    # call and the graph is captured again -- a replay never reads freed or outdated tables
+    caps = gr.captures
+    saved = m.density_plane[0].detach().clone()
+    try:
+        m.density_plane[0].mul_(1.5)
+        want2 = Renderer_TensoIR_train(rays, None, lidx, m, **kw)
+        got2 = gr(rays, lidx)
+        assert gr.captures == caps + 1
+        for k in keys:
+            assert torch.equal(got2[k], want2[k]), k
+        assert not torch.equal(want2["acc_map"], want["acc_map"])
+    finally:
+        m.density_plane[0].copy_(saved)
+    got3 = gr(rays, lidx)
+    for k in keys:
+        assert torch.equal(got3[k], want[k]), k
 
 
 @torch.no_grad()

@@ -17,16 +17,19 @@ with torch.no_grad():
 sc = O.scene_from_state_dict({k: v.cpu() for k, v in m.state_dict().items()}, ck["kwargs"])
 n = int(os.environ.get("N", 2_000_000))
 g = torch.Generator().manual_seed(0)
-feat = (torch.randn(n, 27, generator=g) * 1.5).cuda()
+feat = torch.zeros(n, 32)                       # [A,32] rows as the appearance kernel writes them (16-B aligned: VEC path)
+feat[:, :27] = torch.randn(n, 27, generator=g) * 1.5
+feat = feat.cuda()
 aux = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).cuda()
 sc64 = sc.to(torch.float64)
 k = 4096
-ref = {"rgb": O.render_rgb(sc64, aux[:k].cpu().double(), feat[:k].cpu().double()),
-       "brdf": O.render_brdf(sc64, aux[:k].cpu().double(), feat[:k].cpu().double()),
-       "normal": O.render_normal(sc64, aux[:k].cpu().double(), feat[:k].cpu().double())}
+f64 = feat[:k, :27].cpu().double()
+ref = {"rgb": O.render_rgb(sc64, aux[:k].cpu().double(), f64),
+       "brdf": O.render_brdf(sc64, aux[:k].cpu().double(), f64),
+       "normal": O.render_normal(sc64, aux[:k].cpu().double(), f64)}
 mods = {"rgb": m.renderModule, "brdf": m.renderModule_brdf, "normal": m.renderModule_normal}
 with torch.no_grad():
-    for impl in ("mfma", "bf16x3", "bf16"):
+    for impl in os.environ.get("IMPLS", "mfma,bf16x3,bf16").split(","):
         for name, mod in mods.items():
             pk = mod.packed()
             out = ops.mlp(pk, feat, aux, None, impl)
