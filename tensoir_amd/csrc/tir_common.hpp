@@ -194,6 +194,40 @@ __device__ __forceinline__ float density_feature_chunk(const TirField& f, float 
     return acc;
 }
 
+// Same, with the three density line factors read from an LDS image [line 0 | line 1 | line 2], each [R_i][4*C4] floats
+// (north_star: "LDS-staged factor tiles").  A third of every sample's taps (6 of 18 x 64 B) then never reaches the
+// vector L1 / L2; measured cost of those taps in the march: ~24 % of the kernel (profiles/r02_line_tap_experiment.txt).
+// Same arithmetic, same order of operations: bit-identical to density_feature_chunk.
+template <int C4>
+__device__ __forceinline__ float density_feature_chunk_lds(const TirField& f, const float* __restrict__ ll,
+                                                           float x, float y, float z, int c) {
+    const float p[3] = {x, y, z};
+    float acc = 0.0f;
+    int loff = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int m0 = (i == 2) ? 1 : 0, m1 = (i == 0) ? 1 : 2, vi = 2 - i;
+        const int H = f.grid[m1], W = f.grid[m0], R = f.grid[vi];
+        Tap1 tx = make_tap(p[m0], W), ty = make_tap(p[m1], H), tl = make_tap(p[vi], R);
+        const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
+        const float* pl = f.dplane[i];
+        const unsigned r0 = (unsigned)(ty.i0 * W) * (C4 * 4) + 4 * c, r1 = (unsigned)(ty.i1 * W) * (C4 * 4) + 4 * c;
+        const unsigned x0 = (unsigned)tx.i0 * (C4 * 4), x1 = (unsigned)tx.i1 * (C4 * 4);
+        const float4 a = ld4(pl + (r0 + x0));
+        const float4 b = ld4(pl + (r0 + x1));
+        const float4 cc = ld4(pl + (r1 + x0));
+        const float4 d = ld4(pl + (r1 + x1));
+        const float4 e = ld4(ll + loff + (tl.i0 * (C4 * 4) + 4 * c));
+        const float4 g = ld4(ll + loff + (tl.i1 * (C4 * 4) + 4 * c));
+        loff += R * (C4 * 4);
+        acc = fmaf(fmaf(d.x, w11, fmaf(cc.x, w10, fmaf(b.x, w01, a.x * w00))), fmaf(g.x, tl.w1, e.x * tl.w0), acc);
+        acc = fmaf(fmaf(d.y, w11, fmaf(cc.y, w10, fmaf(b.y, w01, a.y * w00))), fmaf(g.y, tl.w1, e.y * tl.w0), acc);
+        acc = fmaf(fmaf(d.z, w11, fmaf(cc.z, w10, fmaf(b.z, w01, a.z * w00))), fmaf(g.z, tl.w1, e.z * tl.w0), acc);
+        acc = fmaf(fmaf(d.w, w11, fmaf(cc.w, w10, fmaf(b.w, w01, a.w * w00))), fmaf(g.w, tl.w1, e.w * tl.w0), acc);
+    }
+    return acc;
+}
+
 // DPP helper: value of lane (l - shift) within a 16-lane row, `ident` where that lane is outside the row
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_f(float ident, float v) {
@@ -256,6 +290,38 @@ __device__ __forceinline__ float wave_sigma_t(const TirField& f, bool valid, flo
         if (C4 >= 2) part += dpp_f<0xB1, 0xf>(0.0f, part);        // quad_perm [1,0,3,2]
         if (C4 >= 4) part += dpp_f<0x4E, 0xf>(0.0f, part);        // quad_perm [2,3,0,1]
         if (C4 >= 8) part += dpp_f<0x141, 0xf>(0.0f, part);       // row_half_mirror (values are quad-uniform)
+        if (slot < n && c == 0) wl[slot * 4 + 3] = part;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float sig = 0.0f;
+    if (valid) sig = feature2density(f, wl[rank * 4 + 3]);
+    __builtin_amdgcn_wave_barrier();
+    return sig;
+}
+
+// wave_sigma_t with the density lines in LDS (ll); all 64 lanes call it together
+template <int C4>
+__device__ __forceinline__ float wave_sigma_lds(const TirField& f, const float* __restrict__ ll, bool valid, float x, float y,
+                                                float z, float* wl) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long m = __ballot(valid);
+    const int n = __popcll(m);
+    if (n == 0) return 0.0f;
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (valid) { wl[rank * 4] = x; wl[rank * 4 + 1] = y; wl[rank * 4 + 2] = z; }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int PER = 64 / C4;
+    const int slot_in = lane / C4, c = lane % C4;
+    for (int base = 0; base < n; base += PER) {
+        const int slot = base + slot_in;
+        float part = 0.0f;
+        if (slot < n) {
+            const float4 p = *reinterpret_cast<const float4*>(wl + slot * 4);
+            part = density_feature_chunk_lds<C4>(f, ll, p.x, p.y, p.z, c);
+        }
+        if (C4 >= 2) part += dpp_f<0xB1, 0xf>(0.0f, part);
+        if (C4 >= 4) part += dpp_f<0x4E, 0xf>(0.0f, part);
+        if (C4 >= 8) part += dpp_f<0x141, 0xf>(0.0f, part);
         if (slot < n && c == 0) wl[slot * 4 + 3] = part;
     }
     __builtin_amdgcn_wave_barrier();

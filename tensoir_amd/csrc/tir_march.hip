@@ -530,6 +530,191 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K7 with LDS-staged line factors (north_star).  Persistent 512-thread blocks (two per CU): the block copies the three
+// density lines (3 x R x 16 floats = 57.6 KB at R = 300) into LDS once and then walks batches of 64 rays -- 16 half-waves
+// x 4 rays each.  A lane keeps the weights of its 4 x NSTEP samples in registers (n_sample <= 32 * NSTEP), so the
+// record pass needs no weight staging and the block's LDS is lines + 8 KB of gather scratch: 2 blocks = 16 waves per CU
+// (the plain kernel: 134 VGPRs -> 12 waves).  One record reservation (atomic) per 64 rays.  Same arithmetic as
+// k_march_secondary in the same order: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+#define TIR_SECL_RPB 64
+
+template <int C4, int NSTEP>
+__global__ void __launch_bounds__(512, 4)
+k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32_t* __restrict__ org_map,
+                      const float* __restrict__ dirs, const int32_t* __restrict__ dir_map,
+                      const uint8_t* __restrict__ active, int64_t n_rays, int n_dirs, int n_sample,
+                      const float* __restrict__ z_vals, float t_stop, float* __restrict__ vis,
+                      float* __restrict__ one_minus_acc, int32_t* __restrict__ rec_counter, int64_t rec_cap,
+                      int32_t* __restrict__ rec_ray, float* __restrict__ rec_w, float* __restrict__ rec_xyz,
+                      int32_t* __restrict__ ray_rec_off, int32_t* __restrict__ ray_rec_cnt,
+                      unsigned long long* __restrict__ stats, int xcd_on, const int32_t* __restrict__ ray_ids,
+                      const int32_t* __restrict__ n_ids_dev, int line_floats) {
+    extern __shared__ __attribute__((aligned(16))) float sl_lds[];
+    float* ll = sl_lds;                                         // [line 0 | line 1 | line 2]
+    const int nz = (n_sample + 3) & ~3;
+    float* zt = sl_lds + line_floats;
+    float* ws = zt + nz + (threadIdx.x >> 6) * 256;             // this wave's gather scratch
+    int* s_cnt = reinterpret_cast<int*>(zt + nz + 8 * 256);
+    int* s_base = s_cnt + TIR_SECL_RPB;
+    int* s_pid = s_base + TIR_SECL_RPB;
+    {   // stage the line factors (coalesced 16-B copies; lines are [R][16] rows, contiguous)
+        int off = 0;
+        for (int i = 0; i < 3; ++i) {
+            const int nf = f.grid[2 - i] * (C4 * 4);
+            for (int e = threadIdx.x * 4; e < nf; e += 512 * 4)
+                *reinterpret_cast<float4*>(ll + off + e) = *reinterpret_cast<const float4*>(f.dline[i] + e);
+            off += nf;
+        }
+        for (int i = threadIdx.x; i < n_sample; i += 512) zt[i] = z_vals[i];
+    }
+    __syncthreads();
+    if (ray_ids && n_ids_dev) n_rays = min(n_rays, (int64_t)max(*n_ids_dev, 0));
+    const int64_t n_batches = (n_rays + TIR_SECL_RPB - 1) / TIR_SECL_RPB;
+    const XcdRange xr = xcd_range(n_batches, 1, xcd_on != 0);
+    const int hl = threadIdx.x & 31, hw = threadIdx.x >> 5;     // lane in the half-wave, half-wave in the block (0..15)
+    const unsigned half_shift = (threadIdx.x & 32) ? 32 : 0;
+    const bool want_rec = rec_counter != nullptr;
+    unsigned n_gather = 0;
+
+    for (int64_t batch = xr.first; batch < xr.end; batch += xr.stride) {
+        float wreg[4][NSTEP];
+        int cnts[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int rl = g * 16 + hw;
+            const int64_t slot_id = batch * TIR_SECL_RPB + rl;
+            const bool in_range = slot_id < n_rays;
+            const int64_t ray = in_range ? (ray_ids ? (int64_t)ray_ids[slot_id] : slot_id) : 0;
+            const bool live = in_range && !(active && !active[ray]);
+            int cnt = 0;
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) wreg[g][st] = 0.0f;
+            if (__any(live)) {
+                float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+                if (live) {
+                    const size_t oi = org_map ? (size_t)org_map[ray] : (n_dirs > 0 ? (size_t)(ray / n_dirs) : (size_t)ray);
+                    const size_t di = dir_map ? (size_t)dir_map[ray] : (n_dirs > 0 ? (size_t)(ray % n_dirs) : (size_t)ray);
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) { o[a] = origins[3 * oi + a]; d[a] = dirs[3 * di + a]; }
+                }
+                float T = 1.0f, acc = 0.0f;
+                bool done = !live;
+                bool all_done = false;
+#pragma unroll
+                for (int st = 0; st < NSTEP; ++st) {
+                    const int k = st * 32 + hl;
+                    if (!all_done && st * 32 < n_sample) {          // wave-uniform
+                        float z = 0.f, x = 0.f, y = 0.f, zz = 0.f;
+                        bool valid = false;
+                        const bool on = !done && k < n_sample;
+                        if (on) {
+                            z = zt[k];
+                            float px = add_rn(o[0], mul_rn(d[0], z));
+                            float py = add_rn(o[1], mul_rn(d[1], z));
+                            float pz = add_rn(o[2], mul_rn(d[2], z));
+                            valid = sample_valid(f, px, py, pz, x, y, zz);
+                        }
+                        const float sigma = wave_sigma_lds<C4>(f, ll, valid, x, y, zz, ws);
+                        float w = 0.0f, v = 1.0f;
+                        if (on) {
+                            float dist = (k + 1 < n_sample) ? sub_rn(zt[k + 1], z) : 0.0f;
+                            float alpha = 1.0f - expf(-sigma * mul_rn(dist, f.distance_scale));
+                            v = add_rn(sub_rn(1.0f, alpha), 1e-10f);
+                            w = alpha;
+                        }
+                        float incl = scan_prod<32>(v, hl);
+                        float excl = shift_up1<32>(incl, hl);
+                        w = w * (T * excl);
+                        wreg[g][st] = on ? w : 0.0f;
+                        acc += w;
+                        const unsigned long long m = __ballot(w > f.weight_thres);
+                        cnt += __popc((unsigned)(m >> half_shift));
+                        if (stats) n_gather += __popc((unsigned)(__ballot(valid) >> half_shift));
+                        T = T * __shfl(incl, 31, 32);
+                        if (!done && T < t_stop) done = true;
+                        all_done = __all(done);
+                    }
+                }
+                acc = group_sum<32>(acc);
+                if (live && hl == 0) {
+                    if (vis) vis[ray] = T;
+                    if (one_minus_acc) one_minus_acc[ray] = 1.0f - acc;
+                }
+            }
+            cnts[g] = live ? cnt : 0;
+            if (hl == 0) {
+                if (in_range && !live) {
+                    if (vis) vis[ray] = 0.0f;
+                    if (one_minus_acc) one_minus_acc[ray] = 0.0f;
+                }
+                s_cnt[rl] = cnts[g];
+                s_pid[rl] = in_range ? (int)ray : -1;
+            }
+        }
+        if (!want_rec) continue;
+        __syncthreads();
+        if (threadIdx.x < 64) {           // one wave: inclusive scan of the 64 ray counts, one reservation for the batch
+            const int lane = threadIdx.x;
+            const int c = s_cnt[lane];
+            int incl = c;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                int oth = __shfl_up(incl, dd, 64);
+                if (lane >= dd) incl += oth;
+            }
+            const int total = __shfl(incl, 63, 64);
+            int base = 0;
+            if (lane == 63 && total > 0) base = atomicAdd(rec_counter, total);
+            base = __shfl(base, 63, 64);
+            const bool fits = (int64_t)base + total <= rec_cap;
+            if (lane == 63 && total > 0 && fits) atomicMax(rec_counter + 1, base + total);
+            const int pid = s_pid[lane];
+            if (pid >= 0) {
+                ray_rec_off[pid] = base + incl - c;
+                ray_rec_cnt[pid] = fits ? c : 0;
+            }
+            s_base[lane] = (fits && c > 0) ? base + incl - c : -1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int rl = g * 16 + hw;
+            int base = s_base[rl];
+            if (base < 0) continue;                    // uniform inside the half-wave
+            const int64_t ray = s_pid[rl];
+            const size_t oi = org_map ? (size_t)org_map[ray] : (n_dirs > 0 ? (size_t)(ray / n_dirs) : (size_t)ray);
+            const size_t di = dir_map ? (size_t)dir_map[ray] : (n_dirs > 0 ? (size_t)(ray % n_dirs) : (size_t)ray);
+            float o[3], d[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { o[a] = origins[3 * oi + a]; d[a] = dirs[3 * di + a]; }
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                const int k = st * 32 + hl;
+                const float w = wreg[g][st];
+                const bool keep = w > f.weight_thres;
+                const unsigned hm = (unsigned)(__ballot(keep) >> half_shift);
+                if (keep) {
+                    const int slot = base + __popc(hm & ((1u << hl) - 1u));
+                    const float z = zt[k];
+                    rec_ray[slot] = (int32_t)ray;
+                    rec_w[slot] = w;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        float p = add_rn(o[a], mul_rn(d[a], z));
+                        rec_xyz[3 * (size_t)slot + a] = norm_coord(p, f.aabb_min[a], f.inv_aabb[a]);
+                    }
+                }
+                base += __popc(hm);
+            }
+        }
+        // the next batch's s_cnt / s_pid writes come after this batch's readers: s_base is only rewritten behind the
+        // next __syncthreads pair, s_pid[rl] / s_cnt[rl] belong to the half-wave that reads them here
+    }
+    if (stats && hl == 0 && n_gather) atomicAdd(stats, (unsigned long long)n_gather);
+}
+
 extern "C" int tir_march_secondary_fwd(const TirField* f, const float* origins, const int32_t* org_map,
                                        const float* dirs, const int32_t* dir_map, const uint8_t* active,
                                        int64_t n_rays, int32_t n_dirs, int32_t n_sample, const float* z_vals,
@@ -558,9 +743,33 @@ extern "C" int tir_march_secondary_ids_fwd(const TirField* f, const float* origi
     if (rec_counter && (!rec_ray || !rec_w || !rec_xyz || !ray_rec_off || !ray_rec_cnt || rec_cap < 0)) return TIR_ERR_ARG;
     if (n_rays >= (int64_t)1 << 31) return TIR_ERR_UNSUPPORTED;
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
+    const int xcd_on = tir_xcd_mapping();
+    // LDS-staged line factors: 16 density components, <= 96 samples per ray, lines + scratch within half a CU's LDS
+    {
+        const int64_t line_floats = (int64_t)(f->grid[0] + f->grid[1] + f->grid[2]) * f->n_dcomp;
+        const size_t lds2 = ((size_t)line_floats + ((n_sample + 3) & ~3) + 8 * 256 + 3 * TIR_SECL_RPB) * sizeof(float);
+        static int lds_lines = -1;
+        if (lds_lines < 0) { const char* e = getenv("TENSOIR_LDS_LINES"); lds_lines = (e && e[0] == '0') ? 0 : 1; }
+        if (lds_lines && f->n_dcomp == 16 && n_sample <= 96 && lds2 <= 80 * 1024) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_secondary_lds<4, 3>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                attr_set = true;
+            }
+            const int64_t n_batches = (n_rays + TIR_SECL_RPB - 1) / TIR_SECL_RPB;
+            unsigned nblk = (unsigned)std::min<int64_t>(n_batches, 2 * 256);
+            if (xcd_on) nblk = (nblk + 7) / 8 * 8;
+            hipLaunchKernelGGL((k_march_secondary_lds<4, 3>), dim3(nblk), dim3(512), lds2, tir_stream(stream),
+                               *f, origins, org_map, dirs, dir_map, active, n_rays, n_dirs, n_sample, z_vals, t_stop, vis,
+                               one_minus_acc, rec_counter, rec_cap, rec_ray, rec_w, rec_xyz, ray_rec_off, ray_rec_cnt, stats,
+                               xcd_on, ray_ids, n_ids_dev, (int)line_floats);
+            TIR_CHECK_LAUNCH();
+            return TIR_OK;
+        }
+    }
     size_t lds = ((size_t)((n_sample + 3) & ~3) + 4 * 256 + 4 * TIR_SEC_RPB +
                   (rec_counter ? (size_t)TIR_SEC_RPB * n_sample : 0)) * sizeof(float);
-    const int xcd_on = tir_xcd_mapping();
     unsigned nblk = (unsigned)((n_rays + TIR_SEC_RPB - 1) / TIR_SEC_RPB);
     if (xcd_on) nblk = (nblk + 7) / 8 * 8;
     hipLaunchKernelGGL(k_march_secondary, dim3(nblk), dim3(256), lds, tir_stream(stream),
