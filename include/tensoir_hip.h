@@ -154,6 +154,15 @@ int tir_density_grad_fwd(const TirField* f, const float* xyz, float* sigma, floa
 int tir_vm_app_fwd(const TirField* f, const float* xyz, const int32_t* light_idx,
                    const int32_t* idx_map, float* rad_feat, float* int_feat, int32_t out_stride,
                    int32_t idx_div, int64_t n, const int32_t* n_dev, void* stream);
+
+/* Intrinsic feature of JITTERED points xyz + scale * N(0,1) (the smoothness pass of
+ * models/tensorBase_rotated_lights.py:937-938) with the noise drawn inside the gather kernel: Philox4x32-10 keyed by
+ * (seed, offset) -- the caller framework's generator state -- with the point index as counter, Box-Muller.  rng_state
+ * (device int64 {seed, offset}, optional) overrides the by-value pair (HIP-graph replays).  xyz_out [n][3] receives the
+ * jittered points (aux input of the BRDF decoder), int_feat [n][out_stride] their intrinsic features. */
+int tir_vm_app_jitter_fwd(const TirField* f, const float* xyz, int64_t n, const int32_t* n_dev, float scale,
+                          uint64_t seed, uint64_t offset, const int64_t* rng_state, float* xyz_out,
+                          float* int_feat, int32_t out_stride, void* stream);
 /* same contract with the 144 x 27 contraction on v_mfma_f32_16x16x32_bf16 and every operand split x = hi + lo in bf16
  * (three products, fp32 accumulate: parity grade, features agree with the exact kernel to ~1e-6); n_acomp <= 64. */
 int tir_vm_app_fwd_bf16x3(const TirField* f, const float* xyz, const int32_t* light_idx,
@@ -201,6 +210,19 @@ int tir_march_primary_fwd(const TirField* f, const float* rays, const float* ray
                           float* depth, float* t_end, int32_t* app_count,
                           unsigned long long* stats, void* stream);
 
+/* tir_march_primary_fwd plus the by-products that used to be separate launches of a step (each optional, NULL/0 to skip):
+ *   viewdirs [B][3]     rays[:, 3:6] as a contiguous table = aux input of the radiance decoder
+ *                       (the `viewdirs` of models/tensorBase_rotated_lights.py:872);
+ *   zero_words[n_zero]  int32 counters of LATER kernels of the same pass, re-armed here (n_zero <= 256);
+ *   ticket/offsets/cap/total  tir_exclusive_scan_capped(app_count) -> offsets[B+1], *total, done by the workgroup that
+ *                       finishes last; `ticket` is one device int32 that must be zero before the first use (it re-arms
+ *                       itself).  Replaces the boolean-mask bookkeeping of :924-926 without a second launch. */
+int tir_march_primary_fused_fwd(const TirField* f, const float* rays, const float* ray_jitter,
+                                int32_t B, int32_t S, float t_stop, float* weight, float* acc,
+                                float* depth, float* t_end, int32_t* app_count, unsigned long long* stats,
+                                float* viewdirs, int32_t* zero_words, int32_t n_zero, int32_t* ticket,
+                                int32_t* offsets, int32_t cap, int32_t* total, void* stream);
+
 /* exclusive scan of counts[n] -> offsets[n+1] (offsets[n] = total) */
 int tir_exclusive_scan(const int32_t* counts, int32_t* offsets, int32_t n, void* stream);
 /* same, with every offset clamped to `cap` (a record capacity chosen before the counts are known on the host):
@@ -235,6 +257,17 @@ int tir_composite_primary(const float* rays, const int32_t* offsets, const float
                           const float* pred_normal, const float* derived_normal,
                           const float* acc, const float* depth, int32_t B, int32_t white_bg,
                           int32_t is_relight, float fixed_fresnel, float* out_maps, void* stream);
+
+/* tir_composite_primary plus (a) the two smoothness losses = means over all B rays of map columns 17 / 18
+ * (models/tensorBase_rotated_lights.py:999-1000) written to smooth_out[2] by the workgroup that finishes last
+ * (`ticket`: one device int32, zero before the first use, re-arms itself; both or neither), and (b) the per-pass
+ * advance of a device-side jitter-noise state rng_state = int64 {seed, offset}: offset += rng_step (NULL to skip). */
+int tir_composite_primary_fused(const float* rays, const int32_t* offsets, const float* rec_w,
+                                const float* rgb, const float* brdf, const float* brdf_jit,
+                                const float* pred_normal, const float* derived_normal,
+                                const float* acc, const float* depth, int32_t B, int32_t white_bg,
+                                int32_t is_relight, float fixed_fresnel, float* out_maps, int32_t* ticket,
+                                float* smooth_out, int64_t* rng_state, int64_t rng_step, void* stream);
 
 /* ---- K7 secondary march: sample_ray_equally + cull + density + raw2alpha
  *      (models/relight_utils.py:707-722, :657-705, :777-834).

@@ -77,6 +77,10 @@ SIGNATURES = {
     "tir_march_primary_fwd": (C.c_int, [C.POINTER(TirField), P, P, I32, I32, F32, P, P, P, P, P, P, P]),
     "tir_exclusive_scan": (C.c_int, [P, P, I32, P]),
     "tir_exclusive_scan_capped": (C.c_int, [P, P, I32, I32, P, P]),
+    "tir_march_primary_fused_fwd": (C.c_int, [C.POINTER(TirField), P, P, I32, I32, F32, P, P, P, P, P, P,
+                                              P, P, I32, P, P, I32, P, P]),
+    "tir_composite_primary_fused": (C.c_int, [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, F32, P, P, P, P, I64, P]),
+    "tir_vm_app_jitter_fwd": (C.c_int, [C.POINTER(TirField), P, I64, P, F32, C.c_uint64, C.c_uint64, P, P, P, I32, P]),
     "tir_compact_primary": (C.c_int, [C.POINTER(TirField), P, P, P, P, I32, I32, P, P, P, P, P]),
     "tir_composite_primary": (C.c_int, [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, F32, P, P]),
     "tir_march_secondary_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I64, I32, I32, P, F32, P, P,

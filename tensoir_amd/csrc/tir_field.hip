@@ -433,18 +433,53 @@ k_vm_app_valu(TirField f, const float* __restrict__ xyz, const int32_t* __restri
 // at a time.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define TIR_XLD 17   // padded sample stride of the X tile (bank spread for the quad-strided writes)
+#define TIR_XLD 17
 
-template <int C4, bool RAD, bool INTR>
+// In-kernel BRDF-jitter noise (models/tensorBase_rotated_lights.py:937: xyz + randn_like(xyz) * 0.01): the gather of the
+// jittered points draws its own N(0,1) triple per point -- Philox4x32-10 keyed by the framework generator's (seed,
+// offset), counter = point index -- instead of a framework randn + add pair of launches and an [A,3] round trip.
+// rng_dev (int64[2] = {seed, offset} on the device) overrides the by-value pair: a captured graph replays with fresh
+// noise because the compositing kernel of the pass bumps the device-side offset.
+struct TirJitter {
+    float scale;                       // 0 = no jitter
+    unsigned long long seed, offset;
+    const long long* rng_dev;
+    float* xyz_out;                    // [n,3] jittered points (the decoder's aux input)
+};
+
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+}
+
+// three independent N(0,1) values for point `idx` (Box-Muller on the four Philox words)
+__device__ __forceinline__ void jitter_normals(unsigned long long seed, unsigned long long offset, uint64_t idx, float (&nrm)[3]) {
+    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    const float u0 = ((float)c[0] + 0.5f) * 2.3283064365386963e-10f, u1 = ((float)c[1] + 0.5f) * 2.3283064365386963e-10f;
+    const float u2 = ((float)c[2] + 0.5f) * 2.3283064365386963e-10f, u3 = ((float)c[3] + 0.5f) * 2.3283064365386963e-10f;
+    const float r0 = sqrtf(-2.0f * logf(fminf(u0, 0.99999994f))), r1 = sqrtf(-2.0f * logf(fminf(u2, 0.99999994f)));
+    float s0, c0, s1, c1;
+    sincospif(2.0f * u1, &s0, &c0);
+    sincospif(2.0f * u3, &s1, &c1);
+    nrm[0] = r0 * c0; nrm[1] = r0 * s0; nrm[2] = r1 * c1;
+    (void)s1;
+}   // padded sample stride of the X tile (bank spread for the quad-strided writes)
+
+template <int C4, bool RAD, bool INTR, bool JIT = false>
 __global__ void __launch_bounds__(256)
 k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
               const int32_t* __restrict__ idx_map, float* __restrict__ rad_feat, float* __restrict__ int_feat,
-              int out_stride, int idx_div, int64_t n, const int32_t* __restrict__ n_dev, int xcd_on) {
+              int out_stride, int idx_div, int64_t n, const int32_t* __restrict__ n_dev, int xcd_on, TirJitter jt) {
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));        // device-side point count (no host sync needed)
     constexpr int CA = C4 * 4;
     constexpr int NX = (RAD ? 1 : 0) + (INTR ? 1 : 0);
     extern __shared__ __attribute__((aligned(16))) float lds_app[];
     float* Wt = lds_app;                                   // [3*CA][32]
+    if (JIT && jt.rng_dev) { jt.seed = (unsigned long long)jt.rng_dev[0]; jt.offset = (unsigned long long)jt.rng_dev[1]; }
     const int wave = threadIdx.x >> 6, L = threadIdx.x & 63;
     float* X = lds_app + 3 * CA * 32 + wave * (NX * CA * TIR_XLD);   // [NX][CA][17]
     for (int i = threadIdx.x * 4; i < 3 * CA * 32; i += 256 * 4)
@@ -457,7 +492,14 @@ k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restri
     for (int64_t pass = xr.first + wave; pass < xr.end; pass += xr.stride) {
         const int64_t s = pass * 16 + j;
         const int64_t sc = s < n ? s : n - 1;
-        const float p[3] = {xyz[3 * sc], xyz[3 * sc + 1], xyz[3 * sc + 2]};
+        float p[3] = {xyz[3 * sc], xyz[3 * sc + 1], xyz[3 * sc + 2]};
+        if (JIT) {                   // all four lanes of the sample derive the same triple from the same counter
+            float nrm[3];
+            jitter_normals(jt.seed, jt.offset, (uint64_t)sc, nrm);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) p[a] = add_rn(p[a], mul_rn(nrm[a], jt.scale));
+            if (jt.xyz_out && c == 0 && s < n) { jt.xyz_out[3 * s] = p[0]; jt.xyz_out[3 * s + 1] = p[1]; jt.xyz_out[3 * s + 2] = p[2]; }
+        }
         const float* lrow = nullptr;
         if (RAD) {
             int64_t lsel = idx_map ? (int64_t)idx_map[sc] : sc;
@@ -719,7 +761,8 @@ static int launch_app_bf16(const TirField* f, const float* xyz, const int32_t* l
 
 template <int C4>
 static int launch_app(const TirField* f, const float* xyz, const int32_t* li, const int32_t* map,
-                      float* rad, float* intr, int stride, int idx_div, int64_t n, const int32_t* n_dev, hipStream_t s, bool valu) {
+                      float* rad, float* intr, int stride, int idx_div, int64_t n, const int32_t* n_dev, hipStream_t s, bool valu,
+                      const TirJitter& jt = TirJitter{0.0f, 0ull, 0ull, nullptr, nullptr}) {
     if (valu) {
         dim3 g((unsigned)((n + 255) / 256)), b(256);
         if (rad && intr) hipLaunchKernelGGL((k_vm_app_valu<C4, true, true>), g, b, 0, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev);
@@ -743,15 +786,22 @@ static int launch_app(const TirField* f, const float* xyz, const int32_t* li, co
         attr_set = true;
     }
     if (lds > 160 * 1024) return TIR_ERR_UNSUPPORTED;
-    if (rad && intr) hipLaunchKernelGGL((k_vm_app_mfma<C4, true, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on);
-    else if (rad)    hipLaunchKernelGGL((k_vm_app_mfma<C4, true, false>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on);
-    else             hipLaunchKernelGGL((k_vm_app_mfma<C4, false, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on);
+    if (jt.scale != 0.0f) {
+        if (rad || !intr) return TIR_ERR_ARG;
+        static bool jattr = false;
+        if (!jattr) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_mfma<C4, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); jattr = true; }
+        hipLaunchKernelGGL((k_vm_app_mfma<C4, false, true, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on, jt);
+        return TIR_OK;
+    }
+    if (rad && intr) hipLaunchKernelGGL((k_vm_app_mfma<C4, true, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on, jt);
+    else if (rad)    hipLaunchKernelGGL((k_vm_app_mfma<C4, true, false>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on, jt);
+    else             hipLaunchKernelGGL((k_vm_app_mfma<C4, false, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on, jt);
     return TIR_OK;
 }
 
 static int app_fwd(const TirField* f, const float* xyz, const int32_t* light_idx, const int32_t* idx_map,
                    float* rad_feat, float* int_feat, int32_t out_stride, int32_t idx_div, int64_t n, const int32_t* n_dev, void* stream,
-                   bool valu, bool split_bf16 = false) {
+                   bool valu, bool split_bf16 = false, const TirJitter& jt = TirJitter{0.0f, 0ull, 0ull, nullptr, nullptr}) {
     if (!f) return TIR_ERR_ARG;
     for (int i = 0; i < 3; ++i)
         if (f->grid[i] < 2 || !f->aplane[i] || !f->aline[i]) return TIR_ERR_ARG;
@@ -774,10 +824,10 @@ static int app_fwd(const TirField* f, const float* xyz, const int32_t* light_idx
         return TIR_OK;
     }
     switch (f->n_acomp) {
-        case 48: rc = launch_app<12>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, s, valu); break;
-        case 24: rc = launch_app<6>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, s, valu); break;
-        case 16: rc = launch_app<4>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, s, valu); break;
-        case 96: rc = launch_app<24>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, s, valu); break;
+        case 48: rc = launch_app<12>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, s, valu, jt); break;
+        case 24: rc = launch_app<6>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, s, valu, jt); break;
+        case 16: rc = launch_app<4>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, s, valu, jt); break;
+        case 96: rc = launch_app<24>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, s, valu, jt); break;
         default: return TIR_ERR_UNSUPPORTED;
     }
     if (rc) return rc;
@@ -789,6 +839,16 @@ extern "C" int tir_vm_app_fwd(const TirField* f, const float* xyz, const int32_t
                               const int32_t* idx_map, float* rad_feat, float* int_feat, int32_t out_stride,
                               int32_t idx_div, int64_t n, const int32_t* n_dev, void* stream) {
     return app_fwd(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, stream, false);
+}
+
+// Intrinsic feature of the JITTERED points xyz + scale * N(0,1) (models/tensorBase_rotated_lights.py:937-938) with the
+// noise drawn inside the gather kernel; xyz_out receives the jittered points.
+extern "C" int tir_vm_app_jitter_fwd(const TirField* f, const float* xyz, int64_t n, const int32_t* n_dev, float scale,
+                                     uint64_t seed, uint64_t offset, const int64_t* rng_dev, float* xyz_out,
+                                     float* int_feat, int32_t out_stride, void* stream) {
+    if (!xyz_out || !int_feat || scale == 0.0f) return TIR_ERR_ARG;
+    TirJitter jt{scale, (unsigned long long)seed, (unsigned long long)offset, reinterpret_cast<const long long*>(rng_dev), xyz_out};
+    return app_fwd(f, xyz, nullptr, nullptr, nullptr, int_feat, out_stride, 0, n, n_dev, stream, false, false, jt);
 }
 
 extern "C" int tir_vm_app_fwd_valu(const TirField* f, const float* xyz, const int32_t* light_idx,

@@ -6,15 +6,14 @@ using namespace tir;
 // ------------------------------------------------------------------------------------------------
 // primary march: one wave64 per ray, 64 consecutive samples per step, transmittance carried
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_march_primary(TirField f, const float* __restrict__ rays, const float* __restrict__ ray_jitter,
-                int B, int S, float t_stop, float* __restrict__ weight, float* __restrict__ acc_out,
-                float* __restrict__ depth_out, float* __restrict__ tend_out, int32_t* __restrict__ app_count,
-                unsigned long long* __restrict__ stats, float* __restrict__ sigma_out) {
-    const int lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (ray >= B) return;
+__device__ __forceinline__ void march_one_ray(const TirField& f, const float* __restrict__ rays, const float* __restrict__ ray_jitter,
+                                              int B, int S, float t_stop, float* __restrict__ weight, float* __restrict__ acc_out,
+                                              float* __restrict__ depth_out, float* __restrict__ tend_out,
+                                              int32_t* __restrict__ app_count, unsigned long long* __restrict__ stats,
+                                              float* __restrict__ sigma_out, float* __restrict__ viewdirs, bool coh, int ray, int lane) {
     RaySetup rs = ray_setup(f, rays, ray);
+    if (viewdirs && lane < 3) viewdirs[3 * (size_t)ray + lane] = rays[6 * (size_t)ray + 3 + lane];
+
     const bool hj = ray_jitter != nullptr;
     const float jit = hj ? ray_jitter[ray] : 0.0f;
 
@@ -69,9 +68,83 @@ k_march_primary(TirField f, const float* __restrict__ rays, const float* __restr
         acc_out[ray] = acc;
         depth_out[ray] = depth;
         if (tend_out) tend_out[ray] = T;
-        app_count[ray] = cnt;
+        // coh: the count is consumed by ANOTHER workgroup of this launch (the last one scans): write-through store
+        if (coh) __hip_atomic_store(app_count + ray, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else app_count[ray] = cnt;
         if (stats) atomicAdd(stats, (unsigned long long)n_gather);
     }
+}
+
+
+// Optional by-products of the primary march that used to be separate (framework) launches of a step:
+//   viewdirs  [B,3]   the ray directions as a contiguous table (aux input of the radiance decoder);
+//   zero_words        n_zero int32 counters of LATER kernels of the same pass (secondary record counter) re-armed here;
+//   ticket/offsets    the capped exclusive scan of the per-ray record counts, done by the block that finishes last
+//                     (agent-scope release / acquire around a ticket counter that re-arms itself) -- deterministic.
+struct TirMarchExtras {
+    float* viewdirs;
+    int32_t* zero_words; int n_zero;
+    int32_t* ticket; int32_t* offsets; int cap; int32_t* total_out;
+};
+
+__device__ __forceinline__ void block_exclusive_scan_capped(const int32_t* __restrict__ counts, int32_t* __restrict__ offsets,
+                                                             int n, int cap, int32_t* __restrict__ total_out) {
+    // all 256 threads of the calling block; chunked, carry in LDS (same arithmetic as k_exclusive_scan)
+    __shared__ int32_t wsum[4];
+    __shared__ int32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + tid;
+        const int32_t v = (i < n) ? __hip_atomic_load(counts + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        int32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int32_t o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int32_t woff = 0;
+        for (int q = 0; q < wv; ++q) woff += wsum[q];
+        const int32_t carry = carry_s;
+        if (i < n) offsets[i] = min(carry + woff + incl - v, cap);
+        __syncthreads();
+        if (tid == 255) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        offsets[n] = min(carry_s, cap);
+        if (total_out) *total_out = carry_s;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_march_primary(TirField f, const float* __restrict__ rays, const float* __restrict__ ray_jitter,
+                int B, int S, float t_stop, float* __restrict__ weight, float* __restrict__ acc_out,
+                float* __restrict__ depth_out, float* __restrict__ tend_out, int32_t* __restrict__ app_count,
+                unsigned long long* __restrict__ stats, float* __restrict__ sigma_out, TirMarchExtras ex) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ex.zero_words && blockIdx.x == 0 && threadIdx.x < ex.n_zero) ex.zero_words[threadIdx.x] = 0;
+    if (ray < B) march_one_ray(f, rays, ray_jitter, B, S, t_stop, weight, acc_out, depth_out, tend_out, app_count, stats,
+                               sigma_out, ex.viewdirs, ex.ticket != nullptr, ray, lane);
+    if (!ex.ticket) return;
+    // last workgroup done -> scan.  The counts are published with write-through (sc1) stores, each wave drains its own
+    // stores, then one ticket per workgroup; the holder of the last ticket reads all B counts with sc1 loads.  (An
+    // agent-scope release fence per workgroup would write back the XCD's whole dirty L2 -- the 8 MB of weights this
+    // kernel has just produced -- 1024 times: measured 0.035 -> 0.066 ms.)
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(ex.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == (int)gridDim.x - 1);
+        if (s_last) __hip_atomic_store(ex.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed
+    }
+    __syncthreads();
+    if (s_last) block_exclusive_scan_capped(app_count, ex.offsets, B, ex.cap, ex.total_out);
 }
 
 extern "C" int tir_march_primary_fwd(const TirField* f, const float* rays, const float* ray_jitter,
@@ -83,7 +156,26 @@ extern "C" int tir_march_primary_fwd(const TirField* f, const float* rays, const
     if (!rays || !weight || !acc || !depth || !app_count) return TIR_ERR_ARG;
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_march_primary, dim3((B + 3) / 4), dim3(256), 0, tir_stream(stream), *f, rays,
-                       ray_jitter, B, S, t_stop, weight, acc, depth, t_end, app_count, stats, (float*)nullptr);
+                       ray_jitter, B, S, t_stop, weight, acc, depth, t_end, app_count, stats, (float*)nullptr, TirMarchExtras{});
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+// tir_march_primary_fwd + by-products (see TirMarchExtras): viewdirs table, re-armed counters, capped exclusive scan of
+// the record counts (ticket: one int32, zero before the first use; offsets [B+1]; total = uncapped record count).
+extern "C" int tir_march_primary_fused_fwd(const TirField* f, const float* rays, const float* ray_jitter,
+                                           int32_t B, int32_t S, float t_stop, float* weight, float* acc,
+                                           float* depth, float* t_end, int32_t* app_count, unsigned long long* stats,
+                                           float* viewdirs, int32_t* zero_words, int32_t n_zero, int32_t* ticket,
+                                           int32_t* offsets, int32_t cap, int32_t* total, void* stream) {
+    if (!f || B < 0 || S <= 0 || n_zero < 0 || n_zero > 256 || cap < 0) return TIR_ERR_ARG;
+    if ((ticket == nullptr) != (offsets == nullptr)) return TIR_ERR_ARG;
+    if (B == 0) return TIR_OK;
+    if (!rays || !weight || !acc || !depth || !app_count) return TIR_ERR_ARG;
+    if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
+    TirMarchExtras ex{viewdirs, zero_words, n_zero, ticket, offsets, cap, total};
+    hipLaunchKernelGGL(k_march_primary, dim3((B + 3) / 4), dim3(256), 0, tir_stream(stream), *f, rays,
+                       ray_jitter, B, S, t_stop, weight, acc, depth, t_end, app_count, stats, (float*)nullptr, ex);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
@@ -97,7 +189,7 @@ extern "C" int tir_march_primary_train_fwd(const TirField* f, const float* rays,
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_march_primary, dim3((B + 3) / 4), dim3(256), 0, tir_stream(stream), *f, rays,
                        ray_jitter, B, S, t_stop, weight, acc, depth, t_end, app_count,
-                       (unsigned long long*)nullptr, sigma);
+                       (unsigned long long*)nullptr, sigma, TirMarchExtras{});
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
@@ -248,18 +340,17 @@ extern "C" int tir_compact_primary(const TirField* f, const float* rays, const f
 // compositing + tone mapping (models/tensorBase_rotated_lights.py:973-1031): one wave per ray, lanes stride
 // over the ray's records, butterfly reduction (deterministic sums).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_composite_primary(const float* __restrict__ rays, const int32_t* __restrict__ offsets,
+struct TirCompositeExtras {
+    int32_t* ticket; float* smooth_out;      // smoothness means (both or neither)
+    long long* rng_bump; long long rng_step; // device-side {seed, offset} of the jitter noise: offset += step per pass
+};
+
+__device__ __forceinline__ void composite_one_ray(const float* __restrict__ rays, const int32_t* __restrict__ offsets,
                     const float* __restrict__ rec_w, const float* __restrict__ rgb,
                     const float* __restrict__ brdf, const float* __restrict__ brdf_jit,
                     const float* __restrict__ pred_n, const float* __restrict__ der_n,
-                    const float* __restrict__ acc_in, const float* __restrict__ depth_in, int B, int white_bg,
-                    int is_relight, float fixed_fresnel, float* __restrict__ out) {
-    // one wave64 per ray: lane l takes records b+l, b+l+64, ...; fixed-shape butterfly reduction -> the sums
-    // depend only on the ray's own records (deterministic, invariant under ray sharding)
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (r >= B) return;
+                    const float* __restrict__ acc_in, const float* __restrict__ depth_in, int white_bg,
+                    int is_relight, float fixed_fresnel, float* __restrict__ out, bool coh, int r, int lane) {
     const int b = offsets[r], e = offsets[r + 1];
     float c[3] = {0, 0, 0}, nm[3] = {0, 0, 0}, al[3] = {0, 0, 0};
     float rough = 0, ndiff = 0, norient = 0, albc = 0, rghc = 0;
@@ -341,7 +432,54 @@ k_composite_primary(const float* __restrict__ rays, const int32_t* __restrict__ 
     fr = fminf(fmaxf(fr, 0.f), 1.f);
     o[11] = fr; o[12] = fr; o[13] = fr;
     o[14] = acc;
-    o[15] = ndiff; o[16] = norient; o[17] = albc; o[18] = rghc; o[19] = 0.f;
+    o[15] = ndiff; o[16] = norient; o[19] = 0.f;
+    if (coh) {      // read back by the last workgroup of this launch (smoothness means): write-through stores
+        __hip_atomic_store(o + 17, albc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 18, rghc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else { o[17] = albc; o[18] = rghc; }
+}
+
+
+__global__ void __launch_bounds__(256)
+k_composite_primary(const float* __restrict__ rays, const int32_t* __restrict__ offsets,
+                    const float* __restrict__ rec_w, const float* __restrict__ rgb,
+                    const float* __restrict__ brdf, const float* __restrict__ brdf_jit,
+                    const float* __restrict__ pred_n, const float* __restrict__ der_n,
+                    const float* __restrict__ acc_in, const float* __restrict__ depth_in, int B, int white_bg,
+                    int is_relight, float fixed_fresnel, float* __restrict__ out, TirCompositeExtras ex) {
+    // one wave64 per ray: lane l takes records b+l, b+l+64, ...; fixed-shape butterfly reduction -> the sums
+    // depend only on the ray's own records (deterministic, invariant under ray sharding)
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ex.rng_bump && blockIdx.x == 0 && threadIdx.x == 0) ex.rng_bump[1] += ex.rng_step;   // next pass: fresh jitter noise
+    if (r < B) composite_one_ray(rays, offsets, rec_w, rgb, brdf, brdf_jit, pred_n, der_n, acc_in, depth_in, white_bg,
+                                 is_relight, fixed_fresnel, out, ex.ticket != nullptr, r, lane);
+    if (!ex.ticket || !is_relight) return;
+    // the two smoothness losses = means over ALL rays of map columns 17 / 18 (models/tensorBase_rotated_lights.py:999-1000):
+    // the block that finishes last sums the columns in a fixed order (deterministic; no extra reduction launch)
+    __shared__ int s_last;
+    __shared__ float s_part[2][4];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have landed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(ex.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == (int)gridDim.x - 1);
+        if (s_last) __hip_atomic_store(ex.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    float a = 0.0f, g = 0.0f;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        a += __hip_atomic_load(out + (size_t)i * TIR_MAP_STRIDE + 17, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g += __hip_atomic_load(out + (size_t)i * TIR_MAP_STRIDE + 18, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    a = group_sum<64>(a); g = group_sum<64>(g);
+    if (lane == 0) { s_part[0][threadIdx.x >> 6] = a; s_part[1][threadIdx.x >> 6] = g; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ex.smooth_out[0] = ((s_part[0][0] + s_part[0][1]) + (s_part[0][2] + s_part[0][3])) / (float)B;
+        ex.smooth_out[1] = ((s_part[1][0] + s_part[1][1]) + (s_part[1][2] + s_part[1][3])) / (float)B;
+    }
 }
 
 extern "C" int tir_composite_primary(const float* rays, const int32_t* offsets, const float* rec_w,
@@ -354,7 +492,26 @@ extern "C" int tir_composite_primary(const float* rays, const int32_t* offsets, 
     if (!rays || !offsets || !acc || !depth || !out_maps) return TIR_ERR_ARG;
     hipLaunchKernelGGL(k_composite_primary, dim3((B + 3) / 4), dim3(256), 0, tir_stream(stream), rays, offsets,
                        rec_w, rgb, brdf, brdf_jit, pred_normal, derived_normal, acc, depth, B, white_bg,
-                       is_relight, fixed_fresnel, out_maps);
+                       is_relight, fixed_fresnel, out_maps, TirCompositeExtras{});
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+// tir_composite_primary + the two smoothness-loss means (smooth_out[2], ticket: one int32, zero before the first use) and
+// the per-pass bump of the device-side jitter RNG offset (rng_state = int64 {seed, offset}, may be null).
+extern "C" int tir_composite_primary_fused(const float* rays, const int32_t* offsets, const float* rec_w,
+                                           const float* rgb, const float* brdf, const float* brdf_jit,
+                                           const float* pred_normal, const float* derived_normal,
+                                           const float* acc, const float* depth, int32_t B, int32_t white_bg,
+                                           int32_t is_relight, float fixed_fresnel, float* out_maps, int32_t* ticket,
+                                           float* smooth_out, int64_t* rng_state, int64_t rng_step, void* stream) {
+    if (B < 0 || (ticket == nullptr) != (smooth_out == nullptr)) return TIR_ERR_ARG;
+    if (B == 0) return TIR_OK;
+    if (!rays || !offsets || !acc || !depth || !out_maps) return TIR_ERR_ARG;
+    TirCompositeExtras ex{ticket, smooth_out, reinterpret_cast<long long*>(rng_state), (long long)rng_step};
+    hipLaunchKernelGGL(k_composite_primary, dim3((B + 3) / 4), dim3(256), 0, tir_stream(stream), rays, offsets,
+                       rec_w, rgb, brdf, brdf_jit, pred_normal, derived_normal, acc, depth, B, white_bg,
+                       is_relight, fixed_fresnel, out_maps, ex);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

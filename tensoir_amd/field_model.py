@@ -707,18 +707,26 @@ class TensorVMSplit(nn.Module):
         # once everything -- incl. the caller's shading stage when _defer_check -- has been queued.
         hints = self.__dict__.setdefault("_app_cap_hints", {})
         cap = hints.get((B, S)) if (not is_train and _brdf_jitter_dense is None) else None
-        weight, acc, depth, _tend, cnt = ops.march_primary(f, rays, jitter, S, self.march_t_stop)
+        words = viewdirs = None
         if cap is None:
+            weight, acc, depth, _tend, cnt = ops.march_primary(f, rays, jitter, S, self.march_t_stop)
             offsets = ops.exclusive_scan(cnt)
             A = int(offsets[-1].item())                  # the one host sync of the pass
             n_dev = total_dev = None
         else:
-            offsets, total_dev = ops.exclusive_scan_capped(cnt, cap)
+            # hinted (sync-free) route: ONE launch marches, emits the view-direction table, re-arms the counters of the
+            # later kernels of this pass and scans the record counts (its last workgroup)
+            words = self._step_words(dev)
+            weight, acc, depth, cnt, offsets, total_dev, viewdirs = ops.march_primary_fused(f, rays, S, self.march_t_stop,
+                                                                                            cap, words)
+            self.__dict__["_rec_counter_armed"] = words[1:3]
             A, n_dev = cap, offsets[B:]
         rec_ray, rec_k, rec_w, rec_xyz = ops.compact_primary(f, rays, jitter, weight, offsets, A)
         rgb = brdf = brdf_j = pred = derived = None
+        rng_state = None
         if A > 0:
-            viewdirs = rays[:, 3:6].contiguous()
+            if viewdirs is None:
+                viewdirs = rays[:, 3:6].contiguous()
             rad, intr = ops.vm_app(f, rec_xyz, lidx, rec_ray, True, bool(is_relight), None, 0, n_dev)
             rgb = ops.mlp(self.renderModule.packed(), rad, viewdirs, rec_ray, None, 0, n_dev)
             if is_relight:
@@ -726,10 +734,13 @@ class TensorVMSplit(nn.Module):
                 brdf = ops.mlp(pb, intr, rec_xyz, None, None, 0, n_dev)
                 if _brdf_jitter_dense is not None:
                     noise = _brdf_jitter_dense.to(dev, torch.float32)[rec_ray.long(), rec_k.long()]
+                    xyz_j = torch.add(rec_xyz, noise, alpha=0.01)
+                    intr_j = ops.vm_app(f, xyz_j, None, None, False, True, None, 0, n_dev)[1]
                 else:
-                    noise = torch.randn((A, 3), device=dev, dtype=torch.float32)
-                xyz_j = torch.add(rec_xyz, noise, alpha=0.01)
-                intr_j = ops.vm_app(f, xyz_j, None, None, False, True, None, 0, n_dev)[1]
+                    # xyz + randn_like(xyz) * 0.01 (:937): the N(0,1) triples are drawn inside the gather kernel (Philox keyed
+                    # by the framework's CUDA seed, device-side offset advanced once per pass by the compositing kernel)
+                    rng_state = self._jitter_rng(dev)
+                    xyz_j, intr_j = ops.vm_app_jitter(f, rec_xyz, 0.01, 0, 0, rng_state, n_dev)
                 brdf_j = ops.mlp(pb, intr_j, xyz_j, None, None, 0, n_dev)
                 if self.normals_kind == "purely_derived":
                     pred = ops.density_grad(f, rec_xyz, n_dev=n_dev)[2]
@@ -738,8 +749,15 @@ class TensorVMSplit(nn.Module):
                     if self.normals_kind == "derived_plus_predicted":
                         derived = ops.density_grad(f, rec_xyz, n_dev=n_dev)[2]
         bg = bool(white_bg or (is_train and torch.rand((1,)) < 0.5))
-        maps = ops.composite_primary(rays, offsets, rec_w, rgb, brdf, brdf_j, pred, derived, acc, depth,
-                                     bg, is_relight, self.fixed_fresnel)
+        smooth = None
+        if words is not None:
+            maps, smooth = ops.composite_primary_fused(rays, offsets, rec_w, rgb, brdf, brdf_j, pred, derived, acc, depth,
+                                                       bg, is_relight, self.fixed_fresnel, words, rng_state, 1)
+        else:
+            maps = ops.composite_primary(rays, offsets, rec_w, rgb, brdf, brdf_j, pred, derived, acc, depth,
+                                         bg, is_relight, self.fixed_fresnel)
+            if rng_state is not None:
+                rng_state[1] += 1
         if self.normals_kind != "derived_plus_predicted" and is_relight:
             maps[:, 16] = 0.0        # the orientation loss is only filled in the derived_plus_predicted branch (:953-960)
 
@@ -763,8 +781,30 @@ class TensorVMSplit(nn.Module):
         elif not finish():
             return self.forward(rays_chunk, light_idx, white_bg, is_train, ndc_ray, is_relight, N_samples,
                                 _brdf_jitter_dense, _return_maps, False, _want_mask)
-        out = self.unpack_maps(maps, is_relight, want_mask=_want_mask)
+        out = self.unpack_maps(maps, is_relight, want_mask=_want_mask, smooth=smooth)
         return (out, maps) if _return_maps else out
+
+    def _step_words(self, dev):
+        """Persistent int32[8] of device-side counters shared by the kernels of one pass: [0] active (point, direction)
+        pairs, [1:3] secondary record counter {total, written prefix}, [3] / [4] last-workgroup tickets of the primary
+        march / the compositing kernel, [5] primary record total.  Zero at creation; every word is re-armed on the device
+        by the pass itself."""
+        w = self.__dict__.get("_words")
+        if w is None or w.device != torch.device(dev):
+            w = self.__dict__["_words"] = torch.zeros((8,), dtype=torch.int32, device=dev)
+            self.__dict__["_pair_counter"] = w[0:1]
+        return w
+
+    def _jitter_rng(self, dev):
+        """Device-side {seed, offset} of the BRDF-jitter noise; re-keyed when the framework's CUDA seed changes."""
+        seed = int(torch.cuda.initial_seed())
+        st = self.__dict__.get("_jit_rng")
+        if st is None or st[0] != seed or st[1].device != torch.device(dev):
+            if self.__dict__.get("_capture") is not None:
+                raise TensoirHipError("the jitter RNG state must exist before a graph capture (run one eager call first)")
+            t = torch.tensor([seed & (2 ** 63 - 1), 0], dtype=torch.int64).to(dev)
+            st = self.__dict__["_jit_rng"] = (seed, t)
+        return st[1]
 
     def _finish_primary(self):
         """Deferred overflow check of the last forward(..., _defer_check=True); True = results are valid."""
@@ -772,12 +812,13 @@ class TensorVMSplit(nn.Module):
         return True if fin is None else fin()
 
     @staticmethod
-    def unpack_maps(maps, is_relight=True, want_mask=True):
+    def unpack_maps(maps, is_relight=True, want_mask=True, smooth=None):
         """[B,20] map rows -> the reference's 12-tuple (:1033-1036 / :983-986).  want_mask=False leaves acc_mask out
         (None): Renderer_TensoIR_train shades from the map rows and never looks at it -- one launch less per step."""
         if not is_relight:
             return (maps[:, 0:3], maps[:, 3], None, None, None, None, maps[:, 14], None, None, None, None, None)
         acc = maps[:, 14]
-        smooth = torch.mean(maps[:, 17:19], dim=0)        # both smoothness losses in one reduction launch
+        if smooth is None:
+            smooth = torch.mean(maps[:, 17:19], dim=0)    # both smoothness losses in one reduction launch
         return (maps[:, 0:3], maps[:, 3], maps[:, 4:7], maps[:, 7:10], maps[:, 10:11], maps[:, 11:14], acc,
                 maps[:, 15:16], maps[:, 16:17], (acc > 0.5) if want_mask else None, smooth[0], smooth[1])

@@ -305,6 +305,53 @@ def march_primary(field: TirField, rays, ray_jitter, n_samples, t_stop):
     return weight, acc, depth, tend, cnt
 
 
+def march_primary_fused(field: TirField, rays, n_samples, t_stop, cap, words):
+    """Inference-only primary march that also emits the view-direction table, re-arms the pass counters and scans the
+    record counts (tir_march_primary_fused_fwd).  words: persistent int32[8] of the model -- [1:3] secondary record
+    counter (zeroed here), [3] scan ticket, [5] record total.  Returns weight, acc, depth, cnt, offsets, total, viewdirs."""
+    rays = f32(rays, "rays", 6)
+    B = rays.shape[0]
+    dev = rays.device
+    weight = torch.empty((B, n_samples), dtype=torch.float32, device=dev)
+    acc = torch.empty((B,), dtype=torch.float32, device=dev)
+    depth = torch.empty((B,), dtype=torch.float32, device=dev)
+    cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+    off = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+    vd = torch.empty((B, 3), dtype=torch.float32, device=dev)
+    total = words[5:6]
+    _call("tir_march_primary_fused_fwd", C.byref(field), _ptr(rays), None, B, n_samples, float(t_stop), _ptr(weight),
+          _ptr(acc), _ptr(depth), None, _ptr(cnt), _stats_ptr("tir_march_primary_fwd", dev), _ptr(vd),
+          C.c_void_p(words.data_ptr() + 4), 2, C.c_void_p(words.data_ptr() + 12), _ptr(off), int(cap), _ptr(total), _stream())
+    return weight, acc, depth, cnt, off, total, vd
+
+
+def composite_primary_fused(rays, offsets, rec_w, rgb, brdf, brdf_jit, pred_n, der_n, acc, depth, white_bg, is_relight,
+                            fixed_fresnel, words, rng_state=None, rng_step=0):
+    """tir_composite_primary_fused: map rows + the two smoothness means (float32[2]); words[4] is the ticket."""
+    rays = f32(rays, "rays", 6)
+    B = rays.shape[0]
+    out = torch.empty((B, MAP_STRIDE), dtype=torch.float32, device=rays.device)
+    smooth = torch.zeros((2,), dtype=torch.float32, device=rays.device) if B == 0 else \
+        torch.empty((2,), dtype=torch.float32, device=rays.device)
+    _call("tir_composite_primary_fused", _ptr(rays), _ptr(offsets), _ptr(rec_w), _ptr(rgb), _ptr(brdf), _ptr(brdf_jit),
+          _ptr(pred_n), _ptr(der_n), _ptr(acc), _ptr(depth), B, int(bool(white_bg)), int(bool(is_relight)),
+          float(fixed_fresnel), _ptr(out), C.c_void_p(words.data_ptr() + 16), _ptr(smooth), _ptr(rng_state), int(rng_step),
+          _stream())
+    return out, smooth
+
+
+def vm_app_jitter(field: TirField, xyz, scale, seed, offset, rng_state=None, n_dev=None):
+    """Intrinsic features of xyz + scale * N(0,1), noise drawn in the kernel (tir_vm_app_jitter_fwd).
+    Returns (xyz_jittered [n,3], int_feat [n, FEAT_STRIDE])."""
+    xyz = f32(xyz, "xyz", 3).view(-1, 3)
+    n = xyz.shape[0]
+    xyz_j = torch.empty_like(xyz)
+    intr = torch.empty((n, FEAT_STRIDE), dtype=torch.float32, device=xyz.device)
+    _call("tir_vm_app_jitter_fwd", C.byref(field), _ptr(xyz), n, _ptr(n_dev), float(scale), int(seed) & (2 ** 64 - 1),
+          int(offset) & (2 ** 64 - 1), _ptr(rng_state), _ptr(xyz_j), _ptr(intr), FEAT_STRIDE, _stream())
+    return xyz_j, intr
+
+
 def exclusive_scan(counts):
     counts = i32(counts, "counts").view(-1)
     n = counts.numel()
@@ -355,7 +402,7 @@ def composite_primary(rays, offsets, rec_w, rgb, brdf, brdf_jit, pred_n, der_n, 
 # ---- secondary march ------------------------------------------------------------------------------
 def march_secondary(field: TirField, origins, dirs, z_vals, n_rays, org_map=None, dir_map=None,
                     active=None, t_stop=0.0, want_records=False, rec_cap=0, want_nerfactor=True, n_dirs=0,
-                    ray_ids=None, n_ids_dev=None, vis=None, rec_cnt=None):
+                    ray_ids=None, n_ids_dev=None, vis=None, rec_cnt=None, counter=None):
     """ray_ids / n_ids_dev: march only the listed pair ids (tir_march_secondary_ids_fwd); vis / rec_cnt: pre-filled
     per-pair buffers (shade_setup_compact wrote the masked pairs' zeros into them)."""
     origins = f32(origins, "origins", 3)
@@ -373,7 +420,8 @@ def march_secondary(field: TirField, origins, dirs, z_vals, n_rays, org_map=None
     rec = None
     if want_records:
         rec = {
-            "counter": torch.zeros((2,), dtype=torch.int32, device=dev),      # [total, written prefix]
+            # [total, written prefix]; `counter`: a caller-owned pair that is already zero on the device
+            "counter": counter if counter is not None else torch.zeros((2,), dtype=torch.int32, device=dev),
             "ray": torch.empty((rec_cap,), dtype=torch.int32, device=dev),
             "w": torch.empty((rec_cap,), dtype=torch.float32, device=dev),
             "xyz": torch.empty((rec_cap, 3), dtype=torch.float32, device=dev),

@@ -63,9 +63,14 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
         raise ops._lib.TensoirHipError("graph capture needs a warmed-up secondary record-capacity hint")
     if first:
         cap = _rec_capacity(n_rays)
+    # a record counter the primary march of this pass has already zeroed on the device (no fill launch); first attempt only
+    armed = tensoIR.__dict__.pop("_rec_counter_armed", None)
     while True:
         extra = {} if ids is None else dict(ray_ids=ids["pair_ids"], n_ids_dev=ids["n_active"], vis=ids["vis"],
                                             rec_cnt=ids["rec_cnt"])
+        if armed is not None and armed.device == dev:
+            extra["counter"] = armed
+        armed = None
         vis, oma, rec = ops.march_secondary(f, origins, dirs, z, n_rays, org_map, dir_map, active,
                                             tensoIR.march_t_stop, True, cap, want_nerfactor, n_dirs, **extra)
         n_total, n_dev = rec["counter"][0:1], rec["counter"][1:2]      # all records / the written prefix consumers may read

@@ -614,3 +614,83 @@ def test_graphed_chunk_renderer_matches_eager_image(env):
     caps = fn.gr.captures
     tdist.render_sharded(fn, img_rays, img_lidx, rank=0, world=1, chunk=n0)
     assert fn.gr.captures == caps
+
+
+# ---------------------------------------------------------------- fused step kernels (no framework launches inside a step)
+@torch.no_grad()
+def test_fused_primary_march_scan_viewdirs(full):
+    """tir_march_primary_fused_fwd == tir_march_primary_fwd + tir_exclusive_scan_capped + rays[:, 3:6], bit for bit, on
+    the BASELINE batch; repeated (the scan runs in whichever workgroup finishes last and reads the other workgroups'
+    counts across XCDs: a stale read would show up as a wrong offset), with and without a binding capacity."""
+    from tensoir_amd import ops
+    m, rays = full.model, full.rays
+    f = m.packed_field()
+    w0, acc0, dep0, _t, cnt0 = ops.march_primary(f, rays, None, 512, m.march_t_stop)
+    total = int(cnt0.sum())
+    words = m._step_words(rays.device)
+    for it in range(40):
+        cap = total + 1000 if it % 2 == 0 else total // 3
+        off_ref, tot_ref = ops.exclusive_scan_capped(cnt0, cap)
+        words[1:3].fill_(7)                                  # the fused march must re-arm these
+        w, acc, dep, cnt, off, tot, vd = ops.march_primary_fused(f, rays, 512, m.march_t_stop, cap, words)
+        assert torch.equal(cnt, cnt0) and torch.equal(off, off_ref), it
+        assert int(tot) == int(tot_ref) == total
+        assert int(words[1]) == 0 and int(words[2]) == 0 and int(words[3]) == 0      # counters zeroed, ticket re-armed
+        if it < 2:
+            assert torch.equal(w, w0) and torch.equal(acc, acc0) and torch.equal(dep, dep0)
+            assert torch.equal(vd, rays[:, 3:6])
+
+
+@torch.no_grad()
+def test_in_kernel_brdf_jitter_noise(env):
+    """tir_vm_app_jitter_fwd: xyz_out = xyz + 0.01 * N(0,1) with Philox noise drawn in the gather kernel
+    (models/tensorBase_rotated_lights.py:937); the returned features are the intrinsic features of exactly those points;
+    the noise is standard normal (moments, cross-coordinate independence), repeatable for a fixed state and fresh after
+    the state advances."""
+    from tensoir_amd import ops
+    m = env.model
+    f = m.packed_field()
+    n = 200_003
+    g = torch.Generator().manual_seed(3)
+    xyz = (torch.rand(n, 3, generator=g) * 1.6 - 0.8).cuda()
+    state = torch.tensor([1234567, 5], dtype=torch.int64, device="cuda")
+    xj, feat = ops.vm_app_jitter(f, xyz, 0.01, 0, 0, state)
+    xj2, feat2 = ops.vm_app_jitter(f, xyz, 0.01, 0, 0, state)
+    assert torch.equal(xj, xj2) and torch.equal(feat, feat2)
+    ref = ops.vm_app(f, xj, None, None, False, True)[1]
+    assert torch.equal(feat, ref)                                            # same gather, same points
+    z = ((xj - xyz) / 0.01).double().cpu()
+    assert float(z.mean().abs()) < 0.01 and abs(float(z.var()) - 1.0) < 0.01
+    assert abs(float((z ** 4).mean()) - 3.0) < 0.08 and abs(float((z ** 3).mean())) < 0.03       # kurtosis, skewness
+    c = torch.corrcoef(z.T)
+    assert float((c - torch.eye(3, dtype=torch.float64)).abs().max()) < 0.01
+    assert abs(float((z[1:, 0] * z[:-1, 0]).mean())) < 0.01                  # neighbouring points are uncorrelated
+    assert float(z.abs().max()) < 6.5
+    state[1] += 1                                                            # what the compositing kernel does per pass
+    xj3, _ = ops.vm_app_jitter(f, xyz, 0.01, 0, 0, state)
+    z3 = ((xj3 - xyz) / 0.01).double().cpu()
+    assert abs(float((z3[:, 0] * z[:, 0]).mean())) < 0.01                    # fresh, independent noise
+    by_value = ops.vm_app_jitter(f, xyz, 0.01, 1234567, 5, None)[0]          # by-value state == device-side state
+    assert torch.equal(by_value, xj)
+
+
+@torch.no_grad()
+def test_boundary_call_launch_budget_and_smoothness(full):
+    """The hinted inference route: the smoothness losses come out of the compositing kernel (== the column means of the
+    map rows), the jitter state advances once per pass (two calls -> different smoothness noise, same geometry maps)."""
+    from tensoir_amd import Renderer_TensoIR_train
+    m = full.model
+    kw = dict(N_samples=512, args=full.args, device="cuda")
+    Renderer_TensoIR_train(full.rays, None, full.lidx, m, **kw)             # learns the capacity hints
+    out, maps = m(full.rays, full.lidx, N_samples=512, _return_maps=True)
+    want = maps[:, 17:19].double().mean(dim=0)
+    assert abs(float(out[10]) - float(want[0])) <= 1e-6 * abs(float(want[0])) + 1e-12
+    assert abs(float(out[11]) - float(want[1])) <= 1e-6 * abs(float(want[1])) + 1e-12
+    off0 = int(m._jit_rng[1][1])
+    a = Renderer_TensoIR_train(full.rays, None, full.lidx, m, **kw)
+    b = Renderer_TensoIR_train(full.rays, None, full.lidx, m, **kw)
+    assert int(m._jit_rng[1][1]) == off0 + 2
+    for k in ("rgb_map", "depth_map", "normal_map", "albedo_map", "acc_map", "rgb_with_brdf_map"):
+        assert torch.equal(a[k], b[k]), k
+    assert float(a["albedo_smoothness_loss"]) != float(b["albedo_smoothness_loss"])
+    assert abs(float(a["albedo_smoothness_loss"]) / float(b["albedo_smoothness_loss"]) - 1) < 0.2
