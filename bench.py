@@ -62,6 +62,11 @@ def parse():
     ap.add_argument("--breakdown", type=str, default="", help="write the per-kernel table to this file")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying the HIP graph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--workload", default="batch", choices=["batch", "image"],
+                    help="batch = the headline 4096-ray step (weak scaling); image = one 800x800 image of BASELINE configs[3] "
+                         "(3 light rotations, 1036 samples per ray) sharded over the ranks, one all-gather per image (strong scaling)")
+    ap.add_argument("--tile", type=int, default=0, help="image workload: 0 = contiguous row tiles, >0 = interleaved tiles of that many rays")
+    ap.add_argument("--image-side", type=int, default=800)
     ap.add_argument("--force-dist", action="store_true",
                     help="single process: create a 1-rank RCCL group anyway and run the multi-rank code path (all-gather per step)")
     return ap.parse_args()
@@ -130,8 +135,101 @@ def kernel_table(timing, stats, steps, shapes):
     return rows
 
 
+def bench_image(a):
+    """BASELINE configs[3]: an 800x800 image (640 000 rays in chunks of 4096, light index = pixel mod 3) rendered
+    data-parallel -- every rank its shard of the rays (row tiles or interleaved tiles), ONE all-gather of the 96-B per-ray
+    records per image (renderer.py:225-249 is the reference's sequential chunk loop).  A step = one image; strong scaling."""
+    import contextlib
+    import io
+    import torch.distributed as dist
+    import tensoir_amd
+    from tensoir_amd import _lib, synth
+    from tensoir_amd import dist as tdist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: tensoir_amd has no CPU path")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    assert _lib.lib().tir_device_check() == 0
+    use_dist = world > 1 or a.force_dist
+    ck = synth.make_checkpoint(grid=(a.grid,) * 3, seed=20211202, light_rotation=("000", "120", "240"))
+    model = tensoir_amd.model_from_checkpoint(ck, device, envmap_h=a.env_h, envmap_w=a.env_w)
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        model.updateAlphaMask((128, 128, 128))
+    args = types.SimpleNamespace(second_nSample=a.second_samples, second_near=0.05, second_far=1.5)
+    side = a.image_side
+    rays = synth.make_rays(side, side, narrow=1.0).to(device)
+    n = rays.shape[0]
+    lidx = (torch.arange(n, device=device) % 3).to(torch.int32).view(-1, 1)
+    fn = tdist.GraphedChunkRenderer(model, a.rays, args, device=device)
+    with torch.no_grad():          # capture + capacity learning on this rank's own shard, BEFORE any RCCL thread exists
+        tdist.render_sharded(fn, rays, lidx, rank=rank, world=world, chunk=a.rays, tile=a.tile, group=None) \
+            if world == 1 else [fn(rays[c], lidx[c]) for c in torch.split(tdist.shard_rows(n, rank, world, a.tile).to(device), a.rays)
+                                if c.numel() == a.rays]
+        fn.validate()
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(a.backend, **({"device_id": device} if a.backend == "nccl" else {}))
+    gw = world if use_dist else 1
+
+    def one():
+        with torch.no_grad():
+            return tdist.render_sharded_timed(fn, rays, lidx, rank=rank, world=gw, chunk=a.rays, tile=a.tile)
+    t_end = time.perf_counter() + 0.6
+    while time.perf_counter() < t_end:
+        one()
+    for _ in range(a.warmup):
+        one()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loc, exch = [], []
+    for _ in range(a.steps):
+        img, tl, te = one()
+        loc.append(tl)
+        exch.append(te)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [sum(loc) / len(loc)]
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        pr = torch.zeros((gw,), dtype=torch.float64, device=device)
+        pr[rank] = per_rank[0]
+        dist.all_reduce(pr)
+        per_rank = pr.tolist()
+    if rank == 0:
+        hit = float((img["acc_map"] > 0.5).float().mean())
+        print(json.dumps({
+            "metric": "full-image primary+secondary rays/sec, one 800x800 image sharded over the GPUs", "value": round(n * a.steps / elapsed, 1),
+            "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C4: {side}x{side} image = {n} rays in chunks of {a.rays}, VM grid {a.grid}^3, 3 light rotations "
+                                   f"(light index = pixel mod 3), N_samples=-1 ({model.nSamples} per ray), secondary {a.env_h * a.env_w} dirs x "
+                                   f"{a.second_samples}; full field of view ({hit:.2f} of the rays hit the object)",
+                       "sharding": ("contiguous row tiles" if a.tile <= 0 else f"interleaved tiles of {a.tile} rays") +
+                                   f", one all_gather_into_tensor of {tdist.RECORD * 4} B/ray records per image",
+                       "launch": "hip-graph replay per chunk, one capacity check per image"},
+            "world_size": gw, "device_count": torch.cuda.device_count(), "backend": a.backend if use_dist else None,
+            "per_rank_render_ms": [round(1e3 * x, 3) for x in per_rank],
+            "load_imbalance": round(max(per_rank) / max(min(per_rank), 1e-9), 3),
+            "exchange_ms": round(1e3 * sum(exch) / len(exch), 3),
+            "roofline": None, "cpu_baseline": None,
+        }), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.workload == "image":
+        return bench_image(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

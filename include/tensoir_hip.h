@@ -359,6 +359,24 @@ int tir_relight_importance(const float* normal, const float* albedo, const float
                            const float* light_rgb, const float* light_pdf, const float* vis,
                            int32_t M, int32_t Ns, float* out_rgb, void* stream);
 
+/* ---- K9 on the device (models/relight_utils.py:150-205, scripts/relight_importance.py:119-171).
+ * tir_env_sample_setup: Environment_Light.sample_light + the cosine mask.  For every (point m, sample s) one cell of the
+ *   H x W map is drawn from pdf_sample ~ (R+G+B) sin(theta) by inverse-CDF search -- row_cdf [H] = inclusive prefix sum of
+ *   the row marginals (last = 1), col_cdf [H][W] = inclusive prefix sums of every row normalised to 1 -- with Philox
+ *   uniforms keyed by (seed, offset), counter = m*Ns + s (the reference: torch.multinomial on the same pdf).
+ *   cell [M][Ns] = flat cell index; active [M][Ns] = (env_dir[cell] . normal[m] > 1e-6) (:125-127).
+ * tir_relight_importance_cells: tir_relight_importance with light_dir / rgb / pdf looked up by cell in the map's tables
+ *   env_dir [H*W][3], env_rgb [H*W][3], env_pdf [H*W] (= hdr_pdf_return).
+ * tir_env_lookup: Environment_Light.get_light, bilinear background lookup (align_corners=True) at n directions. */
+int tir_env_sample_setup(const float* row_cdf, const float* col_cdf, int32_t H, int32_t W, const float* env_dir,
+                         const float* normal, int32_t M, int32_t Ns, uint64_t seed, uint64_t offset,
+                         int32_t* cell, uint8_t* active, void* stream);
+int tir_relight_importance_cells(const float* normal, const float* albedo, const float* rough,
+                                 const float* fresnel, const float* rays_d, const int32_t* cell,
+                                 const float* env_dir, const float* env_rgb, const float* env_pdf,
+                                 const float* vis, int32_t M, int32_t Ns, float* out_rgb, void* stream);
+int tir_env_lookup(const float* env_rgb, int32_t H, int32_t W, const float* dirs, int64_t n, float* out, void* stream);
+
 /* GGX_specular alone (models/relight_utils.py:17-50): normal/v [M][3], l [M][D][3],
  * rough/fresnel [M][3] -> spec [M][D][3]. */
 int tir_ggx_specular(const float* normal, const float* v, const float* l, const float* rough,

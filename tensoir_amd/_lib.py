@@ -94,6 +94,9 @@ SIGNATURES = {
     "tir_march_secondary_ids_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I64, I32, I32, P, F32, P, P,
                                               P, I64, P, P, P, P, P, P, P, P, P]),
     "tir_relight_importance": (C.c_int, [P, P, P, P, P, P, P, P, P, I32, I32, P, P]),
+    "tir_env_sample_setup": (C.c_int, [P, P, I32, I32, P, P, I32, I32, C.c_uint64, C.c_uint64, P, P, P]),
+    "tir_relight_importance_cells": (C.c_int, [P, P, P, P, P, P, P, P, P, P, I32, I32, P, P]),
+    "tir_env_lookup": (C.c_int, [P, I32, I32, P, I64, P, P]),
     "tir_ggx_specular": (C.c_int, [P, P, P, P, P, I32, I32, P, P]),
     # ---- training (backward) entry points ----
     "tir_march_primary_train_fwd": (C.c_int, [C.POINTER(TirField), P, P, I32, I32, F32, P, P, P, P, P, P, P]),

@@ -447,27 +447,7 @@ struct TirJitter {
     float* xyz_out;                    // [n,3] jittered points (the decoder's aux input)
 };
 
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
-}
-
-// three independent N(0,1) values for point `idx` (Box-Muller on the four Philox words)
-__device__ __forceinline__ void jitter_normals(unsigned long long seed, unsigned long long offset, uint64_t idx, float (&nrm)[3]) {
-    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
-    const float u0 = ((float)c[0] + 0.5f) * 2.3283064365386963e-10f, u1 = ((float)c[1] + 0.5f) * 2.3283064365386963e-10f;
-    const float u2 = ((float)c[2] + 0.5f) * 2.3283064365386963e-10f, u3 = ((float)c[3] + 0.5f) * 2.3283064365386963e-10f;
-    const float r0 = sqrtf(-2.0f * logf(fminf(u0, 0.99999994f))), r1 = sqrtf(-2.0f * logf(fminf(u2, 0.99999994f)));
-    float s0, c0, s1, c1;
-    sincospif(2.0f * u1, &s0, &c0);
-    sincospif(2.0f * u3, &s1, &c1);
-    nrm[0] = r0 * c0; nrm[1] = r0 * s0; nrm[2] = r1 * c1;
-    (void)s1;
-}   // padded sample stride of the X tile (bank spread for the quad-strided writes)
+   // padded sample stride of the X tile (bank spread for the quad-strided writes)
 
 template <int C4, bool RAD, bool INTR, bool JIT = false>
 __global__ void __launch_bounds__(256)

@@ -257,6 +257,106 @@ k_relight_importance(const float* __restrict__ normal, const float* __restrict__
     }
 }
 
+// ---- K9 on the device: importance sampler, cell-indexed integration, background lookup ---------------------------
+// Environment_Light.sample_light (models/relight_utils.py:150-188) draws torch.multinomial over the H*W cells of
+// pdf ~ (R+G+B) sin(theta) -- an inverse-CDF search.  Same distribution here with a two-level CDF (row marginal, then the
+// row-conditional column CDF: short fp32 prefix sums instead of one over 2 M cells), one Philox draw per (point, sample),
+// fused with the cosine mask of scripts/relight_importance.py:125-127: the [M][Ns][3] direction / radiance / pdf tensors
+// of the reference (100 MB per chunk at 4096 x 512) are replaced by one int32 cell index per sample.
+__device__ __forceinline__ int cdf_upper_bound(const float* __restrict__ cdf, int n, float u) {
+    int lo = 0, hi = n - 1;                       // first index with cdf[i] > u (clamped to n-1)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cdf[mid] > u) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256)
+k_env_sample_setup(const float* __restrict__ row_cdf, const float* __restrict__ col_cdf, int H, int W,
+                   const float* __restrict__ env_dir, const float* __restrict__ normal, int M, int Ns,
+                   unsigned long long seed, unsigned long long offset, int32_t* __restrict__ cell,
+                   uint8_t* __restrict__ active) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)M * Ns) return;
+    const int m = (int)(i / Ns);
+    float u[4];
+    tir::philox_uniform4(seed, offset, (uint64_t)i, u);
+    const int row = cdf_upper_bound(row_cdf, H, u[0]);
+    const int col = cdf_upper_bound(col_cdf + (size_t)row * W, W, u[1]);
+    const int c = row * W + col;
+    cell[i] = c;
+    const float* d = env_dir + 3 * (size_t)c;
+    const float* nm = normal + 3 * (size_t)m;
+    const float cosine = d[0] * nm[0] + d[1] * nm[1] + d[2] * nm[2];          // einsum('ijk,ik->ij') (:125)
+    active[i] = cosine > 1e-6f ? 1 : 0;                                       // cosine_mask (:127)
+}
+
+__global__ void __launch_bounds__(256)
+k_relight_importance_cells(const float* __restrict__ normal, const float* __restrict__ albedo,
+                           const float* __restrict__ rough, const float* __restrict__ fresnel,
+                           const float* __restrict__ rays_d, const int32_t* __restrict__ cell,
+                           const float* __restrict__ env_dir, const float* __restrict__ env_rgb,
+                           const float* __restrict__ env_pdf, const float* __restrict__ vis, int M, int Ns,
+                           float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float view[3] = {-rays_d[3 * (size_t)m], -rays_d[3 * (size_t)m + 1], -rays_d[3 * (size_t)m + 2]};
+    normalize3(view[0], view[1], view[2], 1e-6f);
+    const float rough3[3] = {rough[m], rough[m], rough[m]};
+    const float* nm = normal + 3 * (size_t)m;
+    Surface s = make_surface(nm, view, rough3, fresnel + 3 * (size_t)m, albedo + 3 * (size_t)m);
+    float c[3] = {0.f, 0.f, 0.f};
+    for (int j = lane; j < Ns; j += 64) {
+        const size_t mj = (size_t)m * Ns + j;
+        const size_t ce = (size_t)cell[mj];
+        const float lx = env_dir[3 * ce], ly = env_dir[3 * ce + 1], lz = env_dir[3 * ce + 2];
+        const float cosine = lx * nm[0] + ly * nm[1] + lz * nm[2];
+        float spec[3];
+        ggx_dir(s, lx, ly, lz, spec);
+        const float v = vis[mj], pdf = env_pdf[ce];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            c[q] += (s.alb_pi[q] + spec[q]) * (v * env_rgb[3 * ce + q]) * cosine / pdf;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        float t = group_sum<64>(c[q]) / (float)Ns;
+        t = linear2srgb(fminf(fmaxf(t, 0.f), 1.f));
+        if (lane == 0) out[3 * (size_t)m + q] = t;
+    }
+}
+
+// Environment_Light.get_light (models/relight_utils.py:191-205): bilinear lookup of the map at a direction,
+// F.grid_sample(align_corners=True, zero padding) of qx = -theta / pi, qy = 2 (acos(z) - 1e-6) / pi - 1
+__global__ void __launch_bounds__(256)
+k_env_lookup(const float* __restrict__ env_rgb, int H, int W, const float* __restrict__ dirs, int64_t n,
+             float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float dx = dirs[3 * i], dy = dirs[3 * i + 1], dz = dirs[3 * i + 2];
+    const float phi = acosf(dz) - 1e-6f;
+    const float theta = atan2f(dy, dx);
+    const float qy = (phi / 3.14159265358979323846f) * 2.0f - 1.0f;
+    const float qx = -theta / 3.14159265358979323846f;
+    const float ix = ((qx + 1.0f) * 0.5f) * (float)(W - 1), iy = ((qy + 1.0f) * 0.5f) * (float)(H - 1);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float tx = ix - fx, ty = iy - fy;
+    float c[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+        const float w = ((t & 1) ? tx : 1.0f - tx) * ((t >> 1) ? ty : 1.0f - ty);
+        if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
+            const float* p = env_rgb + 3 * ((size_t)yy * W + xx);
+            c[0] = fmaf(w, p[0], c[0]); c[1] = fmaf(w, p[1], c[1]); c[2] = fmaf(w, p[2], c[2]);
+        }
+    }
+    out[3 * i] = c[0]; out[3 * i + 1] = c[1]; out[3 * i + 2] = c[2];
+}
+
 __global__ void __launch_bounds__(256)
 k_ggx(const float* __restrict__ normal, const float* __restrict__ v, const float* __restrict__ l,
       const float* __restrict__ rough, const float* __restrict__ fresnel, int M, int D, float* __restrict__ spec) {
@@ -354,6 +454,44 @@ extern "C" int tir_relight_importance(const float* normal, const float* albedo, 
         return TIR_ERR_ARG;
     hipLaunchKernelGGL(k_relight_importance, dim3((M + 3) / 4), dim3(256), 0, tir_stream(stream), normal, albedo,
                        rough, fresnel, rays_d, light_dir, light_rgb, light_pdf, vis, M, Ns, out_rgb);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_env_sample_setup(const float* row_cdf, const float* col_cdf, int32_t H, int32_t W, const float* env_dir,
+                                    const float* normal, int32_t M, int32_t Ns, uint64_t seed, uint64_t offset,
+                                    int32_t* cell, uint8_t* active, void* stream) {
+    if (M < 0 || Ns <= 0 || H <= 0 || W <= 0) return TIR_ERR_ARG;
+    if (M == 0) return TIR_OK;
+    if (!row_cdf || !col_cdf || !env_dir || !normal || !cell || !active) return TIR_ERR_ARG;
+    const int64_t n = (int64_t)M * Ns;
+    hipLaunchKernelGGL(k_env_sample_setup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tir_stream(stream), row_cdf,
+                       col_cdf, H, W, env_dir, normal, M, Ns, (unsigned long long)seed, (unsigned long long)offset, cell, active);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_relight_importance_cells(const float* normal, const float* albedo, const float* rough,
+                                            const float* fresnel, const float* rays_d, const int32_t* cell,
+                                            const float* env_dir, const float* env_rgb, const float* env_pdf,
+                                            const float* vis, int32_t M, int32_t Ns, float* out_rgb, void* stream) {
+    if (M < 0 || Ns <= 0) return TIR_ERR_ARG;
+    if (M == 0) return TIR_OK;
+    if (!normal || !albedo || !rough || !fresnel || !rays_d || !cell || !env_dir || !env_rgb || !env_pdf || !vis || !out_rgb)
+        return TIR_ERR_ARG;
+    hipLaunchKernelGGL(k_relight_importance_cells, dim3((M + 3) / 4), dim3(256), 0, tir_stream(stream), normal, albedo,
+                       rough, fresnel, rays_d, cell, env_dir, env_rgb, env_pdf, vis, M, Ns, out_rgb);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_env_lookup(const float* env_rgb, int32_t H, int32_t W, const float* dirs, int64_t n, float* out,
+                              void* stream) {
+    if (n < 0 || H <= 0 || W <= 0) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    if (!env_rgb || !dirs || !out) return TIR_ERR_ARG;
+    hipLaunchKernelGGL(k_env_lookup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tir_stream(stream), env_rgb, H, W,
+                       dirs, n, out);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

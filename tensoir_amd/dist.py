@@ -106,6 +106,39 @@ def render_sharded(render_fn, rays, light_idx, rank=None, world=None, chunk=4096
     return unpack_records(gather_records(local, n, rank, world, tile, group))
 
 
+def render_sharded_timed(render_fn, rays, light_idx, rank=None, world=None, chunk=4096, tile=0, group=None):
+    """render_sharded with the two phases timed on the host (device drained at the phase boundaries when the rays live
+    on a GPU): returns (image dict, local_render_s, exchange_s).  Used by ``bench.py --workload image``."""
+    import time
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    on_gpu = rays.is_cuda
+
+    def drain():
+        if on_gpu:
+            torch.cuda.synchronize(rays.device)
+    n = rays.shape[0]
+    mine = shard_rows(n, rank, world, tile).to(rays.device)
+    drain()
+    t0 = time.perf_counter()
+    for attempt in range(4):
+        parts = [pack_records(render_fn(rays[c], light_idx[c])) for c in torch.split(mine, chunk) if c.numel()]
+        validate = getattr(render_fn, "validate", None)
+        if validate is None or validate():
+            break
+    else:
+        raise RuntimeError("render_sharded_timed: the renderer's record capacity kept overflowing")
+    local = torch.cat(parts, dim=0) if parts else torch.zeros((0, RECORD), dtype=torch.float32, device=rays.device)
+    drain()
+    t1 = time.perf_counter()
+    img = unpack_records(gather_records(local, n, rank, world, tile, group))
+    drain()
+    t2 = time.perf_counter()
+    return img, t1 - t0, t2 - t1
+
+
 class GraphedChunkRenderer:
     """render_fn for render_sharded: full chunks replay ONE captured HIP graph with no host wait per chunk (inputs go
     into the graph's static buffers, outputs are packed straight from them, the record-capacity check of all replays

@@ -544,6 +544,44 @@ def relight_importance(normal, albedo, rough, fresnel, rays_d, light_dir, light_
     return out
 
 
+def env_sample_setup(row_cdf, col_cdf, env_dir, normal, n_samples, seed, offset):
+    """Importance samples of an H x W environment map for every surface point + the cosine mask
+    (tir_env_sample_setup).  Returns cell [M, Ns] int32, active [M, Ns] uint8."""
+    H, W = col_cdf.shape
+    normal = f32(normal, "normal", 3)
+    M = normal.shape[0]
+    cell = torch.empty((M, n_samples), dtype=torch.int32, device=normal.device)
+    active = torch.empty((M, n_samples), dtype=torch.uint8, device=normal.device)
+    _call("tir_env_sample_setup", _ptr(f32(row_cdf, "row_cdf")), _ptr(f32(col_cdf, "col_cdf")), H, W,
+          _ptr(f32(env_dir, "env_dir", 3)), _ptr(normal), M, int(n_samples), int(seed) & (2 ** 64 - 1),
+          int(offset) & (2 ** 64 - 1), _ptr(cell), _ptr(active), _stream())
+    return cell, active
+
+
+def relight_importance_cells(normal, albedo, rough, fresnel, rays_d, cell, env_dir, env_rgb, env_pdf, vis):
+    normal, albedo = f32(normal, "normal", 3), f32(albedo, "albedo", 3)
+    rough = f32(rough, "roughness").view(-1)
+    fresnel, rays_d = f32(fresnel, "fresnel", 3), f32(rays_d, "rays_d", 3)
+    cell = i32(cell, "cell")
+    M, Ns = cell.shape
+    vis = f32(vis, "vis").view(M, Ns)
+    out = torch.empty((M, 3), dtype=torch.float32, device=normal.device)
+    _call("tir_relight_importance_cells", _ptr(normal), _ptr(albedo), _ptr(rough), _ptr(fresnel), _ptr(rays_d), _ptr(cell),
+          _ptr(f32(env_dir, "env_dir", 3)), _ptr(f32(env_rgb, "env_rgb", 3)), _ptr(f32(env_pdf, "env_pdf")), _ptr(vis),
+          M, Ns, _ptr(out), _stream())
+    return out
+
+
+def env_lookup(env_rgb, dirs):
+    """Bilinear lookup of an [H, W, 3] map at [n, 3] directions (tir_env_lookup)."""
+    env_rgb = f32(env_rgb, "env_rgb", 3)
+    H, W = env_rgb.shape[0], env_rgb.shape[1]
+    dirs = f32(dirs, "dirs", 3).view(-1, 3)
+    out = torch.empty_like(dirs)
+    _call("tir_env_lookup", _ptr(env_rgb), H, W, _ptr(dirs), dirs.shape[0], _ptr(out), _stream())
+    return out
+
+
 def ggx_specular(normal, v, l, rough, fresnel):
     normal, v = f32(normal, "normal", 3), f32(v, "pts2c", 3)
     l = f32(l, "pts2l", 3)

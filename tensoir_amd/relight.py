@@ -264,6 +264,8 @@ class Environment_Light:
 
     def __init__(self, hdr_path=None, device="cuda", hdr_maps=None):
         self.hdr_rgbs, self.hdr_pdf_sample, self.hdr_pdf_return, self.hdr_dir = {}, {}, {}, {}
+        self.hdr_row_cdf, self.hdr_col_cdf = {}, {}
+        self._draws = 0
         maps = dict(hdr_maps or {})
         if hdr_path is not None:
             import os
@@ -287,6 +289,16 @@ class Environment_Light:
             self.hdr_pdf_sample[name] = pdf.to(device)
             self.hdr_pdf_return[name] = pdf_ret.to(device)
             self.hdr_dir[name] = dirs.to(device)
+            # inverse-CDF tables of the device sampler (tir_env_sample_setup): row marginal + row-conditional columns,
+            # accumulated in fp64 so that the fp32 tables are the correctly rounded prefix sums
+            p2 = pdf.view(H, W).double()
+            rows = p2.sum(dim=1)
+            row_cdf = torch.cumsum(rows, 0) / rows.sum()
+            col_cdf = torch.cumsum(p2, 1) / rows.clamp(min=1e-300).unsqueeze(1)
+            row_cdf[-1] = 1.0
+            col_cdf[:, -1] = 1.0
+            self.hdr_row_cdf[name] = row_cdf.float().to(device).contiguous()
+            self.hdr_col_cdf[name] = col_cdf.float().to(device).contiguous()
 
     @torch.no_grad()
     def sample_light(self, light_name, bs, num_samples, sample_type="importance"):
@@ -301,14 +313,20 @@ class Environment_Light:
         p = self.hdr_pdf_return[light_name].view(-1)[idx].unsqueeze(-1)
         return d, rgb, p
 
+    @torch.no_grad()
+    def sample_cells(self, light_name, normal, num_samples):
+        """Device-side sample_light + cosine mask (tir_env_sample_setup): per surface point `num_samples` cells of the map
+        drawn from hdr_pdf_sample by inverse-CDF search with Philox uniforms keyed by the framework's CUDA seed.  Returns
+        (cell [M, Ns] int32, active [M, Ns] uint8): direction / radiance / pdf are hdr_dir / hdr_rgbs / hdr_pdf_return
+        at the cell -- the [M, Ns, 3] tensors of the reference are never materialised."""
+        self._draws += 1
+        return ops.env_sample_setup(self.hdr_row_cdf[light_name], self.hdr_col_cdf[light_name],
+                                    self.hdr_dir[light_name].view(-1, 3), normal, num_samples,
+                                    torch.cuda.initial_seed(), self._draws)
+
     def get_light(self, light_name, incident_dir):
-        """:191-205 (background lookup, bilinear, align_corners=True)."""
-        import torch.nn.functional as F
-        env = self.hdr_rgbs[light_name].permute(2, 0, 1).unsqueeze(0)
-        phi = torch.arccos(incident_dir[:, 2]).reshape(-1) - 1e-6
-        theta = torch.atan2(incident_dir[:, 1], incident_dir[:, 0]).reshape(-1)
-        grid = torch.stack((-theta / np.pi, (phi / np.pi) * 2 - 1)).permute(1, 0).unsqueeze(0).unsqueeze(0)
-        return F.grid_sample(env, grid, align_corners=True).squeeze().permute(1, 0).reshape(-1, 3)
+        """:191-205 (background lookup, bilinear, align_corners=True) -> tir_env_lookup."""
+        return ops.env_lookup(self.hdr_rgbs[light_name], incident_dir.reshape(-1, 3))
 
 
 def read_hdr(path):
@@ -343,3 +361,34 @@ def relight_with_envmap(tensoIR, surface_xyz, normal, albedo, roughness, fresnel
                                     tensoIR.march_t_stop, False, 0, False)
     return ops.relight_importance(normal, albedo, roughness, fresnel, rays_d, light_dir, light_rgb,
                                   light_pdf, vis.view(M, Ns))
+
+
+@torch.no_grad()
+def relight_importance_sampled(tensoIR, env, light_name, surface_xyz, normal, albedo, roughness, fresnel, rays_d,
+                               num_samples=512, nSample=96, vis_near=0.05, vis_far=1.5):
+    """The loop body of scripts/relight_importance.py:119-170 for one environment map, entirely on the device:
+    importance sampling + cosine mask (tir_env_sample_setup) -> visibility march of the unmasked (point, cell) pairs with
+    the map's direction table as `dirs` and the cell index as `dir_map` -> BRDF x radiance x cosine / pdf mean -> sRGB
+    (tir_relight_importance_cells).  Per sample 5 bytes of bookkeeping instead of the reference's 28 + masks."""
+    dev = surface_xyz.device
+    normal = normal.to(torch.float32).contiguous()
+    M = normal.shape[0]
+    if M == 0:
+        return torch.zeros((0, 3), dtype=torch.float32, device=dev)
+    cell, active = env.sample_cells(light_name, normal, num_samples)
+    key = ("orgmap", M, num_samples, str(dev))
+    org_map = _CONST_CACHE.get(key)
+    if org_map is None:
+        pair = torch.arange(M * num_samples, dtype=torch.int32, device=dev)
+        org_map = torch.div(pair, num_samples, rounding_mode="floor").to(torch.int32)
+        if len(_CONST_CACHE) > 64:
+            _CONST_CACHE.clear()
+        _CONST_CACHE[key] = org_map
+    z = _z_table(nSample, vis_near, vis_far, dev)
+    env_dir = env.hdr_dir[light_name].view(-1, 3)
+    vis, _, _ = ops.march_secondary(tensoIR.packed_field(), surface_xyz.to(torch.float32).contiguous(), env_dir, z,
+                                    M * num_samples, org_map, cell.view(-1), active.view(-1), tensoIR.march_t_stop, False, 0,
+                                    False)
+    return ops.relight_importance_cells(normal, albedo, roughness, fresnel, rays_d, cell, env_dir,
+                                        env.hdr_rgbs[light_name].view(-1, 3), env.hdr_pdf_return[light_name].view(-1),
+                                        vis.view(M, num_samples))

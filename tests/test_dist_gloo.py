@@ -55,6 +55,9 @@ def _worker(rank, world, port, tile, q):
         got = tdist.render_sharded(fake_render, rays, li, chunk=9, tile=tile)
         full = fake_render(rays, li)
         ok = all(torch.equal(got[k], full[k]) for k in got)
+        # the timed variant bench.py --workload image uses: same image, two non-negative phase times
+        got2, t_local, t_exch = tdist.render_sharded_timed(fake_render, rays, li, chunk=9, tile=tile)
+        ok = ok and all(torch.equal(got2[k], full[k]) for k in got2) and t_local >= 0 and t_exch >= 0
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()

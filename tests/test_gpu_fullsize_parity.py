@@ -206,3 +206,77 @@ def test_c5_hdr_2048x1024_importance_512_vs_oracle():
     # coordinate that comes out of acos / atan2 -- 1 ulp of the angle is 1e-4 pixel
     r = _record("C5", "background", bg.cpu()[::16], O.envlight_lookup(hdr, rays[:, 3:].cpu()[::16]))
     assert r["max_rel_pixel"] < 2e-4, r
+
+
+@torch.no_grad()
+def test_c5_device_sampler_distribution_and_integration():
+    """configs[4] with the importance sampler ON THE DEVICE (tir_env_sample_setup; reference: torch.multinomial,
+    models/relight_utils.py:150-188): (a) the drawn cells follow pdf_sample -- chi-square over 32 x 64 coarse blocks of the
+    2048x1024 map (mean of the per-block relative deviation at the Monte-Carlo floor, compared with torch.multinomial's own
+    on the same number of draws), sun-disc mass matched; (b) fed to both implementations, the relit colours of the fused
+    device path (cells -> visibility march -> tir_relight_importance_cells) equal the oracle's loop body
+    (scripts/relight_importance.py:119-170) on every 32nd point; (c) the cosine mask equals the reference's."""
+    from oracle import tensoir_oracle as O
+    from tensoir_amd import relight, synth
+    model, sc = _build(("000",))
+    gen = torch.Generator().manual_seed(71)
+    H, W = 1024, 2048
+    hdr = torch.exp(torch.randn(H // 8, W // 8, 3, generator=gen) * 1.5)
+    hdr = torch.nn.functional.interpolate(hdr.permute(2, 0, 1)[None], size=(H, W), mode="bilinear",
+                                          align_corners=False)[0].permute(1, 2, 0).contiguous()
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    sun = ((yy - 300) ** 2 + (xx - 700) ** 2) < 20 ** 2
+    hdr[sun] *= 100.0
+    env = relight.Environment_Light(hdr_maps={"syn": hdr}, device="cuda")
+    rays = synth.make_rays(64, 64).cuda()
+    lidx = torch.zeros(4096, 1, dtype=torch.int32, device="cuda")
+    out = model(rays, lidx, N_samples=512)
+    depth, normal, albedo, rough, fres, acc = out[1], out[2], out[3], out[4], out[5], out[6]
+    mask = acc > 0.5
+    surf = (rays[:, :3] + depth.unsqueeze(-1) * rays[:, 3:])[mask]
+    nrm = normal[mask].contiguous()
+    M, Ns = surf.shape[0], 512
+    torch.manual_seed(11)
+    cell, active = env.sample_cells("syn", nrm, Ns)
+    assert cell.shape == (M, Ns) and int(cell.min()) >= 0 and int(cell.max()) < H * W
+    # (a) distribution
+    pdf = env.hdr_pdf_sample["syn"].view(H, W).double().cpu()
+    n_draw = M * Ns
+    def block_counts(idx):
+        r, c = (idx // W) // 32, (idx % W) // 32
+        return torch.bincount((r * 64 + c).view(-1).cpu(), minlength=32 * 64).double()
+    expect = pdf.view(32, 32, 64, 32).sum(dim=(1, 3)).view(-1) * n_draw
+    got = block_counts(cell.long())
+    ref_idx = torch.multinomial(env.hdr_pdf_sample["syn"].view(-1), n_draw, replacement=True)
+    ref = block_counts(ref_idx)
+    big = expect > 200
+    chi_dev = float((((got - expect) ** 2 / expect)[big]).mean())
+    chi_ref = float((((ref - expect) ** 2 / expect)[big]).mean())
+    REPORT.setdefault("C5-device-sampler", {})["chi2_per_block"] = {"device": chi_dev, "torch_multinomial": chi_ref,
+                                                                    "blocks": int(big.sum()), "draws": n_draw}
+    assert chi_dev < 1.3 and abs(chi_dev - chi_ref) < 0.3, (chi_dev, chi_ref)         # chi-square / dof ~ 1 for exact sampling
+    sun_mass = float(pdf[sun].sum())
+    sun_hit = float(sun.view(-1)[cell.view(-1).cpu().long()].double().mean())
+    assert abs(sun_hit - sun_mass) < 4 * (sun_mass / n_draw) ** 0.5 + 1e-4, (sun_hit, sun_mass)
+    # different points get different samples; the stream is repeatable for a fixed (seed, draw counter)
+    assert int((cell[0] != cell[1]).sum()) > Ns // 2
+    env._draws -= 1
+    cell2, _ = env.sample_cells("syn", nrm, Ns)
+    assert torch.equal(cell, cell2)
+    # (c) cosine mask
+    ldir = env.hdr_dir["syn"].view(-1, 3)[cell.long()]
+    cos = torch.einsum("ijk,ik->ij", ldir, nrm)
+    flip = (cos - 1e-6).abs() < 1e-7
+    assert bool(((active.bool() == (cos > 1e-6)) | flip).all())
+    # (b) integration: device path vs oracle with the same samples
+    env._draws -= 1
+    got_rgb = relight.relight_importance_sampled(model, env, "syn", surf, nrm, albedo[mask], rough[mask], fres[mask],
+                                                 rays[:, 3:][mask], num_samples=Ns)
+    lrgb = env.hdr_rgbs["syn"].view(-1, 3)[cell.long()]
+    lpdf = env.hdr_pdf_return["syn"].view(-1)[cell.long()].unsqueeze(-1)
+    sel = slice(0, M, 32)
+    c = lambda t: t[sel].cpu()
+    ref_rgb = O.relight_importance(sc, c(surf), c(nrm), c(albedo[mask]), c(rough[mask]), c(fres[mask]),
+                                   c(rays[:, 3:][mask]), c(ldir), c(lrgb), c(lpdf), n_sample=96, near=0.05, far=1.5)
+    r = _record("C5-device-sampler", "relit_rgb", c(got_rgb), ref_rgb)
+    assert r["max_rel_floor1"] < TOL, r
