@@ -51,7 +51,12 @@ def install(reference_root: str):
             else:
                 setattr(m, s, ours[s])
         done[name] = [s.split(":")[0] for s in symbols]
-    synth_dataset.wrap_dataset_dict(importlib.import_module("dataLoader").dataset_dict)
+    # TENSOIR_DEVICE_DATASET=1: the training rays stay resident in HBM (batches are gathered on the device)
+    dev = None
+    if os.environ.get("TENSOIR_DEVICE_DATASET", "0") == "1":
+        import torch
+        dev = "cuda" if torch.cuda.is_available() else None
+    synth_dataset.wrap_dataset_dict(importlib.import_module("dataLoader").dataset_dict, device=dev)
     return done
 
 

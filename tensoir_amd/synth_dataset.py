@@ -109,17 +109,29 @@ class SyntheticDataset(torch.utils.data.Dataset):
                 "rays": fs[0]["rays"], "normals": fs[0]["normals"], "albedo": fs[0]["albedo"]}
 
 
-def wrap_dataset_dict(dataset_dict):
+def _to_device(ds, device):
+    """Training-loop residency: keep the training rays / colours / light indices of a dataset in HBM, so that
+    the unmodified loop's ``rays_filtered[rays_idx]`` (train_tensoIR.py:239-242) gathers on the device and only the 32 KB
+    index tensor crosses PCIe per step (the script builds its permutation on the host with numpy, :49)."""
+    for name in ("all_rays", "all_rgbs", "all_light_idx"):
+        t = getattr(ds, name, None)
+        if torch.is_tensor(t):
+            setattr(ds, name, t.to(device))
+    return ds
+
+
+def wrap_dataset_dict(dataset_dict, device=None):
     """Every entry keeps its reference class for real data directories and builds the analytic dataset when
-    ``datadir`` starts with ``synthetic``."""
+    ``datadir`` starts with ``synthetic``.  device (e.g. 'cuda'): training splits are moved to that device once."""
     for name, cls in list(dataset_dict.items()):
         if getattr(cls, "__tensoir_wrapped__", False):
             continue
 
         def factory(root_dir, *a, _cls=cls, **k):
-            if is_synthetic(root_dir):
-                return SyntheticDataset(root_dir, *a, **k)
-            return _cls(root_dir, *a, **k)
+            ds = SyntheticDataset(root_dir, *a, **k) if is_synthetic(root_dir) else _cls(root_dir, *a, **k)
+            if device is not None and k.get("split", "train") == "train":
+                _to_device(ds, device)
+            return ds
         factory.__tensoir_wrapped__ = True
         factory.__name__ = getattr(cls, "__name__", name)
         dataset_dict[name] = factory
