@@ -173,10 +173,14 @@ class PrimaryRenderFn(torch.autograd.Function):
                 st.calls["brdf"] = _DecoderCall(feat=intr, aux=rec_xyz, aux_map=None, out=brdf, h1=h1, h2=h2)
                 if noise_dense is not None:
                     noise = noise_dense.to(dev, torch.float32)[rec_ray.long(), rec_k.long()]
+                    xyz_j = torch.add(rec_xyz, noise, alpha=0.01)
+                    intr_j = ops.vm_app(f, xyz_j, None, None, False, True, None, 0, n_dev)[1]
                 else:
-                    noise = torch.randn((A, 3), device=dev, dtype=torch.float32)
-                xyz_j = torch.add(rec_xyz, noise, alpha=0.01)
-                intr_j = ops.vm_app(f, xyz_j, None, None, False, True, None, 0, n_dev)[1]
+                    # noise drawn in the gather kernel, keyed by (seed, pass counter, record index): the draw does not depend
+                    # on the record-capacity hint, so a fixed torch seed reproduces the run
+                    rng_state = model._jitter_rng(dev)
+                    xyz_j, intr_j = ops.vm_app_jitter(f, rec_xyz, 0.01, 0, 0, rng_state, n_dev)
+                    rng_state[1] += 1
                 brdf_j, h1, h2 = ops.mlp_train(pb, intr_j, xyz_j, n_dev=n_dev)
                 st.calls["brdf_j"] = _DecoderCall(feat=intr_j, aux=xyz_j, aux_map=None, out=brdf_j, h1=h1, h2=h2)
                 st.xyz_j = xyz_j
