@@ -269,6 +269,11 @@ int tir_composite_primary_fused(const float* rays, const int32_t* offsets, const
                                 int32_t is_relight, float fixed_fresnel, float* out_maps, int32_t* ticket,
                                 float* smooth_out, int64_t* rng_state, int64_t rng_step, void* stream);
 
+/* Selects the secondary-march kernel: 1 (default; env TENSOIR_LDS_LINES=0 turns it off) = density line factors staged in
+ * LDS by persistent blocks where the shape allows (16 density components, <= 96 samples per ray, 3*R*16 floats of lines
+ * within 150 KB), 0 = the plain kernel.  Results are bit-identical; returns the previous setting (-1 = never set). */
+int tir_set_lds_lines(int on);
+
 /* ---- K7 secondary march: sample_ray_equally + cull + density + raw2alpha
  *      (models/relight_utils.py:707-722, :657-705, :777-834).
  *      Ray p starts at origins[org_map ? org_map[p] : p] along dirs[dir_map ? dir_map[p] : p];

@@ -53,6 +53,7 @@ F32 = C.c_float
 # name -> (restype, argtypes); mirrors include/tensoir_hip.h one to one
 SIGNATURES = {
     "tir_version": (C.c_int, []),
+    "tir_set_lds_lines": (C.c_int, [C.c_int]),
     "tir_error_string": (C.c_char_p, [C.c_int]),
     "tir_device_check": (C.c_int, []),
     "tir_pack_plane": (C.c_int, [P, P, I32, I32, I32, P]),

@@ -695,10 +695,11 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
 // (the plain kernel: 134 VGPRs -> 12 waves).  One record reservation (atomic) per 64 rays.  Same arithmetic as
 // k_march_secondary in the same order: bit-identical results.
 // ------------------------------------------------------------------------------------------------
-#define TIR_SECL_RPB 64
 
-template <int C4, int NSTEP>
-__global__ void __launch_bounds__(512, 4)
+// NT = 512 (two blocks per CU while lines + scratch fit 80 KB: R <= ~370) or 1024 (one block per CU, e.g. the 400^3 field
+// of the ficus config: 76.8 KB of lines); RPB = NT / 8 rays per batch.
+template <int C4, int NSTEP, int NT>
+__global__ void __launch_bounds__(NT, 4)
 k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32_t* __restrict__ org_map,
                       const float* __restrict__ dirs, const int32_t* __restrict__ dir_map,
                       const uint8_t* __restrict__ active, int64_t n_rays, int n_dirs, int n_sample,
@@ -708,27 +709,29 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
                       int32_t* __restrict__ ray_rec_off, int32_t* __restrict__ ray_rec_cnt,
                       unsigned long long* __restrict__ stats, int xcd_on, const int32_t* __restrict__ ray_ids,
                       const int32_t* __restrict__ n_ids_dev, int line_floats) {
+    constexpr int RPB = NT / 8, NHW = NT / 32;                  // rays per batch, half-waves per block
     extern __shared__ __attribute__((aligned(16))) float sl_lds[];
     float* ll = sl_lds;                                         // [line 0 | line 1 | line 2]
     const int nz = (n_sample + 3) & ~3;
     float* zt = sl_lds + line_floats;
     float* ws = zt + nz + (threadIdx.x >> 6) * 256;             // this wave's gather scratch
-    int* s_cnt = reinterpret_cast<int*>(zt + nz + 8 * 256);
-    int* s_base = s_cnt + TIR_SECL_RPB;
-    int* s_pid = s_base + TIR_SECL_RPB;
+    int* s_cnt = reinterpret_cast<int*>(zt + nz + (NT / 64) * 256);
+    int* s_base = s_cnt + RPB;
+    int* s_pid = s_base + RPB;
+    __shared__ int s_wtot[2], s_bb, s_fits;
     {   // stage the line factors (coalesced 16-B copies; lines are [R][16] rows, contiguous)
         int off = 0;
         for (int i = 0; i < 3; ++i) {
             const int nf = f.grid[2 - i] * (C4 * 4);
-            for (int e = threadIdx.x * 4; e < nf; e += 512 * 4)
+            for (int e = threadIdx.x * 4; e < nf; e += NT * 4)
                 *reinterpret_cast<float4*>(ll + off + e) = *reinterpret_cast<const float4*>(f.dline[i] + e);
             off += nf;
         }
-        for (int i = threadIdx.x; i < n_sample; i += 512) zt[i] = z_vals[i];
+        for (int i = threadIdx.x; i < n_sample; i += NT) zt[i] = z_vals[i];
     }
     __syncthreads();
     if (ray_ids && n_ids_dev) n_rays = min(n_rays, (int64_t)max(*n_ids_dev, 0));
-    const int64_t n_batches = (n_rays + TIR_SECL_RPB - 1) / TIR_SECL_RPB;
+    const int64_t n_batches = (n_rays + RPB - 1) / RPB;
     const XcdRange xr = xcd_range(n_batches, 1, xcd_on != 0);
     const int hl = threadIdx.x & 31, hw = threadIdx.x >> 5;     // lane in the half-wave, half-wave in the block (0..15)
     const unsigned half_shift = (threadIdx.x & 32) ? 32 : 0;
@@ -740,8 +743,8 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
         int cnts[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int rl = g * 16 + hw;
-            const int64_t slot_id = batch * TIR_SECL_RPB + rl;
+            const int rl = g * NHW + hw;
+            const int64_t slot_id = batch * RPB + rl;
             const bool in_range = slot_id < n_rays;
             const int64_t ray = in_range ? (ray_ids ? (int64_t)ray_ids[slot_id] : slot_id) : 0;
             const bool live = in_range && !(active && !active[ray]);
@@ -812,32 +815,44 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
         }
         if (!want_rec) continue;
         __syncthreads();
-        if (threadIdx.x < 64) {           // one wave: inclusive scan of the 64 ray counts, one reservation for the batch
-            const int lane = threadIdx.x;
-            const int c = s_cnt[lane];
-            int incl = c;
+        // one reservation for the batch: inclusive scan of the RPB ray counts (one or two waves), one atomic
+        int c = 0, incl = 0;
+        if (threadIdx.x < RPB) {
+            const int lane = threadIdx.x & 63;
+            c = s_cnt[threadIdx.x];
+            incl = c;
 #pragma unroll
             for (int dd = 1; dd < 64; dd <<= 1) {
                 int oth = __shfl_up(incl, dd, 64);
                 if (lane >= dd) incl += oth;
             }
-            const int total = __shfl(incl, 63, 64);
+            if (lane == 63) s_wtot[threadIdx.x >> 6] = incl;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int total = s_wtot[0] + (RPB > 64 ? s_wtot[1] : 0);
             int base = 0;
-            if (lane == 63 && total > 0) base = atomicAdd(rec_counter, total);
-            base = __shfl(base, 63, 64);
+            if (total > 0) base = atomicAdd(rec_counter, total);
             const bool fits = (int64_t)base + total <= rec_cap;
-            if (lane == 63 && total > 0 && fits) atomicMax(rec_counter + 1, base + total);
-            const int pid = s_pid[lane];
+            // rec_counter[1]: length of the fully written record prefix (reservations are handed out in increasing order)
+            if (total > 0 && fits) atomicMax(rec_counter + 1, base + total);
+            s_bb = base; s_fits = fits ? 1 : 0;
+        }
+        __syncthreads();
+        if (threadIdx.x < RPB) {
+            if (RPB > 64 && threadIdx.x >= 64) incl += s_wtot[0];
+            const int pid = s_pid[threadIdx.x];
+            const bool fits = s_fits != 0;
             if (pid >= 0) {
-                ray_rec_off[pid] = base + incl - c;
+                ray_rec_off[pid] = s_bb + incl - c;
                 ray_rec_cnt[pid] = fits ? c : 0;
             }
-            s_base[lane] = (fits && c > 0) ? base + incl - c : -1;
+            s_base[threadIdx.x] = (fits && c > 0) ? s_bb + incl - c : -1;
         }
         __syncthreads();
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int rl = g * 16 + hw;
+            const int rl = g * NHW + hw;
             int base = s_base[rl];
             if (base < 0) continue;                    // uniform inside the half-wave
             const int64_t ray = s_pid[rl];
@@ -866,10 +881,19 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
                 base += __popc(hm);
             }
         }
-        // the next batch's s_cnt / s_pid writes come after this batch's readers: s_base is only rewritten behind the
-        // next __syncthreads pair, s_pid[rl] / s_cnt[rl] belong to the half-wave that reads them here
+        // the next batch's s_cnt / s_pid writes come after this batch's readers: s_base / s_bb are only rewritten behind
+        // the next batch's first __syncthreads, s_pid[rl] / s_cnt[rl] belong to the half-wave that reads them here
     }
     if (stats && hl == 0 && n_gather) atomicAdd(stats, (unsigned long long)n_gather);
+}
+
+static int g_lds_lines = -1;      // -1: take TENSOIR_LDS_LINES (default on) at the first launch
+
+// 1 / 0: use / do not use the LDS-staged-lines secondary march where it applies (A/B tests); returns the previous setting
+extern "C" int tir_set_lds_lines(int on) {
+    const int prev = g_lds_lines;
+    g_lds_lines = on ? 1 : 0;
+    return prev;
 }
 
 extern "C" int tir_march_secondary_fwd(const TirField* f, const float* origins, const int32_t* org_map,
@@ -904,23 +928,33 @@ extern "C" int tir_march_secondary_ids_fwd(const TirField* f, const float* origi
     // LDS-staged line factors: 16 density components, <= 96 samples per ray, lines + scratch within half a CU's LDS
     {
         const int64_t line_floats = (int64_t)(f->grid[0] + f->grid[1] + f->grid[2]) * f->n_dcomp;
-        const size_t lds2 = ((size_t)line_floats + ((n_sample + 3) & ~3) + 8 * 256 + 3 * TIR_SECL_RPB) * sizeof(float);
-        static int lds_lines = -1;
-        if (lds_lines < 0) { const char* e = getenv("TENSOIR_LDS_LINES"); lds_lines = (e && e[0] == '0') ? 0 : 1; }
-        if (lds_lines && f->n_dcomp == 16 && n_sample <= 96 && lds2 <= 80 * 1024) {
+        const size_t fixed = ((size_t)line_floats + ((n_sample + 3) & ~3)) * sizeof(float);
+        const size_t lds512 = fixed + (8 * 256 + 3 * 64) * sizeof(float), lds1024 = fixed + (16 * 256 + 3 * 128) * sizeof(float);
+        if (g_lds_lines < 0) { const char* e = getenv("TENSOIR_LDS_LINES"); g_lds_lines = (e && e[0] == '0') ? 0 : 1; }
+        if (g_lds_lines && f->n_dcomp == 16 && n_sample <= 96 && lds1024 <= 150 * 1024) {
             static bool attr_set = false;
             if (!attr_set) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_secondary_lds<4, 3>),
+                hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_secondary_lds<4, 3, 512>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_secondary_lds<4, 3, 1024>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
                 attr_set = true;
             }
-            const int64_t n_batches = (n_rays + TIR_SECL_RPB - 1) / TIR_SECL_RPB;
-            unsigned nblk = (unsigned)std::min<int64_t>(n_batches, 2 * 256);
+            const bool small = lds512 <= 80 * 1024;                 // two 512-thread blocks per CU, else one of 1024
+            const int rpb = small ? 64 : 128;
+            const int64_t n_batches = (n_rays + rpb - 1) / rpb;
+            unsigned nblk = (unsigned)std::min<int64_t>(n_batches, small ? 2 * 256 : 256);
             if (xcd_on) nblk = (nblk + 7) / 8 * 8;
-            hipLaunchKernelGGL((k_march_secondary_lds<4, 3>), dim3(nblk), dim3(512), lds2, tir_stream(stream),
-                               *f, origins, org_map, dirs, dir_map, active, n_rays, n_dirs, n_sample, z_vals, t_stop, vis,
-                               one_minus_acc, rec_counter, rec_cap, rec_ray, rec_w, rec_xyz, ray_rec_off, ray_rec_cnt, stats,
-                               xcd_on, ray_ids, n_ids_dev, (int)line_floats);
+            if (small)
+                hipLaunchKernelGGL((k_march_secondary_lds<4, 3, 512>), dim3(nblk), dim3(512), lds512, tir_stream(stream),
+                                   *f, origins, org_map, dirs, dir_map, active, n_rays, n_dirs, n_sample, z_vals, t_stop, vis,
+                                   one_minus_acc, rec_counter, rec_cap, rec_ray, rec_w, rec_xyz, ray_rec_off, ray_rec_cnt, stats,
+                                   xcd_on, ray_ids, n_ids_dev, (int)line_floats);
+            else
+                hipLaunchKernelGGL((k_march_secondary_lds<4, 3, 1024>), dim3(nblk), dim3(1024), lds1024, tir_stream(stream),
+                                   *f, origins, org_map, dirs, dir_map, active, n_rays, n_dirs, n_sample, z_vals, t_stop, vis,
+                                   one_minus_acc, rec_counter, rec_cap, rec_ray, rec_w, rec_xyz, ray_rec_off, ray_rec_cnt, stats,
+                                   xcd_on, ray_ids, n_ids_dev, (int)line_floats);
             TIR_CHECK_LAUNCH();
             return TIR_OK;
         }

@@ -123,7 +123,8 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
 
 @torch.no_grad()
 def compute_transmittance(tensoIR, surf_pts, light_in_dir, nSample=128, vis_near=0.1, vis_far=2, device="cuda"):
-    """models/relight_utils.py:657-705 -> (nerv_vis [N], nerfactor_vis [N])."""
+    """models/relight_utils.py:657-705 -> (nerv_vis [N], nerfactor_vis [N]).
+    nSample <= 256 (the secondary-march kernels' limit; the reference's configs use 96): larger values raise TensoirHipError."""
     surf_pts = surf_pts.to(torch.float32).contiguous()
     light_in_dir = light_in_dir.to(torch.float32).contiguous()
     z = _z_table(nSample, vis_near, vis_far, surf_pts.device)
@@ -135,7 +136,7 @@ def compute_transmittance(tensoIR, surf_pts, light_in_dir, nSample=128, vis_near
 @torch.no_grad()
 def compute_radiance(tensoIR, surf_pts, light_in_dir, light_idx, nSample=128, vis_near=0.05, vis_far=1.5,
                      device=None):
-    """models/relight_utils.py:777-834 -> (nerv_vis [N], nerfactor_vis [N], indirect [N,3])."""
+    """models/relight_utils.py:777-834 -> (nerv_vis [N], nerfactor_vis [N], indirect [N,3]).  nSample <= 256 (see compute_transmittance)."""
     surf_pts = surf_pts.to(torch.float32).contiguous()
     light_in_dir = light_in_dir.to(torch.float32).contiguous()
     li = light_idx.reshape(-1).to(surf_pts.device, torch.int32).contiguous()

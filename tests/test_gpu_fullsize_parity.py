@@ -122,7 +122,7 @@ def test_c2_c3_headline_batch_vs_oracle(c23, impl, t_stop):
             sub = float(maps[:, col].cpu()[c23.sel].mean())
             ref = float(c23.ref[key])
             REPORT[case][key] = {"hip_subsample_mean": sub, "oracle": ref}
-            assert abs(sub - ref) <= 5e-3 * max(abs(ref), 1e-6) + 1e-7, (key, sub, ref)
+            assert abs(sub - ref) <= 1e-4 * abs(ref) + 1e-12, (key, sub, ref)       # measured 7e-6 relative
         assert int(got["acc_mask"].sum()) == 4096          # the synthetic blob: every ray hits
     finally:
         ops.MLP_IMPL, m.march_t_stop = old_impl, old_stop

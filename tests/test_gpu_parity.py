@@ -694,3 +694,39 @@ def test_boundary_call_launch_budget_and_smoothness(full):
         assert torch.equal(a[k], b[k]), k
     assert float(a["albedo_smoothness_loss"]) != float(b["albedo_smoothness_loss"])
     assert abs(float(a["albedo_smoothness_loss"]) / float(b["albedo_smoothness_loss"]) - 1) < 0.2
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("grid", [300, 400])
+def test_lds_staged_lines_march_is_bit_identical(grid):
+    """The secondary march with the density line factors staged in LDS (north_star; 512-thread blocks at 300^3, one
+    1024-thread block per CU at the 400^3 of the ficus config) against the plain kernel: visibility, 1 - acc, indirect
+    radiance and the record bookkeeping of compute_radiance / compute_transmittance, bit for bit, on a ragged pair count."""
+    import contextlib, io
+    import tensoir_amd
+    from tensoir_amd import _lib, relight, synth
+    ck = synth.make_checkpoint(grid=(grid,) * 3, seed=20211202)
+    m = tensoir_amd.model_from_checkpoint(ck, "cuda", envmap_h=8, envmap_w=16)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m.updateAlphaMask((128, 128, 128))
+    gen = torch.Generator().manual_seed(17)
+    P = 40_000 + 37
+    pts = (torch.rand(P, 3, generator=gen) * 2 - 1).mul(1.1).cuda()
+    dirs = torch.nn.functional.normalize(torch.randn(P, 3, generator=gen), dim=-1).cuda()
+    li = torch.zeros(P, 1, dtype=torch.int32, device="cuda")
+    L = _lib.lib()
+    res = {}
+    prev = L.tir_set_lds_lines(1)
+    try:
+        for on in (1, 0):
+            L.tir_set_lds_lines(on)
+            m.__dict__.pop("_rec_cap_hints", None)
+            v, nf, ind = relight.compute_radiance(m, pts, dirs, li, nSample=96, vis_near=0.05, vis_far=1.5)
+            v2, nf2, ind2 = relight.compute_radiance(m, pts, dirs, li, nSample=96, vis_near=0.05, vis_far=1.5)   # hinted route
+            t, tn = relight.compute_transmittance(m, pts, dirs, nSample=57, vis_near=0.05, vis_far=1.5)
+            res[on] = (v, nf, ind, v2, ind2, t, tn)
+    finally:
+        L.tir_set_lds_lines(1 if prev != 0 else 0)
+    for a, b in zip(res[1], res[0]):
+        assert torch.equal(a, b)
+    assert float(res[1][0].min()) < 0.01 and float(res[1][0].max()) > 0.99 and float(res[1][2].abs().max()) > 0
