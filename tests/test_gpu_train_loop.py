@@ -30,16 +30,28 @@ def tv(x):
     return 2 * ((x[:, :, 1:, :] - x[:, :, :-1, :]).pow(2).sum() / ch + (x[:, :, :, 1:] - x[:, :, :, :-1]).pow(2).sum() / cw) / x.shape[0]
 
 
-def test_reconstruction_call_sequence(tmp_path):
+@pytest.mark.parametrize("variant", ["single_light", "rotated_multi_lights", "general_multi_lights"])
+def test_reconstruction_call_sequence(tmp_path, variant):
+    """variant = which of the reference's three training scripts is mirrored: train_tensoIR.py (one light),
+    train_tensoIR_rotated_multi_lights.py (one SG set seen under three rotations) or
+    train_tensoIR_general_multi_lights.py (one SG set per light, models/tensoRF_general_multi_lights.py)."""
     import types
 
     import tensoir_amd
-    from tensoir_amd import Renderer_TensoIR_train, TensorVMSplit
+    from tensoir_amd import Renderer_TensoIR_train
     from tensoir_amd.synth_dataset import SyntheticDataset
     torch.manual_seed(20211202)
     np.random.seed(20211202)
     dev = torch.device("cuda:0")
-    ds = SyntheticDataset("synthetic:views=4,res=32", "none", split="train", light_rotation=["000"])
+    if variant == "general_multi_lights":
+        from tensoir_amd.general_multi_lights import TensorVMSplit
+        light_kw = dict(light_rotation=None, light_name_list=["sunset", "snow", "courtyard"])
+        ds = SyntheticDataset("synthetic:views=4,res=32", "none", split="train", light_name_list=light_kw["light_name_list"])
+    else:
+        from tensoir_amd import TensorVMSplit
+        rot = ["000"] if variant == "single_light" else ["000", "120", "240"]
+        light_kw = dict(light_rotation=rot)
+        ds = SyntheticDataset("synthetic:views=4,res=32", "none", split="train", light_rotation=rot)
     args = types.SimpleNamespace(second_nSample=96, second_near=0.05, second_far=1.5)
     n_iters, batch = 150, 1024
     upsamp, mask_updates = [100, 130], [60, 110]      # tests/data/synthetic_train.txt (the reference itself
@@ -51,8 +63,8 @@ def test_reconstruction_call_sequence(tmp_path):
     m = TensorVMSplit(aabb, reso, dev, density_n_comp=[16, 16, 16], appearance_n_comp=[48, 48, 48], app_dim=27,
                       near_far=ds.near_far, shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=-10,
                       distance_scale=25, pos_pe=2, view_pe=2, fea_pe=2, featureC=128, step_ratio=0.5,
-                      fea2denseAct="softplus", normals_kind="derived_plus_predicted", light_rotation=["000"],
-                      light_kind="sg", dataset=ds, numLgtSGs=128)
+                      fea2denseAct="softplus", normals_kind="derived_plus_predicted", light_kind="sg", dataset=ds,
+                      numLgtSGs=128, **light_kw)
     lr_factor = 0.1 ** (1 / n_iters)
     opt = torch.optim.Adam(m.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
     all_rays, all_rgbs, all_lidx = ds.all_rays, ds.all_rgbs, ds.all_light_idx
@@ -115,5 +127,8 @@ def test_reconstruction_call_sequence(tmp_path):
     with torch.no_grad():
         a = Renderer_TensoIR_train(probe, None, pl, m, N_samples=-1, device=dev, args=args)
         b = Renderer_TensoIR_train(probe, None, pl, m2, N_samples=-1, device=dev, args=args)
-    for k in ("rgb_map", "depth_map", "acc_map", "rgb_with_brdf_map"):
+    # (the per-light SG sets of the general variant live outside the state_dict, as in the reference: a reloaded model
+    # has fresh ones, so its physically-based re-render differs by design)
+    keys = ("rgb_map", "depth_map", "acc_map") + (() if variant == "general_multi_lights" else ("rgb_with_brdf_map",))
+    for k in keys:
         assert torch.equal(a[k], b[k]), k

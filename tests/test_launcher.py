@@ -21,9 +21,24 @@ CFG = os.path.join(ROOT, "tests", "data", "synthetic_train.txt")
 HAVE_REF = os.path.isfile(os.path.join(REF, "train_tensoIR.py"))
 
 
-def run_script(tmp_path, extra=()):
+SCRIPTS = {     # script -> edits of the synthetic config (the three training entry points of the reference)
+    "train_tensoIR.py": {},
+    "train_tensoIR_rotated_multi_lights.py": {"light_rotation": "[000, 120, 240]"},
+    "train_tensoIR_general_multi_lights.py": {"light_rotation": None, "light_name_list": "[sunset, snow, courtyard]",
+                                              "dataset_name": "tensoIR_unknown_general_multi_lights"},
+}
+
+
+def run_script(tmp_path, extra=(), script="train_tensoIR.py"):
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    cmd = [sys.executable, "-m", "tensoir_amd.run", os.path.join(REF, "train_tensoIR.py"), "--config", CFG,
+    cfg, edits = CFG, SCRIPTS[script]
+    if edits:
+        lines = [l for l in open(CFG).read().splitlines() if l.split("=")[0].strip() not in edits]
+        lines += [f"{k} = {v}" for k, v in edits.items() if v is not None]
+        cfg = os.path.join(str(tmp_path), "config.txt")
+        with open(cfg, "w") as fh:
+            fh.write("\n".join(lines) + "\n")
+    cmd = [sys.executable, "-m", "tensoir_amd.run", os.path.join(REF, script), "--config", cfg,
            "--basedir", str(tmp_path)] + list(extra)
     return subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=1200)
 
@@ -95,8 +110,9 @@ def test_synthetic_dataset_interface():
 
 @pytest.mark.skipif(not HAVE_REF, reason="reference checkout not present")
 @pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-box check (the GPU variant runs the loop)")
-def test_unmodified_train_script_reaches_first_kernel_call(tmp_path):
-    r = run_script(tmp_path)
+@pytest.mark.parametrize("script", list(SCRIPTS))
+def test_unmodified_train_script_reaches_first_kernel_call(tmp_path, script):
+    r = run_script(tmp_path, script=script)
     out = r.stdout + r.stderr
     assert r.returncode != 0
     assert "Finish reading dataset" in out                                  # dataset_dict[...] built (train + test split)
@@ -107,10 +123,11 @@ def test_unmodified_train_script_reaches_first_kernel_call(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not HAVE_REF, reason="reference checkout not present on this box")
-def test_unmodified_train_script_runs_end_to_end(tmp_path):
+@pytest.mark.parametrize("script", list(SCRIPTS))
+def test_unmodified_train_script_runs_end_to_end(tmp_path, script):
     """150 iterations of the unmodified train_tensoIR.py on the HIP path: updateAlphaMask + shrink at 60 (relighting
     starts), upsample at 100 and 130, second mask update + ray re-filtering at 110, final checkpoint saved."""
-    r = run_script(tmp_path)
+    r = run_script(tmp_path, script=script)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-4000:]
     assert "upsamping to" in out and "continuing L1_reg_weight" in out
