@@ -409,7 +409,7 @@ def main():
     # ---- per-kernel attribution: pass 1 brackets every C call with events on the launch stream (no counters),
     #      pass 2 (one step) reads the device-side counters of gathered density samples ------------------
     ops.TIMING, ops.STATS = [], None
-    shapes_acc = {"app_n": 0, "app_out": 0, "mlp_n": 0, "mlp_flops": 0}
+    shapes_acc = {"app_n": 0, "app_out": 0, "mlp_n": 0, "mlp_flops": 0, "mlpm_n": 0, "mlpm_flops": 0}
     orig_app, orig_mlp = ops.vm_app, ops.mlp
 
     # rows actually processed: min(buffer rows, device-side count) -- the counts are read back after the pass
@@ -427,6 +427,13 @@ def main():
         pending.append(("mlp", feat.shape[0], n_dev, m.out_dim))
         return orig_mlp(m, feat, *args, **kw)
 
+    orig_multi = ops.mlp_multi
+
+    def multi_wrap(jobs, n_dev=None):
+        pending.append(("mlpm", jobs[0][1].shape[0], n_dev, [m.out_dim for m, _, _, _ in jobs]))
+        return orig_multi(jobs, n_dev)
+
+    ops.mlp_multi = multi_wrap
     ops.vm_app, ops.mlp = app_wrap, mlp_wrap
     import tensoir_amd.field_model as FM
     import tensoir_amd.relight as RL
@@ -434,12 +441,15 @@ def main():
     for _ in range(psteps):
         step(eager=True)
     torch.cuda.synchronize()
-    ops.vm_app, ops.mlp = orig_app, orig_mlp
+    ops.vm_app, ops.mlp, ops.mlp_multi = orig_app, orig_mlp, orig_multi
     for kind, rows, n_dev, x in pending:
         n = rows if n_dev is None else min(rows, int(n_dev.item()))
         if kind == "app":
             shapes_acc["app_n"] += n
             shapes_acc["app_out"] += n * 27 * 4 * x
+        elif kind == "mlpm":
+            shapes_acc["mlpm_n"] += n * len(x)
+            shapes_acc["mlpm_flops"] += sum(n * 2 * (150 * 128 + 128 * 128 + 128 * o) for o in x)
         else:
             shapes_acc["mlp_n"] += n
             shapes_acc["mlp_flops"] += n * 2 * (150 * 128 + 128 * 128 + 128 * x)
@@ -458,6 +468,7 @@ def main():
         "tir_mlp_fwd": {"n": shapes_acc["mlp_n"], "flops": shapes_acc["mlp_flops"]},
     }
     shapes["tir_mlp_fwd_bf16x3"] = shapes["tir_mlp_fwd"]
+    shapes["tir_mlp_fwd_multi_bf16x3"] = {"n": shapes_acc["mlpm_n"], "flops": shapes_acc["mlpm_flops"]}
     rows = kernel_table(timing, stats, psteps, shapes)
     gpu_ms = sum(r["ms_per_step"] for r in rows)
 

@@ -187,6 +187,14 @@ int tir_mlp_fwd(const TirMlp* m, const float* feat, int32_t feat_stride, const f
 int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
                        const int32_t* aux_map, int32_t aux_mod, float* out, int64_t n, const int32_t* n_dev,
         void* stream);
+
+/* Up to four decoders over the SAME n rows in one launch (split-bf16 matrix cores): the primary stage evaluates the
+ * radiance, BRDF, jittered-BRDF and normal decoders (models/tensorBase_rotated_lights.py:927-955) on the same records.
+ * mlps / feats / auxs / aux_maps / outs are HOST arrays of n_jobs entries (aux_maps or its entries may be NULL); feature
+ * rows must be 16-byte aligned with a stride that is a multiple of 4 floats; outs[i] is [n][mlps[i]->out_dim]. */
+int tir_mlp_fwd_multi_bf16x3(const TirMlp* const* mlps, const float* const* feats, int32_t feat_stride,
+                             const float* const* auxs, const int32_t* const* aux_maps, float* const* outs,
+                             int32_t n_jobs, int64_t n, const int32_t* n_dev, void* stream);
 /* single bf16 product (8 mantissa bits): reduced-precision mode, NOT parity grade (normals ~5e-3). */
 int tir_mlp_fwd_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
                      const int32_t* aux_map, int32_t aux_mod, float* out, int64_t n, const int32_t* n_dev,

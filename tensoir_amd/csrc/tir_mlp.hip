@@ -484,11 +484,13 @@ __device__ __forceinline__ int64_t aux_index(const int32_t* __restrict__ aux_map
     return ai;
 }
 
+// the decoder for the workgroup `bid` of `nblk` cooperating on one (decoder, row set) job
 template <int NPROD, bool VEC, bool SAVE>
-__global__ void __launch_bounds__(512)
-k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int fstride, const float* __restrict__ aux,
-           const int32_t* __restrict__ aux_map, int aux_mod, float* __restrict__ out, int64_t n,
-           const int32_t* __restrict__ n_dev, int out_dim, int act, float* __restrict__ h1o, float* __restrict__ h2o) {
+__device__ __forceinline__ void
+mlp_bf16_body(const float* __restrict__ packed, const float* __restrict__ feat, int fstride, const float* __restrict__ aux,
+              const int32_t* __restrict__ aux_map, int aux_mod, float* __restrict__ out, int64_t n,
+              const int32_t* __restrict__ n_dev, int out_dim, int act, float* __restrict__ h1o, float* __restrict__ h2o,
+              const int bid, const int nblk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
         const float* src = packed + OFF_BF;
@@ -508,12 +510,12 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
     const unsigned w1hi = opaque(lane_off + BW0_ELEMS * 4);
     const unsigned w1lo = opaque(lane_off + BW0_ELEMS * 4 + BW1_ELEMS * 2);
     const int64_t n_tiles = (n + 255) / 256;
-    const int64_t G = gridDim.x;
-    if ((int64_t)blockIdx.x >= n_tiles) return;
+    const int64_t G = nblk;
+    if ((int64_t)bid >= n_tiles) return;
     auto row_of = [&](int64_t tile) { const int64_t sr = tile * 256 + wave * 32 + sl; return sr < n ? sr : n - 1; };
     RowIn cur;
-    { const int64_t sc = row_of(blockIdx.x); load_row<VEC>(feat, fstride, aux, sc, aux_index(aux_map, aux_mod, sc), cur); }
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += G) {
+    { const int64_t sc = row_of(bid); load_row<VEC>(feat, fstride, aux, sc, aux_index(aux_map, aux_mod, sc), cur); }
+    for (int64_t tile = bid; tile < n_tiles; tile += G) {
         const int64_t s_raw = tile * 256 + wave * 32 + sl;
         AuxPE ap;
 #pragma unroll
@@ -596,6 +598,34 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
             if (out_dim > 3) op[3] = act_out(o3 + b2[3], act);
         }
     }
+}
+
+
+template <int NPROD, bool VEC, bool SAVE>
+__global__ void __launch_bounds__(512)
+k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int fstride, const float* __restrict__ aux,
+           const int32_t* __restrict__ aux_map, int aux_mod, float* __restrict__ out, int64_t n,
+           const int32_t* __restrict__ n_dev, int out_dim, int act, float* __restrict__ h1o, float* __restrict__ h2o) {
+    mlp_bf16_body<NPROD, VEC, SAVE>(packed, feat, fstride, aux, aux_map, aux_mod, out, n, n_dev, out_dim, act, h1o, h2o,
+                                    (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several decoders over the same number of rows in ONE launch (the primary stage runs rgb / brdf / jittered brdf / normal
+// on the same records): the grid is split evenly, a workgroup loads ITS decoder's operand image once and walks that
+// decoder's tiles.  Against one launch per decoder: one 150 KB LDS fill per workgroup instead of four, one tail instead
+// of four (at 230 k rows a launch is only 3.5 tiles per workgroup).
+struct TirMlpJob { const float* packed; const float* feat; const float* aux; const int32_t* aux_map; float* out; int out_dim, act; };
+struct TirMlpJobs { TirMlpJob j[4]; int n_jobs; };
+
+template <int NPROD>
+__global__ void __launch_bounds__(512)
+k_mlp_bf16_multi(TirMlpJobs jobs, int fstride, int64_t n, const int32_t* __restrict__ n_dev) {
+    const int per = (int)gridDim.x / jobs.n_jobs;
+    const int ji = (int)blockIdx.x / per;
+    if (ji >= jobs.n_jobs) return;
+    const TirMlpJob& jb = jobs.j[ji];
+    mlp_bf16_body<NPROD, true, false>(jb.packed, jb.feat, fstride, jb.aux, jb.aux_map, 0, jb.out, n, n_dev, jb.out_dim, jb.act,
+                                      nullptr, nullptr, (int)blockIdx.x - ji * per, per);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1149,6 +1179,38 @@ extern "C" int tir_mlp_train_fwd_bf16x3(const TirMlp* m, const float* feat, int3
 extern "C" int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map, int32_t aux_mod,
                                   float* out, int64_t n, const int32_t* n_dev, void* stream) {
     return launch_bf16<3>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream);
+}
+
+extern "C" int tir_mlp_fwd_multi_bf16x3(const TirMlp* const* mlps, const float* const* feats, int32_t feat_stride,
+                                        const float* const* auxs, const int32_t* const* aux_maps, float* const* outs,
+                                        int32_t n_jobs, int64_t n, const int32_t* n_dev, void* stream) {
+    if (n_jobs < 1 || n_jobs > 4 || !mlps || !feats || !auxs || !outs || n < 0) return TIR_ERR_ARG;
+    if (feat_stride % 4 != 0 || feat_stride < F + 1) return TIR_ERR_ARG;          // rows must take the dwordx4 loads
+    TirMlpJobs jobs;
+    jobs.n_jobs = n_jobs;
+    for (int i = 0; i < n_jobs; ++i) {
+        int rc = check_mlp(mlps[i]);
+        if (rc) return rc;
+        if (n > 0 && (!feats[i] || !auxs[i] || !outs[i])) return TIR_ERR_ARG;
+        if (reinterpret_cast<uintptr_t>(feats[i]) % 16 != 0) return TIR_ERR_ARG;
+        jobs.j[i] = TirMlpJob{mlps[i]->packed, feats[i], auxs[i], aux_maps ? aux_maps[i] : nullptr, outs[i], mlps[i]->out_dim,
+                              mlps[i]->act};
+    }
+    if (n == 0) return TIR_OK;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bf16_multi<3>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_BYTES);
+        if (e != hipSuccess) return -(int)e;
+        attr_set = true;
+    }
+    const int64_t tiles = (n + 255) / 256;
+    int per = 256 / n_jobs;
+    if (tiles < per) per = (int)tiles;
+    hipLaunchKernelGGL(k_mlp_bf16_multi<3>, dim3((unsigned)(per * n_jobs)), dim3(512), (size_t)BF_BYTES, tir_stream(stream), jobs,
+                       feat_stride, n, n_dev);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
 }
 
 extern "C" int tir_mlp_fwd_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map, int32_t aux_mod,

@@ -728,10 +728,10 @@ class TensorVMSplit(nn.Module):
             if viewdirs is None:
                 viewdirs = rays[:, 3:6].contiguous()
             rad, intr = ops.vm_app(f, rec_xyz, lidx, rec_ray, True, bool(is_relight), None, 0, n_dev)
-            rgb = ops.mlp(self.renderModule.packed(), rad, viewdirs, rec_ray, None, 0, n_dev)
+            jobs = [(self.renderModule.packed(), rad, viewdirs, rec_ray)]
             if is_relight:
                 pb = self.renderModule_brdf.packed()
-                brdf = ops.mlp(pb, intr, rec_xyz, None, None, 0, n_dev)
+                jobs.append((pb, intr, rec_xyz, None))
                 if _brdf_jitter_dense is not None:
                     noise = _brdf_jitter_dense.to(dev, torch.float32)[rec_ray.long(), rec_k.long()]
                     xyz_j = torch.add(rec_xyz, noise, alpha=0.01)
@@ -741,11 +741,21 @@ class TensorVMSplit(nn.Module):
                     # by the framework's CUDA seed, device-side offset advanced once per pass by the compositing kernel)
                     rng_state = self._jitter_rng(dev)
                     xyz_j, intr_j = ops.vm_app_jitter(f, rec_xyz, 0.01, 0, 0, rng_state, n_dev)
-                brdf_j = ops.mlp(pb, intr_j, xyz_j, None, None, 0, n_dev)
+                jobs.append((pb, intr_j, xyz_j, None))
+                if self.normals_kind != "purely_derived":
+                    jobs.append((self.renderModule_normal.packed(), intr, rec_xyz, None))
+            if ops.MLP_IMPL == "bf16x3":
+                # the decoders of the primary stage run on the same records: ONE launch, the grid split between them
+                outs = ops.mlp_multi(jobs, n_dev)
+            else:
+                outs = [ops.mlp(m, ft, ax, mp, None, 0, n_dev) for m, ft, ax, mp in jobs]
+            rgb = outs[0]
+            if is_relight:
+                brdf, brdf_j = outs[1], outs[2]
                 if self.normals_kind == "purely_derived":
                     pred = ops.density_grad(f, rec_xyz, n_dev=n_dev)[2]
                 else:
-                    pred = ops.mlp(self.renderModule_normal.packed(), intr, rec_xyz, None, None, 0, n_dev)
+                    pred = outs[3]
                     if self.normals_kind == "derived_plus_predicted":
                         derived = ops.density_grad(f, rec_xyz, n_dev=n_dev)[2]
         bg = bool(white_bg or (is_train and torch.rand((1,)) < 0.5))

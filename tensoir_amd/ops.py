@@ -266,6 +266,30 @@ if MLP_IMPL not in MLP_ENTRY:
     raise ValueError(f"TENSOIR_DECODER={MLP_IMPL!r}: expected one of {sorted(MLP_ENTRY)}")
 
 
+def mlp_multi(jobs, n_dev=None):
+    """Several decoders over the same rows in one launch (tir_mlp_fwd_multi_bf16x3).  jobs: list of up to four
+    (PackedMlp, feat [n, FEAT_STRIDE], aux [*, 3], aux_map or None); returns the list of outputs [n, out_dim]."""
+    n = jobs[0][1].shape[0]
+    k = len(jobs)
+    feats, auxs, maps, outs = [], [], [], []
+    for m, feat, aux, aux_map in jobs:
+        feat = f32(feat, "feat")
+        if feat.shape[0] != n or feat.dim() != 2 or feat.shape[1] != FEAT_STRIDE:
+            raise ValueError(f"mlp_multi: every job needs [n, {FEAT_STRIDE}] feature rows")
+        aux = f32(aux, "aux", 3)
+        if aux_map is not None:
+            aux_map = i32(aux_map, "aux_map").view(-1)
+        elif aux.shape[0] != n:
+            raise ValueError("aux must have one row per feature row (or pass aux_map)")
+        feats.append(feat); auxs.append(aux); maps.append(aux_map)
+        outs.append(torch.empty((n, m.out_dim), dtype=torch.float32, device=feat.device))
+    arr = lambda ts: (C.c_void_p * k)(*[None if t is None else t.data_ptr() for t in ts])
+    descs = (C.POINTER(TirMlp) * k)(*[C.pointer(m.desc) for m, _, _, _ in jobs])
+    _call("tir_mlp_fwd_multi_bf16x3", descs, arr(feats), FEAT_STRIDE, arr(auxs), arr(maps), arr(outs), k, n, _ptr(n_dev),
+          _stream())
+    return outs
+
+
 def mlp(m: PackedMlp, feat, aux, aux_map=None, impl=None, aux_mod=0, n_dev=None):
     impl = impl or MLP_IMPL
     feat = f32(feat, "feat")

@@ -730,3 +730,33 @@ def test_lds_staged_lines_march_is_bit_identical(grid):
     for a, b in zip(res[1], res[0]):
         assert torch.equal(a, b)
     assert float(res[1][0].min()) < 0.01 and float(res[1][0].max()) > 0.99 and float(res[1][2].abs().max()) > 0
+
+
+@torch.no_grad()
+def test_multi_decoder_launch_equals_single_launches(env):
+    """tir_mlp_fwd_multi_bf16x3 (the primary stage's decoders in one launch, grid split between them) == one
+    tir_mlp_fwd_bf16x3 launch per decoder, bit for bit, for 1-4 jobs, ragged row counts, with an aux index map and with a
+    device-side row count."""
+    from tensoir_amd import ops
+    m = env.model
+    gen = torch.Generator().manual_seed(23)
+    for n in (70_001, 255, 1):
+        feats = [torch.zeros(n, 32) for _ in range(3)]
+        for f in feats:
+            f[:, :27] = torch.randn(n, 27, generator=gen)
+        feats = [f.cuda() for f in feats]
+        xyz = (torch.rand(n, 3, generator=gen) * 2 - 1).cuda()
+        vd = torch.nn.functional.normalize(torch.randn(37, 3, generator=gen), dim=-1).cuda()
+        amap = torch.randint(0, 37, (n,), generator=gen).int().cuda()
+        jobs = [(m.renderModule.packed(), feats[0], vd, amap), (m.renderModule_brdf.packed(), feats[1], xyz, None),
+                (m.renderModule_brdf.packed(), feats[2], xyz, None), (m.renderModule_normal.packed(), feats[1], xyz, None)]
+        for k in (4, 3, 1):
+            got = ops.mlp_multi(jobs[:k])
+            for (pk, ft, ax, mp), g in zip(jobs[:k], got):
+                want = ops.mlp(pk, ft, ax, mp, "bf16x3")
+                assert torch.equal(g, want), (n, k)
+        if n > 1000:
+            n_dev = torch.tensor([n // 3], dtype=torch.int32, device="cuda")
+            got = ops.mlp_multi(jobs, n_dev)
+            for (pk, ft, ax, mp), g in zip(jobs, got):
+                assert torch.equal(g[: n // 3], ops.mlp(pk, ft, ax, mp, "bf16x3")[: n // 3])
