@@ -453,7 +453,7 @@ template <int C4, bool RAD, bool INTR, bool JIT = false>
 __global__ void __launch_bounds__(256)
 k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
               const int32_t* __restrict__ idx_map, float* __restrict__ rad_feat, float* __restrict__ int_feat,
-              int out_stride, int idx_div, int64_t n, const int32_t* __restrict__ n_dev, int xcd_on, TirJitter jt) {
+              int out_stride, int idx_div, int64_t n, const int32_t* __restrict__ n_dev, int xcd_on, TirJitter jt, int lt_rows) {
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));        // device-side point count (no host sync needed)
     constexpr int CA = C4 * 4;
     constexpr int NX = (RAD ? 1 : 0) + (INTR ? 1 : 0);
@@ -461,9 +461,18 @@ k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restri
     float* Wt = lds_app;                                   // [3*CA][32]
     if (JIT && jt.rng_dev) { jt.seed = (unsigned long long)jt.rng_dev[0]; jt.offset = (unsigned long long)jt.rng_dev[1]; }
     const int wave = threadIdx.x >> 6, L = threadIdx.x & 63;
-    float* X = lds_app + 3 * CA * 32 + wave * (NX * CA * TIR_XLD);   // [NX][CA][17]
+    // light rows in LDS: [n_lt rows of light_line | light_mean] x 3*CA floats (576 B per row).  Their taps were 9 (RAD) +
+    // 9 (INTR) of the 63-72 load instructions of a pass, and the ray-coherent gather is bound by the RATE of load
+    // instructions through the texture addresser (profiles/r02_gather_pred_bench.txt), not by bytes.
+    float* LT = lds_app + 3 * CA * 32;
+    const int n_lt = lt_rows;                              // light_line rows staged (0: read them from memory)
+    float* X = LT + (n_lt + 1) * (3 * CA) + wave * (NX * CA * TIR_XLD);   // [NX][CA][17]
     for (int i = threadIdx.x * 4; i < 3 * CA * 32; i += 256 * 4)
         *reinterpret_cast<float4*>(Wt + i) = *reinterpret_cast<const float4*>(f.basis_t + i);
+    for (int i = threadIdx.x * 4; i < n_lt * 3 * CA; i += 256 * 4)
+        *reinterpret_cast<float4*>(LT + i) = *reinterpret_cast<const float4*>(f.light_line + i);
+    for (int i = threadIdx.x * 4; i < 3 * CA; i += 256 * 4)
+        *reinterpret_cast<float4*>(LT + n_lt * 3 * CA + i) = *reinterpret_cast<const float4*>(f.light_mean + i);
     __syncthreads();
     const int j = L >> 2, c = L & 3;          // gather role: sample slot, 16-byte quarter
     const int jj = L & 15, kq = L >> 4;       // MFMA role: sample column, k quarter / output row quarter
@@ -486,8 +495,9 @@ k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restri
             if (idx_div > 1) lsel /= idx_div;
             int li = light_idx[lsel];
             li = min(max(li, 0), f.n_lights - 1);
-            lrow = f.light_line + (size_t)li * (3 * CA);
+            lrow = n_lt ? LT + li * (3 * CA) : f.light_line + (size_t)li * (3 * CA);
         }
+        const float* lmean = LT + n_lt * (3 * CA);
         f32x4 accr[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         f32x4 acci[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 1
@@ -506,12 +516,24 @@ k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restri
             const float* p11 = pl + (r1 + x1);
             const float* l0 = f.aline[k] + (unsigned)tl.i0 * CA;
             const float* l1 = f.aline[k] + (unsigned)tl.i1 * CA;
+            // all of this group's taps are requested before the first one is used: the gather is bound by how many loads a
+            // wave keeps in flight (a schedule that saves registers by serialising them measured 10-20 % slower)
+            constexpr int NQ = (C4 + 3) / 4;
+            float4 ta[NQ], tb[NQ], tc[NQ], td[NQ], te[NQ], tg[NQ];
 #pragma unroll
-            for (int q = 0; q < (C4 + 3) / 4; ++q) {
+            for (int q = 0; q < NQ; ++q) {
+                const int ch4 = 4 * q + c;
+                if (ch4 < C4) {
+                    ta[q] = ld4(p00 + 4 * ch4); tb[q] = ld4(p01 + 4 * ch4); tc[q] = ld4(p10 + 4 * ch4); td[q] = ld4(p11 + 4 * ch4);
+                    te[q] = ld4(l0 + 4 * ch4); tg[q] = ld4(l1 + 4 * ch4);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
                 const int ch4 = 4 * q + c;                 // this lane's 16-byte chunk of the 64-byte run q
                 if (ch4 < C4) {
-                    const float4 a = ld4(p00 + 4 * ch4), b = ld4(p01 + 4 * ch4), cc = ld4(p10 + 4 * ch4), d = ld4(p11 + 4 * ch4);
-                    const float4 e = ld4(l0 + 4 * ch4), g = ld4(l1 + 4 * ch4);
+                    const float4 a = ta[q], b = tb[q], cc = tc[q], d = td[q], e = te[q], g = tg[q];
                     float val[4];
                     val[0] = fmaf(d.x, w11, fmaf(cc.x, w10, fmaf(b.x, w01, a.x * w00))) * fmaf(g.x, tl.w1, e.x * tl.w0);
                     val[1] = fmaf(d.y, w11, fmaf(cc.y, w10, fmaf(b.y, w01, a.y * w00))) * fmaf(g.y, tl.w1, e.y * tl.w0);
@@ -523,7 +545,7 @@ k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restri
                         xr[0] = val[0] * lr.x; xr[TIR_XLD] = val[1] * lr.y; xr[2 * TIR_XLD] = val[2] * lr.z; xr[3 * TIR_XLD] = val[3] * lr.w;
                     }
                     if (INTR) {
-                        const float4 lm = ld4(f.light_mean + k * CA + 4 * ch4);
+                        const float4 lm = ld4(lmean + k * CA + 4 * ch4);
                         float* xi = X + ((RAD ? CA : 0) + 4 * ch4) * TIR_XLD + j;
                         xi[0] = val[0] * lm.x; xi[TIR_XLD] = val[1] * lm.y; xi[2 * TIR_XLD] = val[2] * lm.z; xi[3 * TIR_XLD] = val[3] * lm.w;
                     }
@@ -752,7 +774,8 @@ static int launch_app(const TirField* f, const float* xyz, const int32_t* li, co
     }
     constexpr int CA = C4 * 4;
     const int nx = (rad ? 1 : 0) + (intr ? 1 : 0);
-    const size_t lds = (size_t)(3 * CA * 32 + 4 * nx * CA * TIR_XLD) * sizeof(float);
+    const int lt_rows = (rad && f->n_lights <= 16) ? f->n_lights : 0;         // light_line rows staged in LDS (576 B each)
+    const size_t lds = (size_t)(3 * CA * 32 + (lt_rows + 1) * 3 * CA + 4 * nx * CA * TIR_XLD) * sizeof(float);
     int64_t blocks = (n + 63) / 64;
     if (blocks > 2048) blocks = 2048;
     const int xcd_on = tir_xcd_mapping();
@@ -770,12 +793,12 @@ static int launch_app(const TirField* f, const float* xyz, const int32_t* li, co
         if (rad || !intr) return TIR_ERR_ARG;
         static bool jattr = false;
         if (!jattr) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_mfma<C4, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); jattr = true; }
-        hipLaunchKernelGGL((k_vm_app_mfma<C4, false, true, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on, jt);
+        hipLaunchKernelGGL((k_vm_app_mfma<C4, false, true, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on, jt, lt_rows);
         return TIR_OK;
     }
-    if (rad && intr) hipLaunchKernelGGL((k_vm_app_mfma<C4, true, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on, jt);
-    else if (rad)    hipLaunchKernelGGL((k_vm_app_mfma<C4, true, false>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on, jt);
-    else             hipLaunchKernelGGL((k_vm_app_mfma<C4, false, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on, jt);
+    if (rad && intr) hipLaunchKernelGGL((k_vm_app_mfma<C4, true, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on, jt, lt_rows);
+    else if (rad)    hipLaunchKernelGGL((k_vm_app_mfma<C4, true, false>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on, jt, lt_rows);
+    else             hipLaunchKernelGGL((k_vm_app_mfma<C4, false, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on, jt, lt_rows);
     return TIR_OK;
 }
 
