@@ -230,10 +230,7 @@ def bench_image(a):
     def one():
         with torch.no_grad():
             return tdist.render_sharded_timed(fn, rays, lidx, rank=rank, world=gw, chunk=a.rays, tile=a.tile)
-    t_end = time.perf_counter() + 0.6
-    while time.perf_counter() < t_end:
-        one()
-    for _ in range(a.warmup):
+    for _ in range(3 + a.warmup):      # clock settle + warm-up: a fixed count (every image ends in a collective)
         one()
     if use_dist:
         dist.barrier()
@@ -356,14 +353,15 @@ def main():
                 dist.all_gather_into_tensor(gathered, tdist.pack_records(ret))
         return ret
 
-    def settle(seconds=0.6):
+    def settle(n_steps=300):
         """Untimed: bring the GPU out of its idle power state (a fresh box reports 'low-power state'; the first ~50 ms of
-        work run at ramping clocks: 2.5 ms per step instead of 1.85 measured right after process start)."""
-        t_end = time.perf_counter() + seconds
-        while time.perf_counter() < t_end:
-            for _ in range(10):
-                step()
-            torch.cuda.synchronize()
+        work run at ramping clocks: 2.5 ms per step instead of 1.85 measured right after process start).  A FIXED number
+        of steps (~0.5 s), not a time budget: with several ranks every step ends in a collective, so all ranks must run the
+        same number of them."""
+        for i in range(n_steps):
+            step()
+            if i % 10 == 9:
+                torch.cuda.synchronize()
 
     def timed(n_warm, n_steps):
         for _ in range(n_warm):
