@@ -514,6 +514,10 @@ def main():
                                      "source": "tools/gather_bench.hip, coherent 192-B taps"}
         else:
             o["frac_of_dense_bf16_peak"] = round(r["achieved"] / BF16_MFMA_PEAK_TF, 4)
+            if r["kernel"] == "tir_mlp_fwd_bf16x3":
+                o["rocprof_kernels"] = ["k_mlp_bf16<3, true, false> (one decoder, the secondary-ray records)",
+                                        "k_mlp_bf16_multi<3> (the four primary-stage decoders in one launch)"]
+                o["aggregation"] = "both launches run the same device code (mlp_bf16_body); avg_launch_ms / units_per_launch are means over the two"
             if r["kernel"].endswith("bf16x3"):
                 o["power_limited"] = {
                     "note": "back-to-back launches of this kernel on random data run at the board power cap: the shader clock "
