@@ -98,7 +98,9 @@ def build_scene(a, device, rank, **blob):
 # entry points that launch the same kernel as another one (same roofline model, same PMC key)
 ALIAS = {"tir_march_secondary_ids_fwd": "tir_march_secondary_fwd", "tir_shade_integrate_records": "tir_shade_integrate",
          # one launch for the primary stage's four decoders: the same device code (mlp_bf16_body) as the single-decoder launch
-         "tir_mlp_fwd_multi_bf16x3": "tir_mlp_fwd_bf16x3"}
+         "tir_mlp_fwd_multi_bf16x3": "tir_mlp_fwd_bf16x3",
+         # the primary stage's two appearance gathers in one launch: app_mfma_body twice, the grid split between them
+         "tir_vm_app_primary_fwd": "tir_vm_app_fwd", "tir_vm_app_jitter_fwd": "tir_vm_app_fwd"}
 
 
 def kernel_table(timing, stats, steps, shapes):
@@ -427,6 +429,20 @@ def main():
         pending.append(("mlp", feat.shape[0], n_dev, m.out_dim))
         return orig_mlp(m, feat, *args, **kw)
 
+    orig_prim, orig_jit = ops.vm_app_primary, ops.vm_app_jitter
+
+    def prim_wrap(field, xyz, *args, **kw):
+        n_dev = kw.get("n_dev", args[4] if len(args) > 4 else None)
+        pending.append(("app", xyz.shape[0], n_dev, 2))            # records: radiance + intrinsic features
+        pending.append(("app", xyz.shape[0], n_dev, 1 + 3 / 27))   # jittered records: intrinsic features + the points
+        return orig_prim(field, xyz, *args, **kw)
+
+    def jit_wrap(field, xyz, *args, **kw):
+        n_dev = kw.get("n_dev", args[4] if len(args) > 4 else None)
+        pending.append(("app", xyz.shape[0], n_dev, 1 + 3 / 27))
+        return orig_jit(field, xyz, *args, **kw)
+
+    ops.vm_app_primary, ops.vm_app_jitter = prim_wrap, jit_wrap
     orig_multi = ops.mlp_multi
 
     def multi_wrap(jobs, n_dev=None):
@@ -442,6 +458,7 @@ def main():
         step(eager=True)
     torch.cuda.synchronize()
     ops.vm_app, ops.mlp, ops.mlp_multi = orig_app, orig_mlp, orig_multi
+    ops.vm_app_primary, ops.vm_app_jitter = orig_prim, orig_jit
     for kind, rows, n_dev, x in pending:
         n = rows if n_dev is None else min(rows, int(n_dev.item()))
         if kind == "app":

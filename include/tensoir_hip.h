@@ -163,6 +163,13 @@ int tir_vm_app_fwd(const TirField* f, const float* xyz, const int32_t* light_idx
 int tir_vm_app_jitter_fwd(const TirField* f, const float* xyz, int64_t n, const int32_t* n_dev, float scale,
                           uint64_t seed, uint64_t offset, const int64_t* rng_state, float* xyz_out,
                           float* int_feat, int32_t out_stride, void* stream);
+
+/* tir_vm_app_fwd (radiance + intrinsic features of xyz) and tir_vm_app_jitter_fwd (intrinsic features of the jittered xyz)
+ * in ONE launch -- the two appearance gathers of the primary stage (n_acomp == 48).  Arguments as in the two calls. */
+int tir_vm_app_primary_fwd(const TirField* f, const float* xyz, const int32_t* light_idx, const int32_t* idx_map,
+                           float* rad_feat, float* int_feat, int32_t out_stride, int64_t n, const int32_t* n_dev,
+                           float scale, uint64_t seed, uint64_t offset, const int64_t* rng_state, float* xyz_out,
+                           float* int_feat_jit, void* stream);
 /* same contract with the 144 x 27 contraction on v_mfma_f32_16x16x32_bf16 and every operand split x = hi + lo in bf16
  * (three products, fp32 accumulate: parity grade, features agree with the exact kernel to ~1e-6); n_acomp <= 64. */
 int tir_vm_app_fwd_bf16x3(const TirField* f, const float* xyz, const int32_t* light_idx,

@@ -432,19 +432,24 @@ __device__ __forceinline__ void philox_uniform4(unsigned long long seed, unsigne
 //     for (i = first; i < end; i += stride)      visits every item of [0, n_items) exactly once over the whole grid.
 // `per` = items a block consumes per iteration (e.g. 4 waves x 1 pass).  gridDim.x must be a multiple of 8 when on.
 struct XcdRange { long long first, end, stride; };
-__device__ __forceinline__ XcdRange xcd_range(long long n_items, int per, bool on) {
+// bid / nblk: this workgroup's index inside, and the size of, the group of workgroups that shares the items (the whole grid,
+// or a slice of it that starts at a multiple of 8 when one launch carries several jobs)
+__device__ __forceinline__ XcdRange xcd_range_at(long long n_items, int per, bool on, int bid, int nblk) {
     XcdRange r;
-    if (!on || (gridDim.x & 7) != 0) {
-        r.first = (long long)blockIdx.x * per; r.end = n_items; r.stride = (long long)gridDim.x * per;
+    if (!on || (nblk & 7) != 0) {
+        r.first = (long long)bid * per; r.end = n_items; r.stride = (long long)nblk * per;
         return r;
     }
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int xcd = bid & 7, local = bid >> 3, per_xcd = nblk >> 3;
     const long long chunk = (n_items + 7) / 8;
     const long long lo = chunk * xcd;
     r.first = lo + (long long)local * per;
     r.end = lo + chunk < n_items ? lo + chunk : n_items;
     r.stride = (long long)per_xcd * per;
     return r;
+}
+__device__ __forceinline__ XcdRange xcd_range(long long n_items, int per, bool on) {
+    return xcd_range_at(n_items, per, on, (int)blockIdx.x, (int)gridDim.x);
 }
 
 }  // namespace tir

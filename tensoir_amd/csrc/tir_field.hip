@@ -449,11 +449,12 @@ struct TirJitter {
 
    // padded sample stride of the X tile (bank spread for the quad-strided writes)
 
-template <int C4, bool RAD, bool INTR, bool JIT = false>
-__global__ void __launch_bounds__(256)
-k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
+template <int C4, bool RAD, bool INTR, bool JIT>
+__device__ __forceinline__ void
+app_mfma_body(const TirField& f, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
               const int32_t* __restrict__ idx_map, float* __restrict__ rad_feat, float* __restrict__ int_feat,
-              int out_stride, int idx_div, int64_t n, const int32_t* __restrict__ n_dev, int xcd_on, TirJitter jt, int lt_rows) {
+              int out_stride, int idx_div, int64_t n, const int32_t* __restrict__ n_dev, int xcd_on, TirJitter jt, int lt_rows,
+              const int bid, const int nblk) {
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));        // device-side point count (no host sync needed)
     constexpr int CA = C4 * 4;
     constexpr int NX = (RAD ? 1 : 0) + (INTR ? 1 : 0);
@@ -477,7 +478,7 @@ k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restri
     const int j = L >> 2, c = L & 3;          // gather role: sample slot, 16-byte quarter
     const int jj = L & 15, kq = L >> 4;       // MFMA role: sample column, k quarter / output row quarter
     const int64_t n_pass = (n + 15) / 16;
-    const XcdRange xr = xcd_range(n_pass, 4, xcd_on != 0);
+    const XcdRange xr = xcd_range_at(n_pass, 4, xcd_on != 0, bid, nblk);
     for (int64_t pass = xr.first + wave; pass < xr.end; pass += xr.stride) {
         const int64_t s = pass * 16 + j;
         const int64_t sc = s < n ? s : n - 1;
@@ -587,6 +588,35 @@ k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restri
                 }
             }
         }
+    }
+}
+
+template <int C4, bool RAD, bool INTR, bool JIT = false>
+__global__ void __launch_bounds__(256)
+k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
+              const int32_t* __restrict__ idx_map, float* __restrict__ rad_feat, float* __restrict__ int_feat,
+              int out_stride, int idx_div, int64_t n, const int32_t* __restrict__ n_dev, int xcd_on, TirJitter jt, int lt_rows) {
+    app_mfma_body<C4, RAD, INTR, JIT>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, xcd_on, jt,
+                                      lt_rows, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The two appearance gathers of the primary stage in ONE launch: workgroups [0, nb0) compute the radiance + intrinsic
+// features of the records (models/tensoRF_rotated_lights.py:132-165), workgroups [nb0, nb0 + nb1) the intrinsic features of
+// the JITTERED records (:937-938, noise drawn in the kernel).  Both are 230 k-row launches of 1.8 passes per wave on
+// their own: merged they fill the chip once instead of twice.
+template <int C4>
+__global__ void __launch_bounds__(256)
+k_vm_app_primary(TirField f, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
+                 const int32_t* __restrict__ idx_map, float* __restrict__ rad_feat, float* __restrict__ int_feat,
+                 float* __restrict__ int_feat_jit, int out_stride, int64_t n, const int32_t* __restrict__ n_dev, int xcd_on,
+                 TirJitter jt, int lt_rows, int nb0) {
+    if ((int)blockIdx.x < nb0) {
+        TirJitter none{0.0f, 0ull, 0ull, nullptr, nullptr};
+        app_mfma_body<C4, true, true, false>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, 0, n, n_dev, xcd_on, none,
+                                             lt_rows, (int)blockIdx.x, nb0);
+    } else {
+        app_mfma_body<C4, false, true, true>(f, xyz, nullptr, nullptr, nullptr, int_feat_jit, out_stride, 0, n, n_dev, xcd_on, jt,
+                                             lt_rows, (int)blockIdx.x - nb0, (int)gridDim.x - nb0);
     }
 }
 
@@ -852,6 +882,38 @@ extern "C" int tir_vm_app_jitter_fwd(const TirField* f, const float* xyz, int64_
     if (!xyz_out || !int_feat || scale == 0.0f) return TIR_ERR_ARG;
     TirJitter jt{scale, (unsigned long long)seed, (unsigned long long)offset, reinterpret_cast<const long long*>(rng_dev), xyz_out};
     return app_fwd(f, xyz, nullptr, nullptr, nullptr, int_feat, out_stride, 0, n, n_dev, stream, false, false, jt);
+}
+
+// tir_vm_app_fwd (both features) + tir_vm_app_jitter_fwd on the same points in one launch (48 appearance components).
+extern "C" int tir_vm_app_primary_fwd(const TirField* f, const float* xyz, const int32_t* light_idx, const int32_t* idx_map,
+                                      float* rad_feat, float* int_feat, int32_t out_stride, int64_t n, const int32_t* n_dev,
+                                      float scale, uint64_t seed, uint64_t offset, const int64_t* rng_state, float* xyz_out,
+                                      float* int_feat_jit, void* stream) {
+    if (!f || !rad_feat || !int_feat || !xyz_out || !int_feat_jit || !light_idx || scale == 0.0f) return TIR_ERR_ARG;
+    for (int i = 0; i < 3; ++i)
+        if (f->grid[i] < 2 || !f->aplane[i] || !f->aline[i]) return TIR_ERR_ARG;
+    if (!f->basis_t || !f->light_mean || !f->light_line) return TIR_ERR_ARG;
+    if (f->n_acomp != 48 || f->app_dim < 1 || f->app_dim > 27) return TIR_ERR_UNSUPPORTED;
+    if (out_stride < f->app_dim || out_stride > 32) return TIR_ERR_ARG;
+    if (n < 0 || (n > 0 && !xyz)) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    constexpr int C4 = 12, CA = 48;
+    const int lt_rows = f->n_lights <= 16 ? f->n_lights : 0;
+    const size_t lds = (size_t)(3 * CA * 32 + (lt_rows + 1) * 3 * CA + 4 * 2 * CA * TIR_XLD) * sizeof(float);
+    int64_t nb = (n + 63) / 64;
+    if (nb > 1024) nb = 1024;
+    nb = (nb + 7) / 8 * 8;                                   // both slices start at a multiple of 8 (XCD mapping)
+    const int xcd_on = tir_xcd_mapping();
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_primary<C4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    TirJitter jt{scale, (unsigned long long)seed, (unsigned long long)offset, reinterpret_cast<const long long*>(rng_state), xyz_out};
+    hipLaunchKernelGGL((k_vm_app_primary<C4>), dim3((unsigned)(2 * nb)), dim3(256), lds, tir_stream(stream), *f, xyz, light_idx, idx_map,
+                       rad_feat, int_feat, int_feat_jit, out_stride, n, n_dev, xcd_on, jt, lt_rows, (int)nb);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
 }
 
 extern "C" int tir_vm_app_fwd_valu(const TirField* f, const float* xyz, const int32_t* light_idx,

@@ -727,12 +727,21 @@ class TensorVMSplit(nn.Module):
         if A > 0:
             if viewdirs is None:
                 viewdirs = rays[:, 3:6].contiguous()
-            rad, intr = ops.vm_app(f, rec_xyz, lidx, rec_ray, True, bool(is_relight), None, 0, n_dev)
+            merged = bool(is_relight) and _brdf_jitter_dense is None and f.n_acomp == 48 and ops.APP_IMPL == "mfma"
+            if merged:
+                # both appearance gathers of the stage in one launch (xyz + randn_like(xyz) * 0.01 of :937 drawn in the kernel:
+                # Philox keyed by the framework's CUDA seed, device-side offset advanced once per pass by the compositing kernel)
+                rng_state = self._jitter_rng(dev)
+                rad, intr, xyz_j, intr_j = ops.vm_app_primary(f, rec_xyz, lidx, rec_ray, 0.01, rng_state, n_dev)
+            else:
+                rad, intr = ops.vm_app(f, rec_xyz, lidx, rec_ray, True, bool(is_relight), None, 0, n_dev)
             jobs = [(self.renderModule.packed(), rad, viewdirs, rec_ray)]
             if is_relight:
                 pb = self.renderModule_brdf.packed()
                 jobs.append((pb, intr, rec_xyz, None))
-                if _brdf_jitter_dense is not None:
+                if merged:
+                    pass
+                elif _brdf_jitter_dense is not None:
                     noise = _brdf_jitter_dense.to(dev, torch.float32)[rec_ray.long(), rec_k.long()]
                     xyz_j = torch.add(rec_xyz, noise, alpha=0.01)
                     intr_j = ops.vm_app(f, xyz_j, None, None, False, True, None, 0, n_dev)[1]

@@ -376,6 +376,22 @@ def vm_app_jitter(field: TirField, xyz, scale, seed, offset, rng_state=None, n_d
     return xyz_j, intr
 
 
+def vm_app_primary(field: TirField, xyz, light_idx, idx_map, scale, rng_state, n_dev=None):
+    """The primary stage's two appearance gathers in one launch (tir_vm_app_primary_fwd): returns
+    (rad [n, FEAT_STRIDE], intr, xyz_jittered [n, 3], intr_jittered)."""
+    xyz = f32(xyz, "xyz", 3).view(-1, 3)
+    n = xyz.shape[0]
+    dev = xyz.device
+    rad = torch.empty((n, FEAT_STRIDE), dtype=torch.float32, device=dev)
+    intr = torch.empty((n, FEAT_STRIDE), dtype=torch.float32, device=dev)
+    intr_j = torch.empty((n, FEAT_STRIDE), dtype=torch.float32, device=dev)
+    xyz_j = torch.empty_like(xyz)
+    _call("tir_vm_app_primary_fwd", C.byref(field), _ptr(xyz), _ptr(i32(light_idx, "light_idx").view(-1)),
+          _ptr(None if idx_map is None else i32(idx_map, "idx_map").view(-1)), _ptr(rad), _ptr(intr), FEAT_STRIDE, n, _ptr(n_dev),
+          float(scale), 0, 0, _ptr(rng_state), _ptr(xyz_j), _ptr(intr_j), _stream())
+    return rad, intr, xyz_j, intr_j
+
+
 def exclusive_scan(counts):
     counts = i32(counts, "counts").view(-1)
     n = counts.numel()

@@ -675,6 +675,29 @@ def test_in_kernel_brdf_jitter_noise(env):
 
 
 @torch.no_grad()
+def test_merged_primary_app_gather_equals_separate_launches(env):
+    """tir_vm_app_primary_fwd (one launch) == tir_vm_app_fwd(both features) + tir_vm_app_jitter_fwd, bit for bit, with and
+    without a ray -> record indirection, for a device-side point count below the buffer size."""
+    from tensoir_amd import ops
+    m = env.model
+    f = m.packed_field()
+    g = torch.Generator().manual_seed(11)
+    for n, n_live in ((230_017, 230_017), (70_001, 33_333), (5, 5)):
+        xyz = (torch.rand(n, 3, generator=g) * 1.6 - 0.8).cuda()
+        n_rays = 4096
+        rec_ray = torch.sort(torch.randint(0, n_rays, (n,), generator=g)).values.int().cuda()
+        lidx = torch.randint(0, max(int(f.n_lights), 1), (n_rays,), generator=g).int().cuda()
+        n_dev = torch.tensor([n_live], dtype=torch.int32, device="cuda")
+        state = torch.tensor([99, 3], dtype=torch.int64, device="cuda")
+        rad0, intr0 = ops.vm_app(f, xyz, lidx, rec_ray, True, True, None, 0, n_dev)
+        xj0, ij0 = ops.vm_app_jitter(f, xyz, 0.01, 0, 0, state, n_dev)
+        rad, intr, xj, ij = ops.vm_app_primary(f, xyz, lidx, rec_ray, 0.01, state, n_dev)
+        w = f.app_dim
+        assert torch.equal(rad[:n_live, :w], rad0[:n_live, :w]) and torch.equal(intr[:n_live, :w], intr0[:n_live, :w])
+        assert torch.equal(xj[:n_live], xj0[:n_live]) and torch.equal(ij[:n_live, :w], ij0[:n_live, :w])
+
+
+@torch.no_grad()
 def test_boundary_call_launch_budget_and_smoothness(full):
     """The hinted inference route: the smoothness losses come out of the compositing kernel (== the column means of the
     map rows), the jitter state advances once per pass (two calls -> different smoothness noise, same geometry maps)."""
