@@ -337,12 +337,16 @@ __device__ __forceinline__ void fast_sincos(float x, float& s, float& c) {
 // products + two selects (each half used to compute both functions and keep one).  t is the exact fraction of
 // v / 2pi (see fast_sincos), |t| <= 1/2, so 2t + q is exact up to one rounding at magnitude <= 1.25 (6e-8 rev).
 __device__ __forceinline__ void pe_pair(float v, float q, float& p1, float& p2) {
+#ifdef EXP_NO_PE      // limit study: no range reduction, no transcendentals (wrong results)
+    p1 = v + q; p2 = fmaf(v, 2.0f, q);
+#else
     const float c_hi = 0.15915493667125702f, c_lo = 6.4206382432985265e-09f;      // c_hi + c_lo = 1 / (2 pi)
     const float k = rintf(v * c_hi);
     float t = fmaf(v, c_hi, -k);
     t = fmaf(v, c_lo, t);
     p1 = __builtin_amdgcn_sinf(t + q);
     p2 = __builtin_amdgcn_sinf(fmaf(t, 2.0f, q));
+#endif
 }
 
 struct AuxPE { float s[3], c[3], s2[3], c2[3]; };   // sin/cos of aux and of 2*aux
@@ -399,6 +403,14 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
     return v;
 }
 
+// limit-study switch (tools/build_variant.sh ... -DEXP_NO_LDS): every k-block reads the operand tile of block 0, which the
+// compiler then keeps in registers -- wrong results, same MFMA / VALU stream, no LDS operand traffic
+#ifdef EXP_NO_LDS
+#define KBX(kb) 0
+#else
+#define KBX(kb) (kb)
+#endif
+
 // ---- per k-block: [issue the A-tile LDS reads] [build that block's 8 inputs on the VALU] [12 MFMAs].
 // The MFMAs of block kb execute on the matrix pipe while the wave's VALU already builds block kb+1 (intra-wave overlap
 // instead of "all inputs, then all MFMAs"), the input build covers the LDS latency, and only one block of inputs is live.
@@ -422,8 +434,8 @@ __device__ __forceinline__ void layer1_interleaved(unsigned whi, unsigned wlo, i
     bf16x8 ah[4], al[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        ah[mt] = lds_tile(whi, KB * 4096 + mt * 512);
-        if (NPROD == 3) al[mt] = lds_tile(wlo, KB * 4096 + mt * 512);
+        ah[mt] = lds_tile(whi, KBX(KB) * 4096 + mt * 512);
+        if (NPROD == 3) al[mt] = lds_tile(wlo, KBX(KB) * 4096 + mt * 512);
     }
     float v[8];
     build_pair<KB, 0>(ft, ax, ap, h, hq, v);
@@ -443,8 +455,8 @@ __device__ __forceinline__ void layer2_interleaved(unsigned whi, unsigned wlo,
     bf16x8 ah[4], al[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        ah[mt] = lds_tile(whi, KB * 4096 + mt * 512);
-        if (NPROD == 3) al[mt] = lds_tile(wlo, KB * 4096 + mt * 512);
+        ah[mt] = lds_tile(whi, KBX(KB) * 4096 + mt * 512);
+        if (NPROD == 3) al[mt] = lds_tile(wlo, KBX(KB) * 4096 + mt * 512);
     }
     float v[8];
 #pragma unroll
@@ -567,6 +579,10 @@ mlp_bf16_body(const float* __restrict__ packed, const float* __restrict__ feat, 
         f32x4 o4[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) o4[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef EXP_NO_L3      // limit study: layer 3 replaced by four adds (wrong results)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o4[c] = f32x4{acc2[c][0], acc2[c][1], acc2[c][2], acc2[c][3]};
+#else
         {
             const float* wp = lds + BH_W2 + (h * 4 + (lane & 3)) * W2A_STRIDE;
 #pragma unroll
@@ -583,6 +599,7 @@ mlp_bf16_body(const float* __restrict__ packed, const float* __restrict__ feat, 
                 }
             }
         }
+#endif
         float o0 = (o4[0][0] + o4[1][0]) + (o4[2][0] + o4[3][0]);
         float o1 = (o4[0][1] + o4[1][1]) + (o4[2][1] + o4[3][1]);
         float o2 = (o4[0][2] + o4[1][2]) + (o4[2][2] + o4[3][2]);

@@ -13,6 +13,7 @@ There is no eager-PyTorch fallback: every derivative below is produced by libten
 """
 from __future__ import annotations
 
+import os
 from types import SimpleNamespace
 
 import torch
@@ -77,7 +78,43 @@ class _DecoderCall(SimpleNamespace):
     pass
 
 
-def _decoder_backward(dec, calls, impl=None):
+class _LeafStream:
+    """The weight-gradient products (dW = X^T dZ per layer, the basis-matrix gradient) are leaves of the backward: nothing
+    in the chain waits for them.  They are HBM-streaming kernels with an atomic epilogue, the chain between them is
+    scatter- and matrix-bound: queued on a second HIP stream they fill the chain's tails instead of extending it.
+    `run` orders the leaf after everything queued so far; `join` makes the caller's stream wait for all leaves.
+    Operands are kept referenced until the join, so the caching allocator cannot hand their memory to a later kernel of
+    the main stream while a leaf still reads it.  TENSOIR_BWD_STREAMS=0: everything on the caller's stream."""
+    _streams = {}
+
+    def __init__(self, dev):
+        self.on = os.environ.get("TENSOIR_BWD_STREAMS", "1") != "0" and not torch.cuda.is_current_stream_capturing()
+        self.keep = []
+        if self.on:
+            key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+            if key not in self._streams:
+                self._streams[key] = torch.cuda.Stream(device=dev)
+            self.side = self._streams[key]
+
+    def run(self, fn, *operands):
+        if not self.on:
+            return fn()
+        self.keep.extend(operands)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            out = fn()
+        self.keep.append(out)
+        return out
+
+    def join(self):
+        if self.on:
+            torch.cuda.current_stream().wait_stream(self.side)
+        self.keep.clear()
+
+
+def _decoder_backward(dec, calls, impl=None, leaf=None):
     """Backward of every recorded invocation of one decoder.  Returns ([g_feat per call], 6 parameter grads)."""
     pm, pb = dec.packed(), _packed_bwd(dec)
     dev = calls[0].feat.device
@@ -90,10 +127,18 @@ def _decoder_backward(dec, calls, impl=None):
     g_feats = []
     for c in calls:
         g_feat, dz1, dz2, dz3 = ops.mlp_bwd(pm, pb, c.feat, c.out, c.g_out, c.h1, c.h2, impl=impl)
-        x = ops.mlp_inputs(pm, c.feat, c.aux, c.aux_map)
-        ops.gemm_tn(dz1, 128, x, 150, dW0, True, impl=impl, bias_out=db0)
-        ops.gemm_tn(dz2, 128, c.h1, 128, dW1, True, impl=impl, bias_out=db1)
-        ops.gemm_tn(dz3, 4, c.h2, 128, dW2, True, impl=impl, bias_out=db2)
+
+        def weight_grads(c=c, dz1=dz1, dz2=dz2, dz3=dz3):
+            x = ops.mlp_inputs(pm, c.feat, c.aux, c.aux_map)
+            ops.gemm_tn(dz1, 128, x, 150, dW0, True, impl=impl, bias_out=db0)
+            ops.gemm_tn(dz2, 128, c.h1, 128, dW1, True, impl=impl, bias_out=db1)
+            ops.gemm_tn(dz3, 4, c.h2, 128, dW2, True, impl=impl, bias_out=db2)
+            return x
+
+        if leaf is None:
+            weight_grads()
+        else:
+            leaf.run(weight_grads, dz1, dz2, dz3, c.feat, c.aux, c.aux_map, c.h1, c.h2, flat)
         g_feats.append(g_feat)
     grads = [dW0, db0, dW1, db1, dW2[:od], db2[:od]]
     return g_feats, grads
@@ -253,32 +298,35 @@ class PrimaryRenderFn(torch.autograd.Function):
             st.rays, st.offsets, st.rec_k, st.rec_w, st.rgb, st.brdf, st.brdf_j, st.pred, st.derived, st.acc, st.depth,
             st.S, st.white_bg, st.is_relight, model.fixed_fresnel, g_maps)
         dec_grads = {}
+        leaf = _LeafStream(dev)
         d_basis = torch.zeros((model.app_dim, 3 * f.n_acomp), dtype=torch.float32, device=dev)
         if st.A > 0:
             c = st.calls["rgb"]
             c.g_out = g_rgb
-            (g_rad,), dec_grads["rgb"] = _decoder_backward(model.renderModule, [c])
+            (g_rad,), dec_grads["rgb"] = _decoder_backward(model.renderModule, [c], leaf=leaf)
             g_int = g_int_j = None
             if st.is_relight:
                 cb, cj = st.calls["brdf"], st.calls["brdf_j"]
                 cb.g_out, cj.g_out = g_brdf, g_brdf_j
-                (g_int, g_int_j), dec_grads["brdf"] = _decoder_backward(model.renderModule_brdf, [cb, cj])
+                (g_int, g_int_j), dec_grads["brdf"] = _decoder_backward(model.renderModule_brdf, [cb, cj], leaf=leaf)
                 if "normal" in st.calls:
                     cn = st.calls["normal"]
                     cn.g_out = g_pred
-                    (g_n,), dec_grads["normal"] = _decoder_backward(model.renderModule_normal, [cn])
+                    (g_n,), dec_grads["normal"] = _decoder_backward(model.renderModule_normal, [cn], leaf=leaf)
                     g_int = g_int + g_n
                     if g_der is not None:
                         ops.density_grad_bwd(f, gd, st.rec_xyz, g_der)
                 else:                                   # purely_derived: the composited normal IS the derived one
                     ops.density_grad_bwd(f, gd, st.rec_xyz, g_pred)
             y_rad, y_int = ops.vm_app_bwd(f, gd, st.rec_xyz, st.lidx, st.rec_ray, g_rad, g_int)
-            ops.gemm_tn(g_rad, model.app_dim, y_rad, 3 * f.n_acomp, d_basis)
+            nb = 3 * f.n_acomp
+            leaf.run(lambda: ops.gemm_tn(g_rad, model.app_dim, y_rad, nb, d_basis), g_rad, y_rad, d_basis)
             if g_int is not None:
-                ops.gemm_tn(g_int, model.app_dim, y_int, 3 * f.n_acomp, d_basis)
+                leaf.run(lambda: ops.gemm_tn(g_int, model.app_dim, y_int, nb, d_basis), g_int, y_int)
                 _, y_j = ops.vm_app_bwd(f, gd, st.xyz_j, None, None, None, g_int_j)
-                ops.gemm_tn(g_int_j, model.app_dim, y_j, 3 * f.n_acomp, d_basis)
+                leaf.run(lambda: ops.gemm_tn(g_int_j, model.app_dim, y_j, nb, d_basis), g_int_j, y_j)
         ops.march_primary_bwd(f, gd, st.rays, st.jitter, st.sigma, st.weight, g_weight, g_acc, g_depth)
+        leaf.join()
         grads = []
         for name in ("dp", "dl", "ap", "al"):
             grads += [_to_param_layout(bufs[f"{name}{i}"]) for i in range(3)]
