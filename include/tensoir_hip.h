@@ -503,6 +503,15 @@ int tir_gemm_tn(const float* A, int32_t lda, int32_t M, const float* B, int32_t 
 int tir_gemm_tn_bf16x3(const float* A, int32_t lda, int32_t M, const float* B, int32_t ldb, int32_t N,
                 int32_t ones_col, int64_t n, float* C, int32_t ldc, float* bias_out, void* stream);
 
+/* optimizer.step() of the training loop (train_tensoIR.py:317; torch.optim.Adam(grad_vars, betas=(0.9, 0.99)), :197) for a
+ * list of tensors in one launch: torch's default Adam update (no amsgrad, no weight decay), element for element,
+ *   m += (g - m)(1 - beta1);  v = v beta2 + (1 - beta2) g g;  p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps).
+ * Host arrays of n_tensors entries: device pointers p / g / m / v (dense storage in the same element order), element
+ * counts, and per tensor lr, bias_correction1 = 1 - beta1^step, bias_correction2 = 1 - beta2^step. */
+int tir_adam_step(int32_t n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                  const int64_t* count, const float* lr, const float* bias_correction1,
+                  const float* bias_correction2, float beta1, float beta2, float eps, void* stream);
+
 /* Backward of tir_shade_integrate w.r.t. the map rows (normal 4:7, albedo 7:10, roughness 10, fresnel 11:14)
  * and the environment radiance.  g_out [M][3] -> g_maps [M][20] (written), g_env [n_lights][D][3] (accumulated).
  * Visibility and indirect light are constants (compute_secondary_shading_effects is @torch.no_grad,

@@ -9,6 +9,7 @@ from .relight import (Environment_Light, GGX_specular, compute_radiance,  # noqa
                       relight_with_envmap)
 from .renderer import Renderer_TensoIR_train  # noqa: F401
 from . import general_multi_lights  # noqa: F401  (TensorVMSplit with one SG set per light)
+from . import optim  # noqa: F401  (Adam with a single-launch step())
 
 __version__ = "0.1.0"
 

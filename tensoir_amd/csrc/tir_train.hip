@@ -1492,3 +1492,82 @@ extern "C" int tir_env_sg_bwd(const TirEnvSG* e, const float* dirs, int32_t D, c
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Adam over a list of tensors in ONE launch (the caller of the training step: optimizer.step(), train_tensoIR.py:317,
+// torch.optim.Adam(grad_vars, betas=(0.9, 0.99)), :197).  The framework's multi-tensor Adam is ~90 launches of ~9 us per
+// step over these ~35 tensors (0.75 ms of a 6.5 ms step); one pass over parameter, gradient and both moments is 28 B per
+// element -- 0.08 ms for the 17.4 M parameters of the 300^3 field at HBM speed.  Same arithmetic as torch's default
+// (non-amsgrad, no weight decay) update, element for element:
+//   m += (g - m) (1 - b1);  v = v b2 + (1 - b2) g g;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps).
+// Operands are raw storage: all four tensors of an entry must be dense with the same element order.
+// ------------------------------------------------------------------------------------------------
+#define ADAM_MAX_T 40
+#define ADAM_CHUNK 8192
+struct AdamEntry { float* p; const float* g; float* m; float* v; long long n; float step_size, inv_bc2_sqrt; int first_chunk; };
+struct AdamTable { AdamEntry e[ADAM_MAX_T]; int n_tensors; };
+
+__global__ void __launch_bounds__(256)
+k_adam(AdamTable tab, float b1, float b2, float eps) {
+    __shared__ int t_sh;
+    if (threadIdx.x == 0) {
+        int t = 0;
+        while (t + 1 < tab.n_tensors && (int)blockIdx.x >= tab.e[t + 1].first_chunk) ++t;
+        t_sh = t;
+    }
+    __syncthreads();
+    const AdamEntry& e = tab.e[t_sh];
+    const long long base = (long long)((int)blockIdx.x - e.first_chunk) * ADAM_CHUNK;
+    const long long end = min(e.n, base + ADAM_CHUNK);
+    const float w1 = 1.0f - b1, w2 = 1.0f - b2;
+    auto upd = [&](float& p, float g, float& m, float& v) {
+        m = m + (g - m) * w1;
+        v = v * b2 + w2 * g * g;
+        const float denom = sqrtf(v) * e.inv_bc2_sqrt + eps;
+        p = p - e.step_size * (m / denom);
+    };
+    const bool vec = ((((size_t)e.p | (size_t)e.g | (size_t)e.m | (size_t)e.v) & 15) == 0);
+    if (vec) {
+        for (long long i = base + 4 * (long long)threadIdx.x; i < end; i += 4 * 256) {
+            if (i + 4 <= end) {
+                float4 p = *reinterpret_cast<float4*>(e.p + i), m = *reinterpret_cast<float4*>(e.m + i), v = *reinterpret_cast<float4*>(e.v + i);
+                const float4 g = *reinterpret_cast<const float4*>(e.g + i);
+                upd(p.x, g.x, m.x, v.x); upd(p.y, g.y, m.y, v.y); upd(p.z, g.z, m.z, v.z); upd(p.w, g.w, m.w, v.w);
+                *reinterpret_cast<float4*>(e.p + i) = p; *reinterpret_cast<float4*>(e.m + i) = m; *reinterpret_cast<float4*>(e.v + i) = v;
+            } else {
+                for (long long j = i; j < end; ++j) upd(e.p[j], e.g[j], e.m[j], e.v[j]);
+            }
+        }
+    } else {
+        for (long long i = base + threadIdx.x; i < end; i += 256) upd(e.p[i], e.g[i], e.m[i], e.v[i]);
+    }
+}
+
+extern "C" int tir_adam_step(int32_t n_tensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                             const int64_t* count, const float* lr, const float* bias_correction1,
+                             const float* bias_correction2, float beta1, float beta2, float eps, void* stream) {
+    if (n_tensors < 0 || (n_tensors > 0 && (!p || !g || !m || !v || !count || !lr || !bias_correction1 || !bias_correction2)))
+        return TIR_ERR_ARG;
+    hipStream_t s = tir_stream(stream);
+    int t = 0;
+    while (t < n_tensors) {
+        AdamTable tab;
+        int k = 0, chunks = 0;
+        for (; t < n_tensors && k < ADAM_MAX_T; ++t) {
+            if (count[t] < 0 || !(bias_correction1[t] > 0.0f) || !(bias_correction2[t] > 0.0f)) return TIR_ERR_ARG;
+            if (count[t] == 0) continue;
+            if (!p[t] || !g[t] || !m[t] || !v[t]) return TIR_ERR_ARG;
+            const int64_t c = (count[t] + ADAM_CHUNK - 1) / ADAM_CHUNK;
+            if (chunks + c > (1 << 30)) break;
+            tab.e[k] = AdamEntry{p[t], g[t], m[t], v[t], (long long)count[t], lr[t] / bias_correction1[t],
+                                 1.0f / sqrtf(bias_correction2[t]), chunks};
+            chunks += (int)c;
+            ++k;
+        }
+        tab.n_tensors = k;
+        if (k == 0) continue;
+        hipLaunchKernelGGL(k_adam, dim3((unsigned)chunks), dim3(256), 0, s, tab, beta1, beta2, eps);
+        TIR_CHECK_LAUNCH();
+    }
+    return TIR_OK;
+}

@@ -780,6 +780,17 @@ def gemm_tn(A, M, B, N, C_out, ones_col=False, impl=None, bias_out=None):
     return C_out
 
 
+def adam_step(entries, beta1, beta2, eps):
+    """tir_adam_step over entries (p, g, m, v, lr, bias_correction1, bias_correction2); the four tensors of an entry are
+    dense with the same element order (tensoir_amd.optim.Adam checks)."""
+    n = len(entries)
+    PA, FA, LA = C.c_void_p * n, C.c_float * n, C.c_int64 * n
+    _call("tir_adam_step", n, PA(*[e[0].data_ptr() for e in entries]), PA(*[e[1].data_ptr() for e in entries]),
+          PA(*[e[2].data_ptr() for e in entries]), PA(*[e[3].data_ptr() for e in entries]),
+          LA(*[e[0].numel() for e in entries]), FA(*[e[4] for e in entries]), FA(*[e[5] for e in entries]),
+          FA(*[e[6] for e in entries]), float(beta1), float(beta2), float(eps), _stream())
+
+
 def shade_integrate_bwd(maps, rays, dirs, light_idx, vis, indirect, env, weight_d, equal_area, use_srgb, acc_thres,
                         g_out):
     maps = f32(maps, "maps", MAP_STRIDE)

@@ -1,0 +1,86 @@
+"""optimizer.step() of the training loop on one HIP launch.
+
+The reference's loop (train_tensoIR.py:197, :315-317) builds `torch.optim.Adam(grad_vars, betas=(0.9, 0.99))` over ~35
+parameter tensors in per-tensor groups and calls `optimizer.step()` after `total_loss.backward()`.  torch's multi-tensor
+Adam spends ~90 launches per step on that list; `Adam` below is the same optimizer (same constructor, same state_dict
+entries `step` / `exp_avg` / `exp_avg_sq`, same update arithmetic for its default mode) whose `step()` is
+`tir_adam_step`: one pass over parameter, gradient and both moments.  `tensoir_amd.run` binds `torch.optim.Adam` to it.
+
+Modes the kernel does not implement (amsgrad, weight decay, maximize, capturable/differentiable, sparse gradients,
+non-fp32 or non-CUDA parameters) raise -- nothing falls back silently.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._lib import TensoirHipError
+
+_TorchAdam = torch.optim.Adam
+
+
+def _dense_key(t):
+    """Strides over the dims of extent > 1 if `t` is non-overlapping and dense, else None."""
+    dims = sorted((st, sz) for sz, st in zip(t.shape, t.stride()) if sz > 1)
+    expect = 1
+    for st, sz in dims:
+        if st != expect:
+            return None
+        expect *= sz
+    return tuple(st for sz, st in zip(t.shape, t.stride()) if sz > 1)
+
+
+class Adam(_TorchAdam):
+    """torch.optim.Adam with a single-launch HIP `step()` (see the module docstring)."""
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        entries = []
+        betas = eps = None
+        for group in self.param_groups:
+            for opt in ("amsgrad", "maximize", "capturable", "differentiable"):
+                if group.get(opt):
+                    raise NotImplementedError(f"tensoir_amd.optim.Adam: {opt}=True is not implemented")
+            if group.get("weight_decay", 0) != 0:
+                raise NotImplementedError("tensoir_amd.optim.Adam: weight_decay != 0 is not implemented")
+            b, e = tuple(float(x) for x in group["betas"]), float(group["eps"])
+            if betas is None:
+                betas, eps = b, e
+            elif (b, e) != (betas, eps):
+                raise NotImplementedError("tensoir_amd.optim.Adam: betas / eps must be the same in every parameter group")
+            lr = float(group["lr"])
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                g = p.grad
+                if g.is_sparse or p.dtype != torch.float32 or g.dtype != torch.float32:
+                    raise NotImplementedError("tensoir_amd.optim.Adam: dense fp32 parameters and gradients only")
+                if not p.is_cuda:
+                    raise TensoirHipError("tensoir_amd.optim.Adam.step needs the parameters on an MI355X (no CPU path)")
+                key = _dense_key(p)
+                if key is None:
+                    raise NotImplementedError("tensoir_amd.optim.Adam: parameters must be non-overlapping and dense")
+                if _dense_key(g) != key:
+                    g = torch.empty_like(p).copy_(g)          # autograd's layout contract makes this the rare case
+                state = self.state[p]
+                if len(state) == 0:
+                    state["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                m, v = state["exp_avg"], state["exp_avg_sq"]
+                if _dense_key(m) != key or _dense_key(v) != key:      # e.g. a state_dict loaded into another layout
+                    m = state["exp_avg"] = torch.empty_like(p).copy_(m)
+                    v = state["exp_avg_sq"] = torch.empty_like(p).copy_(v)
+                state["step"] += 1
+                t = float(state["step"])
+                entries.append((p, g, m, v, lr, 1.0 - betas[0] ** t, 1.0 - betas[1] ** t))
+        if entries:
+            ops.adam_step(entries, betas[0], betas[1], eps)
+            # the kernel wrote parameters and moments through raw pointers: tell autograd (saved-tensor checks) and every
+            # cache keyed by Tensor._version (the model's packed decoder images, light means, descriptors) that they changed
+            torch.autograd.graph.increment_version([t for e in entries for t in (e[0], e[2], e[3])])
+        return loss

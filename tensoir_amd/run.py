@@ -51,6 +51,12 @@ def install(reference_root: str):
             else:
                 setattr(m, s, ours[s])
         done[name] = [s.split(":")[0] for s in symbols]
+    # optimizer.step() of the training loop (train_tensoIR.py:197, :317) on one launch; TENSOIR_TORCH_ADAM=1 keeps torch's
+    if os.environ.get("TENSOIR_TORCH_ADAM", "0") != "1":
+        import torch
+        from tensoir_amd import optim
+        torch.optim.Adam = optim.Adam
+        done["torch.optim"] = ["Adam"]
     # TENSOIR_DEVICE_DATASET=1: the training rays stay resident in HBM (batches are gathered on the device)
     dev = None
     if os.environ.get("TENSOIR_DEVICE_DATASET", "0") == "1":

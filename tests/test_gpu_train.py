@@ -552,3 +552,54 @@ def test_full_size_training_properties():
         assert gerr(g2[n], 2.0 * g1[n]) < 2e-4, n         # (2)
     for n in ("density_plane.0", "density_line.2", "app_plane.1", "app_line.0", "basis_mat.weight"):
         assert float(g1[n].abs().sum()) > 0.0, n
+
+
+def test_single_launch_adam_matches_torch_adam():
+    """tensoir_amd.optim.Adam.step (tir_adam_step, one launch) against torch.optim.Adam on the same gradients for 25 steps:
+    per-tensor groups with different learning rates (train_tensoIR.py:196-197), channel-last parameters (the model's
+    plane storage), odd sizes (scalar tail), an lr rescale mid-run (:321-322) and a parameter whose grad is None."""
+    from tensoir_amd import optim
+    g = torch.Generator().manual_seed(5)
+    shapes = [(1, 16, 37, 41), (1, 48, 29, 1), (27, 144), (128, 150), (128,), (3,), (1, 7, 5, 3)]
+    base = [torch.randn(s, generator=g) for s in shapes]
+    def make():
+        ps = []
+        for i, b in enumerate(base):
+            t = b.clone().cuda()
+            if t.dim() == 4 and i != 6:
+                t = t.contiguous(memory_format=torch.channels_last)
+            ps.append(torch.nn.Parameter(t))
+        return ps
+    pa, pb = make(), make()
+    lrs = [0.02, 0.02, 0.001, 0.001, 0.001, 0.0005, 0.02]
+    oa = optim.Adam([{"params": p, "lr": lr} for p, lr in zip(pa, lrs)], betas=(0.9, 0.99))
+    ob = optim._TorchAdam([{"params": p, "lr": lr} for p, lr in zip(pb, lrs)], betas=(0.9, 0.99))
+    for step in range(25):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 5 and step < 3:
+                a.grad = b.grad = None                   # joins later: its own step count / bias correction
+                continue
+            gr = torch.randn(a.shape, generator=g).cuda() * (10.0 ** ((i % 3) - 1))
+            if i == 0:
+                gr = gr.contiguous(memory_format=torch.channels_last)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        if step == 10:
+            for o in (oa, ob):
+                for grp in o.param_groups:
+                    grp["lr"] = grp["lr"] * 0.7
+        v0 = pa[0]._version
+        oa.step(); ob.step()
+        assert pa[0]._version > v0                       # caches keyed by Tensor._version see the raw-pointer update
+    for a, b in zip(pa, pb):
+        assert a.stride() == b.stride()
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["state"].keys() == sb["state"].keys()
+    for k in sa["state"]:
+        assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
+        assert torch.allclose(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+    ob2 = optim.Adam([{"params": p, "lr": lr} for p, lr in zip(pb, lrs)], betas=(0.9, 0.99))
+    ob2.load_state_dict(sb)                               # a torch.optim.Adam state continues under ours
+    for b in pb:
+        b.grad = torch.ones_like(b)
+    ob2.step()

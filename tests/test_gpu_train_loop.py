@@ -14,6 +14,8 @@ import numpy as np
 import pytest
 import torch
 
+from tensoir_amd.optim import Adam       # what tensoir_amd.run binds torch.optim.Adam to (train_tensoIR.py:197)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -66,7 +68,7 @@ def test_reconstruction_call_sequence(tmp_path, variant):
                       fea2denseAct="softplus", normals_kind="derived_plus_predicted", light_kind="sg", dataset=ds,
                       numLgtSGs=128, **light_kw)
     lr_factor = 0.1 ** (1 / n_iters)
-    opt = torch.optim.Adam(m.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+    opt = Adam(m.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
     all_rays, all_rgbs, all_lidx = ds.all_rays, ds.all_rgbs, ds.all_light_idx
     rays_f, keep = m.filtering_rays(all_rays, bbox_only=True)
     rgbs_f, lidx_f = all_rgbs[keep], all_lidx[keep]
@@ -109,7 +111,7 @@ def test_reconstruction_call_sequence(tmp_path, variant):
             reso = n_to_reso(voxel_list.pop(0), m.aabb)
             n_samples = min(10 ** 6, int(np.linalg.norm(reso) / 0.5))
             m.upsample_volume_grid(reso)
-            opt = torch.optim.Adam(m.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
+            opt = Adam(m.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
             grids.append(tuple(m.gridSize.tolist()))
     assert len(grids) == 3 and grids[-1][0] > grids[0][0]                 # two up-samplings happened
     assert m.alphaMask is not None

@@ -142,7 +142,11 @@ def test_launcher_rebinds_reference_symbols():
     assert r.Renderer_TensoIR_train is tensoir_amd.Renderer_TensoIR_train
     assert ru.render_with_BRDF is tensoir_amd.render_with_BRDF and ru.compute_radiance is tensoir_amd.compute_radiance
     assert tf.TensorVMSplit is tensoir_amd.TensorVMSplit and tf.AlphaGridMask is tensoir_amd.AlphaGridMask
-    assert set(done) == set(run.PATCHES)
+    from tensoir_amd import optim
+    try:
+        assert set(done) == set(run.PATCHES) | {"torch.optim"} and torch.optim.Adam is optim.Adam
+    finally:
+        torch.optim.Adam = optim._TorchAdam              # this process goes on to run other tests on the CPU
 
 
 def test_general_multi_light_variant_host_side():
@@ -187,3 +191,23 @@ def test_to_device_is_a_plain_to_on_cpu():
     t = torch.arange(6).reshape(2, 3)
     out = ops.to_device(t, "cpu", torch.int32)
     assert out.dtype == torch.int32 and torch.equal(out.long(), t)
+
+
+def test_adam_is_constructor_and_state_compatible_and_loud_on_cpu():
+    """tensoir_amd.optim.Adam: same constructor / param_groups / state_dict layout as torch.optim.Adam
+    (train_tensoIR.py:197 builds it over per-tensor groups and rescales group['lr'], :321-322); no CPU path."""
+    import pytest
+    from tensoir_amd import optim
+    from tensoir_amd._lib import TensoirHipError
+    ps = [torch.nn.Parameter(torch.randn(1, 4, 5, 3)), torch.nn.Parameter(torch.randn(7))]
+    groups = [{"params": ps[0], "lr": 0.02}, {"params": ps[1], "lr": 0.001}]
+    o = optim.Adam(groups, betas=(0.9, 0.99))
+    assert isinstance(o, torch.optim.Adam) and [g["lr"] for g in o.param_groups] == [0.02, 0.001]
+    ref = torch.optim.Adam([{"params": [p.detach().clone().requires_grad_()], "lr": g["lr"]} for p, g in zip(ps, groups)], betas=(0.9, 0.99))
+    assert {k for k in o.state_dict()["param_groups"][0]} == {k for k in ref.state_dict()["param_groups"][0]}
+    for p in ps:
+        p.grad = torch.ones_like(p)
+    with pytest.raises(TensoirHipError):
+        o.step()
+    assert optim._dense_key(torch.empty(1, 4, 5, 3).permute(0, 2, 3, 1)) is not None
+    assert optim._dense_key(torch.empty(8, 8)[:, ::2]) is None

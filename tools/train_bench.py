@@ -26,9 +26,10 @@ ckpt, model, rays, lidx = bench.build_scene(a, dev, 0)
 model.march_t_stop = 1e-6
 args = types.SimpleNamespace(second_nSample=96, second_near=0.05, second_far=1.5)
 gt = torch.rand(rays.shape[0], 3, device=dev)
-# TENSOIR_FUSED_ADAM=1: torch's fused multi-tensor Adam (one kernel per parameter group instead of ~10 foreach kernels)
-opt = torch.optim.Adam(model.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99),
-                       **({"fused": True} if os.environ.get("TENSOIR_FUSED_ADAM", "0") == "1" else {}))
+# the optimizer the launcher binds (tensoir_amd.optim.Adam: one launch per step); TENSOIR_TORCH_ADAM=1: torch's multi-tensor Adam
+from tensoir_amd import optim as _optim
+_Adam = _optim._TorchAdam if os.environ.get("TENSOIR_TORCH_ADAM", "0") == "1" else _optim.Adam
+opt = _Adam(model.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99))
 W = dict(rgb_brdf=0.2, normals_diff=0.0005, normals_orientation=0.001, albedo_smoothness=0.001, roughness_smoothness=0.001)
 
 
