@@ -202,6 +202,12 @@ int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, 
 int tir_mlp_fwd_multi_bf16x3(const TirMlp* const* mlps, const float* const* feats, int32_t feat_stride,
                              const float* const* auxs, const int32_t* const* aux_maps, float* const* outs,
                              int32_t n_jobs, int64_t n, const int32_t* n_dev, void* stream);
+/* The same launch for the training forward: every job also writes its post-ReLU hidden activations h1s[i], h2s[i]
+ * [n][128] (what tir_mlp_train_fwd_bf16x3 returns for one decoder). */
+int tir_mlp_train_fwd_multi_bf16x3(const TirMlp* const* mlps, const float* const* feats, int32_t feat_stride,
+                                   const float* const* auxs, const int32_t* const* aux_maps, float* const* outs,
+                                   float* const* h1s, float* const* h2s, int32_t n_jobs, int64_t n,
+                                   const int32_t* n_dev, void* stream);
 /* single bf16 product (8 mantissa bits): reduced-precision mode, NOT parity grade (normals ~5e-3). */
 int tir_mlp_fwd_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
                      const int32_t* aux_map, int32_t aux_mod, float* out, int64_t n, const int32_t* n_dev,

@@ -631,18 +631,19 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
 // on the same records): the grid is split evenly, a workgroup loads ITS decoder's operand image once and walks that
 // decoder's tiles.  Against one launch per decoder: one 150 KB LDS fill per workgroup instead of four, one tail instead
 // of four (at 230 k rows a launch is only 3.5 tiles per workgroup).
-struct TirMlpJob { const float* packed; const float* feat; const float* aux; const int32_t* aux_map; float* out; int out_dim, act; };
+struct TirMlpJob { const float* packed; const float* feat; const float* aux; const int32_t* aux_map; float* out; int out_dim, act;
+                   float* h1; float* h2; };
 struct TirMlpJobs { TirMlpJob j[4]; int n_jobs; };
 
-template <int NPROD>
+template <int NPROD, bool SAVE = false>
 __global__ void __launch_bounds__(512)
 k_mlp_bf16_multi(TirMlpJobs jobs, int fstride, int64_t n, const int32_t* __restrict__ n_dev) {
     const int per = (int)gridDim.x / jobs.n_jobs;
     const int ji = (int)blockIdx.x / per;
     if (ji >= jobs.n_jobs) return;
     const TirMlpJob& jb = jobs.j[ji];
-    mlp_bf16_body<NPROD, true, false>(jb.packed, jb.feat, fstride, jb.aux, jb.aux_map, 0, jb.out, n, n_dev, jb.out_dim, jb.act,
-                                      nullptr, nullptr, (int)blockIdx.x - ji * per, per);
+    mlp_bf16_body<NPROD, true, SAVE>(jb.packed, jb.feat, fstride, jb.aux, jb.aux_map, 0, jb.out, n, n_dev, jb.out_dim, jb.act,
+                                     jb.h1, jb.h2, (int)blockIdx.x - ji * per, per);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1198,10 +1199,12 @@ extern "C" int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t fe
     return launch_bf16<3>(m, feat, feat_stride, aux, aux_map, aux_mod, out, n, n_dev, stream);
 }
 
-extern "C" int tir_mlp_fwd_multi_bf16x3(const TirMlp* const* mlps, const float* const* feats, int32_t feat_stride,
-                                        const float* const* auxs, const int32_t* const* aux_maps, float* const* outs,
-                                        int32_t n_jobs, int64_t n, const int32_t* n_dev, void* stream) {
+template <bool SAVE>
+static int launch_multi(const TirMlp* const* mlps, const float* const* feats, int32_t feat_stride, const float* const* auxs,
+                        const int32_t* const* aux_maps, float* const* outs, float* const* h1s, float* const* h2s,
+                        int32_t n_jobs, int64_t n, const int32_t* n_dev, void* stream) {
     if (n_jobs < 1 || n_jobs > 4 || !mlps || !feats || !auxs || !outs || n < 0) return TIR_ERR_ARG;
+    if (SAVE && (!h1s || !h2s)) return TIR_ERR_ARG;
     if (feat_stride % 4 != 0 || feat_stride < F + 1) return TIR_ERR_ARG;          // rows must take the dwordx4 loads
     TirMlpJobs jobs;
     jobs.n_jobs = n_jobs;
@@ -1209,14 +1212,15 @@ extern "C" int tir_mlp_fwd_multi_bf16x3(const TirMlp* const* mlps, const float* 
         int rc = check_mlp(mlps[i]);
         if (rc) return rc;
         if (n > 0 && (!feats[i] || !auxs[i] || !outs[i])) return TIR_ERR_ARG;
+        if (SAVE && n > 0 && (!h1s[i] || !h2s[i])) return TIR_ERR_ARG;
         if (reinterpret_cast<uintptr_t>(feats[i]) % 16 != 0) return TIR_ERR_ARG;
         jobs.j[i] = TirMlpJob{mlps[i]->packed, feats[i], auxs[i], aux_maps ? aux_maps[i] : nullptr, outs[i], mlps[i]->out_dim,
-                              mlps[i]->act};
+                              mlps[i]->act, SAVE ? h1s[i] : nullptr, SAVE ? h2s[i] : nullptr};
     }
     if (n == 0) return TIR_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bf16_multi<3>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bf16_multi<3, SAVE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_BYTES);
         if (e != hipSuccess) return -(int)e;
         attr_set = true;
@@ -1224,10 +1228,23 @@ extern "C" int tir_mlp_fwd_multi_bf16x3(const TirMlp* const* mlps, const float* 
     const int64_t tiles = (n + 255) / 256;
     int per = 256 / n_jobs;
     if (tiles < per) per = (int)tiles;
-    hipLaunchKernelGGL(k_mlp_bf16_multi<3>, dim3((unsigned)(per * n_jobs)), dim3(512), (size_t)BF_BYTES, tir_stream(stream), jobs,
-                       feat_stride, n, n_dev);
+    hipLaunchKernelGGL((k_mlp_bf16_multi<3, SAVE>), dim3((unsigned)(per * n_jobs)), dim3(512), (size_t)BF_BYTES, tir_stream(stream),
+                       jobs, feat_stride, n, n_dev);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
+}
+
+extern "C" int tir_mlp_fwd_multi_bf16x3(const TirMlp* const* mlps, const float* const* feats, int32_t feat_stride,
+                                        const float* const* auxs, const int32_t* const* aux_maps, float* const* outs,
+                                        int32_t n_jobs, int64_t n, const int32_t* n_dev, void* stream) {
+    return launch_multi<false>(mlps, feats, feat_stride, auxs, aux_maps, outs, nullptr, nullptr, n_jobs, n, n_dev, stream);
+}
+
+extern "C" int tir_mlp_train_fwd_multi_bf16x3(const TirMlp* const* mlps, const float* const* feats, int32_t feat_stride,
+                                              const float* const* auxs, const int32_t* const* aux_maps, float* const* outs,
+                                              float* const* h1s, float* const* h2s, int32_t n_jobs, int64_t n,
+                                              const int32_t* n_dev, void* stream) {
+    return launch_multi<true>(mlps, feats, feat_stride, auxs, aux_maps, outs, h1s, h2s, n_jobs, n, n_dev, stream);
 }
 
 extern "C" int tir_mlp_fwd_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map, int32_t aux_mod,

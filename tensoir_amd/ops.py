@@ -266,9 +266,10 @@ if MLP_IMPL not in MLP_ENTRY:
     raise ValueError(f"TENSOIR_DECODER={MLP_IMPL!r}: expected one of {sorted(MLP_ENTRY)}")
 
 
-def mlp_multi(jobs, n_dev=None):
+def mlp_multi(jobs, n_dev=None, save_hidden=False):
     """Several decoders over the same rows in one launch (tir_mlp_fwd_multi_bf16x3).  jobs: list of up to four
-    (PackedMlp, feat [n, FEAT_STRIDE], aux [*, 3], aux_map or None); returns the list of outputs [n, out_dim]."""
+    (PackedMlp, feat [n, FEAT_STRIDE], aux [*, 3], aux_map or None); returns the list of outputs [n, out_dim] -- with
+    save_hidden (training forward, tir_mlp_train_fwd_multi_bf16x3) the list of (out, h1 [n,128], h2 [n,128])."""
     n = jobs[0][1].shape[0]
     k = len(jobs)
     feats, auxs, maps, outs = [], [], [], []
@@ -285,6 +286,12 @@ def mlp_multi(jobs, n_dev=None):
         outs.append(torch.empty((n, m.out_dim), dtype=torch.float32, device=feat.device))
     arr = lambda ts: (C.c_void_p * k)(*[None if t is None else t.data_ptr() for t in ts])
     descs = (C.POINTER(TirMlp) * k)(*[C.pointer(m.desc) for m, _, _, _ in jobs])
+    if save_hidden:
+        h1s = [torch.empty((n, 128), dtype=torch.float32, device=outs[0].device) for _ in range(k)]
+        h2s = [torch.empty((n, 128), dtype=torch.float32, device=outs[0].device) for _ in range(k)]
+        _call("tir_mlp_train_fwd_multi_bf16x3", descs, arr(feats), FEAT_STRIDE, arr(auxs), arr(maps), arr(outs), arr(h1s), arr(h2s),
+              k, n, _ptr(n_dev), _stream())
+        return list(zip(outs, h1s, h2s))
     _call("tir_mlp_fwd_multi_bf16x3", descs, arr(feats), FEAT_STRIDE, arr(auxs), arr(maps), arr(outs), k, n, _ptr(n_dev),
           _stream())
     return outs

@@ -209,31 +209,48 @@ class PrimaryRenderFn(torch.autograd.Function):
         rgb = brdf = brdf_j = pred = derived = None
         if A > 0:
             viewdirs = rays[:, 3:6].contiguous()
-            rad, intr = ops.vm_app(f, rec_xyz, lidx, rec_ray, True, bool(is_relight), None, 0, n_dev)
-            rgb, h1, h2 = ops.mlp_train(model.renderModule.packed(), rad, viewdirs, rec_ray, n_dev=n_dev)
-            st.calls["rgb"] = _DecoderCall(feat=rad, aux=viewdirs, aux_map=rec_ray, out=rgb, h1=h1, h2=h2)
-            if is_relight:
-                pb = model.renderModule_brdf.packed()
-                brdf, h1, h2 = ops.mlp_train(pb, intr, rec_xyz, n_dev=n_dev)
-                st.calls["brdf"] = _DecoderCall(feat=intr, aux=rec_xyz, aux_map=None, out=brdf, h1=h1, h2=h2)
-                if noise_dense is not None:
+            merged = bool(is_relight) and noise_dense is None and f.n_acomp == 48 and ops.APP_IMPL == "mfma"
+            xyz_j = intr_j = None
+            if merged:
+                # records + jittered records in one gather launch; the noise is drawn in the kernel, keyed by (seed, pass
+                # counter, record index): the draw does not depend on the record-capacity hint, so a fixed torch seed
+                # reproduces the run
+                rng_state = model._jitter_rng(dev)
+                rad, intr, xyz_j, intr_j = ops.vm_app_primary(f, rec_xyz, lidx, rec_ray, 0.01, rng_state, n_dev)
+                rng_state[1] += 1
+            else:
+                rad, intr = ops.vm_app(f, rec_xyz, lidx, rec_ray, True, bool(is_relight), None, 0, n_dev)
+                if is_relight and noise_dense is not None:
                     noise = noise_dense.to(dev, torch.float32)[rec_ray.long(), rec_k.long()]
                     xyz_j = torch.add(rec_xyz, noise, alpha=0.01)
                     intr_j = ops.vm_app(f, xyz_j, None, None, False, True, None, 0, n_dev)[1]
-                else:
-                    # noise drawn in the gather kernel, keyed by (seed, pass counter, record index): the draw does not depend
-                    # on the record-capacity hint, so a fixed torch seed reproduces the run
+                elif is_relight:
                     rng_state = model._jitter_rng(dev)
                     xyz_j, intr_j = ops.vm_app_jitter(f, rec_xyz, 0.01, 0, 0, rng_state, n_dev)
                     rng_state[1] += 1
-                brdf_j, h1, h2 = ops.mlp_train(pb, intr_j, xyz_j, n_dev=n_dev)
-                st.calls["brdf_j"] = _DecoderCall(feat=intr_j, aux=xyz_j, aux_map=None, out=brdf_j, h1=h1, h2=h2)
+            # the decoders of the stage: (name, module, features, aux, aux_map)
+            jobs = [("rgb", model.renderModule, rad, viewdirs, rec_ray)]
+            if is_relight:
+                jobs.append(("brdf", model.renderModule_brdf, intr, rec_xyz, None))
+                jobs.append(("brdf_j", model.renderModule_brdf, intr_j, xyz_j, None))
+                if model.normals_kind != "purely_derived":
+                    jobs.append(("normal", model.renderModule_normal, intr, rec_xyz, None))
+            if ops.MLP_IMPL == "bf16x3" and ops.FEAT_STRIDE == rad.shape[1]:
+                # same records for every decoder: ONE launch, the grid split between them
+                res = ops.mlp_multi([(d.packed(), ft, ax, mp) for _, d, ft, ax, mp in jobs], n_dev, save_hidden=True)
+            else:
+                res = [ops.mlp_train(d.packed(), ft, ax, mp, n_dev=n_dev) for _, d, ft, ax, mp in jobs]
+            outs = {}
+            for (name, _, ft, ax, mp), (o, h1, h2) in zip(jobs, res):
+                outs[name] = o
+                st.calls[name] = _DecoderCall(feat=ft, aux=ax, aux_map=mp, out=o, h1=h1, h2=h2)
+            rgb, brdf, brdf_j = outs["rgb"], outs.get("brdf"), outs.get("brdf_j")
+            if is_relight:
                 st.xyz_j = xyz_j
                 if model.normals_kind == "purely_derived":
                     pred = ops.density_grad(f, rec_xyz, n_dev=n_dev)[2]
                 else:
-                    pred, h1, h2 = ops.mlp_train(model.renderModule_normal.packed(), intr, rec_xyz, n_dev=n_dev)
-                    st.calls["normal"] = _DecoderCall(feat=intr, aux=rec_xyz, aux_map=None, out=pred, h1=h1, h2=h2)
+                    pred = outs["normal"]
                     if model.normals_kind == "derived_plus_predicted":
                         derived = ops.density_grad(f, rec_xyz, n_dev=n_dev)[2]
         st.rgb, st.brdf, st.brdf_j, st.pred, st.derived = rgb, brdf, brdf_j, pred, derived
