@@ -721,6 +721,8 @@ class TensorVMSplit(nn.Module):
                                                                                             cap, words)
             self.__dict__["_rec_counter_armed"] = words[1:3]
             A, n_dev = cap, offsets[B:]
+            # eager calls: the count travels to the host while the rest of the pass is queued (no queue drain at the check)
+            total_host = None if self.__dict__.get("_capture") is not None else ops.AsyncCount(total_dev)
         rec_ray, rec_k, rec_w, rec_xyz = ops.compact_primary(f, rays, jitter, weight, offsets, A)
         rgb = brdf = brdf_j = pred = derived = None
         rng_state = None
@@ -782,7 +784,7 @@ class TensorVMSplit(nn.Module):
 
         def finish():
             """True when the pass is valid; False when the record capacity overflowed (the caller re-runs)."""
-            total = A if total_dev is None else int(total_dev.item())
+            total = A if total_dev is None else (total_host.get() if total_host is not None else int(total_dev.item()))
             if len(hints) > 64:
                 hints.clear()
             hints[(B, S)] = min(max(int(total * 1.25) + 4096, 1 << 14), B * S)

@@ -58,6 +58,27 @@ def _stream(t=None):
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class AsyncCount:
+    """A device-side int32 counter on its way to the host: the copy into pinned memory and an event are queued NOW, on the
+    current stream, right behind the kernel that produced the counter.  `get()` waits for that event only -- not for the
+    launches queued afterwards -- so a capacity check at the end of a pass does not drain the launch queue (with
+    `tensor.item()` it does: the GPU then idles while the host queues the next stage)."""
+
+    def __init__(self, counter):
+        self.pin = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        self.pin.copy_(counter.view(-1)[:1], non_blocking=True)
+        self.ev = torch.cuda.Event()
+        self.ev.record(torch.cuda.current_stream())
+        self.value = None
+
+    def get(self) -> int:
+        if self.value is None:
+            self.ev.synchronize()
+            self.value = int(self.pin[0])
+            self.pin = None
+        return self.value
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 

@@ -74,6 +74,8 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
         vis, oma, rec = ops.march_secondary(f, origins, dirs, z, n_rays, org_map, dir_map, active,
                                             tensoIR.march_t_stop, True, cap, want_nerfactor, n_dirs, **extra)
         n_total, n_dev = rec["counter"][0:1], rec["counter"][1:2]      # all records / the written prefix consumers may read
+        # later attempts: the count travels to the host while the gather / decoder launches are queued
+        total_host = None if (first or capture is not None) else ops.AsyncCount(n_total)
         if first:                                      # no history yet: learn the count before sizing buffers
             total = int(n_total.item())
             if total > cap:
@@ -102,8 +104,8 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
             capture.append((n_total, cap, ("secondary", n_rays)))
             return vis, oma, indirect
         if defer:                                      # the caller checks after ITS remaining launches are queued too
-            def check(n_total=n_total, cap=cap):
-                total = int(n_total.item())
+            def check(total_host=total_host, cap=cap):
+                total = total_host.get()
                 if total > cap:
                     hints.pop(n_rays, None)            # the re-run learns the count first
                     return False
@@ -111,7 +113,7 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
                 return True
             tensoIR.__dict__.setdefault("_pending_checks", []).append(check)
             return vis, oma, indirect
-        total = int(n_total.item())                    # everything is queued: this wait costs no GPU idle time
+        total = total_host.get()                       # waits for the march only, not for what was queued behind it
         if total <= cap:
             break
         cap = int(total * 1.25) + 1024                 # overflow: some rays were dropped -> redo with room

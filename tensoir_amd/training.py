@@ -201,6 +201,7 @@ class PrimaryRenderFn(torch.autograd.Function):
         else:
             offsets, total_dev = ops.exclusive_scan_capped(cnt, cap)
             A, n_dev = cap, offsets[B:]
+            total_host = ops.AsyncCount(total_dev)       # on its way to the host while the rest of the pass is queued
         rec_ray, rec_k, rec_w, rec_xyz = ops.compact_primary(f, rays, jitter, weight, offsets, A)
         st = SimpleNamespace(model=model, rays=rays, lidx=lidx, S=S, white_bg=white_bg, is_relight=is_relight,
                              jitter=jitter, weight=weight, sigma=sigma, acc=acc, depth=depth, offsets=offsets, A=A,
@@ -264,7 +265,7 @@ class PrimaryRenderFn(torch.autograd.Function):
             if total_dev is None:
                 total = A
             else:
-                total = int(total_dev.item())
+                total = total_host.get()
                 if total > cap:
                     hints.pop((B, S), None)            # next call takes the exact (synchronising) route
                     st.valid = False

@@ -12,7 +12,7 @@ import bench
 from tensoir_amd import Renderer_TensoIR_train, ops
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--steps", type=int, default=60)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--samples", type=int, default=512)
@@ -58,10 +58,9 @@ def step():
 
 
 l0 = step()
-t_end = time.perf_counter() + 0.6          # untimed: bring the GPU out of its idle power state (a fresh box ramps its clocks
-while time.perf_counter() < t_end:         # over the first ~100 ms: 13 ms per step instead of 7 measured right after start)
-    step()
-    torch.cuda.synchronize()
+for _ in range(100):                       # untimed, a fixed count (the scene trains while it is timed: same trajectory every
+    step()                                 # run): brings the GPU out of its idle power state -- a fresh box ramps its clocks
+    torch.cuda.synchronize()               # over the first ~100 ms, 13 ms per step instead of 6 measured right after start
 for _ in range(a.warmup):
     step()
 torch.cuda.synchronize()
