@@ -51,17 +51,22 @@ def _packed_bwd(dec):
 
 
 def _grad_buffers(model, field):
-    """Zero-filled gradient buffers in the packed channel-last layout + their TirFieldGrad descriptor."""
+    """Zero-filled gradient buffers in the packed channel-last layout + their TirFieldGrad descriptor.  One allocation and
+    ONE fill launch for all fourteen: each buffer is a view of the flat block with the strides of what the kernels gather
+    from (the channel-last parameter itself or its packed shadow)."""
     keep = model._field_cache
-    bufs = {}
+    names = [f"{name}{i}" for i in range(3) for name in ("dp", "dl", "ap", "al")] + ["ll", "lm"]
+    srcs = [keep[n] for n in names]
+    offs, total = [], 0
+    for t in srcs:
+        offs.append(total)
+        total += (t.numel() + 3) // 4 * 4                 # 16-byte aligned starts
+    flat = torch.zeros((total,), dtype=torch.float32, device=srcs[0].device)
+    bufs = {n: torch.as_strided(flat, t.shape, t.stride(), o) for n, t, o in zip(names, srcs, offs)}
     g = TirFieldGrad()
     for i in range(3):
         for name, dst in (("dp", g.dplane), ("dl", g.dline), ("ap", g.aplane), ("al", g.aline)):
-            t = torch.zeros_like(keep[f"{name}{i}"])
-            bufs[f"{name}{i}"] = t
-            dst[i] = t.data_ptr()
-    bufs["ll"] = torch.zeros_like(keep["ll"])
-    bufs["lm"] = torch.zeros_like(keep["lm"])
+            dst[i] = bufs[f"{name}{i}"].data_ptr()
     g.light_line, g.light_mean = bufs["ll"].data_ptr(), bufs["lm"].data_ptr()
     bufs["desc"] = g
     return bufs
