@@ -541,6 +541,9 @@ def main():
                             "settles below the 2.4 GHz the peak assumes; all-zero data (same instructions) runs at 2.39 GHz and "
                             "15-26 % faster", "board_power_W": "1330-1400", "sustained_sclk_GHz": "1.93-2.07",
                     "frac_at_sustained_clock": round(r["frac"] * 2.4 / 2.0, 4),
+                    "bf16_matrix_rate_TF": round(3.0 * r["achieved"], 1),
+                    "reference_point": "MI355X_MICROARCH.md (DVFS give-back): a tuned bf16 attention main loop sustains 1247 TF "
+                                       "on random data, 1483 TF on zeros; limit study of this kernel: profiles/r02_mlp_limit_study.txt",
                     "source": "tools/mlp_power.py -> profiles/r02_mlp_power.txt (rocm-smi polled during the launches)"}
             o["peak_source"] = ("dense bf16 MFMA 2.5 PF / 3 products of the split-bf16 scheme" if r["kernel"].endswith("bf16x3")
                                 else "dense f32 MFMA 157.3 TF")
