@@ -11,6 +11,8 @@ non-fp32 or non-CUDA parameters) raise -- nothing falls back silently.
 """
 from __future__ import annotations
 
+import functools
+
 import torch
 
 from . import ops
@@ -19,15 +21,20 @@ from ._lib import TensoirHipError
 _TorchAdam = torch.optim.Adam
 
 
-def _dense_key(t):
-    """Strides over the dims of extent > 1 if `t` is non-overlapping and dense, else None."""
-    dims = sorted((st, sz) for sz, st in zip(t.shape, t.stride()) if sz > 1)
+@functools.lru_cache(maxsize=512)
+def _dense_key_of(shape, stride):
+    dims = sorted((st, sz) for sz, st in zip(shape, stride) if sz > 1)
     expect = 1
     for st, sz in dims:
         if st != expect:
             return None
         expect *= sz
-    return tuple(st for sz, st in zip(t.shape, t.stride()) if sz > 1)
+    return tuple(st for sz, st in zip(shape, stride) if sz > 1)
+
+
+def _dense_key(t):
+    """Strides over the dims of extent > 1 if `t` is non-overlapping and dense, else None."""
+    return _dense_key_of(tuple(t.shape), t.stride())
 
 
 class Adam(_TorchAdam):
@@ -61,10 +68,11 @@ class Adam(_TorchAdam):
                     raise NotImplementedError("tensoir_amd.optim.Adam: dense fp32 parameters and gradients only")
                 if not p.is_cuda:
                     raise TensoirHipError("tensoir_amd.optim.Adam.step needs the parameters on an MI355X (no CPU path)")
-                key = _dense_key(p)
+                ps = p.stride()
+                key = _dense_key_of(tuple(p.shape), ps)
                 if key is None:
                     raise NotImplementedError("tensoir_amd.optim.Adam: parameters must be non-overlapping and dense")
-                if _dense_key(g) != key:
+                if g.stride() != ps and _dense_key(g) != key:
                     g = torch.empty_like(p).copy_(g)          # autograd's layout contract makes this the rare case
                 state = self.state[p]
                 if len(state) == 0:
@@ -72,7 +80,7 @@ class Adam(_TorchAdam):
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 m, v = state["exp_avg"], state["exp_avg_sq"]
-                if _dense_key(m) != key or _dense_key(v) != key:      # e.g. a state_dict loaded into another layout
+                if (m.stride() != ps and _dense_key(m) != key) or (v.stride() != ps and _dense_key(v) != key):      # e.g. a state_dict loaded into another layout
                     m = state["exp_avg"] = torch.empty_like(p).copy_(m)
                     v = state["exp_avg_sq"] = torch.empty_like(p).copy_(v)
                 state["step"] += 1
