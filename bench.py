@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--no-exact-pass", action="store_true", help="skip the extra timed pass with the exact fp32 decoders")
     ap.add_argument("--breakdown", type=str, default="", help="write the per-kernel table to this file")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying the HIP graph")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="independent batches in flight: that many captured graphs of the step, replayed round-robin on as many "
+                         "HIP streams (a step's kernels have tails in which CUs idle; another batch fills them).  1 = one stream")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--no-sharp-scene", action="store_true",
                     help="skip the secondary (informative) line on a sharp-surface scene (10-30 appearance samples per ray, as a "
@@ -304,12 +307,16 @@ def main():
     graphed = {}
 
     def make_graph(impl):
+        """One captured step per batch in flight (each with its own input / output buffers and device-side pass state)."""
         ops.MLP_IMPL = impl
-        gr = GraphedRenderer(model, B, N_samples=a.samples, args=args, device=device)
-        gr.rays.copy_(rays)                          # the batch is resident in HBM: it sits in the graph's input buffers
-        gr.lidx.copy_(lidx)
-        gr(clone_outputs=False)                      # capture + one checked replay
-        graphed[impl] = gr
+        grs = []
+        for _ in range(max(1, a.in_flight) if impl == a.decoder else 1):
+            gr = GraphedRenderer(model, B, N_samples=a.samples, args=args, device=device)
+            gr.rays.copy_(rays)                      # the batch is resident in HBM: it sits in the graph's input buffers
+            gr.lidx.copy_(lidx)
+            gr(clone_outputs=False)                  # capture + one checked replay
+            grs.append(gr)
+        graphed[impl] = grs
 
     # Every rank captures its step graph(s) BEFORE the process group exists: no RCCL thread is alive yet that could
     # issue a call into the runtime while the stream is capturing.  Replays and the per-step all-gather then simply
@@ -328,9 +335,33 @@ def main():
         for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(k, v)               # --force-dist in a bare single process
         dist.init_process_group(a.backend, **({"device_id": device} if a.backend == "nccl" else {}))
-    gathered = torch.empty((world * B, tdist.RECORD), dtype=torch.float32, device=device) if use_dist else None
+    lanes = max(1, a.in_flight)
+    gathered = [torch.empty((world * B, tdist.RECORD), dtype=torch.float32, device=device) for _ in range(lanes)] if use_dist else None
+    streams = [torch.cuda.Stream(device=device) for _ in range(lanes)]
+    state = {"i": 0, "lanes": lanes}
+
+    def fork():
+        """The lanes' streams start behind everything queued on the current stream."""
+        cur = torch.cuda.current_stream()
+        for st in streams[:state["lanes"]]:
+            st.wait_stream(cur)
+
+    def join():
+        cur = torch.cuda.current_stream()
+        for st in streams[:state["lanes"]]:
+            cur.wait_stream(st)
 
     def step(eager=False):
+        """One pass over one batch.  Graph replays go round-robin over the lanes (batch i on stream i mod lanes, through that
+        lane's own captured graph); eager passes and the one-lane mode run on the current stream."""
+        if eager or a.no_graph or state["lanes"] == 1:
+            return step_on(0, eager)
+        lane = state["i"] % state["lanes"]
+        state["i"] += 1
+        with torch.cuda.stream(streams[lane]):
+            return step_on(lane, eager)
+
+    def step_on(lane, eager):
         with torch.no_grad():
             if a.no_graph or eager:
                 ret = Renderer_TensoIR_train(rays, None, lidx, model, N_samples=a.samples, white_bg=True,
@@ -342,7 +373,8 @@ def main():
                         if use_dist:
                             raise RuntimeError("no graph was captured for this decoder mode before the process group was created")
                         make_graph(ops.MLP_IMPL)
-                    gr = graphed[ops.MLP_IMPL]
+                    grs = graphed[ops.MLP_IMPL]
+                    gr = grs[lane % len(grs)]
                     # outputs stay in the graph's buffers (valid until the next step); the record-capacity check of all
                     # queued replays is made once, inside the timed region, by validate() below
                     ret = gr(clone_outputs=False, defer_check=not getattr(a, "no_defer", False))
@@ -350,9 +382,9 @@ def main():
                     print(f"[bench] HIP-graph replay unavailable ({type(e).__name__}: {e}); using eager launches",
                           file=sys.stderr, flush=True)
                     a.no_graph = True
-                    return step()
+                    return step_on(lane, eager)
             if use_dist:   # the one exchange step: all-gather of the rendered per-ray records
-                dist.all_gather_into_tensor(gathered, tdist.pack_records(ret))
+                dist.all_gather_into_tensor(gathered[lane], tdist.pack_records(ret))
         return ret
 
     def settle(n_steps=300):
@@ -360,23 +392,29 @@ def main():
         work run at ramping clocks: 2.5 ms per step instead of 1.85 measured right after process start).  A FIXED number
         of steps (~0.5 s), not a time budget: with several ranks every step ends in a collective, so all ranks must run the
         same number of them."""
+        fork()
         for i in range(n_steps):
             step()
             if i % 10 == 9:
                 torch.cuda.synchronize()
+        join()
 
     def timed(n_warm, n_steps):
+        fork()
         for _ in range(n_warm):
             step()
+        join()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         r = None
+        fork()
         for _ in range(n_steps):
             r = step()
+        join()
         torch.cuda.synchronize()
-        valid = all(g.validate() for g in graphed.values())        # sticky overflow flag of every replay queued above
+        valid = all(g.validate() for grs in graphed.values() for g in grs)     # sticky overflow flag of every replay queued above
         if use_dist:
             dist.barrier()
         el = time.perf_counter() - t0
@@ -400,10 +438,25 @@ def main():
     ops.MLP_IMPL = a.decoder
     settle()
     elapsed, ret = timed(a.warmup, a.steps)
+    single = None
+    if state["lanes"] > 1 and not a.no_graph:            # the same steps one at a time on one stream, for reference
+        state["lanes"] = 1
+        el1, _ = timed(1, max(1, a.steps // 2))
+        state["lanes"] = lanes
+        single = {"in_flight": 1, "value": round(n_gpus * B * max(1, a.steps // 2) / el1, 1),
+                  "ms_per_step": round(1e3 * el1 / max(1, a.steps // 2), 4)}
+        if graphed.get(a.decoder) and len(graphed[a.decoder]) > 1:      # every lane's graph computes the same maps, bit for bit
+            o0 = graphed[a.decoder][0].out
+            for g in graphed[a.decoder][1:]:
+                for k, v in o0.items():
+                    if torch.is_tensor(v) and "smoothness" not in k and not torch.equal(v, g.out[k]):
+                        raise SystemExit(f"[bench] lanes disagree on {k}")
     exact = None
     if a.decoder != "mfma" and not a.no_exact_pass:      # same workload with the exact-fp32 decoders, for reference
         ops.MLP_IMPL = "mfma"
+        state["lanes"] = 1                               # one captured graph for this reference pass
         el2, _ = timed(1, max(1, a.steps // 2))
+        state["lanes"] = lanes
         exact = {"decoder": "mfma (exact fp32)", "value": round(n_gpus * rays.shape[0] * max(1, a.steps // 2) / el2, 1),
                  "ms_per_step": round(1e3 * el2 / max(1, a.steps // 2), 4)}
         ops.MLP_IMPL = a.decoder
@@ -644,7 +697,12 @@ def main():
                    "rays_per_gpu": B, "samples": a.samples, "grid": a.grid, "light_dirs": D,
                    "second_samples": a.second_samples, "surface_points": M,
                    "sharding": f"dp{n_gpus} over rays, all-gather of {tdist.RECORD * 4} B/ray records",
-                   "launch": "eager" if a.no_graph else "hip-graph replay (one graph per step)"},
+                   "launch": "eager" if a.no_graph else "hip-graph replay (one graph per step)",
+                   "in_flight": 1 if a.no_graph else lanes,
+                   "in_flight_note": "independent batches in flight per GPU: batch i replays lane (i mod in_flight)'s captured graph "
+                                     "on that lane's HIP stream; every batch is a full step, lanes checked bit-identical; "
+                                     "per-kernel rooflines are measured one kernel at a time (eager pass on one stream)"},
+        "single_stream": single,
         "decoder": {"mode": a.decoder, "note": "bf16x3 = x=hi+lo bf16 split, 3 MFMA products, fp32 accumulate; parity-tested at 1e-4"
                     if a.decoder == "bf16x3" else "exact fp32 MFMA"},
         "exact_fp32_decoders": exact,

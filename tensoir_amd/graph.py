@@ -10,6 +10,11 @@ host memory (tir_record_check), so NOTHING is launched between replays: the host
 samples than the captured capacity) re-captures with room for the largest count seen.  Results are identical to the
 eager path.
 
+Several renderers of one model may be in flight at once (two batches on two HIP streams fill each other's kernel tails:
++10-14 % whole-job rate, `tools/two_stream_probe.py`): every renderer owns the device-side words its pass re-arms (pair /
+record counters, last-workgroup tickets, the jitter RNG state) and installs them in the model while it runs eager calls
+or captures.
+
 Constraints (checked): inference only (no autograd, ``is_train=False``), ``sample_method='fixed_envirmap'`` (the
 stratified direction jitter is a host-side RNG draw), fixed number of rays per call.
 """
@@ -39,6 +44,7 @@ class GraphedRenderer:
         # maxima over all replays [4:8], sticky overflow flag [8]; `_state` is the device side of maxima + flag
         self._host = torch.zeros((9,), dtype=torch.int64).pin_memory()             # allocated outside any capture
         self._state = torch.zeros((5,), dtype=torch.int64, device=self.device)
+        self._own = {}                  # this renderer's device-side pass state (see _own_state)
         self._deferred = 0              # replays queued with defer_check=True since the last validate()
         self.captures = 0
         self._model_key = None          # what the captured descriptors were built from (see _stale)
@@ -57,8 +63,25 @@ class GraphedRenderer:
     def _stale(self):
         return self.graph is not None and self._key() != self._model_key
 
+    _OWN_KEYS = ("_words", "_pair_counter", "_jit_rng")
+
+    def _own_state(self):
+        """Context manager: while it is open the model's per-pass device words are THIS renderer's (created by the
+        model's own accessors on first use), so that another renderer's graph can replay concurrently."""
+        r, d = self, self.model.__dict__
+
+        class _Swap:
+            def __enter__(self):
+                self.saved = {k: d.pop(k) for k in r._OWN_KEYS if k in d}
+                d.update(r._own)
+
+            def __exit__(self, *exc):
+                r._own = {k: d.pop(k) for k in r._OWN_KEYS if k in d}
+                d.update(self.saved)
+        return _Swap()
+
     def _eager(self):
-        with torch.no_grad():
+        with torch.no_grad(), self._own_state():
             return Renderer_TensoIR_train(self.rays, None, self.lidx, self.model, **self.kw)
 
     def _capture(self):
@@ -80,7 +103,7 @@ class GraphedRenderer:
         self.model.__dict__["_capture"] = self.checks
         g = torch.cuda.CUDAGraph()
         try:
-            with torch.no_grad(), torch.cuda.graph(g):
+            with torch.no_grad(), self._own_state(), torch.cuda.graph(g):
                 self.out = Renderer_TensoIR_train(self.rays, None, self.lidx, self.model, **self.kw)
                 if self.checks:
                     # the record counters, their running maxima and a sticky overflow flag (never cleared by a replay)
