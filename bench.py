@@ -217,13 +217,11 @@ def bench_image(a):
     rays = synth.make_rays(side, side, narrow=1.0).to(device)
     n = rays.shape[0]
     lidx = (torch.arange(n, device=device) % 3).to(torch.int32).view(-1, 1)
-    fn = tdist.GraphedChunkRenderer(model, a.rays, args, device=device)
+    fn = tdist.GraphedChunkRenderer(model, a.rays, args, device=device, lanes=max(1, a.in_flight))
     with torch.no_grad():          # capture + capacity learning on this rank's own shard, BEFORE any RCCL thread exists:
-        mine = tdist.shard_rows(n, rank, world, a.tile).to(device)       # repeat until the captured capacities hold for the
-        for _ in range(4):                                                # heaviest chunk of the shard
-            for c in torch.split(mine, a.rays):
-                if c.numel() == a.rays:
-                    fn(rays[c], lidx[c])
+        mine = tdist.shard_rows(n, rank, world, a.tile).to(device)       # repeat until the captured capacities of every lane
+        for _ in range(4):                                                # hold for the heaviest chunk of the shard
+            tdist._render_chunks(fn, rays, lidx, mine, a.rays)
             if fn.validate():
                 break
     if use_dist:
@@ -270,7 +268,7 @@ def bench_image(a):
                                    f"{a.second_samples}; full field of view ({hit:.2f} of the rays hit the object)",
                        "sharding": ("contiguous row tiles" if a.tile <= 0 else f"interleaved tiles of {a.tile} rays") +
                                    f", one all_gather_into_tensor of {tdist.RECORD * 4} B/ray records per image",
-                       "launch": "hip-graph replay per chunk, one capacity check per image"},
+                       "launch": "hip-graph replay per chunk, one capacity check per image", "in_flight": max(1, a.in_flight)},
             "world_size": gw, "device_count": torch.cuda.device_count(), "backend": a.backend if use_dist else None,
             "per_rank_render_ms": [round(1e3 * x, 3) for x in per_rank],
             "load_imbalance": round(max(per_rank) / max(min(per_rank), 1e-9), 3),

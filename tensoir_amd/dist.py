@@ -74,6 +74,20 @@ def gather_records(local: torch.Tensor, n_rays: int, rank: int, world: int, tile
     return out
 
 
+def _render_chunks(render_fn, rays, light_idx, mine, chunk):
+    """This rank's chunks -> list of packed record blocks.  A renderer with ``render_packed`` (GraphedChunkRenderer) runs
+    indexing, replay and packing of chunk i on lane (i mod lanes)'s stream -- several chunks in flight -- and is joined
+    before the blocks are used; any other callable is called chunk by chunk on the current stream."""
+    chunks = [c for c in torch.split(mine, chunk) if c.numel()]
+    packed = getattr(render_fn, "render_packed", None)
+    if packed is None:
+        return [pack_records(render_fn(rays[c], light_idx[c])) for c in chunks]
+    render_fn.fork()
+    parts = [packed(rays, light_idx, c) for c in chunks]
+    render_fn.join()
+    return parts
+
+
 def render_sharded(render_fn, rays, light_idx, rank=None, world=None, chunk=4096, tile=0, group=None):
     """Render `rays` ([N,6], identical on every rank) data-parallel over ranks.
 
@@ -89,11 +103,7 @@ def render_sharded(render_fn, rays, light_idx, rank=None, world=None, chunk=4096
     n = rays.shape[0]
     mine = shard_rows(n, rank, world, tile).to(rays.device)
     for attempt in range(4):
-        parts = []
-        for c in torch.split(mine, chunk):
-            if c.numel() == 0:
-                continue
-            parts.append(pack_records(render_fn(rays[c], light_idx[c])))
+        parts = _render_chunks(render_fn, rays, light_idx, mine, chunk)
         validate = getattr(render_fn, "validate", None)
         if validate is None or validate():
             break
@@ -124,7 +134,7 @@ def render_sharded_timed(render_fn, rays, light_idx, rank=None, world=None, chun
     drain()
     t0 = time.perf_counter()
     for attempt in range(4):
-        parts = [pack_records(render_fn(rays[c], light_idx[c])) for c in torch.split(mine, chunk) if c.numel()]
+        parts = _render_chunks(render_fn, rays, light_idx, mine, chunk)
         validate = getattr(render_fn, "validate", None)
         if validate is None or validate():
             break
@@ -140,21 +150,65 @@ def render_sharded_timed(render_fn, rays, light_idx, rank=None, world=None, chun
 
 
 class GraphedChunkRenderer:
-    """render_fn for render_sharded: full chunks replay ONE captured HIP graph with no host wait per chunk (inputs go
-    into the graph's static buffers, outputs are packed straight from them, the record-capacity check of all replays
-    is made once per image by validate()); a ragged last chunk takes the eager renderer."""
+    """render_fn for render_sharded: full chunks replay a captured HIP graph with no host wait per chunk (inputs go into
+    the graph's static buffers, outputs are packed straight from them, the record-capacity check of all replays is made
+    once per image by validate()); a ragged last chunk takes the eager renderer.
 
-    def __init__(self, tensoIR, chunk, args, N_samples=-1, white_bg=True, is_relight=True, device="cuda"):
+    ``lanes`` chunks are in flight at once: lane l owns a captured graph (own buffers, own device-side pass state) and a
+    HIP stream; chunk i is indexed, replayed and packed on lane (i mod lanes).  A step's kernels have tails in which CUs
+    idle; the other lane's chunk fills them (+10-14 % whole-image rate with two lanes, tools/two_stream_probe.py)."""
+
+    def __init__(self, tensoIR, chunk, args, N_samples=-1, white_bg=True, is_relight=True, device="cuda", lanes=2):
         from .graph import GraphedRenderer
         from .renderer import Renderer_TensoIR_train
-        self.gr = GraphedRenderer(tensoIR, chunk, N_samples=N_samples, white_bg=white_bg, is_relight=is_relight,
-                                  args=args, device=device)
+        self.grs = [GraphedRenderer(tensoIR, chunk, N_samples=N_samples, white_bg=white_bg, is_relight=is_relight,
+                                    args=args, device=device) for _ in range(max(1, int(lanes)))]
+        self.gr = self.grs[0]
+        self.streams = None
+        self.device = torch.device(device)
+        self._i = 0
         self._eager = lambda r, l: Renderer_TensoIR_train(r, None, l, tensoIR, N_samples=N_samples, white_bg=white_bg,
                                                           is_train=False, is_relight=is_relight,
                                                           sample_method="fixed_envirmap", device=device, args=args)
 
+    def _lane_streams(self):
+        if self.streams is None:
+            self.streams = [torch.cuda.Stream(device=self.device) for _ in self.grs]
+        return self.streams
+
+    def fork(self):
+        """The lanes start behind everything queued on the caller's stream (the ray tensors, the shard indices)."""
+        cur = torch.cuda.current_stream(self.device)
+        for st in self._lane_streams():
+            st.wait_stream(cur)
+
+    def join(self):
+        """The caller's stream waits for every lane."""
+        cur = torch.cuda.current_stream(self.device)
+        for st in self._lane_streams():
+            cur.wait_stream(st)
+
+    @torch.no_grad()
+    def render_packed(self, rays, light_idx, idx):
+        """Chunk rays[idx] -> packed records [len(idx), RECORD], everything queued on the next lane's stream.  Call fork()
+        before the first chunk and join() before using the blocks (render_sharded does)."""
+        lane = self._i % len(self.grs)
+        self._i += 1
+        gr, st = self.grs[lane], self._lane_streams()[lane]
+        caller = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(st):
+            if idx.numel() != gr.n_rays:
+                rec = pack_records(self._eager(rays[idx], light_idx[idx]))
+            else:
+                torch.index_select(rays, 0, idx, out=gr.rays)
+                gr.lidx.copy_(light_idx[idx].reshape(-1, 1), non_blocking=True)
+                rec = pack_records(gr(clone_outputs=False, defer_check=True))
+            rec.record_stream(caller)          # allocated on the lane's stream, consumed (after join) on the caller's
+        return rec
+
     @torch.no_grad()
     def __call__(self, rays, light_idx):
+        """One chunk on the caller's stream through lane 0's graph (the single-lane interface)."""
         if rays.shape[0] != self.gr.n_rays:
             return self._eager(rays, light_idx)
         self.gr.rays.copy_(rays, non_blocking=True)
@@ -162,7 +216,9 @@ class GraphedChunkRenderer:
         return self.gr(clone_outputs=False, defer_check=True)
 
     def validate(self):
-        return self.gr.validate()
+        if self.streams is not None:
+            self.join()
+        return all([gr.validate() for gr in self.grs])
 
 
 # ---- data-parallel training (the reference itself never all-reduces: section 2.1) ----------

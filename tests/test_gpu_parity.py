@@ -606,14 +606,18 @@ def test_graphed_chunk_renderer_matches_eager_image(env):
               device="cuda", args=env.args)
     eager = lambda r, l: Renderer_TensoIR_train(r, None, l, m, **kw)
     want = tdist.render_sharded(eager, img_rays, img_lidx, rank=0, world=1, chunk=n0)
-    fn = tdist.GraphedChunkRenderer(m, n0, env.args)
-    for _ in range(2):                                                # second image: no re-capture needed any more
-        got = tdist.render_sharded(fn, img_rays, img_lidx, rank=0, world=1, chunk=n0)
-        for k in ("rgb_map", "depth_map", "normal_map", "acc_map", "rgb_with_brdf_map"):
-            assert torch.equal(got[k], want[k]), k
-    caps = fn.gr.captures
-    tdist.render_sharded(fn, img_rays, img_lidx, rank=0, world=1, chunk=n0)
-    assert fn.gr.captures == caps
+    for lanes in (2, 1, 3):                                           # chunks in flight (own graph + stream per lane)
+        fn = tdist.GraphedChunkRenderer(m, n0, env.args, lanes=lanes)
+        for _ in range(2):                                            # second image: no re-capture needed any more
+            got = tdist.render_sharded(fn, img_rays, img_lidx, rank=0, world=1, chunk=n0)
+            for k in ("rgb_map", "depth_map", "normal_map", "acc_map", "rgb_with_brdf_map"):
+                assert torch.equal(got[k], want[k]), (lanes, k)
+        caps = [g.captures for g in fn.grs]
+        tdist.render_sharded(fn, img_rays, img_lidx, rank=0, world=1, chunk=n0)
+        assert [g.captures for g in fn.grs] == caps
+    # the eager renderer is untouched by the lanes' private pass state
+    again = tdist.render_sharded(eager, img_rays, img_lidx, rank=0, world=1, chunk=n0)
+    assert torch.equal(again["rgb_with_brdf_map"], want["rgb_with_brdf_map"])
 
 
 # ---------------------------------------------------------------- fused step kernels (no framework launches inside a step)
