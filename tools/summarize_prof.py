@@ -17,7 +17,7 @@ def short(name):
 
 print("== kernel stats (rocprofv3 --kernel-trace --stats)")
 for f in find("*kernel_stats.csv"):
-    if "/trace/" not in f:
+    if "/trace" not in f:
         continue
     with open(f) as fh:
         rows = list(csv.DictReader(fh))
