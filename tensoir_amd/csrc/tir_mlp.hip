@@ -1162,7 +1162,8 @@ static int launch_bf16_v(const TirMlp* m, const float* feat, int32_t feat_stride
         attr_set = true;
     }
     int64_t tiles = (n + 255) / 256;
-    unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+    static const int grid_max = [] { const char* e = getenv("TENSOIR_MLP_GRID"); int g = e ? atoi(e) : 256; return g > 0 ? g : 256; }();
+    unsigned grid = (unsigned)(tiles < grid_max ? tiles : grid_max);
     hipLaunchKernelGGL((k_mlp_bf16<NPROD, VEC, SAVE>), dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, feat_stride, aux,
                        aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act, h1, h2);
     TIR_CHECK_LAUNCH();
