@@ -66,6 +66,9 @@ typedef struct TirField {
     int32_t occ_dim[3];      /* W,H,D of the mask volume                                            */
     float occ_aabb_min[3];   /* the mask's own aabb (:105) ...                                      */
     float occ_inv[3];        /* ... and (1/size)*2 (:107)                                           */
+    float occ_lo[3];         /* world-space box that contains every point the mask can report as occupied (the occupied   */
+    float occ_hi[3];         /* voxels' extent + one cell): the march kernels skip 32-sample steps that lie outside of it. */
+                             /* occ_lo >= occ_hi on any axis (e.g. all zeros) = not given, nothing is skipped.            */
 } TirField;
 
 /* One 3-layer decoder (in -> hidden ReLU -> hidden ReLU -> out, then activation):

@@ -28,6 +28,7 @@ class TirField(C.Structure):
         ("basis_t", C.c_void_p), ("light_line", C.c_void_p), ("light_mean", C.c_void_p),
         ("occ_nbr", C.c_void_p),
         ("occ_dim", C.c_int32 * 3), ("occ_aabb_min", C.c_float * 3), ("occ_inv", C.c_float * 3),
+        ("occ_lo", C.c_float * 3), ("occ_hi", C.c_float * 3),
     ]
 
 

@@ -351,6 +351,28 @@ __device__ __forceinline__ bool sample_valid(const TirField& f, float px, float 
     return true;
 }
 
+// Parameter range [t0, t1] of the ray o + t d inside the box that contains everything the occupancy mask can report as
+// occupied (TirField::occ_lo / occ_hi; built with 1.25 cells of margin).  Samples outside of it are culled by
+// sample_valid in any case: the march kernels use the range to skip whole 32-sample steps without touching them, which
+// changes no result (a culled sample contributes alpha = 0: T * (1 + 1e-10) == T in fp32, weight 0).  Box not given
+// (occ_lo >= occ_hi) -> (-inf, +inf); the ray misses the box -> t0 > t1.
+__device__ __forceinline__ void occ_t_range(const TirField& f, const float (&o)[3], const float (&d)[3], float& t0, float& t1) {
+    t0 = -INFINITY; t1 = INFINITY;
+    if (!((f.occ_lo[0] < f.occ_hi[0]) & (f.occ_lo[1] < f.occ_hi[1]) & (f.occ_lo[2] < f.occ_hi[2]))) return;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (fabsf(d[a]) < 1e-20f) {
+            if ((o[a] < f.occ_lo[a]) | (o[a] > f.occ_hi[a])) { t0 = INFINITY; t1 = -INFINITY; }
+        } else {
+            const float inv = 1.0f / d[a];
+            const float ta = (f.occ_lo[a] - o[a]) * inv, tb = (f.occ_hi[a] - o[a]) * inv;
+            t0 = fmaxf(t0, fminf(ta, tb));
+            t1 = fminf(t1, fmaxf(ta, tb));
+        }
+    }
+    t0 -= 1e-4f; t1 += 1e-4f;            // fp32 slack of the slab arithmetic itself
+}
+
 // linear2srgb_torch after the [0,1] clip (models/relight_utils.py:489-515)
 __device__ __forceinline__ float linear2srgb(float x) {
     x = fminf(fmaxf(x, 0.0f), 1.0f);

@@ -24,8 +24,16 @@ __device__ __forceinline__ void march_one_ray(const TirField& f, const float* __
     int cnt = 0;
     int k0 = 0;
     unsigned n_gather = 0;
+    float t_in, t_out;                 // where the ray can meet occupied space at all (occ_t_range)
+    occ_t_range(f, rs.o, rs.d, t_in, t_out);
     for (; k0 < S; k0 += 64) {
         const int k = k0 + lane;
+        // the whole 64-sample step lies outside the occupied box: every sample would be culled (alpha 0, T unchanged)
+        if (sample_z(f, rs.t_min, k0, jit, hj) > t_out || sample_z(f, rs.t_min, min(k0 + 63, S - 1), jit, hj) < t_in) {
+            if (k < S) weight[(size_t)ray * S + k] = 0.0f;
+            if (sigma_out && k < S) sigma_out[(size_t)ray * S + k] = 0.0f;
+            continue;
+        }
         float z = 0.0f, x = 0.f, y = 0.f, zz = 0.f;
         bool valid = false;
         if (k < S) {
@@ -737,6 +745,9 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
     const unsigned half_shift = (threadIdx.x & 32) ? 32 : 0;
     const bool want_rec = rec_counter != nullptr;
     unsigned n_gather = 0;
+#ifdef EXP_COUNT_ITERS
+    unsigned n_iters = 0;
+#endif
 
     for (int64_t batch = xr.first; batch < xr.end; batch += xr.stride) {
         float wreg[4][NSTEP];
@@ -762,10 +773,16 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
                 float T = 1.0f, acc = 0.0f;
                 bool done = !live;
                 bool all_done = false;
+                float t_in, t_out;                                  // where the ray can meet occupied space at all
+                occ_t_range(f, o, d, t_in, t_out);
 #pragma unroll
                 for (int st = 0; st < NSTEP; ++st) {
                     const int k = st * 32 + hl;
                     if (!all_done && st * 32 < n_sample) {          // wave-uniform
+                        // both rays of the wave are past (or not yet at) the occupied box for this whole step: every
+                        // sample would be culled -- T, the sums and the record count stay as they are
+                        const bool touches = !done && zt[st * 32] <= t_out && zt[min(st * 32 + 31, n_sample - 1)] >= t_in;
+                        if (!__any(touches)) continue;
                         float z = 0.f, x = 0.f, y = 0.f, zz = 0.f;
                         bool valid = false;
                         const bool on = !done && k < n_sample;
@@ -792,6 +809,10 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
                         const unsigned long long m = __ballot(w > f.weight_thres);
                         cnt += __popc((unsigned)(m >> half_shift));
                         if (stats) n_gather += __popc((unsigned)(__ballot(valid) >> half_shift));
+#ifdef EXP_COUNT_ITERS      // limit study: 16-sample gather iterations of this wave in bits 32.. of the counter (slot fill = samples / 16 / this)
+                        { const unsigned long long vb = __ballot(valid);        // all 64 lanes vote (not inside the branch)
+                          if (stats && half_shift == 0) n_iters += (__popcll(vb) + 15) / 16; }
+#endif
                         T = T * __shfl(incl, 31, 32);
                         if (!done && T < t_stop) done = true;
                         all_done = __all(done);
@@ -884,7 +905,11 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
         // the next batch's s_cnt / s_pid writes come after this batch's readers: s_base / s_bb are only rewritten behind
         // the next batch's first __syncthreads, s_pid[rl] / s_cnt[rl] belong to the half-wave that reads them here
     }
+#ifdef EXP_COUNT_ITERS
+    if (stats && hl == 0 && (n_gather | n_iters)) atomicAdd(stats, (unsigned long long)n_gather + ((unsigned long long)n_iters << 32));
+#else
     if (stats && hl == 0 && n_gather) atomicAdd(stats, (unsigned long long)n_gather);
+#endif
 }
 
 static int g_lds_lines = -1;      // -1: take TENSOIR_LDS_LINES (default on) at the first launch

@@ -103,6 +103,28 @@ class AlphaGridMask(nn.Module):
         return _host_values(self, "geom", (self.aabb, self.invgridSize),
                             lambda: (self.aabb[0].tolist(), self.invgridSize.tolist()))
 
+    def occupied_box(self):
+        """World-space box (lo[3], hi[3]) outside of which sample_alpha is 0: a point is reported occupied when one of
+        the 8 voxels around it is (trilinear lookup > 0, :112-119), i.e. only within one cell of an occupied voxel; the box
+        is the occupied voxels' index extent grown by 1.25 cells (the quarter cell covers fp32 rounding of positions many
+        times over).  Read back once per mask (three tiny reductions); an empty mask gives an empty box."""
+        def compute():
+            vol = self.alpha_volume.reshape(self.alpha_volume.shape[-3:]) > 0          # [D, H, W]
+            lo, hi = [], []
+            amin, size = self.aabb[0].tolist(), self.aabbSize.tolist()
+            for axis, dims in ((0, (0, 1)), (1, (0, 2)), (2, (1, 2))):              # x <- W, y <- H, z <- D
+                n = vol.shape[2 - axis]
+                idx = torch.nonzero(vol.any(dim=dims).reshape(-1))
+                cell = size[axis] / max(n - 1, 1)
+                if idx.numel() == 0:
+                    lo.append(1.0); hi.append(-1.0)
+                    continue
+                i0, i1 = int(idx.min()), int(idx.max())
+                lo.append(amin[axis] + (i0 - 1.25) * cell)
+                hi.append(amin[axis] + (i1 + 1.25) * cell)
+            return lo, hi
+        return _host_values(self, "occ_box", (self.aabb, self.alpha_volume), compute)
+
     def sample_alpha(self, xyz_sampled):
         """Returns 1.0 where the reference's trilinear lookup is > 0 and 0.0 elsewhere (callers only
         ever test ``> 0``: :804, :823, :893-894)."""
@@ -477,6 +499,11 @@ class TensorVMSplit(nn.Module):
             D, H, W = mask.alpha_volume.shape[-3:]
             f.occ_dim[:] = [W, H, D]
             f.occ_aabb_min[:], f.occ_inv[:] = mask.host_geometry()
+            lo, hi = mask.occupied_box()
+            if all(a < b for a, b in zip(lo, hi)):
+                f.occ_lo[:], f.occ_hi[:] = lo, hi
+            else:                                       # empty mask: nothing can be hit -- a degenerate box far away
+                f.occ_lo[:], f.occ_hi[:] = [3.0e38] * 3, [3.4e38] * 3
         keep["desc"] = f
         self._field_cache, self._field_key = keep, key
         return f

@@ -20,11 +20,34 @@ stratified direction jitter is a host-side RNG draw), fixed number of rays per c
 """
 from __future__ import annotations
 
+import gc
+
 import torch
 
 from . import ops, relight  # noqa: F401  (relight: imported for its caches being warmed by the eager call)
 from ._lib import TensoirHipError
 from .renderer import Renderer_TensoIR_train
+
+
+class _OwnState:
+    """See GraphedRenderer._own_state.  (A plain module-level class: an object created per call must not sit in a reference
+    cycle -- cyclic garbage that keeps a renderer, and with it a captured graph, alive until the collector runs could be
+    freed in the middle of ANOTHER capture, and destroying a graph while a stream is capturing aborts the process.)"""
+    __slots__ = ("r", "saved")
+
+    def __init__(self, renderer):
+        self.r, self.saved = renderer, None
+
+    def __enter__(self):
+        d = self.r.model.__dict__
+        self.saved = {k: d.pop(k) for k in GraphedRenderer._OWN_KEYS if k in d}
+        d.update(self.r._own)
+
+    def __exit__(self, *exc):
+        d = self.r.model.__dict__
+        self.r._own = {k: d.pop(k) for k in GraphedRenderer._OWN_KEYS if k in d}
+        d.update(self.saved)
+        self.saved = None
 
 
 class GraphedRenderer:
@@ -68,17 +91,7 @@ class GraphedRenderer:
     def _own_state(self):
         """Context manager: while it is open the model's per-pass device words are THIS renderer's (created by the
         model's own accessors on first use), so that another renderer's graph can replay concurrently."""
-        r, d = self, self.model.__dict__
-
-        class _Swap:
-            def __enter__(self):
-                self.saved = {k: d.pop(k) for k in r._OWN_KEYS if k in d}
-                d.update(r._own)
-
-            def __exit__(self, *exc):
-                r._own = {k: d.pop(k) for k in r._OWN_KEYS if k in d}
-                d.update(self.saved)
-        return _Swap()
+        return _OwnState(self)
 
     def _eager(self):
         with torch.no_grad(), self._own_state():
@@ -102,6 +115,12 @@ class GraphedRenderer:
         self.checks = []
         self.model.__dict__["_capture"] = self.checks
         g = torch.cuda.CUDAGraph()
+        # No garbage collection while the stream is capturing: the collector may free objects that own device resources
+        # (another renderer's graph, an event, pinned memory), and their destructors call into the runtime -- not permitted
+        # during a capture (the process aborts).  Collect what is pending now, then hold the collector off until the end.
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             with torch.no_grad(), self._own_state(), torch.cuda.graph(g):
                 self.out = Renderer_TensoIR_train(self.rays, None, self.lidx, self.model, **self.kw)
@@ -114,6 +133,8 @@ class GraphedRenderer:
                                      self._state, self._host)
         finally:
             self.model.__dict__.pop("_capture", None)
+            if gc_was_on:
+                gc.enable()
         self.graph = g
         self._model_key = self._key()
         self.captures += 1

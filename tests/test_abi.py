@@ -55,8 +55,9 @@ def test_struct_layout_matches_c(tmp_path, lib):
 #include <stddef.h>
 #include "tensoir_hip.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(TirField), offsetof(TirField, grid), offsetof(TirField, dplane),
-         offsetof(TirField, basis_t), offsetof(TirField, occ_nbr), offsetof(TirField, occ_dim), offsetof(TirField, occ_inv));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(TirField), offsetof(TirField, grid), offsetof(TirField, dplane),
+         offsetof(TirField, basis_t), offsetof(TirField, occ_nbr), offsetof(TirField, occ_dim), offsetof(TirField, occ_inv),
+         offsetof(TirField, occ_hi));
   printf("%zu %zu %zu\n", sizeof(TirMlp), offsetof(TirMlp, feat_dim), offsetof(TirMlp, act));
   printf("%zu %zu\n", sizeof(TirEnvSG), offsetof(TirEnvSG, n_sg));
   return 0; }''')
@@ -65,7 +66,7 @@ int main(void) {
     out = subprocess.check_output([str(exe)]).decode().split("\n")
     F, M, E = _lib.TirField, _lib.TirMlp, _lib.TirEnvSG
     assert [int(x) for x in out[0].split()] == [C.sizeof(F), F.grid.offset, F.dplane.offset, F.basis_t.offset,
-                                                F.occ_nbr.offset, F.occ_dim.offset, F.occ_inv.offset]
+                                                F.occ_nbr.offset, F.occ_dim.offset, F.occ_inv.offset, F.occ_hi.offset]
     assert [int(x) for x in out[1].split()] == [C.sizeof(M), M.feat_dim.offset, M.act.offset]
     assert [int(x) for x in out[2].split()] == [C.sizeof(E), E.n_sg.offset]
 

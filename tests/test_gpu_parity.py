@@ -787,3 +787,45 @@ def test_multi_decoder_launch_equals_single_launches(env):
             got = ops.mlp_multi(jobs, n_dev)
             for (pk, ft, ax, mp), g in zip(jobs, got):
                 assert torch.equal(g[: n // 3], ops.mlp(pk, ft, ax, mp, "bf16x3")[: n // 3])
+
+
+@torch.no_grad()
+def test_occupied_box_step_skipping_changes_nothing():
+    """TirField::occ_lo / occ_hi (the box outside of which the occupancy mask is empty) lets the march kernels skip whole
+    32- / 64-sample steps.  Culled samples contribute alpha = 0, so the results must be the same BIT FOR BIT with the box
+    (as the model builds it from a small off-centre blob: most of the aabb is empty), without it (zeros = not given) and
+    with a box far away from every sample's cell -- primary weights / acc / depth / counts, secondary visibility,
+    1 - acc and indirect radiance, transmittance."""
+    import contextlib, copy, io
+    import tensoir_amd
+    from tensoir_amd import ops, relight, synth
+    ck = synth.make_checkpoint(grid=(96,) * 3, seed=3, blob_sigma=0.18)
+    m = tensoir_amd.model_from_checkpoint(ck, "cuda", envmap_h=4, envmap_w=8)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m.updateAlphaMask((64, 64, 64))
+    f = m.packed_field()
+    lo, hi = list(f.occ_lo), list(f.occ_hi)
+    assert all(a < b for a, b in zip(lo, hi)) and max(b - a for a, b in zip(lo, hi)) < 2.4        # much tighter than the aabb
+    rays = synth.make_rays(48, 48, narrow=1.0).cuda()
+    gen = torch.Generator().manual_seed(5)
+    P = 30_011
+    pts = (torch.rand(P, 3, generator=gen) * 2 - 1).mul(1.2).cuda()
+    dirs = torch.nn.functional.normalize(torch.randn(P, 3, generator=gen), dim=-1).cuda()
+    li = torch.zeros(P, 1, dtype=torch.int32, device="cuda")
+
+    def run():
+        m.__dict__.pop("_rec_cap_hints", None)
+        fd = m.packed_field()
+        w, acc, dep, tend, cnt = ops.march_primary(fd, rays, None, 333, 0.0)
+        w2 = ops.march_primary(fd, rays, None, 333, 1e-6)[0]
+        v, nf, ind = relight.compute_radiance(m, pts, dirs, li, nSample=96, vis_near=0.05, vis_far=1.5)
+        t, tn = relight.compute_transmittance(m, pts, dirs, nSample=57, vis_near=0.05, vis_far=1.5)
+        return w, acc, dep, tend, cnt, w2, v, nf, ind, t, tn
+
+    with_box = run()
+    assert float(with_box[1].max()) > 0.9 and float(with_box[6].min()) < 0.05          # rays do hit the blob
+    f.occ_lo[:], f.occ_hi[:] = [0.0] * 3, [0.0] * 3           # the cached descriptor is passed by value at every launch
+    no_box = run()
+    for a, b in zip(with_box, no_box):
+        assert torch.equal(a, b)
+    f.occ_lo[:], f.occ_hi[:] = lo, hi
