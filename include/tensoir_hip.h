@@ -67,7 +67,7 @@ typedef struct TirField {
     float occ_aabb_min[3];   /* the mask's own aabb (:105) ...                                      */
     float occ_inv[3];        /* ... and (1/size)*2 (:107)                                           */
     float occ_lo[3];         /* world-space box that contains every point the mask can report as occupied (the occupied   */
-    float occ_hi[3];         /* voxels' extent + one cell): the march kernels skip 32-sample steps that lie outside of it. */
+    float occ_hi[3];         /* voxels' extent + one cell): the secondary march skips 32-sample steps that lie outside.  */
                              /* occ_lo >= occ_hi on any axis (e.g. all zeros) = not given, nothing is skipped.            */
 } TirField;
 

@@ -24,16 +24,8 @@ __device__ __forceinline__ void march_one_ray(const TirField& f, const float* __
     int cnt = 0;
     int k0 = 0;
     unsigned n_gather = 0;
-    float t_in, t_out;                 // where the ray can meet occupied space at all (occ_t_range)
-    occ_t_range(f, rs.o, rs.d, t_in, t_out);
     for (; k0 < S; k0 += 64) {
         const int k = k0 + lane;
-        // the whole 64-sample step lies outside the occupied box: every sample would be culled (alpha 0, T unchanged)
-        if (sample_z(f, rs.t_min, k0, jit, hj) > t_out || sample_z(f, rs.t_min, min(k0 + 63, S - 1), jit, hj) < t_in) {
-            if (k < S) weight[(size_t)ray * S + k] = 0.0f;
-            if (sigma_out && k < S) sigma_out[(size_t)ray * S + k] = 0.0f;
-            continue;
-        }
         float z = 0.0f, x = 0.f, y = 0.f, zz = 0.f;
         bool valid = false;
         if (k < S) {

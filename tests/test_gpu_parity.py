@@ -791,8 +791,8 @@ def test_multi_decoder_launch_equals_single_launches(env):
 
 @torch.no_grad()
 def test_occupied_box_step_skipping_changes_nothing():
-    """TirField::occ_lo / occ_hi (the box outside of which the occupancy mask is empty) lets the march kernels skip whole
-    32- / 64-sample steps.  Culled samples contribute alpha = 0, so the results must be the same BIT FOR BIT with the box
+    """TirField::occ_lo / occ_hi (the box outside of which the occupancy mask is empty) lets the secondary march skip whole
+    32-sample steps.  Culled samples contribute alpha = 0, so the results must be the same BIT FOR BIT with the box
     (as the model builds it from a small off-centre blob: most of the aabb is empty), without it (zeros = not given) and
     with a box far away from every sample's cell -- primary weights / acc / depth / counts, secondary visibility,
     1 - acc and indirect radiance, transmittance."""
