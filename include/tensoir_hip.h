@@ -501,6 +501,12 @@ int tir_mlp_bwd(const TirMlp* m, const float* packed_bwd, const float* feat, int
 int tir_mlp_bwd_bf16x3(const TirMlp* m, const float* packed_bwd, const float* feat, int32_t feat_stride,
                 const float* out, const float* g_out, const float* h1, const float* h2, int64_t n,
                 float* g_feat, float* dz1, float* dz2, float* dz3, void* stream);
+/* tir_mlp_bwd_bf16x3 for up to four decoder invocations over the same n rows in one launch (the grid is split between
+ * them; host arrays of n_jobs entries, arguments as in the single call). */
+int tir_mlp_bwd_multi_bf16x3(const TirMlp* const* mlps, const float* const* packed_bwds, const float* const* feats,
+                             int32_t feat_stride, const float* const* outs, const float* const* g_outs,
+                             const float* const* h1s, const float* const* h2s, int32_t n_jobs, int64_t n,
+                             float* const* g_feats, float* const* dz1s, float* const* dz2s, float* const* dz3s, void* stream);
 
 /* C[M][ldc] += A^T B (+ column N = A^T 1 when ones_col != 0: the bias gradient); A [n][lda] (first M columns),
  * B [n][ldb] (first N columns); M <= 128, N + ones_col <= 160.  fp32 MFMA, split over n.  bias_out (may be NULL):

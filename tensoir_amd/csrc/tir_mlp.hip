@@ -941,11 +941,11 @@ k_mlp_bwd(const float* __restrict__ packed_bwd, const float* __restrict__ feat, 
 // Backward-data: 8 waves x 32 samples per 256-sample tile, same lane decomposition as the forward kernels
 // (lane = sample l&31, half h = l>>5 holds hidden units unit_of(q, h)).  d h^T = W^T dz^T has exactly the forward's
 // shape with the transposed weights as the A operand, so the lane that holds h[unit] receives d h[unit].
-__global__ void __launch_bounds__(512)
-k_mlp_bwd_bf16(const float* __restrict__ packed_bwd, const float* __restrict__ feat, int fstride, const float* __restrict__ out,
+__device__ __forceinline__ void
+mlp_bwd_bf16_body(const float* __restrict__ packed_bwd, const float* __restrict__ feat, int fstride, const float* __restrict__ out,
           const float* __restrict__ g_out, const float* __restrict__ h1, const float* __restrict__ h2, int64_t n,
           int out_dim, int act, float* __restrict__ g_feat, float* __restrict__ dz1o, float* __restrict__ dz2o,
-          float* __restrict__ dz3o) {
+          float* __restrict__ dz3o, const int bid, const int nblk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // LDS: W2 (fp32, 512 floats) | bf16 image (W1^T hi, lo, W0^T hi, lo)
     for (int i = threadIdx.x * 4; i < 2 * 64 * 4; i += 512 * 4)
@@ -960,7 +960,7 @@ k_mlp_bwd_bf16(const float* __restrict__ packed_bwd, const float* __restrict__ f
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sl = lane & 31, h = lane >> 5;
     const int64_t n_tiles = (n + 255) / 256;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int64_t tile = bid; tile < n_tiles; tile += nblk) {
         const int64_t s_raw = tile * 256 + wave * 32 + sl;
         const bool on = s_raw < n;
         const int64_t s = on ? s_raw : n - 1;
@@ -1078,6 +1078,31 @@ k_mlp_bwd_bf16(const float* __restrict__ packed_bwd, const float* __restrict__ f
                 *reinterpret_cast<float4*>(g_feat + s * 32 + h * 16 + 4 * i) = make_float4(gf[4 * i], gf[4 * i + 1], gf[4 * i + 2], gf[4 * i + 3]);
         }
     }
+}
+
+__global__ void __launch_bounds__(512)
+k_mlp_bwd_bf16(const float* __restrict__ packed_bwd, const float* __restrict__ feat, int fstride, const float* __restrict__ out,
+          const float* __restrict__ g_out, const float* __restrict__ h1, const float* __restrict__ h2, int64_t n,
+          int out_dim, int act, float* __restrict__ g_feat, float* __restrict__ dz1o, float* __restrict__ dz2o,
+          float* __restrict__ dz3o) {    mlp_bwd_bf16_body(packed_bwd, feat, fstride, out, g_out, h1, h2, n, out_dim, act, g_feat, dz1o, dz2o, dz3o, (int)blockIdx.x,
+                      (int)gridDim.x);
+}
+
+// Backward-data of several decoder invocations over the same number of rows in ONE launch (the primary stage: rgb, brdf,
+// jittered brdf, normal): the grid is split evenly, a workgroup loads ITS job's operand image once and walks that job's
+// tiles -- one 150 KB LDS fill and one tail per workgroup instead of four short launches (see k_mlp_bf16_multi).
+struct TirMlpBwdJob { const float* packed_bwd; const float* feat; const float* out; const float* g_out; const float* h1; const float* h2;
+                      float* g_feat; float* dz1; float* dz2; float* dz3; int out_dim, act; };
+struct TirMlpBwdJobs { TirMlpBwdJob j[4]; int n_jobs; };
+
+__global__ void __launch_bounds__(512)
+k_mlp_bwd_bf16_multi(TirMlpBwdJobs jobs, int fstride, int64_t n) {
+    const int per = (int)gridDim.x / jobs.n_jobs;
+    const int ji = (int)blockIdx.x / per;
+    if (ji >= jobs.n_jobs) return;
+    const TirMlpBwdJob& jb = jobs.j[ji];
+    mlp_bwd_bf16_body(jb.packed_bwd, jb.feat, fstride, jb.out, jb.g_out, jb.h1, jb.h2, n, jb.out_dim, jb.act, jb.g_feat, jb.dz1, jb.dz2,
+                      jb.dz3, (int)blockIdx.x - ji * per, per);
 }
 
 int check_mlp(const TirMlp* m) {
@@ -1312,6 +1337,41 @@ extern "C" int tir_mlp_bwd(const TirMlp* m, const float* packed_bwd, const float
     unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
     hipLaunchKernelGGL(k_mlp_bwd, dim3(grid), dim3(512), lds, tir_stream(stream), packed_bwd, feat, feat_stride, out,
                        g_out, h1, h2, n, m->out_dim, m->act, g_feat, dz1, dz2, dz3);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_mlp_bwd_multi_bf16x3(const TirMlp* const* mlps, const float* const* packed_bwds, const float* const* feats,
+                                       int32_t feat_stride, const float* const* outs, const float* const* g_outs,
+                                       const float* const* h1s, const float* const* h2s, int32_t n_jobs, int64_t n,
+                                       float* const* g_feats, float* const* dz1s, float* const* dz2s, float* const* dz3s, void* stream) {
+    if (n_jobs < 1 || n_jobs > 4 || !mlps || !packed_bwds || !feats || !outs || !g_outs || !h1s || !h2s || !g_feats || !dz1s || !dz2s ||
+        !dz3s || n < 0 || feat_stride < F)
+        return TIR_ERR_ARG;
+    TirMlpBwdJobs jobs;
+    jobs.n_jobs = n_jobs;
+    for (int i = 0; i < n_jobs; ++i) {
+        int rc = check_mlp(mlps[i]);
+        if (rc) return rc;
+        if (!packed_bwds[i]) return TIR_ERR_ARG;
+        if (n > 0 && (!feats[i] || !outs[i] || !g_outs[i] || !h1s[i] || !h2s[i] || !g_feats[i] || !dz1s[i] || !dz2s[i] || !dz3s[i]))
+            return TIR_ERR_ARG;
+        jobs.j[i] = TirMlpBwdJob{packed_bwds[i], feats[i], outs[i], g_outs[i], h1s[i], h2s[i], g_feats[i], dz1s[i], dz2s[i], dz3s[i],
+                                 mlps[i]->out_dim, mlps[i]->act};
+    }
+    if (n == 0) return TIR_OK;
+    static bool attr_set = false;
+    const size_t lds = (size_t)BWD_BF_LDS_BYTES;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_bf16_multi),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return -(int)e;
+        attr_set = true;
+    }
+    const int64_t tiles = (n + 255) / 256;
+    int per = 256 / n_jobs;
+    if (tiles < per) per = (int)tiles;
+    hipLaunchKernelGGL(k_mlp_bwd_bf16_multi, dim3((unsigned)(per * n_jobs)), dim3(512), lds, tir_stream(stream), jobs, feat_stride, n);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

@@ -795,6 +795,32 @@ def mlp_bwd(m: "PackedMlp", packed_bwd, feat, out, g_out, h1, h2, impl=None):
     return g_feat, dz1, dz2, dz3
 
 
+def mlp_bwd_multi(jobs):
+    """Backward-data of up to four decoder invocations over the same rows in one launch (tir_mlp_bwd_multi_bf16x3).
+    jobs: list of (PackedMlp, packed_bwd, feat [n, FEAT_STRIDE], out, g_out, h1, h2); returns [(g_feat, dz1, dz2, dz3)]."""
+    k = len(jobs)
+    n = jobs[0][2].shape[0]
+    dev = jobs[0][2].device
+    res, cols = [], [[] for _ in range(11)]
+    for m, pb, feat, out, g_out, h1, h2 in jobs:
+        feat = f32(feat, "feat")
+        if feat.shape[0] != n or feat.shape[1] != FEAT_STRIDE:
+            raise ValueError(f"mlp_bwd_multi: every job needs [n, {FEAT_STRIDE}] feature rows")
+        g_feat = torch.empty((n, FEAT_STRIDE), dtype=torch.float32, device=dev)
+        dz1 = torch.empty((n, 128), dtype=torch.float32, device=dev)
+        dz2 = torch.empty((n, 128), dtype=torch.float32, device=dev)
+        dz3 = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        res.append((g_feat, dz1, dz2, dz3))
+        for c, t in zip(cols, (pb, feat, f32(out, "out"), f32(g_out, "g_out"), h1, h2, g_feat, dz1, dz2, dz3)):
+            c.append(t)
+    arr = lambda ts: (C.c_void_p * k)(*[t.data_ptr() for t in ts])
+    descs = (C.POINTER(TirMlp) * k)(*[C.pointer(j[0].desc) for j in jobs])
+    _call("tir_mlp_bwd_multi_bf16x3", descs, arr(cols[0]), arr(cols[1]), FEAT_STRIDE, arr(cols[2]), arr(cols[3]), arr(cols[4]),
+          arr(cols[5]), k, n, arr(cols[6]), arr(cols[7]), arr(cols[8]), arr(cols[9]), _stream())
+    _KEEP_ALIVE = cols          # noqa: F841  (operands stay referenced until the launch is queued)
+    return res
+
+
 def gemm_tn(A, M, B, N, C_out, ones_col=False, impl=None, bias_out=None):
     """C_out[M, N(+1)] += A[:, :M]^T @ B[:, :N]  (+ column N = A^T 1, or bias_out[M] += A^T 1 when given).  Split-bf16
     matrix cores when the product's decoder mode is bf16x3 (default), exact fp32 MFMA otherwise."""

@@ -119,8 +119,9 @@ class _LeafStream:
         self.keep.clear()
 
 
-def _decoder_backward(dec, calls, impl=None, leaf=None):
-    """Backward of every recorded invocation of one decoder.  Returns ([g_feat per call], 6 parameter grads)."""
+def _decoder_backward(dec, calls, impl=None, leaf=None, bwd=None):
+    """Backward of every recorded invocation of one decoder.  Returns ([g_feat per call], 6 parameter grads).
+    bwd: the (g_feat, dz1, dz2, dz3) of each call when the backward-data kernel has already run (merged launch)."""
     pm, pb = dec.packed(), _packed_bwd(dec)
     dev = calls[0].feat.device
     od = pm.out_dim
@@ -130,8 +131,11 @@ def _decoder_backward(dec, calls, impl=None, leaf=None):
     dW0, db0, dW1, db1, dW2, db2 = (t.view(shape) for t, shape in zip(
         torch.split(flat, sizes), ((128, 150), (128,), (128, 128), (128,), (4, 128), (4,))))
     g_feats = []
-    for c in calls:
-        g_feat, dz1, dz2, dz3 = ops.mlp_bwd(pm, pb, c.feat, c.out, c.g_out, c.h1, c.h2, impl=impl)
+    for ci, c in enumerate(calls):
+        if bwd is None:
+            g_feat, dz1, dz2, dz3 = ops.mlp_bwd(pm, pb, c.feat, c.out, c.g_out, c.h1, c.h2, impl=impl)
+        else:
+            g_feat, dz1, dz2, dz3 = bwd[ci]
 
         def weight_grads(c=c, dz1=dz1, dz2=dz2, dz3=dz3):
             x = ops.mlp_inputs(pm, c.feat, c.aux, c.aux_map)
@@ -147,6 +151,21 @@ def _decoder_backward(dec, calls, impl=None, leaf=None):
         g_feats.append(g_feat)
     grads = [dW0, db0, dW1, db1, dW2[:od], db2[:od]]
     return g_feats, grads
+
+
+def _merged_backward_data(model, calls):
+    """The backward-data kernel of all recorded decoder invocations of the stage in ONE launch (same rows for every
+    call): {call name: (g_feat, dz1, dz2, dz3)}, or None when the merged launch does not apply."""
+    if ops.MLP_IMPL != "bf16x3" or len(calls) < 2 or len(calls) > 4:
+        return None
+    decs = {"rgb": model.renderModule, "brdf": model.renderModule_brdf, "brdf_j": model.renderModule_brdf,
+            "normal": getattr(model, "renderModule_normal", None)}
+    names = [n for n in ("rgb", "brdf", "brdf_j", "normal") if n in calls]
+    if any(calls[n].feat.shape[1] != ops.FEAT_STRIDE for n in names):
+        return None
+    jobs = [(decs[n].packed(), _packed_bwd(decs[n]), calls[n].feat, calls[n].out, calls[n].g_out, calls[n].h1, calls[n].h2)
+            for n in names]
+    return dict(zip(names, ops.mlp_bwd_multi(jobs)))
 
 
 class _CapacityOverflow(RuntimeError):
@@ -326,16 +345,21 @@ class PrimaryRenderFn(torch.autograd.Function):
         if st.A > 0:
             c = st.calls["rgb"]
             c.g_out = g_rgb
-            (g_rad,), dec_grads["rgb"] = _decoder_backward(model.renderModule, [c], leaf=leaf)
+            if st.is_relight:
+                st.calls["brdf"].g_out, st.calls["brdf_j"].g_out = g_brdf, g_brdf_j
+                if "normal" in st.calls:
+                    st.calls["normal"].g_out = g_pred
+            bd = _merged_backward_data(model, st.calls)      # one launch for the stage's decoders (None: one per call)
+            pick = lambda *names: None if bd is None else [bd[n] for n in names]
+            (g_rad,), dec_grads["rgb"] = _decoder_backward(model.renderModule, [c], leaf=leaf, bwd=pick("rgb"))
             g_int = g_int_j = None
             if st.is_relight:
                 cb, cj = st.calls["brdf"], st.calls["brdf_j"]
-                cb.g_out, cj.g_out = g_brdf, g_brdf_j
-                (g_int, g_int_j), dec_grads["brdf"] = _decoder_backward(model.renderModule_brdf, [cb, cj], leaf=leaf)
+                (g_int, g_int_j), dec_grads["brdf"] = _decoder_backward(model.renderModule_brdf, [cb, cj], leaf=leaf,
+                                                                        bwd=pick("brdf", "brdf_j"))
                 if "normal" in st.calls:
                     cn = st.calls["normal"]
-                    cn.g_out = g_pred
-                    (g_n,), dec_grads["normal"] = _decoder_backward(model.renderModule_normal, [cn], leaf=leaf)
+                    (g_n,), dec_grads["normal"] = _decoder_backward(model.renderModule_normal, [cn], leaf=leaf, bwd=pick("normal"))
                     g_int = g_int + g_n
                     if g_der is not None:
                         ops.density_grad_bwd(f, gd, st.rec_xyz, g_der)
