@@ -211,3 +211,27 @@ def test_adam_is_constructor_and_state_compatible_and_loud_on_cpu():
         o.step()
     assert optim._dense_key(torch.empty(1, 4, 5, 3).permute(0, 2, 3, 1)) is not None
     assert optim._dense_key(torch.empty(8, 8)[:, ::2]) is None
+
+
+def test_graph_lane_state_swap_is_exception_safe():
+    """GraphedRenderer._own_state: while open, the model's per-pass device words are the renderer's own; on exit (also
+    through an exception) the model's come back and whatever the pass created stays with the renderer."""
+    import types
+    from tensoir_amd import graph
+    model = types.SimpleNamespace()
+    model.__dict__.update({"_words": "model-words", "_jit_rng": "model-rng", "other": 1})
+    r = types.SimpleNamespace(model=model, _own={})
+    with graph._OwnState(r):
+        assert "_words" not in model.__dict__ and "_jit_rng" not in model.__dict__ and model.other == 1
+        model.__dict__["_words"] = "lane-words"               # what model._step_words() would create on first use
+        model.__dict__["_pair_counter"] = "lane-counter"
+    assert model._words == "model-words" and model._jit_rng == "model-rng" and "_pair_counter" not in model.__dict__
+    assert r._own == {"_words": "lane-words", "_pair_counter": "lane-counter"}
+    try:
+        with graph._OwnState(r):
+            assert model._words == "lane-words" and model._pair_counter == "lane-counter" and "_jit_rng" not in model.__dict__
+            raise RuntimeError("boom")
+    except RuntimeError:
+        pass
+    assert model._words == "model-words" and model._jit_rng == "model-rng" and "_pair_counter" not in model.__dict__
+    assert r._own == {"_words": "lane-words", "_pair_counter": "lane-counter"}
