@@ -593,6 +593,7 @@ def main():
                             "15-26 % faster", "board_power_W": "1330-1400", "sustained_sclk_GHz": "1.93-2.07",
                     "frac_at_sustained_clock": round(r["frac"] * 2.4 / 2.0, 4),
                     "bf16_matrix_rate_TF": round(3.0 * r["achieved"], 1),
+                    "frac_of_reference_sustained_rate": round(3.0 * r["achieved"] / 1247.0, 4),
                     "reference_point": "MI355X_MICROARCH.md (DVFS give-back): a tuned bf16 attention main loop sustains 1247 TF "
                                        "on random data, 1483 TF on zeros; limit study of this kernel: profiles/r02_mlp_limit_study.txt",
                     "source": "tools/mlp_power.py -> profiles/r02_mlp_power.txt (rocm-smi polled during the launches)"}
