@@ -71,7 +71,10 @@ def parse():
     ap.add_argument("--workload", default="batch", choices=["batch", "image"],
                     help="batch = the headline 4096-ray step (weak scaling); image = one 800x800 image of BASELINE configs[3] "
                          "(3 light rotations, 1036 samples per ray) sharded over the ranks, one all-gather per image (strong scaling)")
-    ap.add_argument("--tile", type=int, default=0, help="image workload: 0 = contiguous row tiles, >0 = interleaved tiles of that many rays")
+    ap.add_argument("--tile", type=int, default=-1,
+                    help="image workload: 0 = contiguous row tiles, >0 = interleaved tiles of that many rays, -1 (default) = "
+                         "interleaved tiles of one chunk when there is more than one rank (background rows finish early: with "
+                         "row tiles the ranks that hold the object set the pace, SURVEY 8e), row tiles on one rank")
     ap.add_argument("--image-side", type=int, default=800)
     ap.add_argument("--force-dist", action="store_true",
                     help="single process: create a 1-rank RCCL group anyway and run the multi-rank code path (all-gather per step)")
@@ -206,6 +209,8 @@ def bench_image(a):
         raise SystemExit("bench.py needs a GPU: tensoir_amd has no CPU path")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if a.tile < 0:                                   # auto: interleave chunk-sized tiles as soon as the image is shared
+        a.tile = a.rays if world > 1 else 0
     assert _lib.lib().tir_device_check() == 0
     use_dist = world > 1 or a.force_dist
     ck = synth.make_checkpoint(grid=(a.grid,) * 3, seed=20211202, light_rotation=("000", "120", "240"))
