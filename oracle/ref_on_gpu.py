@@ -1,0 +1,278 @@
+"""The UNMODIFIED reference, run on the GPU box from a staged checkout.
+
+TEST INFRASTRUCTURE ONLY.  The checkout is staged by tools/stage_reference.sh into the git-ignored
+``gpurun_scratch/reference`` (it travels to the GPU box with the snapshot, never into history) and named by
+``TENSOIR_REFERENCE``; nothing here runs without it.  One invocation does, on the same seeded inputs as bench.py:
+
+  (b) BASELINE.md 2.1: the imported reference ``Renderer_TensoIR_train`` (renderer.py:57-127) timed on the host cores
+      at C2+C3 full size (4096 rays x 512 samples, 128 dirs x 96) -- 2 warm-ups, median of >= 5 calls;
+  (c) the same reference objects on the MI355X through PyTorch-ROCm (its device='cuda' strings resolve to HIP):
+      timed with the GPU protocol (hipEvent pair incl. H2D of the rays, 10 warm-ups, median of 50) and used as the
+      ON-DEVICE ORACLE: every map of tensoir_amd's boundary call vs the reference's, all 4096 rays;
+  (d) occupancy-mask maintenance at full size: reference ``updateAlphaMask((128,)*3)`` (CPU and GPU) vs tensoir_amd's
+      device kernels (voxel mismatches, returned aabb);
+  (e) C5 at 400^3: the loop body of scripts/relight_importance.py:99-171 assembled from the reference's own functions
+      (``Environment_Light.sample_light``, ``compute_transmittance``, ``GGX_specular``, ``linear2srgb_torch``) on the
+      GPU vs ``tensoir_amd.relight.relight_with_envmap`` fed the same drawn directions (sampling fed to both).
+
+Writes one JSON (default gpurun_out/ref_on_gpu.json); copy it to profiles/ per round.
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import tempfile
+import time
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import ref_loader  # noqa: E402
+
+MAPS = ["rgb_map", "depth_map", "normal_map", "albedo_map", "roughness_map", "fresnel_map", "acc_map",
+        "rgb_with_brdf_map", "normals_diff_map", "normals_orientation_loss_map"]
+
+
+def reference_model(ref, ckpt, device, envmap_h, envmap_w):
+    """``TensorVMSplit(**kwargs).load(ckpt)`` of the reference itself (train_tensoIR.py:163-168)."""
+    kw = dict(ckpt["kwargs"])
+    kw.pop("light_num", None)
+    aabb = kw.pop("aabb").to(device)
+    grid = kw.pop("gridSize")
+    kw["light_rotation"] = [f"{int(r):03d}" for r in kw["light_rotation"]]
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = ref.TensorVMSplit(aabb, grid, device, envmap_h=envmap_h, envmap_w=envmap_w, **kw)
+        m.load(ckpt)
+    m.eval()
+    return m
+
+
+def with_mask(ckpt, ref_model):
+    """The checkpoint plus the reference-built occupancy mask, in the reference's own save format
+    (models/tensorBase_rotated_lights.py:675-683)."""
+    ck = dict(ckpt)
+    vol = ref_model.alphaMask.alpha_volume.bool().cpu().numpy()
+    ck["alphaMask.shape"] = vol.shape[2:]
+    ck["alphaMask.mask"] = np.packbits(vol.reshape(-1))
+    ck["alphaMask.aabb"] = ref_model.alphaMask.aabb.cpu()
+    return ck
+
+
+def metrics(a, b):
+    from tests.helpers import parity_metrics
+    return {k: float(f"{v:.3e}") for k, v in parity_metrics(a, b).items()}
+
+
+def synthetic_hdr(H=1024, W=2048):
+    gen = torch.Generator().manual_seed(71)
+    hdr = torch.exp(torch.randn(H // 8, W // 8, 3, generator=gen) * 1.5)
+    hdr = torch.nn.functional.interpolate(hdr.permute(2, 0, 1)[None], size=(H, W), mode="bilinear",
+                                          align_corners=False)[0].permute(1, 2, 0).contiguous()
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    hdr[((yy - 300) ** 2 + (xx - 700) ** 2) < 20 ** 2] *= 100.0
+    return hdr
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "ref_on_gpu.json"))
+    ap.add_argument("--cpu-calls", type=int, default=5)
+    ap.add_argument("--gpu-calls", type=int, default=50)
+    ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-c5", action="store_true")
+    a = ap.parse_args()
+    if not ref_loader.available():
+        raise SystemExit(f"no reference checkout at {ref_loader.REF_ROOT} (stage one with tools/stage_reference.sh)")
+    ref = ref_loader.load()
+    RU, R = ref.RU, ref.renderer
+    import tensoir_amd
+    from tensoir_amd import Renderer_TensoIR_train, relight, synth
+    dev = torch.device("cuda", 0)
+    rep = {"reference_checkout": ref_loader.REF_ROOT, "torch": torch.__version__, "host_nproc": os.cpu_count(),
+           "torch_threads": torch.get_num_threads(), "gpu": torch.cuda.get_device_name(0)}
+    args = types.SimpleNamespace(second_nSample=96, second_near=0.05, second_far=1.5)
+    envh, envw, S = 8, 16, 512
+
+    def flush():
+        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        with open(a.out, "w") as fh:
+            json.dump(rep, fh, indent=1)
+
+    # ------------------------------------------------------------------ C2+C3 scene (bench.py's)
+    ckpt = synth.make_checkpoint(grid=(300,) * 3, seed=20211202)
+    rays = synth.make_rays(64, 64)
+    lidx = torch.zeros(4096, 1, dtype=torch.int32)
+    B = rays.shape[0]
+
+    # (d) reference mask on the GPU, then everything below shares THAT mask
+    ref_gpu = reference_model(ref, ckpt, "cuda", envh, envw)
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        aabb_ref_gpu = ref_gpu.updateAlphaMask((128, 128, 128))
+    ck_m = with_mask(ckpt, ref_gpu)
+    ours = tensoir_amd.model_from_checkpoint(ckpt, "cuda", envmap_h=envh, envmap_w=envw)
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        aabb_ours = ours.updateAlphaMask((128, 128, 128))
+    v_ref = ref_gpu.alphaMask.alpha_volume.bool()
+    v_our = ours.alphaMask.alpha_volume.bool().view_as(v_ref)
+    rep["mask_300"] = {"grid": [128] * 3, "occupied_reference_gpu": int(v_ref.sum()), "occupied_tensoir_amd": int(v_our.sum()),
+                       "voxel_mismatches": int((v_ref != v_our).sum()),
+                       "aabb_max_abs_diff": float((torch.as_tensor(aabb_ref_gpu).cpu() - torch.as_tensor(aabb_ours).cpu()).abs().max())}
+    ours = tensoir_amd.model_from_checkpoint(ck_m, "cuda", envmap_h=envh, envmap_w=envw)     # the reference's mask
+    ref_gpu = reference_model(ref, ck_m, "cuda", envh, envw)
+    flush()
+
+    # (c) reference on the MI355X: on-device oracle + informative timing
+    def call_ref(model, device):
+        with torch.no_grad():
+            return R.Renderer_TensoIR_train(rays, None, lidx, model, N_samples=S, white_bg=True, is_train=False,
+                                            is_relight=True, sample_method="fixed_envirmap", chunk_size=160000,
+                                            device=device, args=args)
+
+    def call_ours():
+        with torch.no_grad():
+            return Renderer_TensoIR_train(rays, None, lidx, ours, N_samples=S, white_bg=True, is_train=False,
+                                          is_relight=True, sample_method="fixed_envirmap", chunk_size=160000,
+                                          device="cuda", args=args)
+
+    def gpu_time(fn, warm, calls):
+        st = torch.cuda.current_stream()
+        ts = []
+        for i in range(warm + calls):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record(st)
+            out = fn()
+            e1.record(st)
+            e1.synchronize()
+            if i >= warm:
+                ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        return out, {"median_ms": round(ts[len(ts) // 2], 4), "min_ms": round(ts[0], 4), "max_ms": round(ts[-1], 4),
+                     "calls": len(ts), "rays_per_s": round(B / (ts[len(ts) // 2] * 1e-3), 1)}
+
+    out_ref, t_ref = gpu_time(lambda: call_ref(ref_gpu, "cuda"), 10, a.gpu_calls)
+    out_our, t_our = gpu_time(call_ours, 10, a.gpu_calls)
+    rep["c2c3_reference_on_mi355x"] = dict(t_ref, protocol="unmodified reference through PyTorch-ROCm, eager, host rays in (H2D per call), "
+                                           "hipEvent pair, 10 warm-ups, median", peak_mem_GB=round(torch.cuda.max_memory_allocated() / 2 ** 30, 2))
+    rep["c2c3_tensoir_amd_boundary_call"] = dict(t_our, protocol="tensoir_amd.Renderer_TensoIR_train, same call, same protocol")
+    rep["c2c3_speedup_vs_reference_on_same_gpu"] = round(t_ref["median_ms"] / t_our["median_ms"], 1)
+    par = {k: metrics(out_our[k], out_ref[k]) for k in MAPS}
+    rep["c2c3_parity_vs_reference_on_device"] = {
+        "rays_compared": B, "surface_points": int((out_ref["acc_map"] > 0.5).sum()), "per_map": par,
+        "max_rel_floor1": max(v["max_rel_floor1"] for v in par.values()),
+        "max_rel_pixel_rgb_normals": max(par[k]["max_rel_pixel"] for k in ("rgb_map", "normal_map", "rgb_with_brdf_map")),
+        "tolerance": 1e-4, "excluded": "the two smoothness losses (torch.randn_like vs the device-side Philox jitter)"}
+    rep["c2c3_parity_vs_reference_on_device"]["ok"] = rep["c2c3_parity_vs_reference_on_device"]["max_rel_floor1"] < 1e-4
+    flush()
+
+    # (b) BASELINE.md 2.1: the reference on the host cores
+    if not a.skip_cpu:
+        ref_cpu = reference_model(ref, ck_m, "cpu", envh, envw)
+        times, out_cpu = [], None
+        for i in range(2 + a.cpu_calls):
+            t0 = time.perf_counter()
+            out_cpu = call_ref(ref_cpu, "cpu")
+            if i >= 2:
+                times.append(time.perf_counter() - t0)
+        times.sort()
+        med = times[len(times) // 2]
+        rep["c2c3_reference_on_host_cpu"] = {
+            "value": round(B / med, 2), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "reference",
+            "reference_checkout": True, "median_s": round(med, 3), "min_s": round(times[0], 3), "max_s": round(times[-1], 3),
+            "sample": f"the full batch ({B} rays x {S} samples, {envh * envw} dirs x 96), 2 warm-ups + {len(times)} timed calls, "
+                      f"time.perf_counter, torch.no_grad; host nproc={os.cpu_count()}"}
+        parc = {k: metrics(out_our[k], out_cpu[k]) for k in MAPS}
+        rep["c2c3_parity_vs_reference_on_cpu"] = {"per_map": parc, "max_rel_floor1": max(v["max_rel_floor1"] for v in parc.values())}
+        rep["c2c3_reference_gpu_vs_reference_cpu"] = {k: metrics(out_ref[k], out_cpu[k]) for k in MAPS}
+        del ref_cpu
+        flush()
+    del ref_gpu, ours
+    torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ (e) C5 at 400^3 (BASELINE configs[4]: ficus)
+    if not a.skip_c5:
+        ck4 = synth.make_checkpoint(grid=(400,) * 3, seed=20211202)
+        ref4 = reference_model(ref, ck4, "cuda", envh, envw)
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            ref4.updateAlphaMask((128, 128, 128))
+        ck4m = with_mask(ck4, ref4)
+        our4 = tensoir_amd.model_from_checkpoint(ck4m, "cuda", envmap_h=envh, envmap_w=envw)
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            our4.updateAlphaMask((128, 128, 128))
+        v_ref = ref4.alphaMask.alpha_volume.bool()
+        rep["mask_400"] = {"voxel_mismatches": int((v_ref != our4.alphaMask.alpha_volume.bool().view_as(v_ref)).sum()),
+                           "occupied": int(v_ref.sum())}
+        our4 = tensoir_amd.model_from_checkpoint(ck4m, "cuda", envmap_h=envh, envmap_w=envw)
+        hdr = synthetic_hdr()
+        tmp = tempfile.mkdtemp()
+        open(os.path.join(tmp, "syn.hdr"), "w").close()
+        RU.read_hdr = lambda path: hdr.numpy()
+        env_ref = RU.Environment_Light(tmp, device="cuda")
+        env_our = relight.Environment_Light(hdr_maps={"syn": hdr}, device="cuda")
+        r = rays.cuda()
+        li = lidx.cuda()
+        with torch.no_grad():
+            o_ref = ref4(r, li, is_train=False, white_bg=True, ndc_ray=False, N_samples=-1)
+            o_our = our4(r, li, is_train=False, white_bg=True, ndc_ray=False, N_samples=-1)
+            names = ["rgb_map", "depth_map", "normal_map", "albedo_map", "roughness_map", "fresnel_map", "acc_map"]
+            rep["c5_400_primary_vs_reference_on_device"] = {n: metrics(o_our[i], o_ref[i]) for i, n in enumerate(names)}
+            rep["c5_400_primary_vs_reference_on_device"]["nSamples"] = int(ref4.nSamples)
+            depth, normal, albedo, rough, fres, acc = o_ref[1:7]           # the reference's maps feed BOTH relight paths
+            mask = acc > 0.5
+            surf = (r[:, :3] + depth.unsqueeze(-1) * r[:, 3:])[mask]
+            nrm, alb, rgh, frs = normal[mask], albedo[mask], rough[mask], fres[mask]
+            vdir = r[:, 3:][mask]
+            M = surf.shape[0]
+            torch.manual_seed(5)
+            parts = [env_ref.sample_light("syn", min(256, M - s), 512) for s in range(0, M, 256)]     # multinomial rows of 2 M
+            ldir, lrgb, lpdf = (torch.cat([p[i] for p in parts]) for i in range(3))
+            # the loop body of scripts/relight_importance.py:115-165, the reference's functions on the device
+            t0 = time.perf_counter()
+            surf2c = RU.safe_l2_normalize(-vdir, dim=-1)
+            cosine = torch.einsum("ijk,ik->ij", ldir, nrm)
+            cmask = cosine > 1e-6
+            vis = torch.zeros((*cmask.shape, 1), device="cuda")
+            pts = surf[:, None, :].expand((*cmask.shape, 3))[cmask]
+            dirs = ldir[cmask]
+            vv = torch.zeros(dirs.shape[0], 1, device="cuda")
+            for idx in torch.split(torch.arange(pts.shape[0], device="cuda"), 100000):
+                nerv, nerfactor = RU.compute_transmittance(tensoIR=ref4, surf_pts=pts[idx], light_in_dir=dirs[idx], nSample=96,
+                                                           vis_near=0.05, vis_far=1.5)
+                vv[idx] = nerv.unsqueeze(-1)                                              # args.vis_equation = 'nerv' (relight_importance.py:364)
+            vis[cmask] = vv
+            spec = RU.GGX_specular(nrm, surf2c, ldir, rgh, frs)
+            brdf = alb.unsqueeze(1).expand(-1, 512, -1) / np.pi + spec
+            contrib = brdf * (vis * lrgb) * cosine[:, :, None] / lpdf
+            rgb_ref = RU.linear2srgb_torch(torch.clamp(contrib.mean(dim=1), 0.0, 1.0))
+            torch.cuda.synchronize()
+            t_ref5 = time.perf_counter() - t0
+            bg_ref = RU.linear2srgb_torch(torch.clamp(env_ref.get_light("syn", r[:, 3:]), 0.0, 1.0))
+            t0 = time.perf_counter()
+            rgb_our = relight.relight_with_envmap(our4, surf, nrm, alb, rgh, frs, vdir, ldir, lrgb, lpdf, nSample=96,
+                                                  vis_near=0.05, vis_far=1.5)
+            torch.cuda.synchronize()
+            t_our5 = time.perf_counter() - t0
+            bg_our = RU.linear2srgb_torch(torch.clamp(env_our.get_light("syn", r[:, 3:]), 0.0, 1.0))
+        m5 = metrics(rgb_our, rgb_ref)
+        rep["c5_400_relight_vs_reference_on_device"] = {
+            "grid": 400, "surface_points": int(M), "importance_samples": 512, "visibility_rays": int(cmask.sum()),
+            "relit_rgb": m5, "background_srgb": metrics(bg_our, bg_ref), "ok": m5["max_rel_floor1"] < 1e-4,
+            "reference_loop_body_s": round(t_ref5, 3), "tensoir_amd_s_first_call": round(t_our5, 4),
+            "note": "every surface point of the chunk (no subsample); light directions drawn by the reference's sample_light "
+                    "(torch.multinomial) and fed to both; vis_equation nerv"}
+        flush()
+    print(json.dumps({k: (v if not isinstance(v, dict) else {kk: vv for kk, vv in v.items() if kk != "per_map"}) for k, v in rep.items()}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

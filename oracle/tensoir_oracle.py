@@ -811,6 +811,19 @@ def update_alpha_mask(sc, grid_size=(200, 200, 200), thres=0.001, backend="aten"
     return torch.stack((valid.amin(0), valid.amax(0)))
 
 
+def filtering_rays(sc, all_rays, n_samples=256, bbox_only=False, backend="aten"):
+    """filtering_rays: models/tensorBase_rotated_lights.py:781-811.  Returns the boolean keep mask [N]."""
+    rays_o, rays_d = all_rays[..., :3], all_rays[..., 3:6]
+    if bbox_only:
+        vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+        rate_a = (sc.aabb[1] - rays_o) / vec
+        rate_b = (sc.aabb[0] - rays_o) / vec
+        return torch.maximum(rate_a, rate_b).amin(-1) > torch.minimum(rate_a, rate_b).amax(-1)
+    pts, _, _ = sample_ray(sc, rays_o, rays_d, n_samples)
+    occ = sample_occupancy(sc, pts.reshape(-1, 3), backend).view(pts.shape[:-1])
+    return (occ > 0).any(-1)
+
+
 # --------------------------------------------------------------------------
 # training step: loss of train_tensoIR.py:262-311 and its parameter gradients (autograd on the
 # functional restatement above) -- the checker for the HIP backward kernels
@@ -838,6 +851,8 @@ def scene_parameters(sc):
             ps[f"{prefix}.mlp.{k}.weight"] = m[f"w{j}"]
             ps[f"{prefix}.mlp.{k}.bias"] = m[f"b{j}"]
     ps["lgtSGs"] = sc.lgtSGs
+    for i, sg in enumerate(getattr(sc, "lgtSGs_list", None) or []):     # general multi-light variant: a plain python list
+        ps[f"lgtSGs_list.{i}"] = sg                                       # (models/tensorBase_general_multi_lights.py:463-479)
     return ps
 
 
@@ -867,6 +882,8 @@ def train_step_grads(sc, rays, light_idx, rgb_gt, is_relight=True, n_samples=-1,
     for name in ("density_plane", "density_line", "app_plane", "app_line"):
         setattr(work, name, [mk(t) for t in getattr(sc, name)])
     work.basis_mat, work.light_line, work.lgtSGs = mk(sc.basis_mat), mk(sc.light_line), mk(sc.lgtSGs)
+    if getattr(sc, "lgtSGs_list", None) is not None:
+        work.lgtSGs_list = [mk(t) for t in sc.lgtSGs_list]
     for name in ("mlp_rgb", "mlp_brdf", "mlp_normal"):
         if getattr(sc, name) is not None:
             setattr(work, name, {k: mk(v) for k, v in getattr(sc, name).items()})
