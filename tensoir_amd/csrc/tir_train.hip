@@ -1565,7 +1565,10 @@ extern "C" int tir_adam_step(int32_t n_tensors, float* const* p, const float* co
             ++k;
         }
         tab.n_tensors = k;
-        if (k == 0) continue;
+        if (k == 0) {                   // nothing fitted: either only empty tensors were left, or ONE tensor needs more
+            if (t < n_tensors) return TIR_ERR_ARG;   // than 2^30 chunks (it can never fit a launch: do not spin on it)
+            continue;
+        }
         hipLaunchKernelGGL(k_adam, dim3((unsigned)chunks), dim3(256), 0, s, tab, beta1, beta2, eps);
         TIR_CHECK_LAUNCH();
     }

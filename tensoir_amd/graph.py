@@ -80,7 +80,9 @@ class GraphedRenderer:
         decs = [getattr(m, n) for n in ("renderModule", "renderModule_brdf", "renderModule_normal") if hasattr(m, n)]
         for d in decs:
             d.packed()
-        return (m._field_key, m.lgtSGs.data_ptr(), m.lgtSGs._version, tuple(d._key for d in decs),
+        # every light parameter: the general multi-light model keeps one SG set per light in a plain list
+        lights = getattr(m, "lgtSGs_list", None) or [m.lgtSGs]
+        return (m._field_key, tuple((t.data_ptr(), t._version) for t in lights), tuple(d._key for d in decs),
                 float(m.march_t_stop), ops.MLP_IMPL)
 
     def _stale(self):

@@ -68,7 +68,7 @@ class AsyncCount:
         self.pin = torch.empty(1, dtype=torch.int32, pin_memory=True)
         self.pin.copy_(counter.view(-1)[:1], non_blocking=True)
         self.ev = torch.cuda.Event()
-        self.ev.record(torch.cuda.current_stream())
+        self.ev.record(torch.cuda.current_stream(counter.device))      # the counter's device, which need not be current
         self.value = None
 
     def get(self) -> int:

@@ -46,7 +46,9 @@ class Adam(_TorchAdam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        entries = []
+        # pass 1 validates EVERY group and parameter and mutates nothing: an unsupported option or tensor on a later
+        # parameter must not leave earlier ones with an advanced step count and no update
+        todo = []
         betas = eps = None
         for group in self.param_groups:
             for opt in ("amsgrad", "maximize", "capturable", "differentiable"):
@@ -59,6 +61,7 @@ class Adam(_TorchAdam):
                 betas, eps = b, e
             elif (b, e) != (betas, eps):
                 raise NotImplementedError("tensoir_amd.optim.Adam: betas / eps must be the same in every parameter group")
+        for group in self.param_groups:
             lr = float(group["lr"])
             for p in group["params"]:
                 if p.grad is None:
@@ -68,24 +71,28 @@ class Adam(_TorchAdam):
                     raise NotImplementedError("tensoir_amd.optim.Adam: dense fp32 parameters and gradients only")
                 if not p.is_cuda:
                     raise TensoirHipError("tensoir_amd.optim.Adam.step needs the parameters on an MI355X (no CPU path)")
-                ps = p.stride()
-                key = _dense_key_of(tuple(p.shape), ps)
+                key = _dense_key_of(tuple(p.shape), p.stride())
                 if key is None:
                     raise NotImplementedError("tensoir_amd.optim.Adam: parameters must be non-overlapping and dense")
-                if g.stride() != ps and _dense_key(g) != key:
-                    g = torch.empty_like(p).copy_(g)          # autograd's layout contract makes this the rare case
-                state = self.state[p]
-                if len(state) == 0:
-                    state["step"] = torch.tensor(0.0, dtype=torch.float32)
-                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                m, v = state["exp_avg"], state["exp_avg_sq"]
-                if (m.stride() != ps and _dense_key(m) != key) or (v.stride() != ps and _dense_key(v) != key):      # e.g. a state_dict loaded into another layout
-                    m = state["exp_avg"] = torch.empty_like(p).copy_(m)
-                    v = state["exp_avg_sq"] = torch.empty_like(p).copy_(v)
-                state["step"] += 1
-                t = float(state["step"])
-                entries.append((p, g, m, v, lr, 1.0 - betas[0] ** t, 1.0 - betas[1] ** t))
+                todo.append((p, g, key, lr))
+        # pass 2: state creation / layout fixes / step counts, then the one launch
+        entries = []
+        for p, g, key, lr in todo:
+            ps = p.stride()
+            if g.stride() != ps and _dense_key(g) != key:
+                g = torch.empty_like(p).copy_(g)          # autograd's layout contract makes this the rare case
+            state = self.state[p]
+            if len(state) == 0:
+                state["step"] = torch.tensor(0.0, dtype=torch.float32)
+                state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            m, v = state["exp_avg"], state["exp_avg_sq"]
+            if (m.stride() != ps and _dense_key(m) != key) or (v.stride() != ps and _dense_key(v) != key):      # e.g. a state_dict loaded into another layout
+                m = state["exp_avg"] = torch.empty_like(p).copy_(m)
+                v = state["exp_avg_sq"] = torch.empty_like(p).copy_(v)
+            state["step"] += 1
+            t = float(state["step"])
+            entries.append((p, g, m, v, lr, 1.0 - betas[0] ** t, 1.0 - betas[1] ** t))
         if entries:
             ops.adam_step(entries, betas[0], betas[1], eps)
             # the kernel wrote parameters and moments through raw pointers: tell autograd (saved-tensor checks) and every

@@ -95,6 +95,7 @@ class _LeafStream:
     def __init__(self, dev):
         self.on = os.environ.get("TENSOIR_BWD_STREAMS", "1") != "0" and not torch.cuda.is_current_stream_capturing()
         self.keep = []
+        self.dev = dev              # every stream query below names the device: the model may live on a non-current GPU
         if self.on:
             key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
             if key not in self._streams:
@@ -106,7 +107,7 @@ class _LeafStream:
             return fn()
         self.keep.extend(operands)
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
+        ev.record(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
             out = fn()
@@ -115,7 +116,7 @@ class _LeafStream:
 
     def join(self):
         if self.on:
-            torch.cuda.current_stream().wait_stream(self.side)
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
         self.keep.clear()
 
 

@@ -50,14 +50,14 @@ def _write_report():
         json.dump(REPORT, fh, indent=1, sort_keys=True)
 
 
-def _build(light_rotation):
+def _build(light_rotation, grid=300):
     import contextlib
     import io
 
     import tensoir_amd
     from tensoir_amd import synth
     from tests.helpers import scene_from_model
-    ck = synth.make_checkpoint(grid=(300, 300, 300), seed=20211202, light_rotation=light_rotation)
+    ck = synth.make_checkpoint(grid=(grid,) * 3, seed=20211202, light_rotation=light_rotation)
     model = tensoir_amd.model_from_checkpoint(ck, "cuda", envmap_h=8, envmap_w=16)
     with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
         model.updateAlphaMask((128, 128, 128))
@@ -166,12 +166,16 @@ def test_c4_three_lights_1036_samples_vs_oracle():
 
 
 @torch.no_grad()
-def test_c5_hdr_2048x1024_importance_512_vs_oracle():
+@pytest.mark.parametrize("grid", [300, 400])
+def test_c5_hdr_2048x1024_importance_512_vs_oracle(grid):
     """configs[4]: 2048x1024 HDR map, 512 importance samples per surface point drawn by sample_light
-    (models/relight_utils.py:150-188) and fed to both implementations; oracle on every 32nd point."""
+    (models/relight_utils.py:150-188) and fed to both implementations; oracle on every 32nd point.
+    grid = 400 is the ficus field of configs/relighting_test/ficus.txt (the visibility march then runs the 1024-thread
+    LDS-lines kernel: 76.8 KB of density lines per workgroup), 300 the other scenes'."""
     from oracle import tensoir_oracle as O
     from tensoir_amd import relight, synth
-    model, sc = _build(("000",))
+    model, sc = _build(("000",), grid)
+    C5 = f"C5/{grid}"
     gen = torch.Generator().manual_seed(71)
     H, W = 1024, 2048
     hdr = torch.exp(torch.randn(H // 8, W // 8, 3, generator=gen) * 1.5)
@@ -182,8 +186,8 @@ def test_c5_hdr_2048x1024_importance_512_vs_oracle():
     env = relight.Environment_Light(hdr_maps={"syn": hdr}, device="cuda")
     # the pdf / direction tables themselves (Environment_Light.__init__, :110-148)
     pdf_s, pdf_r, dirs = O.envlight_tables(hdr)
-    assert _record("C5", "pdf_return", env.hdr_pdf_return["syn"].view(-1).cpu(), pdf_r)["max_rel_floor1"] < 1e-4
-    assert _record("C5", "dirs", env.hdr_dir["syn"].view(-1, 3).cpu(), dirs)["max_abs"] < 1e-6
+    assert _record(C5, "pdf_return", env.hdr_pdf_return["syn"].view(-1).cpu(), pdf_r)["max_rel_floor1"] < 1e-4
+    assert _record(C5, "dirs", env.hdr_dir["syn"].view(-1, 3).cpu(), dirs)["max_abs"] < 1e-6
     rays = synth.make_rays(64, 64).cuda()
     lidx = torch.zeros(4096, 1, dtype=torch.int32, device="cuda")
     out = model(rays, lidx, N_samples=512)
@@ -199,17 +203,18 @@ def test_c5_hdr_2048x1024_importance_512_vs_oracle():
     c = lambda t: t[sel].cpu()
     ref = O.relight_importance(sc, c(surf), c(normal[mask]), c(albedo[mask]), c(rough[mask]), c(fres[mask]),
                                c(rays[:, 3:][mask]), c(ldir), c(lrgb), c(lpdf), n_sample=96, near=0.05, far=1.5)
-    r = _record("C5", "relit_rgb", c(got), ref)
+    r = _record(C5, "relit_rgb", c(got), ref)
     assert r["max_rel_floor1"] < TOL and r["max_rel_pixel"] < 5e-4, r
     bg = env.get_light("syn", rays[:, 3:])
     # HDR radiance is unbounded (sun disc ~1e3): relative metric.  The lookup differentiates a 2048-wide map at a pixel
     # coordinate that comes out of acos / atan2 -- 1 ulp of the angle is 1e-4 pixel
-    r = _record("C5", "background", bg.cpu()[::16], O.envlight_lookup(hdr, rays[:, 3:].cpu()[::16]))
+    r = _record(C5, "background", bg.cpu()[::16], O.envlight_lookup(hdr, rays[:, 3:].cpu()[::16]))
     assert r["max_rel_pixel"] < 2e-4, r
 
 
 @torch.no_grad()
-def test_c5_device_sampler_distribution_and_integration():
+@pytest.mark.parametrize("grid", [300, 400])
+def test_c5_device_sampler_distribution_and_integration(grid):
     """configs[4] with the importance sampler ON THE DEVICE (tir_env_sample_setup; reference: torch.multinomial,
     models/relight_utils.py:150-188): (a) the drawn cells follow pdf_sample -- chi-square over 32 x 64 coarse blocks of the
     2048x1024 map (mean of the per-block relative deviation at the Monte-Carlo floor, compared with torch.multinomial's own
@@ -218,7 +223,8 @@ def test_c5_device_sampler_distribution_and_integration():
     (scripts/relight_importance.py:119-170) on every 32nd point; (c) the cosine mask equals the reference's."""
     from oracle import tensoir_oracle as O
     from tensoir_amd import relight, synth
-    model, sc = _build(("000",))
+    model, sc = _build(("000",), grid)
+    C5S = f"C5-device-sampler/{grid}"
     gen = torch.Generator().manual_seed(71)
     H, W = 1024, 2048
     hdr = torch.exp(torch.randn(H // 8, W // 8, 3, generator=gen) * 1.5)
@@ -252,7 +258,7 @@ def test_c5_device_sampler_distribution_and_integration():
     big = expect > 200
     chi_dev = float((((got - expect) ** 2 / expect)[big]).mean())
     chi_ref = float((((ref - expect) ** 2 / expect)[big]).mean())
-    REPORT.setdefault("C5-device-sampler", {})["chi2_per_block"] = {"device": chi_dev, "torch_multinomial": chi_ref,
+    REPORT.setdefault(C5S, {})["chi2_per_block"] = {"device": chi_dev, "torch_multinomial": chi_ref,
                                                                     "blocks": int(big.sum()), "draws": n_draw}
     assert chi_dev < 1.3 and abs(chi_dev - chi_ref) < 0.3, (chi_dev, chi_ref)         # chi-square / dof ~ 1 for exact sampling
     sun_mass = float(pdf[sun].sum())
@@ -278,5 +284,5 @@ def test_c5_device_sampler_distribution_and_integration():
     c = lambda t: t[sel].cpu()
     ref_rgb = O.relight_importance(sc, c(surf), c(nrm), c(albedo[mask]), c(rough[mask]), c(fres[mask]),
                                    c(rays[:, 3:][mask]), c(ldir), c(lrgb), c(lpdf), n_sample=96, near=0.05, far=1.5)
-    r = _record("C5-device-sampler", "relit_rgb", c(got_rgb), ref_rgb)
+    r = _record(C5S, "relit_rgb", c(got_rgb), ref_rgb)
     assert r["max_rel_floor1"] < TOL, r

@@ -372,6 +372,48 @@ def test_occupancy_maintenance_on_device(env):
 
 
 @torch.no_grad()
+def test_occupancy_maintenance_vs_reference_golden(env):
+    """The same device kernels against tests/golden/mask_maintenance.npz, which the IMPORTED REFERENCE wrote
+    (oracle/make_golden_general.py; models/tensorBase_rotated_lights.py:737-811): getDenseAlpha with and without an
+    existing mask, updateAlphaMask (new volume, returned aabb, mask aabb), filtering_rays in both modes on the new mask,
+    and a second update on top of the first (train_tensoIR.py:385-399)."""
+    import contextlib
+    import io
+    import os
+    import tensoir_amd
+    from tests.helpers import golden_checkpoint
+    mg = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mask_maintenance.npz"))
+    R = lambda k: torch.from_numpy(np.array(mg[k]))
+    eh, ew = [int(x) for x in env.g["scene/envmap_hw"]]
+    ck = golden_checkpoint(env.g)
+    grid = tuple(int(x) for x in mg["grid"])
+    nomask = {k: v for k, v in ck.items() if not k.startswith("alphaMask")}
+    m0 = tensoir_amd.model_from_checkpoint(nomask, "cuda", envmap_h=eh, envmap_w=ew)
+    assert m0.alphaMask is None
+    a, d = m0.getDenseAlpha(grid)
+    assert rel(d, R("dense_xyz"), 1.0) < 1e-6 and float((a.cpu() - R("nomask/alpha")).abs().max()) < 2e-5
+    m = tensoir_amd.model_from_checkpoint(ck, "cuda", envmap_h=eh, envmap_w=ew)
+    a, _ = m.getDenseAlpha(grid)
+    assert float((a.cpu() - R("masked/alpha")).abs().max()) < 2e-5
+    with contextlib.redirect_stdout(io.StringIO()):
+        aabb = m.updateAlphaMask(grid)
+    vol = m.alphaMask.alpha_volume[0, 0].cpu()
+    assert vol.shape == R("update/volume").shape and int((vol != R("update/volume")).sum()) == 0
+    assert rel(aabb, R("update/aabb"), 1.0) < 1e-6
+    assert float((m.alphaMask.aabb.cpu() - R("update/mask_aabb")).abs().max()) == 0.0
+    rays = R("filter/rays")
+    with contextlib.redirect_stdout(io.StringIO()):
+        kept, mask = m.filtering_rays(rays, N_samples=80, bbox_only=False)
+        _, mask_b = m.filtering_rays(rays, bbox_only=True)
+    assert torch.equal(mask.cpu(), R("filter/mask_alpha")) and torch.equal(kept.cpu(), R("filter/kept_alpha"))
+    assert torch.equal(mask_b.cpu(), R("filter/mask_bbox"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        aabb2 = m.updateAlphaMask((33, 29, 31))
+    assert int((m.alphaMask.alpha_volume[0, 0].cpu() != R("update2/volume")).sum()) == 0
+    assert rel(aabb2, R("update2/aabb"), 1.0) < 1e-6
+
+
+@torch.no_grad()
 def test_hip_graph_replay_matches_eager(env):
     """GraphedRenderer: one captured HIP graph per batch shape; identical maps to the eager path, also for a second
     batch of different rays, and an artificially small captured capacity is detected and re-captured."""

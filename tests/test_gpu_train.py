@@ -447,6 +447,68 @@ def test_general_multi_light_variant(env):
         assert gerr(sg.grad, ref.grad) < GTOL
 
 
+def test_general_multi_light_variant_vs_reference_golden(env):
+    """The general multi-light model against tests/golden/general_lights.npz, written by the IMPORTED REFERENCE
+    (oracle/make_golden_general.py; models/tensoRF_general_multi_lights.py, tensorBase_general_multi_lights.py:463-479,
+    :566-582): environment radiance of the three SG sets, the maps of an eval render, and one training step -- rendered
+    maps, loss-relevant outputs and the gradient of every SG set and of the field / decoder parameters."""
+    from tensoir_amd.general_multi_lights import TensorVMSplit as General
+    from tensoir_amd import Renderer_TensoIR_train
+    from tests.helpers import golden_checkpoint
+    O, g = env.O, env.g
+    gg = np.load(os.path.join(ROOT, "tests", "golden", "general_lights.npz"))
+    ckpt = golden_checkpoint(g)
+    kw = dict(ckpt["kwargs"])
+    for k in ("light_num", "light_rotation"):
+        kw.pop(k, None)
+    eh, ew = [int(x) for x in g["scene/envmap_hw"]]
+    m = General(device="cuda", light_name_list=["sunset", "snow", "courtyard"], envmap_h=eh, envmap_w=ew, **kw)
+    m.load_state_dict({k: v for k, v in ckpt["state_dict"].items() if k != "lgtSGs"}, strict=False)
+    m.alphaMask = env.model.alphaMask
+    m._field_key = None
+    m.march_t_stop = 0.0
+    with torch.no_grad():
+        for i, sg in enumerate(m.lgtSGs_list):
+            sg.copy_(T(gg, f"sg/{i}").cuda())
+        got = m.get_light_rgbs(T(gg, "env/dirs").cuda(), device="cuda")
+    assert got.shape == (3, 50, 3) and gerr(got, T(gg, "env/light_rgbs")) < 1e-5
+    rays, lidx = T(g, "rays/rays"), T(g, "rays/light_idx")
+    B, S = rays.shape[0], int(gg["train/n_samples"][0])
+    with torch.no_grad():
+        ret = Renderer_TensoIR_train(rays, None, lidx, m, N_samples=-1, white_bg=True, is_train=False, is_relight=True,
+                                     sample_method="fixed_envirmap", device="cuda", args=env.args)
+    for k in ("rgb_map", "depth_map", "normal_map", "albedo_map", "roughness_map", "acc_map", "rgb_with_brdf_map"):
+        ref = T(gg, f"eval/out/{k}")
+        err = float(((ret[k].cpu() - ref).abs() / ref.abs().clamp(min=1.0)).max())
+        assert err < 1e-4, (k, err)
+    # one training step: the reference's ray jitter replayed (rand [B,1], :717); the BRDF jitter draw (:937) only feeds
+    # the two smoothness losses, on which neither the rendered maps nor the SG / radiance-decoder gradients depend
+    jitter = T(gg, "train/ray_jitter")
+    orig_rand = torch.rand
+
+    def fake_rand(*a, **k):
+        if tuple(a) == (B, 1):
+            return jitter.clone().to(k.get("device", "cpu"))
+        return orig_rand(*a, **k)
+    torch.rand = fake_rand
+    try:
+        ret = Renderer_TensoIR_train(rays, None, lidx, m, N_samples=S, white_bg=True, is_train=True, is_relight=True,
+                                     sample_method="fixed_envirmap", device="cuda", args=env.args)
+    finally:
+        torch.rand = orig_rand
+    for k in ("rgb_map", "acc_map", "rgb_with_brdf_map", "normals_diff_map"):
+        ref = T(gg, f"train/out/{k}")
+        assert float((ret[k].detach().cpu() - ref).abs().max()) < 1e-4, k
+    O.training_loss(ret, T(gg, "train/rgb_gt").cuda(), True).backward()
+    for i, sg in enumerate(m.lgtSGs_list):
+        assert gerr(sg.grad, T(gg, f"train/grad/lgtSGs_list.{i}")) < GTOL, i
+    params = dict(m.named_parameters())
+    for name in ("renderModule.mlp.0.weight", "renderModule.mlp.0.bias", "renderModule.mlp.2.weight", "renderModule.mlp.4.weight"):
+        # the radiance decoder's gradient comes from rgb_map alone (the secondary pass is no_grad, relight_utils.py:344):
+        # independent of the BRDF jitter, so it must match the reference's
+        assert gerr(params[name].grad, T(gg, f"train/grad/{name}")) < GTOL, name
+
+
 def test_training_record_capacity_hints(env):
     """Second and later training steps size their record buffers from the previous step (no mid-pass host read);
     gradients equal those of the exact (first-call) route, also after a forced capacity overflow (pass re-run)."""

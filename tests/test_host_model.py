@@ -209,6 +209,13 @@ def test_adam_is_constructor_and_state_compatible_and_loud_on_cpu():
         p.grad = torch.ones_like(p)
     with pytest.raises(TensoirHipError):
         o.step()
+    # a refused step mutates nothing (validation comes first): no state entry, no advanced step count -- also when the
+    # offending parameter is the LAST one of the list
+    assert all(len(o.state[p]) == 0 for p in ps)
+    o2 = optim.Adam([{"params": ps[0], "lr": 0.02}, {"params": ps[1], "lr": 0.001, "weight_decay": 0.1}], betas=(0.9, 0.99))
+    with pytest.raises(NotImplementedError):
+        o2.step()
+    assert all(len(o2.state[p]) == 0 for p in ps)
     assert optim._dense_key(torch.empty(1, 4, 5, 3).permute(0, 2, 3, 1)) is not None
     assert optim._dense_key(torch.empty(8, 8)[:, ::2]) is None
 
