@@ -803,6 +803,17 @@ def main():
             from tests.helpers import parity_metrics as _pm
             cpu["hip_vs_reference_max_rel_floor1"] = float(f"{max(_pm(ret[k].detach().cpu(), rout[k])['max_rel_floor1'] for k in ('rgb_map', 'depth_map', 'normal_map', 'albedo_map', 'roughness_map', 'acc_map', 'rgb_with_brdf_map')):.3e}")
             del rmodel
+        else:
+            med = sorted(times)[len(times) // 2]
+            cpu = {"value": round(r_cpu.shape[0] / med, 2), "unit": "rays/s", "cores": torch.get_num_threads(),
+                   "kind": "port", "reference_checkout": False,
+                   "note": "the reference checkout (/root/reference) does not exist on the GPU box; the timed code is the oracle, "
+                           "a functional restatement on the same ATen CPU ops (F.grid_sample, cumprod, F.linear), pinned to "
+                           "the imported reference by tests/golden/.  The imported reference itself, staged once on this box "
+                           "(profiles/r03_ref_on_gpu.json): 361-373 rays/s on the full batch, 128 threads",
+                   "sample": f"every {stride}th ray of the batch ({r_cpu.shape[0]} rays x {a.samples} samples, "
+                             f"{D} dirs x {a.second_samples}), 2 warm-ups + {len(times)} timed calls, median "
+                             f"(min {min(times):.2f} s, max {max(times):.2f} s); host nproc={os.cpu_count()}"}
         # parity of the timed HIP path (graph replay outputs `ret`) against those oracle rows
         maps = ["rgb_map", "depth_map", "normal_map", "albedo_map", "roughness_map", "fresnel_map", "acc_map",
                 "rgb_with_brdf_map", "normals_diff_map", "normals_orientation_loss_map"]

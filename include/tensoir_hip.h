@@ -508,6 +508,20 @@ int tir_mlp_bwd_multi_bf16x3(const TirMlp* const* mlps, const float* const* pack
                              const float* const* h1s, const float* const* h2s, int32_t n_jobs, int64_t n,
                              float* const* g_feats, float* const* dz1s, float* const* dz2s, float* const* dz3s, void* stream);
 
+/* Weight gradients of up to four decoder invocations over the same n rows in ONE launch -- the `loss.backward()` leaves of
+ * nn.Linear in MLPRender_Fea / MLPBRDF_PEandFeature (models/tensorBase_rotated_lights.py:122-146, :182-208;
+ * train_tensoIR.py:315):   dW0 [128][150] += dz1^T x,  dW1 [128][128] += dz2^T h1,  dW2 [4][128] += dz3^T h2,
+ * db0 [128] / db1 [128] / db2 [4] += the column sums of dz1 / dz2 / dz3.  dz1, dz2 [n][128], dz3 [n][4] from
+ * tir_mlp_bwd*; h1, h2 [n][128] from the training forward; x is rebuilt in registers from feat [n][feat_stride] and
+ * aux [.][3] (aux_maps[i] may be NULL: row s uses aux row s), so no input-row buffer exists.  Split-bf16 matrix cores,
+ * fp32 accumulation; results are ADDED (atomics): zero-fill the outputs first.  Two jobs may share outputs (the BRDF
+ * decoder's two invocations).  Host arrays of n_jobs entries. */
+int tir_mlp_wgrad_multi(const float* const* dz1s, const float* const* dz2s, const float* const* dz3s,
+                        const float* const* h1s, const float* const* h2s, const float* const* feats,
+                        int32_t feat_stride, const float* const* auxs, const int32_t* const* aux_maps,
+                        float* const* dW0s, float* const* db0s, float* const* dW1s, float* const* db1s,
+                        float* const* dW2s, float* const* db2s, int32_t n_jobs, int64_t n, void* stream);
+
 /* C[M][ldc] += A^T B (+ column N = A^T 1 when ones_col != 0: the bias gradient); A [n][lda] (first M columns),
  * B [n][ldb] (first N columns); M <= 128, N + ones_col <= 160.  fp32 MFMA, split over n.  bias_out (may be NULL):
  * A^T 1 is added to bias_out[M] instead of column N of C, so that C can be the exact [M][N] weight gradient. */

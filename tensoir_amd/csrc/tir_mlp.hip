@@ -1105,6 +1105,214 @@ k_mlp_bwd_bf16_multi(TirMlpBwdJobs jobs, int fstride, int64_t n) {
                       jb.dz3, (int)blockIdx.x - ji * per, per);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradients of up to four decoder invocations in ONE pass over their rows (the leaves of the training backward):
+//     dW0 += dz1^T X  [128 x 150]     dW1 += dz2^T H1  [128 x 128]     dW2 += dz3^T H2  [4 x 128]     db_l += 1^T dz_l
+// One launch replaces, per invocation, tir_mlp_inputs (the 160-wide input rows written to HBM and read back: 0.6 GB per
+// step) and three tir_gemm_tn launches: X is rebuilt in registers from the 27 features + 3 aux values the forward kernel
+// reads, and every operand row is fetched once per workgroup straight into the matrix-core layout -- a lane of
+// v_mfma_f32_32x32x16_bf16 supplies 8 CONSECUTIVE k (= rows) of ONE column, and for a fixed row the 32 lanes of a half-wave
+// read 32 consecutive columns (one 128-B line): the "transposed" operand of a TN product is a plain coalesced load, no LDS
+// staging and no workgroup barrier anywhere.  Split-bf16 operands (hi + lo, three products, fp32 accumulation) as in the
+// forward.  16 waves per workgroup: wave (mt = w & 3, g = w >> 2) owns rows mt*32.. of the products' left operands and
+//     g = 0: dW0 column tiles 0,1,2          (A = dz1; also db0)        g = 2: dW1 column tiles 0,1  (A = dz2; also db1)
+//     g = 1: dW0 column tiles 3,4 + dW2 tile mt (A = dz1, dz3; db2)     g = 3: dW1 column tiles 2,3  (A = dz2)
+// so the four waves of a SIMD (same mt) carry the heavy (X-building) and the light (H1-loading) tiles together.
+// A workgroup walks a contiguous chunk of its job's rows, 16 rows per step, and adds its partial sums atomically at the end.
+// ------------------------------------------------------------------------------------------------
+struct TirWgradJob { const float *dz1, *dz2, *dz3, *h1, *h2, *feat, *aux; const int32_t* aux_map;
+                     float *dW0, *db0, *dW1, *db1, *dW2, *db2; };
+struct TirWgradJobs { TirWgradJob j[4]; int n_jobs; };
+
+struct WgXCol { int off; float mul, phase; bool is_aux, is_pe, zero; };
+
+// decoder input column c (reference order, models/tensorBase_rotated_lights.py:137-142 / :199-204, :12-17) -> how to build it
+__device__ __forceinline__ WgXCol wg_xcol(int c) {
+    WgXCol x{0, 1.0f, 0.0f, false, false, true};
+    if (c < F) { x.off = c; x.zero = false; }
+    else if (c < F + 3) { x.off = c - F; x.is_aux = true; x.zero = false; }
+    else if (c < F + 3 + 2 * NPF) {
+        int q = c - (F + 3);
+        const bool cs = q >= NPF;
+        if (cs) q -= NPF;
+        x.off = q / PE; x.mul = (float)(1 << (q % PE)); x.phase = cs ? 0.25f : 0.0f; x.is_pe = true; x.zero = false;
+    } else if (c < IN) {
+        int q = c - (F + 3 + 2 * NPF);
+        const bool cs = q >= 3 * PE;
+        if (cs) q -= 3 * PE;
+        x.off = q / PE; x.mul = (float)(1 << (q % PE)); x.phase = cs ? 0.25f : 0.0f; x.is_pe = true; x.is_aux = true; x.zero = false;
+    }
+    return x;
+}
+
+// 8 consecutive rows s0.. of column `col` of a row-major [.][ld] matrix (rows >= s0 + nv read as 0)
+template <bool FULL>
+__device__ __forceinline__ void wg_col8(const float* __restrict__ p, int ld, int col, int64_t s0, int nv, float (&v)[8]) {
+    const float* b = p + s0 * ld + col;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (FULL || j < nv) ? b[(int64_t)j * ld] : 0.0f;
+}
+
+// the same for decoder-input column xc of X (never materialised)
+template <bool FULL>
+__device__ __forceinline__ void wg_x8(const WgXCol& xc, const float* __restrict__ feat, int fstride, const float* __restrict__ aux,
+                                      const int64_t (&ai)[8], int64_t s0, int nv, float (&v)[8]) {
+    const float c_hi = 0.15915493667125702f, c_lo = 6.4206382432985265e-09f;      // c_hi + c_lo = 1 / (2 pi), see pe_pair
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float r = 0.0f;
+        if (FULL || j < nv) {
+            const float* src = xc.is_aux ? aux + 3 * ai[j] + xc.off : feat + (s0 + j) * fstride + xc.off;
+            const float b = *src;
+            const float k = rintf(b * c_hi);
+            float t = fmaf(b, c_hi, -k);
+            t = fmaf(b, c_lo, t);
+            const float pe = __builtin_amdgcn_sinf(fmaf(t, xc.mul, xc.phase));
+            r = xc.zero ? 0.0f : (xc.is_pe ? pe : b);
+        }
+        v[j] = r;
+    }
+}
+
+__device__ __forceinline__ void wg_atomic(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// acc tile (rows mt*32.., columns nt*32..) -> C[row][col] += acc, row < M (the D layout of the 32x32 MFMA)
+__device__ __forceinline__ void wg_flush(const f32x16& acc, float* __restrict__ C, int ldc, int row0, int M, int col, int N) {
+    if (col >= N) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        if (row < M) wg_atomic(C + (int64_t)row * ldc + col, acc[r]);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void wg_mma(const bf16x8& ah, const bf16x8& al, const bf16x8 (&bh)[NT], const bf16x8 (&bl)[NT],
+                                       f32x16 (&acc)[NT]) {
+    // product-major: never two consecutive MFMAs on one accumulator
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t], acc[t], 0, 0, 0);
+}
+
+// one 16-row step of wave group G (see the table above)
+template <int G, bool FULL>
+__device__ __forceinline__ void wg_step(const TirWgradJob& jb, int fstride, int mt, int li, int h, int64_t s0, int nv,
+                                        const WgXCol (&xc)[3], f32x16 (&acc)[3], float& bias) {
+    float v[8];
+    bf16x8 ah, al;
+    if (G <= 1) {                                           // left operand dz1, right operand X
+        wg_col8<FULL>(jb.dz1, HID, mt * 32 + li, s0, nv, v);
+        if (G == 0) bias += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        split8(v, ah, al);
+        int64_t ai[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t s = s0 + ((FULL || j < nv) ? j : 0);
+            ai[j] = jb.aux_map ? (int64_t)jb.aux_map[s] : s;
+        }
+        constexpr int NX = (G == 0) ? 3 : 2;
+        bf16x8 bh[NX], bl[NX];
+#pragma unroll
+        for (int t = 0; t < NX; ++t) {
+            float x[8];
+            wg_x8<FULL>(xc[t], jb.feat, fstride, jb.aux, ai, s0, nv, x);
+            split8(x, bh[t], bl[t]);
+        }
+        f32x16 (&a)[NX] = reinterpret_cast<f32x16 (&)[NX]>(acc);
+        wg_mma<NX>(ah, al, bh, bl, a);
+        if (G == 1) {                                       // dW2 tile: left operand dz3 (4 columns), right operand H2 tile mt
+            float z[8], y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = (li < 4 && (FULL || j < nv)) ? jb.dz3[(s0 + j) * 4 + li] : 0.0f;
+            bias += ((z[0] + z[1]) + (z[2] + z[3])) + ((z[4] + z[5]) + (z[6] + z[7]));
+            wg_col8<FULL>(jb.h2, HID, mt * 32 + li, s0, nv, y);
+            bf16x8 zh, zl, yh[1], yl[1];
+            split8(z, zh, zl);
+            split8(y, yh[0], yl[0]);
+            f32x16 (&a2)[1] = reinterpret_cast<f32x16 (&)[1]>(acc[2]);
+            wg_mma<1>(zh, zl, yh, yl, a2);
+        }
+    } else {                                                // left operand dz2, right operand H1 tiles 2(G-2), 2(G-2)+1
+        wg_col8<FULL>(jb.dz2, HID, mt * 32 + li, s0, nv, v);
+        if (G == 2) bias += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        split8(v, ah, al);
+        bf16x8 bh[2], bl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float y[8];
+            wg_col8<FULL>(jb.h1, HID, (2 * (G - 2) + t) * 32 + li, s0, nv, y);
+            split8(y, bh[t], bl[t]);
+        }
+        f32x16 (&a)[2] = reinterpret_cast<f32x16 (&)[2]>(acc);
+        wg_mma<2>(ah, al, bh, bl, a);
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void wg_path(const TirWgradJob& jb, int fstride, int mt, int li, int h, int64_t r0, int64_t r1) {
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    WgXCol xc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) xc[t] = wg_xcol((G == 0 ? t : 3 + t) * 32 + li);
+    float bias = 0.0f;
+    int64_t kb = r0;
+    for (; kb + 16 <= r1; kb += 16) wg_step<G, true>(jb, fstride, mt, li, h, kb + 8 * h, 8, xc, acc, bias);
+    if (kb < r1) {                                          // ragged tail of the chunk
+        const int64_t s0 = kb + 8 * h;
+        const int nv = (int)max((int64_t)0, min((int64_t)8, r1 - s0));
+        wg_step<G, false>(jb, fstride, mt, li, h, min(s0, r1 - 1), s0 < r1 ? nv : 0, xc, acc, bias);
+    }
+    const int row0 = mt * 32 + 4 * h;
+    if (G == 0) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) wg_flush(acc[t], jb.dW0, IN, row0, HID, t * 32 + li, IN);
+    } else if (G == 1) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) wg_flush(acc[t], jb.dW0, IN, row0, HID, (3 + t) * 32 + li, IN);
+        wg_flush(acc[2], jb.dW2, HID, 4 * h, 4, mt * 32 + li, HID);        // rows = the 4 outputs (lanes of half 0, r < 4)
+    } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) wg_flush(acc[t], jb.dW1, HID, row0, HID, (2 * (G - 2) + t) * 32 + li, HID);
+    }
+    if (G != 3) {                                           // column sums of the left operand = the bias gradients
+        bias += __shfl_xor(bias, 32, 64);
+        if (h == 0) {
+            if (G == 0) wg_atomic(jb.db0 + mt * 32 + li, bias);
+            if (G == 2) wg_atomic(jb.db1 + mt * 32 + li, bias);
+            if (G == 1 && mt == 0 && li < 4) wg_atomic(jb.db2 + li, bias);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+k_mlp_wgrad(TirWgradJobs jobs, int fstride, int64_t n) {
+    const int per = (int)gridDim.x / jobs.n_jobs;
+    const int ji = (int)blockIdx.x / per;
+    if (ji >= jobs.n_jobs) return;
+    const TirWgradJob& jb = jobs.j[ji];
+    const int bid = (int)blockIdx.x - ji * per;
+    int64_t chunk = (n + per - 1) / per;
+    chunk = (chunk + 15) / 16 * 16;
+    const int64_t r0 = (int64_t)bid * chunk, r1 = min(n, r0 + chunk);
+    if (r0 >= r1) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5, mt = w & 3;
+    switch (w >> 2) {
+        case 0: wg_path<0>(jb, fstride, mt, li, h, r0, r1); break;
+        case 1: wg_path<1>(jb, fstride, mt, li, h, r0, r1); break;
+        case 2: wg_path<2>(jb, fstride, mt, li, h, r0, r1); break;
+        default: wg_path<3>(jb, fstride, mt, li, h, r0, r1); break;
+    }
+}
+
 int check_mlp(const TirMlp* m) {
     if (!m || !m->packed) return TIR_ERR_ARG;
     if (m->feat_dim != F || m->pe != PE || m->hidden != HID || m->out_dim < 1 || m->out_dim > 4)
@@ -1396,6 +1604,32 @@ extern "C" int tir_mlp_bwd_bf16x3(const TirMlp* m, const float* packed_bwd, cons
     unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
     hipLaunchKernelGGL(k_mlp_bwd_bf16, dim3(grid), dim3(512), lds, tir_stream(stream), packed_bwd, feat, feat_stride, out,
                        g_out, h1, h2, n, m->out_dim, m->act, g_feat, dz1, dz2, dz3);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_mlp_wgrad_multi(const float* const* dz1s, const float* const* dz2s, const float* const* dz3s,
+                                   const float* const* h1s, const float* const* h2s, const float* const* feats,
+                                   int32_t feat_stride, const float* const* auxs, const int32_t* const* aux_maps,
+                                   float* const* dW0s, float* const* db0s, float* const* dW1s, float* const* db1s,
+                                   float* const* dW2s, float* const* db2s, int32_t n_jobs, int64_t n, void* stream) {
+    if (n_jobs < 1 || n_jobs > 4 || n < 0 || feat_stride < F) return TIR_ERR_ARG;
+    if (!dz1s || !dz2s || !dz3s || !h1s || !h2s || !feats || !auxs || !dW0s || !db0s || !dW1s || !db1s || !dW2s || !db2s)
+        return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    TirWgradJobs jobs;
+    jobs.n_jobs = n_jobs;
+    for (int i = 0; i < n_jobs; ++i) {
+        if (!dz1s[i] || !dz2s[i] || !dz3s[i] || !h1s[i] || !h2s[i] || !feats[i] || !auxs[i] || !dW0s[i] || !db0s[i] ||
+            !dW1s[i] || !db1s[i] || !dW2s[i] || !db2s[i])
+            return TIR_ERR_ARG;
+        jobs.j[i] = TirWgradJob{dz1s[i], dz2s[i], dz3s[i], h1s[i], h2s[i], feats[i], auxs[i], aux_maps ? aux_maps[i] : nullptr,
+                                dW0s[i], db0s[i], dW1s[i], db1s[i], dW2s[i], db2s[i]};
+    }
+    int per = 256 / n_jobs;                                  // one workgroup of 16 waves per CU, the grid split between the jobs
+    const int64_t steps = (n + 15) / 16;
+    if (steps < per) per = (int)steps;
+    hipLaunchKernelGGL(k_mlp_wgrad, dim3((unsigned)(per * n_jobs)), dim3(1024), 0, tir_stream(stream), jobs, feat_stride, n);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

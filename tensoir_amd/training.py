@@ -120,9 +120,11 @@ class _LeafStream:
         self.keep.clear()
 
 
-def _decoder_backward(dec, calls, impl=None, leaf=None, bwd=None):
+def _decoder_backward(dec, calls, impl=None, leaf=None, bwd=None, wg=None):
     """Backward of every recorded invocation of one decoder.  Returns ([g_feat per call], 6 parameter grads).
-    bwd: the (g_feat, dz1, dz2, dz3) of each call when the backward-data kernel has already run (merged launch)."""
+    bwd: the (g_feat, dz1, dz2, dz3) of each call when the backward-data kernel has already run (merged launch).
+    wg: a list -- the weight-gradient work of every call is appended to it as a job of ops.mlp_wgrad_multi (the caller
+    launches all of the stage's jobs at once) instead of being issued here as tir_mlp_inputs + three tir_gemm_tn."""
     pm, pb = dec.packed(), _packed_bwd(dec)
     dev = calls[0].feat.device
     od = pm.out_dim
@@ -145,7 +147,9 @@ def _decoder_backward(dec, calls, impl=None, leaf=None, bwd=None):
             ops.gemm_tn(dz3, 4, c.h2, 128, dW2, True, impl=impl, bias_out=db2)
             return x
 
-        if leaf is None:
+        if wg is not None:
+            wg.append((dz1, dz2, dz3, c.h1, c.h2, c.feat, c.aux, c.aux_map, dW0, db0, dW1, db1, dW2, db2))
+        elif leaf is None:
             weight_grads()
         else:
             leaf.run(weight_grads, dz1, dz2, dz3, c.feat, c.aux, c.aux_map, c.h1, c.h2, flat)
@@ -352,20 +356,26 @@ class PrimaryRenderFn(torch.autograd.Function):
                     st.calls["normal"].g_out = g_pred
             bd = _merged_backward_data(model, st.calls)      # one launch for the stage's decoders (None: one per call)
             pick = lambda *names: None if bd is None else [bd[n] for n in names]
-            (g_rad,), dec_grads["rgb"] = _decoder_backward(model.renderModule, [c], leaf=leaf, bwd=pick("rgb"))
+            # the stage's weight gradients in ONE launch on the leaf stream (TENSOIR_FUSED_WGRAD=0: per call, per layer)
+            wg = [] if (ops.MLP_IMPL == "bf16x3" and os.environ.get("TENSOIR_FUSED_WGRAD", "1") != "0" and
+                        all(cc.feat.shape[1] == ops.FEAT_STRIDE for cc in st.calls.values())) else None
+            (g_rad,), dec_grads["rgb"] = _decoder_backward(model.renderModule, [c], leaf=leaf, bwd=pick("rgb"), wg=wg)
             g_int = g_int_j = None
             if st.is_relight:
                 cb, cj = st.calls["brdf"], st.calls["brdf_j"]
                 (g_int, g_int_j), dec_grads["brdf"] = _decoder_backward(model.renderModule_brdf, [cb, cj], leaf=leaf,
-                                                                        bwd=pick("brdf", "brdf_j"))
+                                                                        bwd=pick("brdf", "brdf_j"), wg=wg)
                 if "normal" in st.calls:
                     cn = st.calls["normal"]
-                    (g_n,), dec_grads["normal"] = _decoder_backward(model.renderModule_normal, [cn], leaf=leaf, bwd=pick("normal"))
+                    (g_n,), dec_grads["normal"] = _decoder_backward(model.renderModule_normal, [cn], leaf=leaf, bwd=pick("normal"),
+                                                                    wg=wg)
                     g_int = g_int + g_n
                     if g_der is not None:
                         ops.density_grad_bwd(f, gd, st.rec_xyz, g_der)
                 else:                                   # purely_derived: the composited normal IS the derived one
                     ops.density_grad_bwd(f, gd, st.rec_xyz, g_pred)
+            if wg:
+                leaf.run(lambda: ops.mlp_wgrad_multi(wg), *[t for job in wg for t in job if t is not None])
             y_rad, y_int = ops.vm_app_bwd(f, gd, st.rec_xyz, st.lidx, st.rec_ray, g_rad, g_int)
             nb = 3 * f.n_acomp
             leaf.run(lambda: ops.gemm_tn(g_rad, model.app_dim, y_rad, nb, d_basis), g_rad, y_rad, d_basis)

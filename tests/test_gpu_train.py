@@ -119,6 +119,54 @@ def test_decoder_backward(env, which):
                 assert float(d.max()) < 5e-2 and float((d > 1e-4).double().mean()) < 2e-2, (impl, name, float(d.max()))
 
 
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 700, 4099, 70001])
+def test_fused_weight_gradients(env, n):
+    """tir_mlp_wgrad_multi: dW0 = dz1^T x, dW1 = dz2^T h1, dW2 = dz3^T h2 and the three bias gradients of several decoder
+    invocations in one launch, x rebuilt in registers from feat + aux (no tir_mlp_inputs buffer, no per-layer GEMM):
+    against fp64 products with the oracle's input rows (models/tensorBase_rotated_lights.py:137-142, :12-17).  Ragged row
+    counts (tails of 16-row steps, fewer steps than workgroups), an aux index map, two jobs accumulating into the same
+    outputs (the BRDF decoder's two invocations), NaN poison in the feature padding."""
+    from tensoir_amd import ops
+    O = env.O
+    gen = torch.Generator().manual_seed(100 + n)
+    jobs, refs = [], []
+    outs = [[torch.zeros(128, 150), torch.zeros(128), torch.zeros(128, 128), torch.zeros(128), torch.zeros(4, 128), torch.zeros(4)]
+            for _ in range(2)]
+    dev_outs = [[t.cuda() for t in o] for o in outs]
+    R = max(3, n // 5)                                    # rows of the aux table of the mapped job (rays)
+    for ji, (oi, mapped) in enumerate(((0, True), (1, False), (1, False))):
+        dz1, dz2 = torch.randn(n, 128, generator=gen), torch.randn(n, 128, generator=gen)
+        dz3 = torch.randn(n, 4, generator=gen)
+        if ji == 0:
+            dz3[:, 3] = 0.0                               # a 3-output decoder: the 4th cotangent column is zero
+        h1, h2 = torch.relu(torch.randn(n, 128, generator=gen)), torch.relu(torch.randn(n, 128, generator=gen))
+        feat = torch.randn(n, 27, generator=gen) * 1.5
+        fpad = torch.full((n, 32), float("nan"))          # the padding columns must never be read into a product
+        fpad[:, :27] = feat
+        fpad[:, 27] = 0.0                                 # (column 27 is the forward's zero pad)
+        if mapped:
+            table = torch.randn(R, 3, generator=gen)
+            amap = torch.randint(0, R, (n,), generator=gen).int()
+            aux_rows = table[amap.long()]
+            aux_dev, map_dev = table.cuda(), amap.cuda()
+        else:
+            aux_rows = torch.randn(n, 3, generator=gen)
+            aux_dev, map_dev = aux_rows.cuda(), None
+        x = O.mlp_input(feat.double(), aux_rows.double(), 2, 2)
+        refs.append((oi, dz1.double().T @ x, dz1.double().sum(0), dz2.double().T @ h1.double(), dz2.double().sum(0),
+                     dz3.double().T @ h2.double(), dz3.double().sum(0)))
+        jobs.append((dz1.cuda(), dz2.cuda(), dz3.cuda(), h1.cuda(), h2.cuda(), fpad.cuda(), aux_dev, map_dev) + tuple(dev_outs[oi]))
+    ops.mlp_wgrad_multi(jobs)
+    want = [[torch.zeros_like(t, dtype=torch.float64) for t in o] for o in outs]
+    for oi, *parts in refs:
+        for acc, part in zip(want[oi], parts):
+            acc += part
+    for oi in range(2):
+        for got, ref, name in zip(dev_outs[oi], want[oi], ("dW0", "db0", "dW1", "db1", "dW2", "db2")):
+            assert torch.isfinite(got).all(), (oi, name)
+            assert gerr(got, ref) < 3e-5, (n, oi, name, gerr(got, ref))
+
+
 def _field_grads(env, fn_hip, fn_oracle, names):
     """run fn_hip(field, grad_desc) / fn_oracle(scene with leaf params) and compare the named gradients"""
     from tensoir_amd import training
