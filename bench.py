@@ -73,7 +73,8 @@ def parse():
     ap.add_argument("--no-sharp-scene", action="store_true",
                     help="skip the secondary (informative) line on a sharp-surface scene (10-30 appearance samples per ray, as a "
                          "trained scene keeps; the headline blob keeps ~56)")
-    ap.add_argument("--workload", default="batch", choices=["batch", "image"],
+    ap.add_argument("--maps", type=int, default=5, help="relight workload: environment maps per view (the reference loop uses 5)")
+    ap.add_argument("--workload", default="batch", choices=["batch", "image", "relight", "train"],
                     help="batch = the headline 4096-ray step (weak scaling); image = one 800x800 image of BASELINE configs[3] "
                          "(3 light rotations, 1036 samples per ray) sharded over the ranks, one all-gather per image (strong scaling)")
     ap.add_argument("--tile", type=int, default=-1,
@@ -191,6 +192,212 @@ def kernel_table(timing, stats, steps, shapes, overhead_ms=0.0):
     return rows
 
 
+def attribute_kernels(run_eager, psteps, io_primary, io_secondary, device):
+    """Per-kernel attribution of the inference path: `run_eager()` issues one eager pass (every C call bracketed by events on
+    the launch stream, ops.TIMING); the ops wrappers are instrumented to count the rows each gather / decoder launch really
+    processed (device-side counts), one extra pass reads the counters of gathered density samples.  Returns
+    (rows, gpu_ms_per_step, event_overhead_ms)."""
+    from tensoir_amd import ops
+    # ---- per-kernel attribution: pass 1 brackets every C call with events on the launch stream (no counters),
+    #      pass 2 (one step) reads the device-side counters of gathered density samples ------------------
+    ops.TIMING, ops.STATS = [], None
+    shapes_acc = {"app_n": 0, "app_out": 0, "mlp_n": 0, "mlp_flops": 0, "mlpm_n": 0, "mlpm_flops": 0}
+    orig_app, orig_mlp = ops.vm_app, ops.mlp
+
+    # rows actually processed: min(buffer rows, device-side count) -- the counts are read back after the pass
+    pending = []
+
+    def app_wrap(field, xyz, *args, **kw):
+        n_dev = kw.get("n_dev", args[6] if len(args) > 6 else None)
+        want_rad = kw.get("want_rad", args[2] if len(args) > 2 else True)
+        want_int = kw.get("want_int", args[3] if len(args) > 3 else False)
+        pending.append(("app", xyz.shape[0], n_dev, int(want_rad) + int(want_int)))
+        return orig_app(field, xyz, *args, **kw)
+
+    def mlp_wrap(m, feat, *args, **kw):
+        n_dev = kw.get("n_dev", args[4] if len(args) > 4 else None)
+        pending.append(("mlp", feat.shape[0], n_dev, m.out_dim))
+        return orig_mlp(m, feat, *args, **kw)
+
+    orig_prim, orig_jit = ops.vm_app_primary, ops.vm_app_jitter
+
+    def prim_wrap(field, xyz, *args, **kw):
+        n_dev = kw.get("n_dev", args[4] if len(args) > 4 else None)
+        pending.append(("app", xyz.shape[0], n_dev, 2))            # records: radiance + intrinsic features
+        pending.append(("app", xyz.shape[0], n_dev, 1 + 3 / 27))   # jittered records: intrinsic features + the points
+        return orig_prim(field, xyz, *args, **kw)
+
+    def jit_wrap(field, xyz, *args, **kw):
+        n_dev = kw.get("n_dev", args[4] if len(args) > 4 else None)
+        pending.append(("app", xyz.shape[0], n_dev, 1 + 3 / 27))
+        return orig_jit(field, xyz, *args, **kw)
+
+    ops.vm_app_primary, ops.vm_app_jitter = prim_wrap, jit_wrap
+    orig_multi = ops.mlp_multi
+
+    def multi_wrap(jobs, n_dev=None):
+        pending.append(("mlpm", jobs[0][1].shape[0], n_dev, [m.out_dim for m, _, _, _ in jobs]))
+        return orig_multi(jobs, n_dev)
+
+    ops.mlp_multi = multi_wrap
+    ops.vm_app, ops.mlp = app_wrap, mlp_wrap
+    import tensoir_amd.field_model as FM
+    import tensoir_amd.relight as RL
+    for _ in range(psteps):
+        run_eager()
+    torch.cuda.synchronize()
+    ops.vm_app, ops.mlp, ops.mlp_multi = orig_app, orig_mlp, orig_multi
+    ops.vm_app_primary, ops.vm_app_jitter = orig_prim, orig_jit
+    for kind, rows, n_dev, x in pending:
+        n = rows if n_dev is None else min(rows, int(n_dev.item()))
+        if kind == "app":
+            shapes_acc["app_n"] += n
+            shapes_acc["app_out"] += n * 27 * 4 * x
+        elif kind == "mlpm":
+            shapes_acc["mlpm_n"] += n * len(x)
+            shapes_acc["mlpm_flops"] += sum(n * 2 * (150 * 128 + 128 * 128 + 128 * o) for o in x)
+        else:
+            shapes_acc["mlp_n"] += n
+            shapes_acc["mlp_flops"] += n * 2 * (150 * 128 + 128 * 128 + 128 * x)
+    timing = ops.TIMING
+    ops.TIMING, ops.STATS = None, {}
+    run_eager()
+    torch.cuda.synchronize()
+    stats = {k: v for k, v in ops.STATS.items()}
+    ops.STATS = None
+    shapes = {
+        "tir_march_primary_fwd": {"io_bytes": io_primary},
+        "tir_march_secondary_fwd": {"io_bytes": io_secondary},
+        "tir_vm_app_fwd": {"n": shapes_acc["app_n"], "out_bytes": shapes_acc["app_out"] / max(1, shapes_acc["app_n"])},
+        "tir_mlp_fwd": {"n": shapes_acc["mlp_n"], "flops": shapes_acc["mlp_flops"]},
+    }
+    shapes["tir_mlp_fwd_bf16x3"] = {"n": shapes_acc["mlp_n"] + shapes_acc["mlpm_n"],
+                                    "flops": shapes_acc["mlp_flops"] + shapes_acc["mlpm_flops"]}
+    ev_over = event_bracket_overhead_ms(device)
+    rows = kernel_table(timing, stats, psteps, shapes, ev_over)
+    return rows, sum(r["ms_per_step"] for r in rows), ev_over
+
+
+def load_pmc():
+    """(bytes per launch, issue fractions) from the separate rocprofv3 --pmc passes kept under profiles/."""
+    pmc_traffic = {}
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # bytes per launch from separate rocprofv3 --pmc passes
+    if os.path.exists(pmc):                                      # (tools/profile_gpu.sh + tools/summarize_prof.py)
+        try:
+            pmc_traffic = json.load(open(pmc))
+        except Exception:
+            pmc_traffic = {}
+
+    pmc_issue = {}
+    pi = os.path.join(ROOT, "profiles", "pmc_issue.json")        # issue fractions from separate rocprofv3 --pmc passes
+    if os.path.exists(pi):
+        try:
+            pmc_issue = json.load(open(pi))
+        except Exception:
+            pmc_issue = {}
+
+    return pmc_traffic, pmc_issue
+
+
+def roofline_object(r, pmc_traffic, pmc_issue):
+    """One roofline object.  bound 'mfma': useful decoder FLOPs vs the matrix-core ceiling of the operand scheme.
+    bound 'l2': the VM gathers read a field that is resident in L2 / Infinity Cache (70 MB; PMC HBM traffic is
+    ~2 % of the gather bytes), so the bounding resource is the cache hierarchy, not HBM: gather bytes (SURVEY 8d
+    model) / launch time vs the guide's aggregate L2 bandwidth.  The SURVEY 8d gather-bytes-over-HBM-peak figure is
+    kept as the labelled `sec8d_hbm_model` (a ratio that exceeds 1 for a cache-resident field -- NOT a roofline
+    fraction), next to the counter-measured HBM traffic."""
+    t = pmc_traffic.get(r["kernel"])
+    o = {"kernel": r["kernel"], "bound": r["bound"], "achieved": round(r["achieved"], 2),
+         "peak": r["peak"], "unit": r["runit"], "frac": round(r["frac"], 4),
+         "traffic": t, "avg_launch_ms": round(r["avg_ms"], 4),
+         "units_per_launch": round(r["units"], 1), "unit_of_work": r["unit"]}
+    if r["bound"] == "l2":
+        o["peak_source"] = "MI355X_MICROARCH.md L2 aggregate 34.5 TB/s"
+        o["sec8d_hbm_model"] = {"gather_bytes_per_launch": round(r["gather_bytes"], 1),
+                                "gather_GBps": round(r["achieved"], 2), "hbm_peak_GBps": HBM_PEAK_GBS,
+                                "gather_GBps_over_hbm_peak": round(r["achieved"] / HBM_PEAK_GBS, 3),
+                                "note": "SURVEY 8d gather-bytes model; the field is cache resident, so this ratio is "
+                                        "not bounded by 1 and is not a roofline fraction"}
+        if t:
+            o["hbm_traffic"] = {"bytes_per_launch": t, "GBps": round(t / (r["avg_ms"] * 1e-3) / 1e9, 2),
+                                "frac_of_hbm_peak": round(t / (r["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/pmc_traffic.json"}
+        if "taps_per_s" in r:
+            o["gather_bench"] = {"taps_per_s": round(r["taps_per_s"], 1), "ceiling_taps_per_s": GATHER_BENCH_TAPS,
+                                 "frac": round(r["taps_per_s"] / GATHER_BENCH_TAPS, 4),
+                                 "source": "tools/gather_bench.hip, coherent 192-B taps"}
+        iss = pmc_issue.get(r["kernel"]) or {}
+        if iss.get("valu_issue_frac", 0) >= 0.7:
+            # The counters say this kernel is bound by VALU issue, not by a memory level: label it so.  achieved = the rate
+            # of the unit of work measured here; frac = the share of the SIMD issue time spent on VALU instructions
+            # (separate --pmc pass); peak = the rate the same instruction stream would reach at 100 % issue.
+            # The L2 / HBM figures stay below as secondary readings.
+            per_s = r["units"] / (r["avg_ms"] * 1e-3)
+            o["l2_model"] = {"bound": "l2", "achieved": o["achieved"], "peak": o["peak"], "unit": o["unit"], "frac": o["frac"],
+                             "peak_source": o["peak_source"]}
+            o.update(bound="valu", achieved=round(per_s / 1e9, 4), unit="G " + r["unit"].split("/")[0] + "/s",
+                     frac=round(iss["valu_issue_frac"], 4), peak=round(per_s / 1e9 / iss["valu_issue_frac"], 4),
+                     peak_source="rocprofv3 --pmc: SQ_ACTIVE_INST_VALU / (4 x SQ_BUSY_CU_CYCLES) = VALU share of the SIMD issue "
+                                 f"time (profiles/pmc_issue.json, {iss.get('round', '?')}); peak = achieved / frac",
+                     pmc=iss)
+    else:
+        o["frac_of_dense_bf16_peak"] = round(r["achieved"] / BF16_MFMA_PEAK_TF, 4)
+        if r["kernel"] == "tir_mlp_fwd_bf16x3":
+            o["rocprof_kernels"] = ["k_mlp_bf16<3, true, false> (one decoder, the secondary-ray records)",
+                                    "k_mlp_bf16_multi<3> (the four primary-stage decoders in one launch)"]
+            o["aggregation"] = "both launches run the same device code (mlp_bf16_body); avg_launch_ms / units_per_launch are means over the two"
+        if r["kernel"].endswith("bf16x3"):
+            o["power_limited"] = {
+                "note": "back-to-back launches of this kernel on random data run at the board power cap: the shader clock "
+                        "settles below the 2.4 GHz the peak assumes; all-zero data (same instructions) runs at 2.39 GHz and "
+                        "15-26 % faster", "board_power_W": "1330-1400", "sustained_sclk_GHz": "1.93-2.07",
+                "frac_at_sustained_clock": round(r["frac"] * 2.4 / 2.0, 4),
+                "bf16_matrix_rate_TF": round(3.0 * r["achieved"], 1),
+                "frac_of_reference_sustained_rate": round(3.0 * r["achieved"] / 1247.0, 4),
+                "reference_point": "MI355X_MICROARCH.md (DVFS give-back): a tuned bf16 attention main loop sustains 1247 TF "
+                                   "on random data, 1483 TF on zeros; limit study of this kernel: profiles/r02_mlp_limit_study.txt",
+                "source": "tools/mlp_power.py -> profiles/r02_mlp_power.txt (rocm-smi polled during the launches)"}
+        o["peak_source"] = ("dense bf16 MFMA 2.5 PF / 3 products of the split-bf16 scheme" if r["kernel"].endswith("bf16x3")
+                            else "dense f32 MFMA 157.3 TF")
+    return o
+
+
+def dominant_roofline(rows):
+    pmc_traffic, pmc_issue = load_pmc()
+    dom = next((r for r in rows if "achieved" in r), None)
+    return roofline_object(dom, pmc_traffic, pmc_issue) if dom else None
+
+
+def timed_cpu(fn, warm, calls):
+    """Median wall time of `fn()` on the host cores (warm-ups first, time.perf_counter, no_grad)."""
+    out, ts = None, []
+    with torch.no_grad():
+        for i in range(warm + calls):
+            t0 = time.perf_counter()
+            out = fn()
+            if i >= warm:
+                ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return out, ts[len(ts) // 2], ts
+
+
+def map_parity(got, ref, keys, sel=None):
+    """max |hip - oracle| / max(|oracle|, 1) over the named maps (the test metric), per map and worst."""
+    from tests.helpers import parity_metrics
+    per, worst = {}, 0.0
+    for k in keys:
+        g = got[k].detach().cpu()
+        m = parity_metrics(g[sel] if sel is not None else g, ref[k])
+        per[k] = {kk: float(f"{vv:.3e}") for kk, vv in m.items()}
+        worst = max(worst, m["max_rel_floor1"])
+    return {"ok": worst < 1e-4, "tolerance": 1e-4, "max_rel_floor1": float(f"{worst:.3e}"), "per_map": per,
+            "metric": "max |hip - oracle| / max(|oracle|, 1) per map"}
+
+
+MAP_KEYS = ["rgb_map", "depth_map", "normal_map", "albedo_map", "roughness_map", "fresnel_map", "acc_map",
+            "rgb_with_brdf_map", "normals_diff_map", "normals_orientation_loss_map"]
+
+
 def sharp_scene_line(a, device, args):
     """The same step on a scene whose density rises 3-4x faster across the surface (blob sigma 0.2, gain 2000): the
     number of appearance samples per ray drops from ~56 to what a trained scene keeps (10-30), which moves the kernel mix
@@ -305,12 +512,40 @@ def bench_image(a):
         pr[rank] = per_rank[0]
         dist.all_reduce(pr)
         per_rank = pr.tolist()
+    roofline = parity = cpu = kernels = None
+    if rank == 0 and not a.no_cpu_baseline:
+        # dominant kernel, in-run parity and CPU baseline on ONE chunk of the image (the middle one: rays cross the object)
+        from oracle import tensoir_oracle as O          # checker / CPU baseline only
+        from tests.helpers import scene_from_model
+        from tensoir_amd import Renderer_TensoIR_train
+        c0 = (n // a.rays // 2) * a.rays
+        rc, lc = rays[c0:c0 + a.rays].contiguous(), lidx[c0:c0 + a.rays].contiguous()
+
+        def run():
+            with torch.no_grad():
+                return Renderer_TensoIR_train(rc, None, lc, model, N_samples=-1, white_bg=True, is_train=False, is_relight=True,
+                                              sample_method="fixed_envirmap", chunk_size=160000, device=device, args=args)
+        ret_c = run()
+        Mc, Dn = int((ret_c["acc_map"] > 0.5).sum()), a.env_h * a.env_w
+        rows, gpu_ms, ev_over = attribute_kernels(run, 2, a.rays * 40 + a.rays * model.nSamples * 4, Mc * Dn * 40, device)
+        roofline = dominant_roofline(rows)
+        kernels = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:6]]
+        sc = scene_from_model(ck, model, a.env_h, a.env_w)
+        stride = max(1, a.rays // 128)
+        r_cpu, l_cpu = rc.cpu()[::stride], lc.cpu()[::stride]
+        ref, med, ts = timed_cpu(lambda: O.renderer_train(sc, r_cpu, l_cpu, n_samples=-1, second_n_sample=a.second_samples), 1, 3)
+        parity = map_parity(ret_c, ref, MAP_KEYS, slice(0, None, stride))
+        parity["rays_compared"] = int(r_cpu.shape[0])
+        cpu = {"value": round(r_cpu.shape[0] / med, 2), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"every {stride}th ray of the image's middle chunk ({r_cpu.shape[0]} rays x {model.nSamples} samples, "
+                         f"{Dn} dirs x {a.second_samples}), 1 warm-up + {len(ts)} timed calls, median; host nproc={os.cpu_count()}"}
     if rank == 0:
         hit = float((img["acc_map"] > 0.5).float().mean())
         print(json.dumps({
             "metric": "full-image primary+secondary rays/sec, one 800x800 image sharded over the GPUs", "value": round(n * a.steps / elapsed, 1),
             "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 io; decoders split-bf16 x3 (hi/lo operands, 3 MFMA products), fp32 accumulate", "data": "synthetic",
             "config": {"workload": f"C4: {side}x{side} image = {n} rays in chunks of {a.rays}, VM grid {a.grid}^3, 3 light rotations "
                                    f"(light index = pixel mod 3), N_samples=-1 ({model.nSamples} per ray), secondary {a.env_h * a.env_w} dirs x "
                                    f"{a.second_samples}; full field of view ({hit:.2f} of the rays hit the object)",
@@ -321,10 +556,389 @@ def bench_image(a):
             "per_rank_render_ms": [round(1e3 * x, 3) for x in per_rank],
             "load_imbalance": round(max(per_rank) / max(min(per_rank), 1e-9), 3),
             "exchange_ms": round(1e3 * sum(exch) / len(exch), 3),
-            "roofline": None, "cpu_baseline": None,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "kernels_middle_chunk": kernels,
+            "roofline_note": "dominant kernel of the image's middle chunk, one eager pass bracketed by events (calibrated)",
         }), flush=True)
+        if parity is not None and not parity["ok"]:
+            raise SystemExit(f"[bench] PARITY FAILURE vs the oracle (image workload): {parity}")
     if use_dist:
         dist.destroy_process_group()
+
+
+def synthetic_hdr_maps(n_maps, H=1024, W=2048):
+    """Seeded 2048x1024 HDR environment maps (exp(N(0, 1.5^2)) low-pass filtered + one 100x sun disc each)."""
+    gen = torch.Generator().manual_seed(71)
+    maps = {}
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    for i in range(n_maps):
+        hdr = torch.exp(torch.randn(H // 8, W // 8, 3, generator=gen) * 1.5)
+        hdr = torch.nn.functional.interpolate(hdr.permute(2, 0, 1)[None], size=(H, W), mode="bilinear",
+                                              align_corners=False)[0].permute(1, 2, 0).contiguous()
+        hdr[((yy - 200 - 100 * i) ** 2 + (xx - 300 * (i + 1)) ** 2) < 20 ** 2] *= 100.0
+        maps[f"env{i}"] = hdr
+    return maps
+
+
+def bench_relight(a):
+    """BASELINE configs[4] (ficus relighting_test): one 800x800 view of the 400^3 field relit under `--maps` 2048x1024 HDR
+    environment maps with 512 importance samples per surface point -- the loop body of scripts/relight_importance.py:93-185.
+    Per 4096-ray chunk one primary pass, then per map: importance sampling + cosine mask on the device, visibility march of
+    the unmasked (point, cell) pairs (96 samples), BRDF x radiance x cosine / pdf, sRGB, background lookup.  Chunks are
+    sharded over the ranks (interleaved tiles), ONE all-gather of the relit colours per view.  A step = one view."""
+    import contextlib
+    import io
+    import torch.distributed as dist
+    import tensoir_amd
+    from tensoir_amd import _lib, relight, synth
+    from tensoir_amd import dist as tdist
+    world, rank, local = (int(os.environ.get(k, "0" if k != "WORLD_SIZE" else "1")) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: tensoir_amd has no CPU path")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    assert _lib.lib().tir_device_check() == 0
+    grid = a.grid if a.grid != 300 else 400                 # ficus: N_voxel_final = 400^3 (configs/relighting_test/ficus.txt)
+    ck = synth.make_checkpoint(grid=(grid,) * 3, seed=20211202)
+    model = tensoir_amd.model_from_checkpoint(ck, device, envmap_h=a.env_h, envmap_w=a.env_w)
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        model.updateAlphaMask((128, 128, 128))
+    maps = synthetic_hdr_maps(a.maps)
+    env = relight.Environment_Light(hdr_maps=maps, device=device)
+    side, Ns = a.image_side, 512
+    rays = synth.make_rays(side, side, narrow=1.0).to(device)
+    n = rays.shape[0]
+    lidx = torch.zeros(n, 1, dtype=torch.int32, device=device)
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
+        dist.init_process_group(a.backend, **({"device_id": device} if a.backend == "nccl" else {}))
+    gw = world if use_dist else 1
+    tile = a.rays if (a.tile < 0 and gw > 1) else max(a.tile, 0)
+    mine = tdist.shard_rows(n, rank, gw, tile).to(device)
+
+    @torch.no_grad()
+    def chunk_pass(c, names, counts=None):
+        """One chunk: primary maps, then per environment map the relit colours [len(c), 3] (background where acc <= 0.5)."""
+        r, l = rays[c], lidx[c]
+        out = model(r, l, N_samples=-1)
+        depth, normal, albedo, rough, fres, acc = out[1:7]
+        mask = acc > 0.5
+        surf = (r[:, :3] + depth.unsqueeze(-1) * r[:, 3:])[mask]
+        nrm, alb, rgh, fr, rd = normal[mask], albedo[mask], rough[mask], fres[mask], r[:, 3:][mask]
+        if counts is not None:
+            counts[0] += int(surf.shape[0])
+        cols = []
+        rows_hit = mask.nonzero()[:, 0]
+        for name in names:
+            rgb = relight.relight_importance_sampled(model, env, name, surf, nrm, alb, rgh, fr, rd, num_samples=Ns)
+            img = env.get_light(name, r[:, 3:]).index_put_((rows_hit,), rgb)      # (scripts/relight_importance.py:166-171
+            cols.append(img)                                                          #  tone-maps the background too: host side)
+        return (torch.cat(cols, dim=1) if cols else None), (surf, nrm, alb, rgh, fr, rd)
+
+    def view(counts=None):
+        parts = [chunk_pass(c, list(maps), counts)[0] for c in torch.split(mine, a.rays) if c.numel()]
+        local_rec = torch.cat(parts, dim=0) if parts else torch.zeros((0, 3 * len(maps)), device=device)
+        return tdist.gather_records(local_rec, n, rank, gw, tile)
+
+    for _ in range(1 + a.warmup):
+        view()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    counts = [0]
+    for _ in range(a.steps):
+        img = view(counts)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed / a.steps]
+    if use_dist:
+        pr = torch.zeros((gw,), dtype=torch.float64, device=device)
+        pr[rank] = elapsed / a.steps
+        dist.all_reduce(pr)
+        per_rank, elapsed = pr.tolist(), float(pr.max().item()) * a.steps
+        cnt = torch.tensor(counts, dtype=torch.float64, device=device)
+        dist.all_reduce(cnt)
+        counts = [int(cnt.item())]
+    roofline = parity = cpu = kernels = None
+    if rank == 0 and not a.no_cpu_baseline:
+        from oracle import tensoir_oracle as O          # checker / CPU baseline only
+        from tests.helpers import parity_metrics, scene_from_model
+        c0 = (n // a.rays // 2) * a.rays
+        c = torch.arange(c0, c0 + a.rays, device=device)
+        _, (surf, nrm, alb, rgh, fr, rd) = chunk_pass(c, [])
+        M = int(surf.shape[0])
+        rows, gpu_ms, ev_over = attribute_kernels(lambda: chunk_pass(c, list(maps)), 1,
+                                                  a.rays * 40 + a.rays * model.nSamples * 4, 0, device)
+        for r in rows:                                  # the visibility march: launches per step = maps; io = pair bookkeeping
+            if r["kernel"] == "tir_march_secondary_fwd":
+                r["note"] = f"{len(maps)} launches (one per environment map), {M} surface points x {Ns} importance samples each"
+        roofline = dominant_roofline(rows)
+        kernels = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:6]]
+        # parity: the fused device path vs the oracle's loop body, fed the cells the device drew (SURVEY 8d), map 0
+        sc = scene_from_model(ck, model, a.env_h, a.env_w)
+        name = next(iter(maps))
+        with torch.no_grad():
+            draws = env._draws
+            cell, _active = env.sample_cells(name, nrm.contiguous(), Ns)
+            env._draws = draws                           # the same draw again inside relight_importance_sampled
+            got = relight.relight_importance_sampled(model, env, name, surf, nrm, alb, rgh, fr, rd, num_samples=Ns)
+            ldir = env.hdr_dir[name].view(-1, 3)[cell.long()]
+            lrgb = env.hdr_rgbs[name].view(-1, 3)[cell.long()]
+            lpdf = env.hdr_pdf_return[name].view(-1)[cell.long()].unsqueeze(-1)
+        sel = slice(0, M, max(1, M // 96))
+        cc = lambda t: t[sel].cpu()
+        pts = int(cc(surf).shape[0])
+        ref, med, ts = timed_cpu(lambda: O.relight_importance(sc, cc(surf), cc(nrm), cc(alb), cc(rgh), cc(fr), cc(rd), cc(ldir), cc(lrgb),
+                                                              cc(lpdf), n_sample=96, near=0.05, far=1.5), 1, 3)
+        m = parity_metrics(cc(got), ref)
+        parity = {"ok": m["max_rel_floor1"] < 1e-4, "tolerance": 1e-4, "relit_rgb": {k: float(f"{v:.3e}") for k, v in m.items()},
+                  "surface_points_compared": pts, "note": "every k-th surface point of the view's middle chunk, environment map 0, the "
+                  "device-drawn cells fed to the oracle's restatement of scripts/relight_importance.py:119-170"}
+        vis_rays = pts * Ns
+        cpu = {"value": round(vis_rays / med, 1), "unit": "importance-sampled (point, direction) pairs/s", "cores": torch.get_num_threads(),
+               "kind": "port", "sample": f"{pts} surface points x {Ns} samples x 96 visibility steps, one map, 1 warm-up + {len(ts)} timed "
+               f"calls, median; host nproc={os.cpu_count()}",
+               "gpu_same_unit": round(counts[0] * Ns * len(maps) / elapsed, 1)}
+    if rank == 0:
+        print(json.dumps({
+            "metric": "relit camera rays/sec: one 800x800 view under 2048x1024 HDR maps, 512 importance samples per surface point",
+            "value": round(n * a.steps / elapsed, 1), "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 io; primary-pass decoders split-bf16 x3, fp32 accumulate; relight integration f32", "data": "synthetic",
+            "config": {"workload": f"C5: {side}x{side} view = {n} rays in chunks of {a.rays}, VM grid {grid}^3, {len(maps)} HDR maps "
+                                   f"2048x1024, {Ns} importance samples per surface point, 96 visibility samples per pair",
+                       "sharding": ("contiguous row tiles" if tile <= 0 else f"interleaved tiles of {tile} rays") +
+                                   f", one all_gather_into_tensor of {12 * len(maps)} B/ray relit colours per view",
+                       "launch": "eager per chunk (primary pass + per-map relight kernels)"},
+            "surface_points_per_view": counts[0] // max(1, a.steps),
+            "visibility_pairs_per_s": round(counts[0] * Ns * len(maps) / elapsed, 1),
+            "relit_images_per_s": round(len(maps) * a.steps / elapsed, 3),
+            "world_size": gw, "device_count": torch.cuda.device_count(), "backend": a.backend if use_dist else None,
+            "per_rank_ms_per_step": [round(1e3 * x, 3) for x in per_rank],
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "kernels_middle_chunk": kernels,
+        }), flush=True)
+        if parity is not None and not parity["ok"]:
+            raise SystemExit(f"[bench] PARITY FAILURE vs the oracle (relight workload): {parity}")
+    if use_dist:
+        dist.destroy_process_group()
+
+
+TRAIN_W = dict(rgb_brdf=0.2, normals_diff=0.0005, normals_orientation=0.001, albedo_smoothness=0.001, roughness_smoothness=0.001)
+ATOMIC_SEGMENTS_PER_S = 20.5e9      # tools/atomic_bench.hip (profiles/r01_v4_atomic_bench.txt): L2 fp32 atomics, per 64-B segment
+
+
+def train_loss(ret, gt, relight):
+    """train_tensoIR.py:262-311 with the config weights of configs/single_light/armadillo.txt (regularisers on the raw
+    parameters -- TV / L1 / ortho -- are PyTorch ops on the parameter tensors, off the per-sample path: not part of the step)."""
+    loss = torch.mean((ret["rgb_map"] - gt) ** 2)
+    if relight:
+        loss = loss + TRAIN_W["rgb_brdf"] * torch.mean((ret["rgb_with_brdf_map"] - gt) ** 2) \
+            + TRAIN_W["normals_diff"] * ret["normals_diff_map"].mean() \
+            + TRAIN_W["normals_orientation"] * ret["normals_orientation_loss_map"].mean() \
+            + TRAIN_W["roughness_smoothness"] * ret["roughness_smoothness_loss"] \
+            + TRAIN_W["albedo_smoothness"] * ret["albedo_smoothness_loss"]
+    return loss
+
+
+def bench_train(a):
+    """One training step of train_tensoIR.py:237-317 on the C2 scene: Renderer_TensoIR_train(is_train=True, stratified light
+    directions, is_relight=True) + the loss + total_loss.backward() (hand-written backward kernels) + optimizer.step() (one
+    launch).  Data parallel over ranks: every rank marches its own 4096-ray batch (weak scaling), the parameter gradients are
+    averaged with a bucketed RCCL all-reduce before the optimizer step (the reference never all-reduces: SURVEY 2.1, 8f-4)."""
+    import torch.distributed as dist
+    from tensoir_amd import Renderer_TensoIR_train, _lib, ops, optim
+    from tensoir_amd import dist as tdist
+    world, rank, local = (int(os.environ.get(k, "0" if k != "WORLD_SIZE" else "1")) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: tensoir_amd has no CPU path")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    assert _lib.lib().tir_device_check() == 0
+    ckpt, model, rays, lidx = build_scene(a, device, rank)
+    batches = [b.to(device) for b in pose_batches(rays.cpu(), max(1, a.batches), rank)]
+    model.march_t_stop = 1e-6
+    args = types.SimpleNamespace(second_nSample=a.second_samples, second_near=0.05, second_far=1.5)
+    B = rays.shape[0]
+    # ground-truth colours: the scene's own rendering of each pose, contrast-reduced (0.8 x + 0.1) -- the gradients are real, the
+    # geometry stays put (random colours per pose would teach the field fog, and the record count per step would drift)
+    with torch.no_grad():
+        gts = [(0.8 * Renderer_TensoIR_train(b, None, lidx, model, N_samples=a.samples, white_bg=True, is_train=False, is_relight=True,
+                                             sample_method="fixed_envirmap", device=device, args=args)["rgb_map"] + 0.1).contiguous()
+               for b in batches]
+    opt = optim.Adam(model.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99))
+    params = [p for g in opt.param_groups for p in g["params"]]
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
+        dist.init_process_group(a.backend, **({"device_id": device} if a.backend == "nccl" else {}))
+    state = {"i": 0, "buckets": 0}
+
+    def step():
+        i = state["i"] % len(batches)
+        state["i"] += 1
+        ret = Renderer_TensoIR_train(batches[i], None, lidx, model, N_samples=a.samples, white_bg=True, is_train=True,
+                                     is_relight=True, sample_method="stratified_sampling", device=device, args=args)
+        loss = train_loss(ret, gts[i], True)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if use_dist:
+            state["buckets"] = tdist.allreduce_gradients(params, force=a.force_dist)
+        opt.step()
+        return loss
+
+    l0 = float(step().detach())
+    for _ in range(100):               # untimed, a fixed count: clocks out of the idle state, capacities learnt for every pose
+        step()
+    torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        step()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        l1 = step()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed / a.steps]
+    if use_dist:
+        pr = torch.zeros((dist.get_world_size(),), dtype=torch.float64, device=device)
+        pr[dist.get_rank()] = elapsed / a.steps
+        dist.all_reduce(pr)
+        per_rank, elapsed = pr.tolist(), float(pr.max().item()) * a.steps
+    # ---- per entry point: events around every C call, three steps; rows of the record-bound kernels counted by a wrapper
+    recs = []
+    orig_bwd = ops.vm_app_bwd
+    ops.vm_app_bwd = lambda f, gd, xyz, *r, **k: (recs.append(int(xyz.shape[0])), orig_bwd(f, gd, xyz, *r, **k))[1]
+    ops.TIMING = []
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    ops.vm_app_bwd = orig_bwd
+    ev_over = event_bracket_overhead_ms(device)
+    agg = {}
+    for name, e0, e1 in ops.TIMING:
+        k = agg.setdefault(name, [0.0, 0])
+        k[0] += max(e0.elapsed_time(e1) - ev_over, 1e-4)
+        k[1] += 1
+    ops.TIMING = None
+    rows = sorted(((nm, v[0] / 3, v[1] / 3) for nm, v in agg.items()), key=lambda r: -r[1])
+    A = max(recs[0::2]) if recs else 0           # records (w > 1e-4 samples) of a step: the rows of the decoder / gather backward
+    by = {nm: (ms, cnt) for nm, ms, cnt in rows}
+    roofline = None
+    if "tir_vm_app_bwd" in by and A:
+        # appearance scatter: 18 taps x 48 channels of fp32 atomics per record and gather (144 x 64-B segments with the
+        # 16-lanes-per-sample layout, before run-length combining), two gathers on the records + one on the jittered records
+        ms, cnt = by["tir_vm_app_bwd"]
+        seg = 3 * A * (3 * (4 * 48 + 2 * 48)) / 16.0
+        roofline = {"kernel": "tir_vm_app_bwd", "bound": "l2-atomics", "achieved": round(seg / (ms * 1e-3) / 1e9, 3),
+                    "peak": ATOMIC_SEGMENTS_PER_S / 1e9, "unit": "G 64-B atomic segments/s",
+                    "frac": round(seg / (ms * 1e-3) / ATOMIC_SEGMENTS_PER_S, 4), "traffic": None,
+                    "avg_launch_ms": round(ms / max(cnt, 1), 4), "units_per_launch": round(3 * A / max(cnt, 1), 1),
+                    "unit_of_work": "appearance-gather cotangent rows/launch",
+                    "peak_source": "tools/atomic_bench.hip -> profiles/r01_v4_atomic_bench.txt (chip-wide L2 fp32 atomic rate per 64-B "
+                                   "segment); achieved counts the segments the algorithm requests, before the kernel's run-length "
+                                   "combining of consecutive samples in one cell (a frac above 1 is that combining at work)"}
+    wgrad = None
+    if "tir_mlp_wgrad_multi" in by and A:
+        ms, cnt = by["tir_mlp_wgrad_multi"]
+        nbytes = 4 * A * (128 + 128 + 4 + 128 + 128 + 32 + 3) * 4
+        wgrad = {"kernel": "tir_mlp_wgrad_multi", "bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms / max(cnt, 1), 4),
+                 "algorithmic_bytes": "4 decoder invocations x records x (dz1 128 + dz2 128 + dz3 4 + h1 128 + h2 128 + feat 32 + aux 3) fp32"}
+    parity = cpu = None
+    if rank == 0 and not a.no_cpu_baseline:
+        parity, cpu = train_parity_and_cpu(a, ckpt, model, batches[0], lidx, gts[0], args, device)
+    if rank == 0:
+        value = world * B * a.steps / elapsed
+        print(json.dumps({
+            "metric": "training rays/sec: forward + backward + Adam step at 4096 rays x 512 samples per GPU",
+            "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 io and parameters; decoder forward / backward / weight gradients split-bf16 x3, fp32 accumulate", "data": "synthetic",
+            "config": {"workload": f"train: Renderer_TensoIR_train(is_train=True, is_relight=True, stratified light directions) + loss + "
+                                   f"backward + Adam, {B} rays x {a.samples} samples per GPU, VM grid {a.grid}^3, {a.env_h * a.env_w} dirs x "
+                                   f"{a.second_samples}; the scene trains while it is timed (100 untimed steps first), {len(batches)} camera poses",
+                       "sharding": f"dp{world}: rays[rank-own batch], bucketed all-reduce of the {sum(p.numel() for p in params)} parameter "
+                                   f"gradients per step ({state['buckets']} buckets)" if use_dist else "single GPU",
+                       "records_per_step": A, "launch": "eager; weight-gradient leaves on a second HIP stream"},
+            "it_per_s": round(a.steps / elapsed, 2), "loss_first": l0, "loss_last": float(l1.detach()),
+            "world_size": (dist.get_world_size() if use_dist else 1), "device_count": torch.cuda.device_count(),
+            "backend": a.backend if use_dist else None, "per_rank_ms_per_step": [round(1e3 * x, 4) for x in per_rank],
+            "roofline": roofline, "roofline_weight_gradients": wgrad, "cpu_baseline": cpu, "parity": parity,
+            "hip_ms_per_step": round(sum(r[1] for r in rows), 3), "event_bracket_overhead_ms": round(ev_over, 5),
+            "entry_points": [{"name": nm, "ms_per_step": round(ms, 4), "launches": c} for nm, ms, c in rows[:14]],
+        }), flush=True)
+        if parity is not None and not parity["ok"]:
+            raise SystemExit(f"[bench] PARITY FAILURE vs the oracle (train workload): {parity}")
+    if use_dist:
+        dist.destroy_process_group()
+
+
+def train_parity_and_cpu(a, ckpt, model, rays, lidx, gt, args, device, n_sub=128):
+    """In-run parity of the training kernels at the bench's grid size: ONE step on every k-th ray of the batch (same ray jitter,
+    same BRDF-jitter noise, fixed light grid) -- loss, rendered maps and every parameter gradient against the oracle's autograd
+    (pinned to the reference's loss.backward() by tests/golden/train_grads.npz); the oracle call doubles as the CPU baseline."""
+    from oracle import tensoir_oracle as O          # checker / CPU baseline only
+    from tests.helpers import scene_from_model
+    from tensoir_amd import Renderer_TensoIR_train
+    sc = scene_from_model(ckpt, model, a.env_h, a.env_w)      # the parameters as they are NOW (the scene has been training)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    sc = O.scene_from_state_dict(sd, dict(ckpt["kwargs"]), sc.alpha_volume, sc.alpha_aabb, a.env_h, a.env_w)
+    stride = max(1, rays.shape[0] // n_sub)
+    r, l, g = rays[::stride].contiguous(), lidx[::stride].contiguous(), gt[::stride].contiguous()
+    Bs, S = r.shape[0], a.samples
+    gen = torch.Generator().manual_seed(21)
+    jitter, noise = torch.rand(Bs, 1, generator=gen), torch.randn(Bs, S, 3, generator=gen)
+    w = dict(TRAIN_W)
+    (loss_ref, grads_ref, ret_ref), med, ts = timed_cpu(
+        lambda: O.train_step_grads(sc, r.cpu(), l.cpu(), g.cpu(), is_relight=True, n_samples=S, ray_jitter=jitter, brdf_jitter=noise,
+                                   second_n_sample=a.second_samples, weights=w), 0, 2)
+    model.zero_grad(set_to_none=True)
+    orig_rand, orig_fwd = torch.rand, type(model).forward
+
+    def fake_rand(*aa, **k):
+        if tuple(aa) == (Bs, 1) or (len(aa) == 1 and tuple(aa[0]) == (Bs, 1)):
+            return jitter.clone()
+        return orig_rand(*aa, **k)
+
+    def fwd(self, rr, ll, **k):
+        return orig_fwd(self, rr, ll, _brdf_jitter_dense=noise, **k)
+    torch.rand, type(model).forward = fake_rand, fwd
+    try:
+        ret = Renderer_TensoIR_train(r, None, l, model, N_samples=S, white_bg=True, is_train=True, is_relight=True,
+                                     sample_method="fixed_envirmap", device=device, args=args)
+    finally:
+        torch.rand, type(model).forward = orig_rand, orig_fwd
+    loss = train_loss(ret, g, True)
+    loss.backward()
+    maps = {k: float(f"{float((ret[k].detach().cpu() - ret_ref[k]).abs().max()):.3e}")
+            for k in ("rgb_map", "acc_map", "depth_map", "rgb_with_brdf_map", "normal_map", "albedo_map")}
+    worst = {}
+    for name, p in model.named_parameters():
+        ref = grads_ref.get(name)
+        if ref is None or float(ref.abs().max()) == 0.0 or p.grad is None:
+            continue
+        worst[name] = float(((p.grad.detach().cpu().double() - ref.double()).abs().max() / ref.double().abs().max()))
+    model.zero_grad(set_to_none=True)
+    gmax = max(worst.values()) if worst else 0.0
+    parity = {"ok": abs(float(loss) - float(loss_ref)) < 1e-5 and max(maps.values()) < 1e-4 and gmax < 2e-3,
+              "tolerance": "maps 1e-4 abs; gradients max |hip - ref| / max |ref| per tensor < 2e-3 (fp32 atomics reorder the sums)",
+              "loss_abs_diff": float(f"{abs(float(loss) - float(loss_ref)):.3e}"), "maps_max_abs": maps,
+              "grad_max_rel": float(f"{gmax:.3e}"), "grad_tensors_compared": len(worst),
+              "worst_tensors": {k: float(f"{v:.3e}") for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:4]},
+              "rays_compared": int(Bs), "note": "one extra step on a strided subsample of the batch, identical jitter draws on both sides"}
+    cpu = {"value": round(Bs / med, 2), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"every {stride}th ray of the batch ({Bs} rays x {S} samples, {a.env_h * a.env_w} dirs x {a.second_samples}): forward + "
+                     f"autograd backward of the oracle, {len(ts)} timed calls, median (no optimizer step); host nproc={os.cpu_count()}"}
+    return parity, cpu
 
 
 def check_launch(a):
@@ -344,6 +958,10 @@ def main():
     check_launch(a)
     if a.workload == "image":
         return bench_image(a)
+    if a.workload == "relight":
+        return bench_relight(a)
+    if a.workload == "train":
+        return bench_train(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -554,170 +1172,18 @@ def main():
                  "ms_per_step": round(1e3 * el2 / n2, 4)}
         ops.MLP_IMPL = a.decoder
 
-    # ---- per-kernel attribution: pass 1 brackets every C call with events on the launch stream (no counters),
-    #      pass 2 (one step) reads the device-side counters of gathered density samples ------------------
-    ops.TIMING, ops.STATS = [], None
-    shapes_acc = {"app_n": 0, "app_out": 0, "mlp_n": 0, "mlp_flops": 0, "mlpm_n": 0, "mlpm_flops": 0}
-    orig_app, orig_mlp = ops.vm_app, ops.mlp
-
-    # rows actually processed: min(buffer rows, device-side count) -- the counts are read back after the pass
-    pending = []
-
-    def app_wrap(field, xyz, *args, **kw):
-        n_dev = kw.get("n_dev", args[6] if len(args) > 6 else None)
-        want_rad = kw.get("want_rad", args[2] if len(args) > 2 else True)
-        want_int = kw.get("want_int", args[3] if len(args) > 3 else False)
-        pending.append(("app", xyz.shape[0], n_dev, int(want_rad) + int(want_int)))
-        return orig_app(field, xyz, *args, **kw)
-
-    def mlp_wrap(m, feat, *args, **kw):
-        n_dev = kw.get("n_dev", args[4] if len(args) > 4 else None)
-        pending.append(("mlp", feat.shape[0], n_dev, m.out_dim))
-        return orig_mlp(m, feat, *args, **kw)
-
-    orig_prim, orig_jit = ops.vm_app_primary, ops.vm_app_jitter
-
-    def prim_wrap(field, xyz, *args, **kw):
-        n_dev = kw.get("n_dev", args[4] if len(args) > 4 else None)
-        pending.append(("app", xyz.shape[0], n_dev, 2))            # records: radiance + intrinsic features
-        pending.append(("app", xyz.shape[0], n_dev, 1 + 3 / 27))   # jittered records: intrinsic features + the points
-        return orig_prim(field, xyz, *args, **kw)
-
-    def jit_wrap(field, xyz, *args, **kw):
-        n_dev = kw.get("n_dev", args[4] if len(args) > 4 else None)
-        pending.append(("app", xyz.shape[0], n_dev, 1 + 3 / 27))
-        return orig_jit(field, xyz, *args, **kw)
-
-    ops.vm_app_primary, ops.vm_app_jitter = prim_wrap, jit_wrap
-    orig_multi = ops.mlp_multi
-
-    def multi_wrap(jobs, n_dev=None):
-        pending.append(("mlpm", jobs[0][1].shape[0], n_dev, [m.out_dim for m, _, _, _ in jobs]))
-        return orig_multi(jobs, n_dev)
-
-    ops.mlp_multi = multi_wrap
-    ops.vm_app, ops.mlp = app_wrap, mlp_wrap
-    import tensoir_amd.field_model as FM
-    import tensoir_amd.relight as RL
-    psteps = max(1, min(a.profile_steps, a.steps))
-    for _ in range(psteps):
-        step(eager=True)
-    torch.cuda.synchronize()
-    ops.vm_app, ops.mlp, ops.mlp_multi = orig_app, orig_mlp, orig_multi
-    ops.vm_app_primary, ops.vm_app_jitter = orig_prim, orig_jit
-    for kind, rows, n_dev, x in pending:
-        n = rows if n_dev is None else min(rows, int(n_dev.item()))
-        if kind == "app":
-            shapes_acc["app_n"] += n
-            shapes_acc["app_out"] += n * 27 * 4 * x
-        elif kind == "mlpm":
-            shapes_acc["mlpm_n"] += n * len(x)
-            shapes_acc["mlpm_flops"] += sum(n * 2 * (150 * 128 + 128 * 128 + 128 * o) for o in x)
-        else:
-            shapes_acc["mlp_n"] += n
-            shapes_acc["mlp_flops"] += n * 2 * (150 * 128 + 128 * 128 + 128 * x)
-    timing = ops.TIMING
-    ops.TIMING, ops.STATS = None, {}
-    step(eager=True)
-    torch.cuda.synchronize()
-    stats = {k: v for k, v in ops.STATS.items()}
-    ops.STATS = None
     M = int((ret["acc_map"] > 0.5).sum())
     D = a.env_h * a.env_w
-    shapes = {
-        "tir_march_primary_fwd": {"io_bytes": B * (24 + 4 + 12) + B * a.samples * 4},
-        "tir_march_secondary_fwd": {"io_bytes": M * D * (24 + 16)},
-        "tir_vm_app_fwd": {"n": shapes_acc["app_n"], "out_bytes": shapes_acc["app_out"] / max(1, shapes_acc["app_n"])},
-        "tir_mlp_fwd": {"n": shapes_acc["mlp_n"], "flops": shapes_acc["mlp_flops"]},
-    }
-    shapes["tir_mlp_fwd_bf16x3"] = {"n": shapes_acc["mlp_n"] + shapes_acc["mlpm_n"],
-                                    "flops": shapes_acc["mlp_flops"] + shapes_acc["mlpm_flops"]}
-    ev_over = event_bracket_overhead_ms(device)
-    rows = kernel_table(timing, stats, psteps, shapes, ev_over)
-    gpu_ms = sum(r["ms_per_step"] for r in rows)
+    rows, gpu_ms, ev_over = attribute_kernels(lambda: step(eager=True), max(1, min(a.profile_steps, a.steps)),
+                                              B * (24 + 4 + 12) + B * a.samples * 4, M * D * (24 + 16), device)
 
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
         return
 
-    pmc_traffic = {}
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # bytes per launch from separate rocprofv3 --pmc passes
-    if os.path.exists(pmc):                                      # (tools/profile_gpu.sh + tools/summarize_prof.py)
-        try:
-            pmc_traffic = json.load(open(pmc))
-        except Exception:
-            pmc_traffic = {}
-
-    pmc_issue = {}
-    pi = os.path.join(ROOT, "profiles", "pmc_issue.json")        # issue fractions from separate rocprofv3 --pmc passes
-    if os.path.exists(pi):
-        try:
-            pmc_issue = json.load(open(pi))
-        except Exception:
-            pmc_issue = {}
-
-    def roof(r):
-        """One roofline object.  bound 'mfma': useful decoder FLOPs vs the matrix-core ceiling of the operand scheme.
-        bound 'l2': the VM gathers read a field that is resident in L2 / Infinity Cache (70 MB; PMC HBM traffic is
-        ~2 % of the gather bytes), so the bounding resource is the cache hierarchy, not HBM: gather bytes (SURVEY 8d
-        model) / launch time vs the guide's aggregate L2 bandwidth.  The SURVEY 8d gather-bytes-over-HBM-peak figure is
-        kept as the labelled `sec8d_hbm_model` (a ratio that exceeds 1 for a cache-resident field -- NOT a roofline
-        fraction), next to the counter-measured HBM traffic."""
-        t = pmc_traffic.get(r["kernel"])
-        o = {"kernel": r["kernel"], "bound": r["bound"], "achieved": round(r["achieved"], 2),
-             "peak": r["peak"], "unit": r["runit"], "frac": round(r["frac"], 4),
-             "traffic": t, "avg_launch_ms": round(r["avg_ms"], 4),
-             "units_per_launch": round(r["units"], 1), "unit_of_work": r["unit"]}
-        if r["bound"] == "l2":
-            o["peak_source"] = "MI355X_MICROARCH.md L2 aggregate 34.5 TB/s"
-            o["sec8d_hbm_model"] = {"gather_bytes_per_launch": round(r["gather_bytes"], 1),
-                                    "gather_GBps": round(r["achieved"], 2), "hbm_peak_GBps": HBM_PEAK_GBS,
-                                    "gather_GBps_over_hbm_peak": round(r["achieved"] / HBM_PEAK_GBS, 3),
-                                    "note": "SURVEY 8d gather-bytes model; the field is cache resident, so this ratio is "
-                                            "not bounded by 1 and is not a roofline fraction"}
-            if t:
-                o["hbm_traffic"] = {"bytes_per_launch": t, "GBps": round(t / (r["avg_ms"] * 1e-3) / 1e9, 2),
-                                    "frac_of_hbm_peak": round(t / (r["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                    "source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/pmc_traffic.json"}
-            if "taps_per_s" in r:
-                o["gather_bench"] = {"taps_per_s": round(r["taps_per_s"], 1), "ceiling_taps_per_s": GATHER_BENCH_TAPS,
-                                     "frac": round(r["taps_per_s"] / GATHER_BENCH_TAPS, 4),
-                                     "source": "tools/gather_bench.hip, coherent 192-B taps"}
-            iss = pmc_issue.get(r["kernel"]) or {}
-            if iss.get("valu_issue_frac", 0) >= 0.7:
-                # The counters say this kernel is bound by VALU issue, not by a memory level: label it so.  achieved = the rate
-                # of the unit of work measured here; frac = the share of the SIMD issue time spent on VALU instructions
-                # (separate --pmc pass); peak = the rate the same instruction stream would reach at 100 % issue.
-                # The L2 / HBM figures stay below as secondary readings.
-                per_s = r["units"] / (r["avg_ms"] * 1e-3)
-                o["l2_model"] = {"bound": "l2", "achieved": o["achieved"], "peak": o["peak"], "unit": o["unit"], "frac": o["frac"],
-                                 "peak_source": o["peak_source"]}
-                o.update(bound="valu", achieved=round(per_s / 1e9, 4), unit="G " + r["unit"].split("/")[0] + "/s",
-                         frac=round(iss["valu_issue_frac"], 4), peak=round(per_s / 1e9 / iss["valu_issue_frac"], 4),
-                         peak_source="rocprofv3 --pmc: SQ_ACTIVE_INST_VALU / (4 x SQ_BUSY_CU_CYCLES) = VALU share of the SIMD issue "
-                                     f"time (profiles/pmc_issue.json, {iss.get('round', '?')}); peak = achieved / frac",
-                         pmc=iss)
-        else:
-            o["frac_of_dense_bf16_peak"] = round(r["achieved"] / BF16_MFMA_PEAK_TF, 4)
-            if r["kernel"] == "tir_mlp_fwd_bf16x3":
-                o["rocprof_kernels"] = ["k_mlp_bf16<3, true, false> (one decoder, the secondary-ray records)",
-                                        "k_mlp_bf16_multi<3> (the four primary-stage decoders in one launch)"]
-                o["aggregation"] = "both launches run the same device code (mlp_bf16_body); avg_launch_ms / units_per_launch are means over the two"
-            if r["kernel"].endswith("bf16x3"):
-                o["power_limited"] = {
-                    "note": "back-to-back launches of this kernel on random data run at the board power cap: the shader clock "
-                            "settles below the 2.4 GHz the peak assumes; all-zero data (same instructions) runs at 2.39 GHz and "
-                            "15-26 % faster", "board_power_W": "1330-1400", "sustained_sclk_GHz": "1.93-2.07",
-                    "frac_at_sustained_clock": round(r["frac"] * 2.4 / 2.0, 4),
-                    "bf16_matrix_rate_TF": round(3.0 * r["achieved"], 1),
-                    "frac_of_reference_sustained_rate": round(3.0 * r["achieved"] / 1247.0, 4),
-                    "reference_point": "MI355X_MICROARCH.md (DVFS give-back): a tuned bf16 attention main loop sustains 1247 TF "
-                                       "on random data, 1483 TF on zeros; limit study of this kernel: profiles/r02_mlp_limit_study.txt",
-                    "source": "tools/mlp_power.py -> profiles/r02_mlp_power.txt (rocm-smi polled during the launches)"}
-            o["peak_source"] = ("dense bf16 MFMA 2.5 PF / 3 products of the split-bf16 scheme" if r["kernel"].endswith("bf16x3")
-                                else "dense f32 MFMA 157.3 TF")
-        return o
+    pmc_traffic, pmc_issue = load_pmc()
+    roof = lambda r: roofline_object(r, pmc_traffic, pmc_issue)
     dom = next((r for r in rows if "achieved" in r), None)
     roofline = roof(dom) if dom else None
     # the fused VM-sample (density gather + march) kernel the north star names, whatever its rank in the table

@@ -234,7 +234,7 @@ def _memory_order(p):
     return sorted(range(p.dim()), key=lambda d: (-p.stride(d), d))
 
 
-def allreduce_gradients(params, group=None, bucket_mb: float = 64.0, average: bool = True):
+def allreduce_gradients(params, group=None, bucket_mb: float = 64.0, average: bool = True, force: bool = False):
     """Bucketed all-reduce (RCCL over xGMI with backend 'nccl') of the .grad of `params`, in place.
 
     Buckets are sized for per-link-bound ring collectives on point-to-point xGMI: 64 MB keeps the 17.4 M (300^3) /
@@ -245,7 +245,7 @@ def allreduce_gradients(params, group=None, bucket_mb: float = 64.0, average: bo
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     ps = [p for p in params if p.requires_grad]
-    if world == 1 or not ps:
+    if (world == 1 and not force) or not ps:          # force: issue the collectives on a 1-rank group too (RCCL path tests)
         return 0
     cap = max(1, int(bucket_mb * (1 << 20) / 4))
     buckets, cur, cur_n = [], [], 0

@@ -814,7 +814,7 @@ class TensorVMSplit(nn.Module):
             total = A if total_dev is None else (total_host.get() if total_host is not None else int(total_dev.item()))
             if len(hints) > 64:
                 hints.clear()
-            hints[(B, S)] = min(max(int(total * 1.25) + 4096, 1 << 14), B * S)
+            hints[(B, S)] = min(max(int(total * 1.25) + 4096, 1 << 14, int(0.97 * hints.get((B, S), 0))), B * S)      # decays slowly (alternating light / heavy batches)
             if total_dev is not None and total > cap:
                 hints.pop((B, S), None)               # next call takes the exact (synchronising) route
                 return False

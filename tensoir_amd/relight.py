@@ -109,7 +109,7 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
                 if total > cap:
                     hints.pop(n_rays, None)            # the re-run learns the count first
                     return False
-                hints[n_rays] = max(int(total * 1.5) + 4096, 1 << 14)
+                hints[n_rays] = max(int(total * 1.5) + 4096, 1 << 14, int(0.97 * hints.get(n_rays, 0)))
                 return True
             tensoIR.__dict__.setdefault("_pending_checks", []).append(check)
             return vis, oma, indirect
@@ -119,7 +119,7 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
         cap = int(total * 1.25) + 1024                 # overflow: some rays were dropped -> redo with room
     if len(hints) > 32:
         hints.clear()
-    hints[n_rays] = max(int(total * 1.5) + 4096, 1 << 14)
+    hints[n_rays] = max(int(total * 1.5) + 4096, 1 << 14, int(0.97 * hints.get(n_rays, 0)))
     return vis, oma, indirect
 
 

@@ -303,7 +303,7 @@ class PrimaryRenderFn(torch.autograd.Function):
             if len(hints) > 64:
                 hints.clear()
             if noise_dense is None:
-                hints[(B, S)] = min(max(int(total * 1.25) + 4096, 1 << 14), B * S)
+                hints[(B, S)] = min(max(int(total * 1.25) + 4096, 1 << 14, int(0.97 * hints.get((B, S), 0))), B * S)      # decays slowly: a heavy batch after a light one must not overflow
             return True
 
         st.finish = None if total_dev is None else finish
