@@ -69,6 +69,10 @@ typedef struct TirField {
     float occ_lo[3];         /* world-space box that contains every point the mask can report as occupied (the occupied   */
     float occ_hi[3];         /* voxels' extent + one cell): the secondary march skips 32-sample steps that lie outside.  */
                              /* occ_lo >= occ_hi on any axis (e.g. all zeros) = not given, nothing is skipped.            */
+    /* Launch options (performance only, results are identical either way).  They travel WITH the descriptor: the library
+     * keeps no settable state and reads no environment variable, so two embedders in one process cannot disturb each other. */
+    int32_t tune_lds_lines;  /* secondary march with the density lines staged in LDS: 0 = default (on), 1 = on, 2 = off */
+    int32_t tune_xcd_order;  /* contiguous per-XCD work ranges in the gathers / secondary march: 0 = default (off), 1 = on, 2 = off */
 } TirField;
 
 /* One 3-layer decoder (in -> hidden ReLU -> hidden ReLU -> out, then activation):
@@ -81,6 +85,7 @@ typedef struct TirMlp {
     int32_t hidden;          /* 128                                                                 */
     int32_t out_dim;         /* 3 (rgb, normal) or 4 (albedo+roughness)                             */
     int32_t act;             /* 0 = sigmoid, 1 = tanh                                               */
+    int32_t tune_grid;       /* launch option: persistent workgroups of a decoder launch, 0 = default (256 = one per CU) */
 } TirMlp;
 
 /* Environment light as spherical Gaussians + per-light z-rotation
@@ -293,10 +298,6 @@ int tir_composite_primary_fused(const float* rays, const int32_t* offsets, const
                                 int32_t is_relight, float fixed_fresnel, float* out_maps, int32_t* ticket,
                                 float* smooth_out, int64_t* rng_state, int64_t rng_step, void* stream);
 
-/* Selects the secondary-march kernel: 1 (default; env TENSOIR_LDS_LINES=0 turns it off) = density line factors staged in
- * LDS by persistent blocks where the shape allows (16 density components, <= 96 samples per ray, 3*R*16 floats of lines
- * within 150 KB), 0 = the plain kernel.  Results are bit-identical; returns the previous setting (-1 = never set). */
-int tir_set_lds_lines(int on);
 
 /* ---- K7 secondary march: sample_ray_equally + cull + density + raw2alpha
  *      (models/relight_utils.py:707-722, :657-705, :777-834).
@@ -352,10 +353,12 @@ int tir_shade_setup(const float* maps, const float* rays, const float* dirs, int
  * surf2l[cosine_mask] (models/relight_utils.py:440-441): pair_ids[0 .. *n_active) = m * D + d of the pairs with
  * active != 0 (order of wave-sized groups arbitrary), *n_active += their number (caller zeroes it, or lets
  * tir_shade_integrate_records re-arm it); vis[pair] = 0 and ray_rec_cnt[pair] = 0 (either may be NULL) for the masked
- * pairs, which then need no secondary ray at all (tir_march_secondary_ids_fwd). */
+ * pairs, which then need no secondary ray at all (tir_march_secondary_ids_fwd).  pair_order (launch option, same results):
+ * 0 = default = 1 = direction-major list (a march workgroup walks a bundle of parallel rays from neighbouring points),
+ * 2 = point-major. */
 int tir_shade_setup_compact(const float* maps, const float* rays, const float* dirs, int32_t M,
                             int32_t D, float acc_thres, float* surf, uint8_t* active, int32_t* pair_ids,
-                            int32_t* n_active, float* vis, int32_t* ray_rec_cnt, void* stream);
+                            int32_t* n_active, float* vis, int32_t* ray_rec_cnt, int32_t pair_order, void* stream);
 
 /* ---- K8: GGX_specular + rendering-equation sum + tone map
  *      (models/relight_utils.py:17-50, :452-480, :489-515).

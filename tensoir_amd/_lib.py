@@ -29,6 +29,7 @@ class TirField(C.Structure):
         ("occ_nbr", C.c_void_p),
         ("occ_dim", C.c_int32 * 3), ("occ_aabb_min", C.c_float * 3), ("occ_inv", C.c_float * 3),
         ("occ_lo", C.c_float * 3), ("occ_hi", C.c_float * 3),
+        ("tune_lds_lines", C.c_int32), ("tune_xcd_order", C.c_int32),
     ]
 
 
@@ -39,7 +40,7 @@ class TirFieldGrad(C.Structure):
 
 class TirMlp(C.Structure):
     _fields_ = [("packed", C.c_void_p), ("feat_dim", C.c_int32), ("pe", C.c_int32),
-                ("hidden", C.c_int32), ("out_dim", C.c_int32), ("act", C.c_int32)]
+                ("hidden", C.c_int32), ("out_dim", C.c_int32), ("act", C.c_int32), ("tune_grid", C.c_int32)]
 
 
 class TirEnvSG(C.Structure):
@@ -54,7 +55,6 @@ F32 = C.c_float
 # name -> (restype, argtypes); mirrors include/tensoir_hip.h one to one
 SIGNATURES = {
     "tir_version": (C.c_int, []),
-    "tir_set_lds_lines": (C.c_int, [C.c_int]),
     "tir_error_string": (C.c_char_p, [C.c_int]),
     "tir_device_check": (C.c_int, []),
     "tir_pack_plane": (C.c_int, [P, P, I32, I32, I32, P]),
@@ -95,7 +95,7 @@ SIGNATURES = {
     "tir_shade_setup": (C.c_int, [P, P, P, I32, I32, F32, P, P, P]),
     "tir_shade_integrate": (C.c_int, [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, P, P]),
     "tir_shade_integrate_records": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, P, P, P]),
-    "tir_shade_setup_compact": (C.c_int, [P, P, P, I32, I32, F32, P, P, P, P, P, P, P]),
+    "tir_shade_setup_compact": (C.c_int, [P, P, P, I32, I32, F32, P, P, P, P, P, P, I32, P]),
     "tir_march_secondary_ids_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I64, I32, I32, P, F32, P, P,
                                               P, I64, P, P, P, P, P, P, P, P, P]),
     "tir_relight_importance": (C.c_int, [P, P, P, P, P, P, P, P, P, I32, I32, P, P]),

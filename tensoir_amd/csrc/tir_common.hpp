@@ -17,11 +17,34 @@ static inline hipStream_t tir_stream(void* s) { return reinterpret_cast<hipStrea
 // XCD-aware work mapping switch (see tir::xcd_range).  Measured on the bench scene (same box, A/B): contiguous
 // per-XCD ranges leave the appearance gather unchanged (0.615 ms) and slow the secondary march by 7 % (0.509 -> 0.544 ms:
 // the eighths of the image are not equally expensive, and the 70 MB field is Infinity-Cache resident anyway), so the
-// interleaved order is the default; TIR_XCD=1 enables the partitioned order.
-#include <stdlib.h>
-static inline int tir_xcd_mapping() {
-    const char* e = getenv("TIR_XCD");
-    return (e && e[0] == '1') ? 1 : 0;
+// interleaved order is the default; TirField::tune_xcd_order = 1 enables the partitioned order.  (A per-call option carried
+// by the descriptor: the library reads no environment variable.)
+static inline int tir_xcd_mapping(const TirField* f) { return f->tune_xcd_order == 1 ? 1 : 0; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: remember (kernel, device ordinal) pairs,
+// so that a second GPU driven from the same process gets the attribute too, and hand the runtime's error code back.
+#include <mutex>
+#include <set>
+#include <utility>
+static inline int tir_allow_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return -(int)e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kernel, dev})) return TIR_OK;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return -(int)e;
+    done.insert({kernel, dev});
+    return TIR_OK;
+}
+
+// the occupancy neighbourhood bytes are indexed with 32-bit arithmetic (tir::occupancy_hit)
+static inline bool tir_occ_index_ok(const TirField* f) {
+    if (!f->occ_nbr) return true;
+    const int64_t W = f->occ_dim[0], H = f->occ_dim[1], D = f->occ_dim[2];
+    return W > 0 && H > 0 && D > 0 && H + 1 < (1 << 24) && D + 1 < (1 << 24) && (W + 1) * (H + 1) * (D + 1) < ((int64_t)1 << 31);
 }
 
 // matMode / vecMode of the reference (models/tensorBase_rotated_lights.py:398-399)
@@ -72,6 +95,14 @@ __device__ __forceinline__ Tap1 make_tap(float x, int size) {
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// a * b for a, b < 2^24 on the full-rate 24-bit multiplier.  Opaque to the optimiser on purpose: written as __umul24 the
+// product is re-associated with the following constant factor into one v_mul_lo_u32 (quarter rate).
+__device__ __forceinline__ unsigned mul_u24(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // sum_c bilinear(plane)[c] * linear(line)[c] for one VM component group
 // (one term of compute_densityfeature, models/tensoRF_rotated_lights.py:103-108)
@@ -127,10 +158,31 @@ __device__ __forceinline__ float density_feature_dyn(const TirField& f, float x,
     }
 }
 
-// feature2density (models/tensorBase_rotated_lights.py:813-817); torch softplus: threshold 20
+// torch softplus (beta 1, threshold 20): log1p(exp(x)).  The library log1pf is ~110 VALU instructions (double-float
+// arithmetic) and sat in every step of the VALU-bound march kernels; here log1p(e) = log(u) * e / (u - 1) with u = fl(1 + e)
+// (the rounding of 1 + e cancels in the ratio; u == 1 means e < 2^-24 and log1p(e) = e to that precision), the logarithm
+// on the transcendental unit (v_log_f32, 1 ulp): <= 3.5e-7 relative error over x in [-40, 20] against fp64 (torch's own
+// fp32 softplus: 1.2e-7), ~12 instructions.
+__device__ __forceinline__ float softplus20(float x) {
+    if (x > 20.0f) return x;
+    const float e = expf(x);
+    const float u = 1.0f + e;
+    const float d = u - 1.0f;
+    const float lg = __builtin_amdgcn_logf(u) * 0.69314718055994531f;
+    return (d == 0.0f) ? e : lg * (e * __builtin_amdgcn_rcpf(d));
+}
+
+// feature2density (models/tensorBase_rotated_lights.py:813-817)
 __device__ __forceinline__ float feature2density(const TirField& f, float feat) {
     if (f.act == 1) return fmaxf(feat, 0.0f);
-    float x = feat + f.density_shift;
+    return softplus20(feat + f.density_shift);
+}
+
+// the same through the library's log1pf: occupancy-mask building (tir_dense_alpha) thresholds alpha against 1e-3 and is
+// compared voxel by voxel with masks the reference built -- off the hot path, it keeps the last-ulp behaviour it had
+__device__ __forceinline__ float feature2density_ref(const TirField& f, float feat) {
+    if (f.act == 1) return fmaxf(feat, 0.0f);
+    const float x = feat + f.density_shift;
     return (x > 20.0f) ? x : log1pf(expf(x));
 }
 
@@ -150,7 +202,9 @@ __device__ __forceinline__ bool occupancy_hit(const TirField& f, float px, float
     fx = fminf(fmaxf(fx, -2.0f), (float)W); fy = fminf(fmaxf(fy, -2.0f), (float)H); fz = fminf(fmaxf(fz, -2.0f), (float)D);
     const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
     if ((x0 < -1) | (x0 >= W) | (y0 < -1) | (y0 >= H) | (z0 < -1) | (z0 >= D)) return false;
-    const uint32_t b = f.occ_nbr[((size_t)(z0 + 1) * (H + 1) + (y0 + 1)) * (W + 1) + (x0 + 1)];
+    // 32-bit index (launchers check (W+1)(H+1)(D+1) < 2^31, tir_occ_index_ok): one 24-bit and one 32-bit multiply instead of
+    // two 64-bit ones
+    const uint32_t b = f.occ_nbr[(mul_u24((unsigned)(z0 + 1), (unsigned)(H + 1)) + (unsigned)(y0 + 1)) * (unsigned)(W + 1) + (unsigned)(x0 + 1)];
     // corners with a zero interpolation weight (fraction exactly 0) do not count
     const uint32_t mx = (ix - fx) > 0.0f ? 0xFFu : 0x55u;
     const uint32_t my = (iy - fy) > 0.0f ? 0xFFu : 0x33u;
@@ -178,7 +232,9 @@ __device__ __forceinline__ float density_feature_chunk(const TirField& f, float 
         // 32-bit element offsets (a plane holds < 2^31 floats, checked at launch): scalar base + one VGPR offset per
         // tap instead of 64-bit address arithmetic per lane
         const float* pl = f.dplane[i];
-        const unsigned r0 = (unsigned)(ty.i0 * W) * (C4 * 4) + 4 * c, r1 = (unsigned)(ty.i1 * W) * (C4 * 4) + 4 * c;
+        // row offsets with the full-rate 24-bit multiply (v_mul_u32_u24; indices and extents are < 2^24, the 32-bit
+        // v_mul_lo_u32 issues at a quarter of the rate and this kernel is VALU-issue bound)
+        const unsigned r0 = mul_u24((unsigned)ty.i0, (unsigned)W) * (C4 * 4) + 4 * c, r1 = mul_u24((unsigned)ty.i1, (unsigned)W) * (C4 * 4) + 4 * c;
         const unsigned x0 = (unsigned)tx.i0 * (C4 * 4), x1 = (unsigned)tx.i1 * (C4 * 4);
         const float4 a = ld4(pl + (r0 + x0));
         const float4 b = ld4(pl + (r0 + x1));
@@ -211,7 +267,9 @@ __device__ __forceinline__ float density_feature_chunk_lds(const TirField& f, co
         Tap1 tx = make_tap(p[m0], W), ty = make_tap(p[m1], H), tl = make_tap(p[vi], R);
         const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
         const float* pl = f.dplane[i];
-        const unsigned r0 = (unsigned)(ty.i0 * W) * (C4 * 4) + 4 * c, r1 = (unsigned)(ty.i1 * W) * (C4 * 4) + 4 * c;
+        // row offsets with the full-rate 24-bit multiply (v_mul_u32_u24; indices and extents are < 2^24, the 32-bit
+        // v_mul_lo_u32 issues at a quarter of the rate and this kernel is VALU-issue bound)
+        const unsigned r0 = mul_u24((unsigned)ty.i0, (unsigned)W) * (C4 * 4) + 4 * c, r1 = mul_u24((unsigned)ty.i1, (unsigned)W) * (C4 * 4) + 4 * c;
         const unsigned x0 = (unsigned)tx.i0 * (C4 * 4), x1 = (unsigned)tx.i1 * (C4 * 4);
         const float4 a = ld4(pl + (r0 + x0));
         const float4 b = ld4(pl + (r0 + x1));

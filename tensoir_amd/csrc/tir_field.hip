@@ -88,6 +88,7 @@ static int check_field(const TirField* f) {
         for (int j = i + 1; j < 3; ++j)
             if ((int64_t)f->grid[i] * f->grid[j] * (f->n_acomp > f->n_dcomp ? f->n_acomp : f->n_dcomp) >= ((int64_t)1 << 31)) return TIR_ERR_UNSUPPORTED;
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
+    if (!tir_occ_index_ok(f)) return TIR_ERR_UNSUPPORTED;
     return TIR_OK;
 }
 
@@ -157,7 +158,7 @@ k_dense_alpha(TirField f, const float* __restrict__ lin_x, const float* __restri
         const float x = norm_coord(p[0], f.aabb_min[0], f.inv_aabb[0]);
         const float y = norm_coord(p[1], f.aabb_min[1], f.inv_aabb[1]);
         const float z = norm_coord(p[2], f.aabb_min[2], f.inv_aabb[2]);
-        sigma = feature2density(f, density_feature_dyn(f, x, y, z));
+        sigma = feature2density_ref(f, density_feature_dyn(f, x, y, z));
     }
     alpha[i] = 1.0f - expf(-sigma * length);
 }
@@ -321,7 +322,7 @@ k_density_grad(TirField f, const float* __restrict__ xyz, float* __restrict__ si
     if (f.act == 1) { sg = fmaxf(feat, 0.f); ds = feat > 0.f ? 1.f : 0.f; }
     else {
         float x = feat + f.density_shift;
-        sg = (x > 20.f) ? x : log1pf(expf(x));
+        sg = softplus20(x);
         ds = (x > 20.f) ? 1.f : 1.0f / (1.0f + expf(-x));
     }
     float gx = ds * g[0], gy = ds * g[1], gz = ds * g[2];
@@ -782,7 +783,7 @@ static int launch_app_bf16(const TirField* f, const float* xyz, const int32_t* l
     const size_t lds = (size_t)2 * 3 * 2 * 2 * 64 * 16 + (size_t)4 * nx * 16 * TIR_XS * sizeof(float);
     int64_t blocks = (n + 63) / 64;
     if (blocks > 2048) blocks = 2048;
-    const int xcd_on = tir_xcd_mapping();
+    const int xcd_on = tir_xcd_mapping(f);
     if (xcd_on) blocks = (blocks + 7) / 8 * 8;
     dim3 g((unsigned)blocks), b(256);
     if (rad && intr) hipLaunchKernelGGL((k_vm_app_bf16<C4, true, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on);
@@ -808,21 +809,17 @@ static int launch_app(const TirField* f, const float* xyz, const int32_t* li, co
     const size_t lds = (size_t)(3 * CA * 32 + (lt_rows + 1) * 3 * CA + 4 * nx * CA * TIR_XLD) * sizeof(float);
     int64_t blocks = (n + 63) / 64;
     if (blocks > 2048) blocks = 2048;
-    const int xcd_on = tir_xcd_mapping();
+    const int xcd_on = tir_xcd_mapping(f);
     if (xcd_on) blocks = (blocks + 7) / 8 * 8;
     dim3 g((unsigned)blocks), b(256);
-    static bool attr_set = false;
-    if (!attr_set) {   // > 64 KB only for unusually wide fields; harmless otherwise
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_mfma<C4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_mfma<C4, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_mfma<C4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
     if (lds > 160 * 1024) return TIR_ERR_UNSUPPORTED;
+    // > 64 KB only for unusually wide fields; harmless otherwise
+    if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_vm_app_mfma<C4, true, true>), 160 * 1024)) return rc;
+    if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_vm_app_mfma<C4, true, false>), 160 * 1024)) return rc;
+    if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_vm_app_mfma<C4, false, true>), 160 * 1024)) return rc;
     if (jt.scale != 0.0f) {
         if (rad || !intr) return TIR_ERR_ARG;
-        static bool jattr = false;
-        if (!jattr) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_mfma<C4, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); jattr = true; }
+        if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_vm_app_mfma<C4, false, true, true>), 160 * 1024)) return rc;
         hipLaunchKernelGGL((k_vm_app_mfma<C4, false, true, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on, jt, lt_rows);
         return TIR_OK;
     }
@@ -903,12 +900,8 @@ extern "C" int tir_vm_app_primary_fwd(const TirField* f, const float* xyz, const
     int64_t nb = (n + 63) / 64;
     if (nb > 1024) nb = 1024;
     nb = (nb + 7) / 8 * 8;                                   // both slices start at a multiple of 8 (XCD mapping)
-    const int xcd_on = tir_xcd_mapping();
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_primary<C4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    const int xcd_on = tir_xcd_mapping(f);
+    if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_vm_app_primary<C4>), 160 * 1024)) return rc;
     TirJitter jt{scale, (unsigned long long)seed, (unsigned long long)offset, reinterpret_cast<const long long*>(rng_state), xyz_out};
     hipLaunchKernelGGL((k_vm_app_primary<C4>), dim3((unsigned)(2 * nb)), dim3(256), lds, tir_stream(stream), *f, xyz, light_idx, idx_map,
                        rad_feat, int_feat, int_feat_jit, out_stride, n, n_dev, xcd_on, jt, lt_rows, (int)nb);

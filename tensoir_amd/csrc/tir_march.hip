@@ -155,6 +155,7 @@ extern "C" int tir_march_primary_fwd(const TirField* f, const float* rays, const
     if (B == 0) return TIR_OK;
     if (!rays || !weight || !acc || !depth || !app_count) return TIR_ERR_ARG;
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
+    if (!tir_occ_index_ok(f)) return TIR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_march_primary, dim3((B + 3) / 4), dim3(256), 0, tir_stream(stream), *f, rays,
                        ray_jitter, B, S, t_stop, weight, acc, depth, t_end, app_count, stats, (float*)nullptr, TirMarchExtras{});
     TIR_CHECK_LAUNCH();
@@ -173,6 +174,7 @@ extern "C" int tir_march_primary_fused_fwd(const TirField* f, const float* rays,
     if (B == 0) return TIR_OK;
     if (!rays || !weight || !acc || !depth || !app_count) return TIR_ERR_ARG;
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
+    if (!tir_occ_index_ok(f)) return TIR_ERR_UNSUPPORTED;
     TirMarchExtras ex{viewdirs, zero_words, n_zero, ticket, offsets, cap, total};
     hipLaunchKernelGGL(k_march_primary, dim3((B + 3) / 4), dim3(256), 0, tir_stream(stream), *f, rays,
                        ray_jitter, B, S, t_stop, weight, acc, depth, t_end, app_count, stats, (float*)nullptr, ex);
@@ -187,6 +189,7 @@ extern "C" int tir_march_primary_train_fwd(const TirField* f, const float* rays,
     if (B == 0) return TIR_OK;
     if (!rays || !weight || !sigma || !acc || !depth || !app_count) return TIR_ERR_ARG;
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
+    if (!tir_occ_index_ok(f)) return TIR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_march_primary, dim3((B + 3) / 4), dim3(256), 0, tir_stream(stream), *f, rays,
                        ray_jitter, B, S, t_stop, weight, acc, depth, t_end, app_count,
                        (unsigned long long*)nullptr, sigma, TirMarchExtras{});
@@ -569,8 +572,8 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
         if (__any(live)) {
             float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
             if (live) {
-                const size_t oi = org_map ? (size_t)org_map[ray] : (n_dirs > 0 ? (size_t)(ray / n_dirs) : (size_t)ray);
-                const size_t di = dir_map ? (size_t)dir_map[ray] : (n_dirs > 0 ? (size_t)(ray % n_dirs) : (size_t)ray);
+                const size_t oi = org_map ? (size_t)org_map[ray] : (n_dirs > 0 ? (size_t)((unsigned)ray / (unsigned)n_dirs) : (size_t)ray);
+                const size_t di = dir_map ? (size_t)dir_map[ray] : (n_dirs > 0 ? (size_t)((unsigned)ray % (unsigned)n_dirs) : (size_t)ray);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) { o[a] = origins[3 * oi + a]; d[a] = dirs[3 * di + a]; }
             }
@@ -658,8 +661,8 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
         int base = s_base[rl];
         if (base < 0) continue;                    // uniform inside the half-wave
         const int64_t ray = s_pid[rl];
-        const size_t oi = org_map ? (size_t)org_map[ray] : (n_dirs > 0 ? (size_t)(ray / n_dirs) : (size_t)ray);
-        const size_t di = dir_map ? (size_t)dir_map[ray] : (n_dirs > 0 ? (size_t)(ray % n_dirs) : (size_t)ray);
+        const size_t oi = org_map ? (size_t)org_map[ray] : (n_dirs > 0 ? (size_t)((unsigned)ray / (unsigned)n_dirs) : (size_t)ray);
+        const size_t di = dir_map ? (size_t)dir_map[ray] : (n_dirs > 0 ? (size_t)((unsigned)ray % (unsigned)n_dirs) : (size_t)ray);
         float o[3], d[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) { o[a] = origins[3 * oi + a]; d[a] = dirs[3 * di + a]; }
@@ -757,8 +760,11 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
             if (__any(live)) {
                 float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
                 if (live) {
-                    const size_t oi = org_map ? (size_t)org_map[ray] : (n_dirs > 0 ? (size_t)(ray / n_dirs) : (size_t)ray);
-                    const size_t di = dir_map ? (size_t)dir_map[ray] : (n_dirs > 0 ? (size_t)(ray % n_dirs) : (size_t)ray);
+                    // pair id -> (point, direction) with 32-bit division (pair ids are < 2^31, checked at launch; the 64-bit
+                    // form costs ~200 instructions per ray)
+                    const unsigned ru = (unsigned)ray, nd = (unsigned)n_dirs;
+                    const size_t oi = org_map ? (size_t)org_map[ray] : (n_dirs > 0 ? (size_t)(ru / nd) : (size_t)ray);
+                    const size_t di = dir_map ? (size_t)dir_map[ray] : (n_dirs > 0 ? (size_t)(ru % nd) : (size_t)ray);
 #pragma unroll
                     for (int a = 0; a < 3; ++a) { o[a] = origins[3 * oi + a]; d[a] = dirs[3 * di + a]; }
                 }
@@ -869,8 +875,8 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
             int base = s_base[rl];
             if (base < 0) continue;                    // uniform inside the half-wave
             const int64_t ray = s_pid[rl];
-            const size_t oi = org_map ? (size_t)org_map[ray] : (n_dirs > 0 ? (size_t)(ray / n_dirs) : (size_t)ray);
-            const size_t di = dir_map ? (size_t)dir_map[ray] : (n_dirs > 0 ? (size_t)(ray % n_dirs) : (size_t)ray);
+            const size_t oi = org_map ? (size_t)org_map[ray] : (n_dirs > 0 ? (size_t)((unsigned)ray / (unsigned)n_dirs) : (size_t)ray);
+            const size_t di = dir_map ? (size_t)dir_map[ray] : (n_dirs > 0 ? (size_t)((unsigned)ray % (unsigned)n_dirs) : (size_t)ray);
             float o[3], d[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) { o[a] = origins[3 * oi + a]; d[a] = dirs[3 * di + a]; }
@@ -904,14 +910,6 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
 #endif
 }
 
-static int g_lds_lines = -1;      // -1: take TENSOIR_LDS_LINES (default on) at the first launch
-
-// 1 / 0: use / do not use the LDS-staged-lines secondary march where it applies (A/B tests); returns the previous setting
-extern "C" int tir_set_lds_lines(int on) {
-    const int prev = g_lds_lines;
-    g_lds_lines = on ? 1 : 0;
-    return prev;
-}
 
 extern "C" int tir_march_secondary_fwd(const TirField* f, const float* origins, const int32_t* org_map,
                                        const float* dirs, const int32_t* dir_map, const uint8_t* active,
@@ -941,22 +939,16 @@ extern "C" int tir_march_secondary_ids_fwd(const TirField* f, const float* origi
     if (rec_counter && (!rec_ray || !rec_w || !rec_xyz || !ray_rec_off || !ray_rec_cnt || rec_cap < 0)) return TIR_ERR_ARG;
     if (n_rays >= (int64_t)1 << 31) return TIR_ERR_UNSUPPORTED;
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
-    const int xcd_on = tir_xcd_mapping();
+    if (!tir_occ_index_ok(f)) return TIR_ERR_UNSUPPORTED;
+    const int xcd_on = tir_xcd_mapping(f);
     // LDS-staged line factors: 16 density components, <= 96 samples per ray, lines + scratch within half a CU's LDS
     {
         const int64_t line_floats = (int64_t)(f->grid[0] + f->grid[1] + f->grid[2]) * f->n_dcomp;
         const size_t fixed = ((size_t)line_floats + ((n_sample + 3) & ~3)) * sizeof(float);
         const size_t lds512 = fixed + (8 * 256 + 3 * 64) * sizeof(float), lds1024 = fixed + (16 * 256 + 3 * 128) * sizeof(float);
-        if (g_lds_lines < 0) { const char* e = getenv("TENSOIR_LDS_LINES"); g_lds_lines = (e && e[0] == '0') ? 0 : 1; }
-        if (g_lds_lines && f->n_dcomp == 16 && n_sample <= 96 && lds1024 <= 150 * 1024) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_secondary_lds<4, 3, 512>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-                hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_secondary_lds<4, 3, 1024>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-                attr_set = true;
-            }
+        if (f->tune_lds_lines != 2 && f->n_dcomp == 16 && n_sample <= 96 && lds1024 <= 150 * 1024) {
+            if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_march_secondary_lds<4, 3, 512>), 80 * 1024)) return rc;
+            if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_march_secondary_lds<4, 3, 1024>), 150 * 1024)) return rc;
             const bool small = lds512 <= 80 * 1024;                 // two 512-thread blocks per CU, else one of 1024
             const int rpb = small ? 64 : 128;
             const int64_t n_batches = (n_rays + rpb - 1) / rpb;

@@ -1344,14 +1344,8 @@ extern "C" int tir_mlp_fwd(const TirMlp* m, const float* feat, int32_t feat_stri
     if (rc) return rc;
     if (n < 0 || feat_stride < F || (n > 0 && (!feat || !aux || !out))) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
-    static bool attr_set = false;
     const size_t lds = (size_t)MFMA_FLOATS * sizeof(float);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_mfma<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return -(int)e;
-        attr_set = true;
-    }
+    if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_mlp_mfma<false>), (int)lds)) return rc;
     int64_t tiles = (n + 255) / 256;
     unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
     hipLaunchKernelGGL(k_mlp_mfma<false>, dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, feat_stride, aux,
@@ -1367,14 +1361,8 @@ extern "C" int tir_mlp_train_fwd(const TirMlp* m, const float* feat, int32_t fea
     if (rc) return rc;
     if (n < 0 || feat_stride < F || (n > 0 && (!feat || !aux || !out || !h1 || !h2))) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
-    static bool attr_set = false;
     const size_t lds = (size_t)MFMA_FLOATS * sizeof(float);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_mfma<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return -(int)e;
-        attr_set = true;
-    }
+    if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_mlp_mfma<true>), (int)lds)) return rc;
     int64_t tiles = (n + 255) / 256;
     unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
     hipLaunchKernelGGL(k_mlp_mfma<true>, dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, feat_stride, aux,
@@ -1386,16 +1374,10 @@ extern "C" int tir_mlp_train_fwd(const TirMlp* m, const float* feat, int32_t fea
 template <int NPROD, bool VEC, bool SAVE>
 static int launch_bf16_v(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux, const int32_t* aux_map, int32_t aux_mod,
                          float* out, int64_t n, const int32_t* n_dev, void* stream, float* h1 = nullptr, float* h2 = nullptr) {
-    static bool attr_set = false;
     const size_t lds = (size_t)BF_BYTES;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bf16<NPROD, VEC, SAVE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return -(int)e;
-        attr_set = true;
-    }
+    if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_mlp_bf16<NPROD, VEC, SAVE>), (int)lds)) return rc;
     int64_t tiles = (n + 255) / 256;
-    static const int grid_max = [] { const char* e = getenv("TENSOIR_MLP_GRID"); int g = e ? atoi(e) : 256; return g > 0 ? g : 256; }();
+    const int grid_max = m->tune_grid > 0 ? m->tune_grid : 256;           // launch option carried by the descriptor
     unsigned grid = (unsigned)(tiles < grid_max ? tiles : grid_max);
     hipLaunchKernelGGL((k_mlp_bf16<NPROD, VEC, SAVE>), dim3(grid), dim3(512), lds, tir_stream(stream), m->packed, feat, feat_stride, aux,
                        aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act, h1, h2);
@@ -1452,13 +1434,7 @@ static int launch_multi(const TirMlp* const* mlps, const float* const* feats, in
                               mlps[i]->act, SAVE ? h1s[i] : nullptr, SAVE ? h2s[i] : nullptr};
     }
     if (n == 0) return TIR_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bf16_multi<3, SAVE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_BYTES);
-        if (e != hipSuccess) return -(int)e;
-        attr_set = true;
-    }
+    if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_mlp_bf16_multi<3, SAVE>), (int)BF_BYTES)) return rc;
     const int64_t tiles = (n + 255) / 256;
     int per = 256 / n_jobs;
     if (tiles < per) per = (int)tiles;
@@ -1533,14 +1509,8 @@ extern "C" int tir_mlp_bwd(const TirMlp* m, const float* packed_bwd, const float
     if (!packed_bwd || n < 0 || feat_stride < F) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
     if (!feat || !out || !g_out || !h1 || !h2 || !g_feat || !dz1 || !dz2 || !dz3) return TIR_ERR_ARG;
-    static bool attr_set = false;
     const size_t lds = (size_t)BWD_FLOATS * sizeof(float);
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return -(int)e;
-        attr_set = true;
-    }
+    if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_mlp_bwd), (int)lds)) return rc;
     int64_t tiles = (n + 255) / 256;
     unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
     hipLaunchKernelGGL(k_mlp_bwd, dim3(grid), dim3(512), lds, tir_stream(stream), packed_bwd, feat, feat_stride, out,
@@ -1568,14 +1538,8 @@ extern "C" int tir_mlp_bwd_multi_bf16x3(const TirMlp* const* mlps, const float* 
                                  mlps[i]->out_dim, mlps[i]->act};
     }
     if (n == 0) return TIR_OK;
-    static bool attr_set = false;
     const size_t lds = (size_t)BWD_BF_LDS_BYTES;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_bf16_multi),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return -(int)e;
-        attr_set = true;
-    }
+    if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_mlp_bwd_bf16_multi), (int)lds)) return rc;
     const int64_t tiles = (n + 255) / 256;
     int per = 256 / n_jobs;
     if (tiles < per) per = (int)tiles;
@@ -1592,14 +1556,8 @@ extern "C" int tir_mlp_bwd_bf16x3(const TirMlp* m, const float* packed_bwd, cons
     if (!packed_bwd || n < 0 || feat_stride < F) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
     if (!feat || !out || !g_out || !h1 || !h2 || !g_feat || !dz1 || !dz2 || !dz3) return TIR_ERR_ARG;
-    static bool attr_set = false;
     const size_t lds = (size_t)BWD_BF_LDS_BYTES;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_bf16),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return -(int)e;
-        attr_set = true;
-    }
+    if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_mlp_bwd_bf16), (int)lds)) return rc;
     int64_t tiles = (n + 255) / 256;
     unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
     hipLaunchKernelGGL(k_mlp_bwd_bf16, dim3(grid), dim3(512), lds, tir_stream(stream), packed_bwd, feat, feat_stride, out,

@@ -396,15 +396,16 @@ extern "C" int tir_shade_setup(const float* maps, const float* rays, const float
 
 extern "C" int tir_shade_setup_compact(const float* maps, const float* rays, const float* dirs, int32_t M,
                                        int32_t D, float acc_thres, float* surf, uint8_t* active, int32_t* pair_ids,
-                                       int32_t* n_active, float* vis, int32_t* ray_rec_cnt, void* stream) {
+                                       int32_t* n_active, float* vis, int32_t* ray_rec_cnt, int32_t pair_order, void* stream) {
     if (M < 0 || D <= 0) return TIR_ERR_ARG;
     if (M == 0) return TIR_OK;
     if (!maps || !rays || !dirs || !surf || !active || !pair_ids || !n_active) return TIR_ERR_ARG;
     int64_t n = (int64_t)M * D;
     if (n >= ((int64_t)1 << 31)) return TIR_ERR_UNSUPPORTED;
     // pair-list order: direction-major by default (+3.7 % on the whole step, -9 % on the secondary march);
-    // TIR_PAIR_ORDER=m restores point-major for A/B runs
-    static const int dir_major = [] { const char* e = getenv("TIR_PAIR_ORDER"); return (e && e[0] == 'm') ? 0 : 1; }();
+    // pair_order = 2 gives point-major for A/B runs
+    if (pair_order < 0 || pair_order > 2) return TIR_ERR_ARG;
+    const int dir_major = pair_order == 2 ? 0 : 1;
     hipLaunchKernelGGL(k_shade_setup, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, tir_stream(stream), maps,
                        rays, dirs, M, D, acc_thres, surf, active, pair_ids, n_active, vis, ray_rec_cnt, dir_major);
     TIR_CHECK_LAUNCH();

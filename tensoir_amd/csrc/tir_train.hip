@@ -1267,6 +1267,7 @@ int check_grad_field(const TirField* f, const TirFieldGrad* g, bool density, boo
     if (g1 * g2 > cells) cells = g1 * g2;
     if (density && cells * f->n_dcomp >= (1ll << 31)) return TIR_ERR_UNSUPPORTED;
     if (app && cells * f->n_acomp >= (1ll << 30)) return TIR_ERR_UNSUPPORTED;      // 32-bit BYTE offsets
+    if (!tir_occ_index_ok(f)) return TIR_ERR_UNSUPPORTED;
     return TIR_OK;
 }
 
@@ -1292,8 +1293,7 @@ extern "C" int tir_march_primary_bwd(const TirField* f, const TirFieldGrad* g, c
 #define TIR_LAUNCH_MB(C4)                                                                                             \
     do {                                                                                                              \
         if (ll) {                                                                                                     \
-            static bool attr_set = false;                                                                             \
-            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_march_primary_bwd<C4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set = true; } \
+            if (int rc_ = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_march_primary_bwd<C4, true>), 96 * 1024)) return rc_; \
             hipLaunchKernelGGL((k_march_primary_bwd<C4, true>), grid, blk, lds, s, *f, *g, rays, ray_jitter, B, S, sigma, weight, g_weight, g_acc, g_depth, g_feature); \
         } else                                                                                                        \
             hipLaunchKernelGGL((k_march_primary_bwd<C4, false>), grid, blk, 0, s, *f, *g, rays, ray_jitter, B, S, sigma, weight, g_weight, g_acc, g_depth, g_feature); \
@@ -1327,8 +1327,7 @@ extern "C" int tir_density_grad_bwd(const TirField* f, const TirFieldGrad* g, co
 #define TIR_LAUNCH_DG(C4)                                                                                             \
     do {                                                                                                              \
         if (ll) {                                                                                                     \
-            static bool attr_set = false;                                                                             \
-            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_density_grad_bwd<C4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set = true; } \
+            if (int rc_ = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_density_grad_bwd<C4, true>), 96 * 1024)) return rc_; \
             hipLaunchKernelGGL((k_density_grad_bwd<C4, true>), grid, blk, lds, s, *f, *g, xyz, g_normal, n);          \
         } else                                                                                                        \
             hipLaunchKernelGGL((k_density_grad_bwd<C4, false>), grid, blk, 0, s, *f, *g, xyz, g_normal, n);           \
@@ -1387,13 +1386,9 @@ static int launch_app_bwd(const TirField* f, const TirFieldGrad* g, const float*
     const int64_t per_cu = (lds <= 80 * 1024) ? 2 : 1;           // persistent blocks amortise the LDS zero / flush
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     dim3 grid((unsigned)blocks), blk(threads);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_bwd<C4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_bwd<C4, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_vm_app_bwd<C4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_vm_app_bwd<C4, true, true>), 160 * 1024)) return rc;
+    if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_vm_app_bwd<C4, true, false>), 160 * 1024)) return rc;
+    if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_vm_app_bwd<C4, false, true>), 160 * 1024)) return rc;
     if (g_rad && g_int) hipLaunchKernelGGL((k_vm_app_bwd<C4, true, true>), grid, blk, lds, s, *f, *g, xyz, li, map, n, y_rad, y_int, line_lds);
     else if (g_rad)     hipLaunchKernelGGL((k_vm_app_bwd<C4, true, false>), grid, blk, lds, s, *f, *g, xyz, li, map, n, y_rad, y_int, line_lds);
     else                hipLaunchKernelGGL((k_vm_app_bwd<C4, false, true>), grid, blk, lds, s, *f, *g, xyz, li, map, n, y_rad, y_int, line_lds);

@@ -504,6 +504,7 @@ class TensorVMSplit(nn.Module):
                 f.occ_lo[:], f.occ_hi[:] = lo, hi
             else:                                       # empty mask: nothing can be hit -- a degenerate box far away
                 f.occ_lo[:], f.occ_hi[:] = [3.0e38] * 3, [3.4e38] * 3
+        f.tune_lds_lines, f.tune_xcd_order = ops.TUNE["lds_lines"], ops.TUNE["xcd_order"]      # launch options (ops.TUNE)
         keep["desc"] = f
         self._field_cache, self._field_key = keep, key
         return f

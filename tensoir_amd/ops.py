@@ -21,6 +21,20 @@ MAP_STRIDE = 20
 STATS = None
 TIMING = None
 
+# Launch options (performance only; results are the same either way).  The library itself keeps no settable state and reads no
+# environment variable: the options travel in the descriptors / arguments of each call, and THIS module is where
+# their defaults come from -- the environment of the embedding process, read once at import:
+#   TENSOIR_LDS_LINES=0   secondary march without the LDS-staged line factors        -> TirField.tune_lds_lines = 2
+#   TIR_XCD=1             contiguous per-XCD work ranges in the gathers / the march   -> TirField.tune_xcd_order = 1
+#   TENSOIR_MLP_GRID=n    persistent workgroups of a decoder launch (default 256)     -> TirMlp.tune_grid = n
+#   TIR_PAIR_ORDER=m      point-major secondary pair list (default direction-major)   -> tir_shade_setup_compact(pair_order = 2)
+TUNE = {
+    "lds_lines": 2 if os.environ.get("TENSOIR_LDS_LINES", "1") == "0" else 0,
+    "xcd_order": 1 if os.environ.get("TIR_XCD", "0") == "1" else 0,
+    "mlp_grid": max(0, int(os.environ.get("TENSOIR_MLP_GRID", "0") or 0)),
+    "pair_order": 2 if os.environ.get("TIR_PAIR_ORDER", "d")[:1] == "m" else 0,
+}
+
 
 def _stats_ptr(name, dev):
     if STATS is None:
@@ -187,7 +201,7 @@ class PackedMlp:
                                seq[4].weight, seq[4].bias, feat_dim, pe)
         self.out_dim = seq[4].weight.shape[0]
         self.desc = TirMlp(self.packed.data_ptr(), feat_dim, pe, seq[2].weight.shape[0],
-                           self.out_dim, act)
+                           self.out_dim, act, TUNE["mlp_grid"])
 
 
 # ---- field kernels --------------------------------------------------------------------------------
@@ -554,7 +568,7 @@ def shade_setup_compact(maps, rays, dirs, acc_thres, n_active):
     vis = torch.empty((M * D,), dtype=torch.float32, device=dev)
     rec_cnt = torch.empty((M * D,), dtype=torch.int32, device=dev)
     _call("tir_shade_setup_compact", _ptr(maps), _ptr(rays), _ptr(dirs), M, D, float(acc_thres), _ptr(surf), _ptr(active),
-          _ptr(pair_ids), _ptr(n_active), _ptr(vis), _ptr(rec_cnt), _stream())
+          _ptr(pair_ids), _ptr(n_active), _ptr(vis), _ptr(rec_cnt), TUNE["pair_order"], _stream())
     return surf, active, pair_ids, vis, rec_cnt
 
 

@@ -783,19 +783,20 @@ def test_lds_staged_lines_march_is_bit_identical(grid):
     pts = (torch.rand(P, 3, generator=gen) * 2 - 1).mul(1.1).cuda()
     dirs = torch.nn.functional.normalize(torch.randn(P, 3, generator=gen), dim=-1).cuda()
     li = torch.zeros(P, 1, dtype=torch.int32, device="cuda")
-    L = _lib.lib()
     res = {}
-    prev = L.tir_set_lds_lines(1)
+    f = m.packed_field()                # the launch option travels in the descriptor (TirField.tune_lds_lines: 0/1 = on, 2 = off)
+    prev = f.tune_lds_lines
     try:
         for on in (1, 0):
-            L.tir_set_lds_lines(on)
+            f.tune_lds_lines = 1 if on else 2
+            assert m.packed_field() is f
             m.__dict__.pop("_rec_cap_hints", None)
             v, nf, ind = relight.compute_radiance(m, pts, dirs, li, nSample=96, vis_near=0.05, vis_far=1.5)
             v2, nf2, ind2 = relight.compute_radiance(m, pts, dirs, li, nSample=96, vis_near=0.05, vis_far=1.5)   # hinted route
             t, tn = relight.compute_transmittance(m, pts, dirs, nSample=57, vis_near=0.05, vis_far=1.5)
             res[on] = (v, nf, ind, v2, ind2, t, tn)
     finally:
-        L.tir_set_lds_lines(1 if prev != 0 else 0)
+        f.tune_lds_lines = prev
     for a, b in zip(res[1], res[0]):
         assert torch.equal(a, b)
     assert float(res[1][0].min()) < 0.01 and float(res[1][0].max()) > 0.99 and float(res[1][2].abs().max()) > 0
