@@ -511,6 +511,13 @@ int tir_mlp_bwd_multi_bf16x3(const TirMlp* const* mlps, const float* const* pack
                              const float* const* h1s, const float* const* h2s, int32_t n_jobs, int64_t n,
                              float* const* g_feats, float* const* dz1s, float* const* dz2s, float* const* dz3s, void* stream);
 
+/* C[M][ldc] += sum_j A_j^T B_j for up to three operand pairs over the same n rows, M <= 32, N <= 160: the gradient of
+ * `basis_mat` (nn.Linear(144 -> 27, bias=False), models/tensoRF_rotated_lights.py:17) = g_feat^T y summed over the stage's
+ * appearance gathers, in one launch.  A_j [n][lda] (first M columns), B_j [n][ldb] (first N columns).  Split-bf16 matrix
+ * cores, fp32 accumulation; results are ADDED to C (atomics). */
+int tir_gemm_tn_small_bf16x3(const float* const* As, int32_t lda, int32_t M, const float* const* Bs, int32_t ldb,
+                             int32_t N, int32_t n_jobs, int64_t n, float* C, int32_t ldc, void* stream);
+
 /* Weight gradients of up to four decoder invocations over the same n rows in ONE launch -- the `loss.backward()` leaves of
  * nn.Linear in MLPRender_Fea / MLPBRDF_PEandFeature (models/tensorBase_rotated_lights.py:122-146, :182-208;
  * train_tensoIR.py:315):   dW0 [128][150] += dz1^T x,  dW1 [128][128] += dz2^T h1,  dW2 [4][128] += dz3^T h2,

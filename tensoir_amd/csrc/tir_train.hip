@@ -1024,6 +1024,85 @@ k_gemm_tn_bf16(const float* __restrict__ A, int lda, int M, const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// C[M <= 32][N <= 160] += sum over up to three (A_j, B_j) pairs of A_j[n][lda]^T B_j[n][ldb] -- the basis-matrix gradient
+// d basis_mat = g_feat^T y (27 x 144) of the stage's three appearance gathers in one launch.  Same operand path as
+// tir_mlp_wgrad_multi: a lane of v_mfma_f32_32x32x16_bf16 supplies 8 consecutive k (= rows) of one column, and for a fixed
+// row the 32 lanes of a half-wave read 32 consecutive columns, so the transposed operand is a plain coalesced load -- no
+// LDS staging, no barrier; split-bf16 (3 products, fp32 accumulation).  A wave owns ALL column tiles of the single row tile
+// and walks every fourth 16-row step of its workgroup's chunk; partial sums leave through fp32 atomics.
+// (k_gemm_tn_bf16 above stages 32-row slabs through LDS with two barriers per slab: 0.18 ms for this 230 k x (27, 144)
+// product, ~5 x its HBM time.)
+// ------------------------------------------------------------------------------------------------
+struct TirSmallGemmJob { const float* A; const float* B; };
+struct TirSmallGemmJobs { TirSmallGemmJob j[3]; int n_jobs; };
+
+__device__ __forceinline__ void gs_split8(const float (&v)[8], gb_bf16x8& hi, gb_bf16x8& lo) {
+    unsigned H[4], L[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) gb_split2(v[2 * p], v[2 * p + 1], H[p], L[p]);
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 hv = {H[0], H[1], H[2], H[3]}, lv = {L[0], L[1], L[2], L[3]};
+    hi = __builtin_bit_cast(gb_bf16x8, hv);
+    lo = __builtin_bit_cast(gb_bf16x8, lv);
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256)
+k_gemm_tn_small(TirSmallGemmJobs jobs, int lda, int M, int ldb, int N, int64_t n, float* __restrict__ C, int ldc) {
+    const int per = (int)gridDim.x / jobs.n_jobs;
+    const int ji = (int)blockIdx.x / per;
+    if (ji >= jobs.n_jobs) return;
+    const float* __restrict__ A = jobs.j[ji].A;
+    const float* __restrict__ Bm = jobs.j[ji].B;
+    const int bid = (int)blockIdx.x - ji * per;
+    int64_t chunk = (n + per - 1) / per;
+    chunk = (chunk + 15) / 16 * 16;
+    const int64_t r0 = (int64_t)bid * chunk, r1 = min(n, r0 + chunk);
+    if (r0 >= r1) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const bool a_ok = li < M;
+    for (int64_t kb = r0 + 16 * w; kb < r1; kb += 64) {
+        const int64_t s0 = kb + 8 * h;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (a_ok && s0 + j < r1) ? A[(s0 + j) * lda + li] : 0.f;
+        gb_bf16x8 ah, al, bh[NT], bl[NT];
+        gs_split8(v, ah, al);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = t * 32 + li;
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = (col < N && s0 + j < r1) ? Bm[(s0 + j) * ldb + col] : 0.f;
+            gs_split8(y, bh[t], bl[t]);
+        }
+        // product-major: never two consecutive MFMAs on one accumulator
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = t * 32 + li;
+        if (col >= N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 4 * h + (r & 3) + 8 * (r >> 2);
+            if (row < M) atomic_add_f32(C + (size_t)row * ldc + col, acc[t][r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Shading backward: one wave per surface point, lanes over light directions.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void normalize3(float& x, float& y, float& z, float eps) {
@@ -1567,5 +1646,32 @@ extern "C" int tir_adam_step(int32_t n_tensors, float* const* p, const float* co
         hipLaunchKernelGGL(k_adam, dim3((unsigned)chunks), dim3(256), 0, s, tab, beta1, beta2, eps);
         TIR_CHECK_LAUNCH();
     }
+    return TIR_OK;
+}
+
+extern "C" int tir_gemm_tn_small_bf16x3(const float* const* As, int32_t lda, int32_t M, const float* const* Bs, int32_t ldb,
+                                        int32_t N, int32_t n_jobs, int64_t n, float* C, int32_t ldc, void* stream) {
+    if (n_jobs < 1 || n_jobs > 3 || !As || !Bs || !C || n < 0 || M < 1 || M > 32 || N < 1 || N > 160 || lda < M || ldb < N || ldc < N)
+        return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    TirSmallGemmJobs jobs;
+    jobs.n_jobs = n_jobs;
+    for (int i = 0; i < n_jobs; ++i) {
+        if (!As[i] || !Bs[i]) return TIR_ERR_ARG;
+        jobs.j[i] = TirSmallGemmJob{As[i], Bs[i]};
+    }
+    int per = 256 / n_jobs;
+    const int64_t steps = (n + 63) / 64;                     // a workgroup's four waves take one 16-row step each
+    if (steps < per) per = (int)steps;
+    const dim3 g((unsigned)(per * n_jobs)), b(256);
+    hipStream_t s = tir_stream(stream);
+    switch ((N + 31) / 32) {
+        case 1: hipLaunchKernelGGL(k_gemm_tn_small<1>, g, b, 0, s, jobs, lda, M, ldb, N, n, C, ldc); break;
+        case 2: hipLaunchKernelGGL(k_gemm_tn_small<2>, g, b, 0, s, jobs, lda, M, ldb, N, n, C, ldc); break;
+        case 3: hipLaunchKernelGGL(k_gemm_tn_small<3>, g, b, 0, s, jobs, lda, M, ldb, N, n, C, ldc); break;
+        case 4: hipLaunchKernelGGL(k_gemm_tn_small<4>, g, b, 0, s, jobs, lda, M, ldb, N, n, C, ldc); break;
+        default: hipLaunchKernelGGL(k_gemm_tn_small<5>, g, b, 0, s, jobs, lda, M, ldb, N, n, C, ldc); break;
+    }
+    TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

@@ -835,6 +835,22 @@ def mlp_bwd_multi(jobs):
     return res
 
 
+def gemm_tn_small(pairs, M, N, C_out):
+    """C_out[M, N] += sum over the (A, B) pairs of A[:, :M]^T @ B[:, :N], M <= 32, N <= 160, every pair over the same number of
+    rows (tir_gemm_tn_small_bf16x3: the basis-matrix gradient of several appearance gathers in one launch)."""
+    k = len(pairs)
+    As = [f32(a, "A") for a, _ in pairs]
+    Bs = [f32(b, "B") for _, b in pairs]
+    n = As[0].shape[0]
+    if any(a.shape[0] != n or b.shape[0] != n or a.shape[1] != As[0].shape[1] or b.shape[1] != Bs[0].shape[1] for a, b in zip(As, Bs)):
+        raise ValueError("gemm_tn_small: every pair needs the same row count and strides")
+    arr = lambda ts: (C.c_void_p * k)(*[t.data_ptr() for t in ts])
+    _call("tir_gemm_tn_small_bf16x3", arr(As), As[0].shape[1], int(M), arr(Bs), Bs[0].shape[1], int(N), k, n, _ptr(C_out),
+          C_out.shape[1], _stream())
+    _KEEP_ALIVE = (As, Bs)          # noqa: F841
+    return C_out
+
+
 def mlp_wgrad_multi(jobs):
     """Weight gradients of up to four decoder invocations over the same rows in ONE launch (tir_mlp_wgrad_multi): no
     materialised input rows, no per-layer GEMM launches.  jobs: list of (dz1, dz2, dz3, h1, h2, feat [n, FEAT_STRIDE], aux,

@@ -99,3 +99,35 @@ class Adam(_TorchAdam):
             # cache keyed by Tensor._version (the model's packed decoder images, light means, descriptors) that they changed
             torch.autograd.graph.increment_version([t for e in entries for t in (e[0], e[2], e[3])])
         return loss
+
+
+def _supported(opt) -> bool:
+    """True when every parameter group of `opt` is something the single-launch step implements (see Adam.step)."""
+    betas = eps = None
+    for group in opt.param_groups:
+        if any(group.get(o) for o in ("amsgrad", "maximize", "capturable", "differentiable")) or group.get("weight_decay", 0) != 0:
+            return False
+        b, e = tuple(float(x) for x in group["betas"]), float(group["eps"])
+        if betas is None:
+            betas, eps = b, e
+        elif (b, e) != (betas, eps):
+            return False
+        for p in group["params"]:
+            if not p.is_cuda or p.dtype != torch.float32 or _dense_key(p) is None:
+                return False
+            if p.grad is not None and (p.grad.is_sparse or p.grad.dtype != torch.float32):
+                return False
+    return True
+
+
+class LauncherAdam(Adam):
+    """What `python -m tensoir_amd.run` binds to the name torch.optim.Adam: the training script's optimizer (fp32 CUDA
+    parameters, default options -- train_tensoIR.py:197) takes the single-launch step; any OTHER Adam the process creates
+    (weight decay, amsgrad, CPU parameters: a metric network's, a user's own code) behaves exactly as torch.optim.Adam does.
+    The decision is made per step from the optimizer's own groups, so the rebinding never changes what foreign code gets."""
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if _supported(self):
+            return Adam.step(self, closure)
+        return _TorchAdam.step(self, closure)

@@ -55,7 +55,7 @@ def install(reference_root: str):
     if os.environ.get("TENSOIR_TORCH_ADAM", "0") != "1":
         import torch
         from tensoir_amd import optim
-        torch.optim.Adam = optim.Adam
+        torch.optim.Adam = optim.LauncherAdam       # the script's optimizer: one launch; anything unsupported: torch's own step
         done["torch.optim"] = ["Adam"]
     # TENSOIR_DEVICE_DATASET=1: the training rays stay resident in HBM (batches are gathered on the device)
     dev = None

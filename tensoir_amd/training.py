@@ -378,11 +378,22 @@ class PrimaryRenderFn(torch.autograd.Function):
                 leaf.run(lambda: ops.mlp_wgrad_multi(wg), *[t for job in wg for t in job if t is not None])
             y_rad, y_int = ops.vm_app_bwd(f, gd, st.rec_xyz, st.lidx, st.rec_ray, g_rad, g_int)
             nb = 3 * f.n_acomp
-            leaf.run(lambda: ops.gemm_tn(g_rad, model.app_dim, y_rad, nb, d_basis), g_rad, y_rad, d_basis)
+            small = ops.MLP_IMPL == "bf16x3" and model.app_dim <= 32 and nb <= 160      # d basis_mat: one launch per gather pass
+            if g_int is None:
+                pairs = [(g_rad, y_rad)]
+            else:
+                pairs = [(g_rad, y_rad), (g_int, y_int)]
+            if small:
+                leaf.run(lambda: ops.gemm_tn_small(pairs, model.app_dim, nb, d_basis), *[t for pr in pairs for t in pr], d_basis)
+            else:
+                for ga, ya in pairs:
+                    leaf.run(lambda ga=ga, ya=ya: ops.gemm_tn(ga, model.app_dim, ya, nb, d_basis), ga, ya, d_basis)
             if g_int is not None:
-                leaf.run(lambda: ops.gemm_tn(g_int, model.app_dim, y_int, nb, d_basis), g_int, y_int)
                 _, y_j = ops.vm_app_bwd(f, gd, st.xyz_j, None, None, None, g_int_j)
-                leaf.run(lambda: ops.gemm_tn(g_int_j, model.app_dim, y_j, nb, d_basis), g_int_j, y_j)
+                if small:
+                    leaf.run(lambda: ops.gemm_tn_small([(g_int_j, y_j)], model.app_dim, nb, d_basis), g_int_j, y_j)
+                else:
+                    leaf.run(lambda: ops.gemm_tn(g_int_j, model.app_dim, y_j, nb, d_basis), g_int_j, y_j)
         ops.march_primary_bwd(f, gd, st.rays, st.jitter, st.sigma, st.weight, g_weight, g_acc, g_depth)
         leaf.join()
         grads = []

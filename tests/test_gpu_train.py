@@ -119,6 +119,30 @@ def test_decoder_backward(env, which):
                 assert float(d.max()) < 5e-2 and float((d > 1e-4).double().mean()) < 2e-2, (impl, name, float(d.max()))
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 70001])
+def test_small_gemm_tn(env, n):
+    """tir_gemm_tn_small_bf16x3: C[27, 144] += sum_j A_j^T B_j (the basis-matrix gradient of several gathers in one launch)
+    against fp64; padded A rows carry NaN beyond column M, ragged row counts, 1-3 operand pairs, other shapes."""
+    from tensoir_amd import ops
+    gen = torch.Generator().manual_seed(200 + n)
+    for M, N, lda, ldb, k in ((27, 144, 32, 144, 3), (27, 144, 32, 144, 1), (4, 30, 4, 40, 2), (32, 160, 32, 160, 2)):
+        ref = torch.zeros(M, N, dtype=torch.float64)
+        pairs = []
+        for _ in range(k):
+            A = torch.randn(n, lda, generator=gen)
+            B = torch.randn(n, ldb, generator=gen)
+            ref += A[:, :M].double().T @ B[:, :N].double()
+            A[:, M:] = float("nan")
+            B[:, N:] = float("nan")
+            pairs.append((A.cuda(), B.cuda()))
+        C0 = torch.randn(M, N + 3, generator=gen)
+        Cd = C0.cuda()
+        ops.gemm_tn_small(pairs, M, N, Cd)
+        assert torch.isfinite(Cd).all()
+        assert gerr(Cd[:, :N].cpu().double() - C0[:, :N].double(), ref) < 3e-5, (n, M, N, k)
+        assert torch.equal(Cd[:, N:].cpu(), C0[:, N:])
+
+
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 700, 4099, 70001])
 def test_fused_weight_gradients(env, n):
     """tir_mlp_wgrad_multi: dW0 = dz1^T x, dW1 = dz2^T h1, dW2 = dz3^T h2 and the three bias gradients of several decoder

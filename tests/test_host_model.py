@@ -144,7 +144,7 @@ def test_launcher_rebinds_reference_symbols():
     assert tf.TensorVMSplit is tensoir_amd.TensorVMSplit and tf.AlphaGridMask is tensoir_amd.AlphaGridMask
     from tensoir_amd import optim
     try:
-        assert set(done) == set(run.PATCHES) | {"torch.optim"} and torch.optim.Adam is optim.Adam
+        assert set(done) == set(run.PATCHES) | {"torch.optim"} and torch.optim.Adam is optim.LauncherAdam
     finally:
         torch.optim.Adam = optim._TorchAdam              # this process goes on to run other tests on the CPU
 
@@ -216,6 +216,15 @@ def test_adam_is_constructor_and_state_compatible_and_loud_on_cpu():
     with pytest.raises(NotImplementedError):
         o2.step()
     assert all(len(o2.state[p]) == 0 for p in ps)
+    # the class the launcher binds leaves foreign optimizers alone: CPU parameters / weight decay take torch's own step
+    q = [torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(5))]
+    q[1].data.copy_(q[0].data)
+    for t in q:
+        t.grad = torch.ones_like(t)
+    la = optim.LauncherAdam([q[0]], lr=0.01, weight_decay=0.1)
+    ta = optim._TorchAdam([q[1]], lr=0.01, weight_decay=0.1)
+    la.step(); ta.step()
+    assert isinstance(la, torch.optim.Adam) and torch.equal(q[0].data, q[1].data)
     assert optim._dense_key(torch.empty(1, 4, 5, 3).permute(0, 2, 3, 1)) is not None
     assert optim._dense_key(torch.empty(8, 8)[:, ::2]) is None
 

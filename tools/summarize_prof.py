@@ -80,3 +80,45 @@ if traffic:
     for k, v in traffic.items():
         if not k.endswith(":detail"):
             print(f"  {k:32s} {v/1e6:10.2f} MB")
+
+# ---- issue fractions per entry point (bench.py's bound labels): VALU share of the SIMD issue time and matrix-pipe busy share,
+# from an SQ pass (SQ_ACTIVE_INST_VALU counts quad-cycles = one VALU instruction slot of a SIMD; a CU has 4 SIMDs):
+#   valu_issue_frac = SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES        mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)
+iss = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in find("*counter_collection.csv"):
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            c = r["Counter_Name"]
+            if c not in ("SQ_ACTIVE_INST_VALU", "SQ_BUSY_CU_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY"):
+                continue
+            k = short(r["Kernel_Name"])
+            for pat, op in OP_OF:
+                if pat in k:
+                    t = iss[op][c]
+                    t[0] += float(r["Counter_Value"]); t[1] += 1
+                    break
+issue = {}
+for op, d in iss.items():
+    mean = {c: v[0] / max(1, v[1]) for c, v in d.items()}
+    cu = mean.get("SQ_BUSY_CU_CYCLES", 0.0)
+    if cu <= 0:
+        continue
+    e = {"launches_sampled": int(max(v[1] for v in d.values()))}
+    if "SQ_ACTIVE_INST_VALU" in mean:
+        e["valu_issue_frac"] = round(mean["SQ_ACTIVE_INST_VALU"] / cu, 4)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in mean:
+        e["mfma_busy_frac"] = round(mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * cu), 4)
+    if "SQ_INSTS_VALU" in mean:
+        e["valu_instructions_per_launch"] = round(mean["SQ_INSTS_VALU"])
+    if "SQ_WAIT_INST_ANY" in mean and "SQ_WAVE_CYCLES" in mean and mean["SQ_WAVE_CYCLES"] > 0:
+        e["wait_frac_of_wave_cycles"] = round(mean["SQ_WAIT_INST_ANY"] / mean["SQ_WAVE_CYCLES"], 4)
+    issue[op] = e
+if issue:
+    issue["_note"] = ("valu_issue_frac = SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES (VALU instruction slots per CU-cycle over the 4 SIMDs' "
+                      "one slot per 4 cycles each); mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES); separate rocprofv3 --pmc pass")
+    with open(os.path.join(root, "pmc_issue.json"), "w") as fh:
+        json.dump(issue, fh, indent=1)
+    print("\n== pmc_issue.json")
+    for k, v in issue.items():
+        if k != "_note":
+            print(f"  {k:32s} {v}")
