@@ -130,6 +130,9 @@ def build_scene(a, device, rank, **blob):
 ALIAS = {"tir_march_secondary_ids_fwd": "tir_march_secondary_fwd", "tir_shade_integrate_records": "tir_shade_integrate",
          # one launch for the primary stage's four decoders: the same device code (mlp_bf16_body) as the single-decoder launch
          "tir_mlp_fwd_multi_bf16x3": "tir_mlp_fwd_bf16x3",
+         # the aux-table variants of both (view-direction columns folded into a per-direction accumulator start, 9 k-blocks):
+         # same decoder, same useful FLOPs per row
+         "tir_mlp_fwd_auxtab_bf16x3": "tir_mlp_fwd_bf16x3", "tir_mlp_fwd_multi_auxtab_bf16x3": "tir_mlp_fwd_bf16x3",
          # the primary stage's two appearance gathers in one launch: app_mfma_body twice, the grid split between them
          "tir_vm_app_primary_fwd": "tir_vm_app_fwd", "tir_vm_app_jitter_fwd": "tir_vm_app_fwd"}
 

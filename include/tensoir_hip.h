@@ -210,6 +210,24 @@ int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, 
 int tir_mlp_fwd_multi_bf16x3(const TirMlp* const* mlps, const float* const* feats, int32_t feat_stride,
                              const float* const* auxs, const int32_t* const* aux_maps, float* const* outs,
                              int32_t n_jobs, int64_t n, const int32_t* n_dev, void* stream);
+
+/* ---- aux-table variant of the split-bf16 decoder.  The 3 aux inputs of MLPRender_Fea are the view direction
+ *      (models/tensorBase_rotated_lights.py:137-142): one value per ray in the primary stage, one per light direction for the
+ *      secondary records -- few distinct rows for many decoder rows.  tir_mlp_aux_table evaluates, per aux row a, the part of
+ *      layer 1 that depends on it alone: table[a][unit] = b0[unit] + sum over the 15 columns (aux, sin / cos PE(aux)) of
+ *      W0[unit][col] x_col  (exact fp32; table is [n_aux][hidden], 16-byte aligned).  tir_mlp_fwd_auxtab_bf16x3 is
+ *      tir_mlp_fwd_bf16x3 with that table in place of `aux` (row aux_map[s] -- or s when NULL -- modulo aux_mod when > 0): the
+ *      layer-1 accumulators start from the table row, the matrix product runs over the other 135 inputs (9 instead of 10
+ *      k-blocks).  Same results to fp32 rounding.  tir_mlp_fwd_multi_auxtab_bf16x3: tables[i] != NULL selects the variant for
+ *      job i (auxs[i] is then unused and may be NULL). */
+int tir_mlp_aux_table(const TirMlp* m, const float* aux, int64_t n_aux, float* table, void* stream);
+int tir_mlp_fwd_auxtab_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* table,
+                              const int32_t* aux_map, int32_t aux_mod, float* out, int64_t n, const int32_t* n_dev,
+                              void* stream);
+int tir_mlp_fwd_multi_auxtab_bf16x3(const TirMlp* const* mlps, const float* const* feats, int32_t feat_stride,
+                                    const float* const* auxs, const int32_t* const* aux_maps,
+                                    const float* const* tables, float* const* outs, int32_t n_jobs, int64_t n,
+                                    const int32_t* n_dev, void* stream);
 /* The same launch for the training forward: every job also writes its post-ReLU hidden activations h1s[i], h2s[i]
  * [n][128] (what tir_mlp_train_fwd_bf16x3 returns for one decoder). */
 int tir_mlp_train_fwd_multi_bf16x3(const TirMlp* const* mlps, const float* const* feats, int32_t feat_stride,

@@ -55,7 +55,19 @@ constexpr int BW1_ELEMS = KB1 * 2 * 4 * 32 * 8; // 16384 bf16
 constexpr int BF_BYTES = BH_FLOATS * 4 + (2 * BW0_ELEMS + 2 * BW1_ELEMS) * 2;   // 150,560 B
 constexpr int BF_FLOATS = BF_BYTES / 4;
 constexpr int OFF_BF = FP32_TOTAL;              // float offset of the bf16 image inside the blob
-constexpr int TOTAL_FLOATS = OFF_BF + BF_FLOATS;
+// Second image for the AUX-TABLE variant of layer 1 (k_mlp_bf16<.., AUXT = true>): when the 3 aux inputs of a launch take few
+// distinct values (the view direction of the radiance decoder: one per ray, or one per light direction), their 15 input
+// columns (aux + PE(aux)) and the bias are folded into a per-aux-row fp32 table T[a][unit] = b0 + W0[:, aux part] x_aux
+// (tir_mlp_aux_table) that INITIALISES the layer-1 accumulators; the matrix product then runs over the remaining
+// 27 + 108 = 135 inputs: 68 / 67 per lane half -> 9 k-blocks of 8 instead of 10 (-12 of the 216 MFMAs per 32-sample tile).
+// Same layout as the main image: header | W0A hi | W0A lo | W1 hi | W1 lo.
+constexpr int R0A = 14;                          // raw features handled by half 0 in the aux-table layout (half 1: 13)
+constexpr int KB0A = 9;
+constexpr int BW0A_ELEMS = KB0A * 2 * 4 * 32 * 8;                               // 18432 bf16
+constexpr int BFA_BYTES = BH_FLOATS * 4 + (2 * BW0A_ELEMS + 2 * BW1_ELEMS) * 2; // 142,368 B
+constexpr int BFA_FLOATS = BFA_BYTES / 4;
+constexpr int OFF_BFA = OFF_BF + BF_FLOATS;
+constexpr int TOTAL_FLOATS = OFF_BFA + BFA_FLOATS;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // reference input index (models/tensorBase_rotated_lights.py:137-142, :12-17) handled at step t by half h
@@ -70,6 +82,14 @@ __host__ __device__ inline int kperm(int t, int h) {
     if (q < 3 * PE) return F + 3 + 2 * NPF + q;           // sin(PE aux)
     q -= 3 * PE;
     return F + 3 + 2 * NPF + 3 * PE + q;                  // cos(PE aux)
+}
+
+// the same for the aux-table layout: half 0 -> sin(PE feat), feat[0..R0A); half 1 -> cos(PE feat), feat[R0A..F); -1 = padding
+__host__ __device__ inline int kperm_a(int t, int h) {
+    if (t < NPF) return F + 3 + (h ? NPF : 0) + t;
+    const int q = t - NPF;
+    if (h == 0) return q < R0A ? q : -1;
+    return q < F - R0A ? R0A + q : -1;
 }
 
 // hidden unit held by accumulator register q (= tile*16 + r) of a lane in half h
@@ -110,7 +130,9 @@ __global__ void k_pack_mlp(const float* __restrict__ w0, const float* __restrict
     else if (i < OFF_RB2) { int j = i - OFF_RW2; v = (j / HID < out_dim) ? w2[j] : 0.0f; }
     else if (i < FP32_TOTAL) { int o = i - OFF_RB2; v = (o < out_dim) ? b2[o] : 0.0f; }
     else {
-        int j = i - OFF_BF;                     // float slot inside the bf16 image
+        const bool auxt = i >= OFF_BFA;         // the aux-table image: same header and W1 planes, 9-block W0 planes
+        const int bw0 = auxt ? BW0A_ELEMS : BW0_ELEMS;
+        int j = i - (auxt ? OFF_BFA : OFF_BF);  // float slot inside the bf16 image
         if (j < BH_FLOATS) {
             if (j < BH_B1) v = b0[unit_of(j % 64, j / 64)];
             else if (j < BH_W2) { int q = j - BH_B1; v = b1[unit_of(q % 64, q / 64)]; }
@@ -124,14 +146,15 @@ __global__ void k_pack_mlp(const float* __restrict__ w0, const float* __restrict
             for (int t = 0; t < 2; ++t) {
                 int e_all = (j - BH_FLOATS) * 2 + t;
                 int sec, idx;
-                if (e_all < BW0_ELEMS) { sec = 0; idx = e_all; }
-                else if (e_all < 2 * BW0_ELEMS) { sec = 1; idx = e_all - BW0_ELEMS; }
-                else if (e_all < 2 * BW0_ELEMS + BW1_ELEMS) { sec = 2; idx = e_all - 2 * BW0_ELEMS; }
-                else { sec = 3; idx = e_all - 2 * BW0_ELEMS - BW1_ELEMS; }
+                if (e_all < bw0) { sec = 0; idx = e_all; }
+                else if (e_all < 2 * bw0) { sec = 1; idx = e_all - bw0; }
+                else if (e_all < 2 * bw0 + BW1_ELEMS) { sec = 2; idx = e_all - 2 * bw0; }
+                else { sec = 3; idx = e_all - 2 * bw0 - BW1_ELEMS; }
                 int e = idx % 8, ii = (idx / 8) % 32, mt = (idx / 256) % 4, h = (idx / 1024) % 2, kb = idx / 2048;
                 int kk = kb * 8 + e;
                 float wv;
-                if (sec < 2) wv = (kk < HALF) ? w0[(mt * 32 + ii) * IN + kperm(kk, h)]
+                if (sec < 2 && auxt) { const int in = kperm_a(kk, h); wv = in >= 0 ? w0[(mt * 32 + ii) * IN + in] : 0.0f; }
+                else if (sec < 2) wv = (kk < HALF) ? w0[(mt * 32 + ii) * IN + kperm(kk, h)]
                                               : ((kk == HALF && h == 0) ? b0[mt * 32 + ii] : 0.0f);   // bias slot (input = 1)
                 else wv = w1[(mt * 32 + ii) * HID + unit_of(kk, h)];
                 __bf16 hi = (__bf16)wv;
@@ -370,12 +393,25 @@ __device__ __forceinline__ float tail_input(const float (&ft)[F + 1], const floa
     return h ? b : a;
 }
 
-template <int KB, int E>
+// the aux-table layout's tail: half 0 -> feat[0..R0A), half 1 -> feat[R0A..F), zero padding (no aux inputs, no bias slot)
+template <int T>
+__device__ __forceinline__ float tail_input_a(const float (&ft)[F + 1], int h) {
+    constexpr int q = T - NPF;
+    float a = 0.0f, b = 0.0f;
+    if constexpr (q < R0A) a = ft[q];
+    if constexpr (q < F - R0A) b = ft[R0A + q];
+    return h ? b : a;
+}
+
+template <int KB, int E, bool AUXT>
 __device__ __forceinline__ void build_pair(const float (&ft)[F + 1], const float (&ax)[3], const AuxPE& ap, int h, float hq,
                                            float (&v)[8]) {
     constexpr int t = KB * 8 + E;
     if constexpr (t + 1 < NPF) pe_pair(ft[t >> 1], hq, v[E], v[E + 1]);
-    else {
+    else if constexpr (AUXT) {
+        v[E] = tail_input_a<t>(ft, h);
+        v[E + 1] = tail_input_a<t + 1>(ft, h);
+    } else {
         v[E] = tail_input<t>(ft, ax, ap, h);
         v[E + 1] = tail_input<t + 1>(ft, ax, ap, h);
     }
@@ -427,7 +463,7 @@ __device__ __forceinline__ void mfma12(const bf16x8 (&ah)[4], const bf16x8 (&al)
     }
 }
 
-template <int NPROD, int KB>
+template <int NPROD, int KB, bool AUXT = false>
 __device__ __forceinline__ void layer1_interleaved(unsigned whi, unsigned wlo, int h,
                                                    const float (&ft)[F + 1], const float (&ax)[3], const AuxPE& ap, float hq,
                                                    f32x16 (&acc)[4]) {
@@ -438,15 +474,15 @@ __device__ __forceinline__ void layer1_interleaved(unsigned whi, unsigned wlo, i
         if (NPROD == 3) al[mt] = lds_tile(wlo, KBX(KB) * 4096 + mt * 512);
     }
     float v[8];
-    build_pair<KB, 0>(ft, ax, ap, h, hq, v);
-    build_pair<KB, 2>(ft, ax, ap, h, hq, v);
-    build_pair<KB, 4>(ft, ax, ap, h, hq, v);
-    build_pair<KB, 6>(ft, ax, ap, h, hq, v);
+    build_pair<KB, 0, AUXT>(ft, ax, ap, h, hq, v);
+    build_pair<KB, 2, AUXT>(ft, ax, ap, h, hq, v);
+    build_pair<KB, 4, AUXT>(ft, ax, ap, h, hq, v);
+    build_pair<KB, 6, AUXT>(ft, ax, ap, h, hq, v);
     bf16x8 xh, xl;
     split8(v, xh, xl);
     mfma12<NPROD>(ah, al, xh, xl, acc);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (KB + 1 < KB0) layer1_interleaved<NPROD, KB + 1>(whi, wlo, h, ft, ax, ap, hq, acc);
+    if constexpr (KB + 1 < (AUXT ? KB0A : KB0)) layer1_interleaved<NPROD, KB + 1, AUXT>(whi, wlo, h, ft, ax, ap, hq, acc);
 }
 
 template <int NPROD, int KB>
@@ -469,7 +505,7 @@ __device__ __forceinline__ void layer2_interleaved(unsigned whi, unsigned wlo,
 }
 
 // one sample's decoder inputs as they come from memory: 27 features (+ zero pad) and the 3 aux values
-struct RowIn { float ft[F + 1]; float ax[3]; };
+struct RowIn { float ft[F + 1]; float ax[3]; int64_t ai; };
 
 template <bool VEC>
 __device__ __forceinline__ void load_row(const float* __restrict__ feat, int fstride, const float* __restrict__ aux,
@@ -487,7 +523,9 @@ __device__ __forceinline__ void load_row(const float* __restrict__ feat, int fst
         for (int d = 0; d < F; ++d) r.ft[d] = fr[d];
         r.ft[F] = 0.0f;
     }
-    r.ax[0] = aux[3 * ai]; r.ax[1] = aux[3 * ai + 1]; r.ax[2] = aux[3 * ai + 2];
+    r.ai = ai;
+    if (aux) { r.ax[0] = aux[3 * ai]; r.ax[1] = aux[3 * ai + 1]; r.ax[2] = aux[3 * ai + 2]; }
+    else { r.ax[0] = r.ax[1] = r.ax[2] = 0.0f; }            // aux-table launches never read the aux values
 }
 
 __device__ __forceinline__ int64_t aux_index(const int32_t* __restrict__ aux_map, int aux_mod, int64_t s) {
@@ -497,18 +535,23 @@ __device__ __forceinline__ int64_t aux_index(const int32_t* __restrict__ aux_map
 }
 
 // the decoder for the workgroup `bid` of `nblk` cooperating on one (decoder, row set) job
-template <int NPROD, bool VEC, bool SAVE>
+// AUXT: `aux` is the fp32 table [n_aux][128] of tir_mlp_aux_table (layer-1 accumulators start from its row aux_index(s)
+// instead of 0, the matrix product skips the aux columns and the bias slot: 9 k-blocks), not the [n_aux][3] aux values.
+template <int NPROD, bool VEC, bool SAVE, bool AUXT = false>
 __device__ __forceinline__ void
 mlp_bf16_body(const float* __restrict__ packed, const float* __restrict__ feat, int fstride, const float* __restrict__ aux,
               const int32_t* __restrict__ aux_map, int aux_mod, float* __restrict__ out, int64_t n,
               const int32_t* __restrict__ n_dev, int out_dim, int act, float* __restrict__ h1o, float* __restrict__ h2o,
               const int bid, const int nblk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int W0_ELEMS = AUXT ? BW0A_ELEMS : BW0_ELEMS;
     {
-        const float* src = packed + OFF_BF;
-        for (int i = threadIdx.x * 4; i < BF_FLOATS; i += 512 * 4)
+        const float* src = packed + (AUXT ? OFF_BFA : OFF_BF);
+        for (int i = threadIdx.x * 4; i < (AUXT ? BFA_FLOATS : BF_FLOATS); i += 512 * 4)
             *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(src + i);
     }
+    const float* __restrict__ table = AUXT ? aux : nullptr;
+    const float* __restrict__ auxv = AUXT ? nullptr : aux;
     __syncthreads();
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));      // device-side row count (no host sync needed)
 
@@ -518,35 +561,50 @@ mlp_bf16_body(const float* __restrict__ packed, const float* __restrict__ feat, 
     const unsigned lds0 = (unsigned)(size_t)lds;        // low 32 bits of a flat LDS-aperture address = the LDS byte address
     const unsigned lane_off = lds0 + BH_FLOATS * 4 + (unsigned)(h * 128 + sl) * 16;
     const unsigned w0hi = opaque(lane_off);
-    const unsigned w0lo = opaque(lane_off + BW0_ELEMS * 2);
-    const unsigned w1hi = opaque(lane_off + BW0_ELEMS * 4);
-    const unsigned w1lo = opaque(lane_off + BW0_ELEMS * 4 + BW1_ELEMS * 2);
+    const unsigned w0lo = opaque(lane_off + W0_ELEMS * 2);
+    const unsigned w1hi = opaque(lane_off + W0_ELEMS * 4);
+    const unsigned w1lo = opaque(lane_off + W0_ELEMS * 4 + BW1_ELEMS * 2);
     const int64_t n_tiles = (n + 255) / 256;
     const int64_t G = nblk;
     if ((int64_t)bid >= n_tiles) return;
     auto row_of = [&](int64_t tile) { const int64_t sr = tile * 256 + wave * 32 + sl; return sr < n ? sr : n - 1; };
     RowIn cur;
-    { const int64_t sc = row_of(bid); load_row<VEC>(feat, fstride, aux, sc, aux_index(aux_map, aux_mod, sc), cur); }
-    for (int64_t tile = bid; tile < n_tiles; tile += G) {
-        const int64_t s_raw = tile * 256 + wave * 32 + sl;
-        AuxPE ap;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            fast_sincos(cur.ax[d], ap.s[d], ap.c[d]);
-            ap.s2[d] = 2.0f * ap.s[d] * ap.c[d];
-            ap.c2[d] = fmaf(-2.0f * ap.s[d], ap.s[d], 1.0f);
-        }
-        f32x16 acc[4], acc2[4];
+    { const int64_t sc = row_of(bid); load_row<VEC>(feat, fstride, auxv, sc, aux_index(aux_map, aux_mod, sc), cur); }
+    f32x16 acc[4], acc2[4];
+    // aux-table variant: this lane's 64 layer-1 accumulators start from the table row of its sample's aux index -- units
+    // mt*32 + 8 i + 4 h + (0..3) are accumulator registers 4 i .. 4 i + 3 of tile mt: sixteen 16-byte loads per lane
+    auto load_acc = [&](int64_t ai) {
+        const float* tp = table + ai * HID + 4 * h;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;      // bias: the constant-1 input of k slot HALF
-        layer1_interleaved<NPROD, 0>(w0hi, w0lo, h, cur.ft, cur.ax, ap, 0.25f * (float)h, acc);
+            for (int i = 0; i < 4; ++i) {
+                const float4 t4 = *reinterpret_cast<const float4*>(tp + mt * 32 + 8 * i);
+                acc[mt][4 * i] = t4.x; acc[mt][4 * i + 1] = t4.y; acc[mt][4 * i + 2] = t4.z; acc[mt][4 * i + 3] = t4.w;
+            }
+    };
+    if (AUXT) load_acc(cur.ai);
+    for (int64_t tile = bid; tile < n_tiles; tile += G) {
+        const int64_t s_raw = tile * 256 + wave * 32 + sl;
+        AuxPE ap = {};
+        if (!AUXT) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                fast_sincos(cur.ax[d], ap.s[d], ap.c[d]);
+                ap.s2[d] = 2.0f * ap.s[d] * ap.c[d];
+                ap.c2[d] = fmaf(-2.0f * ap.s[d], ap.s[d], 1.0f);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;      // bias: the constant-1 input of k slot HALF
+        }
+        layer1_interleaved<NPROD, 0, AUXT>(w0hi, w0lo, h, cur.ft, cur.ax, ap, 0.25f * (float)h, acc);
         // the row registers are dead from here on: fetch the NEXT tile's row into them now, so that the global-load
         // latency (the features were just written by the gather kernel: L2 / HBM) hides behind layers 2 and 3
         if (tile + G < n_tiles) {
             const int64_t sc = row_of(tile + G);
-            load_row<VEC>(feat, fstride, aux, sc, aux_index(aux_map, aux_mod, sc), cur);
+            load_row<VEC>(feat, fstride, auxv, sc, aux_index(aux_map, aux_mod, sc), cur);
         }
         if (SAVE && s_raw < n) {      // post-ReLU hidden activations in natural [sample][unit] order (training)
 #pragma unroll
@@ -563,6 +621,9 @@ mlp_bf16_body(const float* __restrict__ packed, const float* __restrict__ feat, 
             for (int r = 0; r < 16; ++r) acc2[mt][r] = bp[r];
         }
         layer2_interleaved<NPROD, 0>(w1hi, w1lo, acc, acc2);
+        // layer 2 has consumed the layer-1 values: the NEXT tile's accumulator start (table row of the row fetched above)
+        // loads into the same registers now and arrives behind layer 3
+        if (AUXT && tile + G < n_tiles) load_acc(cur.ai);
         if (SAVE && s_raw < n) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
@@ -627,12 +688,47 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
                                     (int)blockIdx.x, (int)gridDim.x);
 }
 
+// the aux-table variant (see R0A above): `table` [n_aux][128] from k_mlp_aux_table takes the place of the aux values
+template <bool VEC>
+__global__ void __launch_bounds__(512)
+k_mlp_bf16_auxt(const float* __restrict__ packed, const float* __restrict__ feat, int fstride, const float* __restrict__ table,
+                const int32_t* __restrict__ aux_map, int aux_mod, float* __restrict__ out, int64_t n,
+                const int32_t* __restrict__ n_dev, int out_dim, int act) {
+    mlp_bf16_body<3, VEC, false, true>(packed, feat, fstride, table, aux_map, aux_mod, out, n, n_dev, out_dim, act, nullptr, nullptr,
+                                       (int)blockIdx.x, (int)gridDim.x);
+}
+
+// T[a][u] = b0[u] + sum over the 15 aux-dependent input columns of W0[u][col] x_col(aux_a): exact fp32 FMAs on the raw
+// weights, library sin / cos (the table is tiny: one row per ray or per light direction).  Column order of the reference
+// input (models/tensorBase_rotated_lights.py:137-142, :12-17): aux at F.., sin(PE aux) at F+3+2*NPF.., cos(PE aux) 3*PE later.
+__global__ void k_mlp_aux_table(const float* __restrict__ packed, const float* __restrict__ aux, int64_t n_aux,
+                                float* __restrict__ table) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_aux * HID) return;
+    const int64_t a = i / HID;
+    const int u = (int)(i % HID);
+    const float* w = packed + OFF_RW0 + u * IN;
+    float acc = packed[OFF_RB0 + u];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float x = aux[3 * a + d];
+        acc = fmaf(w[F + d], x, acc);
+#pragma unroll
+        for (int f = 0; f < PE; ++f) {
+            const float y = x * (float)(1 << f);
+            acc = fmaf(w[F + 3 + 2 * NPF + d * PE + f], sinf(y), acc);
+            acc = fmaf(w[F + 3 + 2 * NPF + 3 * PE + d * PE + f], cosf(y), acc);
+        }
+    }
+    table[i] = acc;
+}
+
 // Several decoders over the same number of rows in ONE launch (the primary stage runs rgb / brdf / jittered brdf / normal
 // on the same records): the grid is split evenly, a workgroup loads ITS decoder's operand image once and walks that
 // decoder's tiles.  Against one launch per decoder: one 150 KB LDS fill per workgroup instead of four, one tail instead
 // of four (at 230 k rows a launch is only 3.5 tiles per workgroup).
 struct TirMlpJob { const float* packed; const float* feat; const float* aux; const int32_t* aux_map; float* out; int out_dim, act;
-                   float* h1; float* h2; };
+                   float* h1; float* h2; const float* table; };      // table != NULL: the aux-table variant for this job
 struct TirMlpJobs { TirMlpJob j[4]; int n_jobs; };
 
 template <int NPROD, bool SAVE = false>
@@ -642,8 +738,12 @@ k_mlp_bf16_multi(TirMlpJobs jobs, int fstride, int64_t n, const int32_t* __restr
     const int ji = (int)blockIdx.x / per;
     if (ji >= jobs.n_jobs) return;
     const TirMlpJob& jb = jobs.j[ji];
-    mlp_bf16_body<NPROD, true, SAVE>(jb.packed, jb.feat, fstride, jb.aux, jb.aux_map, 0, jb.out, n, n_dev, jb.out_dim, jb.act,
-                                     jb.h1, jb.h2, (int)blockIdx.x - ji * per, per);
+    if (!SAVE && jb.table)
+        mlp_bf16_body<NPROD, true, false, true>(jb.packed, jb.feat, fstride, jb.table, jb.aux_map, 0, jb.out, n, n_dev, jb.out_dim,
+                                                jb.act, nullptr, nullptr, (int)blockIdx.x - ji * per, per);
+    else
+        mlp_bf16_body<NPROD, true, SAVE>(jb.packed, jb.feat, fstride, jb.aux, jb.aux_map, 0, jb.out, n, n_dev, jb.out_dim, jb.act,
+                                         jb.h1, jb.h2, (int)blockIdx.x - ji * per, per);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1418,7 +1518,7 @@ extern "C" int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t fe
 template <bool SAVE>
 static int launch_multi(const TirMlp* const* mlps, const float* const* feats, int32_t feat_stride, const float* const* auxs,
                         const int32_t* const* aux_maps, float* const* outs, float* const* h1s, float* const* h2s,
-                        int32_t n_jobs, int64_t n, const int32_t* n_dev, void* stream) {
+                        int32_t n_jobs, int64_t n, const int32_t* n_dev, void* stream, const float* const* tables = nullptr) {
     if (n_jobs < 1 || n_jobs > 4 || !mlps || !feats || !auxs || !outs || n < 0) return TIR_ERR_ARG;
     if (SAVE && (!h1s || !h2s)) return TIR_ERR_ARG;
     if (feat_stride % 4 != 0 || feat_stride < F + 1) return TIR_ERR_ARG;          // rows must take the dwordx4 loads
@@ -1427,11 +1527,12 @@ static int launch_multi(const TirMlp* const* mlps, const float* const* feats, in
     for (int i = 0; i < n_jobs; ++i) {
         int rc = check_mlp(mlps[i]);
         if (rc) return rc;
-        if (n > 0 && (!feats[i] || !auxs[i] || !outs[i])) return TIR_ERR_ARG;
+        const float* tab = (!SAVE && tables) ? tables[i] : nullptr;
+        if (n > 0 && (!feats[i] || (!auxs[i] && !tab) || !outs[i])) return TIR_ERR_ARG;
         if (SAVE && n > 0 && (!h1s[i] || !h2s[i])) return TIR_ERR_ARG;
-        if (reinterpret_cast<uintptr_t>(feats[i]) % 16 != 0) return TIR_ERR_ARG;
+        if (reinterpret_cast<uintptr_t>(feats[i]) % 16 != 0 || reinterpret_cast<uintptr_t>(tab) % 16 != 0) return TIR_ERR_ARG;
         jobs.j[i] = TirMlpJob{mlps[i]->packed, feats[i], auxs[i], aux_maps ? aux_maps[i] : nullptr, outs[i], mlps[i]->out_dim,
-                              mlps[i]->act, SAVE ? h1s[i] : nullptr, SAVE ? h2s[i] : nullptr};
+                              mlps[i]->act, SAVE ? h1s[i] : nullptr, SAVE ? h2s[i] : nullptr, tab};
     }
     if (n == 0) return TIR_OK;
     if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_mlp_bf16_multi<3, SAVE>), (int)BF_BYTES)) return rc;
@@ -1448,6 +1549,47 @@ extern "C" int tir_mlp_fwd_multi_bf16x3(const TirMlp* const* mlps, const float* 
                                         const float* const* auxs, const int32_t* const* aux_maps, float* const* outs,
                                         int32_t n_jobs, int64_t n, const int32_t* n_dev, void* stream) {
     return launch_multi<false>(mlps, feats, feat_stride, auxs, aux_maps, outs, nullptr, nullptr, n_jobs, n, n_dev, stream);
+}
+
+extern "C" int tir_mlp_fwd_multi_auxtab_bf16x3(const TirMlp* const* mlps, const float* const* feats, int32_t feat_stride,
+                                               const float* const* auxs, const int32_t* const* aux_maps,
+                                               const float* const* tables, float* const* outs, int32_t n_jobs, int64_t n,
+                                               const int32_t* n_dev, void* stream) {
+    return launch_multi<false>(mlps, feats, feat_stride, auxs, aux_maps, outs, nullptr, nullptr, n_jobs, n, n_dev, stream, tables);
+}
+
+extern "C" int tir_mlp_aux_table(const TirMlp* m, const float* aux, int64_t n_aux, float* table, void* stream) {
+    int rc = check_mlp(m);
+    if (rc) return rc;
+    if (n_aux < 0 || (n_aux > 0 && (!aux || !table))) return TIR_ERR_ARG;
+    if (n_aux == 0) return TIR_OK;
+    const int64_t total = n_aux * HID;
+    hipLaunchKernelGGL(k_mlp_aux_table, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, tir_stream(stream), m->packed, aux, n_aux,
+                       table);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_mlp_fwd_auxtab_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* table,
+                                         const int32_t* aux_map, int32_t aux_mod, float* out, int64_t n, const int32_t* n_dev,
+                                         void* stream) {
+    int rc = check_mlp(m);
+    if (rc) return rc;
+    if (n < 0 || feat_stride < F || (n > 0 && (!feat || !table || !out))) return TIR_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(table) % 16 != 0) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    const bool vec = (feat_stride % 4 == 0) && feat_stride >= F + 1 && (reinterpret_cast<uintptr_t>(feat) % 16 == 0);
+    const void* kfn = vec ? reinterpret_cast<const void*>(k_mlp_bf16_auxt<true>) : reinterpret_cast<const void*>(k_mlp_bf16_auxt<false>);
+    if (int r2 = tir_allow_dynamic_lds(kfn, (int)BFA_BYTES)) return r2;
+    const int64_t tiles = (n + 255) / 256;
+    const int grid_max = m->tune_grid > 0 ? m->tune_grid : 256;
+    const unsigned grid = (unsigned)(tiles < grid_max ? tiles : grid_max);
+    if (vec) hipLaunchKernelGGL(k_mlp_bf16_auxt<true>, dim3(grid), dim3(512), (size_t)BFA_BYTES, tir_stream(stream), m->packed, feat,
+                                feat_stride, table, aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act);
+    else     hipLaunchKernelGGL(k_mlp_bf16_auxt<false>, dim3(grid), dim3(512), (size_t)BFA_BYTES, tir_stream(stream), m->packed, feat,
+                                feat_stride, table, aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
 }
 
 extern "C" int tir_mlp_train_fwd_multi_bf16x3(const TirMlp* const* mlps, const float* const* feats, int32_t feat_stride,

@@ -34,6 +34,19 @@ TUNE = {
     "mlp_grid": max(0, int(os.environ.get("TENSOIR_MLP_GRID", "0") or 0)),
     "pair_order": 2 if os.environ.get("TIR_PAIR_ORDER", "d")[:1] == "m" else 0,
 }
+# TENSOIR_MLP_AUXTAB=0: decoders whose aux input comes through an index map (the radiance decoder's view direction: one per ray
+# or per light direction) run the full 150-input layer 1 instead of the aux-table variant (tir_mlp_aux_table + 9 k-blocks)
+AUX_TABLE = os.environ.get("TENSOIR_MLP_AUXTAB", "1") != "0"
+
+
+def mlp_aux_table(m: "PackedMlp", aux):
+    """T[a][unit] = b0 + W0[:, aux columns] x(aux_a) for every row of `aux` [n_aux, 3] -> [n_aux, 128] fp32 (tir_mlp_aux_table):
+    the start values of the layer-1 accumulators in the aux-table decoder launches."""
+    aux = f32(aux, "aux", 3)
+    table = torch.empty((aux.shape[0], 128), dtype=torch.float32, device=aux.device)
+    _call("tir_mlp_aux_table", C.byref(m.desc), _ptr(aux), aux.shape[0], _ptr(table), _stream())
+    return table
+
 
 
 def _stats_ptr(name, dev):
@@ -321,6 +334,13 @@ def mlp_multi(jobs, n_dev=None, save_hidden=False):
         outs.append(torch.empty((n, m.out_dim), dtype=torch.float32, device=feat.device))
     arr = lambda ts: (C.c_void_p * k)(*[None if t is None else t.data_ptr() for t in ts])
     descs = (C.POINTER(TirMlp) * k)(*[C.pointer(m.desc) for m, _, _, _ in jobs])
+    use_tab = [AUX_TABLE and not save_hidden and mp is not None and aux.shape[0] * 8 <= max(n, 1) for aux, mp in zip(auxs, maps)]
+    if any(use_tab):
+        # jobs whose aux rows come through an index map with few distinct rows (same rule as mlp()): aux-table variant of layer 1
+        tables = [mlp_aux_table(m, aux) if t else None for (m, _, _, _), aux, t in zip(jobs, auxs, use_tab)]
+        _call("tir_mlp_fwd_multi_auxtab_bf16x3", descs, arr(feats), FEAT_STRIDE, arr(auxs), arr(maps), arr(tables), arr(outs), k, n,
+              _ptr(n_dev), _stream())
+        return outs
     if save_hidden:
         h1s = [torch.empty((n, 128), dtype=torch.float32, device=outs[0].device) for _ in range(k)]
         h2s = [torch.empty((n, 128), dtype=torch.float32, device=outs[0].device) for _ in range(k)]
@@ -346,6 +366,13 @@ def mlp(m: PackedMlp, feat, aux, aux_map=None, impl=None, aux_mod=0, n_dev=None)
     elif aux.shape[0] != n and aux_mod <= 0:
         raise ValueError("aux must have one row per feature row")
     out = torch.empty((n, m.out_dim), dtype=torch.float32, device=feat.device)
+    if impl == "bf16x3" and AUX_TABLE and (aux_map is not None or aux_mod > 0) and aux.shape[0] * 8 <= max(n, 1):
+        # few distinct aux rows (one per ray / light direction) for many decoder rows: their 15 input columns + the bias as a
+        # per-aux-row start value of the layer-1 accumulators, 9 instead of 10 k-blocks of matrix work per row
+        table = mlp_aux_table(m, aux)
+        _call("tir_mlp_fwd_auxtab_bf16x3", C.byref(m.desc), _ptr(feat), feat.shape[1], _ptr(table), _ptr(aux_map), int(aux_mod),
+              _ptr(out), n, _ptr(n_dev), _stream())
+        return out
     _call(MLP_ENTRY[impl], C.byref(m.desc), _ptr(feat), feat.shape[1], _ptr(aux),
           _ptr(aux_map), int(aux_mod), _ptr(out), n, _ptr(n_dev), _stream())
     return out

@@ -81,6 +81,65 @@ def test_decoders_vs_reference(env, impl):
 
 
 @torch.no_grad()
+def test_decoder_aux_table_variant(env):
+    """The aux-table variant of the radiance decoder (tir_mlp_aux_table + tir_mlp_fwd_auxtab_bf16x3: the view direction's 15
+    input columns and the bias as a per-direction start value of the layer-1 accumulators, 9 k-blocks of matrix work instead
+    of 10): (a) against the reference's own outputs (tests/golden mlp/rgb) when every row has its own aux row; (b) through an
+    index map and through `aux_mod` (rows >> distinct directions: what the renderer launches) against the exact-fp32 decoder
+    and the full split-bf16 one; (c) inside the multi-decoder launch; ragged row counts, a device-side row count."""
+    from tensoir_amd import ops
+    m = env.model
+    pm = m.renderModule.packed()
+    r, vd = G(env, "feat/both_rad"), G(env, "mlp/viewdirs")
+    n0 = r.shape[0]
+    assert ops.AUX_TABLE
+    # (a) one table row per decoder row (identity map)
+    table = ops.mlp_aux_table(pm, vd)
+    assert table.shape == (n0, 128)
+    out = torch.empty((n0, 3), dtype=torch.float32, device="cuda")
+    ops._call("tir_mlp_fwd_auxtab_bf16x3", C.byref(pm.desc), ops._ptr(r.contiguous()), r.shape[1], ops._ptr(table), None, 0,
+              ops._ptr(out), n0, None, ops._stream())
+    assert rel(out, env.g["mlp/rgb"]) < 1e-5
+    # (b) many rows, few directions
+    gen = torch.Generator().manual_seed(77)
+    for n, D in ((1, 1), (255, 3), (4099, 16), (70001, 128)):
+        feat = torch.zeros(n, 32)
+        feat[:, :27] = torch.randn(n, 27, generator=gen) * 0.8
+        dirs = torch.nn.functional.normalize(torch.randn(D, 3, generator=gen), dim=-1)
+        amap = torch.randint(0, 10 * D, (n,), generator=gen).int()          # pair ids: direction = id mod D
+        f_d, d_d, a_d = feat.cuda(), dirs.cuda(), amap.cuda()
+        exact = ops.mlp(pm, f_d, d_d, a_d, "mfma", D)
+        old = ops.AUX_TABLE
+        try:
+            ops.AUX_TABLE = False
+            full = ops.mlp(pm, f_d, d_d, a_d, "bf16x3", D)
+            ops.AUX_TABLE = True
+            tab = ops.mlp(pm, f_d, d_d, a_d, "bf16x3", D) if D * 8 <= n else None
+            n_dev = torch.tensor([max(1, n - 3)], dtype=torch.int32, device="cuda")
+            part = ops.mlp(pm, f_d, d_d, a_d, "bf16x3", D, n_dev) if D * 8 <= n else None
+        finally:
+            ops.AUX_TABLE = old
+        assert rel(full, exact) < 1e-5
+        if tab is not None:
+            assert rel(tab, exact) < 1e-5 and rel(tab, full) < 1e-5, (n, D)
+            k = max(1, n - 3)
+            assert torch.equal(part[:k], tab[:k])
+    # (c) the multi-decoder launch: job 0 mapped (table variant), the others with per-row aux
+    n = 3001
+    feat = torch.zeros(n, 32)
+    feat[:, :27] = torch.randn(n, 27, generator=gen) * 0.8
+    rays_d = torch.nn.functional.normalize(torch.randn(40, 3, generator=gen), dim=-1).cuda()
+    rmap = torch.randint(0, 40, (n,), generator=gen).int().cuda()
+    pts = (torch.rand(n, 3, generator=gen) * 2 - 1).cuda()
+    f_d = feat.cuda()
+    jobs = [(pm, f_d, rays_d, rmap), (m.renderModule_brdf.packed(), f_d, pts, None), (m.renderModule_normal.packed(), f_d, pts, None)]
+    got = ops.mlp_multi(jobs)
+    want = [ops.mlp(pm, f_d, rays_d, rmap, "mfma"), ops.mlp(jobs[1][0], f_d, pts, None, "mfma"), ops.mlp(jobs[2][0], f_d, pts, None, "mfma")]
+    for a, b in zip(got, want):
+        assert rel(a, b) < 1e-5
+
+
+@torch.no_grad()
 def test_forward_vs_reference(env, decoder):
     rays, lidx = G(env, "rays/rays"), G(env, "rays/light_idx")
     out = env.model(rays, lidx)
