@@ -195,7 +195,7 @@ def kernel_table(timing, stats, steps, shapes, overhead_ms=0.0):
     return rows
 
 
-def attribute_kernels(run_eager, psteps, io_primary, io_secondary, device):
+def attribute_kernels(run_eager, psteps, io_primary, io_secondary, device, stat_steps=1):
     """Per-kernel attribution of the inference path: `run_eager()` issues one eager pass (every C call bracketed by events on
     the launch stream, ops.TIMING); the ops wrappers are instrumented to count the rows each gather / decoder launch really
     processed (device-side counts), one extra pass reads the counters of gathered density samples.  Returns
@@ -264,9 +264,10 @@ def attribute_kernels(run_eager, psteps, io_primary, io_secondary, device):
             shapes_acc["mlp_flops"] += n * 2 * (150 * 128 + 128 * 128 + 128 * x)
     timing = ops.TIMING
     ops.TIMING, ops.STATS = None, {}
-    run_eager()
+    for _ in range(stat_steps):                       # counters accumulate over the passes; kernel_table wants them per step
+        run_eager()
     torch.cuda.synchronize()
-    stats = {k: v for k, v in ops.STATS.items()}
+    stats = {k: v.clone() // stat_steps for k, v in ops.STATS.items()}
     ops.STATS = None
     shapes = {
         "tir_march_primary_fwd": {"io_bytes": io_primary},
@@ -1023,7 +1024,7 @@ def main():
     lanes = max(1, a.in_flight)
     gathered = [torch.empty((world * B, tdist.RECORD), dtype=torch.float32, device=device) for _ in range(lanes)] if use_dist else None
     streams = [torch.cuda.Stream(device=device) for _ in range(lanes)]
-    state = {"i": 0, "lanes": lanes, "b": 0, "last_b": 0}
+    state = {"i": 0, "lanes": lanes, "b": 0, "last_b": 0, "e": 0}
 
     def fork():
         """The lanes' streams start behind everything queued on the current stream."""
@@ -1040,8 +1041,11 @@ def main():
         """One pass over one batch.  Graph replays go round-robin over the lanes (batch i on stream i mod lanes, through that
         lane's own captured graph); eager passes and the one-lane mode run on the current stream.  Timed steps walk through
         the pose batches (step i renders batch i mod --batches); the eager attribution passes render batch 0."""
-        bi = 0 if eager else state["b"] % len(batches)
-        if not eager:
+        if eager:                                       # the attribution passes walk through the poses as the timed steps do
+            bi = state["e"] % len(batches)
+            state["e"] += 1
+        else:
+            bi = state["b"] % len(batches)
             state["b"] += 1
             state["last_b"] = bi
         if eager or a.no_graph or state["lanes"] == 1:
@@ -1177,8 +1181,12 @@ def main():
 
     M = int((ret["acc_map"] > 0.5).sum())
     D = a.env_h * a.env_w
-    rows, gpu_ms, ev_over = attribute_kernels(lambda: step(eager=True), max(1, min(a.profile_steps, a.steps)),
-                                              B * (24 + 4 + 12) + B * a.samples * 4, M * D * (24 + 16), device)
+    # every pose once per round: the per-kernel durations are averages over the same rotation the timed region and a rocprofv3
+    # trace of this command see
+    n_rot = len(batches) * max(1, min(a.profile_steps, a.steps) // len(batches))
+    state["e"] = 0
+    rows, gpu_ms, ev_over = attribute_kernels(lambda: step(eager=True), n_rot, B * (24 + 4 + 12) + B * a.samples * 4,
+                                              M * D * (24 + 16), device, stat_steps=len(batches))
 
     if rank != 0:
         if use_dist:

@@ -37,6 +37,7 @@ TUNE = {
 # TENSOIR_MLP_AUXTAB=0: decoders whose aux input comes through an index map (the radiance decoder's view direction: one per ray
 # or per light direction) run the full 150-input layer 1 instead of the aux-table variant (tir_mlp_aux_table + 9 k-blocks)
 AUX_TABLE = os.environ.get("TENSOIR_MLP_AUXTAB", "1") != "0"
+AUX_TABLE_MULTI = os.environ.get("TENSOIR_MLP_AUXTAB_MULTI", "0") == "1"
 
 
 def mlp_aux_table(m: "PackedMlp", aux):
@@ -334,7 +335,10 @@ def mlp_multi(jobs, n_dev=None, save_hidden=False):
         outs.append(torch.empty((n, m.out_dim), dtype=torch.float32, device=feat.device))
     arr = lambda ts: (C.c_void_p * k)(*[None if t is None else t.data_ptr() for t in ts])
     descs = (C.POINTER(TirMlp) * k)(*[C.pointer(m.desc) for m, _, _, _ in jobs])
-    use_tab = [AUX_TABLE and not save_hidden and mp is not None and aux.shape[0] * 8 <= max(n, 1) for aux, mp in zip(auxs, maps)]
+    # Off by default in the merged primary-stage launch: one job in four would save 12 of its 216 MFMAs per tile (~2 us at
+    # 230 k rows) while its per-ray table costs a 9 us launch of its own.  AUX_TABLE_MULTI = True selects it (tests do).
+    use_tab = [AUX_TABLE and AUX_TABLE_MULTI and not save_hidden and mp is not None and aux.shape[0] * 8 <= max(n, 1)
+               for aux, mp in zip(auxs, maps)]
     if any(use_tab):
         # jobs whose aux rows come through an index map with few distinct rows (same rule as mlp()): aux-table variant of layer 1
         tables = [mlp_aux_table(m, aux) if t else None for (m, _, _, _), aux, t in zip(jobs, auxs, use_tab)]
@@ -369,7 +373,16 @@ def mlp(m: PackedMlp, feat, aux, aux_map=None, impl=None, aux_mod=0, n_dev=None)
     if impl == "bf16x3" and AUX_TABLE and (aux_map is not None or aux_mod > 0) and aux.shape[0] * 8 <= max(n, 1):
         # few distinct aux rows (one per ray / light direction) for many decoder rows: their 15 input columns + the bias as a
         # per-aux-row start value of the layer-1 accumulators, 9 instead of 10 k-blocks of matrix work per row
-        table = mlp_aux_table(m, aux)
+        # the light-direction grid of a scene is a persistent tensor: its table is computed once per (decoder image, aux tensor
+        # version) and kept with the packed decoder (which is rebuilt whenever the weights change)
+        cache = m.__dict__.setdefault("_aux_tables", {})
+        key = (aux.data_ptr(), aux._version, aux.shape[0])
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) >= 4:
+                cache.clear()
+            hit = cache[key] = (aux, mlp_aux_table(m, aux))      # the aux tensor is held too: its address cannot be recycled
+        table = hit[1]                                            # for another tensor while the entry lives
         _call("tir_mlp_fwd_auxtab_bf16x3", C.byref(m.desc), _ptr(feat), feat.shape[1], _ptr(table), _ptr(aux_map), int(aux_mod),
               _ptr(out), n, _ptr(n_dev), _stream())
         return out

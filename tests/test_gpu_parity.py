@@ -133,7 +133,12 @@ def test_decoder_aux_table_variant(env):
     pts = (torch.rand(n, 3, generator=gen) * 2 - 1).cuda()
     f_d = feat.cuda()
     jobs = [(pm, f_d, rays_d, rmap), (m.renderModule_brdf.packed(), f_d, pts, None), (m.renderModule_normal.packed(), f_d, pts, None)]
-    got = ops.mlp_multi(jobs)
+    old_multi = ops.AUX_TABLE_MULTI
+    try:
+        ops.AUX_TABLE_MULTI = True
+        got = ops.mlp_multi(jobs)
+    finally:
+        ops.AUX_TABLE_MULTI = old_multi
     want = [ops.mlp(pm, f_d, rays_d, rmap, "mfma"), ops.mlp(jobs[1][0], f_d, pts, None, "mfma"), ops.mlp(jobs[2][0], f_d, pts, None, "mfma")]
     for a, b in zip(got, want):
         assert rel(a, b) < 1e-5

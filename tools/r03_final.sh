@@ -29,12 +29,15 @@ for wl in image relight train; do
   timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$P/trace_$wl" -o trace -- python $REPO/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline > "$P/trace_$wl.log" 2>&1
   echo "trace $wl rc=$?"
 done
-find "$P" -name "*.db" -size +20M -delete
+# gpurun merges at most 64 MiB back: keep the stats / counter CSVs the summaries are made from, drop the databases and the
+# per-dispatch traces of long runs
+prune() { find "$P" -name "*.db" -delete; find "$P" -name "*kernel_trace.csv" -size +3M -delete; find "$P" -name "*counter_collection.csv" -size +8M -delete; find "$P" -name "*agent_info.csv" -delete; }
 python "$REPO/tools/summarize_prof.py" "$P/trace" > "$P/summary.txt" 2>&1
 python "$REPO/tools/summarize_prof.py" "$P/trace2" > "$P/summary_inflight2.txt" 2>&1
 python "$REPO/tools/summarize_prof.py" "$P" > "$P/summary_all.txt" 2>&1
 for wl in image relight train; do python "$REPO/tools/summarize_prof.py" "$P/trace_$wl" > "$P/summary_$wl.txt" 2>&1; done
 head -30 "$P/summary.txt"; tail -25 "$P/summary_all.txt"
+prune; du -sh "$P" "$OUT"
 cd "$REPO"
 for wl in image relight train; do
   timeout -k 5 500 python bench.py --workload $wl > "$OUT/${TAG}_${wl}_bench.json" 2> "$OUT/${TAG}_${wl}_bench.err"; echo "$wl rc=$?"; tail -c 300 "$OUT/${TAG}_${wl}_bench.json"; echo
@@ -43,3 +46,4 @@ if [ -f "$REPO/gpurun_scratch/reference/train_tensoIR.py" ]; then
   TENSOIR_REFERENCE="$REPO/gpurun_scratch/reference" timeout -k 5 600 python bench.py --no-sharp-scene --no-exact-pass > "$OUT/${TAG}_bench_refcpu.json" 2> "$OUT/${TAG}_bench_refcpu.err"
   echo "bench with reference cpu baseline rc=$?"; python -c "import json; d=json.load(open('$OUT/${TAG}_bench_refcpu.json')); print(d['cpu_baseline'], d.get('speedup_vs_cpu_baseline'))"
 fi
+prune; du -sh "$OUT"
