@@ -874,6 +874,21 @@ def test_multi_decoder_launch_equals_single_launches(env):
     from tensoir_amd import ops
     m = env.model
     gen = torch.Generator().manual_seed(23)
+    _multi_vs_single(ops, m, gen)
+
+
+def _multi_vs_single(ops, m, gen):
+    # like for like: the single launches take the full 150-input layer 1 too (their aux-table variant rounds differently and is
+    # compared in test_decoder_aux_table_variant)
+    old_tab = ops.AUX_TABLE
+    ops.AUX_TABLE = False
+    try:
+        _multi_vs_single_body(ops, m, gen)
+    finally:
+        ops.AUX_TABLE = old_tab
+
+
+def _multi_vs_single_body(ops, m, gen):
     for n in (70_001, 255, 1):
         feats = [torch.zeros(n, 32) for _ in range(3)]
         for f in feats:
