@@ -234,7 +234,10 @@ int tir_mlp_train_fwd_multi_bf16x3(const TirMlp* const* mlps, const float* const
                                    const float* const* auxs, const int32_t* const* aux_maps, float* const* outs,
                                    float* const* h1s, float* const* h2s, int32_t n_jobs, int64_t n,
                                    const int32_t* n_dev, void* stream);
-/* single bf16 product (8 mantissa bits): reduced-precision mode, NOT parity grade (normals ~5e-3). */
+/* single bf16 product (8 mantissa bits): reduced-precision mode, NOT parity grade (normals ~5e-3).  Everything that enters
+ * a matrix product is rounded to bf16 once -- inputs, weights AND layer 1's bias, which rides as the weight of a constant-1
+ * input: a bias of magnitude b carries an error of up to 2^-9 b (the split-bf16 entry keeps ~16 bits of it, the exact entry
+ * all); tests/test_gpu_parity.py::test_decoder_large_biases states the resulting bounds. */
 int tir_mlp_fwd_bf16(const TirMlp* m, const float* feat, int32_t feat_stride, const float* aux,
                      const int32_t* aux_map, int32_t aux_mod, float* out, int64_t n, const int32_t* n_dev,
         void* stream);
