@@ -546,12 +546,14 @@ int tir_gemm_tn_small_bf16x3(const float* const* As, int32_t lda, int32_t M, con
  * tir_mlp_bwd*; h1, h2 [n][128] from the training forward; x is rebuilt in registers from feat [n][feat_stride] and
  * aux [.][3] (aux_maps[i] may be NULL: row s uses aux row s), so no input-row buffer exists.  Split-bf16 matrix cores,
  * fp32 accumulation; results are ADDED (atomics): zero-fill the outputs first.  Two jobs may share outputs (the BRDF
- * decoder's two invocations).  Host arrays of n_jobs entries. */
+ * decoder's two invocations).  Host arrays of n_jobs entries.  max_workgroups (launch option, 0 = 256 = one per CU): a
+ * workgroup occupies a whole CU, so a caller that runs this beside other kernels passes fewer. */
 int tir_mlp_wgrad_multi(const float* const* dz1s, const float* const* dz2s, const float* const* dz3s,
                         const float* const* h1s, const float* const* h2s, const float* const* feats,
                         int32_t feat_stride, const float* const* auxs, const int32_t* const* aux_maps,
                         float* const* dW0s, float* const* db0s, float* const* dW1s, float* const* db1s,
-                        float* const* dW2s, float* const* db2s, int32_t n_jobs, int64_t n, void* stream);
+                        float* const* dW2s, float* const* db2s, int32_t n_jobs, int64_t n, int32_t max_workgroups,
+                        void* stream);
 
 /* C[M][ldc] += A^T B (+ column N = A^T 1 when ones_col != 0: the bias gradient); A [n][lda] (first M columns),
  * B [n][ldb] (first N columns); M <= 128, N + ones_col <= 160.  fp32 MFMA, split over n.  bias_out (may be NULL):

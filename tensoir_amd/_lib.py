@@ -121,7 +121,7 @@ SIGNATURES = {
     "tir_mlp_bwd_bf16x3": (C.c_int, [C.POINTER(TirMlp), P, P, I32, P, P, P, P, I64, P, P, P, P, P]),
     "tir_mlp_bwd_multi_bf16x3": (C.c_int, [P, P, P, I32, P, P, P, P, I32, I64, P, P, P, P, P]),
     "tir_gemm_tn_small_bf16x3": (C.c_int, [P, I32, I32, P, I32, I32, I32, I64, P, I32, P]),
-    "tir_mlp_wgrad_multi": (C.c_int, [P, P, P, P, P, P, I32, P, P, P, P, P, P, P, P, I32, I64, P]),
+    "tir_mlp_wgrad_multi": (C.c_int, [P, P, P, P, P, P, I32, P, P, P, P, P, P, P, P, I32, I64, I32, P]),
     "tir_record_check": (C.c_int, [P, P, I32, P, P, P]),
     "tir_adam_step": (C.c_int, [I32, P, P, P, P, P, P, P, P, F32, F32, F32, P]),
     "tir_gemm_tn": (C.c_int, [P, I32, I32, P, I32, I32, I32, I64, P, I32, P, P]),

@@ -1712,8 +1712,9 @@ extern "C" int tir_mlp_wgrad_multi(const float* const* dz1s, const float* const*
                                    const float* const* h1s, const float* const* h2s, const float* const* feats,
                                    int32_t feat_stride, const float* const* auxs, const int32_t* const* aux_maps,
                                    float* const* dW0s, float* const* db0s, float* const* dW1s, float* const* db1s,
-                                   float* const* dW2s, float* const* db2s, int32_t n_jobs, int64_t n, void* stream) {
-    if (n_jobs < 1 || n_jobs > 4 || n < 0 || feat_stride < F) return TIR_ERR_ARG;
+                                   float* const* dW2s, float* const* db2s, int32_t n_jobs, int64_t n, int32_t max_workgroups,
+                                   void* stream) {
+    if (n_jobs < 1 || n_jobs > 4 || n < 0 || feat_stride < F || max_workgroups < 0) return TIR_ERR_ARG;
     if (!dz1s || !dz2s || !dz3s || !h1s || !h2s || !feats || !auxs || !dW0s || !db0s || !dW1s || !db1s || !dW2s || !db2s)
         return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
@@ -1726,7 +1727,12 @@ extern "C" int tir_mlp_wgrad_multi(const float* const* dz1s, const float* const*
         jobs.j[i] = TirWgradJob{dz1s[i], dz2s[i], dz3s[i], h1s[i], h2s[i], feats[i], auxs[i], aux_maps ? aux_maps[i] : nullptr,
                                 dW0s[i], db0s[i], dW1s[i], db1s[i], dW2s[i], db2s[i]};
     }
-    int per = 256 / n_jobs;                                  // one workgroup of 16 waves per CU, the grid split between the jobs
+    // A workgroup of 16 waves at 128 registers fills a CU's register file: with one per CU nothing else runs on the chip until
+    // the launch ends.  These products are leaves of the backward (they run on a second stream beside the chain that feeds
+    // the optimizer): max_workgroups (0 = 256) lets the caller leave CUs to that chain.
+    const int total = max_workgroups > 0 ? (max_workgroups < 256 ? max_workgroups : 256) : 256;
+    int per = total / n_jobs;                                // the grid split between the jobs
+    if (per < 1) per = 1;
     const int64_t steps = (n + 15) / 16;
     if (steps < per) per = (int)steps;
     hipLaunchKernelGGL(k_mlp_wgrad, dim3((unsigned)(per * n_jobs)), dim3(1024), 0, tir_stream(stream), jobs, feat_stride, n);

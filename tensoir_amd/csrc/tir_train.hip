@@ -539,37 +539,50 @@ template <int C4>
 __global__ void __launch_bounds__(256)
 k_app_dy(const float* __restrict__ basis_t, int app_dim, const float* __restrict__ gfeat, int stride, int64_t n,
          float* __restrict__ y) {
+    // dY tile [32 samples][32 columns] = G[32][28] W[28][32] on v_mfma_f32_32x32x2_f32 (exact fp32), k = 2 t + h.
+    // A wave keeps ITS B operands -- the 14 x NT basis values of its lane (column li of every column tile, k parity h) -- in
+    // registers for all the tiles it walks: no LDS image of basis_mat (round 2 filled a 21 KB LDS copy per workgroup, through
+    // stride-32 reads, for ONE tile per wave: 0.14-0.19 ms per launch for a kernel whose traffic takes 35 us).
     constexpr int CA3 = 12 * C4, NT = (CA3 + 31) / 32;
-    constexpr int LDW = (NT & 1) ? NT * 32 : NT * 32 + 32;       // == 32 mod 64: the two k rows of a step hit disjoint banks
-    __shared__ float Wl[28 * LDW];                                // basis_mat rows (k) x product columns
-    for (int i = threadIdx.x; i < 28 * LDW; i += 256) {
-        const int kk = i / LDW, col = i % LDW;
-        Wl[i] = (kk < app_dim && col < CA3) ? basis_t[(size_t)col * 32 + kk] : 0.0f;
-    }
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, h = lane >> 5;
+    float w[NT][14];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int t = 0; t < 14; ++t) {
+            const int col = 32 * nt + li, kk = 2 * t + h;
+            w[nt][t] = (col < CA3 && kk < app_dim) ? basis_t[(size_t)col * 32 + kk] : 0.0f;
+        }
     const int64_t n_tile = (n + 31) / 32;
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tile; tile += (int64_t)gridDim.x * 4) {
         const int64_t s0 = tile * 32, row = s0 + li;
         float a[14];
 #pragma unroll
         for (int t = 0; t < 14; ++t) a[t] = (row < n && 2 * t + h < app_dim) ? gfeat[row * stride + 2 * t + h] : 0.0f;
-        f32x16 acc[NT];
+        // column tiles in groups of <= 3: 48 accumulator registers live at a time (all NT at once put the kernel at 268
+        // registers = one wave per SIMD); k-major inside a group: consecutive MFMAs go to different accumulators
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        for (int g0 = 0; g0 < NT; g0 += 3) {
+            constexpr int GMAX = 3;
+            f32x16 acc[GMAX];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+            for (int u = 0; u < GMAX; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
 #pragma unroll
             for (int t = 0; t < 14; ++t)
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], Wl[(2 * t + h) * LDW + 32 * nt + li], acc[nt], 0, 0, 0);
-        }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = 32 * nt + li;
+                for (int u = 0; u < GMAX; ++u)
+                    if (g0 + u < NT) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], w[g0 + u][t], acc[u], 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t rr = s0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (rr < n && col < CA3) y[rr * CA3 + col] = acc[nt][r];
+            for (int u = 0; u < GMAX; ++u) {
+                if (g0 + u >= NT) continue;
+                const int col = 32 * (g0 + u) + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t rr = s0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (rr < n && col < CA3) y[rr * CA3 + col] = acc[u][r];
+                }
             }
         }
     }
@@ -1456,8 +1469,8 @@ static int launch_app_bwd(const TirField* f, const TirFieldGrad* g, const float*
     const int line_lds = base + line <= 160 * 1024 ? 1 : 0;     // one line's gradient block-local in LDS when it fits
     const size_t lds = base + (line_lds ? line : 0);
     // dY = g_feat . basis_mat into the y buffers
-    int64_t dyb = (n + 127) / 128;
-    if (dyb > 2048) dyb = 2048;
+    int64_t dyb = (n + 127) / 128;                              // 4 waves x 32 samples per workgroup and pass; persistent beyond 3 per CU
+    if (dyb > 768) dyb = 768;
     if (g_rad) hipLaunchKernelGGL((k_app_dy<C4>), dim3((unsigned)dyb), dim3(256), 0, s, f->basis_t, f->app_dim, g_rad, stride, n, y_rad);
     if (g_int) hipLaunchKernelGGL((k_app_dy<C4>), dim3((unsigned)dyb), dim3(256), 0, s, f->basis_t, f->app_dim, g_int, stride, n, y_int);
     const int threads = TIR_APP_BWD_THREADS;

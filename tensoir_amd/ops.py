@@ -33,6 +33,11 @@ TUNE = {
     "xcd_order": 1 if os.environ.get("TIR_XCD", "0") == "1" else 0,
     "mlp_grid": max(0, int(os.environ.get("TENSOIR_MLP_GRID", "0") or 0)),
     "pair_order": 2 if os.environ.get("TIR_PAIR_ORDER", "d")[:1] == "m" else 0,
+    # TENSOIR_WGRAD_BLOCKS=n: workgroups of the fused weight-gradient launch (0 = 256: each fills a CU).  It runs on the leaf
+    # stream beside the scatter / decoder-backward chain; measured (tools/train_bench.py, same box): 256 -> 4.1-4.3 ms per step,
+    # 128 -> 4.6, 96 -> 4.6, 64 -> 5.2, 48 -> 7.0: with fewer workgroups the scatter kernels get faster (1.14 -> 0.92 ms) but
+    # the leaf launch becomes the critical path
+    "wgrad_blocks": max(0, int(os.environ.get("TENSOIR_WGRAD_BLOCKS", "0") or 0)),
 }
 # TENSOIR_MLP_AUXTAB=0: decoders whose aux input comes through an index map (the radiance decoder's view direction: one per ray
 # or per light direction) run the full 150-input layer 1 instead of the aux-table variant (tir_mlp_aux_table + 9 k-blocks)
@@ -919,7 +924,7 @@ def mlp_wgrad_multi(jobs):
     arr = lambda ts: (C.c_void_p * k)(*[(0 if t is None else t.data_ptr()) for t in ts])
     _call("tir_mlp_wgrad_multi", arr(cols[0]), arr(cols[1]), arr(cols[2]), arr(cols[3]), arr(cols[4]), arr(cols[5]), FEAT_STRIDE,
           arr(cols[6]), (None if null_map else arr(cols[7])), arr(cols[8]), arr(cols[9]), arr(cols[10]), arr(cols[11]),
-          arr(cols[12]), arr(cols[13]), k, n, _stream())
+          arr(cols[12]), arr(cols[13]), k, n, TUNE["wgrad_blocks"], _stream())
     _KEEP_ALIVE = cols          # noqa: F841  (operands stay referenced until the launch is queued)
 
 
