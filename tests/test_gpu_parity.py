@@ -207,6 +207,38 @@ def test_forward_vs_reference(env, decoder):
 
 
 @torch.no_grad()
+def test_smoothness_losses_vs_reference_golden(env):
+    """albedo / roughness smoothness losses (models/tensorBase_rotated_lights.py:937-943, :858-863) against the reference's own
+    values in the golden file, with the reference's jitter draw REPLAYED: its forward draws `torch.randn_like(xyz[app_mask])`
+    from the CPU generator seeded SEED + 3 (oracle/make_golden.py) as the first RNG use of the pass, one row per w > 1e-4
+    sample in (ray, sample) order -- the order of the HIP path's record list -- so the same rows scattered to the records'
+    (ray, sample) positions feed `_brdf_jitter_dense`.  (The product draws its jitter on the device: Philox, another stream.)"""
+    from tensoir_amd import ops
+    m = env.model
+    rays, lidx = G(env, "rays/rays"), G(env, "rays/light_idx")
+    B, S = rays.shape[0], m.nSamples
+    f = m.packed_field()
+    weight, _acc, _depth, _tend, cnt = ops.march_primary(f, rays, None, S, 0.0)
+    offsets = ops.exclusive_scan(cnt)
+    A = int(offsets[-1])
+    rec_ray, rec_k, _w, _xyz = ops.compact_primary(f, rays, None, weight, offsets, A)
+    torch.manual_seed(20211202 + 3)
+    sparse = torch.randn(A, 3)
+    dense = torch.zeros(B, S, 3)
+    dense[rec_ray.cpu().long(), rec_k.cpu().long()] = sparse
+    for impl in ("bf16x3", "mfma"):
+        old = ops.MLP_IMPL
+        ops.MLP_IMPL = impl
+        try:
+            out = m(rays, lidx, _brdf_jitter_dense=dense)
+        finally:
+            ops.MLP_IMPL = old
+        for name, got in (("albedo_smoothness_loss", out[10]), ("roughness_smoothness_loss", out[11])):
+            ref = float(env.g["fwd/" + name])
+            assert abs(float(got) - ref) <= 1e-4 * abs(ref) + 1e-9, (impl, name, float(got), ref)
+
+
+@torch.no_grad()
 def test_secondary_env_ggx_vs_reference(env, decoder):
     from tensoir_amd import relight
     m = env.model
