@@ -866,6 +866,17 @@ class TensorVMSplit(nn.Module):
         (None): Renderer_TensoIR_train shades from the map rows and never looks at it -- one launch less per step."""
         if not is_relight:
             return (maps[:, 0:3], maps[:, 3], None, None, None, None, maps[:, 14], None, None, None, None, None)
+        if maps.requires_grad:
+            # training: ONE autograd node for all the column groups (split_with_sizes: its backward is a single concatenation
+            # of the incoming gradients) instead of one slice node per map, whose backward each fills a zero [B,20] buffer,
+            # copies into it and is then summed with the others -- ~20 small launches of a host-bound stretch of the step
+            rgb, depth, normal, albedo, rough, fresnel, acc, ndiff, norient, sm, _pad = torch.split(
+                maps, [3, 1, 3, 3, 1, 3, 1, 1, 1, 2, 1], dim=1)
+            depth, acc = depth.squeeze(-1), acc.squeeze(-1)
+            if smooth is None:
+                smooth = torch.mean(sm, dim=0)
+            return (rgb, depth, normal, albedo, rough, fresnel, acc, ndiff, norient, (acc > 0.5) if want_mask else None,
+                    smooth[0], smooth[1])
         acc = maps[:, 14]
         if smooth is None:
             smooth = torch.mean(maps[:, 17:19], dim=0)    # both smoothness losses in one reduction launch
