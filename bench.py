@@ -1179,28 +1179,6 @@ def main():
                  "ms_per_step": round(1e3 * el2 / n2, 4)}
         ops.MLP_IMPL = a.decoder
 
-    # the reference marches every ray to its last sample; the product stops a ray once its transmittance is below march_t_stop
-    # (1e-6: bounded, tested deviation).  The same rotation with march_t_stop = 0, one stream, for the record (single process
-    # only: the changed constant re-captures the graph, which must not happen next to live RCCL threads).
-    exact_march = None
-    if not use_dist and not a.no_graph and not a.no_exact_pass and float(model.march_t_stop) != 0.0:
-        old_stop = float(model.march_t_stop)
-        model.march_t_stop = 0.0
-        try:
-            state["lanes"] = 1
-            for b in batches:                                # re-capture + capacities of every pose (rays march further now)
-                graphed[a.decoder][0](rays=b, clone_outputs=False)
-            n3 = max(len(batches), a.steps // 2)
-            state["b"] = 0
-            el3, _ = timed(1, n3)
-            exact_march = {"march_t_stop": 0.0, "in_flight": 1, "steps": n3, "value": round(n_gpus * B * n3 / el3, 1),
-                           "ms_per_step": round(1e3 * el3 / n3, 4)}
-        finally:
-            model.march_t_stop = old_stop
-            state["lanes"] = lanes
-            for g in graphed[a.decoder]:                     # back to the product's constant for everything below
-                g(rays=batches[0], clone_outputs=False)
-
     M = int((ret["acc_map"] > 0.5).sum())
     D = a.env_h * a.env_w
     # every pose once per round: the per-kernel durations are averages over the same rotation the timed region and a rocprofv3
@@ -1338,6 +1316,27 @@ def main():
             sharp = sharp_scene_line(a, device, args)
         except Exception as e:                       # never let the informative line break the headline
             sharp = {"error": f"{type(e).__name__}: {e}"}
+
+    # the reference marches every ray to its last sample; the product stops a ray once its transmittance is below march_t_stop
+    # (1e-6: bounded, tested deviation).  The same rotation with march_t_stop = 0, one stream, for the record (single process
+    # only: the changed constant re-captures the graph, which must not happen next to live RCCL threads; LAST measurement of the
+    # run: it enlarges the record-capacity hints, which would slow the per-kernel passes above by a few per cent).
+    exact_march = None
+    if not use_dist and not a.no_graph and not a.no_exact_pass and float(model.march_t_stop) != 0.0:
+        old_stop = float(model.march_t_stop)
+        model.march_t_stop = 0.0
+        try:
+            state["lanes"] = 1
+            for b in batches:                                # re-capture + capacities of every pose (rays march further now)
+                graphed[a.decoder][0](rays=b, clone_outputs=False)
+            n3 = max(len(batches), a.steps // 2)
+            state["b"] = 0
+            el3, _ = timed(1, n3)
+            exact_march = {"march_t_stop": 0.0, "in_flight": 1, "steps": n3, "value": round(n_gpus * B * n3 / el3, 1),
+                           "ms_per_step": round(1e3 * el3 / n3, 4)}
+        finally:
+            model.march_t_stop = old_stop
+            state["lanes"] = lanes
 
     value = n_gpus * B * a.steps / elapsed
     rccl = None
