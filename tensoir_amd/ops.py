@@ -87,7 +87,14 @@ class _timed:
         return False
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t=None):
+    """The current HIP stream of the current device as the void* the C ABI takes.  The raw accessor skips the Stream object
+    torch.cuda.current_stream() builds per call (~20 calls per step: 10 us -> 1 us each on the host-bound eager path)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
