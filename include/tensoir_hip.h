@@ -363,6 +363,16 @@ int tir_accumulate_records(const int32_t* ray_rec_off, const int32_t* ray_rec_cn
  *      :70-86).  dirs [D][3] -> out [n_lights][D][3]. */
 int tir_env_sg_fwd(const TirEnvSG* e, const float* dirs, int32_t D, float* out, void* stream);
 
+/* ---- a15, light_kind == 'pixel' (models/tensorBase_rotated_lights.py:585-605): the environment map is a learnable image
+ *      light_rgbs [H][W][3] (`_light_rgbs`, :459-460) behind softplus(beta = 5); env[l][d][:] = bilinear lookup
+ *      (F.grid_sample, align_corners=False, zero padding) at the equirectangular position of dirs[d] . rot[l]
+ *      (rot [n_lights][9] row-major light_rotation_matrix).  env [n_lights][n_dirs][3].
+ *      _bwd: g_light [H][W][3] += d loss / d light_rgbs given g_env (atomics; zero-fill first). */
+int tir_env_pixel_fwd(const float* light_rgbs, int32_t H, int32_t W, const float* rot, const float* dirs,
+                      int32_t n_lights, int64_t n_dirs, float* env, void* stream);
+int tir_env_pixel_bwd(const float* light_rgbs, int32_t H, int32_t W, const float* rot, const float* dirs,
+                      int32_t n_lights, int64_t n_dirs, const float* g_env, float* g_light, void* stream);
+
 /* ---- geometry of render_with_BRDF (models/relight_utils.py:417-435): surface point, view
  *      vector and the cosine mask.  maps = [M][TIR_MAP_STRIDE] rows of the selected rays,
  *      rays [M][6], dirs [D][3].  surf [M][3], active [M][D] = cosine > 1e-6 and acc > acc_thres

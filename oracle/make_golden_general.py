@@ -142,12 +142,70 @@ def mask(ref, g0):
     print(f"wrote {path}: {len(g)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def pixel(ref, g0):
+    """light_kind == 'pixel' (models/tensorBase_rotated_lights.py:459-460, :585-605): the learnable envmap_h x envmap_w image behind
+    softplus(beta=5), looked up per rotated direction with grid_sample(align_corners=False) -> tests/golden/pixel_light.npz."""
+    ckpt = golden_checkpoint(g0)
+    ckpt["kwargs"]["light_rotation"] = [int(r) for r in ckpt["kwargs"]["light_rotation"]]
+    ckpt["kwargs"]["light_kind"] = "pixel"
+    ckpt["state_dict"] = {k: v for k, v in ckpt["state_dict"].items() if k != "lgtSGs"}
+    envh, envw = [int(x) for x in g0["scene/envmap_hw"]]
+    gen = torch.Generator().manual_seed(SEED + 21)
+    raw = torch.rand(envh * envw, 3, generator=gen) * 3.0 - 0.5          # uniform(0, 3) as the reference initialises, some negative
+    ckpt["state_dict"]["_light_rgbs"] = raw
+    model = build_reference_model(ref, ckpt, envh, envw)
+    vol = torch.from_numpy(np.array(g0["scene/alpha_volume"]))
+    model.alphaMask = ref.tensorf.AlphaGridMask("cpu", torch.from_numpy(np.array(g0["scene/alpha_aabb"])), vol)
+    assert model.light_kind == "pixel" and torch.equal(model._light_rgbs.data, raw)
+    g = {"light_rgbs_raw": npy(raw)}
+    dirs = torch.nn.functional.normalize(torch.randn(60, 3, generator=gen), dim=-1)
+    # next to the poles and on both sides of the +-pi seam.  (EXACTLY at a pole the lookup column is atan2(+-0, +-0) of the rotated
+    # direction: it depends on the signed zeros the rotation matmul happens to produce -- not a property to pin.)
+    dirs[:4] = torch.nn.functional.normalize(torch.tensor([[1e-3, 2e-3, 1.0], [-2e-3, 1e-3, -1.0], [-1.0, 1e-4, 0.0],
+                                                           [-1.0, -1e-4, 0.0]]), dim=-1)
+    g["env/dirs"] = npy(dirs)
+    with torch.no_grad():
+        g["env/light_rgbs"] = npy(model.get_light_rgbs(dirs, device="cpu"))
+        g["env/light_rgbs_fixed"] = npy(model.get_light_rgbs(model.fixed_viewdirs, device="cpu"))
+    rays = torch.from_numpy(np.array(g0["rays/rays"]))
+    light_idx = torch.from_numpy(np.array(g0["rays/light_idx"]))
+    B, S = rays.shape[0], 64
+    rgb_gt = torch.rand(B, 3, generator=torch.Generator().manual_seed(SEED + 11))
+    args = types.SimpleNamespace(second_nSample=24, second_near=0.05, second_far=1.5)
+    g["train/rgb_gt"], g["train/n_samples"] = npy(rgb_gt), np.array([S], np.int64)
+    model.eval()
+    torch.manual_seed(SEED + 3)
+    with torch.no_grad():
+        ret = ref.renderer.Renderer_TensoIR_train(rays, None, light_idx, model, N_samples=-1, white_bg=True, is_train=False,
+                                                  is_relight=True, sample_method="fixed_envirmap", chunk_size=777, device="cpu", args=args)
+    for k, v in ret.items():
+        g[f"eval/out/{k}"] = npy(v)
+    model.train()
+    model.zero_grad(set_to_none=True)
+    torch.manual_seed(SEED + 12)
+    ret = ref.renderer.Renderer_TensoIR_train(rays, None, light_idx, model, N_samples=S, white_bg=True, is_train=True,
+                                              is_relight=True, sample_method="fixed_envirmap", chunk_size=777, device="cpu", args=args)
+    loss = O.training_loss(ret, rgb_gt, True)
+    loss.backward()
+    g["train/loss"] = npy(loss).reshape(1)
+    for k, v in ret.items():
+        g[f"train/out/{k}"] = npy(v)
+    for name, p in model.named_parameters():
+        g[f"train/grad/{name}"] = npy(torch.zeros_like(p) if p.grad is None else p.grad)
+    torch.manual_seed(SEED + 12)
+    g["train/ray_jitter"] = npy(torch.rand(B, 1))
+    path = os.path.join(OUT, "pixel_light.npz")
+    np.savez_compressed(path, **g)
+    print(f"wrote {path}: {len(g)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 def main():
     ref = ref_loader.load()
     g0 = np.load(os.path.join(OUT, "small_scene.npz"))
     torch.manual_seed(SEED)
     general(ref, g0)
     mask(ref, g0)
+    pixel(ref, g0)
 
 
 if __name__ == "__main__":

@@ -45,11 +45,13 @@ def main():
     args = types.SimpleNamespace(second_nSample=24, second_near=0.05, second_far=1.5)
     S = 64
     g = {"rgb_gt": npy(rgb_gt), "n_samples": np.array([S], np.int64)}
-    for kind in ("purely_predicted", "purely_derived"):
+    normal_gt = torch.nn.functional.normalize(torch.randn(B, 3, generator=torch.Generator().manual_seed(SEED + 13)), dim=-1)
+    g["normal_gt"] = npy(normal_gt)
+    for kind in ("purely_predicted", "purely_derived", "gt_normals"):
         ckpt = golden_checkpoint(g0)
         ckpt["kwargs"]["light_rotation"] = [int(r) for r in ckpt["kwargs"]["light_rotation"]]
         ckpt["kwargs"]["normals_kind"] = kind
-        if kind == "purely_derived":      # no renderModule_normal in that configuration (:417-419)
+        if kind in ("purely_derived", "gt_normals"):      # no renderModule_normal in those configurations (:422-428)
             ckpt["state_dict"] = {k: v for k, v in ckpt["state_dict"].items() if not k.startswith("renderModule_normal")}
         model = build_reference_model(ref, ckpt, envh, envw)
         model.alphaMask = ref.tensorf.AlphaGridMask("cpu", torch.from_numpy(np.array(g0["scene/alpha_aabb"])), vol)
@@ -59,12 +61,21 @@ def main():
         out = model(rays, light_idx, white_bg=True, is_train=False, is_relight=True, N_samples=-1)
         for n, v in zip(NAMES, out):
             g[f"{kind}/fwd/{n}"] = npy(v)
+        # the boundary call in eval mode (gt_normals: the ground-truth normals replace the zero map before shading, renderer.py:82-83)
+        ngt = normal_gt if kind == "gt_normals" else None
+        torch.manual_seed(SEED + 3)
+        with torch.no_grad():
+            ret = ref.renderer.Renderer_TensoIR_train(
+                rays, ngt, light_idx, model, N_samples=-1, white_bg=True, is_train=False, is_relight=True,
+                sample_method="fixed_envirmap", chunk_size=777, device="cpu", args=args)
+        for k, v in ret.items():
+            g[f"{kind}/eval_render/{k}"] = npy(v)
         # one training step through the boundary call
         model.train()
         model.zero_grad(set_to_none=True)
         torch.manual_seed(SEED + 12)
         ret = ref.renderer.Renderer_TensoIR_train(
-            rays, None, light_idx, model, N_samples=S, white_bg=True, is_train=True, is_relight=True,
+            rays, ngt, light_idx, model, N_samples=S, white_bg=True, is_train=True, is_relight=True,
             sample_method="fixed_envirmap", chunk_size=777, device="cpu", args=args)
         loss = O.training_loss(ret, rgb_gt, True)
         loss.backward()

@@ -103,7 +103,9 @@ def scene_from_state_dict(sd, kwargs, alpha_volume=None, alpha_aabb=None,
         mlp_brdf=mlp("renderModule_brdf"),
         mlp_normal=mlp("renderModule_normal") if "renderModule_normal.mlp.0.weight" in sd else None,
         normals_kind=str(kwargs.get("normals_kind", "derived_plus_predicted")),
-        lgtSGs=sd["lgtSGs"],
+        lgtSGs=sd.get("lgtSGs"),
+        light_kind=str(kwargs.get("light_kind", "sg")),
+        light_rgbs_raw=sd.get("_light_rgbs"),         # light_kind == 'pixel': the [envmap_h * envmap_w, 3] map parameters
         light_rotation=[int(r) for r in kwargs["light_rotation"]],
         density_shift=float(kwargs["density_shift"]),
         distance_scale=float(kwargs["distance_scale"]),
@@ -491,6 +493,8 @@ def forward_primary(sc, rays, light_idx, n_samples=-1, white_bg=True, is_relight
                 normal[app_mask] = pred
                 ndiff[app_mask] = torch.sum((pred - derived) ** 2, dim=-1, keepdim=True)
                 norient[app_mask] = torch.sum(vd[app_mask] * pred, dim=-1, keepdim=True).clamp(min=0)
+            elif kind == "gt_normals":
+                pass                                   # zeros: the caller substitutes the ground-truth normals (:951-952, renderer.py:82-83)
             else:
                 raise ValueError(f"normals_kind {kind!r}")
 
@@ -591,6 +595,14 @@ def light_rgbs(sc, dirs):
         return torch.stack([sg_radiance(sg.to(dirs.dtype), d) for sg in sg_list], dim=0)
     rot = light_rotation_matrices(sc.light_rotation).to(dirs.dtype)
     remapped = torch.matmul(dirs.reshape(1, -1, 3), rot).reshape(-1, 3)
+    if getattr(sc, "light_kind", "sg") == "pixel":
+        # models/tensorBase_rotated_lights.py:589-605: softplus(beta=5) map, equirectangular lookup, align_corners=False
+        env = F.softplus(sc.light_rgbs_raw.to(dirs.dtype), beta=5).reshape(sc.envmap_h, sc.envmap_w, 3).permute(2, 0, 1).unsqueeze(0)
+        phi = torch.arccos(remapped[:, 2]).reshape(-1) - 1e-6
+        theta = torch.atan2(remapped[:, 1], remapped[:, 0]).reshape(-1)
+        grid = torch.stack((-theta / math.pi, (phi / math.pi) * 2 - 1)).permute(1, 0).unsqueeze(0).unsqueeze(0)
+        out = F.grid_sample(env, grid, align_corners=False).squeeze(0).squeeze(1).permute(1, 0)
+        return out.reshape(len(sc.light_rotation), -1, 3)
     return sg_radiance(sc.lgtSGs.to(dirs.dtype), remapped).reshape(len(sc.light_rotation), -1, 3)
 
 
@@ -701,12 +713,14 @@ def render_with_brdf(sc, depth, normal, albedo, roughness3, fresnel, rays, light
 
 def renderer_train(sc, rays, light_idx, n_samples=-1, white_bg=True, is_relight=True,
                    second_n_sample=96, second_near=0.05, second_far=1.5,
-                   ray_jitter=None, brdf_jitter=None, dir_jitter=None, backend="aten"):
+                   ray_jitter=None, brdf_jitter=None, dir_jitter=None, backend="aten", normal_gt=None):
     """Renderer_TensoIR_train: renderer.py:57-127.  Returns the 12-key dict."""
     light_idx = light_idx.to(torch.int32)
     (rgb_map, depth, normal, albedo, rough, fresnel, acc, ndiff, norient, acc_mask,
      alb_loss, rgh_loss) = forward_primary(sc, rays, light_idx, n_samples, white_bg, is_relight,
                                            ray_jitter, brdf_jitter, backend)
+    if getattr(sc, "normals_kind", "") == "gt_normals" and normal_gt is not None:      # renderer.py:82-83
+        normal = normal_gt.to(rgb_map.dtype)
     if is_relight:
         masked = render_with_brdf(sc, depth[acc_mask], normal[acc_mask], albedo[acc_mask],
                                   rough[acc_mask].repeat(1, 3), fresnel[acc_mask],
@@ -850,7 +864,10 @@ def scene_parameters(sc):
         for j, k in ((0, "0"), (1, "2"), (2, "4")):
             ps[f"{prefix}.mlp.{k}.weight"] = m[f"w{j}"]
             ps[f"{prefix}.mlp.{k}.bias"] = m[f"b{j}"]
-    ps["lgtSGs"] = sc.lgtSGs
+    if sc.lgtSGs is not None:
+        ps["lgtSGs"] = sc.lgtSGs
+    if getattr(sc, "light_rgbs_raw", None) is not None:
+        ps["_light_rgbs"] = sc.light_rgbs_raw
     for i, sg in enumerate(getattr(sc, "lgtSGs_list", None) or []):     # general multi-light variant: a plain python list
         ps[f"lgtSGs_list.{i}"] = sg                                       # (models/tensorBase_general_multi_lights.py:463-479)
     return ps
@@ -871,7 +888,7 @@ def training_loss(ret, rgb_gt, is_relight, weights=None):
 
 def train_step_grads(sc, rays, light_idx, rgb_gt, is_relight=True, n_samples=-1, white_bg=True,
                      ray_jitter=None, brdf_jitter=None, dir_jitter=None, second_n_sample=96,
-                     second_near=0.05, second_far=1.5, weights=None, backend="aten"):
+                     second_near=0.05, second_far=1.5, weights=None, backend="aten", normal_gt=None):
     """One training forward/backward on the oracle: returns (loss, {name: grad}, ret).  Leaves `sc` untouched."""
     work = Scene(**sc.__dict__)
     leaf = {}
@@ -881,7 +898,10 @@ def train_step_grads(sc, rays, light_idx, rgb_gt, is_relight=True, n_samples=-1,
         return v
     for name in ("density_plane", "density_line", "app_plane", "app_line"):
         setattr(work, name, [mk(t) for t in getattr(sc, name)])
-    work.basis_mat, work.light_line, work.lgtSGs = mk(sc.basis_mat), mk(sc.light_line), mk(sc.lgtSGs)
+    work.basis_mat, work.light_line = mk(sc.basis_mat), mk(sc.light_line)
+    work.lgtSGs = None if sc.lgtSGs is None else mk(sc.lgtSGs)
+    if getattr(sc, "light_rgbs_raw", None) is not None:
+        work.light_rgbs_raw = mk(sc.light_rgbs_raw)
     if getattr(sc, "lgtSGs_list", None) is not None:
         work.lgtSGs_list = [mk(t) for t in sc.lgtSGs_list]
     for name in ("mlp_rgb", "mlp_brdf", "mlp_normal"):
@@ -890,7 +910,7 @@ def train_step_grads(sc, rays, light_idx, rgb_gt, is_relight=True, n_samples=-1,
     leaf = scene_parameters(work)
     with torch.enable_grad():
         ret = renderer_train(work, rays, light_idx, n_samples, white_bg, is_relight, second_n_sample,
-                             second_near, second_far, ray_jitter, brdf_jitter, dir_jitter, backend)
+                             second_near, second_far, ray_jitter, brdf_jitter, dir_jitter, backend, normal_gt)
         loss = training_loss(ret, rgb_gt, is_relight, weights)
     grads = torch.autograd.grad(loss, list(leaf.values()), allow_unused=True)
     out = {n: (torch.zeros_like(p) if g is None else g) for (n, p), g in zip(leaf.items(), grads)}

@@ -357,6 +357,77 @@ k_env_lookup(const float* __restrict__ env_rgb, int H, int W, const float* __res
     out[3 * i] = c[0]; out[3 * i + 1] = c[1]; out[3 * i + 2] = c[2];
 }
 
+// get_light_rgbs for light_kind == 'pixel' (models/tensorBase_rotated_lights.py:585-605): the environment map is a learnable
+// [H][W][3] image passed through softplus(beta = 5); a direction, rotated into light l's frame (dirs . R_l), is looked up with
+// F.grid_sample(align_corners=False, zero padding) at qx = -theta / pi, qy = 2 (acos(z) - 1e-6) / pi - 1.
+// One thread per (light, direction).  PixTap: the four taps of a lookup (index or -1 when outside, weight).
+struct PixTap { int idx[4]; float w[4]; };
+
+__device__ __forceinline__ PixTap pixel_taps(const float* __restrict__ rot, const float* __restrict__ dirs, int l, int64_t d,
+                                             int H, int W) {
+    const float* R = rot + 9 * (size_t)l;
+    const float x = dirs[3 * d], y = dirs[3 * d + 1], z = dirs[3 * d + 2];
+    const float rx = x * R[0] + y * R[3] + z * R[6], ry = x * R[1] + y * R[4] + z * R[7], rz = x * R[2] + y * R[5] + z * R[8];
+    const float PI = 3.14159265358979323846f;
+    const float phi = acosf(rz) - 1e-6f, theta = atan2f(ry, rx);
+    const float qy = (phi / PI) * 2.0f - 1.0f, qx = -theta / PI;
+    const float ix = ((qx + 1.0f) * (float)W - 1.0f) * 0.5f, iy = ((qy + 1.0f) * (float)H - 1.0f) * 0.5f;   // align_corners=False
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float tx = ix - fx, ty = iy - fy;
+    PixTap t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+        t.w[k] = ((k & 1) ? tx : 1.0f - tx) * ((k >> 1) ? ty : 1.0f - ty);
+        t.idx[k] = (xx >= 0 && xx < W && yy >= 0 && yy < H) ? yy * W + xx : -1;
+    }
+    return t;
+}
+
+__device__ __forceinline__ float softplus5(float x) {        // torch softplus(beta=5, threshold=20)
+    const float bx = 5.0f * x;
+    return bx > 20.0f ? x : log1pf(expf(bx)) * 0.2f;
+}
+
+__global__ void __launch_bounds__(256)
+k_env_pixel(const float* __restrict__ light_rgbs, int H, int W, const float* __restrict__ rot, const float* __restrict__ dirs,
+            int L, int64_t D, float* __restrict__ env) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)L * D) return;
+    const int l = (int)(i / D);
+    const PixTap t = pixel_taps(rot, dirs, l, i % D, H, W);
+    float c[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (t.idx[k] >= 0) {
+            const float* p = light_rgbs + 3 * (size_t)t.idx[k];
+            c[0] = fmaf(t.w[k], softplus5(p[0]), c[0]); c[1] = fmaf(t.w[k], softplus5(p[1]), c[1]);
+            c[2] = fmaf(t.w[k], softplus5(p[2]), c[2]);
+        }
+    env[3 * i] = c[0]; env[3 * i + 1] = c[1]; env[3 * i + 2] = c[2];
+}
+
+// d loss / d light_rgbs[h][w][c] += g_env . tap weight . sigmoid(5 x)   (caller zero-fills g_light)
+__global__ void __launch_bounds__(256)
+k_env_pixel_bwd(const float* __restrict__ light_rgbs, int H, int W, const float* __restrict__ rot,
+                const float* __restrict__ dirs, int L, int64_t D, const float* __restrict__ g_env, float* __restrict__ g_light) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)L * D) return;
+    const int l = (int)(i / D);
+    const PixTap t = pixel_taps(rot, dirs, l, i % D, H, W);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (t.idx[k] >= 0) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float x = light_rgbs[3 * (size_t)t.idx[k] + ch];
+                const float ds = (5.0f * x > 20.0f) ? 1.0f : 1.0f / (1.0f + expf(-5.0f * x));
+                unsafeAtomicAdd(g_light + 3 * (size_t)t.idx[k] + ch, g_env[3 * i + ch] * t.w[k] * ds);
+            }
+        }
+}
+
 __global__ void __launch_bounds__(256)
 k_ggx(const float* __restrict__ normal, const float* __restrict__ v, const float* __restrict__ l,
       const float* __restrict__ rough, const float* __restrict__ fresnel, int M, int D, float* __restrict__ spec) {
@@ -493,6 +564,30 @@ extern "C" int tir_env_lookup(const float* env_rgb, int32_t H, int32_t W, const 
     if (!env_rgb || !dirs || !out) return TIR_ERR_ARG;
     hipLaunchKernelGGL(k_env_lookup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tir_stream(stream), env_rgb, H, W,
                        dirs, n, out);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_env_pixel_fwd(const float* light_rgbs, int32_t H, int32_t W, const float* rot, const float* dirs,
+                                 int32_t n_lights, int64_t n_dirs, float* env, void* stream) {
+    if (H <= 0 || W <= 0 || n_lights <= 0 || n_dirs < 0) return TIR_ERR_ARG;
+    if (n_dirs == 0) return TIR_OK;
+    if (!light_rgbs || !rot || !dirs || !env) return TIR_ERR_ARG;
+    const int64_t n = (int64_t)n_lights * n_dirs;
+    hipLaunchKernelGGL(k_env_pixel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tir_stream(stream), light_rgbs, H, W, rot,
+                       dirs, n_lights, n_dirs, env);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_env_pixel_bwd(const float* light_rgbs, int32_t H, int32_t W, const float* rot, const float* dirs,
+                                 int32_t n_lights, int64_t n_dirs, const float* g_env, float* g_light, void* stream) {
+    if (H <= 0 || W <= 0 || n_lights <= 0 || n_dirs < 0) return TIR_ERR_ARG;
+    if (n_dirs == 0) return TIR_OK;
+    if (!light_rgbs || !rot || !dirs || !g_env || !g_light) return TIR_ERR_ARG;
+    const int64_t n = (int64_t)n_lights * n_dirs;
+    hipLaunchKernelGGL(k_env_pixel_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tir_stream(stream), light_rgbs, H, W,
+                       rot, dirs, n_lights, n_dirs, g_env, g_light);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

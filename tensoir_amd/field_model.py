@@ -284,7 +284,7 @@ class TensorVMSplit(nn.Module):
         'purely_predicted' / 'purely_derived'."""
         if shadingMode != "MLP_Fea":
             raise NotImplementedError(f"shadingMode={shadingMode!r}: only 'MLP_Fea' has gfx950 kernels")
-        if self.normals_kind not in ("derived_plus_predicted", "purely_predicted", "purely_derived"):
+        if self.normals_kind not in ("derived_plus_predicted", "purely_predicted", "purely_derived", "gt_normals"):
             raise NotImplementedError(f"normals_kind={self.normals_kind!r} has no gfx950 kernels")
         self.renderModule = MLPRender_Fea(self.app_dim, view_pe, fea_pe, featureC).to(device)
         if self.normals_kind in ("purely_predicted", "derived_plus_predicted"):
@@ -313,8 +313,13 @@ class TensorVMSplit(nn.Module):
     def init_light(self):
         """models/tensorBase_rotated_lights.py:455-488."""
         self.light_area_weight, self.fixed_viewdirs = self.generate_envir_map_dir(self.envmap_h, self.envmap_w)
-        if self.light_kind != "sg":
-            raise NotImplementedError(f"light_kind={self.light_kind!r}: only 'sg' has gfx950 kernels")
+        if self.light_kind not in ("sg", "pixel"):
+            raise NotImplementedError(f"light_kind={self.light_kind!r}: 'sg' and 'pixel' have gfx950 kernels")
+        self._light_rotations()
+        if self.light_kind == "pixel":       # :459-460: a learnable envmap_h x envmap_w image behind softplus(beta=5)
+            nlights = self.envmap_w * self.envmap_h
+            self._light_rgbs = nn.Parameter(torch.FloatTensor(nlights, 3).uniform_(0, 3).to(torch.float32).to(self.device))
+            return
         self.lgtSGs = nn.Parameter(torch.randn(self.numLgtSGs, 7), requires_grad=True)
         self.lgtSGs.data[:, -2:] = self.lgtSGs.data[:, -3:-2].expand((-1, 2))
         self.lgtSGs.data[:, 3:4] = 10.0 + torch.abs(self.lgtSGs.data[:, 3:4] * 20.0)
@@ -324,6 +329,9 @@ class TensorVMSplit(nn.Module):
         self.lgtSGs.data[:self.numLgtSGs // 2, :3] = torch.from_numpy(lobes)
         self.lgtSGs.data[self.numLgtSGs // 2:, :3] = torch.from_numpy(lobes)
         self.lgtSGs.data = self.lgtSGs.data.to(self.device)
+
+    def _light_rotations(self):
+        """:479-487: one z-rotation matrix per light."""
         mats = []
         for i in range(self.light_num):
             a = torch.tensor(self.light_rotation[i] / 180 * torch.pi).to(torch.float32)
@@ -376,6 +384,11 @@ class TensorVMSplit(nn.Module):
         if rot is None or rot.device != dirs.device:
             rot = self.light_rotation_matrix.to(dirs.device).contiguous()
             self.__dict__["_rot_dev"] = rot
+        if self.light_kind == "pixel":           # :585-605; tiny table, evaluated per call (no cache: the map trains)
+            if torch.is_grad_enabled() and self._light_rgbs.requires_grad:
+                from . import training
+                return training.EnvPixelFn.apply(self._light_rgbs, rot, dirs, self.envmap_h, self.envmap_w)
+            return ops.env_pixel(self._light_rgbs, self.envmap_h, self.envmap_w, rot, dirs)
         if torch.is_grad_enabled() and self.lgtSGs.requires_grad:
             from . import training
             return training.EnvSGFn.apply(self.lgtSGs, rot, dirs)
@@ -417,7 +430,14 @@ class TensorVMSplit(nn.Module):
         return g
 
     def _light_param_groups(self):
-        return [{"params": self.lgtSGs, "lr": 0.001}]
+        """models/tensoRF_rotated_lights.py:43-46."""
+        return [{"params": self._light_rgbs if self.light_kind == "pixel" else self.lgtSGs, "lr": 0.001}]
+
+    def light_parameters(self):
+        """The environment light's trainable tensors (cache keys of captured graphs, train / eval routing)."""
+        if self.light_kind == "pixel":
+            return [self._light_rgbs]
+        return list(getattr(self, "lgtSGs_list", None) or [self.lgtSGs])
 
     def vectorDiffs(self, vector_comps):
         total = 0
@@ -781,7 +801,7 @@ class TensorVMSplit(nn.Module):
                     rng_state = self._jitter_rng(dev)
                     xyz_j, intr_j = ops.vm_app_jitter(f, rec_xyz, 0.01, 0, 0, rng_state, n_dev)
                 jobs.append((pb, intr_j, xyz_j, None))
-                if self.normals_kind != "purely_derived":
+                if self.normals_kind not in ("purely_derived", "gt_normals"):
                     jobs.append((self.renderModule_normal.packed(), intr, rec_xyz, None))
             if ops.MLP_IMPL == "bf16x3":
                 # the decoders of the primary stage run on the same records: ONE launch, the grid split between them
@@ -793,6 +813,8 @@ class TensorVMSplit(nn.Module):
                 brdf, brdf_j = outs[1], outs[2]
                 if self.normals_kind == "purely_derived":
                     pred = ops.density_grad(f, rec_xyz, n_dev=n_dev)[2]
+                elif self.normals_kind == "gt_normals":
+                    pred = None                        # zeros (:951-952): Renderer_TensoIR_train substitutes normal_gt
                 else:
                     pred = outs[3]
                     if self.normals_kind == "derived_plus_predicted":

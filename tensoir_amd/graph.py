@@ -81,7 +81,7 @@ class GraphedRenderer:
         for d in decs:
             d.packed()
         # every light parameter: the general multi-light model keeps one SG set per light in a plain list
-        lights = getattr(m, "lgtSGs_list", None) or [m.lgtSGs]
+        lights = m.light_parameters()
         return (m._field_key, tuple((t.data_ptr(), t._version) for t in lights), tuple(d._key for d in decs),
                 float(m.march_t_stop), ops.MLP_IMPL)
 

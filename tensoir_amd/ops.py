@@ -594,6 +594,30 @@ def env_sg(lgtSGs, rot, dirs):
     return out
 
 
+def env_pixel(light_rgbs, H, W, rot, dirs):
+    """light_kind == 'pixel': [H*W, 3] raw map parameters -> environment radiance [L, D, 3] (tir_env_pixel_fwd)."""
+    lr = f32(light_rgbs.detach(), "_light_rgbs", 3).view(-1, 3)
+    if lr.shape[0] != H * W:
+        raise ValueError(f"_light_rgbs: expected {H * W} rows, got {lr.shape[0]}")
+    rot = f32(rot, "light_rotation_matrix").view(-1, 9)
+    dirs = f32(dirs, "dirs", 3).view(-1, 3)
+    L, D = rot.shape[0], dirs.shape[0]
+    out = torch.empty((L, D, 3), dtype=torch.float32, device=dirs.device)
+    _call("tir_env_pixel_fwd", _ptr(lr), int(H), int(W), _ptr(rot), _ptr(dirs), L, D, _ptr(out), _stream())
+    return out
+
+
+def env_pixel_bwd(light_rgbs, H, W, rot, dirs, g_env):
+    lr = f32(light_rgbs.detach(), "_light_rgbs", 3).view(-1, 3)
+    rot = f32(rot, "light_rotation_matrix").view(-1, 9)
+    dirs = f32(dirs, "dirs", 3).view(-1, 3)
+    g_env = f32(g_env, "g_env", 3)
+    L, D = rot.shape[0], dirs.shape[0]
+    g = torch.zeros_like(lr)
+    _call("tir_env_pixel_bwd", _ptr(lr), int(H), int(W), _ptr(rot), _ptr(dirs), L, D, _ptr(g_env), _ptr(g), _stream())
+    return g.view_as(light_rgbs)
+
+
 def shade_setup(maps, rays, dirs, acc_thres=-1e30):
     maps = f32(maps, "maps", MAP_STRIDE)
     rays = f32(rays, "rays", 6)

@@ -210,7 +210,7 @@ def shade_from_maps(tensoIR, maps, rays, light_idx, sample_method="fixed_envirma
     if M == 0:
         out = torch.zeros((0, 3), dtype=torch.float32, device=dev)
         return (out, None) if return_aux else out
-    train = torch.is_grad_enabled() and (maps.requires_grad or tensoIR.lgtSGs.requires_grad)
+    train = torch.is_grad_enabled() and (maps.requires_grad or any(t.requires_grad for t in tensoIR.light_parameters()))
     fuse = not train and not return_aux
     with torch.no_grad():      # compute_secondary_shading_effects is @torch.no_grad (models/relight_utils.py:344)
         # only the pairs that pass the cosine / acc masks get a secondary ray: compacted id list (the reference's

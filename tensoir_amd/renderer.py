@@ -21,8 +21,9 @@ def Renderer_TensoIR_train(rays=None, normal_gt=None, light_idx=None, tensoIR=No
          normals_orientation_loss_map, acc_mask, albedo_smoothness_loss, roughness_smoothness_loss), maps = \
             tensoIR(rays, light_idx, is_train=is_train, white_bg=white_bg, is_relight=is_relight, ndc_ray=ndc_ray,
                     N_samples=N_samples, _return_maps=True, _defer_check=attempt == 0, _want_mask=False)
-        if tensoIR.normals_kind == "gt_normals" and normal_gt is not None:
-            normal_map = ops.to_device(normal_gt, device)
+        if tensoIR.normals_kind == "gt_normals" and normal_gt is not None:       # renderer.py:82-83
+            normal_map = ops.to_device(normal_gt, device).to(torch.float32)
+            maps = torch.cat([maps[:, :4], normal_map, maps[:, 7:]], dim=1)      # the shading kernels read the map rows
         if is_relight:
             # all rays go through the shading kernels; rows with acc <= 0.5 (acc_mask, :1031) spawn no secondary
             # rays and get the white background (renderer.py:86-106) -- no boolean-mask compaction, no host sync

@@ -263,7 +263,7 @@ class PrimaryRenderFn(torch.autograd.Function):
             if is_relight:
                 jobs.append(("brdf", model.renderModule_brdf, intr, rec_xyz, None))
                 jobs.append(("brdf_j", model.renderModule_brdf, intr_j, xyz_j, None))
-                if model.normals_kind != "purely_derived":
+                if model.normals_kind not in ("purely_derived", "gt_normals"):
                     jobs.append(("normal", model.renderModule_normal, intr, rec_xyz, None))
             if ops.MLP_IMPL == "bf16x3" and ops.FEAT_STRIDE == rad.shape[1]:
                 # same records for every decoder: ONE launch, the grid split between them
@@ -279,6 +279,8 @@ class PrimaryRenderFn(torch.autograd.Function):
                 st.xyz_j = xyz_j
                 if model.normals_kind == "purely_derived":
                     pred = ops.density_grad(f, rec_xyz, n_dev=n_dev)[2]
+                elif model.normals_kind == "gt_normals":
+                    pred = None
                 else:
                     pred = outs["normal"]
                     if model.normals_kind == "derived_plus_predicted":
@@ -372,7 +374,7 @@ class PrimaryRenderFn(torch.autograd.Function):
                     g_int = g_int + g_n
                     if g_der is not None:
                         ops.density_grad_bwd(f, gd, st.rec_xyz, g_der)
-                else:                                   # purely_derived: the composited normal IS the derived one
+                elif model.normals_kind == "purely_derived":       # the composited normal IS the derived one
                     ops.density_grad_bwd(f, gd, st.rec_xyz, g_pred)
             if wg:
                 leaf.run(lambda: ops.mlp_wgrad_multi(wg), *[t for job in wg for t in job if t is not None])
@@ -420,6 +422,21 @@ class EnvSGFn(torch.autograd.Function):
     def backward(ctx, g_env):
         lgtSGs, rot, dirs = ctx.saved_tensors
         return ops.env_sg_bwd(lgtSGs, rot, dirs, g_env.contiguous()), None, None
+
+
+class EnvPixelFn(torch.autograd.Function):
+    """get_light_rgbs for light_kind == 'pixel' (models/tensorBase_rotated_lights.py:585-605)."""
+
+    @staticmethod
+    def forward(ctx, light_rgbs, rot, dirs, H, W):
+        ctx.save_for_backward(light_rgbs, rot, dirs)
+        ctx.hw = (H, W)
+        return ops.env_pixel(light_rgbs, H, W, rot, dirs)
+
+    @staticmethod
+    def backward(ctx, g_env):
+        light_rgbs, rot, dirs = ctx.saved_tensors
+        return ops.env_pixel_bwd(light_rgbs, ctx.hw[0], ctx.hw[1], rot, dirs, g_env.contiguous()), None, None, None, None
 
 
 class ShadeFn(torch.autograd.Function):

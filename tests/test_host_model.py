@@ -105,8 +105,17 @@ def test_unsupported_configurations_fail_loudly():
         TensorVMSplit(aabb, [8, 8, 8], "cpu", shadingMode="SH", light_kind="sg", density_n_comp=[16] * 3,
                       appearance_n_comp=[48] * 3)
     with pytest.raises(NotImplementedError):
-        TensorVMSplit(aabb, [8, 8, 8], "cpu", shadingMode="MLP_Fea", light_kind="pixel", density_n_comp=[16] * 3,
+        TensorVMSplit(aabb, [8, 8, 8], "cpu", shadingMode="MLP_Fea", light_kind="gt", density_n_comp=[16] * 3,
                       appearance_n_comp=[48] * 3)
+    with pytest.raises(NotImplementedError):
+        TensorVMSplit(aabb, [8, 8, 8], "cpu", shadingMode="MLP_Fea", light_kind="sg", normals_kind="residue_prediction",
+                      density_n_comp=[16] * 3, appearance_n_comp=[48] * 3)
+    # the other kinds of the reference construct: the learnable pixel environment map (:459-460), ground-truth normals (:951-952)
+    m = TensorVMSplit(aabb, [8, 8, 8], "cpu", shadingMode="MLP_Fea", light_kind="pixel", normals_kind="gt_normals",
+                      envmap_h=4, envmap_w=8, density_n_comp=[16] * 3, appearance_n_comp=[48] * 3)
+    assert m._light_rgbs.shape == (32, 3) and not hasattr(m, "lgtSGs") and not hasattr(m, "renderModule_normal")
+    assert float(m._light_rgbs.min()) >= 0.0 and float(m._light_rgbs.max()) <= 3.0
+    assert m.light_parameters()[0] is m._light_rgbs and "_light_rgbs" in m.state_dict()
 
 
 def test_no_silent_fallbacks(model, golden):

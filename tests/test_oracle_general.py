@@ -119,3 +119,64 @@ def test_update_alpha_mask_vs_reference(golden, mg):
     aabb2 = O.update_alpha_mask(sc, (33, 29, 31))
     assert int((sc.alpha_volume != T(mg, "update2/volume")).sum()) == 0
     assert float((aabb2 - T(mg, "update2/aabb")).abs().max()) < 1e-6
+
+
+# ---------------------------------------------------------------- light_kind == 'pixel' (tests/golden/pixel_light.npz)
+@pytest.fixture(scope="module")
+def pg():
+    return np.load(os.path.join(ROOT, "tests", "golden", "pixel_light.npz"))
+
+
+def pixel_checkpoint(golden, pg):
+    from tests.helpers import golden_checkpoint
+    ck = golden_checkpoint(golden)
+    ck["kwargs"]["light_kind"] = "pixel"
+    ck["state_dict"] = {k: v for k, v in ck["state_dict"].items() if k != "lgtSGs"}
+    ck["state_dict"]["_light_rgbs"] = T(pg, "light_rgbs_raw")
+    return ck
+
+
+def pixel_scene(golden, pg):
+    from tests.helpers import scene_from_checkpoint
+    eh, ew = [int(x) for x in golden["scene/envmap_hw"]]
+    return scene_from_checkpoint(pixel_checkpoint(golden, pg), eh, ew)
+
+
+def test_pixel_light_rgbs_vs_reference(golden, pg):
+    """get_light_rgbs for the learnable pixel environment map (models/tensorBase_rotated_lights.py:585-605), incl. the poles
+    and the +-pi seam of the equirectangular lookup, three light rotations."""
+    sc = pixel_scene(golden, pg)
+    for dk, ek in (("env/dirs", "env/light_rgbs"),):
+        got = O.light_rgbs(sc, T(pg, dk))
+        ref = T(pg, ek)
+        assert got.shape == ref.shape and float((got - ref).abs().max()) < 1e-6
+    assert float((T(pg, "env/light_rgbs")[0] - T(pg, "env/light_rgbs")[1]).abs().max()) > 1e-2     # the rotations matter
+
+
+def test_pixel_light_render_and_grads_vs_reference(golden, pg):
+    sc = pixel_scene(golden, pg)
+    rays, lidx = T(golden, "rays/rays"), T(golden, "rays/light_idx")
+    torch.manual_seed(SEED + 3)
+    with torch.no_grad():
+        ret = O.renderer_train(sc, rays, lidx, n_samples=-1, second_n_sample=24, second_near=0.05, second_far=1.5)
+    for k in ("rgb_map", "normal_map", "albedo_map", "acc_map", "rgb_with_brdf_map"):
+        assert float((ret[k] - T(pg, f"eval/out/{k}")).abs().max()) < 3e-5, k
+    S = int(pg["train/n_samples"][0])
+    torch.manual_seed(SEED + 12)
+    jit = torch.rand(rays.shape[0], 1)
+    assert np.array_equal(jit.numpy(), pg["train/ray_jitter"])
+    loss, grads, ret = O.train_step_grads(sc, rays, lidx, T(pg, "train/rgb_gt"), is_relight=True, n_samples=S,
+                                          ray_jitter=jit, second_n_sample=24, second_near=0.05, second_far=1.5)
+    assert abs(float(loss) - float(pg["train/loss"][0])) < 2e-6
+    assert "_light_rgbs" in grads and "lgtSGs" not in grads
+    checked = 0
+    for name, gr in grads.items():
+        ref = torch.from_numpy(pg[f"train/grad/{name}"]).double()
+        if float(ref.abs().max()) == 0:
+            assert float(gr.abs().max()) == 0, name
+            continue
+        err = float((gr.double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-3, (name, err)
+        checked += 1
+    assert checked >= 30 and float(np.abs(pg["train/grad/_light_rgbs"]).max()) > 0
+
