@@ -570,17 +570,9 @@ def bench_image(a):
 
 
 def synthetic_hdr_maps(n_maps, H=1024, W=2048):
-    """Seeded 2048x1024 HDR environment maps (exp(N(0, 1.5^2)) low-pass filtered + one 100x sun disc each)."""
-    gen = torch.Generator().manual_seed(71)
-    maps = {}
-    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
-    for i in range(n_maps):
-        hdr = torch.exp(torch.randn(H // 8, W // 8, 3, generator=gen) * 1.5)
-        hdr = torch.nn.functional.interpolate(hdr.permute(2, 0, 1)[None], size=(H, W), mode="bilinear",
-                                              align_corners=False)[0].permute(1, 2, 0).contiguous()
-        hdr[((yy - 200 - 100 * i) ** 2 + (xx - 300 * (i + 1)) ** 2) < 20 ** 2] *= 100.0
-        maps[f"env{i}"] = hdr
-    return maps
+    """Seeded 2048x1024 HDR environment maps (tensoir_amd.synth.make_hdr_maps)."""
+    from tensoir_amd import synth
+    return synth.make_hdr_maps([f"env{i}" for i in range(n_maps)], H, W)
 
 
 def bench_relight(a):

@@ -270,7 +270,14 @@ class Environment_Light:
         self.hdr_row_cdf, self.hdr_col_cdf = {}, {}
         self._draws = 0
         maps = dict(hdr_maps or {})
-        if hdr_path is not None:
+        if torch.device(device).type == "cuda" and not torch.cuda.is_available():
+            raise ops._lib.TensoirHipError("Environment_Light: no GPU is visible; tensoir_amd has no CPU path")
+        if hdr_path is not None and str(hdr_path).startswith("synthetic"):       # no *.hdr files offline: seeded maps
+            from . import synth
+            from .synth_dataset import parse_spec
+            spec = {"h": 32, "w": 64, **{k: v for k, v in parse_spec(hdr_path).items() if k in ("h", "w")}}
+            maps.update(synth.make_hdr_maps(synth.HDR_NAMES, int(spec["h"]), int(spec["w"])))
+        elif hdr_path is not None:
             import os
             for file in os.listdir(hdr_path):
                 if file.endswith(".hdr"):

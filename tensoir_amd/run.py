@@ -63,7 +63,23 @@ def install(reference_root: str):
         import torch
         dev = "cuda" if torch.cuda.is_available() else None
     synth_dataset.wrap_dataset_dict(importlib.import_module("dataLoader").dataset_dict, device=dev)
+    _allow_numpy_in_checkpoints()
     return done
+
+
+def _allow_numpy_in_checkpoints():
+    """The scripts call ``torch.load(args.ckpt, map_location=device)`` (train_tensoIR.py:54, :77, :164); TensoIR checkpoints
+    carry the occupancy mask as ``np.packbits`` bytes (tensorBase_rotated_lights.py:681), which torch >= 2.6 refuses under its
+    new ``weights_only=True`` default.  Allow-list numpy's array reconstruction so that --ckpt / --render_only keep working."""
+    import numpy as np
+    import torch
+    try:
+        import numpy._core.multiarray as ma
+    except ImportError:                          # numpy 1.x
+        import numpy.core.multiarray as ma
+    if hasattr(torch.serialization, "add_safe_globals"):
+        torch.serialization.add_safe_globals([ma._reconstruct, np.ndarray, np.dtype] + sorted(
+            {type(np.dtype(t)) for t in (np.uint8, np.bool_, np.float32, np.float64, np.int32, np.int64)}, key=repr))
 
 
 def main(argv=None):

@@ -4,6 +4,9 @@ tensorboard.  Product side (used by ``python -m tensoir_amd.run``): a module is 
 cannot be imported.  None of them is on the hot path -- they are image I/O, logging, metrics and CLI parsing --
 so the stand-ins either implement the few functions the training script actually calls (``configargparse``,
 ``SummaryWriter``, ``kornia.create_meshgrid``, ``imageio.imwrite`` through PIL) or raise a clear error on use.
+scripts/relight_importance.py additionally writes videos, reads its own PNGs back, colour-maps depth and asks for LPIPS:
+``imageio.mimsave`` / ``imageio.v2.imread`` go through PIL, ``cv2.applyColorMap`` is a small numpy jet ramp, and ``lpips.LPIPS``
+-- whose pretrained networks cannot exist offline -- reports NaN (the metric is then visibly unmeasured, nothing else changes).
 """
 from __future__ import annotations
 
@@ -199,7 +202,73 @@ def _imwrite(path, img, *a, **k):
     arr = np.asarray(img)
     if arr.dtype != np.uint8:
         arr = (np.clip(arr, 0, 1) * 255).astype(np.uint8)
+    if arr.ndim == 3 and arr.shape[2] == 1:
+        arr = arr[:, :, 0]
     Image.fromarray(arr).save(path)
+
+
+def _imread(path, *a, **k):
+    import numpy as np
+    from PIL import Image
+    return np.asarray(Image.open(path))
+
+
+def _mimsave(path, frames, *a, **k):
+    """No video encoder offline: the frames go into an animated PNG at the requested path."""
+    import numpy as np
+    from PIL import Image
+    imgs = [Image.fromarray(np.asarray(f).astype(np.uint8)) for f in frames]
+    if imgs:
+        with open(path, "wb") as fh:
+            imgs[0].save(fh, format="PNG", save_all=True, append_images=imgs[1:])
+
+
+def _apply_color_map(x, cmap=2):
+    """cv2.applyColorMap for utils.visualize_depth_numpy (:30): uint8 [H,W] -> BGR uint8 [H,W,3], piecewise-linear jet."""
+    import numpy as np
+    v = np.asarray(x, dtype=np.float32).reshape(np.asarray(x).shape[:2]) / 255.0
+    r = np.clip(1.5 - np.abs(4 * v - 3), 0, 1)
+    g = np.clip(1.5 - np.abs(4 * v - 2), 0, 1)
+    b = np.clip(1.5 - np.abs(4 * v - 1), 0, 1)
+    return (np.stack([b, g, r], -1) * 255).astype(np.uint8)
+
+
+class _NoLPIPS:
+    """lpips.LPIPS needs pretrained AlexNet / VGG weights; offline the metric is reported as NaN."""
+
+    def __init__(self, *a, **k):
+        import warnings
+        warnings.warn("lpips is not installed: LPIPS metrics are reported as NaN (tensoir_amd.shims)")
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def __call__(self, gt, im, *a, **k):
+        import torch
+        return torch.full((1,), float("nan"))
+
+
+def _make_grid(tensor, nrow=8, padding=2, normalize=False, value_range=None, scale_each=False, pad_value=0.0, **k):
+    """torchvision.utils.make_grid for the evaluation loop's tensorboard images (renderer.py:443-452): [N,C,H,W] -> [C,H',W']."""
+    import torch
+    t = torch.stack(list(tensor)) if isinstance(tensor, (list, tuple)) else tensor
+    t = t.float()
+    if t.dim() == 3:
+        t = t[None]
+    if normalize:
+        lo, hi = value_range if value_range is not None else (float(t.min()), float(t.max()))
+        t = (t.clamp(lo, hi) - lo) / max(hi - lo, 1e-5)
+    n, c, h, w = t.shape
+    cols = min(nrow, n)
+    rows = (n + cols - 1) // cols
+    grid = t.new_full((c, rows * (h + padding) + padding, cols * (w + padding) + padding), pad_value)
+    for i in range(n):
+        y, x = (i // cols) * (h + padding) + padding, (i % cols) * (w + padding) + padding
+        grid[:, y:y + h, x:x + w] = t[i]
+    return grid
 
 
 class _ToTensor:
@@ -228,7 +297,8 @@ def install():
     """Install the stand-ins for whatever is missing; returns the list of module names that were shimmed."""
     done = []
     if _missing("cv2"):
-        _lazy("cv2", COLORMAP_JET=2, IMREAD_UNCHANGED=-1, COLOR_BGR2RGB=4, COLOR_RGB2BGR=4, INTER_AREA=3, INTER_LINEAR=1)
+        _lazy("cv2", COLORMAP_JET=2, IMREAD_UNCHANGED=-1, COLOR_BGR2RGB=4, COLOR_RGB2BGR=4, INTER_AREA=3, INTER_LINEAR=1,
+              applyColorMap=_apply_color_map)
         done.append("cv2")
     if _missing("loguru"):
         log = types.SimpleNamespace(**{k: (lambda *a, **kw: None) for k in
@@ -241,11 +311,13 @@ def install():
     if _missing("torchvision"):
         tv = _lazy("torchvision")
         _lazy("torchvision.transforms", Compose=_Compose, ToTensor=_ToTensor)
-        _lazy("torchvision.utils")
+        _lazy("torchvision.utils", make_grid=_make_grid)
         tv.__path__ = []
         done.append("torchvision")
     if _missing("imageio"):
-        _lazy("imageio", imwrite=_imwrite, imsave=_imwrite)
+        io = _lazy("imageio", imwrite=_imwrite, imsave=_imwrite, imread=_imread, mimsave=_mimsave, mimwrite=_mimsave)
+        io.__path__ = []
+        _lazy("imageio.v2", imwrite=_imwrite, imread=_imread, mimsave=_mimsave)
         done.append("imageio")
     if _missing("plyfile"):
         _lazy("plyfile", PlyData=None, PlyElement=None)
@@ -257,7 +329,7 @@ def install():
         _lazy("skimage.metrics")
         done.append("skimage")
     if _missing("lpips"):
-        _lazy("lpips")
+        _lazy("lpips", LPIPS=_NoLPIPS)
         done.append("lpips")
     if _missing("configargparse"):
         _module("configargparse", ArgumentParser=ConfigArgumentParser, ArgParser=ConfigArgumentParser,

@@ -100,3 +100,22 @@ def make_rays(h, w, cam_z=4.0, fov=0.6911, narrow=0.45, device="cpu"):
     d = d / torch.linalg.norm(d, dim=-1, keepdim=True)
     o = torch.tensor([0.0, 0.0, cam_z]).expand_as(d)
     return torch.cat([o, d], dim=-1).contiguous().to(device)
+
+
+HDR_NAMES = ("bridge", "city", "fireplace", "forest", "night")       # the maps scripts/relight_importance.py:361 asks for
+
+
+def make_hdr_maps(names=HDR_NAMES, H=1024, W=2048, seed=71):
+    """Seeded HDR environment maps (exp(N(0, 1.5^2)) low-pass filtered + one 100x sun disc each) -- there are no
+    *.hdr files offline.  ``Environment_Light("synthetic:h=32,w=64")`` builds them for HDR_NAMES."""
+    gen = torch.Generator().manual_seed(seed)
+    maps = {}
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    for i, name in enumerate(names):
+        hdr = torch.exp(torch.randn(max(H // 8, 2), max(W // 8, 2), 3, generator=gen) * 1.5)
+        hdr = torch.nn.functional.interpolate(hdr.permute(2, 0, 1)[None], size=(H, W), mode="bilinear",
+                                              align_corners=False)[0].permute(1, 2, 0).contiguous()
+        cy, cx, rad = (200 + 100 * i) * H // 1024, 300 * (i + 1) * W // 2048, max(20 * H // 1024, 1)
+        hdr[((yy - cy) ** 2 + (xx - cx) ** 2) < rad ** 2] *= 100.0
+        maps[name] = hdr
+    return maps

@@ -32,7 +32,8 @@ def is_synthetic(root_dir):
 
 class SyntheticDataset(torch.utils.data.Dataset):
     def __init__(self, root_dir, hdr_dir=None, split="train", random_test=False, N_vis=-1, downsample=1.0, sub=0,
-                 light_rotation=("000",), light_name="sunset", light_name_list=None, is_stack=False, **unused):
+                 light_rotation=("000",), light_name="sunset", light_name_list=None, is_stack=False, light_names=None,
+                 **unused):
         spec = parse_spec(root_dir)
         self.split = split
         self.N_vis = N_vis
@@ -42,6 +43,8 @@ class SyntheticDataset(torch.utils.data.Dataset):
         self.scene_bbox = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]]) * downsample
         self.light_name = light_name
         names = light_name_list if light_name_list else list(light_rotation or ["000"])
+        if light_names:          # the relighting test split (dataLoader/tensoIR_relighting_test.py:15-25): one G.T. image per map
+            names = self.light_names = list(light_names)
         self.light_rotation = [str(r) for r in names]
         self.light_num = len(self.light_rotation)
         self.lights_probes = None

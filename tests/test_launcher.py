@@ -21,8 +21,9 @@ CFG = os.path.join(ROOT, "tests", "data", "synthetic_train.txt")
 HAVE_REF = os.path.isfile(os.path.join(REF, "train_tensoIR.py"))
 
 
-SCRIPTS = {     # script -> edits of the synthetic config (the three training entry points of the reference)
+SCRIPTS = {     # script -> edits of the synthetic config (the four training entry points of the reference)
     "train_tensoIR.py": {},
+    "train_tensoIR_simple.py": {"dataset_name": "tensoIR_simple", "hdrdir": None},
     "train_tensoIR_rotated_multi_lights.py": {"light_rotation": "[000, 120, 240]"},
     "train_tensoIR_general_multi_lights.py": {"light_rotation": None, "light_name_list": "[sunset, snow, courtyard]",
                                               "dataset_name": "tensoIR_unknown_general_multi_lights"},
@@ -123,6 +124,29 @@ def test_unmodified_train_script_reaches_first_kernel_call(tmp_path, script):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not HAVE_REF, reason="reference checkout not present on this box")
+def test_unmodified_train_script_with_evaluation_loops(tmp_path, monkeypatch):
+    """The same run with the reference's evaluation loops on (renderer.py:135-519): `evaluation_iter_TensoIR` at
+    iteration 139 (N_vis views) and over the whole test split after training (render_test, test_all=True incl.
+    compute_rescale_ratio, SSIM, image dumps); every chunk goes through our Renderer_TensoIR_train."""
+    monkeypatch.setitem(SCRIPTS, "train_tensoIR.py", {"render_test": "1", "N_vis": "2", "vis_every": "140"})
+    r = run_script(tmp_path, script="train_tensoIR.py")
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    run = os.path.join(str(tmp_path), "synth_run")
+    assert os.path.isfile(os.path.join(run, "imgs_vis", "nvs_with_brdf", "000139_000.png")), os.listdir(run)
+    assert os.path.isdir(os.path.join(run, "imgs_test_all"))
+    assert "test all: nvs psnr" in out
+    # --render_only on the checkpoint just written (render_test(), train_tensoIR.py:62-108): torch.load of a file that carries
+    # the occupancy mask as numpy bytes, TensorVMSplit(**kwargs).load(ckpt), evaluation over the test split
+    ck = os.path.join(run, "synth_run.th")
+    r = run_script(tmp_path, script="train_tensoIR.py", extra=["--ckpt", ck, "--render_only", "1"])
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    assert "PSNRs_rgb_brdf_test" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not HAVE_REF, reason="reference checkout not present on this box")
 @pytest.mark.parametrize("script", list(SCRIPTS))
 def test_unmodified_train_script_runs_end_to_end(tmp_path, script):
     """150 iterations of the unmodified train_tensoIR.py on the HIP path: updateAlphaMask + shrink at 60 (relighting
@@ -135,3 +159,48 @@ def test_unmodified_train_script_runs_end_to_end(tmp_path, script):
     assert os.path.isfile(ck)
     ckpt = torch.load(ck, map_location="cpu", weights_only=False)
     assert "alphaMask.aabb" in ckpt and ckpt["kwargs"]["gridSize"][0] > 32
+
+
+# ---- scripts/relight_importance.py (BASELINE configs[4]: the caller of SURVEY row a20 / a17), unmodified ----------------
+def run_relight_script(tmp_path):
+    """A random-init blob field saved in the reference's checkpoint format, the analytic relighting test split
+    (one G.T. image per environment map) and seeded HDR maps: `python -m tensoir_amd.run <TensoIR>/scripts/relight_importance.py`."""
+    from tensoir_amd import synth
+    ck = os.path.join(str(tmp_path), "blob.th")
+    torch.save(synth.make_checkpoint(grid=(48, 48, 48)), ck)
+    edits = {"dataset_name": "tensoIR_relighting_test", "datadir": "synthetic:views=3,res=32", "hdrdir": "synthetic:h=16,w=32",
+             "ckpt": ck, "geo_buffer_path": os.path.join(str(tmp_path), "relight"), "batch_size": "512"}
+    lines = [l for l in open(CFG).read().splitlines() if l.split("=")[0].strip() not in edits]
+    lines += [f"{k} = {v}" for k, v in edits.items()]
+    cfg = os.path.join(str(tmp_path), "relight.txt")
+    with open(cfg, "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "tensoir_amd.run", os.path.join(REF, "scripts", "relight_importance.py"), "--config", cfg]
+    return subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=1200), edits
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="reference checkout not present")
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-box check (the GPU variant runs the loop)")
+def test_unmodified_relight_script_reaches_first_kernel_call(tmp_path):
+    r, _ = run_relight_script(tmp_path)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0
+    assert "Environment_Light" in out and "TensoirHipError" in out, out[-3000:]      # checkpoint loaded, model built, light tables next
+    assert "ModuleNotFoundError" not in out and "ImportError" not in out and "TypeError" not in out
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not HAVE_REF, reason="reference checkout not present on this box")
+def test_unmodified_relight_script_runs_end_to_end(tmp_path):
+    """The unmodified relighting script on the HIP path: primary pass, Environment_Light.sample_light, compute_transmittance
+    (tir_march_secondary_fwd), GGX_specular, get_light; five maps x 512 importance samples per surface point, PNGs + PSNR file."""
+    r, edits = run_relight_script(tmp_path)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    view = os.path.join(edits["geo_buffer_path"], "test_000")
+    for name in ("bridge", "city", "fireplace", "forest", "night"):
+        assert os.path.isfile(os.path.join(view, "relighting_without_bg", f"{name}.png"))
+        assert os.path.isfile(os.path.join(view, "relighting_with_bg", f"{name}.png"))
+    txt = open(os.path.join(edits["geo_buffer_path"], "relight_psnr.txt")).read()
+    assert txt.count("PSNR") == 5 and "PSNR nan" not in txt and "PSNR inf" not in txt

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box visit with the staged reference checkout (tools/stage_reference.sh): the three unmodified training scripts end to
+# One GPU-box visit with the staged reference checkout (tools/stage_reference.sh): the unmodified training / evaluation / relighting scripts end to
 # end on the HIP path, then oracle/ref_on_gpu.py (reference on the host cores, reference on the MI355X as on-device oracle,
 # mask maintenance, C5 at 400^3).  Usage (via gpurun): tools/ref_round.sh <tag> [extra ref_on_gpu.py flags]  -> gpurun_out/<tag>_*
 set -u
