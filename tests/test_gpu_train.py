@@ -406,7 +406,7 @@ def _check_training_step(env, m, sc, relight, t_stop, min_checked, normal_gt=Non
         torch.rand = orig_rand
         torch.set_rng_state(state)
     loss = O.training_loss(ret, gt.cuda(), relight)
-    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-5
     for k in ("rgb_map", "acc_map", "depth_map") + (("rgb_with_brdf_map", "normal_map", "albedo_map", "normals_diff_map",
                                                      "normals_orientation_loss_map") if relight else ()):
         assert float((ret[k].detach().cpu() - ret_ref[k]).abs().max()) < 1e-4, k
