@@ -42,6 +42,13 @@ def install(reference_root: str):
     if reference_root not in sys.path:
         sys.path.insert(0, reference_root)
     done = {}
+    _host_threads()
+    if os.environ.get("TENSOIR_LAUNCH_MODE", "hip") == "reference":
+        # A/B aid (tools/script_head_to_head.sh): the same launcher, stand-ins and analytic dataset, but NOTHING rebound --
+        # the script runs the reference's own PyTorch implementation (on the GPU through PyTorch-ROCm, or on the host)
+        synth_dataset.wrap_dataset_dict(importlib.import_module("dataLoader").dataset_dict, device=None)
+        _allow_numpy_in_checkpoints()
+        return done
     for name, symbols in PATCHES.items():
         m = importlib.import_module(name)
         for s in symbols:
@@ -65,6 +72,20 @@ def install(reference_root: str):
     synth_dataset.wrap_dataset_dict(importlib.import_module("dataLoader").dataset_dict, device=dev)
     _allow_numpy_in_checkpoints()
     return done
+
+
+def _host_threads():
+    """The training loop's host side is a handful of tiny CPU tensor ops per iteration (three 4096-row gathers from the ray
+    table, train_tensoIR.py:240-242).  PyTorch sizes its OpenMP team to the core count; on a 128-core / 256-thread MI355X host
+    every such op then costs ~2 ms of team start-up (measured: 36.8 ms per iteration of the unmodified script against 8.7 ms
+    with 8 threads, 7.6 ms of it GPU work; profiles/r03_script_head_to_head.json).  Unless the user chose a thread count
+    (OMP_NUM_THREADS / TENSOIR_HOST_THREADS=0 keeps PyTorch's default) the launcher uses 8."""
+    if "OMP_NUM_THREADS" in os.environ:
+        return
+    n = int(os.environ.get("TENSOIR_HOST_THREADS", "8"))
+    if n > 0:
+        import torch
+        torch.set_num_threads(min(n, os.cpu_count() or n))
 
 
 def _allow_numpy_in_checkpoints():
