@@ -33,7 +33,34 @@ def run(mode, ref, cfg, script, timeout, host_threads=None):
         if m:
             marks.setdefault(int(m.group(2)), (float(m.group(1)), float(m.group(3)), float(m.group(4))))
     tail = open(log, errors="replace").read()[-1500:]
-    return {"mode": mode, "rc": rc, "wall_s": round(wall, 2), "marks": marks, "log_tail": tail if rc else ""}
+    return {"mode": mode, "rc": rc, "wall_s": round(wall, 2), "marks": marks, "log_tail": tail if rc else "", "dir": tmp}
+
+
+def render(mode, ref, cfg, script, ckpt, timeout, host_threads=None):
+    """`--render_only 1 --render_test 1 --ckpt <ckpt>` (render_test(), train_tensoIR.py:62-108): the reference's evaluation loop
+    over the test split; seconds per image from its own "test i / N" lines, metrics from its final prints."""
+    tmp = tempfile.mkdtemp(prefix=f"h2h_render_{mode}_")
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), TENSOIR_LAUNCH_MODE=mode,
+               PYTHONUNBUFFERED="1")
+    if host_threads is not None:
+        env["TENSOIR_HOST_THREADS"] = str(host_threads)
+    log = os.path.join(tmp, "log.txt")
+    cmd = (f"{sys.executable} -u -m tensoir_amd.run {os.path.join(ref, script)} --config {cfg} --basedir {tmp} --ckpt {ckpt} "
+           f"--render_only 1 --render_test 1 2>&1 | {sys.executable} {os.path.join(ROOT, 'tools', 'stamp.py')} > {log}")
+    rc = subprocess.run(["bash", "-c", f"set -o pipefail; timeout {timeout} {cmd}"], env=env, cwd=tmp).returncode
+    text = open(log, errors="replace").read()
+    marks = [(float(m.group(1)), int(m.group(2))) for m in re.finditer(r"^\s*([0-9.]+) test (\d+) / \d+", text, re.M)]
+    out = {"mode": mode, "rc": rc, "images": len(marks)}
+    if len(marks) >= 2:
+        out["s_per_image"] = round((marks[-1][0] - marks[0][0]) / (marks[-1][1] - marks[0][1]), 4)
+    for key in ("PSNRs_test", "PSNRs_rgb_brdf_test", "MAE_test", "PSNR_albedo_three"):
+        m = re.search(rf"{key}: (.*)", text)
+        if m:
+            nums = [float(x) for x in re.findall(r"-?\d+\.\d+(?:e-?\d+)?", m.group(1))]
+            out[key] = round(sum(nums) / len(nums), 4) if nums else None
+    if rc:
+        out["log_tail"] = text[-1500:]
+    return out
 
 
 def phase(marks, a, b):
@@ -49,6 +76,7 @@ def main():
     p.add_argument("--script", default="train_tensoIR.py")
     p.add_argument("--modes", nargs="+", default=["hip", "reference"])
     p.add_argument("--timeout", type=int, default=900)
+    p.add_argument("--render", type=int, default=1, help="also run --render_only on the hip run's checkpoint in every mode")
     p.add_argument("--host-threads", default=None, help="TENSOIR_HOST_THREADS for both modes (0 = PyTorch's default team)")
     a = p.parse_args()
     ref = os.environ.get("TENSOIR_REFERENCE", "/root/reference")
@@ -67,6 +95,18 @@ def main():
         r["last_progress"] = {"iteration": last, "train_rgb_psnr": marks[last][1], "train_rgb_brdf_psnr": marks[last][2]} if marks else None
         res[mode] = r
         print(json.dumps({mode: r})[:1200], flush=True)
+    if a.render and "hip" in res:
+        # the checkpoint the HIP run wrote, rendered by BOTH implementations: same file format, comparable metrics
+        expname = re.search(r"^expname\s*=\s*(\S+)", open(a.config).read(), re.M).group(1)
+        ckpt = os.path.join(res["hip"]["dir"], expname, f"{expname}.th")
+        res["render_test"] = {"checkpoint": "written by the hip training run above", "note": "seconds per image of the reference's "
+                              "evaluation loop (renderer.py:135-519: chunked renderer calls, 10 D2H copies per chunk, SSIM, PNG "
+                              "dumps), test split of the analytic dataset"}
+        for mode in a.modes:
+            res["render_test"][mode] = render(mode, ref, a.config, a.script, ckpt, a.timeout, a.host_threads)
+            print(json.dumps(res["render_test"][mode])[:800], flush=True)
+    for mode in a.modes:
+        res.get(mode, {}).pop("dir", None)
     if "hip" in res and "reference" in res:
         res["speedup"] = {k: (round(res["reference"]["ms_per_iteration"][k] / res["hip"]["ms_per_iteration"][k], 2)
                               if res["reference"]["ms_per_iteration"][k] and res["hip"]["ms_per_iteration"][k] else None)
