@@ -109,6 +109,76 @@ def test_synthetic_dataset_interface():
     assert isinstance(d["x"]("/data/lego", "none"), Real)
 
 
+def test_image_and_metric_stand_ins(tmp_path):
+    """What the evaluation / relighting scripts additionally touch (renderer.py:443-452, :507-514; relight_importance.py:246,
+    :296-303; utils.py:30, :74): PNG write + read back, frame stacks, the depth colour map, make_grid, and LPIPS = NaN offline."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from tensoir_amd import shims; shims.install()\n"
+            "import numpy as np, torch, imageio, imageio.v2, cv2, lpips, torchvision.utils as vutils\n"
+            "a = (np.arange(6 * 5 * 4).reshape(6, 5, 4) %% 256).astype(np.uint8)\n"
+            "imageio.imwrite(%r + '/a.png', a); assert (imageio.v2.imread(%r + '/a.png') == a).all()\n"
+            "imageio.imwrite(%r + '/m.png', a[:, :, :1]); assert imageio.imread(%r + '/m.png').shape == (6, 5)\n"
+            "imageio.mimsave(%r + '/v.mp4', np.stack([a[:, :, :3], a[:, :, :3] // 2]), fps=24, quality=8)\n"
+            "from PIL import Image; im = Image.open(%r + '/v.mp4'); assert getattr(im, 'n_frames', 1) == 2\n"
+            "c = cv2.applyColorMap(np.array([[0, 128, 255]], np.uint8), cv2.COLORMAP_JET)\n"
+            "assert c.shape == (1, 3, 3) and c.dtype == np.uint8 and c[0, 0, 0] > c[0, 0, 2] and c[0, 2, 2] > c[0, 2, 0]   # BGR: blue -> red\n"
+            "g = vutils.make_grid(torch.arange(3 * 3 * 2 * 2, dtype=torch.float32).view(3, 3, 2, 2), padding=0, normalize=True, value_range=(0, 255))\n"
+            "assert tuple(g.shape) == (3, 2, 6) and float(g.max()) <= 1 and abs(float(g[0, 0, 2]) - 12 / 255) < 1e-6\n"
+            "import warnings; warnings.simplefilter('ignore'); m = lpips.LPIPS(net='alex', version='0.1').eval().to('cpu')\n"
+            "v = m(torch.zeros(3, 4, 4), torch.zeros(3, 4, 4), normalize=True).item(); assert v != v\n"
+            "print('ok')\n") % ((ROOT,) + (str(tmp_path),) * 6)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_relighting_split_and_synthetic_hdr_maps():
+    from tensoir_amd import synth
+    from tensoir_amd.synth_dataset import SyntheticDataset
+    names = ["bridge", "city", "night"]
+    ds = SyntheticDataset("synthetic:views=6,res=16", "synthetic:h=16,w=32", split="test", random_test=False, downsample=1.0,
+                          light_names=names, light_rotation=["000"])
+    assert ds.light_names == names and len(ds) == 2 and ds.img_wh == (16, 16)
+    item = ds[0]
+    assert item["rgbs"].shape == (3, 256, 3) and item["rgbs_mask"].shape == (256, 1) and item["albedo"].shape == (256, 3)
+    maps = synth.make_hdr_maps(synth.HDR_NAMES, 16, 32)
+    assert list(maps) == ["bridge", "city", "fireplace", "forest", "night"]
+    again = synth.make_hdr_maps(synth.HDR_NAMES, 16, 32)
+    assert all(m.shape == (16, 32, 3) and float(m.min()) > 0 and torch.equal(m, again[k]) for k, m in maps.items())
+    assert float(maps["bridge"].max()) > 20 * float(maps["bridge"].median())          # the sun disc
+
+
+def test_launcher_host_thread_cap(monkeypatch):
+    from tensoir_amd import run
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+        monkeypatch.setenv("TENSOIR_HOST_THREADS", "2")
+        run._host_threads()
+        assert torch.get_num_threads() == min(2, os.cpu_count())
+        torch.set_num_threads(before)
+        monkeypatch.setenv("TENSOIR_HOST_THREADS", "0")
+        run._host_threads()
+        assert torch.get_num_threads() == before
+        monkeypatch.setenv("OMP_NUM_THREADS", "3")
+        monkeypatch.setenv("TENSOIR_HOST_THREADS", "2")
+        run._host_threads()
+        assert torch.get_num_threads() == before                            # an explicit OMP_NUM_THREADS wins
+    finally:
+        torch.set_num_threads(before)
+
+
+def test_checkpoints_with_numpy_payload_load_by_default(tmp_path):
+    """TensoIR checkpoints carry np.packbits bytes (tensorBase_rotated_lights.py:681); the scripts' bare torch.load must take them."""
+    import numpy as np
+    from tensoir_amd import run
+    ck = os.path.join(str(tmp_path), "c.th")
+    torch.save({"kwargs": {"gridSize": [4, 4, 4]}, "alphaMask.mask": np.packbits(np.ones(64, bool)), "alphaMask.shape": (4, 4, 4),
+                "state_dict": {"w": torch.ones(2)}}, ck)
+    run._allow_numpy_in_checkpoints()
+    got = torch.load(ck, map_location="cpu")
+    assert got["alphaMask.mask"].dtype == np.uint8 and got["alphaMask.mask"].sum() == 8 * 255
+
+
 @pytest.mark.skipif(not HAVE_REF, reason="reference checkout not present")
 @pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-box check (the GPU variant runs the loop)")
 @pytest.mark.parametrize("script", list(SCRIPTS))
