@@ -123,6 +123,16 @@ def _to_device(ds, device):
     return ds
 
 
+def _light_defaults(cls):
+    import inspect
+    try:
+        params = inspect.signature(cls.__init__).parameters
+    except (TypeError, ValueError):
+        return {}
+    return {k: p.default for k, p in params.items()
+            if k in ("light_name_list", "light_rotation", "light_names", "light_name") and p.default is not inspect.Parameter.empty}
+
+
 def wrap_dataset_dict(dataset_dict, device=None):
     """Every entry keeps its reference class for real data directories and builds the analytic dataset when
     ``datadir`` starts with ``synthetic``.  device (e.g. 'cuda'): training splits are moved to that device once."""
@@ -131,6 +141,10 @@ def wrap_dataset_dict(dataset_dict, device=None):
             continue
 
         def factory(root_dir, *a, _cls=cls, **k):
+            if is_synthetic(root_dir):
+                # a caller that leaves the light set to the class default (render_test() of the general multi-light script,
+                # train_tensoIR_general_multi_lights.py:74) gets THAT reference class's default, not ours
+                k = {**_light_defaults(_cls), **k}
             ds = SyntheticDataset(root_dir, *a, **k) if is_synthetic(root_dir) else _cls(root_dir, *a, **k)
             if device is not None and k.get("split", "train") == "train":
                 _to_device(ds, device)

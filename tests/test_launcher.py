@@ -25,7 +25,7 @@ SCRIPTS = {     # script -> edits of the synthetic config (the four training ent
     "train_tensoIR.py": {},
     "train_tensoIR_simple.py": {"dataset_name": "tensoIR_simple", "hdrdir": None},
     "train_tensoIR_rotated_multi_lights.py": {"light_rotation": "[000, 120, 240]"},
-    "train_tensoIR_general_multi_lights.py": {"light_rotation": None, "light_name_list": "[sunset, snow, courtyard]",
+    "train_tensoIR_general_multi_lights.py": {"light_name_list": "[sunset, snow, courtyard]",        # + light_rotation = [000], as configs/multi_light_general/*.txt
                                               "dataset_name": "tensoIR_unknown_general_multi_lights"},
 }
 
@@ -107,6 +107,13 @@ def test_synthetic_dataset_interface():
     d = wrap_dataset_dict({"x": Real})
     assert isinstance(d["x"]("synthetic:views=1,res=8", "none"), SyntheticDataset)
     assert isinstance(d["x"]("/data/lego", "none"), Real)
+
+    class General:                       # dataLoader/tensoIR_general_multi_lights.py:16-26: the light set defaults in the class
+        def __init__(self, root_dir, hdr_dir, split="train", light_name_list=["sunset", "snow", "courtyard"], **temp):
+            pass
+    g = wrap_dataset_dict({"g": General})["g"]("synthetic:views=3,res=8", "none", split="test")
+    assert g.light_num == 3 and g[0]["rgbs"].shape == (3, 64, 3)
+    assert wrap_dataset_dict({"g": General})["g"]("synthetic:views=3,res=8", "none", light_name_list=["a"]).light_num == 1
 
 
 def test_image_and_metric_stand_ins(tmp_path):

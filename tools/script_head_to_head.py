@@ -78,11 +78,21 @@ def main():
     p.add_argument("--timeout", type=int, default=900)
     p.add_argument("--render", type=int, default=1, help="also run --render_only on the hip run's checkpoint in every mode")
     p.add_argument("--host-threads", default=None, help="TENSOIR_HOST_THREADS for both modes (0 = PyTorch's default team)")
+    p.add_argument("--set", nargs="*", default=[], metavar="KEY=VALUE", help="config edits (VALUE 'none' drops the key), e.g. "
+                   "light_rotation='[000, 120, 240]' for train_tensoIR_rotated_multi_lights.py")
     a = p.parse_args()
+    if a.set:
+        edits = dict(kv.split("=", 1) for kv in a.set)
+        lines = [l for l in open(a.config).read().splitlines() if l.split("=")[0].strip() not in edits]
+        lines += [f"{k} = {v}" for k, v in edits.items() if v.lower() != "none"]
+        fd, path = tempfile.mkstemp(prefix="h2h_cfg_", suffix=".txt")
+        with os.fdopen(fd, "w") as fh:
+            fh.write("\n".join(lines) + "\n")
+        a.base_config, a.config = a.config, path
     ref = os.environ.get("TENSOIR_REFERENCE", "/root/reference")
     if not os.path.isfile(os.path.join(ref, a.script)):
         raise SystemExit("no reference checkout (TENSOIR_REFERENCE)")
-    res = {"config": os.path.relpath(a.config, ROOT), "script": a.script,
+    res = {"config": os.path.relpath(getattr(a, "base_config", a.config), ROOT), "config_edits": a.set, "script": a.script,
            "phases": {"radiance_only_128^3": [10, 40], "relight_210^3..260^3": [110, 190], "relight_300^3": [210, 390]},
            "host_threads": a.host_threads if a.host_threads is not None else "launcher default (8)", "host_cpus": os.cpu_count(),
            "note": "ms per training iteration of the UNMODIFIED script (data sampling, forward, losses, backward, Adam, "
