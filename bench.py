@@ -796,10 +796,13 @@ def bench_train(a):
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    mem0 = torch.cuda.memory_allocated(device)
+    torch.cuda.reset_peak_memory_stats(device)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         l1 = step()
     torch.cuda.synchronize()
+    mem1, mem_peak = torch.cuda.memory_allocated(device), torch.cuda.max_memory_allocated(device)
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -866,6 +869,9 @@ def bench_train(a):
                                    f"gradients per step ({state['buckets']} buckets)" if use_dist else "single GPU",
                        "records_per_step": A, "launch": "eager; weight-gradient leaves on a second HIP stream"},
             "it_per_s": round(a.steps / elapsed, 2), "loss_first": l0, "loss_last": float(l1.detach()),
+            "device_memory_MB": {"allocated_before_timed_steps": round(mem0 / 2**20, 1), "allocated_after": round(mem1 / 2**20, 1),
+                                 "peak_during": round(mem_peak / 2**20, 1), "note": "torch caching allocator, this rank; equal "
+                                 "before / after over --steps steps = no per-step growth (run with --steps 3000 as a soak)"},
             "world_size": (dist.get_world_size() if use_dist else 1), "device_count": torch.cuda.device_count(),
             "backend": a.backend if use_dist else None, "per_rank_ms_per_step": [round(1e3 * x, 4) for x in per_rank],
             "roofline": roofline, "roofline_weight_gradients": wgrad, "cpu_baseline": cpu, "parity": parity,
