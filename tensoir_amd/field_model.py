@@ -210,6 +210,19 @@ def compute_energy(lgtSGs):
     return mu * 2.0 * np.pi / lam * (1.0 - torch.exp(-2.0 * lam))
 
 
+# constructor arguments of the reference class that are kept verbatim as attributes (models/tensorBase_rotated_lights.py:343-403)
+_PLAIN_CTOR_ARGS = ("app_dim", "alphaMask", "device", "density_shift", "alphaMask_thres", "distance_scale", "rayMarch_weight_thres",
+                    "fea2denseAct", "near_far", "step_ratio", "shadingMode", "normals_kind", "pos_pe", "view_pe", "fea_pe",
+                    "featureC", "envmap_w", "envmap_h", "dataset", "light_kind", "numLgtSGs", "fixed_fresnel")
+# what a checkpoint's 'kwargs' entry carries (:646-673): checkpoint key -> attribute
+_CKPT_KWARGS = {"density_n_comp": "density_n_comp", "appearance_n_comp": "app_n_comp", "app_dim": "app_dim",
+                "density_shift": "density_shift", "alphaMask_thres": "alphaMask_thres", "distance_scale": "distance_scale",
+                "rayMarch_weight_thres": "rayMarch_weight_thres", "fea2denseAct": "fea2denseAct", "near_far": "near_far",
+                "step_ratio": "step_ratio", "shadingMode": "shadingMode", "pos_pe": "pos_pe", "view_pe": "view_pe",
+                "fea_pe": "fea_pe", "featureC": "featureC", "normals_kind": "normals_kind", "light_num": "light_num",
+                "light_kind": "light_kind", "numLgtSGs": "numLgtSGs", "light_rotation": "light_rotation"}
+
+
 class TensorVMSplit(nn.Module):
     """TensorVMSplit (models/tensoRF_rotated_lights.py:6) on top of TensorBase
     (models/tensorBase_rotated_lights.py:343-403): same kwargs, same state_dict."""
@@ -222,43 +235,22 @@ class TensorVMSplit(nn.Module):
                  envmap_w=32, envmap_h=16, light_kind="pixel", dataset=None, numLgtSGs=128,
                  fixed_fresnel=0.04, march_t_stop=1e-6, **kwargs):
         super().__init__()
-        if isinstance(density_n_comp, int):
-            density_n_comp = [density_n_comp] * 3
-        if isinstance(appearance_n_comp, int):
-            appearance_n_comp = [appearance_n_comp] * 3
-        self.density_n_comp = list(density_n_comp)
-        self.app_n_comp = list(appearance_n_comp)
-        self.app_dim = app_dim
+        given = locals()
+        for name in _PLAIN_CTOR_ARGS:               # stored under their own names (what get_kwargs() hands back)
+            setattr(self, name, given[name])
+        as_triple = lambda c: [c] * 3 if isinstance(c, int) else list(c)
+        self.density_n_comp, self.app_n_comp = as_triple(density_n_comp), as_triple(appearance_n_comp)
         self.aabb = torch.as_tensor(aabb, dtype=torch.float32).to(device)
-        self.alphaMask = alphaMask
-        self.device = device
-        self.density_shift = density_shift
-        self.alphaMask_thres = alphaMask_thres
-        self.distance_scale = distance_scale
-        self.rayMarch_weight_thres = rayMarch_weight_thres
-        self.fea2denseAct = fea2denseAct
-        self.near_far = near_far
-        self.step_ratio = step_ratio
-        self.shadingMode, self.normals_kind = shadingMode, normals_kind
-        self.pos_pe, self.view_pe, self.fea_pe, self.featureC = pos_pe, view_pe, fea_pe, featureC
-        self.light_num = len(light_rotation)
         self.light_rotation = [int(r) for r in light_rotation]
-        self.envmap_w, self.envmap_h = envmap_w, envmap_h
-        self.dataset = dataset
-        self.light_kind = light_kind
-        self.numLgtSGs = numLgtSGs
-        self.fixed_fresnel = fixed_fresnel
+        self.light_num = len(self.light_rotation)
         # transmittance below which a primary / secondary ray stops marching (error in acc, vis and gradients < this;
         # the reference marches every ray to the end: march_t_stop=0 reproduces that exactly)
         self.march_t_stop = float(march_t_stop)
-        self.matMode = MAT_MODE
-        self.vecMode = VEC_MODE
-        self.comp_w = [1, 1, 1]
-        self._field_cache = None
-        self._field_key = None
+        self.matMode, self.vecMode, self.comp_w = MAT_MODE, VEC_MODE, [1, 1, 1]
+        self._field_cache = self._field_key = None
         self.update_stepSize(gridSize)
-        self.init_svd_volume(gridSize[0], device)
-        self.init_render_func(shadingMode, pos_pe, view_pe, fea_pe, featureC, device)
+        self.init_svd_volume(gridSize[0], device)           # same construction order as the reference: seeded runs draw
+        self.init_render_func(shadingMode, pos_pe, view_pe, fea_pe, featureC, device)      # the same initial parameters
         self.init_light()
 
     # ---- construction ----------------------------------------------------------------------------
@@ -293,42 +285,52 @@ class TensorVMSplit(nn.Module):
         self.renderModule_brdf = MLPBRDF_PEandFeature(self.app_dim, pos_pe, fea_pe, featureC, outc=4,
                                                       act_net=nn.Sigmoid()).to(device)
 
+    @staticmethod
+    def _equirect_cells(rows, cols, row_hi, row_step):
+        """Cell centres of a rows x cols equirect grid: the row coordinate runs row_hi - step/2 .. -row_hi + step/2, the azimuth
+        pi - lng/2 .. -pi + lng/2 (the reference's orientation, models/tensorBase_rotated_lights.py:437-441)."""
+        lng = 2 * np.pi / cols
+        return torch.meshgrid([torch.linspace(row_hi - 0.5 * row_step, -row_hi + 0.5 * row_step, rows),
+                               torch.linspace(np.pi - 0.5 * lng, -np.pi + 0.5 * lng, cols)], indexing="ij") + (lng,)
+
+    @staticmethod
+    def _unit_dirs(phi, theta):
+        return torch.stack([torch.cos(theta) * torch.cos(phi), torch.sin(theta) * torch.cos(phi), torch.sin(phi)], dim=-1)
+
     def generate_envir_map_dir(self, envmap_h, envmap_w, is_jittor=False):
-        """models/tensorBase_rotated_lights.py:435-453 (host side, tiny)."""
+        """models/tensorBase_rotated_lights.py:435-453 (host side, tiny): solid-angle weights (sum 4 pi) and unit directions of the
+        envmap_h x envmap_w cells, optionally jittered uniformly inside each cell (elevation drawn first, as the reference does)."""
         lat = np.pi / envmap_h
-        lng = 2 * np.pi / envmap_w
-        phi, theta = torch.meshgrid([torch.linspace(np.pi / 2 - 0.5 * lat, -np.pi / 2 + 0.5 * lat, envmap_h),
-                                     torch.linspace(np.pi - 0.5 * lng, -np.pi + 0.5 * lng, envmap_w)], indexing="ij")
+        phi, theta, lng = self._equirect_cells(envmap_h, envmap_w, np.pi / 2, lat)
         sin_phi = torch.sin(torch.pi / 2 - phi)
-        light_area_weight = 4 * torch.pi * sin_phi / torch.sum(sin_phi)
-        assert 0 not in light_area_weight, "There shouldn't be light pixel that doesn't contribute"
-        light_area_weight = light_area_weight.to(torch.float32).reshape(-1)
+        weights = 4 * torch.pi * sin_phi / torch.sum(sin_phi)
+        assert 0 not in weights, "every cell of the light grid must have a solid angle"
         if is_jittor:
-            pj, tj = lat * (torch.rand_like(phi) - 0.5), lng * (torch.rand_like(theta) - 0.5)
-            phi, theta = phi + pj, theta + tj
-        view_dirs = torch.stack([torch.cos(theta) * torch.cos(phi), torch.sin(theta) * torch.cos(phi),
-                                 torch.sin(phi)], dim=-1).view(-1, 3)
-        return light_area_weight, view_dirs
+            phi = phi + lat * (torch.rand_like(phi) - 0.5)
+            theta = theta + lng * (torch.rand_like(theta) - 0.5)
+        return weights.to(torch.float32).reshape(-1), self._unit_dirs(phi, theta).view(-1, 3)
 
     def init_light(self):
-        """models/tensorBase_rotated_lights.py:455-488."""
+        """models/tensorBase_rotated_lights.py:455-488: the fixed direction grid, the z-rotation of every light and the trainable
+        light -- 128 spherical Gaussians (lobe axis 3, sharpness 1, amplitude 3) or the pixel image."""
         self.light_area_weight, self.fixed_viewdirs = self.generate_envir_map_dir(self.envmap_h, self.envmap_w)
         if self.light_kind not in ("sg", "pixel"):
             raise NotImplementedError(f"light_kind={self.light_kind!r}: 'sg' and 'pixel' have gfx950 kernels")
         self._light_rotations()
         if self.light_kind == "pixel":       # :459-460: a learnable envmap_h x envmap_w image behind softplus(beta=5)
-            nlights = self.envmap_w * self.envmap_h
-            self._light_rgbs = nn.Parameter(torch.FloatTensor(nlights, 3).uniform_(0, 3).to(torch.float32).to(self.device))
+            cells = self.envmap_w * self.envmap_h
+            self._light_rgbs = nn.Parameter(torch.FloatTensor(cells, 3).uniform_(0, 3).to(torch.float32).to(self.device))
             return
-        self.lgtSGs = nn.Parameter(torch.randn(self.numLgtSGs, 7), requires_grad=True)
-        self.lgtSGs.data[:, -2:] = self.lgtSGs.data[:, -3:-2].expand((-1, 2))
-        self.lgtSGs.data[:, 3:4] = 10.0 + torch.abs(self.lgtSGs.data[:, 3:4] * 20.0)
-        energy = compute_energy(self.lgtSGs.data)
-        self.lgtSGs.data[:, 4:] = torch.abs(self.lgtSGs.data[:, 4:]) / torch.sum(energy, dim=0, keepdim=True) * 2.0 * np.pi * 0.8
-        lobes = fibonacci_sphere(self.numLgtSGs // 2).astype(np.float32)
-        self.lgtSGs.data[:self.numLgtSGs // 2, :3] = torch.from_numpy(lobes)
-        self.lgtSGs.data[self.numLgtSGs // 2:, :3] = torch.from_numpy(lobes)
-        self.lgtSGs.data = self.lgtSGs.data.to(self.device)
+        n = self.numLgtSGs
+        sg = torch.randn(n, 7)                                   # the ONE random draw (seeded runs match the reference's)
+        sg[:, 5:] = sg[:, 4:5].expand(-1, 2)                     # grey amplitudes
+        sg[:, 3:4] = 10.0 + torch.abs(sg[:, 3:4] * 20.0)         # sharpness >= 10
+        amplitude = torch.abs(sg[:, 4:])
+        sg[:, 4:] = amplitude / torch.sum(compute_energy(sg), dim=0, keepdim=True) * 2.0 * np.pi * 0.8    # total energy 1.6 pi
+        lobes = torch.from_numpy(fibonacci_sphere(n // 2).astype(np.float32))
+        sg[:n // 2, :3] = lobes                                  # two Gaussians per Fibonacci direction
+        sg[n // 2:, :3] = lobes
+        self.lgtSGs = nn.Parameter(sg.to(self.device), requires_grad=True)
 
     def _light_rotations(self):
         """:479-487: one z-rotation matrix per light."""
@@ -343,22 +345,16 @@ class TensorVMSplit(nn.Module):
         """models/tensorBase_rotated_lights.py:492-574 (host-side direction tables)."""
         if method == "fixed_envirmap":
             dirs = self.fixed_viewdirs
-        elif method == "stratified_sampling":
-            lat, lng = np.pi / self.envmap_h, 2 * np.pi / self.envmap_w
-            pb, tb = torch.meshgrid([torch.linspace(np.pi / 2 - 0.5 * lat, -np.pi / 2 + 0.5 * lat, self.envmap_h),
-                                     torch.linspace(np.pi - 0.5 * lng, -np.pi + 0.5 * lng, self.envmap_w)], indexing="ij")
-            pj, tj = lat * (torch.rand_like(pb) - 0.5), lng * (torch.rand_like(tb) - 0.5)
-            phi, theta = pb + pj, tb + tj
-            dirs = torch.stack([torch.cos(theta) * torch.cos(phi), torch.sin(theta) * torch.cos(phi),
-                                torch.sin(phi)], dim=-1)
-        elif method == "stratifed_sample_equal_areas":
-            sps, lng = 2 / self.envmap_h, 2 * np.pi / self.envmap_w
-            sb, tb = torch.meshgrid([torch.linspace(1 - 0.5 * sps, -1 + 0.5 * sps, self.envmap_h),
-                                     torch.linspace(np.pi - 0.5 * lng, -np.pi + 0.5 * lng, self.envmap_w)], indexing="ij")
-            sj, tj = sps * (torch.rand_like(sb) - 0.5), lng * (torch.rand_like(tb) - 0.5)
-            phi, theta = torch.asin(sb + sj), tb + tj
-            dirs = torch.stack([torch.cos(theta) * torch.cos(phi), torch.sin(theta) * torch.cos(phi),
-                                torch.sin(phi)], dim=-1)
+        elif method == "stratified_sampling":                   # one uniform draw inside every cell of the grid
+            lat = np.pi / self.envmap_h
+            phi, theta, lng = self._equirect_cells(self.envmap_h, self.envmap_w, np.pi / 2, lat)
+            phi = phi + lat * (torch.rand_like(phi) - 0.5)
+            dirs = self._unit_dirs(phi, theta + lng * (torch.rand_like(theta) - 0.5))
+        elif method == "stratifed_sample_equal_areas":         # rows uniform in sin(elevation): equal-area cells
+            band = 2 / self.envmap_h
+            sin_phi, theta, lng = self._equirect_cells(self.envmap_h, self.envmap_w, 1.0, band)
+            sin_phi = sin_phi + band * (torch.rand_like(sin_phi) - 0.5)
+            dirs = self._unit_dirs(torch.asin(sin_phi), theta + lng * (torch.rand_like(theta) - 0.5))
         elif method == "importance_sample":
             _, view_dirs = self.generate_envir_map_dir(128, 256, is_jittor=True)
             envir_map = self.get_light_rgbs(view_dirs.reshape(-1, 3).to(device), device=device)[0]
@@ -401,13 +397,14 @@ class TensorVMSplit(nn.Module):
         return cached[1]
 
     def update_stepSize(self, gridSize):
-        """models/tensorBase_rotated_lights.py:608-619."""
-        self.aabbSize = self.aabb[1] - self.aabb[0]
-        self.invaabbSize = 2.0 / self.aabbSize
+        """models/tensorBase_rotated_lights.py:608-619: voxel size, march step (step_ratio mean voxels) and the number of samples
+        that covers the box diagonal."""
+        extent = self.aabb[1] - self.aabb[0]
+        self.aabbSize, self.invaabbSize = extent, 2.0 / extent
         self.gridSize = torch.LongTensor([int(g) for g in gridSize]).to(self.device)
-        self.units = self.aabbSize / (self.gridSize - 1)
+        self.units = extent / (self.gridSize - 1)
         self.stepSize = torch.mean(self.units) * self.step_ratio
-        self.aabbDiag = torch.sqrt(torch.sum(torch.square(self.aabbSize)))
+        self.aabbDiag = torch.sqrt(torch.sum(torch.square(extent)))
         self.nSamples = int((self.aabbDiag / self.stepSize).item()) + 1
         self._field_key = None
 
@@ -440,35 +437,31 @@ class TensorVMSplit(nn.Module):
         return list(getattr(self, "lgtSGs_list", None) or [self.lgtSGs])
 
     def vectorDiffs(self, vector_comps):
+        """Mean |off-diagonal| of every line factor's Gram matrix (models/tensoRF_rotated_lights.py:59-69)."""
         total = 0
-        for idx in range(len(vector_comps)):
-            n_comp, n_size = vector_comps[idx].shape[1:-1]
-            v = vector_comps[idx].view(n_comp, n_size)
-            dotp = torch.matmul(v, v.transpose(-1, -2))
-            non_diag = dotp.view(-1)[1:].view(n_comp - 1, n_comp + 1)[..., :-1]
-            total = total + torch.mean(torch.abs(non_diag))
+        for comp in vector_comps:
+            v = comp.view(comp.shape[1], comp.shape[2])
+            gram = v @ v.t()
+            n = gram.shape[0]
+            off_diag = gram.flatten()[1:].view(n - 1, n + 1)[:, :-1]         # drops the diagonal of an n x n matrix
+            total = total + off_diag.abs().mean()
         return total
 
     def vector_comp_diffs(self):
         return self.vectorDiffs(self.density_line) + self.vectorDiffs(self.app_line)
 
     def density_L1(self):
+        """:74-78.  (Summed in the reference's order: fp32 addition is not associative and the loss is logged.)"""
         total = 0
-        for idx in range(len(self.density_plane)):
-            total = total + torch.mean(torch.abs(self.density_plane[idx])) + torch.mean(torch.abs(self.density_line[idx]))
+        for plane, line in zip(self.density_plane, self.density_line):
+            total = total + plane.abs().mean() + line.abs().mean()
         return total
 
     def TV_loss_density(self, reg):
-        total = 0
-        for idx in range(len(self.density_plane)):
-            total = total + reg(self.density_plane[idx]) * 1e-2
-        return total
+        return sum((reg(plane) * 1e-2 for plane in self.density_plane), 0)
 
     def TV_loss_app(self, reg):
-        total = 0
-        for idx in range(len(self.app_plane)):
-            total = total + reg(self.app_plane[idx]) * 1e-2
-        return total
+        return sum((reg(plane) * 1e-2 for plane in self.app_plane), 0)
 
     # ---- packed shadow of the parameters -----------------------------------------------------------
     def _field_params(self):
@@ -625,32 +618,28 @@ class TensorVMSplit(nn.Module):
     def sample_ray(self, rays_o, rays_d, is_train=True, N_samples=-1):
         """models/tensorBase_rotated_lights.py:705-724 (kept for filtering_rays; the march kernels
         generate the same samples on the fly and never materialise them)."""
-        N_samples = N_samples if N_samples > 0 else self.nSamples
-        near, far = self.near_far
-        vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
-        rate_a = (self.aabb[1] - rays_o) / vec
-        rate_b = (self.aabb[0] - rays_o) / vec
-        t_min = torch.minimum(rate_a, rate_b).amax(-1).clamp(min=near, max=far)
-        rng = torch.arange(N_samples)[None].float()
-        if is_train:
-            rng = rng.repeat(rays_d.shape[-2], 1)
-            rng += torch.rand_like(rng[:, [0]])
-        step = self.stepSize * ops.to_device(rng, rays_o.device)
-        interpx = t_min[..., None] + step
-        rays_pts = rays_o[..., None, :] + rays_d[..., None, :] * interpx[..., None]
-        mask_outbbox = ((self.aabb[0] > rays_pts) | (rays_pts > self.aabb[1])).any(dim=-1)
-        return rays_pts, interpx, ~mask_outbbox
+        n = N_samples if N_samples > 0 else self.nSamples
+        safe_d = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+        t_enter = torch.minimum((self.aabb[1] - rays_o) / safe_d, (self.aabb[0] - rays_o) / safe_d).amax(-1)
+        t_enter = t_enter.clamp(min=self.near_far[0], max=self.near_far[1])
+        k = torch.arange(n)[None].float()
+        if is_train:                                            # one jitter per ray, shared by all of its samples
+            k = k.repeat(rays_d.shape[-2], 1)
+            k += torch.rand_like(k[:, [0]])
+        z = t_enter[..., None] + self.stepSize * ops.to_device(k, rays_o.device)
+        pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., None]
+        inside = ~((self.aabb[0] > pts) | (pts > self.aabb[1])).any(dim=-1)
+        return pts, z, inside
 
     # ---- resolution changes (models/tensoRF_rotated_lights.py:227-288) ---------------------------------
     @torch.no_grad()
     def up_sampling_VM(self, plane_coef, line_coef, res_target):
-        for i in range(3):
-            vec_id = self.vecMode[i]
-            m0, m1 = self.matMode[i]
-            plane_coef[i] = nn.Parameter(channel_last(F.interpolate(plane_coef[i].data, size=(res_target[m1], res_target[m0]),
-                                                                    mode="bilinear", align_corners=True)))
-            line_coef[i] = nn.Parameter(channel_last(F.interpolate(line_coef[i].data, size=(res_target[vec_id], 1),
-                                                                   mode="bilinear", align_corners=True)))
+        """Bilinear (align_corners) resampling of every factor to res_target; the results are channel-last parameters."""
+        def resized(t, size):
+            return nn.Parameter(channel_last(F.interpolate(t.data, size=size, mode="bilinear", align_corners=True)))
+        for i, ((m0, m1), v) in enumerate(zip(self.matMode, self.vecMode)):
+            plane_coef[i] = resized(plane_coef[i], (res_target[m1], res_target[m0]))
+            line_coef[i] = resized(line_coef[i], (res_target[v], 1))
         return plane_coef, line_coef
 
     @torch.no_grad()
@@ -662,55 +651,43 @@ class TensorVMSplit(nn.Module):
 
     @torch.no_grad()
     def shrink(self, new_aabb):
-        xyz_min, xyz_max = new_aabb
-        t_l, b_r = (xyz_min - self.aabb[0]) / self.units, (xyz_max - self.aabb[0]) / self.units
-        t_l, b_r = torch.round(torch.round(t_l)).long(), torch.round(b_r).long() + 1
-        b_r = torch.stack([b_r, self.gridSize]).amin(0)
-        for i in range(3):
-            mode0 = self.vecMode[i]
-            self.density_line[i] = nn.Parameter(channel_last(self.density_line[i].data[..., t_l[mode0]:b_r[mode0], :]))
-            self.app_line[i] = nn.Parameter(channel_last(self.app_line[i].data[..., t_l[mode0]:b_r[mode0], :]))
-            mode0, mode1 = self.matMode[i]
-            self.density_plane[i] = nn.Parameter(channel_last(self.density_plane[i].data[..., t_l[mode1]:b_r[mode1], t_l[mode0]:b_r[mode0]]))
-            self.app_plane[i] = nn.Parameter(channel_last(self.app_plane[i].data[..., t_l[mode1]:b_r[mode1], t_l[mode0]:b_r[mode0]]))
+        """Crop every factor to the voxel range covering new_aabb (models/tensoRF_rotated_lights.py:254-288).  When the occupancy
+        grid and the field grid differ, the box actually kept is the one spanned by the cropped voxel range (:277-285)."""
+        first = torch.round(torch.round((new_aabb[0] - self.aabb[0]) / self.units)).long()
+        last = torch.minimum(torch.round((new_aabb[1] - self.aabb[0]) / self.units).long() + 1, self.gridSize)      # exclusive
+        keep = [slice(int(a), int(b)) for a, b in zip(first, last)]              # per world axis
+        cropped = lambda t: nn.Parameter(channel_last(t))
+        for i, ((m0, m1), v) in enumerate(zip(self.matMode, self.vecMode)):
+            for lines, planes in ((self.density_line, self.density_plane), (self.app_line, self.app_plane)):
+                lines[i] = cropped(lines[i].data[..., keep[v], :])                 # [1, C, R, 1]
+                planes[i] = cropped(planes[i].data[..., keep[m1], keep[m0]])       # [1, C, grid[m1], grid[m0]]
         if not torch.all(self.alphaMask.gridSize == self.gridSize):
-            t_l_r, b_r_r = t_l / (self.gridSize - 1), (b_r - 1) / (self.gridSize - 1)
-            correct_aabb = torch.zeros_like(new_aabb)
-            correct_aabb[0] = (1 - t_l_r) * self.aabb[0] + t_l_r * self.aabb[1]
-            correct_aabb[1] = (1 - b_r_r) * self.aabb[0] + b_r_r * self.aabb[1]
-            new_aabb = correct_aabb
-        newSize = b_r - t_l
+            lo_frac, hi_frac = first / (self.gridSize - 1), (last - 1) / (self.gridSize - 1)
+            lo, hi = self.aabb[0], self.aabb[1]
+            new_aabb = torch.stack([(1 - lo_frac) * lo + lo_frac * hi, (1 - hi_frac) * lo + hi_frac * hi]).to(new_aabb.dtype)
         self.aabb = new_aabb
-        self.update_stepSize((newSize[0], newSize[1], newSize[2]))
+        self.update_stepSize(tuple(last - first))
 
     # ---- checkpoint I/O (models/tensorBase_rotated_lights.py:646-692) ---------------------------------
     def get_kwargs(self):
-        return {
-            "aabb": self.aabb, "gridSize": self.gridSize.tolist(), "density_n_comp": self.density_n_comp,
-            "appearance_n_comp": self.app_n_comp, "app_dim": self.app_dim, "density_shift": self.density_shift,
-            "alphaMask_thres": self.alphaMask_thres, "distance_scale": self.distance_scale,
-            "rayMarch_weight_thres": self.rayMarch_weight_thres, "fea2denseAct": self.fea2denseAct,
-            "near_far": self.near_far, "step_ratio": self.step_ratio, "shadingMode": self.shadingMode,
-            "pos_pe": self.pos_pe, "view_pe": self.view_pe, "fea_pe": self.fea_pe, "featureC": self.featureC,
-            "normals_kind": self.normals_kind, "light_num": self.light_num, "light_kind": self.light_kind,
-            "numLgtSGs": self.numLgtSGs, "light_rotation": self.light_rotation,
-        }
+        return {"aabb": self.aabb, "gridSize": self.gridSize.tolist(), **{k: getattr(self, a) for k, a in _CKPT_KWARGS.items()}}
 
     def save(self, path):
+        """The reference's file layout: kwargs + state_dict + the occupancy volume as packed bits (:675-683)."""
         ckpt = {"kwargs": self.get_kwargs(), "state_dict": self.state_dict()}
         if self.alphaMask is not None:
-            alpha_volume = self.alphaMask.alpha_volume.bool().cpu().numpy()
-            ckpt.update({"alphaMask.shape": alpha_volume.shape})
-            ckpt.update({"alphaMask.mask": np.packbits(alpha_volume.reshape(-1))})
-            ckpt.update({"alphaMask.aabb": self.alphaMask.aabb.cpu()})
+            occupied = self.alphaMask.alpha_volume.bool().cpu().numpy()
+            ckpt["alphaMask.shape"] = occupied.shape
+            ckpt["alphaMask.mask"] = np.packbits(occupied.reshape(-1))
+            ckpt["alphaMask.aabb"] = self.alphaMask.aabb.cpu()
         torch.save(ckpt, path)
 
     def load(self, ckpt):
-        if "alphaMask.aabb" in ckpt.keys():
-            length = int(np.prod(ckpt["alphaMask.shape"]))
-            alpha_volume = torch.from_numpy(np.unpackbits(ckpt["alphaMask.mask"])[:length].reshape(ckpt["alphaMask.shape"]))
+        if "alphaMask.aabb" in ckpt:
+            shape = tuple(ckpt["alphaMask.shape"])
+            bits = np.unpackbits(ckpt["alphaMask.mask"])[:int(np.prod(shape))]
             self.alphaMask = AlphaGridMask(self.device, ckpt["alphaMask.aabb"].to(self.device),
-                                           alpha_volume.float().to(self.device))
+                                           torch.from_numpy(bits.reshape(shape)).float().to(self.device))
         self.load_state_dict(ckpt["state_dict"])
         self._field_key = None
 
