@@ -1413,6 +1413,248 @@ k_mlp_wgrad(TirWgradJobs jobs, int fstride, int64_t n) {
     }
 }
 
+// ---- the same products with the operand rows staged through LDS, double buffered -------------------------------------------
+// The direct-load kernel above exposes one memory latency per 16-row step (its 128-register budget has no room to prefetch),
+// and every dz row is fetched by two wave groups.  Here half of the workgroup (the waves with registers to spare) fetches the NEXT step's 16 rows of
+// dz1, dz2, h1, h2 (coalesced float4 loads), features, dz3 and aux into registers while the waves work on the current
+// step out of LDS, then park them in the other buffer: one barrier per step, each row read from L2 / HBM once per workgroup,
+// LDS addresses are immediates (no 64-bit address arithmetic in the loop).  Row strides 132 / 36 floats: the two half-waves
+// of an operand read (rows r and r + 8) land 32 banks apart.
+constexpr int WL_LD = 132, WL_LDF = 36;
+// a staged row of `feat` is [0..31] the feature row as stored (27 used), [32..34] the row's aux triple, [35] zero
+struct WgStage { float dz1[16 * WL_LD], dz2[16 * WL_LD], h1[16 * WL_LD], h2[16 * WL_LD], feat[16 * WL_LDF], dz3[16 * 4]; };
+struct WlXCol { int off; float mul, phase; };        // mul == 0: the raw value at `off`; else sin(2 pi (mul x + phase))
+
+__device__ __forceinline__ WlXCol wl_xcol(int c) {
+    const WgXCol x = wg_xcol(c);
+    WlXCol r;
+    r.off = x.zero ? 35 : (x.is_aux ? 32 + x.off : x.off);
+    r.mul = (x.zero || !x.is_pe) ? 0.0f : x.mul;
+    r.phase = x.phase;
+    return r;
+}
+constexpr int WL_XCOLS = 160;                          // X column descriptors (3 floats each) live behind the two stages
+constexpr int WL_LDS_BYTES = 2 * (int)sizeof(WgStage) + WL_XCOLS * 3 * (int)sizeof(float);
+
+struct WgFetch { float4 z1, z2, a1, a2; };
+
+// The fetching is done by the waves with registers to spare while they compute: the 512 threads of wave groups 2 and 3 (two
+// accumulator tiles, no X columns) bring in the four [16][128] operands, u = threadIdx.x - 512; the 256 threads of group 1
+// (two X tiles + the small dW2 tile) the feature rows, dz3 and the aux triples, u1 = threadIdx.x - 256.  Rows >= r1 read as 0.
+// Uniform 64-bit row bases + one 32-bit lane offset: scalar-base addressing, no per-lane 64-bit arithmetic.
+__device__ __forceinline__ WgFetch wl_fetch(const TirWgradJob& jb, int64_t s0, int64_t r1, int u) {
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    WgFetch f{zero, zero, zero, zero};
+    const unsigned row = (unsigned)u >> 5, o = row * HID + 4u * ((unsigned)u & 31u);
+    if ((int64_t)row < r1 - s0) {
+        f.z1 = *reinterpret_cast<const float4*>(jb.dz1 + s0 * HID + o);
+        f.z2 = *reinterpret_cast<const float4*>(jb.dz2 + s0 * HID + o);
+        f.a1 = *reinterpret_cast<const float4*>(jb.h1 + s0 * HID + o);
+        f.a2 = *reinterpret_cast<const float4*>(jb.h2 + s0 * HID + o);
+    }
+    return f;
+}
+
+__device__ __forceinline__ void wl_park(WgStage& st, const WgFetch& f, int u) {
+    const int o = (u >> 5) * WL_LD + 4 * (u & 31);
+    *reinterpret_cast<float4*>(st.dz1 + o) = f.z1;
+    *reinterpret_cast<float4*>(st.dz2 + o) = f.z2;
+    *reinterpret_cast<float4*>(st.h1 + o) = f.a1;
+    *reinterpret_cast<float4*>(st.h2 + o) = f.a2;
+}
+
+// ai = the aux row of an aux-role thread (looked up one step earlier)
+__device__ __forceinline__ float4 wl_fetch_side(const TirWgradJob& jb, int fstride, int64_t s0, int64_t r1, int ai, int u1) {
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int left = (int)min((int64_t)16, r1 - s0);
+    if (u1 < 128) {
+        const unsigned fr = (unsigned)u1 >> 3;
+        if ((int)fr < left) c = *reinterpret_cast<const float4*>(jb.feat + s0 * fstride + (fr * (unsigned)fstride + 4u * ((unsigned)u1 & 7u)));
+    } else if (u1 < 144) {
+        if (u1 - 128 < left) c = *reinterpret_cast<const float4*>(jb.dz3 + s0 * 4 + 4u * (unsigned)(u1 - 128));
+    } else if (u1 < 192) {
+        const int q = u1 - 144;
+        if (q / 3 < left) c.x = jb.aux[3 * (int64_t)ai + q % 3];
+    }
+    return c;
+}
+
+__device__ __forceinline__ void wl_park_side(WgStage& st, const float4& c, int u1) {
+    if (u1 < 128) *reinterpret_cast<float4*>(st.feat + (u1 >> 3) * WL_LDF + 4 * (u1 & 7)) = c;
+    else if (u1 < 144) *reinterpret_cast<float4*>(st.dz3 + (u1 - 128) * 4) = c;
+    else if (u1 < 192) st.feat[((u1 - 144) / 3) * WL_LDF + 32 + (u1 - 144) % 3] = c.x;
+}
+
+// rows 8h .. 8h+7 of column col of a staged [16][WL_LD] operand
+__device__ __forceinline__ void wl_col8(const float* __restrict__ m, int col, int h, float (&v)[8]) {
+    const float* b = m + 8 * h * WL_LD + col;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = b[j * WL_LD];
+}
+
+// column descriptor c is re-read from the LDS table every step: three registers per column for the duration of its eight
+// values instead of nine held across the loop (the 3-tile wave groups sit exactly at the 128-register budget)
+__device__ __forceinline__ void wl_x8(const float* __restrict__ xtab, int c, const WgStage& st, int h, float (&v)[8]) {
+    const float c_hi = 0.15915493667125702f, c_lo = 6.4206382432985265e-09f;      // c_hi + c_lo = 1 / (2 pi), see pe_pair
+    const int off = __float_as_int(xtab[3 * c]);
+    const float mul = xtab[3 * c + 1], phase = xtab[3 * c + 2];
+    const float* src = st.feat + 8 * h * WL_LDF + off;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float b = src[j * WL_LDF];
+        const float k = rintf(b * c_hi);
+        float t = fmaf(b, c_hi, -k);
+        t = fmaf(b, c_lo, t);
+        const float pe = __builtin_amdgcn_sinf(fmaf(t, mul, phase));
+        v[j] = mul == 0.0f ? b : pe;
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void wl_step(const WgStage& st, const float* __restrict__ xtab, int mt, int li, int h, f32x16 (&acc)[3], float& bias) {
+    float v[8];
+    bf16x8 ah, al;
+    if (G <= 1) {
+        wl_col8(st.dz1, mt * 32 + li, h, v);
+        if (G == 0) bias += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        split8(v, ah, al);
+        constexpr int NX = (G == 0) ? 3 : 2;
+        bf16x8 bh[NX], bl[NX];
+#pragma unroll
+        for (int t = 0; t < NX; ++t) {
+            float x[8];
+            wl_x8(xtab, (G == 0 ? t : 3 + t) * 32 + li, st, h, x);
+            split8(x, bh[t], bl[t]);
+        }
+        f32x16 (&a)[NX] = reinterpret_cast<f32x16 (&)[NX]>(acc);
+        wg_mma<NX>(ah, al, bh, bl, a);
+        if (G == 1) {
+            float z[8], y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] = li < 4 ? st.dz3[(8 * h + j) * 4 + li] : 0.0f;
+            bias += ((z[0] + z[1]) + (z[2] + z[3])) + ((z[4] + z[5]) + (z[6] + z[7]));
+            wl_col8(st.h2, mt * 32 + li, h, y);
+            bf16x8 zh, zl, yh[1], yl[1];
+            split8(z, zh, zl);
+            split8(y, yh[0], yl[0]);
+            f32x16 (&a2)[1] = reinterpret_cast<f32x16 (&)[1]>(acc[2]);
+            wg_mma<1>(zh, zl, yh, yl, a2);
+        }
+    } else {
+        wl_col8(st.dz2, mt * 32 + li, h, v);
+        if (G == 2) bias += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        split8(v, ah, al);
+        bf16x8 bh[2], bl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float y[8];
+            wl_col8(st.h1, (2 * (G - 2) + t) * 32 + li, h, y);
+            split8(y, bh[t], bl[t]);
+        }
+        f32x16 (&a)[2] = reinterpret_cast<f32x16 (&)[2]>(acc);
+        wg_mma<2>(ah, al, bh, bl, a);
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void wl_path(const TirWgradJob& jb, int fstride, WgStage* stage, int mt, int li, int h, int64_t r0, int64_t r1) {
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    float* xtab = reinterpret_cast<float*>(stage + 2);
+    float bias = 0.0f;
+    if (threadIdx.x < 32) stage[threadIdx.x >> 4].feat[(threadIdx.x & 15) * WL_LDF + 35] = 0.0f;      // the zero column of both buffers
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + WL_XCOLS) {
+        const WlXCol x = wl_xcol((int)threadIdx.x - 64);
+        float* e = xtab + 3 * ((int)threadIdx.x - 64);
+        e[0] = __int_as_float(x.off); e[1] = x.mul; e[2] = x.phase;
+    }
+    // aux rows are looked up through aux_map: the index of step k + 2 is fetched while step k + 1's data is, so the dependent
+    // load never sits inside one step's window
+    constexpr bool FETCH = G >= 2, SIDE = G == 1;
+    const int u = (int)threadIdx.x - 512, u1 = (int)threadIdx.x - 256;
+    const bool aux_role = SIDE && u1 >= 144 && u1 < 192;
+    const int arow = aux_role ? (u1 - 144) / 3 : 0;
+    auto aux_index = [&](int64_t s0) -> int {              // rows < 2^31 (checked by the launcher)
+        const int64_t s = s0 + arow;
+        if (!aux_role || s >= r1) return 0;
+        return jb.aux_map ? jb.aux_map[s] : (int)s;
+    };
+    int ai = 0, ai_next = 0;
+    WgFetch f;
+    float4 side;
+    if (FETCH) {
+        f = wl_fetch(jb, r0, r1, u);
+        wl_park(stage[0], f, u);
+    }
+    if (SIDE) {
+        ai = aux_index(r0); ai_next = aux_index(r0 + 16);
+        side = wl_fetch_side(jb, fstride, r0, r1, ai, u1);
+        wl_park_side(stage[0], side, u1);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int64_t kb = r0; kb < r1; kb += 16) {
+        const bool more = kb + 16 < r1;
+        if (FETCH && more) f = wl_fetch(jb, kb + 16, r1, u);
+        if (SIDE && more) {
+            ai = ai_next;
+            ai_next = aux_index(kb + 32);
+            side = wl_fetch_side(jb, fstride, kb + 16, r1, ai, u1);
+        }
+        wl_step<G>(stage[cur], xtab, mt, li, h, acc, bias);
+        if (FETCH && more) wl_park(stage[cur ^ 1], f, u);
+        if (SIDE && more) wl_park_side(stage[cur ^ 1], side, u1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const int row0 = mt * 32 + 4 * h;
+    if (G == 0) {
+#pragma unroll
+        for (int t2 = 0; t2 < 3; ++t2) wg_flush(acc[t2], jb.dW0, IN, row0, HID, t2 * 32 + li, IN);
+    } else if (G == 1) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) wg_flush(acc[t2], jb.dW0, IN, row0, HID, (3 + t2) * 32 + li, IN);
+        wg_flush(acc[2], jb.dW2, HID, 4 * h, 4, mt * 32 + li, HID);
+    } else {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) wg_flush(acc[t2], jb.dW1, HID, row0, HID, (2 * (G - 2) + t2) * 32 + li, HID);
+    }
+    if (G != 3) {
+        bias += __shfl_xor(bias, 32, 64);
+        if (h == 0) {
+            if (G == 0) wg_atomic(jb.db0 + mt * 32 + li, bias);
+            if (G == 2) wg_atomic(jb.db1 + mt * 32 + li, bias);
+            if (G == 1 && mt == 0 && li < 4) wg_atomic(jb.db2 + li, bias);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+k_mlp_wgrad_lds(TirWgradJobs jobs, int fstride, int64_t n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wl_lds[];
+    WgStage* stage = reinterpret_cast<WgStage*>(wl_lds);
+    const int per = (int)gridDim.x / jobs.n_jobs;
+    const int ji = (int)blockIdx.x / per;
+    if (ji >= jobs.n_jobs) return;
+    const TirWgradJob& jb = jobs.j[ji];
+    const int bid = (int)blockIdx.x - ji * per;
+    int64_t chunk = (n + per - 1) / per;
+    chunk = (chunk + 15) / 16 * 16;
+    const int64_t r0 = (int64_t)bid * chunk, r1 = min(n, r0 + chunk);
+    if (r0 >= r1) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5, mt = w & 3;
+    switch (w >> 2) {
+        case 0: wl_path<0>(jb, fstride, stage, mt, li, h, r0, r1); break;
+        case 1: wl_path<1>(jb, fstride, stage, mt, li, h, r0, r1); break;
+        case 2: wl_path<2>(jb, fstride, stage, mt, li, h, r0, r1); break;
+        default: wl_path<3>(jb, fstride, stage, mt, li, h, r0, r1); break;
+    }
+}
+
 int check_mlp(const TirMlp* m) {
     if (!m || !m->packed) return TIR_ERR_ARG;
     if (m->feat_dim != F || m->pe != PE || m->hidden != HID || m->out_dim < 1 || m->out_dim > 4)
@@ -1735,7 +1977,13 @@ extern "C" int tir_mlp_wgrad_multi(const float* const* dz1s, const float* const*
     if (per < 1) per = 1;
     const int64_t steps = (n + 15) / 16;
     if (steps < per) per = (int)steps;
-    hipLaunchKernelGGL(k_mlp_wgrad, dim3((unsigned)(per * n_jobs)), dim3(1024), 0, tir_stream(stream), jobs, feat_stride, n);
+    if ((feat_stride & 3) || feat_stride < 32 || n >= ((int64_t)1 << 31)) {      // rows not float4-addressable: the direct-load kernel
+        hipLaunchKernelGGL(k_mlp_wgrad, dim3((unsigned)(per * n_jobs)), dim3(1024), 0, tir_stream(stream), jobs, feat_stride, n);
+    } else {
+        if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_mlp_wgrad_lds), WL_LDS_BYTES)) return rc;
+        hipLaunchKernelGGL(k_mlp_wgrad_lds, dim3((unsigned)(per * n_jobs)), dim3(1024), WL_LDS_BYTES, tir_stream(stream), jobs,
+                           feat_stride, n);
+    }
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
