@@ -929,7 +929,7 @@ def gemm_tn_small(pairs, M, N, C_out):
 
 def mlp_wgrad_multi(jobs):
     """Weight gradients of up to four decoder invocations over the same rows in ONE launch (tir_mlp_wgrad_multi): no
-    materialised input rows, no per-layer GEMM launches.  jobs: list of (dz1, dz2, dz3, h1, h2, feat [n, FEAT_STRIDE], aux,
+    materialised input rows, no per-layer GEMM launches.  jobs: list of (dz1, dz2, dz3, h1, h2, feat [n, stride >= 27; 32 = FEAT_STRIDE takes the LDS-staged kernel], aux,
     aux_map or None, dW0 [128,150], db0 [128], dW1 [128,128], db1 [128], dW2 [4,128], db2 [4]); the six outputs are
     accumulated into (zero them first; two jobs may name the same outputs)."""
     k = len(jobs)
@@ -939,8 +939,8 @@ def mlp_wgrad_multi(jobs):
     for job in jobs:
         dz1, dz2, dz3, h1, h2, feat, aux, aux_map, dW0, db0, dW1, db1, dW2, db2 = job
         feat = f32(feat, "feat")
-        if feat.shape[0] != n or feat.shape[1] != FEAT_STRIDE:
-            raise ValueError(f"mlp_wgrad_multi: every job needs [n, {FEAT_STRIDE}] feature rows")
+        if feat.shape[0] != n or feat.shape[1] < 27 or feat.shape[1] != jobs[0][5].shape[1]:
+            raise ValueError("mlp_wgrad_multi: every job needs [n, stride >= 27] feature rows of one common stride")
         for t, shape, name in ((dz1, (n, 128), "dz1"), (dz2, (n, 128), "dz2"), (dz3, (n, 4), "dz3"), (h1, (n, 128), "h1"),
                                (h2, (n, 128), "h2"), (dW0, (128, 150), "dW0"), (db0, (128,), "db0"), (dW1, (128, 128), "dW1"),
                                (db1, (128,), "db1"), (dW2, (4, 128), "dW2"), (db2, (4,), "db2")):
@@ -953,7 +953,7 @@ def mlp_wgrad_multi(jobs):
         for c, t in zip(cols, (dz1, dz2, dz3, h1, h2, feat, aux, aux_map, dW0, db0, dW1, db1, dW2, db2)):
             c.append(t)
     arr = lambda ts: (C.c_void_p * k)(*[(0 if t is None else t.data_ptr()) for t in ts])
-    _call("tir_mlp_wgrad_multi", arr(cols[0]), arr(cols[1]), arr(cols[2]), arr(cols[3]), arr(cols[4]), arr(cols[5]), FEAT_STRIDE,
+    _call("tir_mlp_wgrad_multi", arr(cols[0]), arr(cols[1]), arr(cols[2]), arr(cols[3]), arr(cols[4]), arr(cols[5]), int(jobs[0][5].shape[1]),
           arr(cols[6]), (None if null_map else arr(cols[7])), arr(cols[8]), arr(cols[9]), arr(cols[10]), arr(cols[11]),
           arr(cols[12]), arr(cols[13]), k, n, TUNE["wgrad_blocks"], _stream())
     _KEEP_ALIVE = cols          # noqa: F841  (operands stay referenced until the launch is queued)

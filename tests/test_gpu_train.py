@@ -143,8 +143,9 @@ def test_small_gemm_tn(env, n):
         assert torch.equal(Cd[:, N:].cpu(), C0[:, N:])
 
 
+@pytest.mark.parametrize("stride", [32, 29])             # 32: the LDS-staged kernel; 29 (rows not float4-addressable): direct loads
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 700, 4099, 70001])
-def test_fused_weight_gradients(env, n):
+def test_fused_weight_gradients(env, n, stride):
     """tir_mlp_wgrad_multi: dW0 = dz1^T x, dW1 = dz2^T h1, dW2 = dz3^T h2 and the three bias gradients of several decoder
     invocations in one launch, x rebuilt in registers from feat + aux (no tir_mlp_inputs buffer, no per-layer GEMM):
     against fp64 products with the oracle's input rows (models/tensorBase_rotated_lights.py:137-142, :12-17).  Ragged row
@@ -165,7 +166,7 @@ def test_fused_weight_gradients(env, n):
             dz3[:, 3] = 0.0                               # a 3-output decoder: the 4th cotangent column is zero
         h1, h2 = torch.relu(torch.randn(n, 128, generator=gen)), torch.relu(torch.randn(n, 128, generator=gen))
         feat = torch.randn(n, 27, generator=gen) * 1.5
-        fpad = torch.full((n, 32), float("nan"))          # the padding columns must never be read into a product
+        fpad = torch.full((n, stride), float("nan"))      # the padding columns must never be read into a product
         fpad[:, :27] = feat
         fpad[:, 27] = 0.0                                 # (column 27 is the forward's zero pad)
         if mapped:
