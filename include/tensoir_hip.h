@@ -224,6 +224,13 @@ int tir_mlp_aux_table(const TirMlp* m, const float* aux, int64_t n_aux, float* t
 int tir_mlp_fwd_auxtab_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* table,
                               const int32_t* aux_map, int32_t aux_mod, float* out, int64_t n, const int32_t* n_dev,
                               void* stream);
+/* The same launch for the training forward (h1, h2 [n][128] post-ReLU, as tir_mlp_train_fwd_bf16x3).  With aux_map == NULL and
+ * aux_mod == 0 the table has one row PER DECODER ROW: that is how normals_kind == 'residue_prediction' is evaluated -- its decoder
+ * MLPNormal_normal_and_PExyz (models/tensorBase_rotated_lights.py:236-262) feeds the derived normal as three more inputs of layer 1,
+ * which the caller adds to the table rows (table += n W0[:, 3:6]^T) before the launch. */
+int tir_mlp_train_fwd_auxtab_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* table,
+                                    const int32_t* aux_map, int32_t aux_mod, float* out, float* h1, float* h2, int64_t n,
+                                    const int32_t* n_dev, void* stream);
 int tir_mlp_fwd_multi_auxtab_bf16x3(const TirMlp* const* mlps, const float* const* feats, int32_t feat_stride,
                                     const float* const* auxs, const int32_t* const* aux_maps,
                                     const float* const* tables, float* const* outs, int32_t n_jobs, int64_t n,

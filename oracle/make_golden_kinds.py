@@ -47,12 +47,18 @@ def main():
     g = {"rgb_gt": npy(rgb_gt), "n_samples": np.array([S], np.int64)}
     normal_gt = torch.nn.functional.normalize(torch.randn(B, 3, generator=torch.Generator().manual_seed(SEED + 13)), dim=-1)
     g["normal_gt"] = npy(normal_gt)
-    for kind in ("purely_predicted", "purely_derived", "gt_normals"):
+    for kind in ("purely_predicted", "purely_derived", "gt_normals", "residue_prediction"):
         ckpt = golden_checkpoint(g0)
         ckpt["kwargs"]["light_rotation"] = [int(r) for r in ckpt["kwargs"]["light_rotation"]]
         ckpt["kwargs"]["normals_kind"] = kind
         if kind in ("purely_derived", "gt_normals"):      # no renderModule_normal in those configurations (:422-428)
             ckpt["state_dict"] = {k: v for k, v in ckpt["state_dict"].items() if not k.startswith("renderModule_normal")}
+        if kind == "residue_prediction":                  # MLPNormal_normal_and_PExyz: layer 1 is 153 wide (:240); seeded weights
+            gen = torch.Generator().manual_seed(SEED + 17)
+            w0 = ckpt["state_dict"]["renderModule_normal.mlp.0.weight"]
+            wide = torch.empty(w0.shape[0], w0.shape[1] + 3).uniform_(-1, 1, generator=gen) / float(w0.shape[1] + 3) ** 0.5
+            ckpt["state_dict"]["renderModule_normal.mlp.0.weight"] = wide
+            g[f"{kind}/w0_normal_decoder"] = npy(wide)
         model = build_reference_model(ref, ckpt, envh, envw)
         model.alphaMask = ref.tensorf.AlphaGridMask("cpu", torch.from_numpy(np.array(g0["scene/alpha_aabb"])), vol)
         # eval forward (the randn_like draw of :937 only feeds the smoothness losses)

@@ -353,6 +353,17 @@ def render_normal(sc, pts, feat):
     return torch.tanh(mlp3(sc.mlp_normal, mlp_input(feat, pts, sc.fea_pe, sc.pos_pe)))
 
 
+def render_normal_residue(sc, pts, derived, feat):
+    """MLPNormal_normal_and_PExyz (outc=3, tanh): models/tensorBase_rotated_lights.py:253-262, wired at :426-428 -- the
+    'residue_prediction' decoder; input order [pts, derived normal, features, PE(features), PE(pts)]."""
+    parts = [pts, derived, feat]
+    if sc.fea_pe > 0:
+        parts.append(positional_encoding(feat, sc.fea_pe))
+    if sc.pos_pe > 0:
+        parts.append(positional_encoding(pts, sc.pos_pe))
+    return torch.tanh(mlp3(sc.mlp_normal, torch.cat(parts, dim=-1)))
+
+
 # --------------------------------------------------------------------------
 # ray marching (K1, K3)
 # --------------------------------------------------------------------------
@@ -490,6 +501,12 @@ def forward_primary(sc, rays, light_idx, n_samples=-1, white_bg=True, is_relight
             elif kind == "derived_plus_predicted":
                 _, _, derived = density_grad(sc, xa)
                 pred = render_normal(sc, xa, int_f)
+                normal[app_mask] = pred
+                ndiff[app_mask] = torch.sum((pred - derived) ** 2, dim=-1, keepdim=True)
+                norient[app_mask] = torch.sum(vd[app_mask] * pred, dim=-1, keepdim=True).clamp(min=0)
+            elif kind == "residue_prediction":         # :962-968
+                _, _, derived = density_grad(sc, xa)
+                pred = render_normal_residue(sc, xa, derived, int_f)
                 normal[app_mask] = pred
                 ndiff[app_mask] = torch.sum((pred - derived) ** 2, dim=-1, keepdim=True)
                 norient[app_mask] = torch.sum(vd[app_mask] * pred, dim=-1, keepdim=True).clamp(min=0)

@@ -78,6 +78,7 @@ SIGNATURES = {
     "tir_mlp_fwd_multi_auxtab_bf16x3": (C.c_int, [P, P, I32, P, P, P, P, I32, I64, P, P]),
     "tir_mlp_aux_table": (C.c_int, [C.POINTER(TirMlp), P, I64, P, P]),
     "tir_mlp_fwd_auxtab_bf16x3": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P, P]),
+    "tir_mlp_train_fwd_auxtab_bf16x3": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, P, P, I64, P, P]),
     "tir_mlp_train_fwd_multi_bf16x3": (C.c_int, [P, P, I32, P, P, P, P, P, I32, I64, P, P]),
     "tir_mlp_fwd_bf16": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P, P]),
     "tir_mlp_fwd_valu": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P, P]),

@@ -689,13 +689,13 @@ k_mlp_bf16(const float* __restrict__ packed, const float* __restrict__ feat, int
 }
 
 // the aux-table variant (see R0A above): `table` [n_aux][128] from k_mlp_aux_table takes the place of the aux values
-template <bool VEC>
+template <bool VEC, bool SAVE = false>
 __global__ void __launch_bounds__(512)
 k_mlp_bf16_auxt(const float* __restrict__ packed, const float* __restrict__ feat, int fstride, const float* __restrict__ table,
                 const int32_t* __restrict__ aux_map, int aux_mod, float* __restrict__ out, int64_t n,
-                const int32_t* __restrict__ n_dev, int out_dim, int act) {
-    mlp_bf16_body<3, VEC, false, true>(packed, feat, fstride, table, aux_map, aux_mod, out, n, n_dev, out_dim, act, nullptr, nullptr,
-                                       (int)blockIdx.x, (int)gridDim.x);
+                const int32_t* __restrict__ n_dev, int out_dim, int act, float* __restrict__ h1o, float* __restrict__ h2o) {
+    mlp_bf16_body<3, VEC, SAVE, true>(packed, feat, fstride, table, aux_map, aux_mod, out, n, n_dev, out_dim, act, h1o, h2o,
+                                      (int)blockIdx.x, (int)gridDim.x);
 }
 
 // T[a][u] = b0[u] + sum over the 15 aux-dependent input columns of W0[u][col] x_col(aux_a): exact fp32 FMAs on the raw
@@ -1812,26 +1812,38 @@ extern "C" int tir_mlp_aux_table(const TirMlp* m, const float* aux, int64_t n_au
     return TIR_OK;
 }
 
-extern "C" int tir_mlp_fwd_auxtab_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* table,
-                                         const int32_t* aux_map, int32_t aux_mod, float* out, int64_t n, const int32_t* n_dev,
-                                         void* stream) {
+template <bool SAVE>
+static int launch_auxtab(const TirMlp* m, const float* feat, int32_t feat_stride, const float* table, const int32_t* aux_map,
+                         int32_t aux_mod, float* out, float* h1, float* h2, int64_t n, const int32_t* n_dev, void* stream) {
     int rc = check_mlp(m);
     if (rc) return rc;
-    if (n < 0 || feat_stride < F || (n > 0 && (!feat || !table || !out))) return TIR_ERR_ARG;
+    if (n < 0 || feat_stride < F || (n > 0 && (!feat || !table || !out || (SAVE && (!h1 || !h2))))) return TIR_ERR_ARG;
     if (reinterpret_cast<uintptr_t>(table) % 16 != 0) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
     const bool vec = (feat_stride % 4 == 0) && feat_stride >= F + 1 && (reinterpret_cast<uintptr_t>(feat) % 16 == 0);
-    const void* kfn = vec ? reinterpret_cast<const void*>(k_mlp_bf16_auxt<true>) : reinterpret_cast<const void*>(k_mlp_bf16_auxt<false>);
+    const void* kfn = vec ? reinterpret_cast<const void*>(k_mlp_bf16_auxt<true, SAVE>) : reinterpret_cast<const void*>(k_mlp_bf16_auxt<false, SAVE>);
     if (int r2 = tir_allow_dynamic_lds(kfn, (int)BFA_BYTES)) return r2;
     const int64_t tiles = (n + 255) / 256;
     const int grid_max = m->tune_grid > 0 ? m->tune_grid : 256;
     const unsigned grid = (unsigned)(tiles < grid_max ? tiles : grid_max);
-    if (vec) hipLaunchKernelGGL(k_mlp_bf16_auxt<true>, dim3(grid), dim3(512), (size_t)BFA_BYTES, tir_stream(stream), m->packed, feat,
-                                feat_stride, table, aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act);
-    else     hipLaunchKernelGGL(k_mlp_bf16_auxt<false>, dim3(grid), dim3(512), (size_t)BFA_BYTES, tir_stream(stream), m->packed, feat,
-                                feat_stride, table, aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act);
+    if (vec) hipLaunchKernelGGL((k_mlp_bf16_auxt<true, SAVE>), dim3(grid), dim3(512), (size_t)BFA_BYTES, tir_stream(stream), m->packed,
+                                feat, feat_stride, table, aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act, h1, h2);
+    else     hipLaunchKernelGGL((k_mlp_bf16_auxt<false, SAVE>), dim3(grid), dim3(512), (size_t)BFA_BYTES, tir_stream(stream), m->packed,
+                                feat, feat_stride, table, aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act, h1, h2);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
+}
+
+extern "C" int tir_mlp_fwd_auxtab_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* table,
+                                         const int32_t* aux_map, int32_t aux_mod, float* out, int64_t n, const int32_t* n_dev,
+                                         void* stream) {
+    return launch_auxtab<false>(m, feat, feat_stride, table, aux_map, aux_mod, out, nullptr, nullptr, n, n_dev, stream);
+}
+
+extern "C" int tir_mlp_train_fwd_auxtab_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* table,
+                                               const int32_t* aux_map, int32_t aux_mod, float* out, float* h1, float* h2,
+                                               int64_t n, const int32_t* n_dev, void* stream) {
+    return launch_auxtab<true>(m, feat, feat_stride, table, aux_map, aux_mod, out, h1, h2, n, n_dev, stream);
 }
 
 extern "C" int tir_mlp_train_fwd_multi_bf16x3(const TirMlp* const* mlps, const float* const* feats, int32_t feat_stride,

@@ -139,9 +139,9 @@ class _Decoder(nn.Module):
     """Parameter container of one 150->128->128->out MLP with the reference's module layout
     (``.mlp.{0,2,4}``), evaluated by tir_mlp_fwd."""
 
-    def __init__(self, in_chanel, pe_aux, feape, feature_c, outc, act):
+    def __init__(self, in_chanel, pe_aux, feape, feature_c, outc, act, extra_in=0):
         super().__init__()
-        self.in_mlpC = 2 * pe_aux * 3 + 2 * feape * in_chanel + 3 + in_chanel
+        self.in_mlpC = 2 * pe_aux * 3 + 2 * feape * in_chanel + 3 + in_chanel + extra_in
         self.feape = feape
         self.pe_aux = pe_aux
         self.outc = outc
@@ -162,9 +162,13 @@ class _Decoder(nn.Module):
         if key != self._key:
             if self.feape != self.pe_aux:
                 raise TensoirHipError("the gfx950 decoder kernel needs fea_pe == view_pe == pos_pe")
-            self._packed = ops.PackedMlp(self.mlp, self.in_chanel, self.feape, self._act)
+            self._packed = ops.PackedMlp(self.mlp, self.in_chanel, self.feape, self._act, w0=self.w0_std())
             self._key = key
         return self._packed
+
+    def w0_std(self):
+        """Layer-1 weights in the kernels' column order [feat, aux, PE(feat), PE(aux)] -- the module's own for these decoders."""
+        return self.mlp[0].weight
 
     def run(self, feat, aux, aux_map=None):
         _no_grad_only(type(self).__name__, feat, aux, *self.parameters())
@@ -195,6 +199,40 @@ class MLPBRDF_PEandFeature(_Decoder):
         return self.run(features, pts)
 
 
+class MLPNormal_normal_and_PExyz(_Decoder):
+    """models/tensorBase_rotated_lights.py:236-262, the normal decoder of normals_kind == 'residue_prediction': its layer 1 sees
+    [pts, derived normal, features, PE(features), PE(pts)] (153 columns).  Evaluated by the same kernels as the other decoders:
+    the 150 columns they know are handed over in their order (w0_std), and the three normal columns -- like the bias and the
+    position columns -- enter through the per-row start values of the layer-1 accumulators (ops.mlp_rows_table)."""
+
+    def __init__(self, inChanel, pospe=6, feape=6, featureC=128, outc=1, act_net=None):
+        act = 1 if isinstance(act_net, nn.Tanh) else 0
+        super().__init__(inChanel, pospe, feape, featureC, outc, act, extra_in=3)
+        self.pospe = pospe
+        self.act_net = act_net if act_net is not None else nn.Sigmoid()
+        F_, nf, na = inChanel, 2 * feape * inChanel, 2 * pospe * 3
+        # module column of every kernel-order column: features, pts, PE(features), PE(pts)
+        self.std_cols = list(range(6, 6 + F_)) + [0, 1, 2] + list(range(6 + F_, 6 + F_ + nf)) + list(range(6 + F_ + nf, 6 + F_ + nf + na))
+
+    def w0_std(self):
+        return self.mlp[0].weight.detach()[:, self.std_cols].contiguous()
+
+    def w0_normal(self):
+        return self.mlp[0].weight.detach()[:, 3:6]
+
+    def layer1_table(self, pts, normal):
+        """[n, 128]: b0 + W0[:, pts and PE(pts) columns] x(pts) + W0[:, normal columns] normal."""
+        table = ops.mlp_aux_table(self.packed(), pts)
+        return table.addmm_(normal.to(torch.float32), self.w0_normal().t())
+
+    def rows(self, pts, normal, features, n_dev=None, save_hidden=False):
+        return ops.mlp_rows_table(self.packed(), features, self.layer1_table(pts, normal), n_dev, save_hidden)
+
+    def forward(self, pts, normal, features):
+        _no_grad_only(type(self).__name__, pts, normal, features, *self.parameters())
+        return self.rows(pts, normal, features)
+
+
 def fibonacci_sphere(samples=1):
     """models/tensorBase_rotated_lights.py:49-67."""
     i = np.arange(samples, dtype=np.float64)
@@ -209,6 +247,8 @@ def compute_energy(lgtSGs):
     mu = torch.abs(lgtSGs[:, 4:])
     return mu * 2.0 * np.pi / lam * (1.0 - torch.exp(-2.0 * lam))
 
+
+NORMAL_LOSS_KINDS = ("derived_plus_predicted", "residue_prediction")     # the kinds that fill normals_diff / orientation (:953-968)
 
 # constructor arguments of the reference class that are kept verbatim as attributes (models/tensorBase_rotated_lights.py:343-403)
 _PLAIN_CTOR_ARGS = ("app_dim", "alphaMask", "device", "density_shift", "alphaMask_thres", "distance_scale", "rayMarch_weight_thres",
@@ -271,17 +311,19 @@ class TensorVMSplit(nn.Module):
         return nn.ParameterList(planes).to(device), nn.ParameterList(lines).to(device)
 
     def init_render_func(self, shadingMode, pos_pe, view_pe, fea_pe, featureC, device):
-        """models/tensorBase_rotated_lights.py:405-431.  Only the configuration every shipped config
-        uses is implemented in HIP: shadingMode 'MLP_Fea', normals 'derived_plus_predicted' /
-        'purely_predicted' / 'purely_derived'."""
+        """models/tensorBase_rotated_lights.py:405-431.  shadingMode 'MLP_Fea' (every shipped config) has gfx950 kernels; all five
+        normals kinds of opt.py:198 do."""
         if shadingMode != "MLP_Fea":
             raise NotImplementedError(f"shadingMode={shadingMode!r}: only 'MLP_Fea' has gfx950 kernels")
-        if self.normals_kind not in ("derived_plus_predicted", "purely_predicted", "purely_derived", "gt_normals"):
-            raise NotImplementedError(f"normals_kind={self.normals_kind!r} has no gfx950 kernels")
+        if self.normals_kind not in ("derived_plus_predicted", "purely_predicted", "purely_derived", "gt_normals", "residue_prediction"):
+            raise NotImplementedError(f"normals_kind={self.normals_kind!r} is not one of the reference's (opt.py:198)")
         self.renderModule = MLPRender_Fea(self.app_dim, view_pe, fea_pe, featureC).to(device)
         if self.normals_kind in ("purely_predicted", "derived_plus_predicted"):
             self.renderModule_normal = MLPBRDF_PEandFeature(self.app_dim, pos_pe, fea_pe, featureC, outc=3,
                                                             act_net=nn.Tanh()).to(device)
+        elif self.normals_kind == "residue_prediction":                      # :426-428
+            self.renderModule_normal = MLPNormal_normal_and_PExyz(self.app_dim, pos_pe, fea_pe, featureC, outc=3,
+                                                                  act_net=nn.Tanh()).to(device)
         self.renderModule_brdf = MLPBRDF_PEandFeature(self.app_dim, pos_pe, fea_pe, featureC, outc=4,
                                                       act_net=nn.Sigmoid()).to(device)
 
@@ -778,7 +820,7 @@ class TensorVMSplit(nn.Module):
                     rng_state = self._jitter_rng(dev)
                     xyz_j, intr_j = ops.vm_app_jitter(f, rec_xyz, 0.01, 0, 0, rng_state, n_dev)
                 jobs.append((pb, intr_j, xyz_j, None))
-                if self.normals_kind not in ("purely_derived", "gt_normals"):
+                if self.normals_kind in ("purely_predicted", "derived_plus_predicted"):
                     jobs.append((self.renderModule_normal.packed(), intr, rec_xyz, None))
             if ops.MLP_IMPL == "bf16x3":
                 # the decoders of the primary stage run on the same records: ONE launch, the grid split between them
@@ -792,6 +834,9 @@ class TensorVMSplit(nn.Module):
                     pred = ops.density_grad(f, rec_xyz, n_dev=n_dev)[2]
                 elif self.normals_kind == "gt_normals":
                     pred = None                        # zeros (:951-952): Renderer_TensoIR_train substitutes normal_gt
+                elif self.normals_kind == "residue_prediction":        # :962-968: the decoder also sees the derived normal
+                    derived = ops.density_grad(f, rec_xyz, n_dev=n_dev)[2]
+                    pred = self.renderModule_normal.rows(rec_xyz, derived, intr, n_dev)
                 else:
                     pred = outs[3]
                     if self.normals_kind == "derived_plus_predicted":
@@ -806,8 +851,8 @@ class TensorVMSplit(nn.Module):
                                          bg, is_relight, self.fixed_fresnel)
             if rng_state is not None:
                 rng_state[1] += 1
-        if self.normals_kind != "derived_plus_predicted" and is_relight:
-            maps[:, 16] = 0.0        # the orientation loss is only filled in the derived_plus_predicted branch (:953-960)
+        if self.normals_kind not in NORMAL_LOSS_KINDS and is_relight:
+            maps[:, 16] = 0.0        # the orientation loss is only filled in the branches that predict AND derive (:953-968)
 
         def finish():
             """True when the pass is valid; False when the record capacity overflowed (the caller re-runs)."""

@@ -55,6 +55,29 @@ def mlp_aux_table(m: "PackedMlp", aux):
 
 
 
+def mlp_rows_table(m: "PackedMlp", feat, table, n_dev=None, save_hidden=False):
+    """The split-bf16 decoder with ONE table row per decoder row (tir_mlp_[train_]fwd_auxtab_bf16x3, aux_map = NULL): `table`
+    [n, 128] carries everything of layer 1 that is not a function of the features -- bias, the aux columns and, for the
+    residue-prediction normal decoder, the derived-normal columns.  -> out, or (out, h1, h2) with save_hidden."""
+    if MLP_IMPL != "bf16x3":
+        raise NotImplementedError("per-row layer-1 tables exist for the split-bf16 decoder only (TENSOIR_MLP=bf16x3)")
+    feat = f32(feat, "feat")
+    n = feat.shape[0]
+    table = f32(table, "table", 128)
+    if table.shape[0] != n:
+        raise ValueError("table must have one row per feature row")
+    out = torch.empty((n, m.out_dim), dtype=torch.float32, device=feat.device)
+    if not save_hidden:
+        _call("tir_mlp_fwd_auxtab_bf16x3", C.byref(m.desc), _ptr(feat), feat.shape[1], _ptr(table), None, 0, _ptr(out), n,
+              _ptr(n_dev), _stream())
+        return out
+    h1 = torch.empty((n, 128), dtype=torch.float32, device=feat.device)
+    h2 = torch.empty((n, 128), dtype=torch.float32, device=feat.device)
+    _call("tir_mlp_train_fwd_auxtab_bf16x3", C.byref(m.desc), _ptr(feat), feat.shape[1], _ptr(table), None, 0, _ptr(out),
+          _ptr(h1), _ptr(h2), n, _ptr(n_dev), _stream())
+    return out, h1, h2
+
+
 def _stats_ptr(name, dev):
     if STATS is None:
         return None
@@ -221,9 +244,10 @@ def pack_mlp(w0, b0, w1, b1, w2, b2, feat_dim, pe):
 
 
 class PackedMlp:
-    def __init__(self, seq, feat_dim, pe, act):
-        """seq: the reference's nn.Sequential(Linear, ReLU, Linear, ReLU, Linear)."""
-        self.packed = pack_mlp(seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias,
+    def __init__(self, seq, feat_dim, pe, act, w0=None):
+        """seq: the reference's nn.Sequential(Linear, ReLU, Linear, ReLU, Linear); w0: layer-1 weights in the kernels' column
+        order [feat, aux, PE(feat), PE(aux)] when the module stores them differently (the residue-prediction normal decoder)."""
+        self.packed = pack_mlp(seq[0].weight if w0 is None else w0, seq[0].bias, seq[2].weight, seq[2].bias,
                                seq[4].weight, seq[4].bias, feat_dim, pe)
         self.out_dim = seq[4].weight.shape[0]
         self.desc = TirMlp(self.packed.data_ptr(), feat_dim, pe, seq[2].weight.shape[0],

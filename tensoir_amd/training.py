@@ -22,6 +22,9 @@ from . import ops
 from ._lib import TensoirHipError, TirFieldGrad
 
 
+from .field_model import NORMAL_LOSS_KINDS  # noqa: E402
+
+
 def field_param_list(model):
     """Parameters PrimaryRenderFn differentiates, in the order its backward returns their gradients."""
     ps = list(model.density_plane) + list(model.density_line) + list(model.app_plane) + list(model.app_line)
@@ -45,7 +48,7 @@ def _packed_bwd(dec):
     key = tuple((p.data_ptr(), p._version) for p in ps)
     cache = dec.__dict__.get("_bwd_cache")
     if cache is None or cache[0] != key:
-        cache = (key, ops.pack_mlp_bwd(ps[0], ps[1], ps[2], dec.in_chanel, dec.feape))
+        cache = (key, ops.pack_mlp_bwd(dec.w0_std(), ps[1], ps[2], dec.in_chanel, dec.feape))
         dec.__dict__["_bwd_cache"] = cache
     return cache[1]
 
@@ -120,7 +123,7 @@ class _LeafStream:
         self.keep.clear()
 
 
-def _decoder_backward(dec, calls, impl=None, leaf=None, bwd=None, wg=None):
+def _decoder_backward(dec, calls, impl=None, leaf=None, bwd=None, wg=None, keep_dz1=None):
     """Backward of every recorded invocation of one decoder.  Returns ([g_feat per call], 6 parameter grads).
     bwd: the (g_feat, dz1, dz2, dz3) of each call when the backward-data kernel has already run (merged launch).
     wg: a list -- the weight-gradient work of every call is appended to it as a job of ops.mlp_wgrad_multi (the caller
@@ -139,6 +142,8 @@ def _decoder_backward(dec, calls, impl=None, leaf=None, bwd=None, wg=None):
             g_feat, dz1, dz2, dz3 = ops.mlp_bwd(pm, pb, c.feat, c.out, c.g_out, c.h1, c.h2, impl=impl)
         else:
             g_feat, dz1, dz2, dz3 = bwd[ci]
+        if keep_dz1 is not None:
+            keep_dz1.append(dz1)
 
         def weight_grads(c=c, dz1=dz1, dz2=dz2, dz3=dz3):
             x = ops.mlp_inputs(pm, c.feat, c.aux, c.aux_map)
@@ -263,7 +268,7 @@ class PrimaryRenderFn(torch.autograd.Function):
             if is_relight:
                 jobs.append(("brdf", model.renderModule_brdf, intr, rec_xyz, None))
                 jobs.append(("brdf_j", model.renderModule_brdf, intr_j, xyz_j, None))
-                if model.normals_kind not in ("purely_derived", "gt_normals"):
+                if model.normals_kind in ("purely_predicted", "derived_plus_predicted"):
                     jobs.append(("normal", model.renderModule_normal, intr, rec_xyz, None))
             if ops.MLP_IMPL == "bf16x3" and ops.FEAT_STRIDE == rad.shape[1]:
                 # same records for every decoder: ONE launch, the grid split between them
@@ -281,6 +286,10 @@ class PrimaryRenderFn(torch.autograd.Function):
                     pred = ops.density_grad(f, rec_xyz, n_dev=n_dev)[2]
                 elif model.normals_kind == "gt_normals":
                     pred = None
+                elif model.normals_kind == "residue_prediction":      # :962-968: its decoder also takes the derived normal
+                    derived = ops.density_grad(f, rec_xyz, n_dev=n_dev)[2]
+                    pred, h1, h2 = model.renderModule_normal.rows(rec_xyz, derived, intr, n_dev, save_hidden=True)
+                    st.calls["normal"] = _DecoderCall(feat=intr, aux=rec_xyz, aux_map=None, out=pred, h1=h1, h2=h2)
                 else:
                     pred = outs["normal"]
                     if model.normals_kind == "derived_plus_predicted":
@@ -288,8 +297,8 @@ class PrimaryRenderFn(torch.autograd.Function):
         st.rgb, st.brdf, st.brdf_j, st.pred, st.derived = rgb, brdf, brdf_j, pred, derived
         maps = ops.composite_primary(rays, offsets, rec_w, rgb, brdf, brdf_j, pred, derived, acc, depth,
                                      white_bg, is_relight, model.fixed_fresnel)
-        if model.normals_kind != "derived_plus_predicted" and is_relight:
-            maps[:, 16] = 0.0            # only the derived_plus_predicted branch fills it (tensorBase_rotated_lights.py:953-960)
+        if model.normals_kind not in NORMAL_LOSS_KINDS and is_relight:
+            maps[:, 16] = 0.0            # only the predict-and-derive branches fill it (tensorBase_rotated_lights.py:953-968)
 
         def finish():
             """Read the record count; trim the saved rows to it.  False = the capacity overflowed (re-run the pass)."""
@@ -337,7 +346,7 @@ class PrimaryRenderFn(torch.autograd.Function):
             raise TensoirHipError("backward through a training forward whose record capacity overflowed")
         f = model.packed_field()
         g_maps = g_maps.contiguous().to(torch.float32)
-        if model.normals_kind != "derived_plus_predicted" and st.is_relight:
+        if model.normals_kind not in NORMAL_LOSS_KINDS and st.is_relight:
             g_maps = g_maps.clone()
             g_maps[:, 16] = 0.0
         bufs = _grad_buffers(model, f)
@@ -369,9 +378,17 @@ class PrimaryRenderFn(torch.autograd.Function):
                                                                         bwd=pick("brdf", "brdf_j"), wg=wg)
                 if "normal" in st.calls:
                     cn = st.calls["normal"]
+                    residue = model.normals_kind == "residue_prediction"
+                    dz1 = [] if residue else None
                     (g_n,), dec_grads["normal"] = _decoder_backward(model.renderModule_normal, [cn], leaf=leaf, bwd=pick("normal"),
-                                                                    wg=wg)
+                                                                    wg=wg, keep_dz1=dz1)
                     g_int = g_int + g_n
+                    if residue:
+                        # the three derived-normal columns of layer 1 ride outside the kernels (they entered through the per-row
+                        # table): their weight gradient dz1^T n and the cotangent of the derived normal dz1 W0[:, 3:6]
+                        wn = model.renderModule_normal.w0_normal()
+                        residue_dw = dz1[0].t() @ st.derived
+                        g_der = g_der + dz1[0] @ wn
                     if g_der is not None:
                         ops.density_grad_bwd(f, gd, st.rec_xyz, g_der)
                 elif model.normals_kind == "purely_derived":       # the composited normal IS the derived one
@@ -403,6 +420,13 @@ class PrimaryRenderFn(torch.autograd.Function):
             grads += [_to_param_layout(bufs[f"{name}{i}"]) for i in range(3)]
         grads.append(d_basis)
         grads.append(torch.add(bufs["ll"], bufs["lm"][None, :], alpha=1.0 / float(model.light_num)))
+        if st.A > 0 and model.normals_kind == "residue_prediction" and "normal" in dec_grads:
+            # [128,150] in the kernels' column order + the three normal columns -> the module's [128,153] layout
+            dec = model.renderModule_normal
+            full = torch.zeros_like(dec.mlp[0].weight)
+            full[:, dec.std_cols] = dec_grads["normal"][0]
+            full[:, 3:6] = residue_dw
+            dec_grads["normal"][0] = full
         for key, dec in zip(("rgb", "brdf", "normal"), _decoders(model)):
             grads += dec_grads.get(key, [None] * 6)
         assert len(grads) == st.n_params

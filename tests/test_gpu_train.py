@@ -320,7 +320,7 @@ def test_training_step_vs_oracle(env, relight, t_stop):
     _check_training_step(env, env.model, env.sc, relight, t_stop, 18 if not relight else 30)
 
 
-@pytest.mark.parametrize("kind", ["purely_predicted", "purely_derived", "gt_normals"])
+@pytest.mark.parametrize("kind", ["purely_predicted", "purely_derived", "gt_normals", "residue_prediction"])
 def test_normals_kinds_vs_reference(env, kind):
     """normals_kind 'purely_predicted' (the reference's class default) and 'purely_derived': forward maps against the
     imported reference (tests/golden/normals_kinds.npz) -- normals_diff and normals_orientation_loss are ZERO in both
@@ -333,6 +333,8 @@ def test_normals_kinds_vs_reference(env, kind):
     ck["kwargs"]["normals_kind"] = kind
     if kind in ("purely_derived", "gt_normals"):
         ck["state_dict"] = {k: v for k, v in ck["state_dict"].items() if not k.startswith("renderModule_normal")}
+    if kind == "residue_prediction":        # MLPNormal_normal_and_PExyz (:236-262): layer 1 also takes the derived normal (153 columns)
+        ck["state_dict"]["renderModule_normal.mlp.0.weight"] = T(kg, "residue_prediction/w0_normal_decoder")
     eh, ew = [int(x) for x in env.g["scene/envmap_hw"]]
     m = tensoir_amd.model_from_checkpoint(ck, "cuda", envmap_h=eh, envmap_w=ew)
     m.march_t_stop = 0.0
@@ -352,7 +354,10 @@ def test_normals_kinds_vs_reference(env, kind):
             assert float((a.cpu()[sel] - ref[sel]).abs().max()) < 1e-4, (kind, n)
             continue
         assert float((a.cpu() - ref).abs().max()) < 1e-4, (kind, n)
-    assert float(out[7].abs().max()) == 0.0 and float(out[8].abs().max()) == 0.0
+    if kind == "residue_prediction":        # like derived_plus_predicted it fills the two normal losses (:966-968)
+        assert float(out[7].abs().max()) > 0.0
+    else:
+        assert float(out[7].abs().max()) == 0.0 and float(out[8].abs().max()) == 0.0
     # the boundary call against the reference's own (renderer.py:57-127); 'gt_normals': the ground-truth normals replace the
     # zero map before the shading stage and in the returned dict (:82-83)
     from tensoir_amd import Renderer_TensoIR_train
@@ -364,6 +369,15 @@ def test_normals_kinds_vs_reference(env, kind):
         ref = torch.from_numpy(kg[f"{kind}/eval_render/{k}"])
         assert float((ret[k].cpu() - ref).abs().max()) < 1e-4, (kind, k)
     _check_training_step(env, m, sc, True, 0.0, 19 if kind == "gt_normals" else 25, normal_gt=ngt)
+    if kind == "residue_prediction":        # the stand-alone decoder call of the reference interface (pts, normal, features)
+        n = 257
+        gen = torch.Generator().manual_seed(3)
+        pts, nrm = torch.rand(n, 3, generator=gen) * 2 - 1, torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+        feat = torch.randn(n, 27, generator=gen)
+        with torch.no_grad():
+            got = m.renderModule_normal(pts.cuda(), nrm.cuda(), feat.cuda()).cpu()
+        want = env.O.render_normal_residue(sc, pts, nrm, feat)
+        assert float((got - want).abs().max()) < 1e-5
 
 
 def _check_training_step(env, m, sc, relight, t_stop, min_checked, normal_gt=None):

@@ -108,8 +108,14 @@ def test_unsupported_configurations_fail_loudly():
         TensorVMSplit(aabb, [8, 8, 8], "cpu", shadingMode="MLP_Fea", light_kind="gt", density_n_comp=[16] * 3,
                       appearance_n_comp=[48] * 3)
     with pytest.raises(NotImplementedError):
-        TensorVMSplit(aabb, [8, 8, 8], "cpu", shadingMode="MLP_Fea", light_kind="sg", normals_kind="residue_prediction",
+        TensorVMSplit(aabb, [8, 8, 8], "cpu", shadingMode="MLP_Fea", light_kind="sg", normals_kind="no_such_kind",
                       density_n_comp=[16] * 3, appearance_n_comp=[48] * 3)
+    # 'residue_prediction' (:426-428): a 153-column layer 1 in the reference's own column order
+    r = TensorVMSplit(aabb, [8, 8, 8], "cpu", shadingMode="MLP_Fea", light_kind="sg", normals_kind="residue_prediction",
+                      density_n_comp=[16] * 3, appearance_n_comp=[48] * 3)
+    dec = r.renderModule_normal
+    assert dec.mlp[0].weight.shape == (128, 153) and sorted(dec.std_cols) == [0, 1, 2] + list(range(6, 153))
+    assert torch.equal(dec.w0_std()[:, 27:30], dec.mlp[0].weight[:, 0:3]) and torch.equal(dec.w0_std()[:, :27], dec.mlp[0].weight[:, 6:33])
     # the other kinds of the reference construct: the learnable pixel environment map (:459-460), ground-truth normals (:951-952)
     m = TensorVMSplit(aabb, [8, 8, 8], "cpu", shadingMode="MLP_Fea", light_kind="pixel", normals_kind="gt_normals",
                       envmap_h=4, envmap_w=8, density_n_comp=[16] * 3, appearance_n_comp=[48] * 3)
@@ -329,8 +335,9 @@ def test_regularisers_match_the_reference(golden):
     assert na == nb
 
 
-@pytest.mark.parametrize("light_kind", ["sg", "pixel"])
-def test_seeded_construction_draws_the_reference_parameters(golden, light_kind):
+@pytest.mark.parametrize("light_kind,normals_kind", [("sg", "derived_plus_predicted"), ("pixel", "derived_plus_predicted"),
+                                                     ("sg", "residue_prediction")])
+def test_seeded_construction_draws_the_reference_parameters(golden, light_kind, normals_kind):
     """Same torch seed -> the same initial planes, lines, decoders, SGs / pixel light as the reference constructor (the order and
     shapes of the random draws are part of the drop-in: seeded experiments reproduce)."""
     import contextlib
@@ -340,7 +347,7 @@ def test_seeded_construction_draws_the_reference_parameters(golden, light_kind):
     ref = ref_loader.load()
     aabb = torch.tensor([[-1.5, -1.4, -1.3], [1.5, 1.4, 1.3]])
     kw = dict(density_n_comp=[16, 16, 16], appearance_n_comp=[48, 48, 48], app_dim=27, shadingMode="MLP_Fea", step_ratio=0.5,
-              normals_kind="derived_plus_predicted", light_rotation=["000", "120"], envmap_w=8, envmap_h=4,
+              normals_kind=normals_kind, light_rotation=["000", "120"], envmap_w=8, envmap_h=4,
               light_kind=light_kind, numLgtSGs=128)
     torch.manual_seed(77)
     with contextlib.redirect_stdout(io.StringIO()):

@@ -9,6 +9,7 @@ TensoirHipError on a box without a GPU -- i.e. every import and signature of the
 GPU box (-m gpu): the same script runs 150 iterations end to end across updateAlphaMask / shrink / upsample when a
 checkout is available (TENSOIR_REFERENCE); tests/test_gpu_train_loop.py drives the same call sequence without it."""
 import os
+import re
 import subprocess
 import sys
 
@@ -197,6 +198,41 @@ def test_unmodified_train_script_reaches_first_kernel_call(tmp_path, script):
     assert "initial TV_weight density" in out                               # model ctor, optparam groups, Adam: done
     assert "filtering_rays" in out and "TensoirHipError" in out, out[-3000:]     # first kernel call on a box without GPU
     assert "ModuleNotFoundError" not in out and "ImportError" not in out and "TypeError" not in out
+
+
+VARIANTS = {"residue_prediction": {"normals_kind": "residue_prediction"}, "pixel_light": {"light_kind": "pixel"}}
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="reference checkout not present")
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-box check (the GPU variant runs the loop)")
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_unmodified_train_script_variants_reach_first_kernel_call(tmp_path, monkeypatch, variant):
+    """The configuration switches no shipped config uses -- the residue-prediction normal decoder (153-column layer 1) and the
+    learnable pixel environment light -- through the unmodified script's own constructor call and optimizer groups."""
+    monkeypatch.setitem(SCRIPTS, "train_tensoIR.py", VARIANTS[variant])
+    r = run_script(tmp_path, script="train_tensoIR.py")
+    out = r.stdout + r.stderr
+    assert r.returncode != 0 and "initial TV_weight density" in out
+    assert "filtering_rays" in out and "TensoirHipError" in out, out[-3000:]
+    assert "ModuleNotFoundError" not in out and "ImportError" not in out and "TypeError" not in out and "NotImplementedError" not in out
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not HAVE_REF, reason="reference checkout not present on this box")
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_unmodified_train_script_variants_run_end_to_end(tmp_path, monkeypatch, variant):
+    monkeypatch.setitem(SCRIPTS, "train_tensoIR.py", VARIANTS[variant])
+    r = run_script(tmp_path, script="train_tensoIR.py")
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    ckpt = torch.load(os.path.join(str(tmp_path), "synth_run", "synth_run.th"), map_location="cpu", weights_only=False)
+    assert ckpt["kwargs"]["normals_kind" if variant == "residue_prediction" else "light_kind"] == list(VARIANTS[variant].values())[0]
+    if variant == "residue_prediction":
+        assert ckpt["state_dict"]["renderModule_normal.mlp.0.weight"].shape == (128, 153)
+    else:
+        assert "_light_rgbs" in ckpt["state_dict"] and "lgtSGs" not in ckpt["state_dict"]
+    m = re.findall(r"train_rgb_brdf = ([0-9.]+)", out)
+    assert m and float(m[-1]) > 15.0, m[-3:]                 # the physically based branch trains too
 
 
 @pytest.mark.gpu

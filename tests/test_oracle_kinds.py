@@ -23,16 +23,25 @@ def kg():
     return np.load(os.path.join(ROOT, "tests", "golden", "normals_kinds.npz"))
 
 
-def kind_scene(golden, kind):
+def kind_checkpoint(golden, kind, kg=None):
     ck = golden_checkpoint(golden)
     ck["kwargs"]["normals_kind"] = kind
     if kind in ("purely_derived", "gt_normals"):
         ck["state_dict"] = {k: v for k, v in ck["state_dict"].items() if not k.startswith("renderModule_normal")}
+    if kind == "residue_prediction":          # MLPNormal_normal_and_PExyz: a 153-wide layer 1 (the fixture's seeded weights)
+        kg = np.load(os.path.join(ROOT, "tests", "golden", "normals_kinds.npz")) if kg is None else kg
+        ck["state_dict"]["renderModule_normal.mlp.0.weight"] = T(kg, "residue_prediction/w0_normal_decoder")
+    return ck
+
+
+def kind_scene(golden, kind):
+    ck = kind_checkpoint(golden, kind)
     eh, ew = [int(x) for x in golden["scene/envmap_hw"]]
     return scene_from_checkpoint(ck, eh, ew)
 
 
-KINDS = ["purely_predicted", "purely_derived", "gt_normals"]
+KINDS = ["purely_predicted", "purely_derived", "gt_normals", "residue_prediction"]
+DERIVING = ("purely_derived", "residue_prediction")          # kinds whose forward differentiates the density (autograd in the oracle)
 
 
 @pytest.mark.parametrize("kind", KINDS)
@@ -40,7 +49,7 @@ def test_forward_kinds_vs_reference(golden, kg, kind):
     sc = kind_scene(golden, kind)
     rays, lidx = T(golden, "rays/rays"), T(golden, "rays/light_idx")
     torch.manual_seed(SEED + 3)
-    with torch.set_grad_enabled(kind == "purely_derived"):
+    with torch.set_grad_enabled(kind in DERIVING):
         out = O.forward_primary(sc, rays, lidx.int())
     for n, v in zip(NAMES, out):
         ref = kg[f"{kind}/fwd/{n}"]
@@ -48,8 +57,11 @@ def test_forward_kinds_vs_reference(golden, kg, kind):
             assert np.array_equal(v.numpy(), ref)
         else:
             assert float((v.detach() - torch.from_numpy(ref)).abs().max()) < 3e-5, n
-    assert float(np.abs(kg[f"{kind}/fwd/normals_orientation_loss_map"]).max()) == 0.0
-    assert float(np.abs(kg[f"{kind}/fwd/normals_diff_map"]).max()) == 0.0
+    if kind == "residue_prediction":          # the second kind that fills the two normal losses (:962-968)
+        assert float(np.abs(kg[f"{kind}/fwd/normals_diff_map"]).max()) > 0.0
+    else:
+        assert float(np.abs(kg[f"{kind}/fwd/normals_orientation_loss_map"]).max()) == 0.0
+        assert float(np.abs(kg[f"{kind}/fwd/normals_diff_map"]).max()) == 0.0
 
 
 @pytest.mark.parametrize("kind", KINDS)
@@ -60,7 +72,7 @@ def test_eval_render_kinds_vs_reference(golden, kg, kind):
     rays, lidx = T(golden, "rays/rays"), T(golden, "rays/light_idx")
     ngt = T(kg, "normal_gt") if kind == "gt_normals" else None
     torch.manual_seed(SEED + 3)
-    with torch.set_grad_enabled(kind == "purely_derived"):
+    with torch.set_grad_enabled(kind in DERIVING):
         ret = O.renderer_train(sc, rays, lidx, n_samples=-1, second_n_sample=24, second_near=0.05, second_far=1.5, normal_gt=ngt)
     for k in ("rgb_map", "depth_map", "normal_map", "albedo_map", "roughness_map", "acc_map", "rgb_with_brdf_map"):
         assert float((ret[k].detach() - T(kg, f"{kind}/eval_render/{k}")).abs().max()) < 3e-5, (kind, k)
