@@ -374,9 +374,11 @@ int tir_env_sg_fwd(const TirEnvSG* e, const float* dirs, int32_t D, float* out, 
  *      light_rgbs [H][W][3] (`_light_rgbs`, :459-460) behind softplus(beta = 5); env[l][d][:] = bilinear lookup
  *      (F.grid_sample, align_corners=False, zero padding) at the equirectangular position of dirs[d] . rot[l]
  *      (rot [n_lights][9] row-major light_rotation_matrix).  env [n_lights][n_dirs][3].
- *      _bwd: g_light [H][W][3] += d loss / d light_rgbs given g_env (atomics; zero-fill first). */
+ *      softplus = 0: the image is used as it is -- light_kind == 'gt', the data set's own probe (`dataset.lights_probes`, :592-593).
+ *      _bwd: g_light [H][W][3] += d loss / d light_rgbs given g_env (atomics; zero-fill first; the softplus form only:
+ *      the 'gt' probe is not trained). */
 int tir_env_pixel_fwd(const float* light_rgbs, int32_t H, int32_t W, const float* rot, const float* dirs,
-                      int32_t n_lights, int64_t n_dirs, float* env, void* stream);
+                      int32_t n_lights, int64_t n_dirs, int32_t softplus, float* env, void* stream);
 int tir_env_pixel_bwd(const float* light_rgbs, int32_t H, int32_t W, const float* rot, const float* dirs,
                       int32_t n_lights, int64_t n_dirs, const float* g_env, float* g_light, void* stream);
 

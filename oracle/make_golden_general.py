@@ -194,6 +194,24 @@ def pixel(ref, g0):
         g[f"train/grad/{name}"] = npy(torch.zeros_like(p) if p.grad is None else p.grad)
     torch.manual_seed(SEED + 12)
     g["train/ray_jitter"] = npy(torch.rand(B, 1))
+    # light_kind == 'gt' (:592-593): the data set's probe looked up as it is -- same lookup, no activation, nothing to train
+    probe = torch.rand(envh * envw, 3, generator=gen) * 4.0
+    gt_ck = golden_checkpoint(g0)
+    gt_ck["kwargs"]["light_rotation"] = [int(r) for r in gt_ck["kwargs"]["light_rotation"]]
+    gt_ck["kwargs"]["light_kind"] = "gt"
+    gt_ck["kwargs"]["dataset"] = types.SimpleNamespace(lights_probes=probe)
+    gt_ck["state_dict"] = {k: v for k, v in gt_ck["state_dict"].items() if k != "lgtSGs"}
+    gt_model = build_reference_model(ref, gt_ck, envh, envw)
+    gt_model.alphaMask = ref.tensorf.AlphaGridMask("cpu", torch.from_numpy(np.array(g0["scene/alpha_aabb"])), vol)
+    g["gt/probe"] = npy(probe)
+    gt_model.eval()
+    with torch.no_grad():
+        g["gt/light_rgbs"] = npy(gt_model.get_light_rgbs(dirs, device="cpu"))
+        torch.manual_seed(SEED + 3)
+        ret = ref.renderer.Renderer_TensoIR_train(rays, None, light_idx, gt_model, N_samples=-1, white_bg=True, is_train=False,
+                                                  is_relight=True, sample_method="fixed_envirmap", chunk_size=777, device="cpu", args=args)
+    for k, v in ret.items():
+        g[f"gt/eval/out/{k}"] = npy(v)
     path = os.path.join(OUT, "pixel_light.npz")
     np.savez_compressed(path, **g)
     print(f"wrote {path}: {len(g)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")

@@ -612,9 +612,11 @@ def light_rgbs(sc, dirs):
         return torch.stack([sg_radiance(sg.to(dirs.dtype), d) for sg in sg_list], dim=0)
     rot = light_rotation_matrices(sc.light_rotation).to(dirs.dtype)
     remapped = torch.matmul(dirs.reshape(1, -1, 3), rot).reshape(-1, 3)
-    if getattr(sc, "light_kind", "sg") == "pixel":
-        # models/tensorBase_rotated_lights.py:589-605: softplus(beta=5) map, equirectangular lookup, align_corners=False
-        env = F.softplus(sc.light_rgbs_raw.to(dirs.dtype), beta=5).reshape(sc.envmap_h, sc.envmap_w, 3).permute(2, 0, 1).unsqueeze(0)
+    if getattr(sc, "light_kind", "sg") in ("pixel", "gt"):
+        # models/tensorBase_rotated_lights.py:589-605: softplus(beta=5) map ('pixel') or the data set's probe as it is ('gt',
+        # `sc.light_probe` [envmap_h * envmap_w, 3]), equirectangular lookup, align_corners=False
+        img = F.softplus(sc.light_rgbs_raw.to(dirs.dtype), beta=5) if sc.light_kind == "pixel" else sc.light_probe.to(dirs.dtype)
+        env = img.reshape(sc.envmap_h, sc.envmap_w, 3).permute(2, 0, 1).unsqueeze(0)
         phi = torch.arccos(remapped[:, 2]).reshape(-1) - 1e-6
         theta = torch.atan2(remapped[:, 1], remapped[:, 0]).reshape(-1)
         grid = torch.stack((-theta / math.pi, (phi / math.pi) * 2 - 1)).permute(1, 0).unsqueeze(0).unsqueeze(0)

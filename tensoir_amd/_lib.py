@@ -96,7 +96,7 @@ SIGNATURES = {
                                           P, I64, P, P, P, P, P, P, P]),
     "tir_accumulate_records": (C.c_int, [P, P, P, P, I64, P, P]),
     "tir_env_sg_fwd": (C.c_int, [C.POINTER(TirEnvSG), P, I32, P, P]),
-    "tir_env_pixel_fwd": (C.c_int, [P, I32, I32, P, P, I32, I64, P, P]),
+    "tir_env_pixel_fwd": (C.c_int, [P, I32, I32, P, P, I32, I64, I32, P, P]),
     "tir_env_pixel_bwd": (C.c_int, [P, I32, I32, P, P, I32, I64, P, P, P]),
     "tir_shade_setup": (C.c_int, [P, P, P, I32, I32, F32, P, P, P]),
     "tir_shade_integrate": (C.c_int, [P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, P, P]),

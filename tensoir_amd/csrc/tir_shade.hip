@@ -392,7 +392,7 @@ __device__ __forceinline__ float softplus5(float x) {        // torch softplus(b
 
 __global__ void __launch_bounds__(256)
 k_env_pixel(const float* __restrict__ light_rgbs, int H, int W, const float* __restrict__ rot, const float* __restrict__ dirs,
-            int L, int64_t D, float* __restrict__ env) {
+            int L, int64_t D, int softplus, float* __restrict__ env) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)L * D) return;
     const int l = (int)(i / D);
@@ -402,8 +402,8 @@ k_env_pixel(const float* __restrict__ light_rgbs, int H, int W, const float* __r
     for (int k = 0; k < 4; ++k)
         if (t.idx[k] >= 0) {
             const float* p = light_rgbs + 3 * (size_t)t.idx[k];
-            c[0] = fmaf(t.w[k], softplus5(p[0]), c[0]); c[1] = fmaf(t.w[k], softplus5(p[1]), c[1]);
-            c[2] = fmaf(t.w[k], softplus5(p[2]), c[2]);
+            c[0] = fmaf(t.w[k], softplus ? softplus5(p[0]) : p[0], c[0]); c[1] = fmaf(t.w[k], softplus ? softplus5(p[1]) : p[1], c[1]);
+            c[2] = fmaf(t.w[k], softplus ? softplus5(p[2]) : p[2], c[2]);
         }
     env[3 * i] = c[0]; env[3 * i + 1] = c[1]; env[3 * i + 2] = c[2];
 }
@@ -569,13 +569,13 @@ extern "C" int tir_env_lookup(const float* env_rgb, int32_t H, int32_t W, const 
 }
 
 extern "C" int tir_env_pixel_fwd(const float* light_rgbs, int32_t H, int32_t W, const float* rot, const float* dirs,
-                                 int32_t n_lights, int64_t n_dirs, float* env, void* stream) {
-    if (H <= 0 || W <= 0 || n_lights <= 0 || n_dirs < 0) return TIR_ERR_ARG;
+                                 int32_t n_lights, int64_t n_dirs, int32_t softplus, float* env, void* stream) {
+    if (H <= 0 || W <= 0 || n_lights <= 0 || n_dirs < 0 || (softplus != 0 && softplus != 1)) return TIR_ERR_ARG;
     if (n_dirs == 0) return TIR_OK;
     if (!light_rgbs || !rot || !dirs || !env) return TIR_ERR_ARG;
     const int64_t n = (int64_t)n_lights * n_dirs;
     hipLaunchKernelGGL(k_env_pixel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tir_stream(stream), light_rgbs, H, W, rot,
-                       dirs, n_lights, n_dirs, env);
+                       dirs, n_lights, n_dirs, softplus, env);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

@@ -356,9 +356,11 @@ class TensorVMSplit(nn.Module):
         """models/tensorBase_rotated_lights.py:455-488: the fixed direction grid, the z-rotation of every light and the trainable
         light -- 128 spherical Gaussians (lobe axis 3, sharpness 1, amplitude 3) or the pixel image."""
         self.light_area_weight, self.fixed_viewdirs = self.generate_envir_map_dir(self.envmap_h, self.envmap_w)
-        if self.light_kind not in ("sg", "pixel"):
-            raise NotImplementedError(f"light_kind={self.light_kind!r}: 'sg' and 'pixel' have gfx950 kernels")
+        if self.light_kind not in ("sg", "pixel", "gt"):
+            raise NotImplementedError(f"light_kind={self.light_kind!r} is not one of the reference's ('sg', 'pixel', 'gt')")
         self._light_rotations()
+        if self.light_kind == "gt":          # :592-593: nothing to train, the data set's probe is looked up as it is
+            return
         if self.light_kind == "pixel":       # :459-460: a learnable envmap_h x envmap_w image behind softplus(beta=5)
             cells = self.envmap_w * self.envmap_h
             self._light_rgbs = nn.Parameter(torch.FloatTensor(cells, 3).uniform_(0, 3).to(torch.float32).to(self.device))
@@ -422,6 +424,12 @@ class TensorVMSplit(nn.Module):
         if rot is None or rot.device != dirs.device:
             rot = self.light_rotation_matrix.to(dirs.device).contiguous()
             self.__dict__["_rot_dev"] = rot
+        if self.light_kind == "gt":              # :592-593 -- `dataset.lights_probes` [envmap_h * envmap_w, 3], no activation
+            probe = getattr(self.dataset, "lights_probes", None)
+            if probe is None:
+                raise TensoirHipError("light_kind='gt' needs a dataset with lights_probes (the environment map of the scene)")
+            probe = ops.to_device(probe, dirs.device, torch.float32).reshape(-1, 3).contiguous()
+            return ops.env_pixel(probe, self.envmap_h, self.envmap_w, rot, dirs, softplus=False)
         if self.light_kind == "pixel":           # :585-605; tiny table, evaluated per call (no cache: the map trains)
             if torch.is_grad_enabled() and self._light_rgbs.requires_grad:
                 from . import training
@@ -470,12 +478,16 @@ class TensorVMSplit(nn.Module):
 
     def _light_param_groups(self):
         """models/tensoRF_rotated_lights.py:43-46."""
+        if self.light_kind == "gt":
+            return []
         return [{"params": self._light_rgbs if self.light_kind == "pixel" else self.lgtSGs, "lr": 0.001}]
 
     def light_parameters(self):
         """The environment light's trainable tensors (cache keys of captured graphs, train / eval routing)."""
         if self.light_kind == "pixel":
             return [self._light_rgbs]
+        if self.light_kind == "gt":
+            return []
         return list(getattr(self, "lgtSGs_list", None) or [self.lgtSGs])
 
     def vectorDiffs(self, vector_comps):

@@ -618,8 +618,9 @@ def env_sg(lgtSGs, rot, dirs):
     return out
 
 
-def env_pixel(light_rgbs, H, W, rot, dirs):
-    """light_kind == 'pixel': [H*W, 3] raw map parameters -> environment radiance [L, D, 3] (tir_env_pixel_fwd)."""
+def env_pixel(light_rgbs, H, W, rot, dirs, softplus=True):
+    """light_kind == 'pixel': [H*W, 3] raw map parameters -> environment radiance [L, D, 3] (tir_env_pixel_fwd); softplus=False:
+    the image as it is (light_kind == 'gt', the data set's probe)."""
     lr = f32(light_rgbs.detach(), "_light_rgbs", 3).view(-1, 3)
     if lr.shape[0] != H * W:
         raise ValueError(f"_light_rgbs: expected {H * W} rows, got {lr.shape[0]}")
@@ -627,7 +628,7 @@ def env_pixel(light_rgbs, H, W, rot, dirs):
     dirs = f32(dirs, "dirs", 3).view(-1, 3)
     L, D = rot.shape[0], dirs.shape[0]
     out = torch.empty((L, D, 3), dtype=torch.float32, device=dirs.device)
-    _call("tir_env_pixel_fwd", _ptr(lr), int(H), int(W), _ptr(rot), _ptr(dirs), L, D, _ptr(out), _stream())
+    _call("tir_env_pixel_fwd", _ptr(lr), int(H), int(W), _ptr(rot), _ptr(dirs), L, D, int(bool(softplus)), _ptr(out), _stream())
     return out
 
 

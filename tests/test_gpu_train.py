@@ -486,7 +486,7 @@ def test_optimizer_steps_reduce_loss(env):
         opt.zero_grad()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
 
 
@@ -611,6 +611,38 @@ def test_general_multi_light_variant_vs_reference_golden(env):
         # the radiance decoder's gradient comes from rgb_map alone (the secondary pass is no_grad, relight_utils.py:344):
         # independent of the BRDF jitter, so it must match the reference's
         assert gerr(params[name].grad, T(gg, f"train/grad/{name}")) < GTOL, name
+
+
+def test_gt_probe_light_vs_reference_golden(env):
+    """light_kind == 'gt' (:592-593): `dataset.lights_probes` looked up as it is (tir_env_pixel_fwd, softplus = 0); no light
+    parameter in the optimizer groups; a training step still differentiates everything else."""
+    import types
+    import tensoir_amd
+    from tensoir_amd import Renderer_TensoIR_train
+    from tests.helpers import golden_checkpoint
+    g = env.g
+    pg = np.load(os.path.join(ROOT, "tests", "golden", "pixel_light.npz"))
+    ck = golden_checkpoint(g)
+    ck["kwargs"]["light_kind"] = "gt"
+    ck["kwargs"]["dataset"] = types.SimpleNamespace(lights_probes=T(pg, "gt/probe"))
+    ck["state_dict"] = {k: v for k, v in ck["state_dict"].items() if k != "lgtSGs"}
+    eh, ew = [int(x) for x in g["scene/envmap_hw"]]
+    m = tensoir_amd.model_from_checkpoint(ck, "cuda", envmap_h=eh, envmap_w=ew)
+    m.march_t_stop = 0.0
+    assert m.light_kind == "gt" and not hasattr(m, "lgtSGs") and m.light_parameters() == []
+    with torch.no_grad():
+        got = m.get_light_rgbs(T(pg, "env/dirs").cuda(), device="cuda")
+    assert got.shape == (3, 60, 3) and gerr(got, T(pg, "gt/light_rgbs")) < 1e-5
+    rays, lidx = T(g, "rays/rays"), T(g, "rays/light_idx")
+    with torch.no_grad():
+        ret = Renderer_TensoIR_train(rays, None, lidx, m, N_samples=-1, white_bg=True, is_train=False, is_relight=True,
+                                     sample_method="fixed_envirmap", device="cuda", args=env.args)
+    for k in ("rgb_map", "normal_map", "albedo_map", "acc_map", "rgb_with_brdf_map"):
+        assert float((ret[k].cpu() - T(pg, f"gt/eval/out/{k}")).abs().max()) < 1e-4, k
+    ret = Renderer_TensoIR_train(rays, None, lidx, m, N_samples=64, white_bg=True, is_train=True, is_relight=True,
+                                 sample_method="fixed_envirmap", device="cuda", args=env.args)
+    ret["rgb_with_brdf_map"].mean().backward()
+    assert m.renderModule_brdf.mlp[0].weight.grad is not None and float(m.renderModule_brdf.mlp[0].weight.grad.abs().max()) > 0
 
 
 def test_pixel_environment_light_vs_reference_golden(env):

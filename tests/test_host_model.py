@@ -105,8 +105,12 @@ def test_unsupported_configurations_fail_loudly():
         TensorVMSplit(aabb, [8, 8, 8], "cpu", shadingMode="SH", light_kind="sg", density_n_comp=[16] * 3,
                       appearance_n_comp=[48] * 3)
     with pytest.raises(NotImplementedError):
-        TensorVMSplit(aabb, [8, 8, 8], "cpu", shadingMode="MLP_Fea", light_kind="gt", density_n_comp=[16] * 3,
+        TensorVMSplit(aabb, [8, 8, 8], "cpu", shadingMode="MLP_Fea", light_kind="no_such_light", density_n_comp=[16] * 3,
                       appearance_n_comp=[48] * 3)
+    # light_kind='gt' (:592-593) constructs without a light parameter
+    gtm = TensorVMSplit(aabb, [8, 8, 8], "cpu", shadingMode="MLP_Fea", light_kind="gt", density_n_comp=[16] * 3,
+                        appearance_n_comp=[48] * 3)
+    assert gtm.light_parameters() == [] and not hasattr(gtm, "lgtSGs") and len(gtm.get_optparam_groups()) == 9
     with pytest.raises(NotImplementedError):
         TensorVMSplit(aabb, [8, 8, 8], "cpu", shadingMode="MLP_Fea", light_kind="sg", normals_kind="no_such_kind",
                       density_n_comp=[16] * 3, appearance_n_comp=[48] * 3)

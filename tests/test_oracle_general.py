@@ -180,3 +180,24 @@ def test_pixel_light_render_and_grads_vs_reference(golden, pg):
         checked += 1
     assert checked >= 30 and float(np.abs(pg["train/grad/_light_rgbs"]).max()) > 0
 
+
+
+def test_gt_probe_light_vs_reference(golden, pg):
+    """light_kind == 'gt' (models/tensorBase_rotated_lights.py:592-593): the data set's probe, looked up like the pixel map but
+    without the softplus and with nothing to train -- radiance at the probe directions and the eval render."""
+    import types
+    from tests.helpers import golden_checkpoint, scene_from_checkpoint
+    ck = golden_checkpoint(golden)
+    ck["kwargs"]["light_kind"] = "gt"
+    ck["state_dict"] = {k: v for k, v in ck["state_dict"].items() if k != "lgtSGs"}
+    eh, ew = [int(x) for x in golden["scene/envmap_hw"]]
+    sc = scene_from_checkpoint(ck, eh, ew)
+    sc.light_probe = T(pg, "gt/probe")
+    got = O.light_rgbs(sc, T(pg, "env/dirs"))
+    assert float((got - T(pg, "gt/light_rgbs")).abs().max()) < 1e-6
+    rays, lidx = T(golden, "rays/rays"), T(golden, "rays/light_idx")
+    torch.manual_seed(SEED + 3)
+    with torch.no_grad():
+        ret = O.renderer_train(sc, rays, lidx, n_samples=-1, second_n_sample=24, second_near=0.05, second_far=1.5)
+    for k in ("rgb_map", "normal_map", "albedo_map", "acc_map", "rgb_with_brdf_map"):
+        assert float((ret[k] - T(pg, f"gt/eval/out/{k}")).abs().max()) < 3e-5, k
