@@ -1989,7 +1989,11 @@ extern "C" int tir_mlp_wgrad_multi(const float* const* dz1s, const float* const*
     if (per < 1) per = 1;
     const int64_t steps = (n + 15) / 16;
     if (steps < per) per = (int)steps;
-    if ((feat_stride & 3) || feat_stride < 32 || n >= ((int64_t)1 << 31)) {      // rows not float4-addressable: the direct-load kernel
+    bool vec_ok = !(feat_stride & 3) && feat_stride >= 32 && n < ((int64_t)1 << 31);
+    for (int i = 0; i < n_jobs && vec_ok; ++i)                                  // the staged kernel fetches rows as float4
+        for (const float* q : {dz1s[i], dz2s[i], dz3s[i], h1s[i], h2s[i], feats[i]})
+            if (reinterpret_cast<uintptr_t>(q) % 16 != 0) vec_ok = false;
+    if (!vec_ok) {                                                              // rows not float4-addressable: the direct-load kernel
         hipLaunchKernelGGL(k_mlp_wgrad, dim3((unsigned)(per * n_jobs)), dim3(1024), 0, tir_stream(stream), jobs, feat_stride, n);
     } else {
         if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_mlp_wgrad_lds), WL_LDS_BYTES)) return rc;

@@ -143,7 +143,8 @@ def test_small_gemm_tn(env, n):
         assert torch.equal(Cd[:, N:].cpu(), C0[:, N:])
 
 
-@pytest.mark.parametrize("stride", [32, 29])             # 32: the LDS-staged kernel; 29 (rows not float4-addressable): direct loads
+@pytest.mark.parametrize("stride", [32, 29, -32])        # 32: the LDS-staged kernel; 29 (rows not float4-addressable) and
+                                                           # -32 (stride 32, base pointer off by one float): direct loads
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 700, 4099, 70001])
 def test_fused_weight_gradients(env, n, stride):
     """tir_mlp_wgrad_multi: dW0 = dz1^T x, dW1 = dz2^T h1, dW2 = dz3^T h2 and the three bias gradients of several decoder
@@ -166,7 +167,8 @@ def test_fused_weight_gradients(env, n, stride):
             dz3[:, 3] = 0.0                               # a 3-output decoder: the 4th cotangent column is zero
         h1, h2 = torch.relu(torch.randn(n, 128, generator=gen)), torch.relu(torch.randn(n, 128, generator=gen))
         feat = torch.randn(n, 27, generator=gen) * 1.5
-        fpad = torch.full((n, stride), float("nan"))      # the padding columns must never be read into a product
+        misaligned, stride_ = stride < 0, abs(stride)
+        fpad = torch.full((n, stride_), float("nan"))     # the padding columns must never be read into a product
         fpad[:, :27] = feat
         fpad[:, 27] = 0.0                                 # (column 27 is the forward's zero pad)
         if mapped:
@@ -180,7 +182,13 @@ def test_fused_weight_gradients(env, n, stride):
         x = O.mlp_input(feat.double(), aux_rows.double(), 2, 2)
         refs.append((oi, dz1.double().T @ x, dz1.double().sum(0), dz2.double().T @ h1.double(), dz2.double().sum(0),
                      dz3.double().T @ h2.double(), dz3.double().sum(0)))
-        jobs.append((dz1.cuda(), dz2.cuda(), dz3.cuda(), h1.cuda(), h2.cuda(), fpad.cuda(), aux_dev, map_dev) + tuple(dev_outs[oi]))
+        fdev = fpad.cuda()
+        if misaligned:                                    # the same rows one float into a larger allocation
+            hold = torch.empty(fdev.numel() + 1, device="cuda")
+            hold[1:] = fdev.reshape(-1)
+            fdev = hold[1:].view(n, stride_)
+            assert fdev.data_ptr() % 16 == 4
+        jobs.append((dz1.cuda(), dz2.cuda(), dz3.cuda(), h1.cuda(), h2.cuda(), fdev, aux_dev, map_dev) + tuple(dev_outs[oi]))
     ops.mlp_wgrad_multi(jobs)
     want = [[torch.zeros_like(t, dtype=torch.float64) for t in o] for o in outs]
     for oi, *parts in refs:
