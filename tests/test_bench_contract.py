@@ -1,0 +1,65 @@
+"""The bench.py contract the driver depends on, checked on the CPU box: the CLI parses with no flags (N = 1, small K / W), refuses
+a scaling line from fewer ranks than it claims, fails loudly without a GPU (no CPU fallback), and the committed evidence lines
+(profiles/r03_v9_*bench.json, written by bench.py on an MI355X) carry every field of the contract incl. the `roofline` and
+`cpu_baseline` objects."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _bench(*args, env=None):
+    e = dict(os.environ, **(env or {}))
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600, env=e)
+
+
+def test_defaults_and_help():
+    r = _bench("--help")
+    assert r.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--workload"):
+        assert flag in r.stdout
+    sys.path.insert(0, ROOT)
+    import bench
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py"]
+        a = bench.parse()
+    finally:
+        sys.argv = old
+    assert a.gpus == 1 and 1 <= a.steps <= 200 and 0 <= a.warmup <= 20 and a.workload == "batch"
+
+
+def test_no_gpu_is_an_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-box check")
+    r = _bench("--steps", "1", "--warmup", "0")
+    assert r.returncode != 0 and not any(l.startswith('{"metric"') for l in r.stdout.splitlines())
+
+
+def test_scaling_line_needs_its_ranks():
+    r = _bench("--gpus", "2", "--steps", "1", env={"WORLD_SIZE": "1"})
+    assert r.returncode != 0 and "2" in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_v9_*bench.json"))))
+def test_committed_bench_lines_carry_the_contract(path):
+    d = json.load(open(path))
+    missing = [k for k in REQUIRED if k not in d]
+    assert not missing, (os.path.basename(path), missing)
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert isinstance(d["config"], dict) and "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf is None or all(k in rf for k in ("bound", "achieved", "peak", "unit", "frac"))
+    if os.path.basename(path) == "r03_v9_bench.json":
+        assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["traffic"]
+        cb = d["cpu_baseline"]
+        assert all(k in cb for k in ("value", "unit", "cores", "kind")) and cb["kind"] in ("reference", "port")
+        assert d["parity"]["ok"] is True and d["metric"].startswith("primary+secondary rays/sec")
