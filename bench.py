@@ -458,9 +458,9 @@ def bench_image(a):
     from tensoir_amd import dist as tdist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: tensoir_amd has no CPU path")
+    local = local_device(a)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if a.tile < 0:                                   # auto: interleave chunk-sized tiles as soon as the image is shared
@@ -587,9 +587,10 @@ def bench_relight(a):
     import tensoir_amd
     from tensoir_amd import _lib, relight, synth
     from tensoir_amd import dist as tdist
-    world, rank, local = (int(os.environ.get(k, "0" if k != "WORLD_SIZE" else "1")) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"))
+    world, rank = (int(os.environ.get(k, "0" if k != "WORLD_SIZE" else "1")) for k in ("WORLD_SIZE", "RANK"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: tensoir_amd has no CPU path")
+    local = local_device(a)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     assert _lib.lib().tir_device_check() == 0
@@ -748,9 +749,10 @@ def bench_train(a):
     import torch.distributed as dist
     from tensoir_amd import Renderer_TensoIR_train, _lib, ops, optim
     from tensoir_amd import dist as tdist
-    world, rank, local = (int(os.environ.get(k, "0" if k != "WORLD_SIZE" else "1")) for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"))
+    world, rank = (int(os.environ.get(k, "0" if k != "WORLD_SIZE" else "1")) for k in ("WORLD_SIZE", "RANK"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: tensoir_amd has no CPU path")
+    local = local_device(a)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     assert _lib.lib().tir_device_check() == 0
@@ -943,16 +945,58 @@ def train_parity_and_cpu(a, ckpt, model, rays, lidx, gt, args, device, n_sub=128
     return parity, cpu
 
 
+def local_device(a):
+    """This rank's GPU index: LOCAL_RANK, or LOCAL_RANK modulo the visible devices with --allow-shared-gpu (plumbing runs of
+    several ranks on one device)."""
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.allow_shared_gpu and torch.cuda.is_available() and torch.cuda.device_count() > 0:
+        local %= torch.cuda.device_count()
+    return local
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: become the launcher.  Re-executes this command
+    under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU, the
+    reference's own env rendezvous: train_tensoIR.py:22-27 reads RANK / WORLD_SIZE / MASTER_* the same way) and exits with
+    the launcher's return code; rank 0's JSON line is the child's stdout, passed through."""
+    import socket
+    import subprocess
+    if torch.cuda.is_available() and torch.cuda.device_count() < a.gpus and not a.allow_shared_gpu:
+        raise SystemExit(f"[bench] --gpus {a.gpus} but only {torch.cuda.device_count()} visible GPU(s) "
+                         "(--allow-shared-gpu: plumbing runs of several ranks on one device, not a measurement)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    env["TENSOIR_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print(f"[bench] --gpus {a.gpus} without a launcher environment: starting {a.gpus} ranks: {' '.join(cmd[1:9])} bench.py ...",
+          file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def check_launch(a):
-    """--gpus N must be the number of ranks actually launched, each with a GPU of its own: a scaling
-    line must not be printable from fewer processes or devices than it claims."""
+    """--gpus N must be the number of ranks actually running, each with a GPU of its own: a scaling
+    line must not be printable from fewer processes or devices than it claims.  A bare `python bench.py --gpus N` (no
+    WORLD_SIZE / RANK in the environment) starts its N ranks itself (self_launch); a launcher environment whose WORLD_SIZE
+    differs from --gpus is refused."""
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        self_launch(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
         raise SystemExit(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU, e.g. python -m "
-                         f"torch.distributed.run --nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus}")
+                         f"torch.distributed.run --nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} "
+                         f"(or unset WORLD_SIZE / RANK and bench.py starts its ranks itself)")
     if torch.cuda.is_available() and torch.cuda.device_count() < world and not a.allow_shared_gpu:
         raise SystemExit(f"[bench] {world} ranks but only {torch.cuda.device_count()} visible GPU(s) "
                          "(--allow-shared-gpu: plumbing tests of several ranks on one device, not a measurement)")
+    if world > 1:
+        print(f"[bench] rank {os.environ.get('RANK', '0')}/{world} up (local rank {os.environ.get('LOCAL_RANK', '0')}, "
+              f"backend {a.backend})", file=sys.stderr, flush=True)
 
 
 def main():
@@ -966,9 +1010,9 @@ def main():
         return bench_train(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: tensoir_amd has no CPU path")
+    local = local_device(a)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist

@@ -45,8 +45,26 @@ def test_no_gpu_is_an_error_not_a_fallback():
 
 
 def test_scaling_line_needs_its_ranks():
+    """A launcher environment that disagrees with --gpus is refused (a 2-GPU line must not come from one rank)."""
     r = _bench("--gpus", "2", "--steps", "1", env={"WORLD_SIZE": "1"})
     assert r.returncode != 0 and "2" in (r.stderr + r.stdout)
+    assert "starting 2 ranks" not in r.stderr
+
+
+def test_bare_multi_gpu_invocation_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE / RANK in the environment re-executes itself under
+    torch.distributed.run with one rank per GPU.  On this box (no GPU) both ranks come up, say so, and fail loudly -- the
+    launch itself is what is checked here; tests/test_gpu_multirank.py and tools/two_rank_gloo.sh run it on hardware."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-box check")
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=600, env=e)
+    assert r.returncode != 0
+    assert "starting 2 ranks" in r.stderr and "--nproc-per-node=2" in r.stderr and "--master-addr 127.0.0.1" in r.stderr
+    assert "rank 0/2 up" in r.stderr and "rank 1/2 up" in r.stderr
+    assert r.stderr.count("bench.py needs a GPU") >= 1 and not any(l.startswith('{"metric"') for l in r.stdout.splitlines())
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_v9_*bench.json"))))
