@@ -83,6 +83,8 @@ def parse():
                          "row tiles the ranks that hold the object set the pace, SURVEY 8e), row tiles on one rank")
     ap.add_argument("--image-side", type=int, default=800)
     ap.add_argument("--allow-shared-gpu", action="store_true", help="let several ranks share one GPU (gloo plumbing tests only)")
+    ap.add_argument("--no-side-workloads", action="store_true",
+                    help="batch workload, one GPU: skip the reduced-repetition image / relight / train lines of the `workloads` block")
     ap.add_argument("--force-dist", action="store_true",
                     help="single process: create a 1-rank RCCL group anyway and run the multi-rank code path (all-gather per step)")
     return ap.parse_args()

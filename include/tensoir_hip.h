@@ -75,6 +75,18 @@ typedef struct TirField {
     int32_t tune_xcd_order;  /* contiguous per-XCD work ranges in the gathers / secondary march: 0 = default (off), 1 = on, 2 = off */
 } TirField;
 
+/* fp16 shadow of the appearance planes / lines (same channel-last element order as TirField::aplane / aline; 16-byte aligned),
+ * produced by tir_pack_half and read by tir_vm_app_fwd_h16. */
+typedef struct TirFieldHalf {
+    const void* aplane[3];   /* [H_i][W_i][n_acomp] fp16 */
+    const void* aline[3];    /* [R_i][n_acomp]      fp16 */
+} TirFieldHalf;
+
+/* (internal launch records of tir_pack_half) */
+#define TIR_HALF_MAX_JOBS 8
+typedef struct TirHalfJob { const float* src; void* dst; int64_t n; } TirHalfJob;
+typedef struct TirHalfJobs { TirHalfJob job[TIR_HALF_MAX_JOBS]; } TirHalfJobs;
+
 /* One 3-layer decoder (in -> hidden ReLU -> hidden ReLU -> out, then activation):
  * MLPRender_Fea / MLPBRDF_PEandFeature (models/tensorBase_rotated_lights.py:122-146, :182-208).
  * `packed` is produced by tir_pack_mlp. */
@@ -203,6 +215,20 @@ int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, 
                        const int32_t* aux_map, int32_t aux_mod, float* out, int64_t n, const int32_t* n_dev,
         void* stream);
 
+/* ---- precision policy for INDIRECT light (the radiance of the secondary-ray records, models/relight_utils.py:818-832).
+ *      tir_pack_half: fp32 -> fp16 copies (round to nearest even) of up to TIR_HALF_MAX_JOBS tables in one launch; srcs /
+ *      dsts / counts are HOST arrays, tables 16-byte aligned.
+ *      tir_vm_app_fwd_h16 = tir_vm_app_fwd(rad_feat only) for n_acomp == 48 on the fp16 shadow `fh` of f->aplane / f->aline:
+ *      half the bytes through the vector L1 (the bound of the fp32 gather), interpolation and light-row product in fp32, the
+ *      basis_mat contraction on v_mfma_f32_32x32x16_f16 (operands rounded to 11 bits, fp32 accumulate).  ~2e-4 relative on a
+ *      feature: NOT parity grade on its own -- the product path uses it only for the secondary-ray records, whose radiance is
+ *      averaged over a ray's records and the light directions before it reaches rgb_with_brdf_map.  Other arguments as
+ *      tir_vm_app_fwd. */
+int tir_pack_half(const float* const* srcs, void* const* dsts, const int64_t* counts, int32_t n_tables, void* stream);
+int tir_vm_app_fwd_h16(const TirField* f, const TirFieldHalf* fh, const float* xyz, const int32_t* light_idx,
+                       const int32_t* idx_map, float* rad_feat, int32_t out_stride, int32_t idx_div, int64_t n,
+                       const int32_t* n_dev, void* stream);
+
 /* Up to four decoders over the SAME n rows in one launch (split-bf16 matrix cores): the primary stage evaluates the
  * radiance, BRDF, jittered-BRDF and normal decoders (models/tensorBase_rotated_lights.py:927-955) on the same records.
  * mlps / feats / auxs / aux_maps / outs are HOST arrays of n_jobs entries (aux_maps or its entries may be NULL); feature
@@ -224,6 +250,13 @@ int tir_mlp_aux_table(const TirMlp* m, const float* aux, int64_t n_aux, float* t
 int tir_mlp_fwd_auxtab_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* table,
                               const int32_t* aux_map, int32_t aux_mod, float* out, int64_t n, const int32_t* n_dev,
                               void* stream);
+/* The aux-table decoder with ONE fp16 product per tile (v_mfma_f32_32x32x16_f16; operands rounded to 11 bits, fp32 accumulate,
+ * layer 3 exact fp32): a third of the matrix work of tir_mlp_fwd_auxtab_bf16x3 at ~1e-4 absolute error per decoder output.
+ * NOT parity grade by itself: meant for the radiance of the secondary-ray records (models/relight_utils.py:818-832), whose
+ * error is averaged over a ray's records and the light directions before it reaches rgb_with_brdf_map.  Same arguments. */
+int tir_mlp_fwd_auxtab_f16(const TirMlp* m, const float* feat, int32_t feat_stride, const float* table,
+                           const int32_t* aux_map, int32_t aux_mod, float* out, int64_t n, const int32_t* n_dev,
+                           void* stream);
 /* The same launch for the training forward (h1, h2 [n][128] post-ReLU, as tir_mlp_train_fwd_bf16x3).  With aux_map == NULL and
  * aux_mod == 0 the table has one row PER DECODER ROW: that is how normals_kind == 'residue_prediction' is evaluated -- its decoder
  * MLPNormal_normal_and_PExyz (models/tensorBase_rotated_lights.py:236-262) feeds the derived normal as three more inputs of layer 1,

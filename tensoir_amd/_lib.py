@@ -33,6 +33,10 @@ class TirField(C.Structure):
     ]
 
 
+class TirFieldHalf(C.Structure):
+    _fields_ = [("aplane", C.c_void_p * 3), ("aline", C.c_void_p * 3)]
+
+
 class TirFieldGrad(C.Structure):
     _fields_ = [("dplane", C.c_void_p * 3), ("dline", C.c_void_p * 3), ("aplane", C.c_void_p * 3),
                 ("aline", C.c_void_p * 3), ("light_line", C.c_void_p), ("light_mean", C.c_void_p)]
@@ -71,6 +75,8 @@ SIGNATURES = {
     "tir_density_grad_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, I64, P, P]),
     "tir_vm_app_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I32, I64, P, P]),
     "tir_vm_app_fwd_bf16x3": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I32, I64, P, P]),
+    "tir_pack_half": (C.c_int, [P, P, P, I32, P]),
+    "tir_vm_app_fwd_h16": (C.c_int, [C.POINTER(TirField), C.POINTER(TirFieldHalf), P, P, P, P, I32, I32, I64, P, P]),
     "tir_vm_app_fwd_valu": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I32, I64, P, P]),
     "tir_mlp_fwd": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P, P]),
     "tir_mlp_fwd_bf16x3": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P, P]),
@@ -78,6 +84,7 @@ SIGNATURES = {
     "tir_mlp_fwd_multi_auxtab_bf16x3": (C.c_int, [P, P, I32, P, P, P, P, I32, I64, P, P]),
     "tir_mlp_aux_table": (C.c_int, [C.POINTER(TirMlp), P, I64, P, P]),
     "tir_mlp_fwd_auxtab_bf16x3": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P, P]),
+    "tir_mlp_fwd_auxtab_f16": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P, P]),
     "tir_mlp_train_fwd_auxtab_bf16x3": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, P, P, I64, P, P]),
     "tir_mlp_train_fwd_multi_bf16x3": (C.c_int, [P, P, I32, P, P, P, P, P, I32, I64, P, P]),
     "tir_mlp_fwd_bf16": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P, P]),

@@ -776,6 +776,153 @@ k_vm_app_bf16(TirField f, const float* __restrict__ xyz, const int32_t* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// K4 for the SECONDARY-ray records (indirect light, models/relight_utils.py:818-829) on fp16 storage and fp16 matrix
+// operands, fp32 arithmetic and accumulation (precision policy).
+//
+// The fp32 gather above is bound by the L1 fill rate (64 B/clk/CU: 3 456 B per record = 12 GB per bench step through the
+// vector L1s, 0.63 of the chip's 34.5 TB/s) with the exact-fp32 contraction (72 v_mfma_f32_16x16x4_f32 per 16 records) as the
+// second bound.  Here the taps come from an fp16 shadow of the appearance planes / lines (tir_pack_half: same channel-last
+// layout, 96 B per texel -> half the bytes through the L1), two lanes per record each owning every other 16-byte chunk of
+// a tap (32 records per wave pass, the same 54 load instructions per lane), interpolation and the light-row product in fp32
+// (v_fma_mix_f32 reads the half operands in place: no conversion instructions), the products rounded once to fp16 into a
+// per-wave LDS tile [record][channel] and contracted against an fp16 image of basis_mat^T with v_mfma_f32_32x32x16_f16:
+// 9 matrix instructions of 8 passes per 32 records instead of 144 of 8.  Unit roundoff 2^-12 on the stored taps, on the
+// products and on basis_mat; the features feed the single-product fp16 decoder, which rounds its inputs the same way.
+// NOT parity grade on a feature by itself (~2e-4 relative): used only where the radiance is averaged over a secondary ray's
+// records and 128+ light directions before it reaches rgb_with_brdf_map (measured there: profiles/r04_precision_policy.json).
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 app_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 app_f16x2 __attribute__((ext_vector_type(2)));
+typedef float app_f32x16 __attribute__((ext_vector_type(16)));
+typedef float app_f32x2 __attribute__((ext_vector_type(2)));
+#define TIR_XH 56      // record stride of the fp16 X tile in halves (48 channels + 8: 112-B rows keep ds_read_b128 conflict-free)
+
+__global__ void k_pack_half(TirHalfJobs jobs) {
+    const TirHalfJob jb = jobs.job[blockIdx.y];
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i >= jb.n) return;
+    _Float16* dst = reinterpret_cast<_Float16*>(jb.dst);
+    if (i + 8 <= jb.n) {
+        const float4 a = ld4(jb.src + i), b = ld4(jb.src + i + 4);
+        app_f16x8 h = {(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w, (_Float16)b.x, (_Float16)b.y, (_Float16)b.z, (_Float16)b.w};
+        *reinterpret_cast<app_f16x8*>(dst + i) = h;
+    } else {
+        for (int64_t e = i; e < jb.n; ++e) dst[e] = (_Float16)jb.src[e];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_vm_app_h16(TirField f, TirFieldHalf fh, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
+             const int32_t* __restrict__ idx_map, float* __restrict__ rad_feat, int out_stride, int idx_div, int64_t n,
+             const int32_t* __restrict__ n_dev, int xcd_on, int lt_rows) {
+    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
+    constexpr int CA = 48, NQ = 3;                          // 6 16-byte chunks per tap, two lanes per record
+    extern __shared__ __attribute__((aligned(16))) float lds_app[];
+    // basis_mat^T as A-operand tiles: [group 3][k-step 3][k-group 2][row 32] x 8 halves
+    app_f16x8* Wh = reinterpret_cast<app_f16x8*>(lds_app);
+    float* LT = lds_app + (3 * 3 * 2 * 32 * 8) / 2;         // light rows, fp32: [n_lt rows of light_line | light_mean] x 144
+    const int n_lt = lt_rows;
+    const int wave = threadIdx.x >> 6, L = threadIdx.x & 63;
+    _Float16* X = reinterpret_cast<_Float16*>(LT + (n_lt + 1) * (3 * CA)) + wave * (32 * TIR_XH);
+    for (int e = threadIdx.x; e < 3 * 3 * 2 * 32; e += 256) {
+        const int row = e & 31, kg = (e >> 5) & 1, t = (e >> 6) % 3, k = e / 192;
+        app_f16x8 h;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) h[q] = (_Float16)f.basis_t[(size_t)(k * CA + 16 * t + 8 * kg + q) * 32 + row];
+        Wh[e] = h;
+    }
+    for (int i = threadIdx.x * 4; i < n_lt * 3 * CA; i += 256 * 4)
+        *reinterpret_cast<float4*>(LT + i) = *reinterpret_cast<const float4*>(f.light_line + i);
+    for (int i = threadIdx.x * 4; i < 3 * CA; i += 256 * 4)
+        *reinterpret_cast<float4*>(LT + n_lt * 3 * CA + i) = *reinterpret_cast<const float4*>(f.light_mean + i);
+    __syncthreads();
+    const int j = L >> 1, c = L & 1;          // gather role: record slot, which of every two 16-byte chunks
+    const int col = L & 31, kg = L >> 5;      // MFMA role: record column / feature row, k group
+    const int64_t n_pass = (n + 31) / 32;
+    const XcdRange xr = xcd_range_at(n_pass, 4, xcd_on != 0, (int)blockIdx.x, (int)gridDim.x);
+    for (int64_t pass = xr.first + wave; pass < xr.end; pass += xr.stride) {
+        const int64_t s = pass * 32 + j;
+        const int64_t sc = s < n ? s : n - 1;
+        const float p[3] = {xyz[3 * sc], xyz[3 * sc + 1], xyz[3 * sc + 2]};
+        int64_t lsel = idx_map ? (int64_t)idx_map[sc] : sc;
+        if (idx_div > 1) lsel /= idx_div;
+        int li = light_idx[lsel];
+        li = min(max(li, 0), f.n_lights - 1);
+        const float* lrow = n_lt ? LT + li * (3 * CA) : f.light_line + (size_t)li * (3 * CA);
+        app_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll 1
+        for (int k = 0; k < 3; ++k) {
+            const int H = f.grid[(k == 0) ? 1 : 2], W = f.grid[(k == 2) ? 1 : 0], R = f.grid[2 - k];
+            const float u = (k == 2) ? p[1] : p[0], v = (k == 0) ? p[1] : p[2], w = (k == 0) ? p[2] : ((k == 1) ? p[1] : p[0]);
+            Tap1 tx = make_tap(u, W), ty = make_tap(v, H), tl = make_tap(w, R);
+            const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
+            const _Float16* pl = reinterpret_cast<const _Float16*>(fh.aplane[k]);
+            const _Float16* ln = reinterpret_cast<const _Float16*>(fh.aline[k]);
+            const unsigned r0 = (unsigned)(ty.i0 * W) * CA, r1 = (unsigned)(ty.i1 * W) * CA;     // 32-bit element offsets
+            const unsigned x0 = (unsigned)tx.i0 * CA + 8 * c, x1 = (unsigned)tx.i1 * CA + 8 * c;
+            const _Float16* p00 = pl + (r0 + x0);
+            const _Float16* p01 = pl + (r0 + x1);
+            const _Float16* p10 = pl + (r1 + x0);
+            const _Float16* p11 = pl + (r1 + x1);
+            const _Float16* l0 = ln + ((unsigned)tl.i0 * CA + 8 * c);
+            const _Float16* l1 = ln + ((unsigned)tl.i1 * CA + 8 * c);
+            // all 18 taps of the group in flight before the first is used (as in the fp32 gather)
+            app_f16x8 ta[NQ], tb[NQ], tc[NQ], td[NQ], te[NQ], tg[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                ta[q] = *reinterpret_cast<const app_f16x8*>(p00 + 16 * q); tb[q] = *reinterpret_cast<const app_f16x8*>(p01 + 16 * q);
+                tc[q] = *reinterpret_cast<const app_f16x8*>(p10 + 16 * q); td[q] = *reinterpret_cast<const app_f16x8*>(p11 + 16 * q);
+                te[q] = *reinterpret_cast<const app_f16x8*>(l0 + 16 * q);  tg[q] = *reinterpret_cast<const app_f16x8*>(l1 + 16 * q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int ch0 = 16 * q + 8 * c;            // this lane's 8 channels of chunk pair q
+                const float4 lr0 = ld4(lrow + k * CA + ch0), lr1 = ld4(lrow + k * CA + ch0 + 4);
+                const float lr[8] = {lr0.x, lr0.y, lr0.z, lr0.w, lr1.x, lr1.y, lr1.z, lr1.w};
+                unsigned pk[4];
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    float val[2];
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) {
+                        const float pv = fmaf((float)td[q][e + o], w11, fmaf((float)tc[q][e + o], w10,
+                                         fmaf((float)tb[q][e + o], w01, (float)ta[q][e + o] * w00)));
+                        const float lv = fmaf((float)tg[q][e + o], tl.w1, (float)te[q][e + o] * tl.w0);
+                        val[o] = (pv * lv) * lr[e + o];
+                    }
+                    const app_f32x2 v2 = {val[0], val[1]};
+                    pk[e >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, app_f16x2));
+                }
+                *reinterpret_cast<uint4*>(X + j * TIR_XH + ch0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            }
+            __builtin_amdgcn_wave_barrier();      // LDS ops of one wave complete in order; keep the compiler from reordering
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const app_f16x8 a = Wh[((k * 3 + t) * 2 + kg) * 32 + col];
+                const app_f16x8 b = *reinterpret_cast<const app_f16x8*>(X + col * TIR_XH + 16 * t + 8 * kg);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // D layout: column = record col, rows (features) 8 i + 4 kg + (0..3) in registers 4 i .. 4 i + 3
+        const int64_t so = pass * 32 + col;
+        if (so < n) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row0 = 8 * i + 4 * kg;
+                float* o = rad_feat + so * out_stride + row0;
+                if (row0 + 4 <= out_stride && (out_stride & 3) == 0)
+                    *reinterpret_cast<float4*>(o) = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
+                else for (int r = 0; r < 4; ++r) if (row0 + r < out_stride) o[r] = acc[4 * i + r];
+            }
+        }
+    }
+}
+
 template <int C4>
 static int launch_app_bf16(const TirField* f, const float* xyz, const int32_t* li, const int32_t* map,
                            float* rad, float* intr, int stride, int idx_div, int64_t n, const int32_t* n_dev, hipStream_t s) {
@@ -919,4 +1066,46 @@ extern "C" int tir_vm_app_fwd_bf16x3(const TirField* f, const float* xyz, const 
                                      const int32_t* idx_map, float* rad_feat, float* int_feat, int32_t out_stride,
                                      int32_t idx_div, int64_t n, const int32_t* n_dev, void* stream) {
     return app_fwd(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, stream, false, true);
+}
+
+// fp32 -> fp16 copies of up to 8 tables in one launch (same element order): the shadow planes / lines of tir_vm_app_fwd_h16
+extern "C" int tir_pack_half(const float* const* srcs, void* const* dsts, const int64_t* counts, int32_t n_tables, void* stream) {
+    if (n_tables < 0 || n_tables > TIR_HALF_MAX_JOBS || (n_tables > 0 && (!srcs || !dsts || !counts))) return TIR_ERR_ARG;
+    if (n_tables == 0) return TIR_OK;
+    TirHalfJobs jobs;
+    int64_t most = 0;
+    for (int i = 0; i < n_tables; ++i) {
+        if (counts[i] < 0 || (counts[i] > 0 && (!srcs[i] || !dsts[i]))) return TIR_ERR_ARG;
+        if (reinterpret_cast<uintptr_t>(srcs[i]) % 16 != 0 || reinterpret_cast<uintptr_t>(dsts[i]) % 16 != 0) return TIR_ERR_ARG;
+        jobs.job[i] = TirHalfJob{srcs[i], dsts[i], counts[i]};
+        most = counts[i] > most ? counts[i] : most;
+    }
+    if (most == 0) return TIR_OK;
+    hipLaunchKernelGGL(k_pack_half, dim3((unsigned)((most + 2047) / 2048), (unsigned)n_tables), dim3(256), 0, tir_stream(stream), jobs);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_vm_app_fwd_h16(const TirField* f, const TirFieldHalf* fh, const float* xyz, const int32_t* light_idx,
+                                  const int32_t* idx_map, float* rad_feat, int32_t out_stride, int32_t idx_div, int64_t n,
+                                  const int32_t* n_dev, void* stream) {
+    if (!f || !fh) return TIR_ERR_ARG;
+    for (int i = 0; i < 3; ++i)
+        if (f->grid[i] < 2 || !fh->aplane[i] || !fh->aline[i] || reinterpret_cast<uintptr_t>(fh->aplane[i]) % 16 != 0 ||
+            reinterpret_cast<uintptr_t>(fh->aline[i]) % 16 != 0) return TIR_ERR_ARG;
+    if (!f->basis_t || !f->light_mean || !f->light_line) return TIR_ERR_ARG;
+    if (f->n_acomp != 48 || f->app_dim < 1 || f->app_dim > 27) return TIR_ERR_UNSUPPORTED;
+    if (out_stride < f->app_dim || out_stride > 32) return TIR_ERR_ARG;
+    if (n < 0 || (n > 0 && (!xyz || !rad_feat || !light_idx))) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    const int lt_rows = f->n_lights <= 16 ? f->n_lights : 0;
+    const size_t lds = (size_t)(3 * 3 * 2 * 32) * 16 + (size_t)(lt_rows + 1) * 144 * sizeof(float) + (size_t)4 * 32 * TIR_XH * 2;
+    int64_t blocks = (n + 127) / 128;
+    if (blocks > 2048) blocks = 2048;
+    const int xcd_on = tir_xcd_mapping(f);
+    if (xcd_on) blocks = (blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL(k_vm_app_h16, dim3((unsigned)blocks), dim3(256), lds, tir_stream(stream), *f, *fh, xyz, light_idx, idx_map,
+                       rad_feat, out_stride, idx_div, n, n_dev, xcd_on, lt_rows);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
 }

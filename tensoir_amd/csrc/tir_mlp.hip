@@ -49,7 +49,8 @@ constexpr int FP32_TOTAL = OFF_RB2 + 4;
 constexpr int KB0 = (HALF + 7) / 8;             // 10 k-blocks of 16 for layer 1 (75 -> 80 per half)
 constexpr int KB1 = 64 / 8;                     // 8 k-blocks for layer 2
 constexpr int W2A_STRIDE = 68;
-constexpr int BH_B0 = 0, BH_B1 = 128, BH_W2 = 256, BH_B2 = BH_W2 + 2 * 4 * W2A_STRIDE, BH_FLOATS = BH_B2 + 8;
+[[maybe_unused]] constexpr int BH_B0 = 0;
+constexpr int BH_B1 = 128, BH_W2 = 256, BH_B2 = BH_W2 + 2 * 4 * W2A_STRIDE, BH_FLOATS = BH_B2 + 8;
 constexpr int BW0_ELEMS = KB0 * 2 * 4 * 32 * 8; // 20480 bf16
 constexpr int BW1_ELEMS = KB1 * 2 * 4 * 32 * 8; // 16384 bf16
 constexpr int BF_BYTES = BH_FLOATS * 4 + (2 * BW0_ELEMS + 2 * BW1_ELEMS) * 2;   // 150,560 B
@@ -67,8 +68,18 @@ constexpr int BW0A_ELEMS = KB0A * 2 * 4 * 32 * 8;                               
 constexpr int BFA_BYTES = BH_FLOATS * 4 + (2 * BW0A_ELEMS + 2 * BW1_ELEMS) * 2; // 142,368 B
 constexpr int BFA_FLOATS = BFA_BYTES / 4;
 constexpr int OFF_BFA = OFF_BF + BF_FLOATS;
-constexpr int TOTAL_FLOATS = OFF_BFA + BFA_FLOATS;
+// Third image: the aux-table layout with ONE fp16 operand plane per layer (header | W0A f16 | W1 f16, 72,864 B) for the
+// single-product fp16 decoder (k_mlp_f16_auxt, v_mfma_f32_32x32x16_f16): 11-bit operands, one MFMA per tile and k-block
+// instead of three.  Unit roundoff 2^-12 per operand (bf16 single product: 2^-9): ~1e-4 on a decoder output -- NOT parity
+// grade on its own; the product path uses it only where the output is averaged down before it reaches a rendered map (the
+// radiance of the secondary-ray records, i.e. indirect light: models/relight_utils.py:818-832), see DESIGN section 4.1.
+constexpr int FH_BYTES = BH_FLOATS * 4 + (BW0A_ELEMS + BW1_ELEMS) * 2;          // 72,864 B
+constexpr int FH_FLOATS = FH_BYTES / 4;
+constexpr int OFF_FH = OFF_BFA + BFA_FLOATS;
+constexpr int TOTAL_FLOATS = OFF_FH + FH_FLOATS;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
 // reference input index (models/tensorBase_rotated_lights.py:137-142, :12-17) handled at step t by half h
 __host__ __device__ inline int kperm(int t, int h) {
@@ -130,9 +141,10 @@ __global__ void k_pack_mlp(const float* __restrict__ w0, const float* __restrict
     else if (i < OFF_RB2) { int j = i - OFF_RW2; v = (j / HID < out_dim) ? w2[j] : 0.0f; }
     else if (i < FP32_TOTAL) { int o = i - OFF_RB2; v = (o < out_dim) ? b2[o] : 0.0f; }
     else {
+        const bool f16 = i >= OFF_FH;           // the fp16 image: aux-table layout, one operand plane per layer
         const bool auxt = i >= OFF_BFA;         // the aux-table image: same header and W1 planes, 9-block W0 planes
         const int bw0 = auxt ? BW0A_ELEMS : BW0_ELEMS;
-        int j = i - (auxt ? OFF_BFA : OFF_BF);  // float slot inside the bf16 image
+        int j = i - (f16 ? OFF_FH : auxt ? OFF_BFA : OFF_BF);  // float slot inside the image
         if (j < BH_FLOATS) {
             if (j < BH_B1) v = b0[unit_of(j % 64, j / 64)];
             else if (j < BH_W2) { int q = j - BH_B1; v = b1[unit_of(q % 64, q / 64)]; }
@@ -146,7 +158,11 @@ __global__ void k_pack_mlp(const float* __restrict__ w0, const float* __restrict
             for (int t = 0; t < 2; ++t) {
                 int e_all = (j - BH_FLOATS) * 2 + t;
                 int sec, idx;
-                if (e_all < bw0) { sec = 0; idx = e_all; }
+                if (f16) {
+                    if (e_all < bw0) { sec = 0; idx = e_all; }
+                    else { sec = 2; idx = e_all - bw0; }
+                }
+                else if (e_all < bw0) { sec = 0; idx = e_all; }
                 else if (e_all < 2 * bw0) { sec = 1; idx = e_all - bw0; }
                 else if (e_all < 2 * bw0 + BW1_ELEMS) { sec = 2; idx = e_all - 2 * bw0; }
                 else { sec = 3; idx = e_all - 2 * bw0 - BW1_ELEMS; }
@@ -157,6 +173,10 @@ __global__ void k_pack_mlp(const float* __restrict__ w0, const float* __restrict
                 else if (sec < 2) wv = (kk < HALF) ? w0[(mt * 32 + ii) * IN + kperm(kk, h)]
                                               : ((kk == HALF && h == 0) ? b0[mt * 32 + ii] : 0.0f);   // bias slot (input = 1)
                 else wv = w1[(mt * 32 + ii) * HID + unit_of(kk, h)];
+                if (f16) {
+                    hw[t] = __builtin_bit_cast(unsigned short, (_Float16)wv);
+                    continue;
+                }
                 __bf16 hi = (__bf16)wv;
                 __bf16 r = (sec & 1) ? (__bf16)(wv - (float)hi) : hi;
                 hw[t] = __builtin_bit_cast(unsigned short, r);
@@ -450,9 +470,26 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 // ---- per k-block: [issue the A-tile LDS reads] [build that block's 8 inputs on the VALU] [12 MFMAs].
 // The MFMAs of block kb execute on the matrix pipe while the wave's VALU already builds block kb+1 (intra-wave overlap
 // instead of "all inputs, then all MFMAs"), the input build covers the LDS latency, and only one block of inputs is live.
-template <int NPROD>
+// 8 floats -> one fp16 operand vector (round to nearest even: v_cvt_pk_f16_f32), carried in the bf16x8 register type
+__device__ __forceinline__ void cvt8_f16(const float* v, bf16x8& x) {
+    u32x4_t H;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const f32x2_t f = {v[2 * p], v[2 * p + 1]};
+        H[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(f, f16x2_t));
+    }
+    x = __builtin_bit_cast(bf16x8, H);
+}
+
+template <int NPROD, bool F16 = false>
 __device__ __forceinline__ void mfma12(const bf16x8 (&ah)[4], const bf16x8 (&al)[4], const bf16x8& bh, const bf16x8& bl,
                                        f32x16 (&acc)[4]) {
+    if constexpr (F16) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[mt]), __builtin_bit_cast(f16x8, bh), acc[mt], 0, 0, 0);
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh, acc[mt], 0, 0, 0);
     if (NPROD == 3) {
@@ -463,7 +500,7 @@ __device__ __forceinline__ void mfma12(const bf16x8 (&ah)[4], const bf16x8 (&al)
     }
 }
 
-template <int NPROD, int KB, bool AUXT = false>
+template <int NPROD, int KB, bool AUXT = false, bool F16 = false>
 __device__ __forceinline__ void layer1_interleaved(unsigned whi, unsigned wlo, int h,
                                                    const float (&ft)[F + 1], const float (&ax)[3], const AuxPE& ap, float hq,
                                                    f32x16 (&acc)[4]) {
@@ -478,14 +515,22 @@ __device__ __forceinline__ void layer1_interleaved(unsigned whi, unsigned wlo, i
     build_pair<KB, 2, AUXT>(ft, ax, ap, h, hq, v);
     build_pair<KB, 4, AUXT>(ft, ax, ap, h, hq, v);
     build_pair<KB, 6, AUXT>(ft, ax, ap, h, hq, v);
-    bf16x8 xh, xl;
-    split8(v, xh, xl);
-    mfma12<NPROD>(ah, al, xh, xl, acc);
+    bf16x8 xh, xl = {};
+    if constexpr (F16) cvt8_f16(v, xh); else split8(v, xh, xl);
+    mfma12<NPROD, F16>(ah, al, xh, xl, acc);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (KB + 1 < (AUXT ? KB0A : KB0)) layer1_interleaved<NPROD, KB + 1, AUXT>(whi, wlo, h, ft, ax, ap, hq, acc);
+    if constexpr (KB + 1 < (AUXT ? KB0A : KB0)) layer1_interleaved<NPROD, KB + 1, AUXT, F16>(whi, wlo, h, ft, ax, ap, hq, acc);
 }
 
-template <int NPROD, int KB>
+// ReLU that also saturates at the largest finite fp16 (one v_med3_f32, the same issue slot as the plain ReLU): the hidden
+// activations of the fp16 decoder are rounded to fp16 operands, and a value above 65504 would turn into +inf there.
+__device__ __forceinline__ float relu_sat16(float x) {
+    float r;
+    asm("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(65504.0f));
+    return r;
+}
+
+template <int NPROD, int KB, bool F16 = false>
 __device__ __forceinline__ void layer2_interleaved(unsigned whi, unsigned wlo,
                                                    const f32x16 (&hid)[4], f32x16 (&acc)[4]) {
     bf16x8 ah[4], al[4];
@@ -496,12 +541,15 @@ __device__ __forceinline__ void layer2_interleaved(unsigned whi, unsigned wlo,
     }
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { constexpr int q0 = KB * 8; v[e] = relu(hid[(q0 + e) >> 4][(q0 + e) & 15]); }
-    bf16x8 xh, xl;
-    split8(v, xh, xl);
-    mfma12<NPROD>(ah, al, xh, xl, acc);
+    for (int e = 0; e < 8; ++e) {
+        constexpr int q0 = KB * 8;
+        v[e] = F16 ? relu_sat16(hid[(q0 + e) >> 4][(q0 + e) & 15]) : relu(hid[(q0 + e) >> 4][(q0 + e) & 15]);
+    }
+    bf16x8 xh, xl = {};
+    if constexpr (F16) cvt8_f16(v, xh); else split8(v, xh, xl);
+    mfma12<NPROD, F16>(ah, al, xh, xl, acc);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (KB + 1 < KB1) layer2_interleaved<NPROD, KB + 1>(whi, wlo, hid, acc);
+    if constexpr (KB + 1 < KB1) layer2_interleaved<NPROD, KB + 1, F16>(whi, wlo, hid, acc);
 }
 
 // one sample's decoder inputs as they come from memory: 27 features (+ zero pad) and the 3 aux values
@@ -537,7 +585,8 @@ __device__ __forceinline__ int64_t aux_index(const int32_t* __restrict__ aux_map
 // the decoder for the workgroup `bid` of `nblk` cooperating on one (decoder, row set) job
 // AUXT: `aux` is the fp32 table [n_aux][128] of tir_mlp_aux_table (layer-1 accumulators start from its row aux_index(s)
 // instead of 0, the matrix product skips the aux columns and the bias slot: 9 k-blocks), not the [n_aux][3] aux values.
-template <int NPROD, bool VEC, bool SAVE, bool AUXT = false>
+// F16 (with AUXT, NPROD = 1): the single-product fp16 operand image (OFF_FH) instead of the bf16 hi / lo planes.
+template <int NPROD, bool VEC, bool SAVE, bool AUXT = false, bool F16 = false>
 __device__ __forceinline__ void
 mlp_bf16_body(const float* __restrict__ packed, const float* __restrict__ feat, int fstride, const float* __restrict__ aux,
               const int32_t* __restrict__ aux_map, int aux_mod, float* __restrict__ out, int64_t n,
@@ -545,9 +594,10 @@ mlp_bf16_body(const float* __restrict__ packed, const float* __restrict__ feat, 
               const int bid, const int nblk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int W0_ELEMS = AUXT ? BW0A_ELEMS : BW0_ELEMS;
+    static_assert(!F16 || (AUXT && NPROD == 1), "the fp16 image exists for the aux-table layout, one product");
     {
-        const float* src = packed + (AUXT ? OFF_BFA : OFF_BF);
-        for (int i = threadIdx.x * 4; i < (AUXT ? BFA_FLOATS : BF_FLOATS); i += 512 * 4)
+        const float* src = packed + (F16 ? OFF_FH : AUXT ? OFF_BFA : OFF_BF);
+        for (int i = threadIdx.x * 4; i < (F16 ? FH_FLOATS : AUXT ? BFA_FLOATS : BF_FLOATS); i += 512 * 4)
             *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(src + i);
     }
     const float* __restrict__ table = AUXT ? aux : nullptr;
@@ -561,8 +611,8 @@ mlp_bf16_body(const float* __restrict__ packed, const float* __restrict__ feat, 
     const unsigned lds0 = (unsigned)(size_t)lds;        // low 32 bits of a flat LDS-aperture address = the LDS byte address
     const unsigned lane_off = lds0 + BH_FLOATS * 4 + (unsigned)(h * 128 + sl) * 16;
     const unsigned w0hi = opaque(lane_off);
-    const unsigned w0lo = opaque(lane_off + W0_ELEMS * 2);
-    const unsigned w1hi = opaque(lane_off + W0_ELEMS * 4);
+    const unsigned w0lo = opaque(lane_off + W0_ELEMS * 2);             // (F16: no lo planes; the lo bases are never read)
+    const unsigned w1hi = opaque(lane_off + W0_ELEMS * (F16 ? 2 : 4));
     const unsigned w1lo = opaque(lane_off + W0_ELEMS * 4 + BW1_ELEMS * 2);
     const int64_t n_tiles = (n + 255) / 256;
     const int64_t G = nblk;
@@ -599,7 +649,11 @@ mlp_bf16_body(const float* __restrict__ packed, const float* __restrict__ feat, 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][r] = 0.0f;      // bias: the constant-1 input of k slot HALF
         }
-        layer1_interleaved<NPROD, 0, AUXT>(w0hi, w0lo, h, cur.ft, cur.ax, ap, 0.25f * (float)h, acc);
+        if constexpr (F16) {       // raw features enter layer 1 as fp16 operands: keep them finite there (|f| <= 65504)
+#pragma unroll
+            for (int d = 0; d < F; ++d) cur.ft[d] = __builtin_amdgcn_fmed3f(cur.ft[d], -65504.0f, 65504.0f);
+        }
+        layer1_interleaved<NPROD, 0, AUXT, F16>(w0hi, w0lo, h, cur.ft, cur.ax, ap, 0.25f * (float)h, acc);
         // the row registers are dead from here on: fetch the NEXT tile's row into them now, so that the global-load
         // latency (the features were just written by the gather kernel: L2 / HBM) hides behind layers 2 and 3
         if (tile + G < n_tiles) {
@@ -620,7 +674,7 @@ mlp_bf16_body(const float* __restrict__ packed, const float* __restrict__ feat, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[mt][r] = bp[r];
         }
-        layer2_interleaved<NPROD, 0>(w1hi, w1lo, acc, acc2);
+        layer2_interleaved<NPROD, 0, F16>(w1hi, w1lo, acc, acc2);
         // layer 2 has consumed the layer-1 values: the NEXT tile's accumulator start (table row of the row fetched above)
         // loads into the same registers now and arrives behind layer 3
         if (AUXT && tile + G < n_tiles) load_acc(cur.ai);
@@ -701,6 +755,16 @@ k_mlp_bf16_auxt(const float* __restrict__ packed, const float* __restrict__ feat
 // T[a][u] = b0[u] + sum over the 15 aux-dependent input columns of W0[u][col] x_col(aux_a): exact fp32 FMAs on the raw
 // weights, library sin / cos (the table is tiny: one row per ray or per light direction).  Column order of the reference
 // input (models/tensorBase_rotated_lights.py:137-142, :12-17): aux at F.., sin(PE aux) at F+3+2*NPF.., cos(PE aux) 3*PE later.
+// single-product fp16 form of the aux-table decoder (see FH_BYTES above): same lane decomposition, same layer 3 (exact fp32)
+template <bool VEC>
+__global__ void __launch_bounds__(512)
+k_mlp_f16_auxt(const float* __restrict__ packed, const float* __restrict__ feat, int fstride, const float* __restrict__ table,
+               const int32_t* __restrict__ aux_map, int aux_mod, float* __restrict__ out, int64_t n,
+               const int32_t* __restrict__ n_dev, int out_dim, int act) {
+    mlp_bf16_body<1, VEC, false, true, true>(packed, feat, fstride, table, aux_map, aux_mod, out, n, n_dev, out_dim, act, nullptr, nullptr,
+                                             (int)blockIdx.x, (int)gridDim.x);
+}
+
 __global__ void k_mlp_aux_table(const float* __restrict__ packed, const float* __restrict__ aux, int64_t n_aux,
                                 float* __restrict__ table) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1838,6 +1902,28 @@ extern "C" int tir_mlp_fwd_auxtab_bf16x3(const TirMlp* m, const float* feat, int
                                          const int32_t* aux_map, int32_t aux_mod, float* out, int64_t n, const int32_t* n_dev,
                                          void* stream) {
     return launch_auxtab<false>(m, feat, feat_stride, table, aux_map, aux_mod, out, nullptr, nullptr, n, n_dev, stream);
+}
+
+extern "C" int tir_mlp_fwd_auxtab_f16(const TirMlp* m, const float* feat, int32_t feat_stride, const float* table,
+                                      const int32_t* aux_map, int32_t aux_mod, float* out, int64_t n, const int32_t* n_dev,
+                                      void* stream) {
+    int rc = check_mlp(m);
+    if (rc) return rc;
+    if (n < 0 || feat_stride < F || (n > 0 && (!feat || !table || !out))) return TIR_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(table) % 16 != 0) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    const bool vec = (feat_stride % 4 == 0) && feat_stride >= F + 1 && (reinterpret_cast<uintptr_t>(feat) % 16 == 0);
+    const void* kfn = vec ? reinterpret_cast<const void*>(k_mlp_f16_auxt<true>) : reinterpret_cast<const void*>(k_mlp_f16_auxt<false>);
+    if (int r2 = tir_allow_dynamic_lds(kfn, (int)FH_BYTES)) return r2;
+    const int64_t tiles = (n + 255) / 256;
+    const int grid_max = m->tune_grid > 0 ? m->tune_grid : 256;
+    const unsigned grid = (unsigned)(tiles < grid_max ? tiles : grid_max);
+    if (vec) hipLaunchKernelGGL((k_mlp_f16_auxt<true>), dim3(grid), dim3(512), (size_t)FH_BYTES, tir_stream(stream), m->packed, feat,
+                                feat_stride, table, aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act);
+    else     hipLaunchKernelGGL((k_mlp_f16_auxt<false>), dim3(grid), dim3(512), (size_t)FH_BYTES, tir_stream(stream), m->packed, feat,
+                                feat_stride, table, aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
 }
 
 extern "C" int tir_mlp_train_fwd_auxtab_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, const float* table,

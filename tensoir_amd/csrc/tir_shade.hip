@@ -627,6 +627,6 @@ extern "C" int tir_device_check(void) {
     hipLaunchKernelGGL(k_probe, dim3(1), dim3(64), 0, 0, d);
     int h = 0;
     hipError_t e = hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost);
-    hipFree(d);
+    (void)hipFree(d);
     return (e == hipSuccess && h == 950) ? TIR_OK : TIR_ERR_NO_DEVICE;
 }

@@ -737,7 +737,6 @@ k_vm_app_bwd(TirField f, TirFieldGrad g, const float* __restrict__ xyz, const in
                 for (int cq = 0; cq < NCQ; ++cq) {
                     const bool chan = 16 * cq + c < CA;
                     const bool live = on && chan;
-                    const unsigned cb = chan ? 64u * cq : 0u;
                     const int ch = k * CA + (chan ? 16 * cq : 0) + c;      // channel of the 3*CA product vector
                     float lrv = 0.f, lmv = 0.f;
                     if (RAD) lrv = lds_light ? Lt[li * CA3 + ch] : f.light_line[(size_t)li * CA3 + ch];

@@ -576,6 +576,25 @@ class TensorVMSplit(nn.Module):
         self._field_cache, self._field_key = keep, key
         return f
 
+    def packed_field_half(self):
+        """TirFieldHalf: fp16 shadow of the appearance planes / lines for the indirect-light gather (ops.vm_app_h16), or None
+        when the field is not 48 components wide.  Built with one launch, cached with the packed field (same key: any
+        optimizer step, upsample, shrink or load rebuilds it)."""
+        from ._lib import TirFieldHalf
+        self.packed_field()
+        keep = self._field_cache
+        if "half" not in keep:
+            if self.app_n_comp[0] != 48:
+                keep["half"] = None
+            else:
+                src = [keep[f"ap{i}"] for i in range(3)] + [keep[f"al{i}"] for i in range(3)]
+                tabs = ops.pack_half(src)
+                fh = TirFieldHalf()
+                for i in range(3):
+                    fh.aplane[i], fh.aline[i] = tabs[i].data_ptr(), tabs[3 + i].data_ptr()
+                keep["half"] = (fh, tabs)
+        return keep["half"][0] if keep["half"] is not None else None
+
     # ---- per-point field functions (reference signatures) ---------------------------------------------
     def compute_densityfeature(self, xyz_sampled):
         """models/tensoRF_rotated_lights.py:95-110 -> tir_vm_density_fwd."""

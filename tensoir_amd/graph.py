@@ -83,7 +83,7 @@ class GraphedRenderer:
         # every light parameter: the general multi-light model keeps one SG set per light in a plain list
         lights = m.light_parameters()
         return (m._field_key, tuple((t.data_ptr(), t._version) for t in lights), tuple(d._key for d in decs),
-                float(m.march_t_stop), ops.MLP_IMPL)
+                float(m.march_t_stop), ops.MLP_IMPL, ops.secondary_mlp_impl(), ops.secondary_app_impl())
 
     def _stale(self):
         return self.graph is not None and self._key() != self._model_key
@@ -116,6 +116,7 @@ class GraphedRenderer:
                 self.model._app_cap_hints[k] = shrink
         self.checks = []
         self.model.__dict__["_capture"] = self.checks
+        self._keepalive = []           # tensors outside the graph's pool whose addresses the captured launches bake in (ops.CAPTURE_KEEPALIVE)
         g = torch.cuda.CUDAGraph()
         # No garbage collection while the stream is capturing: the collector may free objects that own device resources
         # (another renderer's graph, an event, pinned memory), and their destructors call into the runtime -- not permitted
@@ -123,6 +124,7 @@ class GraphedRenderer:
         gc.collect()
         gc_was_on = gc.isenabled()
         gc.disable()
+        ops.CAPTURE_KEEPALIVE = self._keepalive
         try:
             with torch.no_grad(), self._own_state(), torch.cuda.graph(g):
                 self.out = Renderer_TensoIR_train(self.rays, None, self.lidx, self.model, **self.kw)
@@ -134,6 +136,7 @@ class GraphedRenderer:
                     ops.record_check([t.reshape(1) for t, _, _ in self.checks], [c for _, c, _ in self.checks],
                                      self._state, self._host)
         finally:
+            ops.CAPTURE_KEEPALIVE = None
             self.model.__dict__.pop("_capture", None)
             if gc_was_on:
                 gc.enable()

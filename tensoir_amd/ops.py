@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import TirEnvSG, TirField, TirMlp, check, lib
+from ._lib import TirEnvSG, TirField, TirFieldHalf, TirMlp, check, lib
 
 MAP_STRIDE = 20
 
@@ -53,6 +53,42 @@ def mlp_aux_table(m: "PackedMlp", aux):
     _call("tir_mlp_aux_table", C.byref(m.desc), _ptr(aux), aux.shape[0], _ptr(table), _stream())
     return table
 
+
+
+# While a HIP graph is being captured (GraphedRenderer._capture sets this to a list it keeps for the graph's lifetime) every
+# cached table a captured launch reads is appended here: the graph bakes the table's raw address, so the tensor must outlive
+# its cache entry (the cache holds at most four tables per decoder and evicts on the fifth aux tensor).
+CAPTURE_KEEPALIVE = None
+
+
+def _aux_table_cached(m: "PackedMlp", aux):
+    """The per-aux-row layer-1 table of (decoder image, aux tensor version), computed once and kept with the packed decoder
+    (which is rebuilt whenever the weights change).  An entry remembers the stream that computed it and an event behind that
+    launch: a later user on ANOTHER stream waits for the event first (one model driven from several streams -- two batches in
+    flight -- must not read a table whose kernel has not run yet)."""
+    cache = m.__dict__.setdefault("_aux_tables", {})
+    key = (aux.data_ptr(), aux._version, aux.shape[0])
+    capturing = torch.cuda.is_current_stream_capturing()
+    hit = cache.get(key)
+    if hit is None:
+        if capturing:
+            # a miss inside a capture: the table is computed by a node of the graph itself and lives in the graph's pool
+            # (recomputed per replay; not cached -- an eager call must never see pool memory)
+            return mlp_aux_table(m, aux)
+        if len(cache) >= 4:
+            cache.clear()                # evicted tables stay alive wherever a captured graph holds them (CAPTURE_KEEPALIVE)
+        table = mlp_aux_table(m, aux)
+        ev = torch.cuda.Event()
+        ev.record()
+        # the aux tensor is held too: its address cannot be recycled for another tensor while the entry lives
+        hit = cache[key] = (aux, table, ev, _raw_stream(torch.cuda.current_device()) if _raw_stream else None)
+    elif not capturing and (_raw_stream is None or hit[3] != _raw_stream(torch.cuda.current_device())):
+        torch.cuda.current_stream().wait_event(hit[2])
+    # (capturing: GraphedRenderer drains the device after its eager warm-up passes and before the capture starts, so a cached
+    #  table is complete; an event recorded outside the capture must not be waited on inside it)
+    if capturing and CAPTURE_KEEPALIVE is not None:
+        CAPTURE_KEEPALIVE.append(hit)
+    return hit[1]
 
 
 def mlp_rows_table(m: "PackedMlp", feat, table, n_dev=None, save_hidden=False):
@@ -204,6 +240,30 @@ def pack_plane(src):
     return dst
 
 
+def pack_half(tables):
+    """fp16 copies (round to nearest even, same element order) of up to 8 fp32 tensors in ONE launch (tir_pack_half)."""
+    tables = [t.detach() for t in tables]
+    for t in tables:
+        if t.dtype != torch.float32 or not t.is_cuda:
+            raise ValueError("pack_half: fp32 CUDA tensors expected")
+    # same strides as the source (the channel-last planes keep their layout): a raw element-for-element copy of the storage
+    outs = [torch.empty_strided(t.shape, t.stride(), dtype=torch.float16, device=t.device) for t in tables]
+    k = len(tables)
+    srcs = (C.c_void_p * k)(*[t.data_ptr() for t in tables])
+    dsts = (C.c_void_p * k)(*[o.data_ptr() for o in outs])
+    cnts = (C.c_int64 * k)(*[_storage_span(t) for t in tables])
+    _call("tir_pack_half", srcs, dsts, cnts, k, _stream())
+    return outs
+
+
+def _storage_span(t):
+    """Elements between the first and the last element of a dense (possibly permuted) tensor."""
+    n = 1 + sum((s - 1) * st for s, st in zip(t.shape, t.stride()))
+    if n != t.numel():
+        raise ValueError("pack_half: dense tensors expected")
+    return n
+
+
 def pack_occupancy(vol):
     """[.., D, H, W] float 0/1 volume -> (D+1)(H+1)(W+1) neighbourhood bytes."""
     vol = f32(vol.detach(), "alpha_volume")
@@ -342,6 +402,24 @@ def vm_app(field: TirField, xyz, light_idx=None, idx_map=None, want_rad=True, wa
     return rad, intr
 
 
+def vm_app_h16(field: TirField, fh: TirFieldHalf, xyz, light_idx, idx_map=None, idx_div=0, n_dev=None):
+    """Radiance features [n, FEAT_STRIDE] from the fp16 shadow of the appearance planes / lines (tir_vm_app_fwd_h16): the
+    indirect-light precision policy's gather (48 appearance components per plane only)."""
+    xyz = f32(xyz, "xyz", 3).view(-1, 3)
+    n = xyz.shape[0]
+    light_idx = i32(light_idx, "light_idx").view(-1)
+    if idx_map is not None:
+        idx_map = i32(idx_map, "idx_map").view(-1)
+        if idx_map.numel() != n:
+            raise ValueError("idx_map must have one entry per point")
+    elif light_idx.numel() != n and idx_div <= 1:
+        raise ValueError("light_idx must have one entry per point")
+    rad = torch.empty((n, FEAT_STRIDE), dtype=torch.float32, device=xyz.device)
+    _call("tir_vm_app_fwd_h16", C.byref(field), C.byref(fh), _ptr(xyz), _ptr(light_idx), _ptr(idx_map), _ptr(rad), FEAT_STRIDE,
+          int(idx_div), n, _ptr(n_dev), _stream())
+    return rad
+
+
 # decoder implementations: "mfma" = exact fp32 matrix cores, "bf16x3" = split-bf16 matrix cores (parity
 # grade, ~5x fewer MFMA cycles), "bf16" = single-product reduced precision, "valu" = cross-check kernel
 MLP_ENTRY = {"mfma": "tir_mlp_fwd", "bf16x3": "tir_mlp_fwd_bf16x3", "bf16": "tir_mlp_fwd_bf16",
@@ -349,6 +427,29 @@ MLP_ENTRY = {"mfma": "tir_mlp_fwd", "bf16x3": "tir_mlp_fwd_bf16x3", "bf16": "tir
 MLP_IMPL = os.environ.get("TENSOIR_DECODER", "bf16x3")
 if MLP_IMPL not in MLP_ENTRY:
     raise ValueError(f"TENSOIR_DECODER={MLP_IMPL!r}: expected one of {sorted(MLP_ENTRY)}")
+# Precision policy for INDIRECT light.  The radiance of the SECONDARY-ray records (models/relight_utils.py:818-832)
+# is averaged over a ray's records and over the light directions before it reaches rgb_with_brdf_map; its gather and decoder may
+# run at another precision than the launches whose outputs are composited into the maps directly:
+#   TENSOIR_INDIRECT_PRECISION = f16 (default): appearance taps from an fp16 shadow of the planes / lines (tir_vm_app_fwd_h16)
+#                                  and the single-product fp16 decoder (tir_mlp_fwd_auxtab_f16), fp32 accumulation everywhere;
+#                                  measured on rgb_with_brdf_map: profiles/r04_precision_policy.json
+#                              = full: the same kernels as the primary stage (fp32 taps, split-bf16 x3 decoder)
+# Applies only while MLP_IMPL is the split-bf16 default (the exact / cross-check decoder modes stay exact end to end).
+_IND = os.environ.get("TENSOIR_INDIRECT_PRECISION", "f16")
+if _IND not in ("f16", "full"):
+    raise ValueError(f"TENSOIR_INDIRECT_PRECISION={_IND!r}: expected f16 or full")
+SECONDARY_MLP_IMPL = "f16" if _IND == "f16" else None       # None | "f16" | "bf16" (probe only) | "bf16x3"
+SECONDARY_APP_IMPL = "h16" if _IND == "f16" else None       # None | "h16"
+
+
+def secondary_app_impl():
+    """Gather mode of the secondary-record radiance features under the current settings."""
+    return SECONDARY_APP_IMPL if (MLP_IMPL == "bf16x3" and SECONDARY_APP_IMPL) else None
+
+
+def secondary_mlp_impl():
+    """Decoder mode of the secondary-record radiance launch under the current settings."""
+    return SECONDARY_MLP_IMPL if (MLP_IMPL == "bf16x3" and SECONDARY_MLP_IMPL) else None
 
 
 def mlp_multi(jobs, n_dev=None, save_hidden=False):
@@ -406,21 +507,17 @@ def mlp(m: PackedMlp, feat, aux, aux_map=None, impl=None, aux_mod=0, n_dev=None)
     elif aux.shape[0] != n and aux_mod <= 0:
         raise ValueError("aux must have one row per feature row")
     out = torch.empty((n, m.out_dim), dtype=torch.float32, device=feat.device)
+    f16 = impl == "f16"
+    if f16:
+        impl = "bf16x3"              # rows that do not qualify for the aux-table launch below take the parity-grade kernel
     if impl == "bf16x3" and AUX_TABLE and (aux_map is not None or aux_mod > 0) and aux.shape[0] * 8 <= max(n, 1):
         # few distinct aux rows (one per ray / light direction) for many decoder rows: their 15 input columns + the bias as a
         # per-aux-row start value of the layer-1 accumulators, 9 instead of 10 k-blocks of matrix work per row
         # the light-direction grid of a scene is a persistent tensor: its table is computed once per (decoder image, aux tensor
         # version) and kept with the packed decoder (which is rebuilt whenever the weights change)
-        cache = m.__dict__.setdefault("_aux_tables", {})
-        key = (aux.data_ptr(), aux._version, aux.shape[0])
-        hit = cache.get(key)
-        if hit is None:
-            if len(cache) >= 4:
-                cache.clear()
-            hit = cache[key] = (aux, mlp_aux_table(m, aux))      # the aux tensor is held too: its address cannot be recycled
-        table = hit[1]                                            # for another tensor while the entry lives
-        _call("tir_mlp_fwd_auxtab_bf16x3", C.byref(m.desc), _ptr(feat), feat.shape[1], _ptr(table), _ptr(aux_map), int(aux_mod),
-              _ptr(out), n, _ptr(n_dev), _stream())
+        table = _aux_table_cached(m, aux)
+        _call("tir_mlp_fwd_auxtab_f16" if f16 else "tir_mlp_fwd_auxtab_bf16x3", C.byref(m.desc), _ptr(feat), feat.shape[1], _ptr(table),
+              _ptr(aux_map), int(aux_mod), _ptr(out), n, _ptr(n_dev), _stream())
         return out
     _call(MLP_ENTRY[impl], C.byref(m.desc), _ptr(feat), feat.shape[1], _ptr(aux),
           _ptr(aux_map), int(aux_mod), _ptr(out), n, _ptr(n_dev), _stream())

@@ -89,9 +89,14 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
             rec_ray, rec_w, rec_xyz = rec["ray"][:n_rows], rec["w"][:n_rows], rec["xyz"][:n_rows]
             # light index / view direction of a record = those of its ray (ray id -> point via idx_div,
             # ray id -> direction via aux_mod on the dense [point][direction] grid)
-            feat = ops.vm_app(f, rec_xyz, light_idx, rec_ray, True, False, None, light_div, n_dev)[0]
+            fh = tensoIR.packed_field_half() if ops.secondary_app_impl() == "h16" else None
+            if fh is not None:         # indirect-light precision policy: fp16 shadow taps, fp16 matrix operands
+                feat = ops.vm_app_h16(f, fh, rec_xyz, light_idx, rec_ray, light_div, n_dev)
+            else:
+                feat = ops.vm_app(f, rec_xyz, light_idx, rec_ray, True, False, None, light_div, n_dev)[0]
             rgb = ops.mlp(tensoIR.renderModule.packed(), feat, dirs, rec_ray if dir_map is None else
-                          dir_map[rec_ray.long().clamp_(0, dir_map.numel() - 1)].contiguous(), None, n_dirs if dir_map is None else 0, n_dev)
+                          dir_map[rec_ray.long().clamp_(0, dir_map.numel() - 1)].contiguous(), ops.secondary_mlp_impl(),
+                          n_dirs if dir_map is None else 0, n_dev)
             if keep_records:       # the caller's integration kernel sums the records itself (tir_shade_integrate_records)
                 indirect = {"off": rec["off"], "cnt": rec["cnt"], "w": rec_w, "rgb": rgb}
             else:

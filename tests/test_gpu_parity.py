@@ -125,6 +125,70 @@ def test_decoder_large_biases(env):
 
 
 @torch.no_grad()
+def test_indirect_precision_policy_kernels(env):
+    """The two launches of the indirect-light precision policy, each against the parity-grade kernel it replaces
+    on the secondary-ray records:
+    * tir_mlp_fwd_auxtab_f16 (single-product fp16 decoder, operands rounded to 11 bits): |rgb - exact| < 2e-4 on every row
+      (measured ~4e-5 max, 7e-6 rms), unbiased (|mean| < 2e-6), finite for feature / activation magnitudes beyond the fp16
+      range (operands saturate at 65504 instead of turning into inf), ragged and device-side row counts;
+    * tir_vm_app_fwd_h16 (fp16 shadow of the appearance planes / lines, fp16 basis contraction): |feat - fp32 gather| <
+      2e-3 of the feature scale on every element, padding columns zero, index-map / idx_div / n_dev forms;
+    and the policy switch itself: `full` reproduces the primary-stage kernels bit for bit."""
+    from tensoir_amd import ops
+    m = env.model
+    pm = m.renderModule.packed()
+    gen = torch.Generator().manual_seed(11)
+    for n, D in ((255, 3), (4099, 16), (70001, 128)):
+        feat = torch.zeros(n, 32)
+        feat[:, :27] = torch.randn(n, 27, generator=gen) * 0.8
+        dirs = torch.nn.functional.normalize(torch.randn(D, 3, generator=gen), dim=-1).cuda()
+        amap = torch.randint(0, 10 * D, (n,), generator=gen).int().cuda()
+        f_d = feat.cuda()
+        exact = ops.mlp(pm, f_d, dirs, amap, "mfma", D)
+        half = ops.mlp(pm, f_d, dirs, amap, "f16", D)
+        d = (half - exact).double()
+        assert float(d.abs().max()) < 2e-4 and abs(float(d.mean())) < 2e-6, (n, D, float(d.abs().max()), float(d.mean()))
+        n_dev = torch.tensor([max(1, n - 5)], dtype=torch.int32, device="cuda")
+        part = ops.mlp(pm, f_d, dirs, amap, "f16", D, n_dev)
+        assert torch.equal(part[:n - 5], half[:n - 5])
+    big = f_d * 1.0e6                                                  # far outside fp16: operands saturate, nothing turns into NaN / inf
+    assert bool(torch.isfinite(ops.mlp(pm, big, dirs, amap, "f16", D)).all())
+    # ---- the gather
+    xyz, li = G(env, "feat/xyz"), G(env, "feat/light_idx")
+    fld, fh = m.packed_field(), m.packed_field_half()
+    assert fh is not None
+    r32 = ops.vm_app(fld, xyz, li, None, True, False)[0]
+    r16 = ops.vm_app_h16(fld, fh, xyz, li)
+    scale = float(r32[:, :27].abs().max())
+    assert float((r16 - r32)[:, :27].abs().max()) < 2e-3 * scale and bool((r16[:, 27:] == 0).all())
+    assert rel(r16[:, :27], env.g["feat/app"]) < 2e-3 * max(1.0, scale)          # and against the reference's own features
+    pts = (torch.rand(5003, 3, generator=gen) * 1.9 - 0.95).cuda()              # incl. points near / outside the borders
+    npt = 40
+    lpt = torch.randint(0, m.light_num, (npt,), generator=gen).int().cuda()
+    imap = torch.randint(0, npt * 7, (5003,), generator=gen).int().cuda()        # pair ids: light index of point id // 7
+    a32 = ops.vm_app(fld, pts, lpt, imap, True, False, None, 7)[0]
+    a16 = ops.vm_app_h16(fld, fh, pts, lpt, imap, 7)
+    assert float((a16 - a32).abs().max()) < 2e-3 * max(float(a32.abs().max()), 1e-6)
+    n_dev = torch.tensor([4000], dtype=torch.int32, device="cuda")
+    assert torch.equal(ops.vm_app_h16(fld, fh, pts, lpt, imap, 7, n_dev)[:4000], a16[:4000])
+    # ---- the switch: `full` = the primary-stage kernels
+    from tensoir_amd import Renderer_TensoIR_train
+    rays, lidx = G(env, "rays/rays"), G(env, "rays/light_idx")
+    kw = dict(N_samples=-1, white_bg=True, is_train=False, is_relight=True, sample_method="fixed_envirmap", device="cuda", args=env.args)
+    old = ops.SECONDARY_MLP_IMPL, ops.SECONDARY_APP_IMPL
+    try:
+        ops.SECONDARY_MLP_IMPL, ops.SECONDARY_APP_IMPL = "f16", "h16"
+        pol = Renderer_TensoIR_train(rays, None, lidx, m, **kw)
+        ops.SECONDARY_MLP_IMPL, ops.SECONDARY_APP_IMPL = None, None
+        full = Renderer_TensoIR_train(rays, None, lidx, m, **kw)
+    finally:
+        ops.SECONDARY_MLP_IMPL, ops.SECONDARY_APP_IMPL = old
+    for k in ("rgb_map", "normal_map", "albedo_map", "acc_map", "depth_map"):
+        assert torch.equal(pol[k], full[k]), k                         # the policy touches indirect light only
+    assert float((pol["rgb_with_brdf_map"] - full["rgb_with_brdf_map"]).abs().max()) < 1e-5
+
+
+@torch.no_grad()
 def test_decoder_aux_table_variant(env):
     """The aux-table variant of the radiance decoder (tir_mlp_aux_table + tir_mlp_fwd_auxtab_bf16x3: the view direction's 15
     input columns and the bias as a per-direction start value of the layer-1 accumulators, 9 k-blocks of matrix work instead
