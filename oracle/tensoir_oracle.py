@@ -693,7 +693,7 @@ def ggx_specular(normal, pts2c, pts2l, roughness, fresnel):
 
 def render_with_brdf(sc, depth, normal, albedo, roughness3, fresnel, rays, light_idx,
                      n_sample=96, near=0.05, far=1.5, dir_jitter=None, backend="aten",
-                     use_srgb=True, return_aux=False):
+                     use_srgb=True, return_aux=False, chunk_size=15000):
     """render_with_BRDF: models/relight_utils.py:403-483 (sample_method
     'fixed_envirmap', or 'stratified_sampling' when dir_jitter is given)."""
     rays_o, rays_d = rays[..., :3], rays[..., 3:]
@@ -711,9 +711,15 @@ def render_with_brdf(sc, depth, normal, albedo, roughness3, fresnel, rays, light
     ind = torch.zeros(M, D, 3, dtype=rays.dtype)
     if cmask.any():
         with torch.no_grad():      # compute_secondary_shading_effects is @torch.no_grad (models/relight_utils.py:344)
-            v, _, i = compute_radiance(
-                sc, surf.unsqueeze(1).expand(-1, D, -1)[cmask], surf2l[cmask],
-                light_idx.view(-1, 1, 1).expand(M, D, 1)[cmask], n_sample, near, far, backend)
+            # ... and walks the masked (point, direction) pairs in chunks (:373-391; renderer.py:97 hands its chunk_size
+            # down).  Every pair is independent, so the chunking changes no value -- only the size of the temporaries (the
+            # whole 4096 x 128 pair set at once is ~2x slower on the host cores than the reference's chunks).
+            p_all, l_all = surf.unsqueeze(1).expand(-1, D, -1)[cmask], surf2l[cmask]
+            li_all = light_idx.view(-1, 1, 1).expand(M, D, 1)[cmask]
+            v = torch.zeros(p_all.shape[0], dtype=rays.dtype)
+            i = torch.zeros(p_all.shape[0], 3, dtype=rays.dtype)
+            for c in torch.split(torch.arange(p_all.shape[0]), int(chunk_size)):
+                v[c], _, i[c] = compute_radiance(sc, p_all[c], l_all[c], li_all[c], n_sample, near, far, backend)
         vis[cmask] = v.reshape(-1, 1)
         ind[cmask] = i
     spec = ggx_specular(normal, surf2c, surf2l, roughness3, fresnel)
@@ -732,8 +738,9 @@ def render_with_brdf(sc, depth, normal, albedo, roughness3, fresnel, rays, light
 
 def renderer_train(sc, rays, light_idx, n_samples=-1, white_bg=True, is_relight=True,
                    second_n_sample=96, second_near=0.05, second_far=1.5,
-                   ray_jitter=None, brdf_jitter=None, dir_jitter=None, backend="aten", normal_gt=None):
-    """Renderer_TensoIR_train: renderer.py:57-127.  Returns the 12-key dict."""
+                   ray_jitter=None, brdf_jitter=None, dir_jitter=None, backend="aten", normal_gt=None, chunk_size=160000):
+    """Renderer_TensoIR_train: renderer.py:57-127.  Returns the 12-key dict.  chunk_size: pairs per secondary-pass chunk
+    (renderer.py:68 / :97; the training scripts pass args.relight_chunk_size = 160000, opt.py)."""
     light_idx = light_idx.to(torch.int32)
     (rgb_map, depth, normal, albedo, rough, fresnel, acc, ndiff, norient, acc_mask,
      alb_loss, rgh_loss) = forward_primary(sc, rays, light_idx, n_samples, white_bg, is_relight,
@@ -744,7 +751,7 @@ def renderer_train(sc, rays, light_idx, n_samples=-1, white_bg=True, is_relight=
         masked = render_with_brdf(sc, depth[acc_mask], normal[acc_mask], albedo[acc_mask],
                                   rough[acc_mask].repeat(1, 3), fresnel[acc_mask],
                                   rays[acc_mask], light_idx[acc_mask], second_n_sample,
-                                  second_near, second_far, dir_jitter, backend)
+                                  second_near, second_far, dir_jitter, backend, chunk_size=chunk_size)
         rgb_brdf = torch.ones_like(rgb_map)
         rgb_brdf[acc_mask] = masked
     else:

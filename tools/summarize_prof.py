@@ -49,7 +49,18 @@ for f in find("*counter_collection.csv"):
 # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md, HBM
 # section) -> doubled.  WRITE_SIZE is taken as reported (uncalibrated per the guide).  Collected in separate passes.
 import json
-OP_OF = (("k_mlp_bf16_auxt", "tir_mlp_fwd_bf16x3"), ("k_mlp_bf16<3", "tir_mlp_fwd_bf16x3"), ("k_mlp_bf16_multi<3", "tir_mlp_fwd_bf16x3"), ("k_mlp_bf16<1", "tir_mlp_fwd_bf16"), ("k_mlp_mfma", "tir_mlp_fwd"),
+
+
+def library_hash():
+    """Source hash of the library these counters were collected with (csrc/build.sh writes it next to the .so)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    try:
+        return open(os.path.join(here, "..", "tensoir_amd", "libtensoir_hip.so.srchash")).read().strip()
+    except OSError:
+        return None
+
+
+OP_OF = (("k_mlp_f16_auxt", "tir_mlp_fwd_auxtab_f16"), ("k_vm_app_h16", "tir_vm_app_fwd_h16"), ("k_mlp_bf16_auxt", "tir_mlp_fwd_bf16x3"), ("k_mlp_bf16<3", "tir_mlp_fwd_bf16x3"), ("k_mlp_bf16_multi<3", "tir_mlp_fwd_bf16x3"), ("k_mlp_bf16<1", "tir_mlp_fwd_bf16"), ("k_mlp_mfma", "tir_mlp_fwd"),
          ("k_vm_app_mfma", "tir_vm_app_fwd"), ("k_vm_app_primary", "tir_vm_app_fwd"), ("k_march_secondary", "tir_march_secondary_fwd"),
          ("k_march_primary", "tir_march_primary_fwd"), ("k_composite_primary", "tir_composite_primary"),
          ("k_density_grad", "tir_density_grad_fwd"), ("k_shade_integrate", "tir_shade_integrate"))
@@ -74,11 +85,12 @@ for op, d in tot.items():
     traffic[op + ":detail"] = {"fetch_bytes_x2_corrected": round(fe), "write_bytes": round(wr),
                                "launches_sampled": d["FETCH_SIZE"][1]}
 if traffic:
+    traffic["_library_source_hash"] = library_hash()
     with open(os.path.join(root, "pmc_traffic.json"), "w") as fh:
         json.dump(traffic, fh, indent=1)
     print("\n== pmc_traffic.json (bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE)")
     for k, v in traffic.items():
-        if not k.endswith(":detail"):
+        if not k.endswith(":detail") and not k.startswith("_"):
             print(f"  {k:32s} {v/1e6:10.2f} MB")
 
 # ---- issue fractions per entry point (bench.py's bound labels): VALU share of the SIMD issue time and matrix-pipe busy share,
@@ -114,11 +126,12 @@ for op, d in iss.items():
         e["wait_frac_of_wave_cycles"] = round(mean["SQ_WAIT_INST_ANY"] / mean["SQ_WAVE_CYCLES"], 4)
     issue[op] = e
 if issue:
+    issue["_library_source_hash"] = library_hash()
     issue["_note"] = ("valu_issue_frac = SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES (VALU instruction slots per CU-cycle over the 4 SIMDs' "
                       "one slot per 4 cycles each); mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES); separate rocprofv3 --pmc pass")
     with open(os.path.join(root, "pmc_issue.json"), "w") as fh:
         json.dump(issue, fh, indent=1)
     print("\n== pmc_issue.json")
     for k, v in issue.items():
-        if k != "_note":
+        if not k.startswith("_"):
             print(f"  {k:32s} {v}")
