@@ -47,6 +47,14 @@ static inline bool tir_occ_index_ok(const TirField* f) {
     return W > 0 && H > 0 && D > 0 && H + 1 < (1 << 24) && D + 1 < (1 << 24) && (W + 1) * (H + 1) * (D + 1) < ((int64_t)1 << 31);
 }
 
+// the density gathers address plane taps with 32-bit BYTE offsets (tir::density_chunk_impl): every plane must be < 4 GB
+static inline bool tir_plane_index_ok(const TirField* f) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if ((int64_t)f->grid[i] * f->grid[j] * f->n_dcomp * 4 >= ((int64_t)1 << 32) || (int64_t)f->grid[i] * f->n_dcomp * 4 >= (1 << 24) || (int64_t)f->grid[j] * f->n_dcomp * 4 >= (1 << 24)) return false;
+    return true;
+}
+
 // matMode / vecMode of the reference (models/tensorBase_rotated_lights.py:398-399)
 __device__ __constant__ const int kMat0[3] = {0, 0, 1};
 __device__ __constant__ const int kMat1[3] = {1, 2, 2};
@@ -218,72 +226,118 @@ __device__ __forceinline__ bool in_bbox(const TirField& f, float px, float py, f
              (py > f.aabb_max[1]) | (f.aabb_min[2] > pz) | (pz > f.aabb_max[2]));
 }
 
-// partial density feature: this lane's 16-byte chunk `c` of every tap (4 of the 4*C4 channels)
-template <int C4>
-__device__ __forceinline__ float density_feature_chunk(const TirField& f, float x, float y, float z, int c) {
-    const float p[3] = {x, y, z};
+// ---- the density gather's arithmetic, written for the VALU-issue-bound march kernels (ISA of a 16-sample gather pass before /
+// after: profiles/r04_march_isa.txt).
+// * make_tap_q = make_tap's indices and weights (bit for bit, for every input incl. out-of-range points) with the range tests
+//   as one unsigned compare each and the clamps as v_med3_i32: 6 instead of 10 instructions per axis.
+// * the three axes' taps are computed once per sample and shared by the three planes / lines that use them.
+// * tap addresses are 32-bit BYTE offsets from a wave-uniform base (global_load ... v_off, s[base]: no 64-bit address
+//   arithmetic per lane; planes are < 4 GB, tir_plane_index_ok).
+// * the bilinear / linear interpolations run two channels per instruction (v_pk_mul_f32 / v_pk_fma_f32: the same IEEE
+//   operations in the same order per channel, so every result is bit-identical to the scalar chain); the plane x line
+//   product keeps its scalar x, y, z, w accumulation order.
+typedef float tir_f2 __attribute__((ext_vector_type(2)));
+
+struct TapQ { unsigned i0, i1; tir_f2 w; };          // clamped indices; (w0, w1) masked weights as one register pair
+
+__device__ __forceinline__ unsigned clamp_index(int i, int size_m1) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(i), "v"(size_m1));
+    return (unsigned)r;
+}
+
+__device__ __forceinline__ TapQ make_tap_q(float x, int size) {
+    const float ix = unnorm(x, size);
+    const float f0 = floorf(ix);
+    const float t = ix - f0;
+    const int i0 = (int)f0, i1 = i0 + 1;
+    TapQ r;
+    r.w.x = ((unsigned)i0 < (unsigned)size) ? (1.0f - t) : 0.0f;
+    r.w.y = ((unsigned)i1 < (unsigned)size) ? t : 0.0f;
+    r.i0 = clamp_index(i0, size - 1);
+    r.i1 = clamp_index(i1, size - 1);
+    return r;
+}
+
+__device__ __forceinline__ float4 ld4b(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// sum over this lane's 4 channels of bilinear(plane) * linear(line), added to acc in x, y, z, w order.
+// wa = (w00, w01) = tx.w * ty.w0, wb = (w10, w11) = tx.w * ty.w1, wl = (line w0, w1)
+__device__ __forceinline__ float plane_line_4ch(const float4& a, const float4& b, const float4& cc, const float4& d,
+                                                const float4& e, const float4& g, tir_f2 wa, tir_f2 wb, tir_f2 wl, float acc) {
+    tir_f2 pxy = tir_f2{a.x, a.y} * tir_f2{wa.x, wa.x}, pzw = tir_f2{a.z, a.w} * tir_f2{wa.x, wa.x};
+    pxy = __builtin_elementwise_fma(tir_f2{b.x, b.y}, tir_f2{wa.y, wa.y}, pxy);
+    pzw = __builtin_elementwise_fma(tir_f2{b.z, b.w}, tir_f2{wa.y, wa.y}, pzw);
+    pxy = __builtin_elementwise_fma(tir_f2{cc.x, cc.y}, tir_f2{wb.x, wb.x}, pxy);
+    pzw = __builtin_elementwise_fma(tir_f2{cc.z, cc.w}, tir_f2{wb.x, wb.x}, pzw);
+    pxy = __builtin_elementwise_fma(tir_f2{d.x, d.y}, tir_f2{wb.y, wb.y}, pxy);
+    pzw = __builtin_elementwise_fma(tir_f2{d.z, d.w}, tir_f2{wb.y, wb.y}, pzw);
+    tir_f2 lxy = tir_f2{e.x, e.y} * tir_f2{wl.x, wl.x}, lzw = tir_f2{e.z, e.w} * tir_f2{wl.x, wl.x};
+    lxy = __builtin_elementwise_fma(tir_f2{g.x, g.y}, tir_f2{wl.y, wl.y}, lxy);
+    lzw = __builtin_elementwise_fma(tir_f2{g.z, g.w}, tir_f2{wl.y, wl.y}, lzw);
+    acc = fmaf(pxy.x, lxy.x, acc);
+    acc = fmaf(pxy.y, lxy.y, acc);
+    acc = fmaf(pzw.x, lzw.x, acc);
+    acc = fmaf(pzw.y, lzw.y, acc);
+    return acc;
+}
+
+// partial density feature: this lane's 16-byte chunk `c` of every tap (4 of the 4*C4 channels).  LDSL: the three density
+// line factors come from an LDS image `ll` = [line 0 | line 1 | line 2], each [R_i][4*C4] floats (north_star: "LDS-staged
+// factor tiles": a third of every sample's taps (6 of 18 x 64 B) then never reaches the vector L1 / L2; measured cost of
+// those taps in the march: ~24 % of the kernel, profiles/r02_line_tap_experiment.txt).  Same arithmetic either way.
+template <int C4, bool LDSL>
+__device__ __forceinline__ float density_chunk_impl(const TirField& f, const float* __restrict__ ll, float x, float y, float z, int c) {
+    constexpr unsigned TB = C4 * 16;                     // bytes per texel / line row
+    const TapQ ta[3] = {make_tap_q(x, f.grid[0]), make_tap_q(y, f.grid[1]), make_tap_q(z, f.grid[2])};
+    const unsigned cb = 16u * (unsigned)c;
+    // byte offset of this lane's chunk within row `index` of an axis: the x offset of a plane tap AND the offset of the line
+    // row of the same axis (both tables have TB bytes per row): 6 values serve all 18 taps
+    unsigned ob[3][2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { ob[a][0] = ta[a].i0 * TB + cb; ob[a][1] = ta[a].i1 * TB + cb; }
     float acc = 0.0f;
+    unsigned loff = 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int m0 = (i == 2) ? 1 : 0, m1 = (i == 0) ? 1 : 2, vi = 2 - i;
-        const int H = f.grid[m1], W = f.grid[m0], R = f.grid[vi];
-        Tap1 tx = make_tap(p[m0], W), ty = make_tap(p[m1], H), tl = make_tap(p[vi], R);
-        const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
-        // 32-bit element offsets (a plane holds < 2^31 floats, checked at launch): scalar base + one VGPR offset per
-        // tap instead of 64-bit address arithmetic per lane
+        const TapQ &tx = ta[m0], &ty = ta[m1], &tl = ta[vi];
+        const tir_f2 wa = tx.w * tir_f2{ty.w.x, ty.w.x}, wb = tx.w * tir_f2{ty.w.y, ty.w.y};
+        // row starts in bytes with the full-rate 24-bit multiply (v_mul_u32_u24: indices < 2^24 and row bytes < 2^24,
+        // tir_plane_index_ok; the 32-bit v_mul_lo_u32 issues at a quarter of the rate)
+        const unsigned row_bytes = (unsigned)f.grid[m0] * TB;
+        const unsigned r0 = mul_u24(ty.i0, row_bytes), r1 = mul_u24(ty.i1, row_bytes);
         const float* pl = f.dplane[i];
-        // row offsets with the full-rate 24-bit multiply (v_mul_u32_u24; indices and extents are < 2^24, the 32-bit
-        // v_mul_lo_u32 issues at a quarter of the rate and this kernel is VALU-issue bound)
-        const unsigned r0 = mul_u24((unsigned)ty.i0, (unsigned)W) * (C4 * 4) + 4 * c, r1 = mul_u24((unsigned)ty.i1, (unsigned)W) * (C4 * 4) + 4 * c;
-        const unsigned x0 = (unsigned)tx.i0 * (C4 * 4), x1 = (unsigned)tx.i1 * (C4 * 4);
-        const float4 a = ld4(pl + (r0 + x0));
-        const float4 b = ld4(pl + (r0 + x1));
-        const float4 cc = ld4(pl + (r1 + x0));
-        const float4 d = ld4(pl + (r1 + x1));
-        const float4 e = ld4(f.dline[i] + ((unsigned)tl.i0 * (C4 * 4) + 4 * c));
-        const float4 g = ld4(f.dline[i] + ((unsigned)tl.i1 * (C4 * 4) + 4 * c));
-        acc = fmaf(fmaf(d.x, w11, fmaf(cc.x, w10, fmaf(b.x, w01, a.x * w00))), fmaf(g.x, tl.w1, e.x * tl.w0), acc);
-        acc = fmaf(fmaf(d.y, w11, fmaf(cc.y, w10, fmaf(b.y, w01, a.y * w00))), fmaf(g.y, tl.w1, e.y * tl.w0), acc);
-        acc = fmaf(fmaf(d.z, w11, fmaf(cc.z, w10, fmaf(b.z, w01, a.z * w00))), fmaf(g.z, tl.w1, e.z * tl.w0), acc);
-        acc = fmaf(fmaf(d.w, w11, fmaf(cc.w, w10, fmaf(b.w, w01, a.w * w00))), fmaf(g.w, tl.w1, e.w * tl.w0), acc);
+        const float4 a = ld4b(pl, r0 + ob[m0][0]);
+        const float4 b = ld4b(pl, r0 + ob[m0][1]);
+        const float4 cc = ld4b(pl, r1 + ob[m0][0]);
+        const float4 d = ld4b(pl, r1 + ob[m0][1]);
+        float4 e, g;
+        if (LDSL) {
+            const char* lb = reinterpret_cast<const char*>(ll + loff);
+            e = *reinterpret_cast<const float4*>(lb + ob[vi][0]);
+            g = *reinterpret_cast<const float4*>(lb + ob[vi][1]);
+            loff += (unsigned)f.grid[vi] * (C4 * 4);
+        } else {
+            e = ld4b(f.dline[i], ob[vi][0]);
+            g = ld4b(f.dline[i], ob[vi][1]);
+        }
+        acc = plane_line_4ch(a, b, cc, d, e, g, wa, wb, tl.w, acc);
     }
     return acc;
 }
 
-// Same, with the three density line factors read from an LDS image [line 0 | line 1 | line 2], each [R_i][4*C4] floats
-// (north_star: "LDS-staged factor tiles").  A third of every sample's taps (6 of 18 x 64 B) then never reaches the
-// vector L1 / L2; measured cost of those taps in the march: ~24 % of the kernel (profiles/r02_line_tap_experiment.txt).
-// Same arithmetic, same order of operations: bit-identical to density_feature_chunk.
+template <int C4>
+__device__ __forceinline__ float density_feature_chunk(const TirField& f, float x, float y, float z, int c) {
+    return density_chunk_impl<C4, false>(f, nullptr, x, y, z, c);
+}
+
 template <int C4>
 __device__ __forceinline__ float density_feature_chunk_lds(const TirField& f, const float* __restrict__ ll,
                                                            float x, float y, float z, int c) {
-    const float p[3] = {x, y, z};
-    float acc = 0.0f;
-    int loff = 0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int m0 = (i == 2) ? 1 : 0, m1 = (i == 0) ? 1 : 2, vi = 2 - i;
-        const int H = f.grid[m1], W = f.grid[m0], R = f.grid[vi];
-        Tap1 tx = make_tap(p[m0], W), ty = make_tap(p[m1], H), tl = make_tap(p[vi], R);
-        const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
-        const float* pl = f.dplane[i];
-        // row offsets with the full-rate 24-bit multiply (v_mul_u32_u24; indices and extents are < 2^24, the 32-bit
-        // v_mul_lo_u32 issues at a quarter of the rate and this kernel is VALU-issue bound)
-        const unsigned r0 = mul_u24((unsigned)ty.i0, (unsigned)W) * (C4 * 4) + 4 * c, r1 = mul_u24((unsigned)ty.i1, (unsigned)W) * (C4 * 4) + 4 * c;
-        const unsigned x0 = (unsigned)tx.i0 * (C4 * 4), x1 = (unsigned)tx.i1 * (C4 * 4);
-        const float4 a = ld4(pl + (r0 + x0));
-        const float4 b = ld4(pl + (r0 + x1));
-        const float4 cc = ld4(pl + (r1 + x0));
-        const float4 d = ld4(pl + (r1 + x1));
-        const float4 e = ld4(ll + loff + (tl.i0 * (C4 * 4) + 4 * c));
-        const float4 g = ld4(ll + loff + (tl.i1 * (C4 * 4) + 4 * c));
-        loff += R * (C4 * 4);
-        acc = fmaf(fmaf(d.x, w11, fmaf(cc.x, w10, fmaf(b.x, w01, a.x * w00))), fmaf(g.x, tl.w1, e.x * tl.w0), acc);
-        acc = fmaf(fmaf(d.y, w11, fmaf(cc.y, w10, fmaf(b.y, w01, a.y * w00))), fmaf(g.y, tl.w1, e.y * tl.w0), acc);
-        acc = fmaf(fmaf(d.z, w11, fmaf(cc.z, w10, fmaf(b.z, w01, a.z * w00))), fmaf(g.z, tl.w1, e.z * tl.w0), acc);
-        acc = fmaf(fmaf(d.w, w11, fmaf(cc.w, w10, fmaf(b.w, w01, a.w * w00))), fmaf(g.w, tl.w1, e.w * tl.w0), acc);
-    }
-    return acc;
+    return density_chunk_impl<C4, true>(f, ll, x, y, z, c);
 }
 
 // DPP helper: value of lane (l - shift) within a 16-lane row, `ident` where that lane is outside the row

@@ -88,7 +88,7 @@ static int check_field(const TirField* f) {
         for (int j = i + 1; j < 3; ++j)
             if ((int64_t)f->grid[i] * f->grid[j] * (f->n_acomp > f->n_dcomp ? f->n_acomp : f->n_dcomp) >= ((int64_t)1 << 31)) return TIR_ERR_UNSUPPORTED;
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
-    if (!tir_occ_index_ok(f)) return TIR_ERR_UNSUPPORTED;
+    if (!tir_occ_index_ok(f) || !tir_plane_index_ok(f)) return TIR_ERR_UNSUPPORTED;
     return TIR_OK;
 }
 

@@ -155,7 +155,7 @@ extern "C" int tir_march_primary_fwd(const TirField* f, const float* rays, const
     if (B == 0) return TIR_OK;
     if (!rays || !weight || !acc || !depth || !app_count) return TIR_ERR_ARG;
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
-    if (!tir_occ_index_ok(f)) return TIR_ERR_UNSUPPORTED;
+    if (!tir_occ_index_ok(f) || !tir_plane_index_ok(f)) return TIR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_march_primary, dim3((B + 3) / 4), dim3(256), 0, tir_stream(stream), *f, rays,
                        ray_jitter, B, S, t_stop, weight, acc, depth, t_end, app_count, stats, (float*)nullptr, TirMarchExtras{});
     TIR_CHECK_LAUNCH();
@@ -174,7 +174,7 @@ extern "C" int tir_march_primary_fused_fwd(const TirField* f, const float* rays,
     if (B == 0) return TIR_OK;
     if (!rays || !weight || !acc || !depth || !app_count) return TIR_ERR_ARG;
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
-    if (!tir_occ_index_ok(f)) return TIR_ERR_UNSUPPORTED;
+    if (!tir_occ_index_ok(f) || !tir_plane_index_ok(f)) return TIR_ERR_UNSUPPORTED;
     TirMarchExtras ex{viewdirs, zero_words, n_zero, ticket, offsets, cap, total};
     hipLaunchKernelGGL(k_march_primary, dim3((B + 3) / 4), dim3(256), 0, tir_stream(stream), *f, rays,
                        ray_jitter, B, S, t_stop, weight, acc, depth, t_end, app_count, stats, (float*)nullptr, ex);
@@ -189,7 +189,7 @@ extern "C" int tir_march_primary_train_fwd(const TirField* f, const float* rays,
     if (B == 0) return TIR_OK;
     if (!rays || !weight || !sigma || !acc || !depth || !app_count) return TIR_ERR_ARG;
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
-    if (!tir_occ_index_ok(f)) return TIR_ERR_UNSUPPORTED;
+    if (!tir_occ_index_ok(f) || !tir_plane_index_ok(f)) return TIR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_march_primary, dim3((B + 3) / 4), dim3(256), 0, tir_stream(stream), *f, rays,
                        ray_jitter, B, S, t_stop, weight, acc, depth, t_end, app_count,
                        (unsigned long long*)nullptr, sigma, TirMarchExtras{});
@@ -939,7 +939,7 @@ extern "C" int tir_march_secondary_ids_fwd(const TirField* f, const float* origi
     if (rec_counter && (!rec_ray || !rec_w || !rec_xyz || !ray_rec_off || !ray_rec_cnt || rec_cap < 0)) return TIR_ERR_ARG;
     if (n_rays >= (int64_t)1 << 31) return TIR_ERR_UNSUPPORTED;
     if (!(f->n_dcomp == 4 || f->n_dcomp == 8 || f->n_dcomp == 16 || f->n_dcomp == 32)) return TIR_ERR_UNSUPPORTED;
-    if (!tir_occ_index_ok(f)) return TIR_ERR_UNSUPPORTED;
+    if (!tir_occ_index_ok(f) || !tir_plane_index_ok(f)) return TIR_ERR_UNSUPPORTED;
     const int xcd_on = tir_xcd_mapping(f);
     // LDS-staged line factors: 16 density components, <= 96 samples per ray, lines + scratch within half a CU's LDS
     {
