@@ -86,11 +86,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rays", type=int, default=256)
     ap.add_argument("--calls", type=int, default=3)
+    ap.add_argument("--grid", type=int, default=300)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "port_over_reference.json"))
     a = ap.parse_args()
     if not ref_loader.available():
         raise SystemExit(f"no reference checkout at {ref_loader.REF_ROOT}")
-    rep = measure(a.rays, a.calls)
+    rep = measure(a.rays, a.calls, grid=a.grid)
     rep["gpu_box_measurement_r03"] = ("profiles/r03_ref_on_gpu.json + r03_v9_bench.json (staged checkout on the MI355X box, 128 threads): reference "
                                       "361-373 rays/s on the full batch, port 222.65 rays/s on a quarter batch")
     with open(a.out, "w") as fh:

@@ -336,7 +336,9 @@ k_env_lookup(const float* __restrict__ env_rgb, int H, int W, const float* __res
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float dx = dirs[3 * i], dy = dirs[3 * i + 1], dz = dirs[3 * i + 2];
-    const float phi = acosf(dz) - 1e-6f;
+    // |dz| can exceed 1 by an ulp after the rotation / normalisation: acosf would return NaN and the (int) conversion of the
+    // NaN row index is undefined; the reference has the same NaN at the source, reproducing it buys nothing
+    const float phi = acosf(fminf(fmaxf(dz, -1.0f), 1.0f)) - 1e-6f;
     const float theta = atan2f(dy, dx);
     const float qy = (phi / 3.14159265358979323846f) * 2.0f - 1.0f;
     const float qx = -theta / 3.14159265358979323846f;
@@ -369,7 +371,8 @@ __device__ __forceinline__ PixTap pixel_taps(const float* __restrict__ rot, cons
     const float x = dirs[3 * d], y = dirs[3 * d + 1], z = dirs[3 * d + 2];
     const float rx = x * R[0] + y * R[3] + z * R[6], ry = x * R[1] + y * R[4] + z * R[7], rz = x * R[2] + y * R[5] + z * R[8];
     const float PI = 3.14159265358979323846f;
-    const float phi = acosf(rz) - 1e-6f, theta = atan2f(ry, rx);
+    // clamp: see k_env_lookup -- here a NaN tap weight would be atomically added into the light image's gradient and stay there
+    const float phi = acosf(fminf(fmaxf(rz, -1.0f), 1.0f)) - 1e-6f, theta = atan2f(ry, rx);
     const float qy = (phi / PI) * 2.0f - 1.0f, qx = -theta / PI;
     const float ix = ((qx + 1.0f) * (float)W - 1.0f) * 0.5f, iy = ((qy + 1.0f) * (float)H - 1.0f) * 0.5f;   // align_corners=False
     const float fx = floorf(ix), fy = floorf(iy);

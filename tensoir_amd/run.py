@@ -85,7 +85,12 @@ def _host_threads():
     n = int(os.environ.get("TENSOIR_HOST_THREADS", "8"))
     if n > 0:
         import torch
-        torch.set_num_threads(min(n, os.cpu_count() or n))
+        n = min(n, os.cpu_count() or n)
+        torch.set_num_threads(n)
+        # a process-wide side effect of install(): say so once (CPU-heavy phases of an unmodified script -- real-dataset ray
+        # generation, image metrics -- run on this many threads too; INTEGRATION.md "Host threads")
+        print(f"[tensoir_amd.run] PyTorch intra-op threads set to {n} for this process (TENSOIR_HOST_THREADS=N or OMP_NUM_THREADS "
+              f"choose another count, TENSOIR_HOST_THREADS=0 keeps PyTorch's default of {os.cpu_count()})", file=sys.stderr, flush=True)
 
 
 def _allow_numpy_in_checkpoints():

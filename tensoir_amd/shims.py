@@ -219,6 +219,12 @@ def _mimsave(path, frames, *a, **k):
     from PIL import Image
     imgs = [Image.fromarray(np.asarray(f).astype(np.uint8)) for f in frames]
     if imgs:
+        if not _mimsave.__dict__.get("warned"):
+            _mimsave.warned = True
+            import warnings
+            warnings.warn(f"tensoir_amd.shims: no video encoder in this environment -- {path} and every later imageio.mimsave "
+                          "output is written as an ANIMATED PNG (APNG container, whatever the file extension says); players that "
+                          "expect a video stream will not open it", stacklevel=2)
         with open(path, "wb") as fh:
             imgs[0].save(fh, format="PNG", save_all=True, append_images=imgs[1:])
 

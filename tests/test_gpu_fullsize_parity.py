@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-4
 # per-pixel relative bound for the maps north_star names (rgb, normals): a sample whose weight sits within fp32
 # rounding of the 1e-4 threshold (tensorBase_rotated_lights.py:924) moves a pixel by < 1e-4 of its value
-TOL_PIXEL = 2e-4
+TOL_PIXEL = 1e-4          # north_star: 1e-4 relative on rendered RGB / normals, as the true per-pixel figure (measured <= 1.3e-5)
 MAPS = ["rgb_map", "depth_map", "normal_map", "albedo_map", "roughness_map", "fresnel_map", "acc_map",
         "normals_diff_map", "normals_orientation_loss_map"]
 REPORT = {}
@@ -138,6 +138,8 @@ def test_c2_c3_boundary_call_equals_checked_route(c23):
     for n in MAPS + ["rgb_with_brdf_map"]:
         r = _record("C2+C3/boundary-call", n, ret[n].cpu()[c23.sel], c23.ref[n])
         assert r["max_rel_floor1"] < TOL, (n, r)
+        if n in ("rgb_map", "normal_map", "rgb_with_brdf_map"):
+            assert r["max_rel_pixel"] < TOL_PIXEL, (n, r)
 
 
 @torch.no_grad()
@@ -204,7 +206,7 @@ def test_c5_hdr_2048x1024_importance_512_vs_oracle(grid):
     ref = O.relight_importance(sc, c(surf), c(normal[mask]), c(albedo[mask]), c(rough[mask]), c(fres[mask]),
                                c(rays[:, 3:][mask]), c(ldir), c(lrgb), c(lpdf), n_sample=96, near=0.05, far=1.5)
     r = _record(C5, "relit_rgb", c(got), ref)
-    assert r["max_rel_floor1"] < TOL and r["max_rel_pixel"] < 5e-4, r
+    assert r["max_rel_floor1"] < TOL and r["max_rel_pixel"] < TOL_PIXEL, r          # measured 1.3e-7
     bg = env.get_light("syn", rays[:, 3:])
     # HDR radiance is unbounded (sun disc ~1e3): relative metric.  The lookup differentiates a 2048-wide map at a pixel
     # coordinate that comes out of acos / atan2 -- 1 ulp of the angle is 1e-4 pixel

@@ -62,6 +62,19 @@ def test_light_tables_match_reference(golden, model):
         model.gen_light_incident_dirs(method="nope")
 
 
+def test_importance_sample_direction_table_matches_reference(model):
+    """The jittered 128 x 256 table `gen_light_incident_dirs(method='importance_sample')` draws from
+    (models/tensorBase_rotated_lights.py:548: generate_envir_map_dir(128, 256, is_jittor=True)): same CPU generator draws as the
+    reference -> the reference's table (tests/golden/importance_sample.npz).  The radiance / pdf / sampling side runs on the
+    device: tests/test_gpu_parity.py::test_importance_sampled_light_directions."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "importance_sample.npz"))
+    torch.manual_seed(int(g["seed"][0]))
+    _, dirs = model.generate_envir_map_dir(128, 256, is_jittor=True)
+    assert torch.allclose(dirs.reshape(-1, 3), torch.from_numpy(g["view_dirs"]), atol=1e-6)
+    assert abs(float(g["pdf_to_sample"].sum()) - 1.0) < 1e-5 and g["draw_idx"].shape == (4096,)
+
+
 def test_sample_ray_matches_reference(golden, model):
     rays = T(golden, "rays/rays")
     pts, z, valid = model.sample_ray(rays[:, :3], rays[:, 3:6], is_train=False)
