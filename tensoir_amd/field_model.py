@@ -214,8 +214,24 @@ class MLPNormal_normal_and_PExyz(_Decoder):
         # module column of every kernel-order column: features, pts, PE(features), PE(pts)
         self.std_cols = list(range(6, 6 + F_)) + [0, 1, 2] + list(range(6 + F_, 6 + F_ + nf)) + list(range(6 + F_ + nf, 6 + F_ + nf + na))
 
+    def std_cols_index(self, device):
+        """std_cols as a device LongTensor (built once per device: a Python list index re-uploads 150 indices per use)."""
+        cache = self.__dict__.setdefault("_std_cols_dev", {})
+        key = str(device)
+        if key not in cache:
+            cache[key] = torch.tensor(self.std_cols, dtype=torch.long, device=device)
+        return cache[key]
+
     def w0_std(self):
-        return self.mlp[0].weight.detach()[:, self.std_cols].contiguous()
+        """W0 gathered into the kernels' column order, once per parameter version (the forward pack and the backward pack of a
+        training step share it: ADVICE r3)."""
+        w = self.mlp[0].weight
+        key = (w.data_ptr(), w._version)
+        hit = self.__dict__.get("_w0_std")
+        if hit is None or hit[0] != key:
+            hit = (key, w.detach().index_select(1, self.std_cols_index(w.device)).contiguous())
+            self.__dict__["_w0_std"] = hit
+        return hit[1]
 
     def w0_normal(self):
         return self.mlp[0].weight.detach()[:, 3:6]

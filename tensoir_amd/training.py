@@ -427,8 +427,8 @@ class PrimaryRenderFn(torch.autograd.Function):
         if st.A > 0 and model.normals_kind == "residue_prediction" and "normal" in dec_grads:
             # [128,150] in the kernels' column order + the three normal columns -> the module's [128,153] layout
             dec = model.renderModule_normal
-            full = torch.zeros_like(dec.mlp[0].weight)
-            full[:, dec.std_cols] = dec_grads["normal"][0]
+            full = torch.empty_like(dec.mlp[0].weight)                 # every column is written below: no fill launch
+            full.index_copy_(1, dec.std_cols_index(full.device), dec_grads["normal"][0])
             full[:, 3:6] = residue_dw
             dec_grads["normal"][0] = full
         for key, dec in zip(("rgb", "brdf", "normal"), _decoders(model)):
