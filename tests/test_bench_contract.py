@@ -1,7 +1,8 @@
 """The bench.py contract the driver depends on, checked on the CPU box: the CLI parses with no flags (N = 1, small K / W), refuses
 a scaling line from fewer ranks than it claims, fails loudly without a GPU (no CPU fallback), and the committed evidence lines
-(profiles/r03_v9_*bench.json, written by bench.py on an MI355X) carry every field of the contract incl. the `roofline` and
-`cpu_baseline` objects."""
+(profiles/r03_v9_*bench.json and profiles/r04*_bench.json, written by bench.py on an MI355X) carry every field of the contract incl.
+the `roofline` and `cpu_baseline` objects; the round-4 lines additionally: every roofline fraction <= 1 against an independent
+peak, the side workloads inside the headline line, the full-batch CPU baseline and its relation to the reference."""
 import glob
 import json
 import os
@@ -81,3 +82,41 @@ def test_committed_bench_lines_carry_the_contract(path):
         cb = d["cpu_baseline"]
         assert all(k in cb for k in ("value", "unit", "cores", "kind")) and cb["kind"] in ("reference", "port")
         assert d["parity"]["ok"] is True and d["metric"].startswith("primary+secondary rays/sec")
+
+
+def _rooflines(d):
+    out = [(k, v) for k, v in d.items() if k.startswith("roofline") and isinstance(v, dict) and "frac" in v]
+    for wl, v in (d.get("workloads") or {}).items():
+        if isinstance(v, dict) and isinstance(v.get("roofline"), dict):
+            out.append((f"workloads.{wl}", v["roofline"]))
+    return out
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "profiles", "r04*_bench.json"))))
+def test_round4_bench_lines(path):
+    """no roofline fraction above 1, no self-referential peak; the headline line carries the three
+    side workloads with parity and roofline each, a full-batch CPU baseline and the port-vs-reference relation."""
+    d = json.load(open(path))
+    missing = [k for k in REQUIRED if k not in d]
+    assert not missing, (os.path.basename(path), missing)
+    rls = _rooflines(d)
+    assert rls, path
+    for name, rf in rls:
+        assert all(k in rf for k in ("kernel", "bound", "achieved", "peak", "unit", "frac")), (name, rf)
+        assert rf["bound"] in ("hbm", "mfma", "l2", "valu", "l2-atomics") and 0.0 < rf["frac"] <= 1.0, (name, rf)
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 2e-3, (name, rf)            # achieved / peak, nothing else
+        assert "peak = achieved / frac" not in json.dumps(rf), name                        # round 3's circular VALU peak is gone
+    assert d["parity"] is None or d["parity"]["ok"] is True
+    if d["metric"].startswith("primary+secondary rays/sec"):
+        assert d["settle_steps"] == 300 and d["library"]["source_hash"] and "stale" in d["pmc"]
+        assert d["precision_policy"]["indirect"] in ("f16", "full")
+        cb = d["cpu_baseline"]
+        assert cb["kind"] in ("port", "reference") and "full batch" in cb["sample"] and "vs_reference" in cb
+        assert d["parity"]["max_rel"] < 1e-4 and d["parity"]["max_rel_floor1"] < 1e-4          # both metrics asserted by the run
+        wl = d["workloads"]
+        assert set(wl) == {"image", "relight", "train"}
+        for k, v in wl.items():
+            assert "error" not in v, (k, v)
+            assert v["value"] > 0 and v["roofline"] and v["cpu_baseline"] and v["parity"]["ok"] in (True, False)
+        vm = d["roofline_vm_sample"]
+        assert vm["bound"] == "valu" and "valu" in vm and vm["valu"]["fma_floor_per_pass"] == 84.0
