@@ -229,6 +229,15 @@ int tir_vm_app_fwd_h16(const TirField* f, const TirFieldHalf* fh, const float* x
                        const int32_t* idx_map, float* rad_feat, int32_t out_stride, int32_t idx_div, int64_t n,
                        const int32_t* n_dev, void* stream);
 
+/* The two launches above fused (north_star: gathers and decoder "in one pass"): for every record s < min(n, *n_dev) the radiance
+ * features of xyz[s] (light row light_idx[rec_map[s] / idx_div]) are gathered from the fp16 shadow, contracted with basis_mat and
+ * decoded by `m` (the radiance decoder; view-direction columns from `table` row rec_map[s] % aux_mod, tir_mlp_aux_table) without
+ * the feature rows ever reaching HBM.  out [n][m->out_dim].  n_acomp == 48, app_dim == 27.  Same precision class as the pair
+ * tir_vm_app_fwd_h16 + tir_mlp_fwd_auxtab_f16 (results agree to fp32 summation order). */
+int tir_indirect_fused_fwd(const TirField* f, const TirFieldHalf* fh, const TirMlp* m, const float* xyz,
+                           const int32_t* light_idx, const int32_t* rec_map, int32_t idx_div, int32_t aux_mod,
+                           const float* table, float* out, int64_t n, const int32_t* n_dev, void* stream);
+
 /* Up to four decoders over the SAME n rows in one launch (split-bf16 matrix cores): the primary stage evaluates the
  * radiance, BRDF, jittered-BRDF and normal decoders (models/tensorBase_rotated_lights.py:927-955) on the same records.
  * mlps / feats / auxs / aux_maps / outs are HOST arrays of n_jobs entries (aux_maps or its entries may be NULL); feature

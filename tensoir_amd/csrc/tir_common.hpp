@@ -340,6 +340,43 @@ __device__ __forceinline__ float density_feature_chunk_lds(const TirField& f, co
     return density_chunk_impl<C4, true>(f, ll, x, y, z, c);
 }
 
+// ---- fp16-shadow appearance taps (indirect-light precision policy): d = float(half of h2) * w + acc in ONE instruction
+// (v_fma_mix_f32 reads an fp16 operand in place, fp32 arithmetic, one rounding -- what fmaf((float)h, w, acc) computes).  Left
+// to the compiler the same source becomes v_cvt_f32_f16 per tap-channel plus packed FMAs: 1.5 instructions per tap-channel.
+__device__ __forceinline__ float fma_mix_lo(unsigned h2, float w, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(w), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ float fma_mix_hi(unsigned h2, float w, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(w), "v"(acc));
+    return d;
+}
+
+// 8 channels of one VM group: bilinear(plane taps a, b, c, d) * linear(line taps e, g) * light row lr[0..8) -> 8 halves (4 dwords)
+typedef _Float16 tir_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 h16_chunk(const uint4& a, const uint4& b, const uint4& c, const uint4& d, const uint4& e,
+                                           const uint4& g, float w00, float w01, float w10, float w11, float l0, float l1,
+                                           const float4& lr0, const float4& lr1) {
+    const unsigned A[4] = {a.x, a.y, a.z, a.w}, B[4] = {b.x, b.y, b.z, b.w}, Cc[4] = {c.x, c.y, c.z, c.w}, D[4] = {d.x, d.y, d.z, d.w};
+    const unsigned E[4] = {e.x, e.y, e.z, e.w}, G[4] = {g.x, g.y, g.z, g.w};
+    const float lr[8] = {lr0.x, lr0.y, lr0.z, lr0.w, lr1.x, lr1.y, lr1.z, lr1.w};
+    unsigned pk[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        float pl = fma_mix_lo(A[p], w00, 0.0f), ph = fma_mix_hi(A[p], w00, 0.0f);
+        pl = fma_mix_lo(B[p], w01, pl);  ph = fma_mix_hi(B[p], w01, ph);
+        pl = fma_mix_lo(Cc[p], w10, pl); ph = fma_mix_hi(Cc[p], w10, ph);
+        pl = fma_mix_lo(D[p], w11, pl);  ph = fma_mix_hi(D[p], w11, ph);
+        float ll = fma_mix_lo(E[p], l0, 0.0f), lh = fma_mix_hi(E[p], l0, 0.0f);
+        ll = fma_mix_lo(G[p], l1, ll);   lh = fma_mix_hi(G[p], l1, lh);
+        const tir_f2 v2 = {(pl * ll) * lr[2 * p], (ph * lh) * lr[2 * p + 1]};
+        pk[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, tir_h2));
+    }
+    return make_uint4(pk[0], pk[1], pk[2], pk[3]);
+}
+
 // DPP helper: value of lane (l - shift) within a 16-lane row, `ident` where that lane is outside the row
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_f(float ident, float v) {

@@ -870,34 +870,20 @@ k_vm_app_h16(TirField f, TirFieldHalf fh, const float* __restrict__ xyz, const i
             const _Float16* l0 = ln + ((unsigned)tl.i0 * CA + 8 * c);
             const _Float16* l1 = ln + ((unsigned)tl.i1 * CA + 8 * c);
             // all 18 taps of the group in flight before the first is used (as in the fp32 gather)
-            app_f16x8 ta[NQ], tb[NQ], tc[NQ], td[NQ], te[NQ], tg[NQ];
+            uint4 ta[NQ], tb[NQ], tc[NQ], td[NQ], te[NQ], tg[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                ta[q] = *reinterpret_cast<const app_f16x8*>(p00 + 16 * q); tb[q] = *reinterpret_cast<const app_f16x8*>(p01 + 16 * q);
-                tc[q] = *reinterpret_cast<const app_f16x8*>(p10 + 16 * q); td[q] = *reinterpret_cast<const app_f16x8*>(p11 + 16 * q);
-                te[q] = *reinterpret_cast<const app_f16x8*>(l0 + 16 * q);  tg[q] = *reinterpret_cast<const app_f16x8*>(l1 + 16 * q);
+                ta[q] = *reinterpret_cast<const uint4*>(p00 + 16 * q); tb[q] = *reinterpret_cast<const uint4*>(p01 + 16 * q);
+                tc[q] = *reinterpret_cast<const uint4*>(p10 + 16 * q); td[q] = *reinterpret_cast<const uint4*>(p11 + 16 * q);
+                te[q] = *reinterpret_cast<const uint4*>(l0 + 16 * q);  tg[q] = *reinterpret_cast<const uint4*>(l1 + 16 * q);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int ch0 = 16 * q + 8 * c;            // this lane's 8 channels of chunk pair q
-                const float4 lr0 = ld4(lrow + k * CA + ch0), lr1 = ld4(lrow + k * CA + ch0 + 4);
-                const float lr[8] = {lr0.x, lr0.y, lr0.z, lr0.w, lr1.x, lr1.y, lr1.z, lr1.w};
-                unsigned pk[4];
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    float val[2];
-#pragma unroll
-                    for (int o = 0; o < 2; ++o) {
-                        const float pv = fmaf((float)td[q][e + o], w11, fmaf((float)tc[q][e + o], w10,
-                                         fmaf((float)tb[q][e + o], w01, (float)ta[q][e + o] * w00)));
-                        const float lv = fmaf((float)tg[q][e + o], tl.w1, (float)te[q][e + o] * tl.w0);
-                        val[o] = (pv * lv) * lr[e + o];
-                    }
-                    const app_f32x2 v2 = {val[0], val[1]};
-                    pk[e >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, app_f16x2));
-                }
-                *reinterpret_cast<uint4*>(X + j * TIR_XH + ch0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                *reinterpret_cast<uint4*>(X + j * TIR_XH + ch0) =
+                    h16_chunk(ta[q], tb[q], tc[q], td[q], te[q], tg[q], w00, w01, w10, w11, tl.w0, tl.w1,
+                              ld4(lrow + k * CA + ch0), ld4(lrow + k * CA + ch0 + 4));
             }
             __builtin_amdgcn_wave_barrier();      // LDS ops of one wave complete in order; keep the compiler from reordering
 #pragma unroll

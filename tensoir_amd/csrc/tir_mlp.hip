@@ -76,7 +76,14 @@ constexpr int OFF_BFA = OFF_BF + BF_FLOATS;
 constexpr int FH_BYTES = BH_FLOATS * 4 + (BW0A_ELEMS + BW1_ELEMS) * 2;          // 72,864 B
 constexpr int FH_FLOATS = FH_BYTES / 4;
 constexpr int OFF_FH = OFF_BFA + BFA_FLOATS;
-constexpr int TOTAL_FLOATS = OFF_FH + FH_FLOATS;
+// Fourth image: the fp16 decoder for the FUSED gather + decoder kernel (k_indirect_fused).  There a lane half does not see all
+// 27 features: the gather's 32x32 MFMA leaves half h of a record's lane pair with 16 of the 32 feature rows, and basis_mat's
+// rows are dealt so that half 0 owns features 0..13 and half 1 owns 14..26.  Layer 1's contraction order per half is therefore
+// [for each own feature j: sin f, sin 2f, cos f, cos 2f, f] (5 inputs per feature, 70 / 65 -> 9 k-blocks); the aux columns and
+// the bias come from the aux table as in the other aux-table images.  Same size and header as the fp16 image.
+constexpr int FUS_NF0 = 14;                       // features owned by lane half 0 (half 1: F - 14 = 13)
+constexpr int OFF_FF = OFF_FH + FH_FLOATS;
+constexpr int TOTAL_FLOATS = OFF_FF + FH_FLOATS;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
@@ -101,6 +108,20 @@ __host__ __device__ inline int kperm_a(int t, int h) {
     const int q = t - NPF;
     if (h == 0) return q < R0A ? q : -1;
     return q < F - R0A ? R0A + q : -1;
+}
+
+// the fused layout: reference input column of k-slot kk of half h (-1 = padding)
+__host__ __device__ inline int kperm_f(int kk, int h) {
+    const int j = kk / 5, kind = kk % 5, nf = h ? F - FUS_NF0 : FUS_NF0;
+    if (j >= nf) return -1;
+    const int f = h ? FUS_NF0 + j : j;
+    switch (kind) {
+        case 0: return F + 3 + 2 * f;                 // sin(f)
+        case 1: return F + 3 + 2 * f + 1;             // sin(2f)
+        case 2: return F + 3 + NPF + 2 * f;           // cos(f)
+        case 3: return F + 3 + NPF + 2 * f + 1;       // cos(2f)
+        default: return f;                            // f itself
+    }
 }
 
 // hidden unit held by accumulator register q (= tile*16 + r) of a lane in half h
@@ -141,10 +162,11 @@ __global__ void k_pack_mlp(const float* __restrict__ w0, const float* __restrict
     else if (i < OFF_RB2) { int j = i - OFF_RW2; v = (j / HID < out_dim) ? w2[j] : 0.0f; }
     else if (i < FP32_TOTAL) { int o = i - OFF_RB2; v = (o < out_dim) ? b2[o] : 0.0f; }
     else {
-        const bool f16 = i >= OFF_FH;           // the fp16 image: aux-table layout, one operand plane per layer
+        const bool fused = i >= OFF_FF;         // the fused kernel's fp16 image: per-half feature ownership (kperm_f)
+        const bool f16 = i >= OFF_FH;           // the fp16 images: aux-table layout, one operand plane per layer
         const bool auxt = i >= OFF_BFA;         // the aux-table image: same header and W1 planes, 9-block W0 planes
         const int bw0 = auxt ? BW0A_ELEMS : BW0_ELEMS;
-        int j = i - (f16 ? OFF_FH : auxt ? OFF_BFA : OFF_BF);  // float slot inside the image
+        int j = i - (fused ? OFF_FF : f16 ? OFF_FH : auxt ? OFF_BFA : OFF_BF);  // float slot inside the image
         if (j < BH_FLOATS) {
             if (j < BH_B1) v = b0[unit_of(j % 64, j / 64)];
             else if (j < BH_W2) { int q = j - BH_B1; v = b1[unit_of(q % 64, q / 64)]; }
@@ -169,7 +191,8 @@ __global__ void k_pack_mlp(const float* __restrict__ w0, const float* __restrict
                 int e = idx % 8, ii = (idx / 8) % 32, mt = (idx / 256) % 4, h = (idx / 1024) % 2, kb = idx / 2048;
                 int kk = kb * 8 + e;
                 float wv;
-                if (sec < 2 && auxt) { const int in = kperm_a(kk, h); wv = in >= 0 ? w0[(mt * 32 + ii) * IN + in] : 0.0f; }
+                if (sec < 2 && fused) { const int in = kperm_f(kk, h); wv = in >= 0 ? w0[(mt * 32 + ii) * IN + in] : 0.0f; }
+                else if (sec < 2 && auxt) { const int in = kperm_a(kk, h); wv = in >= 0 ? w0[(mt * 32 + ii) * IN + in] : 0.0f; }
                 else if (sec < 2) wv = (kk < HALF) ? w0[(mt * 32 + ii) * IN + kperm(kk, h)]
                                               : ((kk == HALF && h == 0) ? b0[mt * 32 + ii] : 0.0f);   // bias slot (input = 1)
                 else wv = w1[(mt * 32 + ii) * HID + unit_of(kk, h)];
@@ -755,6 +778,214 @@ k_mlp_bf16_auxt(const float* __restrict__ packed, const float* __restrict__ feat
 // T[a][u] = b0[u] + sum over the 15 aux-dependent input columns of W0[u][col] x_col(aux_a): exact fp32 FMAs on the raw
 // weights, library sin / cos (the table is tiny: one row per ray or per light direction).  Column order of the reference
 // input (models/tensorBase_rotated_lights.py:137-142, :12-17): aux at F.., sin(PE aux) at F+3+2*NPF.., cos(PE aux) 3*PE later.
+// ------------------------------------------------------------------------------------------------
+// FUSED indirect-light kernel: appearance gather (fp16 shadow planes) -> basis_mat contraction -> radiance decoder (fp16
+// operands) for the secondary-ray records, in one pass (north_star: "fused into one pass"; models/relight_utils.py:818-829 =
+// compute_appfeature -> renderModule).  The feature rows never reach HBM: the gather's v_mfma_f32_32x32x16_f16 leaves lane
+// (record = l & 31, half = l >> 5) with 16 of the record's 32 feature rows in its accumulators, and basis_mat's rows are dealt so
+// that those are exactly the features whose PE and raw value this lane half feeds into layer 1 (image OFF_FF, kperm_f).
+// 512 threads = 8 waves x 32 records, persistent over 256-record tiles; per wave and tile: [gather phase, L1-bound] then
+// [decoder phase, VALU / MFMA-bound] -- the two waves of a SIMD drift out of phase and overlap the two.
+// LDS: fp16 decoder image (72.9 KB) | basis_mat^T fp16 tiles (9.2 KB) | light rows fp32 | 8 X tiles (3.5 KB each).
+// ------------------------------------------------------------------------------------------------
+constexpr int FUS_XH = 56;                                  // X tile row stride in halves (48 channels + 8)
+constexpr int FUS_WH_BYTES = 3 * 3 * 2 * 32 * 16;           // basis tiles [group][k-step][k-group][row] x 8 halves
+
+__device__ __forceinline__ int fus_feature_of_row(int row) {      // basis_mat row (feature) behind MFMA output row `row`, -1 = none
+    const int kg = (row >> 2) & 1, slot = (row >> 3) * 4 + (row & 3);
+    if (kg == 0) return slot < FUS_NF0 ? slot : -1;
+    return slot < F - FUS_NF0 ? FUS_NF0 + slot : -1;
+}
+
+template <int KB>
+__device__ __forceinline__ void fus_layer1(unsigned whi, const float (&fo)[16], const float (&pe)[FUS_NF0][4], f32x16 (&acc)[4]) {
+    bf16x8 ah[4], al[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) ah[mt] = lds_tile(whi, KBX(KB) * 4096 + mt * 512);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        constexpr int base = KB * 8;
+        const int kk = base + e, j = kk / 5, kind = kk % 5;
+        v[e] = (j >= FUS_NF0) ? 0.0f : (kind == 4 ? fo[j] : pe[j][kind]);
+    }
+    bf16x8 xh, xl = {};
+    cvt8_f16(v, xh);
+    mfma12<1, true>(ah, al, xh, xl, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (KB + 1 < KB0A) fus_layer1<KB + 1>(whi, fo, pe, acc);
+}
+
+typedef _Float16 fus_f16x2 __attribute__((ext_vector_type(2)));
+
+__global__ void __launch_bounds__(512)
+k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, const float* __restrict__ xyz,
+                 const int32_t* __restrict__ light_idx, const int32_t* __restrict__ rec_map, int idx_div, int aux_mod,
+                 const float* __restrict__ table, float* __restrict__ out, int64_t n, const int32_t* __restrict__ n_dev,
+                 int out_dim, int act, int lt_rows) {
+    using namespace tir;
+    constexpr int CA = 48, NQ = 3;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int i = threadIdx.x * 4; i < FH_FLOATS; i += 512 * 4)
+        *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(packed + OFF_FF + i);
+    f16x8* Wh = reinterpret_cast<f16x8*>(lds + FH_FLOATS);
+    float* LT = lds + FH_FLOATS + FUS_WH_BYTES / 4;
+    const int n_lt = lt_rows;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    _Float16* X = reinterpret_cast<_Float16*>(LT + (n_lt + 1) * (3 * CA)) + wave * (32 * FUS_XH);
+    for (int e = threadIdx.x; e < 3 * 3 * 2 * 32; e += 512) {
+        const int row = e & 31, kg = (e >> 5) & 1, t = (e >> 6) % 3, k = e / 192;
+        const int feat = fus_feature_of_row(row);
+        f16x8 hv;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) hv[q] = feat >= 0 ? (_Float16)f.basis_t[(size_t)(k * CA + 16 * t + 8 * kg + q) * 32 + feat] : (_Float16)0.0f;
+        Wh[e] = hv;
+    }
+    for (int i = threadIdx.x * 4; i < n_lt * 3 * CA; i += 512 * 4)
+        *reinterpret_cast<float4*>(LT + i) = *reinterpret_cast<const float4*>(f.light_line + i);
+    for (int i = threadIdx.x * 4; i < 3 * CA; i += 512 * 4)
+        *reinterpret_cast<float4*>(LT + n_lt * 3 * CA + i) = *reinterpret_cast<const float4*>(f.light_mean + i);
+    __syncthreads();
+    if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
+#ifdef EXP_FUSED_STAGGER      // limit study: start the second wave of every SIMD half a tile late (gather of one over the decoder of the other)
+    if (wave >= 4) for (int i = 0; i < EXP_FUSED_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+    const int sl = lane & 31, h = lane >> 5;               // decoder / MFMA role: record column, lane half (= k group)
+    const int gj = lane >> 1, gc = lane & 1;               // gather role: record slot, which of every two 16-byte chunks
+    const unsigned lds0 = (unsigned)(size_t)lds;
+    const unsigned lane_off = lds0 + BH_FLOATS * 4 + (unsigned)(h * 128 + sl) * 16;
+    const unsigned w0hi = opaque(lane_off);
+    const unsigned w1hi = opaque(lane_off + BW0A_ELEMS * 2);
+    const int64_t n_tiles = (n + 255) / 256;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t r0 = tile * 256 + wave * 32;
+        // ---------------- gather phase: record gj of this wave's 32, two lanes per record
+        const int64_t sg = r0 + gj, sgc = sg < n ? sg : n - 1;
+        const float p[3] = {xyz[3 * sgc], xyz[3 * sgc + 1], xyz[3 * sgc + 2]};
+        const float* lrow;
+        {
+            int64_t lsel = rec_map ? (int64_t)rec_map[sgc] : sgc;
+            if (idx_div > 1) lsel /= idx_div;
+            int li = light_idx[lsel];
+            li = min(max(li, 0), f.n_lights - 1);
+            lrow = n_lt ? LT + li * (3 * CA) : f.light_line + (size_t)li * (3 * CA);
+        }
+        // decoder role: this lane's record and its aux-table row
+        const int64_t sd = r0 + sl, sdc = sd < n ? sd : n - 1;
+        int64_t ai = rec_map ? (int64_t)rec_map[sdc] : sdc;
+        if (aux_mod > 0) ai %= aux_mod;
+        f32x16 facc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) facc[r] = 0.0f;
+        f32x16 acc[4], acc2[4];
+#pragma unroll 1
+        for (int k = 0; k < 3; ++k) {
+            const int H = f.grid[(k == 0) ? 1 : 2], W = f.grid[(k == 2) ? 1 : 0], R = f.grid[2 - k];
+            const float u = (k == 2) ? p[1] : p[0], v = (k == 0) ? p[1] : p[2], w = (k == 0) ? p[2] : ((k == 1) ? p[1] : p[0]);
+            Tap1 tx = make_tap(u, W), ty = make_tap(v, H), tl = make_tap(w, R);
+            const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
+            const _Float16* pl = reinterpret_cast<const _Float16*>(fh.aplane[k]);
+            const _Float16* ln = reinterpret_cast<const _Float16*>(fh.aline[k]);
+            const unsigned q0 = (unsigned)(ty.i0 * W) * CA, q1 = (unsigned)(ty.i1 * W) * CA;
+            const unsigned x0 = (unsigned)tx.i0 * CA + 8 * gc, x1 = (unsigned)tx.i1 * CA + 8 * gc;
+            const _Float16* p00 = pl + (q0 + x0);
+            const _Float16* p01 = pl + (q0 + x1);
+            const _Float16* p10 = pl + (q1 + x0);
+            const _Float16* p11 = pl + (q1 + x1);
+            const _Float16* l0 = ln + ((unsigned)tl.i0 * CA + 8 * gc);
+            const _Float16* l1 = ln + ((unsigned)tl.i1 * CA + 8 * gc);
+            uint4 ta[NQ], tb[NQ], tc[NQ], td[NQ], te[NQ], tg[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                ta[q] = *reinterpret_cast<const uint4*>(p00 + 16 * q); tb[q] = *reinterpret_cast<const uint4*>(p01 + 16 * q);
+                tc[q] = *reinterpret_cast<const uint4*>(p10 + 16 * q); td[q] = *reinterpret_cast<const uint4*>(p11 + 16 * q);
+                te[q] = *reinterpret_cast<const uint4*>(l0 + 16 * q);  tg[q] = *reinterpret_cast<const uint4*>(l1 + 16 * q);
+            }
+            if (k == 2) {      // the layer-1 accumulators' start values (aux-table row of the record's direction): in flight behind the last gather group
+                const float* tp = table + ai * HID + 4 * h;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(tp + mt * 32 + 8 * i);
+                        acc[mt][4 * i] = t4.x; acc[mt][4 * i + 1] = t4.y; acc[mt][4 * i + 2] = t4.z; acc[mt][4 * i + 3] = t4.w;
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int ch0 = 16 * q + 8 * gc;
+                *reinterpret_cast<uint4*>(X + gj * FUS_XH + ch0) =
+                    h16_chunk(ta[q], tb[q], tc[q], td[q], te[q], tg[q], w00, w01, w10, w11, tl.w0, tl.w1,
+                              *reinterpret_cast<const float4*>(lrow + k * CA + ch0), *reinterpret_cast<const float4*>(lrow + k * CA + ch0 + 4));
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const f16x8 a = Wh[((k * 3 + t) * 2 + h) * 32 + sl];
+                const f16x8 b = *reinterpret_cast<const f16x8*>(X + sl * FUS_XH + 16 * t + 8 * h);
+                facc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, facc, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---------------- decoder phase: facc[4 i + r] = this half's feature slot 4 i + r  (half 0: features 0..13, half 1: 14..26)
+        float fo[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fo[r] = __builtin_amdgcn_fmed3f(facc[r], -65504.0f, 65504.0f);
+        float pe[FUS_NF0][4];
+#pragma unroll
+        for (int j = 0; j < FUS_NF0; ++j) {
+            const float c_hi = 0.15915493667125702f, c_lo = 6.4206382432985265e-09f;      // c_hi + c_lo = 1 / (2 pi), see pe_pair
+            const float kr = rintf(fo[j] * c_hi);
+            float t = fmaf(fo[j], c_hi, -kr);
+            t = fmaf(fo[j], c_lo, t);
+            pe[j][0] = __builtin_amdgcn_sinf(t);
+            pe[j][1] = __builtin_amdgcn_sinf(t + t);
+            pe[j][2] = __builtin_amdgcn_sinf(t + 0.25f);
+            pe[j][3] = __builtin_amdgcn_sinf(fmaf(t, 2.0f, 0.25f));
+        }
+        fus_layer1<0>(w0hi, fo, pe, acc);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const float* bp = lds + BH_B1 + (h * 4 + mt) * 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[mt][r] = bp[r];
+        }
+        layer2_interleaved<1, 0, true>(w1hi, w1hi, acc, acc2);
+        f32x4 o4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o4[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const float* wp = lds + BH_W2 + (h * 4 + (lane & 3)) * W2A_STRIDE;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float4 w = *reinterpret_cast<const float4*>(wp + 4 * g);
+                const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int q = 4 * g + e;
+                    const float x = acc2[q >> 4][q & 15];
+                    o4[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], x + __builtin_fabsf(x), o4[e], 0, 0, 0);
+                }
+            }
+        }
+        float o0 = (o4[0][0] + o4[1][0]) + (o4[2][0] + o4[3][0]);
+        float o1 = (o4[0][1] + o4[1][1]) + (o4[2][1] + o4[3][1]);
+        float o2 = (o4[0][2] + o4[1][2]) + (o4[2][2] + o4[3][2]);
+        float o3 = (o4[0][3] + o4[1][3]) + (o4[2][3] + o4[3][3]);
+        o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64);
+        o2 += __shfl_xor(o2, 32, 64); o3 += __shfl_xor(o3, 32, 64);
+        if (h == 0 && sd < n) {
+            const float* b2 = lds + BH_B2;
+            float* op = out + sd * out_dim;
+            op[0] = act_out(o0 + b2[0], act);
+            if (out_dim > 1) op[1] = act_out(o1 + b2[1], act);
+            if (out_dim > 2) op[2] = act_out(o2 + b2[2], act);
+            if (out_dim > 3) op[3] = act_out(o3 + b2[3], act);
+        }
+    }
+}
+
 // single-product fp16 form of the aux-table decoder (see FH_BYTES above): same lane decomposition, same layer 3 (exact fp32)
 template <bool VEC>
 __global__ void __launch_bounds__(512)
@@ -1922,6 +2153,32 @@ extern "C" int tir_mlp_fwd_auxtab_f16(const TirMlp* m, const float* feat, int32_
                                 feat_stride, table, aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act);
     else     hipLaunchKernelGGL((k_mlp_f16_auxt<false>), dim3(grid), dim3(512), (size_t)FH_BYTES, tir_stream(stream), m->packed, feat,
                                 feat_stride, table, aux_map, aux_mod, out, n, n_dev, m->out_dim, m->act);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_indirect_fused_fwd(const TirField* f, const TirFieldHalf* fh, const TirMlp* m, const float* xyz,
+                                      const int32_t* light_idx, const int32_t* rec_map, int32_t idx_div, int32_t aux_mod,
+                                      const float* table, float* out, int64_t n, const int32_t* n_dev, void* stream) {
+    if (!f || !fh) return TIR_ERR_ARG;
+    int rc = check_mlp(m);
+    if (rc) return rc;
+    for (int i = 0; i < 3; ++i)
+        if (f->grid[i] < 2 || !fh->aplane[i] || !fh->aline[i] || reinterpret_cast<uintptr_t>(fh->aplane[i]) % 16 != 0 ||
+            reinterpret_cast<uintptr_t>(fh->aline[i]) % 16 != 0) return TIR_ERR_ARG;
+    if (!f->basis_t || !f->light_mean || !f->light_line) return TIR_ERR_ARG;
+    if (f->n_acomp != 48 || f->app_dim != F) return TIR_ERR_UNSUPPORTED;
+    if (n < 0 || (n > 0 && (!xyz || !light_idx || !table || !out))) return TIR_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(table) % 16 != 0) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    const int lt_rows = f->n_lights <= 16 ? f->n_lights : 0;
+    const size_t lds = (size_t)FH_BYTES + FUS_WH_BYTES + (size_t)(lt_rows + 1) * 144 * sizeof(float) + (size_t)8 * 32 * FUS_XH * 2;
+    if (int r2 = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_indirect_fused), (int)lds)) return r2;
+    const int64_t tiles = (n + 255) / 256;
+    const int grid_max = m->tune_grid > 0 ? m->tune_grid : 256;
+    const unsigned grid = (unsigned)(tiles < grid_max ? tiles : grid_max);
+    hipLaunchKernelGGL(k_indirect_fused, dim3(grid), dim3(512), lds, tir_stream(stream), *f, *fh, m->packed, xyz, light_idx, rec_map,
+                       idx_div, aux_mod, table, out, n, n_dev, m->out_dim, m->act, lt_rows);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

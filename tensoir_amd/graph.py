@@ -83,7 +83,7 @@ class GraphedRenderer:
         # every light parameter: the general multi-light model keeps one SG set per light in a plain list
         lights = m.light_parameters()
         return (m._field_key, tuple((t.data_ptr(), t._version) for t in lights), tuple(d._key for d in decs),
-                float(m.march_t_stop), ops.MLP_IMPL, ops.secondary_mlp_impl(), ops.secondary_app_impl())
+                float(m.march_t_stop), ops.MLP_IMPL, ops.secondary_mlp_impl(), ops.secondary_app_impl(), ops.fused_indirect())
 
     def _stale(self):
         return self.graph is not None and self._key() != self._model_key

@@ -420,6 +420,24 @@ def vm_app_h16(field: TirField, fh: TirFieldHalf, xyz, light_idx, idx_map=None, 
     return rad
 
 
+def indirect_fused(field: TirField, fh: TirFieldHalf, m: "PackedMlp", xyz, light_idx, rec_map, idx_div, dirs, n_dirs, n_dev=None):
+    """Radiance [n, out_dim] of the secondary-ray records in ONE launch (tir_indirect_fused_fwd): fp16-shadow appearance gather,
+    basis_mat contraction and the radiance decoder, the feature rows staying in registers.  rec_map[s] = pair id of record s:
+    light index = light_idx[pair // idx_div], view direction = dirs[pair % n_dirs] (through the cached aux table)."""
+    xyz = f32(xyz, "xyz", 3).view(-1, 3)
+    n = xyz.shape[0]
+    light_idx = i32(light_idx, "light_idx").view(-1)
+    rec_map = i32(rec_map, "rec_map").view(-1)
+    if rec_map.numel() != n:
+        raise ValueError("rec_map must have one entry per record")
+    dirs = f32(dirs, "dirs", 3)
+    table = _aux_table_cached(m, dirs)
+    out = torch.empty((n, m.out_dim), dtype=torch.float32, device=xyz.device)
+    _call("tir_indirect_fused_fwd", C.byref(field), C.byref(fh), C.byref(m.desc), _ptr(xyz), _ptr(light_idx), _ptr(rec_map), int(idx_div),
+          int(n_dirs), _ptr(table), _ptr(out), n, _ptr(n_dev), _stream())
+    return out
+
+
 # decoder implementations: "mfma" = exact fp32 matrix cores, "bf16x3" = split-bf16 matrix cores (parity
 # grade, ~5x fewer MFMA cycles), "bf16" = single-product reduced precision, "valu" = cross-check kernel
 MLP_ENTRY = {"mfma": "tir_mlp_fwd", "bf16x3": "tir_mlp_fwd_bf16x3", "bf16": "tir_mlp_fwd_bf16",
@@ -440,6 +458,15 @@ if _IND not in ("f16", "full"):
     raise ValueError(f"TENSOIR_INDIRECT_PRECISION={_IND!r}: expected f16 or full")
 SECONDARY_MLP_IMPL = "f16" if _IND == "f16" else None       # None | "f16" | "bf16" (probe only) | "bf16x3"
 SECONDARY_APP_IMPL = "h16" if _IND == "f16" else None       # None | "h16"
+
+
+# TENSOIR_FUSED_INDIRECT=0: gather and decoder of the secondary-ray records as two launches (tir_vm_app_fwd_h16 +
+# tir_mlp_fwd_auxtab_f16, features through HBM) instead of the fused kernel (tir_indirect_fused_fwd).  Only meaningful under the f16 policy.
+FUSED_INDIRECT = os.environ.get("TENSOIR_FUSED_INDIRECT", "1") != "0"
+
+
+def fused_indirect():
+    return FUSED_INDIRECT and AUX_TABLE and secondary_app_impl() == "h16" and secondary_mlp_impl() == "f16"
 
 
 def secondary_app_impl():

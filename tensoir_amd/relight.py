@@ -41,6 +41,18 @@ def _rec_capacity(n_rays):
     return int(min(max(1 << 20, 16 * n_rays), 1 << 28))
 
 
+def _gather_then_decode(tensoIR, f, fh, rec_xyz, light_idx, rec_ray, light_div, dirs, dir_map, n_dirs, n_dev):
+    """Appearance gather, then the radiance decoder, as two launches (features through HBM)."""
+    if fh is not None:         # indirect-light precision policy: fp16 shadow taps, fp16 matrix operands
+        feat = ops.vm_app_h16(f, fh, rec_xyz, light_idx, rec_ray, light_div, n_dev)
+    else:
+        feat = ops.vm_app(f, rec_xyz, light_idx, rec_ray, True, False, None, light_div, n_dev)[0]
+    # view direction of a record = that of its ray (ray id -> direction via aux_mod on the dense [point][direction] grid)
+    return ops.mlp(tensoIR.renderModule.packed(), feat, dirs, rec_ray if dir_map is None else
+                   dir_map[rec_ray.long().clamp_(0, dir_map.numel() - 1)].contiguous(), ops.secondary_mlp_impl(),
+                   n_dirs if dir_map is None else 0, n_dev)
+
+
 def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, light_idx, light_div,
                want_indirect, want_nerfactor=False, n_dirs=0, keep_records=False, ids=None, defer=False):
     """Shared driver of compute_transmittance / compute_radiance / render_with_BRDF:
@@ -90,13 +102,12 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
             # light index / view direction of a record = those of its ray (ray id -> point via idx_div,
             # ray id -> direction via aux_mod on the dense [point][direction] grid)
             fh = tensoIR.packed_field_half() if ops.secondary_app_impl() == "h16" else None
-            if fh is not None:         # indirect-light precision policy: fp16 shadow taps, fp16 matrix operands
-                feat = ops.vm_app_h16(f, fh, rec_xyz, light_idx, rec_ray, light_div, n_dev)
+            if fh is not None and dir_map is None and n_dirs > 0 and ops.fused_indirect() and dirs.shape[0] * 8 <= max(n_rows, 1) \
+                    and int(f.app_dim) == 27:
+                # gather -> basis contraction -> radiance decoder in ONE launch, the feature rows never reach HBM
+                rgb = ops.indirect_fused(f, fh, tensoIR.renderModule.packed(), rec_xyz, light_idx, rec_ray, light_div, dirs, n_dirs, n_dev)
             else:
-                feat = ops.vm_app(f, rec_xyz, light_idx, rec_ray, True, False, None, light_div, n_dev)[0]
-            rgb = ops.mlp(tensoIR.renderModule.packed(), feat, dirs, rec_ray if dir_map is None else
-                          dir_map[rec_ray.long().clamp_(0, dir_map.numel() - 1)].contiguous(), ops.secondary_mlp_impl(),
-                          n_dirs if dir_map is None else 0, n_dev)
+                rgb = _gather_then_decode(tensoIR, f, fh, rec_xyz, light_idx, rec_ray, light_div, dirs, dir_map, n_dirs, n_dev)
             if keep_records:       # the caller's integration kernel sums the records itself (tir_shade_integrate_records)
                 indirect = {"off": rec["off"], "cnt": rec["cnt"], "w": rec_w, "rgb": rgb}
             else:

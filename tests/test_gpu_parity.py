@@ -188,6 +188,23 @@ def test_indirect_precision_policy_kernels(env):
     assert float((a16 - a32).abs().max()) < 2e-3 * max(float(a32.abs().max()), 1e-6)
     n_dev = torch.tensor([4000], dtype=torch.int32, device="cuda")
     assert torch.equal(ops.vm_app_h16(fld, fh, pts, lpt, imap, 7, n_dev)[:4000], a16[:4000])
+    # ---- the fused launch (gather -> basis contraction -> decoder, features in registers) against the two launches it replaces
+    D = 16
+    dirs = torch.nn.functional.normalize(torch.randn(D, 3, generator=gen), dim=-1).cuda()
+    for npts in (1, 255, 5003):
+        pts_f = (torch.rand(npts, 3, generator=gen) * 1.9 - 0.95).cuda()
+        pair = torch.randint(0, npt * D, (npts,), generator=gen).int().cuda()            # pair id: point = id // D, direction = id % D
+        two = ops.mlp(pm, ops.vm_app_h16(fld, fh, pts_f, lpt, pair, D), dirs, pair, "f16", D) if D * 8 <= npts else None
+        one = ops.indirect_fused(fld, fh, pm, pts_f, lpt, pair, D, dirs, D)
+        assert one.shape == (npts, 3) and bool(torch.isfinite(one).all())
+        if two is not None:
+            assert float((one - two).abs().max()) < 1e-5, (npts, float((one - two).abs().max()))
+        exact = ops.mlp(pm, ops.vm_app(fld, pts_f, lpt, pair, True, False, None, D)[0], dirs, pair, "mfma", D)
+        assert float((one - exact).abs().max()) < 5e-4, (npts, float((one - exact).abs().max()))      # the policy's precision class
+        if npts > 10:
+            n_dev = torch.tensor([npts - 7], dtype=torch.int32, device="cuda")
+            part = ops.indirect_fused(fld, fh, pm, pts_f, lpt, pair, D, dirs, D, n_dev)
+            assert torch.equal(part[:npts - 7], one[:npts - 7])
     # ---- the switch: `full` = the primary-stage kernels
     from tensoir_amd import Renderer_TensoIR_train
     rays, lidx = G(env, "rays/rays"), G(env, "rays/light_idx")
@@ -195,7 +212,15 @@ def test_indirect_precision_policy_kernels(env):
     old = ops.SECONDARY_MLP_IMPL, ops.SECONDARY_APP_IMPL
     try:
         ops.SECONDARY_MLP_IMPL, ops.SECONDARY_APP_IMPL = "f16", "h16"
-        pol = Renderer_TensoIR_train(rays, None, lidx, m, **kw)
+        old_fused = ops.FUSED_INDIRECT
+        try:
+            ops.FUSED_INDIRECT = False
+            unfused = Renderer_TensoIR_train(rays, None, lidx, m, **kw)
+            ops.FUSED_INDIRECT = True
+            pol = Renderer_TensoIR_train(rays, None, lidx, m, **kw)
+        finally:
+            ops.FUSED_INDIRECT = old_fused
+        assert float((pol["rgb_with_brdf_map"] - unfused["rgb_with_brdf_map"]).abs().max()) < 2e-6
         ops.SECONDARY_MLP_IMPL, ops.SECONDARY_APP_IMPL = None, None
         full = Renderer_TensoIR_train(rays, None, lidx, m, **kw)
     finally:

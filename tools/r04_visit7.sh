@@ -1,0 +1,11 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+cat > /tmp/pb.py <<'PY'
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print(sys.argv[1], {k:d[k] for k in ('value','ms_per_step')}, 'single', d['single_stream']['value'], [ (k['kernel'], round(k['avg_ms'],4)) for k in d['kernels'][:2]])
+PY
+for v in base stag1 stag2 stag4 base; do
+  L=$GRAFT_REPO_ROOT/tensoir_amd/libtensoir_hip.so; [ $v != base ] && L=$GRAFT_REPO_ROOT/gpurun_scratch/lib_$v.so
+  TENSOIR_HIP_LIB=$L timeout -k 5 300 python bench.py --no-side-workloads --no-sharp-scene --no-exact-pass --boundary-calls 3 --no-cpu-baseline 2>/dev/null | python /tmp/pb.py $v
+done
