@@ -797,23 +797,39 @@ __device__ __forceinline__ int fus_feature_of_row(int row) {      // basis_mat r
     return slot < F - FUS_NF0 ? FUS_NF0 + slot : -1;
 }
 
+// input slot KK of a lane half in the fused layout: [for each own feature j: sin f, sin 2f, cos f, cos 2f, f].  Each slot evaluates
+// its own PE value from fo[j] (the three-instruction range reduction is shared by the slots of a k-block through CSE): no PE
+// array exists, so nothing can end up in scratch memory (an array of PE values did: 0.4 GB of HBM writes per launch, measured)
+template <int KK>
+__device__ __forceinline__ float fus_input(const float (&fo)[16]) {
+    constexpr int j = KK / 5, kind = KK % 5;
+    if constexpr (j >= FUS_NF0) return 0.0f;
+    else if constexpr (kind == 4) return fo[j];
+    else {
+        const float c_hi = 0.15915493667125702f, c_lo = 6.4206382432985265e-09f;      // c_hi + c_lo = 1 / (2 pi), see pe_pair
+        const float kr = rintf(fo[j] * c_hi);
+        float t = fmaf(fo[j], c_hi, -kr);
+        t = fmaf(fo[j], c_lo, t);
+        if constexpr (kind == 0) return __builtin_amdgcn_sinf(t);
+        else if constexpr (kind == 1) return __builtin_amdgcn_sinf(t + t);
+        else if constexpr (kind == 2) return __builtin_amdgcn_sinf(t + 0.25f);
+        else return __builtin_amdgcn_sinf(fmaf(t, 2.0f, 0.25f));
+    }
+}
+
 template <int KB>
-__device__ __forceinline__ void fus_layer1(unsigned whi, const float (&fo)[16], const float (&pe)[FUS_NF0][4], f32x16 (&acc)[4]) {
+__device__ __forceinline__ void fus_layer1(unsigned whi, const float (&fo)[16], f32x16 (&acc)[4]) {
     bf16x8 ah[4], al[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) ah[mt] = lds_tile(whi, KBX(KB) * 4096 + mt * 512);
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        constexpr int base = KB * 8;
-        const int kk = base + e, j = kk / 5, kind = kk % 5;
-        v[e] = (j >= FUS_NF0) ? 0.0f : (kind == 4 ? fo[j] : pe[j][kind]);
-    }
+    // compile-time slots (a run-time index into pe[][] would send the array to scratch memory)
+    const float v[8] = {fus_input<KB * 8 + 0>(fo), fus_input<KB * 8 + 1>(fo), fus_input<KB * 8 + 2>(fo), fus_input<KB * 8 + 3>(fo),
+                        fus_input<KB * 8 + 4>(fo), fus_input<KB * 8 + 5>(fo), fus_input<KB * 8 + 6>(fo), fus_input<KB * 8 + 7>(fo)};
     bf16x8 xh, xl = {};
     cvt8_f16(v, xh);
     mfma12<1, true>(ah, al, xh, xl, acc);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (KB + 1 < KB0A) fus_layer1<KB + 1>(whi, fo, pe, acc);
+    if constexpr (KB + 1 < KB0A) fus_layer1<KB + 1>(whi, fo, acc);
 }
 
 typedef _Float16 fus_f16x2 __attribute__((ext_vector_type(2)));
@@ -878,8 +894,8 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) facc[r] = 0.0f;
         f32x16 acc[4], acc2[4];
-#pragma unroll 1
-        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {      // unrolled: with a run-time k the coordinate selects below become a scratch table (72 B stored per lane and tile = 0.4 GB of HBM writes per launch, measured)
             const int H = f.grid[(k == 0) ? 1 : 2], W = f.grid[(k == 2) ? 1 : 0], R = f.grid[2 - k];
             const float u = (k == 2) ? p[1] : p[0], v = (k == 0) ? p[1] : p[2], w = (k == 0) ? p[2] : ((k == 1) ? p[1] : p[0]);
             Tap1 tx = make_tap(u, W), ty = make_tap(v, H), tl = make_tap(w, R);
@@ -932,19 +948,7 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
         float fo[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) fo[r] = __builtin_amdgcn_fmed3f(facc[r], -65504.0f, 65504.0f);
-        float pe[FUS_NF0][4];
-#pragma unroll
-        for (int j = 0; j < FUS_NF0; ++j) {
-            const float c_hi = 0.15915493667125702f, c_lo = 6.4206382432985265e-09f;      // c_hi + c_lo = 1 / (2 pi), see pe_pair
-            const float kr = rintf(fo[j] * c_hi);
-            float t = fmaf(fo[j], c_hi, -kr);
-            t = fmaf(fo[j], c_lo, t);
-            pe[j][0] = __builtin_amdgcn_sinf(t);
-            pe[j][1] = __builtin_amdgcn_sinf(t + t);
-            pe[j][2] = __builtin_amdgcn_sinf(t + 0.25f);
-            pe[j][3] = __builtin_amdgcn_sinf(fmaf(t, 2.0f, 0.25f));
-        }
-        fus_layer1<0>(w0hi, fo, pe, acc);
+        fus_layer1<0>(w0hi, fo, acc);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const float* bp = lds + BH_B1 + (h * 4 + mt) * 16;

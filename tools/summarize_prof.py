@@ -35,7 +35,7 @@ for f in find("*counter_collection.csv"):
             agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print(f"# {os.path.relpath(f, root)}")
     for k, cs in sorted(agg.items()):
-        if not any(t in k for t in ("k_march", "k_mlp", "k_vm_app", "k_composite", "k_density", "k_shade")):
+        if not any(t in k for t in ("k_march", "k_mlp", "k_vm_app", "k_composite", "k_density", "k_shade", "k_indirect")):
             continue
         parts = [f"{c}={sum(v)/len(v):.4g} (n={len(v)})" for c, v in sorted(cs.items())]
         print(f"  {k:40s} " + "  ".join(parts))
@@ -60,7 +60,7 @@ def library_hash():
         return None
 
 
-OP_OF = (("k_mlp_f16_auxt", "tir_mlp_fwd_auxtab_f16"), ("k_vm_app_h16", "tir_vm_app_fwd_h16"), ("k_mlp_bf16_auxt", "tir_mlp_fwd_bf16x3"), ("k_mlp_bf16<3", "tir_mlp_fwd_bf16x3"), ("k_mlp_bf16_multi<3", "tir_mlp_fwd_bf16x3"), ("k_mlp_bf16<1", "tir_mlp_fwd_bf16"), ("k_mlp_mfma", "tir_mlp_fwd"),
+OP_OF = (("k_indirect_fused", "tir_indirect_fused_fwd"), ("k_mlp_f16_auxt", "tir_mlp_fwd_auxtab_f16"), ("k_vm_app_h16", "tir_vm_app_fwd_h16"), ("k_mlp_bf16_auxt", "tir_mlp_fwd_bf16x3"), ("k_mlp_bf16<3", "tir_mlp_fwd_bf16x3"), ("k_mlp_bf16_multi<3", "tir_mlp_fwd_bf16x3"), ("k_mlp_bf16<1", "tir_mlp_fwd_bf16"), ("k_mlp_mfma", "tir_mlp_fwd"),
          ("k_vm_app_mfma", "tir_vm_app_fwd"), ("k_vm_app_primary", "tir_vm_app_fwd"), ("k_march_secondary", "tir_march_secondary_fwd"),
          ("k_march_primary", "tir_march_primary_fwd"), ("k_composite_primary", "tir_composite_primary"),
          ("k_density_grad", "tir_density_grad_fwd"), ("k_shade_integrate", "tir_shade_integrate"))
