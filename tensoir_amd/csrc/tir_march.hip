@@ -743,6 +743,9 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
 #ifdef EXP_COUNT_ITERS
     unsigned n_iters = 0;
 #endif
+#ifdef EXP_COUNT_STEPS      // limit study: 64-sample steps this wave executes / those in which no sample is valid (low word)
+    unsigned n_steps = 0, n_empty = 0;
+#endif
 
     for (int64_t batch = xr.first; batch < xr.end; batch += xr.stride) {
         float wreg[4][NSTEP];
@@ -810,6 +813,10 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
 #ifdef EXP_COUNT_ITERS      // limit study: 16-sample gather iterations of this wave in bits 32.. of the counter (slot fill = samples / 16 / this)
                         { const unsigned long long vb = __ballot(valid);        // all 64 lanes vote (not inside the branch)
                           if (stats && half_shift == 0) n_iters += (__popcll(vb) + 15) / 16; }
+#endif
+#ifdef EXP_COUNT_STEPS
+                        { const unsigned long long vb = __ballot(valid);
+                          if (stats && (threadIdx.x & 63) == 0) { n_steps += 1; n_empty += (vb == 0ull); } }
 #endif
                         T = T * __shfl(incl, 31, 32);
                         if (!done && T < t_stop) done = true;
@@ -903,7 +910,9 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
         // the next batch's s_cnt / s_pid writes come after this batch's readers: s_base / s_bb are only rewritten behind
         // the next batch's first __syncthreads, s_pid[rl] / s_cnt[rl] belong to the half-wave that reads them here
     }
-#ifdef EXP_COUNT_ITERS
+#if defined(EXP_COUNT_STEPS)
+    if (stats && (threadIdx.x & 63) == 0 && n_steps) atomicAdd(stats, (unsigned long long)n_empty + ((unsigned long long)n_steps << 32));
+#elif defined(EXP_COUNT_ITERS)
     if (stats && hl == 0 && (n_gather | n_iters)) atomicAdd(stats, (unsigned long long)n_gather + ((unsigned long long)n_iters << 32));
 #else
     if (stats && hl == 0 && n_gather) atomicAdd(stats, (unsigned long long)n_gather);
