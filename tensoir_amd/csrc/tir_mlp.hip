@@ -834,7 +834,26 @@ __device__ __forceinline__ void fus_layer1(unsigned whi, const float (&fo)[16], 
 
 typedef _Float16 fus_f16x2 __attribute__((ext_vector_type(2)));
 
-__global__ void __launch_bounds__(512)
+// layer 2 from PACKED layer-1 activations: hp[p] = (relu(h[2p]), relu(h[2p+1])) as fp16 pairs in accumulator order -- the B operand of
+// k-block KB is hp[4 KB .. 4 KB + 3] as it stands.  With the activations packed (32 registers) the 64 fp32 layer-1 accumulators
+// are dead before layer 2 starts: acc and acc2 never coexist, which is what lets three waves share a SIMD (<= 168 VGPRs).
+template <int KB>
+__device__ __forceinline__ void fus_layer2p(unsigned whi, const unsigned (&hp)[32], f32x16 (&acc)[4]) {
+    bf16x8 ah[4], al[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) ah[mt] = lds_tile(whi, KBX(KB) * 4096 + mt * 512);
+    const u32x4_t H = {hp[4 * KB], hp[4 * KB + 1], hp[4 * KB + 2], hp[4 * KB + 3]};
+    const bf16x8 xh = __builtin_bit_cast(bf16x8, H), xl = {};
+    mfma12<1, true>(ah, al, xh, xl, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (KB + 1 < KB1) fus_layer2p<KB + 1>(whi, hp, acc);
+}
+
+// NW waves per workgroup (tile = 32 NW records).  PACK: the three-waves-per-SIMD form -- the aux-table row is loaded at the START of
+// the decoder phase (no prefetch registers during the gather; the other two waves of the SIMD cover the latency) and layer 2 runs on
+// packed activations (fus_layer2p).
+template <int NW, bool PACK>
+__global__ void __launch_bounds__(NW * 64)
 k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, const float* __restrict__ xyz,
                  const int32_t* __restrict__ light_idx, const int32_t* __restrict__ rec_map, int idx_div, int aux_mod,
                  const float* __restrict__ table, float* __restrict__ out, int64_t n, const int32_t* __restrict__ n_dev,
@@ -842,14 +861,14 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
     using namespace tir;
     constexpr int CA = 48, NQ = 3;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    for (int i = threadIdx.x * 4; i < FH_FLOATS; i += 512 * 4)
+    for (int i = threadIdx.x * 4; i < FH_FLOATS; i += NW * 64 * 4)
         *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(packed + OFF_FF + i);
     f16x8* Wh = reinterpret_cast<f16x8*>(lds + FH_FLOATS);
     float* LT = lds + FH_FLOATS + FUS_WH_BYTES / 4;
     const int n_lt = lt_rows;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     _Float16* X = reinterpret_cast<_Float16*>(LT + (n_lt + 1) * (3 * CA)) + wave * (32 * FUS_XH);
-    for (int e = threadIdx.x; e < 3 * 3 * 2 * 32; e += 512) {
+    for (int e = threadIdx.x; e < 3 * 3 * 2 * 32; e += NW * 64) {
         const int row = e & 31, kg = (e >> 5) & 1, t = (e >> 6) % 3, k = e / 192;
         const int feat = fus_feature_of_row(row);
         f16x8 hv;
@@ -857,14 +876,14 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
         for (int q = 0; q < 8; ++q) hv[q] = feat >= 0 ? (_Float16)f.basis_t[(size_t)(k * CA + 16 * t + 8 * kg + q) * 32 + feat] : (_Float16)0.0f;
         Wh[e] = hv;
     }
-    for (int i = threadIdx.x * 4; i < n_lt * 3 * CA; i += 512 * 4)
+    for (int i = threadIdx.x * 4; i < n_lt * 3 * CA; i += NW * 64 * 4)
         *reinterpret_cast<float4*>(LT + i) = *reinterpret_cast<const float4*>(f.light_line + i);
-    for (int i = threadIdx.x * 4; i < 3 * CA; i += 512 * 4)
+    for (int i = threadIdx.x * 4; i < 3 * CA; i += NW * 64 * 4)
         *reinterpret_cast<float4*>(LT + n_lt * 3 * CA + i) = *reinterpret_cast<const float4*>(f.light_mean + i);
     __syncthreads();
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
 #ifdef EXP_FUSED_STAGGER      // limit study: start the second wave of every SIMD half a tile late (gather of one over the decoder of the other)
-    if (wave >= 4) for (int i = 0; i < EXP_FUSED_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    if (wave >= NW / 2) for (int i = 0; i < EXP_FUSED_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
     const int sl = lane & 31, h = lane >> 5;               // decoder / MFMA role: record column, lane half (= k group)
     const int gj = lane >> 1, gc = lane & 1;               // gather role: record slot, which of every two 16-byte chunks
@@ -872,9 +891,10 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
     const unsigned lane_off = lds0 + BH_FLOATS * 4 + (unsigned)(h * 128 + sl) * 16;
     const unsigned w0hi = opaque(lane_off);
     const unsigned w1hi = opaque(lane_off + BW0A_ELEMS * 2);
-    const int64_t n_tiles = (n + 255) / 256;
+    constexpr int TILE = NW * 32;
+    const int64_t n_tiles = (n + TILE - 1) / TILE;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t r0 = tile * 256 + wave * 32;
+        const int64_t r0 = tile * TILE + wave * 32;
         // ---------------- gather phase: record gj of this wave's 32, two lanes per record
         const int64_t sg = r0 + gj, sgc = sg < n ? sg : n - 1;
         const float p[3] = {xyz[3 * sgc], xyz[3 * sgc + 1], xyz[3 * sgc + 2]};
@@ -893,7 +913,17 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
         f32x16 facc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) facc[r] = 0.0f;
-        f32x16 acc[4], acc2[4];
+        f32x16 acc[4];
+        auto load_table = [&]() {       // the layer-1 accumulators' start values: aux-table row of the record's direction
+            const float* tp = table + ai * HID + 4 * h;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(tp + mt * 32 + 8 * i);
+                    acc[mt][4 * i] = t4.x; acc[mt][4 * i + 1] = t4.y; acc[mt][4 * i + 2] = t4.z; acc[mt][4 * i + 3] = t4.w;
+                }
+        };
 #pragma unroll
         for (int k = 0; k < 3; ++k) {      // unrolled: with a run-time k the coordinate selects below become a scratch table (72 B stored per lane and tile = 0.4 GB of HBM writes per launch, measured)
             const int H = f.grid[(k == 0) ? 1 : 2], W = f.grid[(k == 2) ? 1 : 0], R = f.grid[2 - k];
@@ -917,16 +947,7 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
                 tc[q] = *reinterpret_cast<const uint4*>(p10 + 16 * q); td[q] = *reinterpret_cast<const uint4*>(p11 + 16 * q);
                 te[q] = *reinterpret_cast<const uint4*>(l0 + 16 * q);  tg[q] = *reinterpret_cast<const uint4*>(l1 + 16 * q);
             }
-            if (k == 2) {      // the layer-1 accumulators' start values (aux-table row of the record's direction): in flight behind the last gather group
-                const float* tp = table + ai * HID + 4 * h;
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float4 t4 = *reinterpret_cast<const float4*>(tp + mt * 32 + 8 * i);
-                        acc[mt][4 * i] = t4.x; acc[mt][4 * i + 1] = t4.y; acc[mt][4 * i + 2] = t4.z; acc[mt][4 * i + 3] = t4.w;
-                    }
-            }
+            if (!PACK && k == 2) load_table();      // two waves per SIMD: in flight behind the last gather group
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -948,14 +969,35 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
         float fo[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) fo[r] = __builtin_amdgcn_fmed3f(facc[r], -65504.0f, 65504.0f);
+        if (PACK) load_table();
         fus_layer1<0>(w0hi, fo, acc);
+        f32x16 acc2[4];
+        if constexpr (PACK) {
+            unsigned hp[32];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const float* bp = lds + BH_B1 + (h * 4 + mt) * 16;
+            for (int q = 0; q < 64; q += 2) {
+                // (the builtin, not the inline-asm relu_sat16: these reads come straight behind layer 1's last MFMAs, and the hazard
+                //  recogniser does not insert the MFMA -> VALU wait states for inline asm -- that read stale accumulators: 1e-3 errors)
+                const f32x2_t v2 = {__builtin_amdgcn_fmed3f(acc[q >> 4][q & 15], 0.0f, 65504.0f),
+                                    __builtin_amdgcn_fmed3f(acc[(q + 1) >> 4][(q + 1) & 15], 0.0f, 65504.0f)};
+                hp[q >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, fus_f16x2));
+            }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[mt][r] = bp[r];
+            for (int mt = 0; mt < 4; ++mt) {
+                const float* bp = lds + BH_B1 + (h * 4 + mt) * 16;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[mt][r] = bp[r];
+            }
+            fus_layer2p<0>(w1hi, hp, acc2);
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float* bp = lds + BH_B1 + (h * 4 + mt) * 16;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[mt][r] = bp[r];
+            }
+            layer2_interleaved<1, 0, true>(w1hi, w1hi, acc, acc2);
         }
-        layer2_interleaved<1, 0, true>(w1hi, w1hi, acc, acc2);
         f32x4 o4[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) o4[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -2176,12 +2218,19 @@ extern "C" int tir_indirect_fused_fwd(const TirField* f, const TirFieldHalf* fh,
     if (reinterpret_cast<uintptr_t>(table) % 16 != 0) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
     const int lt_rows = f->n_lights <= 16 ? f->n_lights : 0;
-    const size_t lds = (size_t)FH_BYTES + FUS_WH_BYTES + (size_t)(lt_rows + 1) * 144 * sizeof(float) + (size_t)8 * 32 * FUS_XH * 2;
-    if (int r2 = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_indirect_fused), (int)lds)) return r2;
-    const int64_t tiles = (n + 255) / 256;
+#if defined(EXP_FUSED_W8)   // limit study: two waves per SIMD, aux-table row prefetched during the gather, fp32 layer-1 accumulators kept through layer 2
+    constexpr int NW = 8; constexpr bool PACK = false;
+#elif defined(EXP_FUSED_NW)
+    constexpr int NW = EXP_FUSED_NW; constexpr bool PACK = EXP_FUSED_PACK;
+#else
+    constexpr int NW = 12; constexpr bool PACK = true;
+#endif
+    const size_t lds = (size_t)FH_BYTES + FUS_WH_BYTES + (size_t)(lt_rows + 1) * 144 * sizeof(float) + (size_t)NW * 32 * FUS_XH * 2;
+    if (int r2 = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_indirect_fused<NW, PACK>), (int)lds)) return r2;
+    const int64_t tiles = (n + NW * 32 - 1) / (NW * 32);
     const int grid_max = m->tune_grid > 0 ? m->tune_grid : 256;
     const unsigned grid = (unsigned)(tiles < grid_max ? tiles : grid_max);
-    hipLaunchKernelGGL(k_indirect_fused, dim3(grid), dim3(512), lds, tir_stream(stream), *f, *fh, m->packed, xyz, light_idx, rec_map,
+    hipLaunchKernelGGL((k_indirect_fused<NW, PACK>), dim3(grid), dim3(NW * 64), lds, tir_stream(stream), *f, *fh, m->packed, xyz, light_idx, rec_map,
                        idx_div, aux_mod, table, out, n, n_dev, m->out_dim, m->act, lt_rows);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
