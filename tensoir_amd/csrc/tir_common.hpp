@@ -44,7 +44,7 @@ static inline int tir_allow_dynamic_lds(const void* kernel, int bytes) {
 static inline bool tir_occ_index_ok(const TirField* f) {
     if (!f->occ_nbr) return true;
     const int64_t W = f->occ_dim[0], H = f->occ_dim[1], D = f->occ_dim[2];
-    return W > 0 && H > 0 && D > 0 && H + 1 < (1 << 24) && D + 1 < (1 << 24) && (W + 1) * (H + 1) * (D + 1) < ((int64_t)1 << 31);
+    return W > 0 && H > 0 && D > 0 && W + 1 < (1 << 24) && (H + 1) * (D + 1) < (1 << 24) && (W + 1) * (H + 1) * (D + 1) < ((int64_t)1 << 31);
 }
 
 // the density gathers address plane taps with 32-bit BYTE offsets (tir::density_chunk_impl): every plane must be < 4 GB
@@ -210,9 +210,9 @@ __device__ __forceinline__ bool occupancy_hit(const TirField& f, float px, float
     fx = fminf(fmaxf(fx, -2.0f), (float)W); fy = fminf(fmaxf(fy, -2.0f), (float)H); fz = fminf(fmaxf(fz, -2.0f), (float)D);
     const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
     if ((x0 < -1) | (x0 >= W) | (y0 < -1) | (y0 >= H) | (z0 < -1) | (z0 >= D)) return false;
-    // 32-bit index (launchers check (W+1)(H+1)(D+1) < 2^31, tir_occ_index_ok): one 24-bit and one 32-bit multiply instead of
-    // two 64-bit ones
-    const uint32_t b = f.occ_nbr[(mul_u24((unsigned)(z0 + 1), (unsigned)(H + 1)) + (unsigned)(y0 + 1)) * (unsigned)(W + 1) + (unsigned)(x0 + 1)];
+    // 32-bit index (launchers check (W+1)(H+1)(D+1) < 2^31 and (D+1)(H+1), W+1 < 2^24, tir_occ_index_ok): two full-rate 24-bit
+    // multiplies instead of two 64-bit ones (the 32-bit v_mul_lo_u32 issues at a quarter of the rate)
+    const uint32_t b = f.occ_nbr[mul_u24(mul_u24((unsigned)(z0 + 1), (unsigned)(H + 1)) + (unsigned)(y0 + 1), (unsigned)(W + 1)) + (unsigned)(x0 + 1)];
     // corners with a zero interpolation weight (fraction exactly 0) do not count
     const uint32_t mx = (ix - fx) > 0.0f ? 0xFFu : 0x55u;
     const uint32_t my = (iy - fy) > 0.0f ? 0xFFu : 0x33u;
@@ -513,7 +513,9 @@ __device__ __forceinline__ void occ_t_range(const TirField& f, const float (&o)[
         if (fabsf(d[a]) < 1e-20f) {
             if ((o[a] < f.occ_lo[a]) | (o[a] > f.occ_hi[a])) { t0 = INFINITY; t1 = -INFINITY; }
         } else {
-            const float inv = 1.0f / d[a];
+            // v_rcp_f32 (1 ulp) instead of the IEEE division (~10 instructions per axis): the range only has to be conservative,
+            // and the 1e-4 slack below is ~1000 x the error of the fast reciprocal at these magnitudes (|t| < 10)
+            const float inv = __builtin_amdgcn_rcpf(d[a]);
             const float ta = (f.occ_lo[a] - o[a]) * inv, tb = (f.occ_hi[a] - o[a]) * inv;
             t0 = fmaxf(t0, fminf(ta, tb));
             t1 = fminf(t1, fmaxf(ta, tb));
