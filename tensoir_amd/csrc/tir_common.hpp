@@ -505,18 +505,19 @@ __device__ __forceinline__ bool sample_valid(const TirField& f, float px, float 
 // sample_valid in any case: the march kernels use the range to skip whole 32-sample steps without touching them, which
 // changes no result (a culled sample contributes alpha = 0: T * (1 + 1e-10) == T in fp32, weight 0).  Box not given
 // (occ_lo >= occ_hi) -> (-inf, +inf); the ray misses the box -> t0 > t1.
-__device__ __forceinline__ void occ_t_range(const TirField& f, const float (&o)[3], const float (&d)[3], float& t0, float& t1) {
+__device__ __forceinline__ void occ_t_range(const float (&occ_lo)[3], const float (&occ_hi)[3], const float (&o)[3], const float (&d)[3],
+                                            float& t0, float& t1) {
     t0 = -INFINITY; t1 = INFINITY;
-    if (!((f.occ_lo[0] < f.occ_hi[0]) & (f.occ_lo[1] < f.occ_hi[1]) & (f.occ_lo[2] < f.occ_hi[2]))) return;
+    if (!((occ_lo[0] < occ_hi[0]) & (occ_lo[1] < occ_hi[1]) & (occ_lo[2] < occ_hi[2]))) return;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         if (fabsf(d[a]) < 1e-20f) {
-            if ((o[a] < f.occ_lo[a]) | (o[a] > f.occ_hi[a])) { t0 = INFINITY; t1 = -INFINITY; }
+            if ((o[a] < occ_lo[a]) | (o[a] > occ_hi[a])) { t0 = INFINITY; t1 = -INFINITY; }
         } else {
             // v_rcp_f32 (1 ulp) instead of the IEEE division (~10 instructions per axis): the range only has to be conservative,
             // and the 1e-4 slack below is ~1000 x the error of the fast reciprocal at these magnitudes (|t| < 10)
             const float inv = __builtin_amdgcn_rcpf(d[a]);
-            const float ta = (f.occ_lo[a] - o[a]) * inv, tb = (f.occ_hi[a] - o[a]) * inv;
+            const float ta = (occ_lo[a] - o[a]) * inv, tb = (occ_hi[a] - o[a]) * inv;
             t0 = fmaxf(t0, fminf(ta, tb));
             t1 = fminf(t1, fmaxf(ta, tb));
         }

@@ -703,14 +703,14 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
 // of the ficus config: 76.8 KB of lines); RPB = NT / 8 rays per batch.
 template <int C4, int NSTEP, int NT>
 __global__ void __launch_bounds__(NT, 4)
-k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32_t* __restrict__ org_map,
-                      const float* __restrict__ dirs, const int32_t* __restrict__ dir_map,
-                      const uint8_t* __restrict__ active, int64_t n_rays, int n_dirs, int n_sample,
-                      const float* __restrict__ z_vals, float t_stop, float* __restrict__ vis,
-                      float* __restrict__ one_minus_acc, int32_t* __restrict__ rec_counter, int64_t rec_cap,
-                      int32_t* __restrict__ rec_ray, float* __restrict__ rec_w, float* __restrict__ rec_xyz,
-                      int32_t* __restrict__ ray_rec_off, int32_t* __restrict__ ray_rec_cnt,
-                      unsigned long long* __restrict__ stats, int xcd_on, const int32_t* __restrict__ ray_ids,
+k_march_secondary_lds(TirField f, const float* __restrict__ origins_a, const int32_t* __restrict__ org_map_a,
+                      const float* __restrict__ dirs_a, const int32_t* __restrict__ dir_map_a,
+                      const uint8_t* __restrict__ active_a, int64_t n_rays, int n_dirs, int n_sample,
+                      const float* __restrict__ z_vals, float t_stop, float* __restrict__ vis_a,
+                      float* __restrict__ one_minus_acc_a, int32_t* __restrict__ rec_counter_a, int64_t rec_cap_a,
+                      int32_t* __restrict__ rec_ray_a, float* __restrict__ rec_w_a, float* __restrict__ rec_xyz_a,
+                      int32_t* __restrict__ ray_rec_off_a, int32_t* __restrict__ ray_rec_cnt_a,
+                      unsigned long long* __restrict__ stats_a, int xcd_on, const int32_t* __restrict__ ray_ids_a,
                       const int32_t* __restrict__ n_ids_dev, int line_floats) {
     constexpr int RPB = NT / 8, NHW = NT / 32;                  // rays per batch, half-waves per block
     extern __shared__ __attribute__((aligned(16))) float sl_lds[];
@@ -722,6 +722,19 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
     int* s_base = s_cnt + RPB;
     int* s_pid = s_base + RPB;
     __shared__ int s_wtot[2], s_bb, s_fits;
+    // The seven record-phase arguments are used once per batch of 64 / 128 rays, but as kernel arguments they would sit in 14
+    // SGPRs through the whole march -- whose hot loop already spills ~100 SGPRs to VGPR lanes and pays a v_readlane (VALU, the
+    // binding pipe) for each use.  They are parked in LDS here and read back (as per-lane values) where the records are written.
+    // (the per-ray arguments -- pair list, origins, directions, outputs: used four times per batch -- are parked with them)
+    struct Parked { int32_t* rec_counter; int64_t rec_cap; int32_t* rec_ray; float* rec_w; float* rec_xyz; int32_t* ray_rec_off; int32_t* ray_rec_cnt;
+                    const float* origins; const int32_t* org_map; const float* dirs; const int32_t* dir_map; const uint8_t* active;
+                    float* vis; float* one_minus_acc; const int32_t* ray_ids; unsigned long long* stats; float occ_lo[3], occ_hi[3]; };
+    __shared__ Parked s_park;
+    const bool want_rec = rec_counter_a != nullptr;
+    if (threadIdx.x == 0) s_park = Parked{rec_counter_a, rec_cap_a, rec_ray_a, rec_w_a, rec_xyz_a, ray_rec_off_a, ray_rec_cnt_a,
+                                          origins_a, org_map_a, dirs_a, dir_map_a, active_a, vis_a, one_minus_acc_a, ray_ids_a, stats_a,
+                                          {f.occ_lo[0], f.occ_lo[1], f.occ_lo[2]}, {f.occ_hi[0], f.occ_hi[1], f.occ_hi[2]}};
+    const bool stats = stats_a != nullptr;
     {   // stage the line factors (coalesced 16-B copies; lines are [R][16] rows, contiguous)
         int off = 0;
         for (int i = 0; i < 3; ++i) {
@@ -733,12 +746,11 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
         for (int i = threadIdx.x; i < n_sample; i += NT) zt[i] = z_vals[i];
     }
     __syncthreads();
-    if (ray_ids && n_ids_dev) n_rays = min(n_rays, (int64_t)max(*n_ids_dev, 0));
+    if (ray_ids_a && n_ids_dev) n_rays = min(n_rays, (int64_t)max(*n_ids_dev, 0));
     const int64_t n_batches = (n_rays + RPB - 1) / RPB;
     const XcdRange xr = xcd_range(n_batches, 1, xcd_on != 0);
     const int hl = threadIdx.x & 31, hw = threadIdx.x >> 5;     // lane in the half-wave, half-wave in the block (0..15)
     const unsigned half_shift = (threadIdx.x & 32) ? 32 : 0;
-    const bool want_rec = rec_counter != nullptr;
     unsigned n_gather = 0;
 #ifdef EXP_COUNT_ITERS
     unsigned n_iters = 0;
@@ -752,6 +764,10 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
         int cnts[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            const float* const origins = s_park.origins; const int32_t* const org_map = s_park.org_map;
+            const float* const dirs = s_park.dirs; const int32_t* const dir_map = s_park.dir_map;
+            const uint8_t* const active = s_park.active; const int32_t* const ray_ids = s_park.ray_ids;
+            float* const vis = s_park.vis; float* const one_minus_acc = s_park.one_minus_acc;
             const int rl = g * NHW + hw;
             const int64_t slot_id = batch * RPB + rl;
             const bool in_range = slot_id < n_rays;
@@ -775,7 +791,7 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
                 bool done = !live;
                 bool all_done = false;
                 float t_in, t_out;                                  // where the ray can meet occupied space at all
-                occ_t_range(f, o, d, t_in, t_out);
+                occ_t_range(s_park.occ_lo, s_park.occ_hi, o, d, t_in, t_out);
 #pragma unroll
                 for (int st = 0; st < NSTEP; ++st) {
                     const int k = st * 32 + hl;
@@ -856,6 +872,8 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
         }
         __syncthreads();
         if (threadIdx.x == 0) {
+            int32_t* rec_counter = s_park.rec_counter;
+            const int64_t rec_cap = s_park.rec_cap;
             const int total = s_wtot[0] + (RPB > 64 ? s_wtot[1] : 0);
             int base = 0;
             if (total > 0) base = atomicAdd(rec_counter, total);
@@ -870,12 +888,17 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
             const int pid = s_pid[threadIdx.x];
             const bool fits = s_fits != 0;
             if (pid >= 0) {
-                ray_rec_off[pid] = s_bb + incl - c;
-                ray_rec_cnt[pid] = fits ? c : 0;
+                s_park.ray_rec_off[pid] = s_bb + incl - c;
+                s_park.ray_rec_cnt[pid] = fits ? c : 0;
             }
             s_base[threadIdx.x] = (fits && c > 0) ? s_bb + incl - c : -1;
         }
         __syncthreads();
+        int32_t* const rec_ray = s_park.rec_ray;
+        float* const rec_w = s_park.rec_w;
+        float* const rec_xyz = s_park.rec_xyz;
+        const float* const origins = s_park.origins; const int32_t* const org_map = s_park.org_map;
+        const float* const dirs = s_park.dirs; const int32_t* const dir_map = s_park.dir_map;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int rl = g * NHW + hw;
@@ -911,11 +934,11 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins, const int32
         // the next batch's first __syncthreads, s_pid[rl] / s_cnt[rl] belong to the half-wave that reads them here
     }
 #if defined(EXP_COUNT_STEPS)
-    if (stats && (threadIdx.x & 63) == 0 && n_steps) atomicAdd(stats, (unsigned long long)n_empty + ((unsigned long long)n_steps << 32));
+    if (stats && (threadIdx.x & 63) == 0 && n_steps) atomicAdd(s_park.stats, (unsigned long long)n_empty + ((unsigned long long)n_steps << 32));
 #elif defined(EXP_COUNT_ITERS)
-    if (stats && hl == 0 && (n_gather | n_iters)) atomicAdd(stats, (unsigned long long)n_gather + ((unsigned long long)n_iters << 32));
+    if (stats && hl == 0 && (n_gather | n_iters)) atomicAdd(s_park.stats, (unsigned long long)n_gather + ((unsigned long long)n_iters << 32));
 #else
-    if (stats && hl == 0 && n_gather) atomicAdd(stats, (unsigned long long)n_gather);
+    if (stats && hl == 0 && n_gather) atomicAdd(s_park.stats, (unsigned long long)n_gather);
 #endif
 }
 
