@@ -485,6 +485,21 @@ int tir_relight_importance(const float* normal, const float* albedo, const float
 int tir_env_sample_setup(const float* row_cdf, const float* col_cdf, int32_t H, int32_t W, const float* env_dir,
                          const float* normal, int32_t M, int32_t Ns, uint64_t seed, uint64_t offset,
                          int32_t* cell, uint8_t* active, void* stream);
+/* tir_env_sample_setup_list: the same draws and mask (same Philox counters: identical cells), plus what the visibility
+ *   query of :128-160 needs -- the UNMASKED pairs only, as a list.  pair_ids [M*Ns] receives the ids m*Ns + s of the pairs
+ *   that pass the cosine mask, n_active [1] (zero on entry) their count; vis [M][Ns] is set to 0 for the masked pairs (the
+ *   march -- tir_march_secondary_ids_fwd with ray_ids = pair_ids, n_ids_dev = n_active -- fills the rest).  The list is
+ *   grouped: blocks of `block_pairs` consecutive pairs (256 ... 32768), inside a block by direction bin (bins_r x bins_c
+ *   equal cells of the map, <= 255 bins; 1 x 1 = plain compaction), so that neighbouring list entries are nearly parallel
+ *   rays from neighbouring surface points.  The order of the list enters no result.
+ *   row_guide [guide_rows + 1] / col_guide [H][guide_cols + 2] (both or neither; sizes powers of two; a column row holds
+ *   guide_cols + 1 entries and one pad): guide[k] = the search result for u = k / G (last entry = n - 1); the inverse-CDF
+ *   search then starts inside [guide[k], guide[k+1]], k = floor(u G), and returns the same cell as the full search. */
+int tir_env_sample_setup_list(const float* row_cdf, const float* col_cdf, int32_t H, int32_t W, const float* env_dir,
+                                const float* normal, int32_t M, int32_t Ns, uint64_t seed, uint64_t offset,
+                                int32_t bins_r, int32_t bins_c, int32_t block_pairs, const int32_t* row_guide,
+                                const uint16_t* col_guide, int32_t guide_rows, int32_t guide_cols, int32_t* cell,
+                                float* vis, int32_t* pair_ids, int32_t* n_active, void* stream);
 int tir_relight_importance_cells(const float* normal, const float* albedo, const float* rough,
                                  const float* fresnel, const float* rays_d, const int32_t* cell,
                                  const float* env_dir, const float* env_rgb, const float* env_pdf,

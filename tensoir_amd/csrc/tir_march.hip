@@ -730,6 +730,7 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins_a, const int
                     const float* origins; const int32_t* org_map; const float* dirs; const int32_t* dir_map; const uint8_t* active;
                     float* vis; float* one_minus_acc; const int32_t* ray_ids; unsigned long long* stats; float occ_lo[3], occ_hi[3]; };
     __shared__ Parked s_park;
+    __shared__ __attribute__((aligned(16))) float s_setup[NT / 64][8][12];     // per wave: set-up slots of its 8 rays of a batch
     const bool want_rec = rec_counter_a != nullptr;
     if (threadIdx.x == 0) s_park = Parked{rec_counter_a, rec_cap_a, rec_ray_a, rec_w_a, rec_xyz_a, ray_rec_off_a, ray_rec_cnt_a,
                                           origins_a, org_map_a, dirs_a, dir_map_a, active_a, vis_a, one_minus_acc_a, ray_ids_a, stats_a,
@@ -759,39 +760,62 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins_a, const int
     unsigned n_steps = 0, n_empty = 0;
 #endif
 
+    // this wave's 8 rays of a batch (4 groups x 2 half-waves): set-up slots of 12 floats [o | d | t_in t_out | pair id, flags]
+    float* const sw = &s_setup[threadIdx.x >> 6][0][0];
+    const float* const sh = sw + ((threadIdx.x >> 5) & 1) * 12;   // group g of this half-wave: sh + 24 g
+
     for (int64_t batch = xr.first; batch < xr.end; batch += xr.stride) {
         float wreg[4][NSTEP];
         int cnts[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        // Per-ray set-up ONCE per batch with one lane per ray (lanes 0..7 of the wave), handed to the half-waves through LDS:
+        // pair id -> (point, direction) division, the six loads and the slab test were ~160 VALU instructions executed by all
+        // 64 lanes for 2 rays, four times per batch (17 % of the kernel's VALU work), and again in the record pass.
+        if ((threadIdx.x & 63) < 8) {
+            const int q = threadIdx.x & 7;
+            const int rl = (q >> 1) * NHW + ((threadIdx.x >> 6) << 1) + (q & 1);
             const float* const origins = s_park.origins; const int32_t* const org_map = s_park.org_map;
             const float* const dirs = s_park.dirs; const int32_t* const dir_map = s_park.dir_map;
             const uint8_t* const active = s_park.active; const int32_t* const ray_ids = s_park.ray_ids;
-            float* const vis = s_park.vis; float* const one_minus_acc = s_park.one_minus_acc;
-            const int rl = g * NHW + hw;
             const int64_t slot_id = batch * RPB + rl;
             const bool in_range = slot_id < n_rays;
             const int64_t ray = in_range ? (ray_ids ? (int64_t)ray_ids[slot_id] : slot_id) : 0;
             const bool live = in_range && !(active && !active[ray]);
+            float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+            if (live) {
+                // pair id -> (point, direction) with 32-bit division (pair ids are < 2^31, checked at launch; the 64-bit
+                // form costs ~200 instructions per ray)
+                const unsigned ru = (unsigned)ray, nd = (unsigned)n_dirs;
+                const size_t oi = org_map ? (size_t)org_map[ray] : (n_dirs > 0 ? (size_t)(ru / nd) : (size_t)ray);
+                const size_t di = dir_map ? (size_t)dir_map[ray] : (n_dirs > 0 ? (size_t)(ru % nd) : (size_t)ray);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { o[a] = origins[3 * oi + a]; d[a] = dirs[3 * di + a]; }
+            }
+            float t_in, t_out;                                  // where the ray can meet occupied space at all
+            occ_t_range(s_park.occ_lo, s_park.occ_hi, o, d, t_in, t_out);
+            float4* const dst = reinterpret_cast<float4*>(sw + q * 12);
+            dst[0] = make_float4(o[0], o[1], o[2], d[0]);
+            dst[1] = make_float4(d[1], d[2], t_in, t_out);
+            dst[2] = make_float4(__int_as_float((int)ray), __int_as_float((in_range ? 1 : 0) | (live ? 2 : 0)), 0.f, 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();      // LDS ops of one wave complete in order; keep the compiler from reordering
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float* const vis = s_park.vis; float* const one_minus_acc = s_park.one_minus_acc;
+            const int rl = g * NHW + hw;
+            const float4 s0 = *reinterpret_cast<const float4*>(sh + 24 * g);
+            const float4 s1 = *reinterpret_cast<const float4*>(sh + 24 * g + 4);
+            const float4 s2 = *reinterpret_cast<const float4*>(sh + 24 * g + 8);
+            const int64_t ray = (int64_t)__float_as_int(s2.x);
+            const bool in_range = (__float_as_int(s2.y) & 1) != 0, live = (__float_as_int(s2.y) & 2) != 0;
             int cnt = 0;
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st) wreg[g][st] = 0.0f;
             if (__any(live)) {
-                float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
-                if (live) {
-                    // pair id -> (point, direction) with 32-bit division (pair ids are < 2^31, checked at launch; the 64-bit
-                    // form costs ~200 instructions per ray)
-                    const unsigned ru = (unsigned)ray, nd = (unsigned)n_dirs;
-                    const size_t oi = org_map ? (size_t)org_map[ray] : (n_dirs > 0 ? (size_t)(ru / nd) : (size_t)ray);
-                    const size_t di = dir_map ? (size_t)dir_map[ray] : (n_dirs > 0 ? (size_t)(ru % nd) : (size_t)ray);
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) { o[a] = origins[3 * oi + a]; d[a] = dirs[3 * di + a]; }
-                }
+                const float o[3] = {s0.x, s0.y, s0.z}, d[3] = {s0.w, s1.x, s1.y};
+                const float t_in = s1.z, t_out = s1.w;
                 float T = 1.0f, acc = 0.0f;
                 bool done = !live;
                 bool all_done = false;
-                float t_in, t_out;                                  // where the ray can meet occupied space at all
-                occ_t_range(s_park.occ_lo, s_park.occ_hi, o, d, t_in, t_out);
 #pragma unroll
                 for (int st = 0; st < NSTEP; ++st) {
                     const int k = st * 32 + hl;
@@ -897,19 +921,15 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins_a, const int
         int32_t* const rec_ray = s_park.rec_ray;
         float* const rec_w = s_park.rec_w;
         float* const rec_xyz = s_park.rec_xyz;
-        const float* const origins = s_park.origins; const int32_t* const org_map = s_park.org_map;
-        const float* const dirs = s_park.dirs; const int32_t* const dir_map = s_park.dir_map;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int rl = g * NHW + hw;
             int base = s_base[rl];
             if (base < 0) continue;                    // uniform inside the half-wave
             const int64_t ray = s_pid[rl];
-            const size_t oi = org_map ? (size_t)org_map[ray] : (n_dirs > 0 ? (size_t)((unsigned)ray / (unsigned)n_dirs) : (size_t)ray);
-            const size_t di = dir_map ? (size_t)dir_map[ray] : (n_dirs > 0 ? (size_t)((unsigned)ray % (unsigned)n_dirs) : (size_t)ray);
-            float o[3], d[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) { o[a] = origins[3 * oi + a]; d[a] = dirs[3 * di + a]; }
+            const float4 s0 = *reinterpret_cast<const float4*>(sh + 24 * g);          // this batch's set-up slot of the ray
+            const float2 s1 = *reinterpret_cast<const float2*>(sh + 24 * g + 4);
+            const float o[3] = {s0.x, s0.y, s0.z}, d[3] = {s0.w, s1.x, s1.y};
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st) {
                 const int k = st * 32 + hl;
@@ -978,10 +998,10 @@ extern "C" int tir_march_secondary_ids_fwd(const TirField* f, const float* origi
         const int64_t line_floats = (int64_t)(f->grid[0] + f->grid[1] + f->grid[2]) * f->n_dcomp;
         const size_t fixed = ((size_t)line_floats + ((n_sample + 3) & ~3)) * sizeof(float);
         const size_t lds512 = fixed + (8 * 256 + 3 * 64) * sizeof(float), lds1024 = fixed + (16 * 256 + 3 * 128) * sizeof(float);
-        if (f->tune_lds_lines != 2 && f->n_dcomp == 16 && n_sample <= 96 && lds1024 <= 150 * 1024) {
+        if (f->tune_lds_lines != 2 && f->n_dcomp == 16 && n_sample <= 96 && lds1024 + 8192 <= 158 * 1024) {
             if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_march_secondary_lds<4, 3, 512>), 80 * 1024)) return rc;
             if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_march_secondary_lds<4, 3, 1024>), 150 * 1024)) return rc;
-            const bool small = lds512 <= 80 * 1024;                 // two 512-thread blocks per CU, else one of 1024
+            const bool small = lds512 + 4096 <= 80 * 1024;          // two 512-thread blocks per CU (4 KB: the kernel's static LDS), else one of 1024
             const int rpb = small ? 64 : 128;
             const int64_t n_batches = (n_rays + rpb - 1) / rpb;
             unsigned nblk = (unsigned)std::min<int64_t>(n_batches, small ? 2 * 256 : 256);

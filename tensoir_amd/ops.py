@@ -865,6 +865,66 @@ def env_sample_setup(row_cdf, col_cdf, env_dir, normal, n_samples, seed, offset)
     return cell, active
 
 
+def c5_pair_order():
+    """How the importance-sampled (point, cell) pairs reach the visibility march: TENSOIR_C5_PAIRS = `binned` (default: the
+    compacted list of the unmasked pairs, every 512 consecutive pairs -- one surface point at 512 samples -- ordered by a
+    15 x 17 grid of direction bins, tir_env_sample_setup_list), `compact` (the same list without the bins) or `mask` (every
+    pair with a uint8 mask, tir_env_sample_setup).  Results do not depend on it (profiles/r04_c5_pair_lists.json).
+    Returns (mode, bins, block_pairs); TENSOIR_C5_BINS = `RxC` and TENSOIR_C5_BLOCK_PAIRS override the list's grouping."""
+    mode = os.environ.get("TENSOIR_C5_PAIRS", "binned").strip().lower() or "binned"
+    if mode not in ("binned", "compact", "mask"):
+        raise ValueError(f"TENSOIR_C5_PAIRS={mode!r}: expected binned, compact or mask")
+    bins, block = ((15, 17), 512) if mode == "binned" else ((1, 1), 512)
+    if os.environ.get("TENSOIR_C5_BINS"):
+        bins = tuple(int(v) for v in os.environ["TENSOIR_C5_BINS"].lower().split("x"))
+        if len(bins) != 2:
+            raise ValueError("TENSOIR_C5_BINS: expected ROWSxCOLS, e.g. 8x8")
+    if os.environ.get("TENSOIR_C5_BLOCK_PAIRS"):
+        block = int(os.environ["TENSOIR_C5_BLOCK_PAIRS"])
+    return mode, bins, block
+
+
+def cdf_guide_tables(row_cdf, col_cdf):
+    """Guide tables of the inverse-CDF search (tir_env_sample_setup_list): for G = the next power of two >= n, entry k of
+    a table is the search result for u = k / G -- the first index whose cdf exceeds it, clamped to n - 1.  Built with
+    torch.searchsorted on the fp32 tables the kernel searches (k / G is exact in fp32).  Returns (row_guide int32 [Gr + 1],
+    col_guide [H, Gc + 2] 16-bit entries packed in pairs into int32 [H, Gc / 2 + 1] (little endian; the last entry pads the
+    row to whole words), Gr, Gc), or None when a row has more than 65535 columns."""
+    H, W = col_cdf.shape
+    if W > 65535:
+        return None
+    gr, gc = 1 << max(0, (H - 1).bit_length()), 1 << max(0, (W - 1).bit_length())
+    dev = row_cdf.device
+    tr = torch.arange(gr + 1, dtype=torch.float32, device=dev) / gr
+    tc = torch.arange(gc + 1, dtype=torch.float32, device=dev) / gc
+    rg = torch.searchsorted(row_cdf.contiguous(), tr, right=True).clamp_(max=H - 1).to(torch.int32)
+    cg = torch.searchsorted(col_cdf.contiguous(), tc.unsqueeze(0).expand(H, -1).contiguous(), right=True).clamp_(max=W - 1)
+    rg[-1], cg[:, -1] = H - 1, W - 1
+    cg = torch.cat([cg, cg[:, -1:]], dim=1).to(torch.int32)                      # Gc + 2 entries per row
+    packed = (cg[:, 0::2] | (cg[:, 1::2] << 16)).to(torch.int32)                 # two 16-bit entries per word
+    return rg.contiguous(), packed.contiguous(), gr, gc
+
+
+def env_sample_setup_list(row_cdf, col_cdf, env_dir, normal, n_samples, seed, offset, bins=(1, 1), block_pairs=256, guide=None):
+    """tir_env_sample_setup_list: cells of every (point, sample) + the list of the pairs that pass the cosine mask.
+    Returns cell [M, Ns] int32, vis [M, Ns] fp32 (0 where masked, the rest for the march to fill), pair_ids [M*Ns] int32,
+    n_active [1] int32 (device)."""
+    H, W = col_cdf.shape
+    normal = f32(normal, "normal", 3)
+    M, dev = normal.shape[0], normal.device
+    cell = torch.empty((M, n_samples), dtype=torch.int32, device=dev)
+    vis = torch.empty((M, n_samples), dtype=torch.float32, device=dev)
+    pair_ids = torch.empty((M * n_samples,), dtype=torch.int32, device=dev)
+    n_active = torch.zeros((1,), dtype=torch.int32, device=dev)
+    _call("tir_env_sample_setup_list", _ptr(f32(row_cdf, "row_cdf")), _ptr(f32(col_cdf, "col_cdf")), H, W,
+          _ptr(f32(env_dir, "env_dir", 3)), _ptr(normal), M, int(n_samples), int(seed) & (2 ** 64 - 1),
+          int(offset) & (2 ** 64 - 1), int(bins[0]), int(bins[1]), int(block_pairs),
+          *((None, None, 0, 0) if guide is None else (_ptr(_req(guide[0], torch.int32, "row_guide")),
+                                                      _ptr(_req(guide[1], torch.int32, "col_guide")), int(guide[2]), int(guide[3]))),
+          _ptr(cell), _ptr(vis), _ptr(pair_ids), _ptr(n_active), _stream())
+    return cell, vis, pair_ids, n_active
+
+
 def relight_importance_cells(normal, albedo, rough, fresnel, rays_d, cell, env_dir, env_rgb, env_pdf, vis):
     normal, albedo = f32(normal, "normal", 3), f32(albedo, "albedo", 3)
     rough = f32(rough, "roughness").view(-1)

@@ -2,6 +2,8 @@
 meaning and return shapes; per-sample work runs in libtensoir_hip.so."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -283,7 +285,7 @@ class Environment_Light:
 
     def __init__(self, hdr_path=None, device="cuda", hdr_maps=None):
         self.hdr_rgbs, self.hdr_pdf_sample, self.hdr_pdf_return, self.hdr_dir = {}, {}, {}, {}
-        self.hdr_row_cdf, self.hdr_col_cdf = {}, {}
+        self.hdr_row_cdf, self.hdr_col_cdf, self.hdr_cdf_guide = {}, {}, {}
         self._draws = 0
         maps = dict(hdr_maps or {})
         if torch.device(device).type == "cuda" and not torch.cuda.is_available():
@@ -294,7 +296,6 @@ class Environment_Light:
             spec = {"h": 32, "w": 64, **{k: v for k, v in parse_spec(hdr_path).items() if k in ("h", "w")}}
             maps.update(synth.make_hdr_maps(synth.HDR_NAMES, int(spec["h"]), int(spec["w"])))
         elif hdr_path is not None:
-            import os
             for file in os.listdir(hdr_path):
                 if file.endswith(".hdr"):
                     maps[file.split(".")[0]] = torch.from_numpy(read_hdr(os.path.join(hdr_path, file)))
@@ -325,6 +326,9 @@ class Environment_Light:
             col_cdf[:, -1] = 1.0
             self.hdr_row_cdf[name] = row_cdf.float().to(device).contiguous()
             self.hdr_col_cdf[name] = col_cdf.float().to(device).contiguous()
+            # guide tables of that search (ops.cdf_guide_tables): ~4 dependent loads per draw instead of log2(H) + log2(W)
+            self.hdr_cdf_guide[name] = (ops.cdf_guide_tables(self.hdr_row_cdf[name], self.hdr_col_cdf[name])
+                                        if os.environ.get("TENSOIR_CDF_GUIDE", "1") != "0" else None)
 
     @torch.no_grad()
     def sample_light(self, light_name, bs, num_samples, sample_type="importance"):
@@ -349,6 +353,17 @@ class Environment_Light:
         return ops.env_sample_setup(self.hdr_row_cdf[light_name], self.hdr_col_cdf[light_name],
                                     self.hdr_dir[light_name].view(-1, 3), normal, num_samples,
                                     torch.cuda.initial_seed(), self._draws)
+
+    @torch.no_grad()
+    def sample_cells_listed(self, light_name, normal, num_samples, bins=(1, 1), block_pairs=256):
+        """sample_cells with the same draws (same Philox counters) + the compacted list of the unmasked pairs, optionally
+        direction-binned inside blocks of `block_pairs` pairs (tir_env_sample_setup_list).  Returns (cell [M, Ns], vis [M, Ns] with the masked pairs' zeros, pair_ids,
+        n_active)."""
+        self._draws += 1
+        return ops.env_sample_setup_list(self.hdr_row_cdf[light_name], self.hdr_col_cdf[light_name],
+                                           self.hdr_dir[light_name].view(-1, 3), normal, num_samples,
+                                           torch.cuda.initial_seed(), self._draws, bins, block_pairs,
+                                           self.hdr_cdf_guide.get(light_name))
 
     def get_light(self, light_name, incident_dir):
         """:191-205 (background lookup, bilinear, align_corners=True) -> tir_env_lookup."""
@@ -401,7 +416,15 @@ def relight_importance_sampled(tensoIR, env, light_name, surface_xyz, normal, al
     M = normal.shape[0]
     if M == 0:
         return torch.zeros((0, 3), dtype=torch.float32, device=dev)
-    cell, active = env.sample_cells(light_name, normal, num_samples)
+    order, bins, block_pairs = ops.c5_pair_order()
+    if order == "mask":
+        cell, active = env.sample_cells(light_name, normal, num_samples)
+        listed = {}
+    else:
+        # :127-131 query visibility for the unmasked pairs only: so does the march, from a compacted list
+        cell, vis0, pair_ids, n_active = env.sample_cells_listed(light_name, normal, num_samples, bins, block_pairs)
+        active = None
+        listed = dict(ray_ids=pair_ids, n_ids_dev=n_active, vis=vis0.view(-1))
     key = ("orgmap", M, num_samples, str(dev))
     org_map = _CONST_CACHE.get(key)
     if org_map is None:
@@ -413,8 +436,8 @@ def relight_importance_sampled(tensoIR, env, light_name, surface_xyz, normal, al
     z = _z_table(nSample, vis_near, vis_far, dev)
     env_dir = env.hdr_dir[light_name].view(-1, 3)
     vis, _, _ = ops.march_secondary(tensoIR.packed_field(), surface_xyz.to(torch.float32).contiguous(), env_dir, z,
-                                    M * num_samples, org_map, cell.view(-1), active.view(-1), tensoIR.march_t_stop, False, 0,
-                                    False)
+                                    M * num_samples, org_map, cell.view(-1), None if active is None else active.view(-1),
+                                    tensoIR.march_t_stop, False, 0, False, **listed)
     return ops.relight_importance_cells(normal, albedo, roughness, fresnel, rays_d, cell, env_dir,
                                         env.hdr_rgbs[light_name].view(-1, 3), env.hdr_pdf_return[light_name].view(-1),
                                         vis.view(M, num_samples))

@@ -907,6 +907,71 @@ def test_c5_hdr_relight_2048x1024_importance_512(full3):
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("ns", [512, 100])
+def test_c5_pair_list_orders_are_bit_identical(full3, monkeypatch, ns):
+    """scripts/relight_importance.py:127-131 queries visibility for the pairs that pass the cosine mask only.  The device
+    path hands them to the march as a compacted, direction-binned list (tir_env_sample_setup_list): same cells as the
+    masked sampler (same Philox counters), the list = exactly the unmasked pair ids, zeros in vis where masked, and relit
+    colours bit-identical between the masked march, the plain compaction and binned lists of several block sizes
+    (ragged tail: M * Ns is not a multiple of the block)."""
+    from tensoir_amd import relight, synth
+    m = full3.model
+    gen = torch.Generator().manual_seed(72)
+    H, W = (256, 512) if ns == 512 else (200, 300)     # the second: guide tables larger than the map (256 / 512 thresholds)
+    hdr = torch.exp(torch.randn(H // 8, W // 4, 3, generator=gen) * 1.5)
+    hdr = torch.nn.functional.interpolate(hdr.permute(2, 0, 1)[None], size=(H, W), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).contiguous()
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    hdr[((yy - 70) ** 2 + (xx - 200) ** 2) < 6 ** 2] *= 300.0         # a sun: long plateaus and one steep step in the CDFs
+    hdr[150:160] = 0.0                                                  # rows without mass
+    env = relight.Environment_Light(hdr_maps={"syn": hdr}, device="cuda")
+    assert env.hdr_cdf_guide["syn"] is not None       # the listed sampler searches from guide tables, sample_cells does not
+    rays = synth.make_rays(64, 64).cuda()[::3].contiguous()
+    lidx = torch.zeros(rays.shape[0], 1, dtype=torch.int32, device="cuda")
+    out = m(rays, lidx, N_samples=512)
+    depth, normal, albedo, rough, fres, acc = out[1], out[2], out[3], out[4], out[5], out[6]
+    mask = acc > 0.5
+    M = int(mask.sum())
+    assert M > 500
+    surf = (rays[:, :3] + depth.unsqueeze(-1) * rays[:, 3:])[mask]
+    nrm = normal[mask].contiguous()
+    torch.manual_seed(9)
+    draws = env._draws
+    cell, active = env.sample_cells("syn", nrm, ns)
+    assert float((((cell // W) - 70).abs() <= 6).float().mean()) > 0.02          # the sun's rows are drawn often
+    for bins, block in (((8, 8), 4096), ((1, 1), 256), ((15, 17), 32768), ((4, 16), 1000)):
+        env._draws = draws
+        cell_b, vis0, pair_ids, n_active = env.sample_cells_listed("syn", nrm, ns, bins, block)
+        torch.cuda.synchronize()
+        n = int(n_active.item())
+        assert torch.equal(cell_b, cell)
+        assert n == int(active.sum())
+        want = torch.nonzero(active.view(-1)).view(-1).to(torch.int32)
+        assert torch.equal(torch.sort(pair_ids[:n]).values, want)
+        assert bool((vis0.view(-1)[~active.view(-1).bool()] == 0).all())
+        if bins == (8, 8):                 # inside a block the list is bin-major
+            ids = pair_ids[:n].long()
+            c = cell.view(-1)[ids].long()
+            key = ((c // W) * 8 // H) * 8 + ((c % W) * 8 // W)
+            blk = ids // block
+            same = blk[1:] == blk[:-1]
+            assert bool((key[1:][same] >= key[:-1][same]).all())
+    cols = {}
+    for mode, extra in (("mask", {}), ("compact", {}), ("binned", {}), ("binned", {"TENSOIR_C5_BLOCK_PAIRS": "1000", "TENSOIR_C5_BINS": "3x5"})):
+        monkeypatch.setenv("TENSOIR_C5_PAIRS", mode)
+        for k in ("TENSOIR_C5_BLOCK_PAIRS", "TENSOIR_C5_BINS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in extra.items():
+            monkeypatch.setenv(k, v)
+        env._draws = draws
+        cols[(mode, tuple(extra))] = relight.relight_importance_sampled(m, env, "syn", surf, nrm, albedo[mask], rough[mask], fres[mask],
+                                                                       rays[:, 3:][mask], num_samples=ns)
+    base = cols[("mask", ())]
+    assert base.shape == (M, 3) and bool(torch.isfinite(base).all()) and float(base.mean()) > 0.01
+    for k, v in cols.items():
+        assert torch.equal(v, base), k
+
+
+@torch.no_grad()
 def test_graphed_chunk_renderer_matches_eager_image(env):
     """render_sharded through GraphedChunkRenderer (one captured graph replayed per full chunk, capacity checks
     deferred to one validate() per image, ragged tail eager) gives the image of the eager per-chunk renderer, also

@@ -387,3 +387,46 @@ def test_seeded_construction_draws_the_reference_parameters(golden, light_kind, 
     torch.manual_seed(6)
     db = ours.gen_light_incident_dirs(method="stratifed_sample_equal_areas")
     assert torch.equal(da, db)
+
+
+def test_cdf_guide_tables_restrict_the_search_without_changing_it():
+    """ops.cdf_guide_tables (the inverse-CDF importance sampler of models/relight_utils.py:150-188 on the device): the search
+    started inside [guide[k], guide[k + 1]], k = floor(u G), returns the index the full search returns -- emulated here with
+    the kernel's loop on a map with a sun, empty rows, and sizes that are not powers of two; thresholds and their
+    predecessors included."""
+    from tensoir_amd import ops
+    gen = torch.Generator().manual_seed(0)
+    H, W = 100, 300
+    pdf = torch.rand(H, W, generator=gen).double() ** 4
+    pdf[10, 20:30] *= 1000
+    pdf[40:44] = 0
+    rows = pdf.sum(1)
+    row_cdf = (torch.cumsum(rows, 0) / rows.sum()).float()
+    col_cdf = (torch.cumsum(pdf, 1) / rows.clamp(min=1e-300).unsqueeze(1)).float()
+    row_cdf[-1] = 1.0
+    col_cdf[:, -1] = 1.0
+    rg, packed, gr, gc = ops.cdf_guide_tables(row_cdf, col_cdf)
+    assert (gr, gc) == (128, 512) and rg.shape == (gr + 1,) and packed.shape == (H, gc // 2 + 1) and packed.dtype == torch.int32
+    cg = np.ascontiguousarray(packed.numpy()).view(np.uint16).reshape(H, gc + 2)         # what the kernel reads (little endian)
+    assert int(rg[-1]) == H - 1 and bool((cg[:, gc] == W - 1).all())
+    assert bool((np.diff(rg.numpy()) >= 0).all()) and bool((np.diff(cg[:, :gc + 1].astype(np.int64), axis=1) >= 0).all())
+
+    def upper(cdf, u, lo, hi):
+        while lo < hi:
+            mid = (lo + hi) >> 1
+            if cdf[mid] > u:
+                hi = mid
+            else:
+                lo = mid + 1
+        return lo
+    rng = np.random.default_rng(1)
+    tr = (np.arange(gr + 1, dtype=np.float32) / np.float32(gr))
+    us = np.concatenate([rng.random(3000).astype(np.float32), np.float32([0.0, 1.0 - 2.0 ** -24, 0.5]), tr[:-1],
+                         np.nextafter(tr[1:], np.float32(0)).astype(np.float32)])
+    rc, cc = row_cdf.numpy(), col_cdf.numpy()
+    for u in us:
+        row = upper(rc, u, 0, H - 1)
+        k = min(int(np.float32(u) * np.float32(gr)), gr - 1)
+        assert upper(rc, u, int(rg[k]), int(rg[k + 1])) == row
+        k = min(int(np.float32(u) * np.float32(gc)), gc - 1)
+        assert upper(cc[row], u, int(cg[row, k]), int(cg[row, k + 1])) == upper(cc[row], u, 0, W - 1)
