@@ -1,7 +1,7 @@
 #!/bin/bash
-# One GPU-box visit for the round's evidence: -m gpu tests, the default bench line, rocprofv3 kernel traces of the bench command
+# One GPU-box visit for the round's evidence: -m gpu tests, rocprofv3 kernel traces of the bench command
 # (one batch in flight, then the default two), separate PMC passes (HBM traffic: FETCH_SIZE / WRITE_SIZE; issue: SQ counters),
-# the three side workloads with their kernel traces, and -- when a reference checkout is staged -- the bench line with the
+# the three side workloads with their kernel traces, then the default bench line and the workload lines (with the fresh PMC files), and -- when a reference checkout is staged -- the bench line with the
 # imported reference timed as cpu_baseline.  Usage (via gpurun): tools/r04_final.sh <tag>   -> gpurun_out/<tag>_*
 set -u
 TAG="${1:-r04}"
@@ -12,8 +12,6 @@ cd "$REPO"
 timeout -k 5 1200 python -m pytest tests -m gpu -q > "$OUT/${TAG}_tests.log" 2>&1
 echo "tests rc=$?" >> "$OUT/${TAG}_tests.log"; tail -3 "$OUT/${TAG}_tests.log"
 cp "$OUT/parity_fullsize.json" "$OUT/${TAG}_parity_fullsize.json" 2>/dev/null
-timeout -k 5 900 python bench.py --breakdown "$OUT/${TAG}_breakdown.json" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
-echo "bench rc=$?"; tail -c 600 "$OUT/${TAG}_bench.json"; echo; tail -3 "$OUT/${TAG}_bench.err"
 P="$OUT/prof_${TAG}"; mkdir -p "$P"
 cd /tmp && export TMPDIR=/tmp
 CMD1="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --profile-steps 1 --boundary-calls 3 --no-exact-pass --no-sharp-scene --no-side-workloads --sustained-steps 10 --in-flight 1"
@@ -37,9 +35,14 @@ python "$REPO/tools/summarize_prof.py" "$P/trace2" > "$P/summary_inflight2.txt" 
 python "$REPO/tools/summarize_prof.py" "$P" > "$P/summary_all.txt" 2>&1
 for wl in image relight train; do python "$REPO/tools/summarize_prof.py" "$P/trace_$wl" > "$P/summary_$wl.txt" 2>&1; done
 cp "$P/pmc_traffic.json" "$OUT/${TAG}_pmc_traffic.json" 2>/dev/null; cp "$P/pmc_issue.json" "$OUT/${TAG}_pmc_issue.json" 2>/dev/null
+# the bench lines come AFTER the counter passes: bench.py reads profiles/pmc_*.json, which must belong to this library
+# (stamped with its source hash) -- on the box they are installed here, in the repository tools/collect_profiles.sh does it
+if [ -s "$P/pmc_traffic.json" ] && [ -s "$P/pmc_issue.json" ]; then cp "$P/pmc_traffic.json" "$P/pmc_issue.json" "$REPO/profiles/"; fi
 head -30 "$P/summary.txt"; tail -25 "$P/summary_all.txt"
 prune; du -sh "$P" "$OUT"
 cd "$REPO"
+timeout -k 5 900 python bench.py --breakdown "$OUT/${TAG}_breakdown.json" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
+echo "bench rc=$?"; tail -c 600 "$OUT/${TAG}_bench.json"; echo; tail -3 "$OUT/${TAG}_bench.err"
 for wl in image relight train; do
   timeout -k 5 500 python bench.py --workload $wl > "$OUT/${TAG}_${wl}_bench.json" 2> "$OUT/${TAG}_${wl}_bench.err"; echo "$wl rc=$?"; tail -c 300 "$OUT/${TAG}_${wl}_bench.json"; echo
 done
