@@ -525,6 +525,20 @@ __device__ __forceinline__ void occ_t_range(const float (&occ_lo)[3], const floa
     t0 -= 1e-4f; t1 += 1e-4f;            // fp32 slack of the slab arithmetic itself
 }
 
+// x / d and x % d for a launch-invariant divisor and x < 2^32: m = floor((2^32 - 1) / d) gives q0 = mulhi(x, m) in {q - 1, q}
+// (m d = 2^32 - e with 1 <= e <= d, so x m / 2^32 = x / d - x e / (d 2^32) > x / d - 1), one correction makes it exact.  The
+// compiler's 64-bit division sequence costs ~30 VALU instructions even on its 32-bit fast path; this is 2 quarter-rate
+// multiplies + 4.
+struct UDiv { unsigned d, m; };
+__device__ __forceinline__ UDiv make_udiv(int d) { return UDiv{d > 1 ? (unsigned)d : 1u, d > 1 ? 0xFFFFFFFFu / (unsigned)d : 0u}; }
+__device__ __forceinline__ unsigned udiv(unsigned x, const UDiv& u, unsigned& rem) {
+    if (u.d == 1) { rem = 0; return x; }
+    unsigned q = __umulhi(x, u.m), r = x - q * u.d;
+    if (r >= u.d) { q += 1; r -= u.d; }
+    rem = r;
+    return q;
+}
+
 // linear2srgb_torch after the [0,1] clip (models/relight_utils.py:489-515)
 __device__ __forceinline__ float linear2srgb(float x) {
     x = fminf(fmaxf(x, 0.0f), 1.0f);

@@ -893,6 +893,7 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
     const unsigned w1hi = opaque(lane_off + BW0A_ELEMS * 2);
     constexpr int TILE = NW * 32;
     const int64_t n_tiles = (n + TILE - 1) / TILE;
+    const UDiv by_div = make_udiv(idx_div), by_mod = make_udiv(aux_mod);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t r0 = tile * TILE + wave * 32;
         // ---------------- gather phase: record gj of this wave's 32, two lanes per record
@@ -900,22 +901,22 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
         const float p[3] = {xyz[3 * sgc], xyz[3 * sgc + 1], xyz[3 * sgc + 2]};
         const float* lrow;
         {
-            int64_t lsel = rec_map ? (int64_t)rec_map[sgc] : sgc;
-            if (idx_div > 1) lsel /= idx_div;
+            unsigned lsel = rec_map ? (unsigned)rec_map[sgc] : (unsigned)sgc, rem_;      // record -> ray: / idx_div (n < 2^31, launcher)
+            lsel = udiv(lsel, by_div, rem_);
             int li = light_idx[lsel];
             li = min(max(li, 0), f.n_lights - 1);
             lrow = n_lt ? LT + li * (3 * CA) : f.light_line + (size_t)li * (3 * CA);
         }
         // decoder role: this lane's record and its aux-table row
         const int64_t sd = r0 + sl, sdc = sd < n ? sd : n - 1;
-        int64_t ai = rec_map ? (int64_t)rec_map[sdc] : sdc;
-        if (aux_mod > 0) ai %= aux_mod;
+        unsigned ai = rec_map ? (unsigned)rec_map[sdc] : (unsigned)sdc;
+        if (aux_mod > 0) udiv(ai, by_mod, ai);
         f32x16 facc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) facc[r] = 0.0f;
         f32x16 acc[4];
         auto load_table = [&]() {       // the layer-1 accumulators' start values: aux-table row of the record's direction
-            const float* tp = table + ai * HID + 4 * h;
+            const float* tp = table + (size_t)ai * HID + 4 * h;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -2217,6 +2218,7 @@ extern "C" int tir_indirect_fused_fwd(const TirField* f, const TirFieldHalf* fh,
     if (n < 0 || (n > 0 && (!xyz || !light_idx || !table || !out))) return TIR_ERR_ARG;
     if (reinterpret_cast<uintptr_t>(table) % 16 != 0) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
+    if (n >= (int64_t)1 << 31 || idx_div < 0 || aux_mod < 0) return TIR_ERR_UNSUPPORTED;       // 32-bit record / ray arithmetic in the kernel
     const int lt_rows = f->n_lights <= 16 ? f->n_lights : 0;
 #if defined(EXP_FUSED_W8)   // limit study: two waves per SIMD, aux-table row prefetched during the gather, fp32 layer-1 accumulators kept through layer 2
     constexpr int NW = 8; constexpr bool PACK = false;
