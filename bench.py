@@ -655,8 +655,9 @@ def bench_relight(a, embed=False):
     import io
     import torch.distributed as dist
     import tensoir_amd
-    from tensoir_amd import _lib, relight, synth
+    from tensoir_amd import _lib, ops, relight, synth
     from tensoir_amd import dist as tdist
+    pair_order = ops.c5_pair_order()
     world, rank = (int(os.environ.get(k, "0" if k != "WORLD_SIZE" else "1")) for k in ("WORLD_SIZE", "RANK"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: tensoir_amd has no CPU path")
@@ -780,7 +781,10 @@ def bench_relight(a, embed=False):
                                    f"2048x1024, {Ns} importance samples per surface point, 96 visibility samples per pair",
                        "sharding": ("contiguous row tiles" if tile <= 0 else f"interleaved tiles of {tile} rays") +
                                    f", one all_gather_into_tensor of {12 * len(maps)} B/ray relit colours per view",
-                       "launch": "eager per chunk (primary pass + per-map relight kernels)"},
+                       "launch": "eager per chunk (primary pass + per-map relight kernels)",
+                       "visibility_pairs": "{} (bins {}x{}, blocks of {} pairs): only the pairs that pass the cosine mask are marched "
+                                           "(scripts/relight_importance.py:127-131); TENSOIR_C5_PAIRS".format(
+                                               pair_order[0], pair_order[1][0], pair_order[1][1], pair_order[2])},
             "surface_points_per_view": counts[0] // max(1, a.steps),
             "visibility_pairs_per_s": round(counts[0] * Ns * len(maps) / elapsed, 1),
             "relit_images_per_s": round(len(maps) * a.steps / elapsed, 3),
