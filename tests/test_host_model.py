@@ -430,3 +430,27 @@ def test_cdf_guide_tables_restrict_the_search_without_changing_it():
         assert upper(rc, u, int(rg[k]), int(rg[k + 1])) == row
         k = min(int(np.float32(u) * np.float32(gc)), gc - 1)
         assert upper(cc[row], u, int(cg[row, k]), int(cg[row, k + 1])) == upper(cc[row], u, 0, W - 1)
+
+
+def test_c5_pair_order_switches(monkeypatch):
+    """TENSOIR_C5_PAIRS / _BINS / _BLOCK_PAIRS (ops.c5_pair_order): how the importance-sampled pairs of
+    scripts/relight_importance.py:127-131 reach the visibility march; unknown values fail loudly."""
+    from tensoir_amd import ops
+    for k in ("TENSOIR_C5_PAIRS", "TENSOIR_C5_BINS", "TENSOIR_C5_BLOCK_PAIRS"):
+        monkeypatch.delenv(k, raising=False)
+    assert ops.c5_pair_order() == ("binned", (15, 17), 512)
+    monkeypatch.setenv("TENSOIR_C5_PAIRS", "compact")
+    assert ops.c5_pair_order() == ("compact", (1, 1), 512)
+    monkeypatch.setenv("TENSOIR_C5_PAIRS", "mask")
+    assert ops.c5_pair_order()[0] == "mask"
+    monkeypatch.setenv("TENSOIR_C5_PAIRS", "Binned")
+    monkeypatch.setenv("TENSOIR_C5_BINS", "8x8")
+    monkeypatch.setenv("TENSOIR_C5_BLOCK_PAIRS", "4096")
+    assert ops.c5_pair_order() == ("binned", (8, 8), 4096)
+    monkeypatch.setenv("TENSOIR_C5_BINS", "8")
+    with pytest.raises(ValueError):
+        ops.c5_pair_order()
+    monkeypatch.delenv("TENSOIR_C5_BINS")
+    monkeypatch.setenv("TENSOIR_C5_PAIRS", "sorted")
+    with pytest.raises(ValueError):
+        ops.c5_pair_order()
