@@ -494,9 +494,11 @@ int tir_env_sample_setup(const float* row_cdf, const float* col_cdf, int32_t H, 
  *   rays from neighbouring surface points.  The order of the list enters no result.
  *   row_guide [guide_rows + 1] / col_guide [H][guide_cols + 2] (both or neither; sizes powers of two; a column row holds
  *   guide_cols + 1 entries and one pad): guide[k] = the search result for u = k / G (last entry = n - 1); the inverse-CDF
- *   search then starts inside [guide[k], guide[k+1]], k = floor(u G), and returns the same cell as the full search. */
+ *   search then starts inside [guide[k], guide[k+1]], k = floor(u G), and returns the same cell as the full search.
+ *   dir_stride: floats between the directions of consecutive cells in env_dir (3 = the [H*W][3] table; 8 = the packed records
+ *   of tir_relight_importance_cells_packed, whose first three floats are the direction). */
 int tir_env_sample_setup_list(const float* row_cdf, const float* col_cdf, int32_t H, int32_t W, const float* env_dir,
-                                const float* normal, int32_t M, int32_t Ns, uint64_t seed, uint64_t offset,
+                                int32_t dir_stride, const float* normal, int32_t M, int32_t Ns, uint64_t seed, uint64_t offset,
                                 int32_t bins_r, int32_t bins_c, int32_t block_pairs, const int32_t* row_guide,
                                 const uint16_t* col_guide, int32_t guide_rows, int32_t guide_cols, int32_t* cell,
                                 float* vis, int32_t* pair_ids, int32_t* n_active, void* stream);
@@ -504,6 +506,12 @@ int tir_relight_importance_cells(const float* normal, const float* albedo, const
                                  const float* fresnel, const float* rays_d, const int32_t* cell,
                                  const float* env_dir, const float* env_rgb, const float* env_pdf,
                                  const float* vis, int32_t M, int32_t Ns, float* out_rgb, void* stream);
+/* the same with the three per-cell tables interleaved: env_cell [H*W][8] = {dir.x, dir.y, dir.z, pdf_return, r, g, b, 0}
+ * (16-byte aligned): one 32-byte record per sample instead of three reads at unrelated addresses; same arithmetic. */
+int tir_relight_importance_cells_packed(const float* normal, const float* albedo, const float* rough,
+                                        const float* fresnel, const float* rays_d, const int32_t* cell,
+                                        const float* env_cell, const float* vis, int32_t M, int32_t Ns,
+                                        float* out_rgb, void* stream);
 int tir_env_lookup(const float* env_rgb, int32_t H, int32_t W, const float* dirs, int64_t n, float* out, void* stream);
 
 /* GGX_specular alone (models/relight_utils.py:17-50): normal/v [M][3], l [M][D][3],

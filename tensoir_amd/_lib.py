@@ -114,8 +114,9 @@ SIGNATURES = {
                                               P, I64, P, P, P, P, P, P, P, P, P]),
     "tir_relight_importance": (C.c_int, [P, P, P, P, P, P, P, P, P, I32, I32, P, P]),
     "tir_env_sample_setup": (C.c_int, [P, P, I32, I32, P, P, I32, I32, C.c_uint64, C.c_uint64, P, P, P]),
-    "tir_env_sample_setup_list": (C.c_int, [P, P, I32, I32, P, P, I32, I32, C.c_uint64, C.c_uint64, I32, I32, I32, P, P, I32, I32, P, P, P, P, P]),
+    "tir_env_sample_setup_list": (C.c_int, [P, P, I32, I32, P, I32, P, I32, I32, C.c_uint64, C.c_uint64, I32, I32, I32, P, P, I32, I32, P, P, P, P, P]),
     "tir_relight_importance_cells": (C.c_int, [P, P, P, P, P, P, P, P, P, P, I32, I32, P, P]),
+    "tir_relight_importance_cells_packed": (C.c_int, [P, P, P, P, P, P, P, P, I32, I32, P, P]),
     "tir_env_lookup": (C.c_int, [P, I32, I32, P, I64, P, P]),
     "tir_ggx_specular": (C.c_int, [P, P, P, P, P, I32, I32, P, P]),
     # ---- training (backward) entry points ----

@@ -320,7 +320,7 @@ k_env_sample_setup(const float* __restrict__ row_cdf, const float* __restrict__ 
 // addressed by pair id.  The inverse-CDF search starts from guide tables (cdf_upper_bound_guided).
 __global__ void __launch_bounds__(256)
 k_env_sample_list(const float* __restrict__ row_cdf, const float* __restrict__ col_cdf, int H, int W,
-                    const float* __restrict__ env_dir, const float* __restrict__ normal, int M, int Ns,
+                    const float* __restrict__ env_dir, int dir_stride, const float* __restrict__ normal, int M, int Ns,
                     unsigned long long seed, unsigned long long offset, int bins_r, int bins_c, int block_pairs,
                     const int32_t* __restrict__ row_guide, const uint16_t* __restrict__ col_guide, int g_rows, int g_cols,
                     int32_t* __restrict__ cell, float* __restrict__ vis, int32_t* __restrict__ pair_ids,
@@ -345,7 +345,7 @@ k_env_sample_list(const float* __restrict__ row_cdf, const float* __restrict__ c
                                   : cdf_upper_bound(col_cdf + (size_t)row * W, W, u[1]);
         const int c = row * W + col;
         cell[i] = c;
-        const float* d = env_dir + 3 * (size_t)c;
+        const float* d = env_dir + (size_t)dir_stride * (size_t)c;
         const float* nm = normal + 3 * (size_t)m;
         const float cosine = d[0] * nm[0] + d[1] * nm[1] + d[2] * nm[2];          // einsum('ijk,ik->ij') (:125)
         int key = 255;
@@ -390,6 +390,9 @@ k_env_sample_list(const float* __restrict__ row_cdf, const float* __restrict__ c
     for (int j = threadIdx.x; j < total; j += 256) pair_ids[ob + j] = (int32_t)(base + list[j]);
 }
 
+// PACKED: direction, pdf and radiance of a cell come from ONE 32-byte record [dir.xyz, pdf, rgb, 0] (env_dir = that table) instead
+// of three tables (12 + 12 + 4 bytes at unrelated addresses: three sectors per sample of a 2 M-cell map, every one a cache miss).
+template <bool PACKED>
 __global__ void __launch_bounds__(256)
 k_relight_importance_cells(const float* __restrict__ normal, const float* __restrict__ albedo,
                            const float* __restrict__ rough, const float* __restrict__ fresnel,
@@ -409,14 +412,21 @@ k_relight_importance_cells(const float* __restrict__ normal, const float* __rest
     for (int j = lane; j < Ns; j += 64) {
         const size_t mj = (size_t)m * Ns + j;
         const size_t ce = (size_t)cell[mj];
-        const float lx = env_dir[3 * ce], ly = env_dir[3 * ce + 1], lz = env_dir[3 * ce + 2];
+        float lx, ly, lz, pdf, er[3];
+        if (PACKED) {
+            const float4 a = *reinterpret_cast<const float4*>(env_dir + 8 * ce), b = *reinterpret_cast<const float4*>(env_dir + 8 * ce + 4);
+            lx = a.x; ly = a.y; lz = a.z; pdf = a.w; er[0] = b.x; er[1] = b.y; er[2] = b.z;
+        } else {
+            lx = env_dir[3 * ce]; ly = env_dir[3 * ce + 1]; lz = env_dir[3 * ce + 2]; pdf = env_pdf[ce];
+            er[0] = env_rgb[3 * ce]; er[1] = env_rgb[3 * ce + 1]; er[2] = env_rgb[3 * ce + 2];
+        }
         const float cosine = lx * nm[0] + ly * nm[1] + lz * nm[2];
         float spec[3];
         ggx_dir(s, lx, ly, lz, spec);
-        const float v = vis[mj], pdf = env_pdf[ce];
+        const float v = vis[mj];
 #pragma unroll
         for (int q = 0; q < 3; ++q)
-            c[q] += (s.alb_pi[q] + spec[q]) * (v * env_rgb[3 * ce + q]) * cosine / pdf;
+            c[q] += (s.alb_pi[q] + spec[q]) * (v * er[q]) * cosine / pdf;
     }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -645,11 +655,11 @@ extern "C" int tir_env_sample_setup(const float* row_cdf, const float* col_cdf, 
 }
 
 extern "C" int tir_env_sample_setup_list(const float* row_cdf, const float* col_cdf, int32_t H, int32_t W, const float* env_dir,
-                                           const float* normal, int32_t M, int32_t Ns, uint64_t seed, uint64_t offset,
+                                           int32_t dir_stride, const float* normal, int32_t M, int32_t Ns, uint64_t seed, uint64_t offset,
                                            int32_t bins_r, int32_t bins_c, int32_t block_pairs, const int32_t* row_guide,
                                            const uint16_t* col_guide, int32_t guide_rows, int32_t guide_cols, int32_t* cell,
                                            float* vis, int32_t* pair_ids, int32_t* n_active, void* stream) {
-    if (M < 0 || Ns <= 0 || H <= 0 || W <= 0 || bins_r <= 0 || bins_c <= 0) return TIR_ERR_ARG;
+    if (M < 0 || Ns <= 0 || H <= 0 || W <= 0 || bins_r <= 0 || bins_c <= 0 || dir_stride < 3) return TIR_ERR_ARG;
     if ((row_guide == nullptr) != (col_guide == nullptr)) return TIR_ERR_ARG;
     if (row_guide) {        // power-of-two guide sizes (exact k / G thresholds), column indices in 16 bits
         if (guide_rows <= 0 || guide_cols <= 0 || (guide_rows & (guide_rows - 1)) || (guide_cols & (guide_cols - 1))) return TIR_ERR_ARG;
@@ -663,7 +673,7 @@ extern "C" int tir_env_sample_setup_list(const float* row_cdf, const float* col_
     const size_t lds = (size_t)block_pairs * 3;
     if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_env_sample_list), 100 * 1024)) return rc;
     hipLaunchKernelGGL(k_env_sample_list, dim3((unsigned)((n + block_pairs - 1) / block_pairs)), dim3(256), lds,
-                       tir_stream(stream), row_cdf, col_cdf, H, W, env_dir, normal, M, Ns, (unsigned long long)seed,
+                       tir_stream(stream), row_cdf, col_cdf, H, W, env_dir, dir_stride, normal, M, Ns, (unsigned long long)seed,
                        (unsigned long long)offset, bins_r, bins_c, block_pairs, row_guide, col_guide, guide_rows, guide_cols, cell,
                        vis, pair_ids, n_active);
     TIR_CHECK_LAUNCH();
@@ -678,8 +688,22 @@ extern "C" int tir_relight_importance_cells(const float* normal, const float* al
     if (M == 0) return TIR_OK;
     if (!normal || !albedo || !rough || !fresnel || !rays_d || !cell || !env_dir || !env_rgb || !env_pdf || !vis || !out_rgb)
         return TIR_ERR_ARG;
-    hipLaunchKernelGGL(k_relight_importance_cells, dim3((M + 3) / 4), dim3(256), 0, tir_stream(stream), normal, albedo,
+    hipLaunchKernelGGL(k_relight_importance_cells<false>, dim3((M + 3) / 4), dim3(256), 0, tir_stream(stream), normal, albedo,
                        rough, fresnel, rays_d, cell, env_dir, env_rgb, env_pdf, vis, M, Ns, out_rgb);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_relight_importance_cells_packed(const float* normal, const float* albedo, const float* rough,
+                                                   const float* fresnel, const float* rays_d, const int32_t* cell,
+                                                   const float* env_cell, const float* vis, int32_t M, int32_t Ns,
+                                                   float* out_rgb, void* stream) {
+    if (M < 0 || Ns <= 0) return TIR_ERR_ARG;
+    if (M == 0) return TIR_OK;
+    if (!normal || !albedo || !rough || !fresnel || !rays_d || !cell || !env_cell || !vis || !out_rgb) return TIR_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(env_cell) % 16 != 0) return TIR_ERR_ARG;
+    hipLaunchKernelGGL(k_relight_importance_cells<true>, dim3((M + 3) / 4), dim3(256), 0, tir_stream(stream), normal, albedo,
+                       rough, fresnel, rays_d, cell, env_cell, nullptr, nullptr, vis, M, Ns, out_rgb);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

@@ -916,8 +916,11 @@ def env_sample_setup_list(row_cdf, col_cdf, env_dir, normal, n_samples, seed, of
     vis = torch.empty((M, n_samples), dtype=torch.float32, device=dev)
     pair_ids = torch.empty((M * n_samples,), dtype=torch.int32, device=dev)
     n_active = torch.zeros((1,), dtype=torch.int32, device=dev)
+    stride = int(env_dir.shape[-1])                    # [H*W, 3] directions or the [H*W, 8] records of pack_env_cells
+    if stride not in (3, 8):
+        raise ValueError(f"env_dir: expected [H*W, 3] directions or [H*W, 8] cell records, got {tuple(env_dir.shape)}")
     _call("tir_env_sample_setup_list", _ptr(f32(row_cdf, "row_cdf")), _ptr(f32(col_cdf, "col_cdf")), H, W,
-          _ptr(f32(env_dir, "env_dir", 3)), _ptr(normal), M, int(n_samples), int(seed) & (2 ** 64 - 1),
+          _ptr(f32(env_dir, "env_dir", stride)), stride, _ptr(normal), M, int(n_samples), int(seed) & (2 ** 64 - 1),
           int(offset) & (2 ** 64 - 1), int(bins[0]), int(bins[1]), int(block_pairs),
           *((None, None, 0, 0) if guide is None else (_ptr(_req(guide[0], torch.int32, "row_guide")),
                                                       _ptr(_req(guide[1], torch.int32, "col_guide")), int(guide[2]), int(guide[3]))),
@@ -925,7 +928,15 @@ def env_sample_setup_list(row_cdf, col_cdf, env_dir, normal, n_samples, seed, of
     return cell, vis, pair_ids, n_active
 
 
-def relight_importance_cells(normal, albedo, rough, fresnel, rays_d, cell, env_dir, env_rgb, env_pdf, vis):
+def pack_env_cells(env_dir, env_rgb, env_pdf):
+    """[H*W, 8] fp32 records {dir.xyz, pdf_return, rgb, 0} of an environment map for tir_relight_importance_cells_packed."""
+    d, c, p = f32(env_dir, "env_dir", 3).view(-1, 3), f32(env_rgb, "env_rgb", 3).view(-1, 3), f32(env_pdf, "env_pdf").view(-1, 1)
+    return torch.cat([d, p, c, torch.zeros_like(p)], dim=1).contiguous()
+
+
+def relight_importance_cells(normal, albedo, rough, fresnel, rays_d, cell, env_dir, env_rgb, env_pdf, vis, env_cell=None):
+    """BRDF x radiance x cosine / pdf mean over a point's samples -> sRGB (scripts/relight_importance.py:133-160).  env_cell
+    (pack_env_cells of the same three tables): one 32-byte record per sample instead of three gathers; same result."""
     normal, albedo = f32(normal, "normal", 3), f32(albedo, "albedo", 3)
     rough = f32(rough, "roughness").view(-1)
     fresnel, rays_d = f32(fresnel, "fresnel", 3), f32(rays_d, "rays_d", 3)
@@ -933,6 +944,10 @@ def relight_importance_cells(normal, albedo, rough, fresnel, rays_d, cell, env_d
     M, Ns = cell.shape
     vis = f32(vis, "vis").view(M, Ns)
     out = torch.empty((M, 3), dtype=torch.float32, device=normal.device)
+    if env_cell is not None:
+        _call("tir_relight_importance_cells_packed", _ptr(normal), _ptr(albedo), _ptr(rough), _ptr(fresnel), _ptr(rays_d), _ptr(cell),
+              _ptr(f32(env_cell, "env_cell", 8)), _ptr(vis), M, Ns, _ptr(out), _stream())
+        return out
     _call("tir_relight_importance_cells", _ptr(normal), _ptr(albedo), _ptr(rough), _ptr(fresnel), _ptr(rays_d), _ptr(cell),
           _ptr(f32(env_dir, "env_dir", 3)), _ptr(f32(env_rgb, "env_rgb", 3)), _ptr(f32(env_pdf, "env_pdf")), _ptr(vis),
           M, Ns, _ptr(out), _stream())

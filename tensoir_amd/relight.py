@@ -285,7 +285,7 @@ class Environment_Light:
 
     def __init__(self, hdr_path=None, device="cuda", hdr_maps=None):
         self.hdr_rgbs, self.hdr_pdf_sample, self.hdr_pdf_return, self.hdr_dir = {}, {}, {}, {}
-        self.hdr_row_cdf, self.hdr_col_cdf, self.hdr_cdf_guide = {}, {}, {}
+        self.hdr_row_cdf, self.hdr_col_cdf, self.hdr_cdf_guide, self._cell_records = {}, {}, {}, {}
         self._draws = 0
         maps = dict(hdr_maps or {})
         if torch.device(device).type == "cuda" and not torch.cuda.is_available():
@@ -360,10 +360,22 @@ class Environment_Light:
         direction-binned inside blocks of `block_pairs` pairs (tir_env_sample_setup_list).  Returns (cell [M, Ns], vis [M, Ns] with the masked pairs' zeros, pair_ids,
         n_active)."""
         self._draws += 1
+        rec = self.cell_records(light_name)               # the direction comes from the records the integration reads later
         return ops.env_sample_setup_list(self.hdr_row_cdf[light_name], self.hdr_col_cdf[light_name],
-                                           self.hdr_dir[light_name].view(-1, 3), normal, num_samples,
+                                           self.hdr_dir[light_name].view(-1, 3) if rec is None else rec, normal, num_samples,
                                            torch.cuda.initial_seed(), self._draws, bins, block_pairs,
                                            self.hdr_cdf_guide.get(light_name))
+
+    def cell_records(self, light_name):
+        """[H*W, 8] records {direction, pdf_return, radiance, 0} of a map (ops.pack_env_cells), built on first use: the
+        integration kernel reads one 32-byte record per sample instead of three tables.  TENSOIR_ENV_RECORDS=0: None."""
+        if os.environ.get("TENSOIR_ENV_RECORDS", "1") == "0":
+            return None
+        rec = self._cell_records.get(light_name)
+        if rec is None:
+            rec = ops.pack_env_cells(self.hdr_dir[light_name], self.hdr_rgbs[light_name], self.hdr_pdf_return[light_name])
+            self._cell_records[light_name] = rec
+        return rec
 
     def get_light(self, light_name, incident_dir):
         """:191-205 (background lookup, bilinear, align_corners=True) -> tir_env_lookup."""
@@ -440,4 +452,4 @@ def relight_importance_sampled(tensoIR, env, light_name, surface_xyz, normal, al
                                     tensoIR.march_t_stop, False, 0, False, **listed)
     return ops.relight_importance_cells(normal, albedo, roughness, fresnel, rays_d, cell, env_dir,
                                         env.hdr_rgbs[light_name].view(-1, 3), env.hdr_pdf_return[light_name].view(-1),
-                                        vis.view(M, num_samples))
+                                        vis.view(M, num_samples), env_cell=env.cell_records(light_name))

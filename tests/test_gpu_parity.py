@@ -956,9 +956,10 @@ def test_c5_pair_list_orders_are_bit_identical(full3, monkeypatch, ns):
             same = blk[1:] == blk[:-1]
             assert bool((key[1:][same] >= key[:-1][same]).all())
     cols = {}
-    for mode, extra in (("mask", {}), ("compact", {}), ("binned", {}), ("binned", {"TENSOIR_C5_BLOCK_PAIRS": "1000", "TENSOIR_C5_BINS": "3x5"})):
+    for mode, extra in (("mask", {}), ("compact", {}), ("binned", {}), ("binned", {"TENSOIR_C5_BLOCK_PAIRS": "1000", "TENSOIR_C5_BINS": "3x5"}),
+                        ("binned", {"TENSOIR_ENV_RECORDS": "0"})):      # the last: direction / radiance / pdf from three tables
         monkeypatch.setenv("TENSOIR_C5_PAIRS", mode)
-        for k in ("TENSOIR_C5_BLOCK_PAIRS", "TENSOIR_C5_BINS"):
+        for k in ("TENSOIR_C5_BLOCK_PAIRS", "TENSOIR_C5_BINS", "TENSOIR_ENV_RECORDS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in extra.items():
             monkeypatch.setenv(k, v)
