@@ -357,8 +357,8 @@ class Environment_Light:
     @torch.no_grad()
     def sample_cells_listed(self, light_name, normal, num_samples, bins=(1, 1), block_pairs=256):
         """sample_cells with the same draws (same Philox counters) + the compacted list of the unmasked pairs, optionally
-        direction-binned inside blocks of `block_pairs` pairs (tir_env_sample_setup_list).  Returns (cell [M, Ns], vis [M, Ns] with the masked pairs' zeros, pair_ids,
-        n_active)."""
+        direction-binned inside blocks of `block_pairs` pairs (tir_env_sample_setup_list).  Returns (cell [M, Ns],
+        vis [M, Ns] with the masked pairs' zeros, pair_ids [M * Ns], n_active [1] on the device)."""
         self._draws += 1
         rec = self.cell_records(light_name)               # the direction comes from the records the integration reads later
         return ops.env_sample_setup_list(self.hdr_row_cdf[light_name], self.hdr_col_cdf[light_name],
