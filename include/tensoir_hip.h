@@ -84,7 +84,7 @@ typedef struct TirFieldHalf {
 
 /* (internal launch records of tir_pack_half) */
 #define TIR_HALF_MAX_JOBS 8
-typedef struct TirHalfJob { const float* src; void* dst; int64_t n; } TirHalfJob;
+typedef struct TirHalfJob { const float* src; void* dst; int64_t n; unsigned* absmax; } TirHalfJob;
 typedef struct TirHalfJobs { TirHalfJob job[TIR_HALF_MAX_JOBS]; } TirHalfJobs;
 
 /* One 3-layer decoder (in -> hidden ReLU -> hidden ReLU -> out, then activation):
@@ -216,8 +216,15 @@ int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, 
         void* stream);
 
 /* ---- precision policy for INDIRECT light (the radiance of the secondary-ray records, models/relight_utils.py:818-832).
- *      tir_pack_half: fp32 -> fp16 copies (round to nearest even) of up to TIR_HALF_MAX_JOBS tables in one launch; srcs /
- *      dsts / counts are HOST arrays, tables 16-byte aligned.
+ *      tir_pack_half: fp32 -> fp16 copies (round to nearest even, SATURATING: |x| > 65504 -> +-65504, never inf) of up to
+ *      TIR_HALF_MAX_JOBS tables in one launch; srcs / dsts / counts are HOST arrays, tables 16-byte aligned.
+ *      tir_pack_half_checked: the same, and absmax[i] (DEVICE floats, zeroed by the caller before the call) receives max |x| of
+ *      table i (a NaN anywhere in the table is reported as NaN); dsts[i] == NULL scans table i without writing a copy (light
+ *      rows, basis_mat).  RANGE CONTRACT of the fp16 gather below: the products plane * line * light-row are rounded to fp16
+ *      WITHOUT a saturation test in the hot loop, so the caller must establish max|plane_i| * max|line_i| * max|light row| < 65504
+ *      for i = 0..2 and max|basis_mat| < 65504 from these maxima (bilinear taps are convex combinations, so the bound is
+ *      rigorous) and use the fp32 gather (tir_vm_app_fwd) otherwise -- the host mirror does exactly that
+ *      (tensoir_amd/relight.py: _indirect_mode).
  *      tir_vm_app_fwd_h16 = tir_vm_app_fwd(rad_feat only) for n_acomp == 48 on the fp16 shadow `fh` of f->aplane / f->aline:
  *      half the bytes through the vector L1 (the bound of the fp32 gather), interpolation and light-row product in fp32, the
  *      basis_mat contraction on v_mfma_f32_32x32x16_f16 (operands rounded to 11 bits, fp32 accumulate).  ~2e-4 relative on a
@@ -225,6 +232,8 @@ int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, 
  *      averaged over a ray's records and the light directions before it reaches rgb_with_brdf_map.  Other arguments as
  *      tir_vm_app_fwd. */
 int tir_pack_half(const float* const* srcs, void* const* dsts, const int64_t* counts, int32_t n_tables, void* stream);
+int tir_pack_half_checked(const float* const* srcs, void* const* dsts, const int64_t* counts, int32_t n_tables, float* absmax,
+                          void* stream);
 int tir_vm_app_fwd_h16(const TirField* f, const TirFieldHalf* fh, const float* xyz, const int32_t* light_idx,
                        const int32_t* idx_map, float* rad_feat, int32_t out_stride, int32_t idx_div, int64_t n,
                        const int32_t* n_dev, void* stream);

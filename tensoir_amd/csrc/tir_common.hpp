@@ -55,6 +55,14 @@ static inline bool tir_plane_index_ok(const TirField* f) {
     return true;
 }
 
+// the fp16 appearance gathers (k_vm_app_h16, k_indirect_fused) address plane taps with 32-bit ELEMENT offsets
+static inline bool tir_app_index_ok(const TirField* f) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if ((int64_t)f->grid[i] * f->grid[j] * f->n_acomp >= ((int64_t)1 << 31)) return false;
+    return true;
+}
+
 // matMode / vecMode of the reference (models/tensorBase_rotated_lights.py:398-399)
 __device__ __constant__ const int kMat0[3] = {0, 0, 1};
 __device__ __constant__ const int kMat1[3] = {1, 2, 2};
@@ -353,6 +361,9 @@ __device__ __forceinline__ float fma_mix_hi(unsigned h2, float w, float acc) {
     asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h2), "v"(w), "v"(acc));
     return d;
 }
+
+// fp32 -> fp16 with saturation (|x| > 65504 -> +-65504, never inf)
+__device__ __forceinline__ _Float16 sat_half(float x) { return (_Float16)__builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
 
 // 8 channels of one VM group: bilinear(plane taps a, b, c, d) * linear(line taps e, g) * light row lr[0..8) -> 8 halves (4 dwords)
 typedef _Float16 tir_h2 __attribute__((ext_vector_type(2)));

@@ -798,17 +798,35 @@ typedef float app_f32x16 __attribute__((ext_vector_type(16)));
 typedef float app_f32x2 __attribute__((ext_vector_type(2)));
 #define TIR_XH 56      // record stride of the fp16 X tile in halves (48 channels + 8: 112-B rows keep ds_read_b128 conflict-free)
 
+// fp16 shadow copy with SATURATING casts (|x| > 65504 -> +-65504, never inf) and, when jb.absmax is given, the table's
+// abs-max (bit pattern of |x|: non-negative floats order like unsigned integers, a NaN sorts above inf and is reported as
+// such) -- the range guard of the indirect-light precision policy reads it (ops.pack_half, relight._indirect_mode).
+// dst == NULL: scan only (light rows, basis_mat: tables the gather reads as fp32 / casts in-kernel).
 __global__ void k_pack_half(TirHalfJobs jobs) {
     const TirHalfJob jb = jobs.job[blockIdx.y];
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
-    if (i >= jb.n) return;
     _Float16* dst = reinterpret_cast<_Float16*>(jb.dst);
+    unsigned m = 0;
     if (i + 8 <= jb.n) {
         const float4 a = ld4(jb.src + i), b = ld4(jb.src + i + 4);
-        app_f16x8 h = {(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w, (_Float16)b.x, (_Float16)b.y, (_Float16)b.z, (_Float16)b.w};
-        *reinterpret_cast<app_f16x8*>(dst + i) = h;
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m = max(m, __builtin_bit_cast(unsigned, v[q]) & 0x7fffffffu);
+        if (dst) {
+            app_f16x8 h = {sat_half(a.x), sat_half(a.y), sat_half(a.z), sat_half(a.w), sat_half(b.x), sat_half(b.y), sat_half(b.z), sat_half(b.w)};
+            *reinterpret_cast<app_f16x8*>(dst + i) = h;
+        }
     } else {
-        for (int64_t e = i; e < jb.n; ++e) dst[e] = (_Float16)jb.src[e];
+        for (int64_t e = i; e < jb.n; ++e) {
+            const float x = jb.src[e];
+            m = max(m, __builtin_bit_cast(unsigned, x) & 0x7fffffffu);
+            if (dst) dst[e] = sat_half(x);
+        }
+    }
+    if (jb.absmax) {      // (block-uniform branch)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+        if ((threadIdx.x & 63) == 0 && m) atomicMax(jb.absmax, m);
     }
 }
 
@@ -829,7 +847,7 @@ k_vm_app_h16(TirField f, TirFieldHalf fh, const float* __restrict__ xyz, const i
         const int row = e & 31, kg = (e >> 5) & 1, t = (e >> 6) % 3, k = e / 192;
         app_f16x8 h;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) h[q] = (_Float16)f.basis_t[(size_t)(k * CA + 16 * t + 8 * kg + q) * 32 + row];
+        for (int q = 0; q < 8; ++q) h[q] = sat_half(f.basis_t[(size_t)(k * CA + 16 * t + 8 * kg + q) * 32 + row]);
         Wh[e] = h;
     }
     for (int i = threadIdx.x * 4; i < n_lt * 3 * CA; i += 256 * 4)
@@ -1055,21 +1073,34 @@ extern "C" int tir_vm_app_fwd_bf16x3(const TirField* f, const float* xyz, const 
 }
 
 // fp32 -> fp16 copies of up to 8 tables in one launch (same element order): the shadow planes / lines of tir_vm_app_fwd_h16
-extern "C" int tir_pack_half(const float* const* srcs, void* const* dsts, const int64_t* counts, int32_t n_tables, void* stream) {
+static int pack_half_launch(const float* const* srcs, void* const* dsts, const int64_t* counts, int32_t n_tables, float* absmax, void* stream) {
     if (n_tables < 0 || n_tables > TIR_HALF_MAX_JOBS || (n_tables > 0 && (!srcs || !dsts || !counts))) return TIR_ERR_ARG;
     if (n_tables == 0) return TIR_OK;
     TirHalfJobs jobs;
     int64_t most = 0;
     for (int i = 0; i < n_tables; ++i) {
-        if (counts[i] < 0 || (counts[i] > 0 && (!srcs[i] || !dsts[i]))) return TIR_ERR_ARG;
+        if (counts[i] < 0 || (counts[i] > 0 && !srcs[i])) return TIR_ERR_ARG;
+        if (counts[i] > 0 && !dsts[i] && !absmax) return TIR_ERR_ARG;           // a scan-only table needs somewhere to report
         if (reinterpret_cast<uintptr_t>(srcs[i]) % 16 != 0 || reinterpret_cast<uintptr_t>(dsts[i]) % 16 != 0) return TIR_ERR_ARG;
-        jobs.job[i] = TirHalfJob{srcs[i], dsts[i], counts[i]};
+        jobs.job[i] = TirHalfJob{srcs[i], dsts[i], counts[i], absmax ? reinterpret_cast<unsigned*>(absmax) + i : nullptr};
         most = counts[i] > most ? counts[i] : most;
     }
     if (most == 0) return TIR_OK;
     hipLaunchKernelGGL(k_pack_half, dim3((unsigned)((most + 2047) / 2048), (unsigned)n_tables), dim3(256), 0, tir_stream(stream), jobs);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
+}
+
+// fp32 -> fp16 copies of up to 8 tables in one launch (same element order, saturating): the shadow planes / lines of tir_vm_app_fwd_h16
+extern "C" int tir_pack_half(const float* const* srcs, void* const* dsts, const int64_t* counts, int32_t n_tables, void* stream) {
+    return pack_half_launch(srcs, dsts, counts, n_tables, nullptr, stream);
+}
+
+// ... and the abs-max of every table (absmax[i], device floats the CALLER has zeroed; dsts[i] == NULL: scan table i only)
+extern "C" int tir_pack_half_checked(const float* const* srcs, void* const* dsts, const int64_t* counts, int32_t n_tables, float* absmax,
+                                     void* stream) {
+    if (!absmax) return TIR_ERR_ARG;
+    return pack_half_launch(srcs, dsts, counts, n_tables, absmax, stream);
 }
 
 extern "C" int tir_vm_app_fwd_h16(const TirField* f, const TirFieldHalf* fh, const float* xyz, const int32_t* light_idx,
@@ -1080,7 +1111,7 @@ extern "C" int tir_vm_app_fwd_h16(const TirField* f, const TirFieldHalf* fh, con
         if (f->grid[i] < 2 || !fh->aplane[i] || !fh->aline[i] || reinterpret_cast<uintptr_t>(fh->aplane[i]) % 16 != 0 ||
             reinterpret_cast<uintptr_t>(fh->aline[i]) % 16 != 0) return TIR_ERR_ARG;
     if (!f->basis_t || !f->light_mean || !f->light_line) return TIR_ERR_ARG;
-    if (f->n_acomp != 48 || f->app_dim < 1 || f->app_dim > 27) return TIR_ERR_UNSUPPORTED;
+    if (f->n_acomp != 48 || f->app_dim < 1 || f->app_dim > 27 || !tir_app_index_ok(f)) return TIR_ERR_UNSUPPORTED;
     if (out_stride < f->app_dim || out_stride > 32) return TIR_ERR_ARG;
     if (n < 0 || (n > 0 && (!xyz || !rad_feat || !light_idx))) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;

@@ -461,12 +461,14 @@ __device__ __forceinline__ void build_pair(const float (&ft)[F + 1], const float
 }
 
 // ReLU.  fmaxf(x, 0) (and med3(x, 0, inf), which the compiler folds back) lowers to a canonicalising v_max(x, x) plus
-// the real v_max; MFMA accumulators are never signalling NaNs, so the single instruction is the same function at half
-// the VALU issue slots -- and the decoder kernel is VALU-issue bound.
+// the real v_max, and the decoder kernel is VALU-issue bound.  One instruction instead: the INTEGER maximum of the bit
+// pattern and 0 (every float with the sign bit set is a negative integer -> +0.0, every other pattern is returned as it
+// is) -- the same function as v_max_f32(0, x) for every non-NaN x, and a NaN stays a NaN as torch.relu keeps it.
+// A builtin, not inline asm: these reads come straight behind MFMAs that wrote the operand, and the hazard recogniser
+// inserts the MFMA -> VALU wait states only for instructions it can see (inline asm read stale accumulators in the
+// first fused kernel: 1e-3 errors).
 __device__ __forceinline__ float relu(float x) {
-    float r;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-    return r;
+    return __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, x), 0));
 }
 
 // LDS operand tiles are read through four per-lane byte bases (W0hi / W0lo / W1hi / W1lo section start + this lane's
@@ -548,9 +550,7 @@ __device__ __forceinline__ void layer1_interleaved(unsigned whi, unsigned wlo, i
 // ReLU that also saturates at the largest finite fp16 (one v_med3_f32, the same issue slot as the plain ReLU): the hidden
 // activations of the fp16 decoder are rounded to fp16 operands, and a value above 65504 would turn into +inf there.
 __device__ __forceinline__ float relu_sat16(float x) {
-    float r;
-    asm("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(65504.0f));
-    return r;
+    return __builtin_amdgcn_fmed3f(x, 0.0f, 65504.0f);      // (builtin: visible to the hazard recogniser, see relu)
 }
 
 template <int NPROD, int KB, bool F16 = false>
@@ -873,7 +873,7 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
         const int feat = fus_feature_of_row(row);
         f16x8 hv;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) hv[q] = feat >= 0 ? (_Float16)f.basis_t[(size_t)(k * CA + 16 * t + 8 * kg + q) * 32 + feat] : (_Float16)0.0f;
+        for (int q = 0; q < 8; ++q) hv[q] = feat >= 0 ? sat_half(f.basis_t[(size_t)(k * CA + 16 * t + 8 * kg + q) * 32 + feat]) : (_Float16)0.0f;
         Wh[e] = hv;
     }
     for (int i = threadIdx.x * 4; i < n_lt * 3 * CA; i += NW * 64 * 4)
@@ -2214,7 +2214,7 @@ extern "C" int tir_indirect_fused_fwd(const TirField* f, const TirFieldHalf* fh,
         if (f->grid[i] < 2 || !fh->aplane[i] || !fh->aline[i] || reinterpret_cast<uintptr_t>(fh->aplane[i]) % 16 != 0 ||
             reinterpret_cast<uintptr_t>(fh->aline[i]) % 16 != 0) return TIR_ERR_ARG;
     if (!f->basis_t || !f->light_mean || !f->light_line) return TIR_ERR_ARG;
-    if (f->n_acomp != 48 || f->app_dim != F) return TIR_ERR_UNSUPPORTED;
+    if (f->n_acomp != 48 || f->app_dim != F || !tir_app_index_ok(f)) return TIR_ERR_UNSUPPORTED;
     if (n < 0 || (n > 0 && (!xyz || !light_idx || !table || !out))) return TIR_ERR_ARG;
     if (reinterpret_cast<uintptr_t>(table) % 16 != 0) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;

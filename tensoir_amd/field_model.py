@@ -593,9 +593,10 @@ class TensorVMSplit(nn.Module):
         return f
 
     def packed_field_half(self):
-        """TirFieldHalf: fp16 shadow of the appearance planes / lines for the indirect-light gather (ops.vm_app_h16), or None
-        when the field is not 48 components wide.  Built with one launch, cached with the packed field (same key: any
-        optimizer step, upsample, shrink or load rebuilds it)."""
+        """TirFieldHalf: fp16 shadow (saturating casts) of the appearance planes / lines for the indirect-light gather
+        (ops.vm_app_h16 / ops.indirect_fused), or None when the field is not 48 components wide.  Built with one launch, cached
+        with the packed field (same key: any optimizer step, upsample, shrink or load rebuilds it).  The same launch measures
+        the abs-maxima the range guard needs (half_range())."""
         from ._lib import TirFieldHalf
         self.packed_field()
         keep = self._field_cache
@@ -604,12 +605,25 @@ class TensorVMSplit(nn.Module):
                 keep["half"] = None
             else:
                 src = [keep[f"ap{i}"] for i in range(3)] + [keep[f"al{i}"] for i in range(3)]
-                tabs = ops.pack_half(src)
+                tabs, absmax = ops.pack_half(src, scan=(keep["ll"], keep["basis"]))
                 fh = TirFieldHalf()
                 for i in range(3):
                     fh.aplane[i], fh.aline[i] = tabs[i].data_ptr(), tabs[3 + i].data_ptr()
                 keep["half"] = (fh, tabs)
+                keep["half_range"] = ops.HalfRange(absmax)
         return keep["half"][0] if keep["half"] is not None else None
+
+    def half_range(self):
+        """ops.HalfRange of the current fp16 shadow (None without one)."""
+        return self._field_cache.get("half_range") if self.packed_field_half() is not None else None
+
+    def indirect_precision(self):
+        """What the indirect-light precision policy decided for this model so far (ops.INDIRECT_GUARD, relight._indirect_mode):
+        {"policy": auto|f16|full, "mode": f16|full|None, "why": ..., "probe": {...}} -- also written into checkpoints."""
+        st = self.__dict__.get("_indirect_state") or {}
+        pol = "full" if (ops.secondary_mlp_impl() is None and ops.secondary_app_impl() is None) else ("auto" if ops.INDIRECT_GUARD else "f16")
+        return {"policy": pol, "mode": st.get("verdict") if pol == "auto" else pol, "why": st.get("why"), "probe": st.get("stats"),
+                "probes_run": st.get("probes", 0), "fallbacks": st.get("fallbacks", 0)}
 
     # ---- per-point field functions (reference signatures) ---------------------------------------------
     def compute_densityfeature(self, xyz_sampled):
@@ -770,6 +784,14 @@ class TensorVMSplit(nn.Module):
             ckpt["alphaMask.mask"] = np.packbits(occupied.reshape(-1))
             ckpt["alphaMask.aabb"] = self.alphaMask.aabb.cpu()
         torch.save(ckpt, path)
+        # the checkpoint file keeps exactly the reference's keys; which precision the indirect-light stage ran at for these
+        # parameters (ops.INDIRECT_GUARD) goes into a sidecar next to it
+        try:
+            import json
+            with open(str(path) + ".tensoir_amd.json", "w") as fh:
+                json.dump({"indirect_precision": self.indirect_precision()}, fh, indent=1, default=str)
+        except OSError:
+            pass
 
     def load(self, ckpt):
         if "alphaMask.aabb" in ckpt:
@@ -779,6 +801,7 @@ class TensorVMSplit(nn.Module):
                                            torch.from_numpy(bits.reshape(shape)).float().to(self.device))
         self.load_state_dict(ckpt["state_dict"])
         self._field_key = None
+        self.__dict__.pop("_indirect_state", None)      # new parameters in the old storage: the precision verdict must be re-established
 
     # ---- the primary pass ----------------------------------------------------------------------------
     def forward(self, rays_chunk, light_idx, white_bg=True, is_train=False, ndc_ray=False, is_relight=True,

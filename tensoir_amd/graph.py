@@ -83,7 +83,8 @@ class GraphedRenderer:
         # every light parameter: the general multi-light model keeps one SG set per light in a plain list
         lights = m.light_parameters()
         return (m._field_key, tuple((t.data_ptr(), t._version) for t in lights), tuple(d._key for d in decs),
-                float(m.march_t_stop), ops.MLP_IMPL, ops.secondary_mlp_impl(), ops.secondary_app_impl(), ops.fused_indirect())
+                float(m.march_t_stop), ops.MLP_IMPL, ops.secondary_mlp_impl(), ops.secondary_app_impl(), ops.fused_indirect(),
+                ops.INDIRECT_GUARD and (m.__dict__.get("_indirect_state") or {}).get("verdict"))
 
     def _stale(self):
         return self.graph is not None and self._key() != self._model_key
@@ -124,8 +125,8 @@ class GraphedRenderer:
         gc.collect()
         gc_was_on = gc.isenabled()
         gc.disable()
-        ops.CAPTURE_KEEPALIVE = self._keepalive
         try:
+            ops.CAPTURE_KEEPALIVE = self._keepalive
             with torch.no_grad(), self._own_state(), torch.cuda.graph(g):
                 self.out = Renderer_TensoIR_train(self.rays, None, self.lidx, self.model, **self.kw)
                 if self.checks:

@@ -178,6 +178,50 @@ class AsyncCount:
         return self.value
 
 
+class AsyncFloats:
+    """A few device floats on their way to the host (AsyncCount for float tables): copy into pinned memory + event queued NOW."""
+
+    def __init__(self, t):
+        self.pin = torch.empty(t.numel(), dtype=torch.float32, pin_memory=True)
+        self.pin.copy_(t.view(-1), non_blocking=True)
+        self.ev = torch.cuda.Event()
+        self.ev.record(torch.cuda.current_stream(t.device))
+        self.value = None
+
+    def ready(self):
+        return self.value is not None or self.ev.query()
+
+    def get(self):
+        if self.value is None:
+            self.ev.synchronize()
+            self.value = [float(v) for v in self.pin]
+            self.pin = None
+        return self.value
+
+
+class HalfRange:
+    """Range guard of one fp16 shadow of the field (tir_pack_half_checked's RANGE CONTRACT): the abs-maxima of the three
+    appearance planes, the three lines, the light rows and basis_mat^T travel to the host behind the pack launch; ok() is
+    True when no plane * line * light-row product and no basis_mat element can leave the finite fp16 range."""
+
+    def __init__(self, absmax):
+        self.pending = AsyncFloats(absmax)
+        self.maxima = self.bound = self.result = None
+
+    def ready(self):
+        return self.result is not None or self.pending.ready()
+
+    def ok(self):
+        if self.result is None:
+            m = self.pending.get()
+            self.maxima = {"plane": m[0:3], "line": m[3:6], "light": m[6], "basis": m[7]}
+            self.bound = max(m[i] * m[3 + i] for i in range(3)) * m[6]
+            lim = INDIRECT_PROBE["range"]
+            # (a NaN maximum fails both comparisons)
+            self.result = bool(self.bound < lim and m[7] < lim and all(v < lim for v in m[:7]))
+        return self.result
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -240,20 +284,25 @@ def pack_plane(src):
     return dst
 
 
-def pack_half(tables):
-    """fp16 copies (round to nearest even, same element order) of up to 8 fp32 tensors in ONE launch (tir_pack_half)."""
+def pack_half(tables, scan=()):
+    """fp16 copies (round to nearest even, SATURATING, same element order) of up to 8 fp32 tensors in ONE launch
+    (tir_pack_half_checked) -> (copies, absmax): absmax[i] = max |x| of tables[i], then of every tensor in `scan` (tables whose
+    range matters but which the kernels read as fp32: light rows, basis_mat) -- a device tensor, read by the range guard of the
+    indirect-light precision policy (relight.HalfRange); a NaN anywhere in a table shows as NaN."""
     tables = [t.detach() for t in tables]
-    for t in tables:
+    scan = [t.detach() for t in scan]
+    for t in tables + scan:
         if t.dtype != torch.float32 or not t.is_cuda:
             raise ValueError("pack_half: fp32 CUDA tensors expected")
     # same strides as the source (the channel-last planes keep their layout): a raw element-for-element copy of the storage
     outs = [torch.empty_strided(t.shape, t.stride(), dtype=torch.float16, device=t.device) for t in tables]
-    k = len(tables)
-    srcs = (C.c_void_p * k)(*[t.data_ptr() for t in tables])
-    dsts = (C.c_void_p * k)(*[o.data_ptr() for o in outs])
-    cnts = (C.c_int64 * k)(*[_storage_span(t) for t in tables])
-    _call("tir_pack_half", srcs, dsts, cnts, k, _stream())
-    return outs
+    k = len(tables) + len(scan)
+    srcs = (C.c_void_p * k)(*[t.data_ptr() for t in tables + scan])
+    dsts = (C.c_void_p * k)(*([o.data_ptr() for o in outs] + [None] * len(scan)))
+    cnts = (C.c_int64 * k)(*[_storage_span(t) for t in tables + scan])
+    absmax = torch.zeros((k,), dtype=torch.float32, device=(tables + scan)[0].device)
+    _call("tir_pack_half_checked", srcs, dsts, cnts, k, _ptr(absmax), _stream())
+    return outs, absmax
 
 
 def _storage_span(t):
@@ -448,16 +497,30 @@ if MLP_IMPL not in MLP_ENTRY:
 # Precision policy for INDIRECT light.  The radiance of the SECONDARY-ray records (models/relight_utils.py:818-832)
 # is averaged over a ray's records and over the light directions before it reaches rgb_with_brdf_map; its gather and decoder may
 # run at another precision than the launches whose outputs are composited into the maps directly:
-#   TENSOIR_INDIRECT_PRECISION = f16 (default): appearance taps from an fp16 shadow of the planes / lines (tir_vm_app_fwd_h16)
+#   TENSOIR_INDIRECT_PRECISION = f16: appearance taps from an fp16 shadow of the planes / lines (tir_vm_app_fwd_h16)
 #                                  and the single-product fp16 decoder (tir_mlp_fwd_auxtab_f16), fp32 accumulation everywhere;
 #                                  measured on rgb_with_brdf_map: profiles/r04_precision_policy.json
 #                              = full: the same kernels as the primary stage (fp32 taps, split-bf16 x3 decoder)
+#                              = auto (default, round 5): the f16 kernels, but only for field / decoder versions that pass (i) the
+#                                  RANGE guard -- max|plane_i| max|line_i| max|light row| and max|basis_mat| from the pack launch
+#                                  bound every fp16 product below 6e4, checked for every new parameter version without an extra
+#                                  host synchronisation -- and (ii) the SELF-CHECK probe: up to INDIRECT_PROBE["records"] of the
+#                                  pass's own records are decoded by both paths and the f16 path is kept only while the signed
+#                                  mean / rms / max difference stay inside INDIRECT_PROBE's limits; re-probed whenever parameter
+#                                  storage changes (load, upsample, shrink) and every INDIRECT_PROBE["interval"] parameter
+#                                  versions otherwise (optimizer steps).  Anything else falls back to `full` for that version
+#                                  (relight._indirect_mode; the verdict is kept with the model and written into checkpoints).
 # Applies only while MLP_IMPL is the split-bf16 default (the exact / cross-check decoder modes stay exact end to end).
-_IND = os.environ.get("TENSOIR_INDIRECT_PRECISION", "f16")
-if _IND not in ("f16", "full"):
-    raise ValueError(f"TENSOIR_INDIRECT_PRECISION={_IND!r}: expected f16 or full")
-SECONDARY_MLP_IMPL = "f16" if _IND == "f16" else None       # None | "f16" | "bf16" (probe only) | "bf16x3"
-SECONDARY_APP_IMPL = "h16" if _IND == "f16" else None       # None | "h16"
+_IND = os.environ.get("TENSOIR_INDIRECT_PRECISION", "auto")
+if _IND not in ("auto", "f16", "full"):
+    raise ValueError(f"TENSOIR_INDIRECT_PRECISION={_IND!r}: expected auto, f16 or full")
+SECONDARY_MLP_IMPL = "f16" if _IND != "full" else None       # None | "f16" | "bf16" (probe only) | "bf16x3"
+SECONDARY_APP_IMPL = "h16" if _IND != "full" else None       # None | "h16"
+INDIRECT_GUARD = _IND == "auto"        # False: the settings above apply unconditionally (f16: the caller vouches for range and precision)
+# Limits of the self-check (differences of the decoded radiance, f16 path - full path, over the probe records; calibrated on
+# trained and adversarially scaled fields so that passing implies |d rgb_with_brdf_map| < 2.5e-5, a quarter of the 1e-4
+# budget: profiles/r05_precision_sweep.json) and of the range guard (largest finite fp16 = 65504).
+INDIRECT_PROBE = {"records": 32768, "interval": 64, "bias": 4e-6, "rms": 4e-5, "max": 1e-3, "range": 6.0e4}
 
 
 # TENSOIR_FUSED_INDIRECT=0: gather and decoder of the secondary-ray records as two launches (tir_vm_app_fwd_h16 +
@@ -889,9 +952,10 @@ def cdf_guide_tables(row_cdf, col_cdf):
     a table is the search result for u = k / G -- the first index whose cdf exceeds it, clamped to n - 1.  Built with
     torch.searchsorted on the fp32 tables the kernel searches (k / G is exact in fp32).  Returns (row_guide int32 [Gr + 1],
     col_guide [H, Gc + 2] 16-bit entries packed in pairs into int32 [H, Gc / 2 + 1] (little endian; the last entry pads the
-    row to whole words), Gr, Gc), or None when a row has more than 65535 columns."""
+    row to whole words), Gr, Gc), or None when a row has more than 65535 columns or fewer than 2 (Gc + 2 entries would not
+    fill whole words; a one-column map needs no search)."""
     H, W = col_cdf.shape
-    if W > 65535:
+    if W > 65535 or W < 2:
         return None
     gr, gc = 1 << max(0, (H - 1).bit_length()), 1 << max(0, (W - 1).bit_length())
     dev = row_cdf.device

@@ -43,20 +43,90 @@ def _rec_capacity(n_rays):
     return int(min(max(1 << 20, 16 * n_rays), 1 << 28))
 
 
-def _gather_then_decode(tensoIR, f, fh, rec_xyz, light_idx, rec_ray, light_div, dirs, dir_map, n_dirs, n_dev):
-    """Appearance gather, then the radiance decoder, as two launches (features through HBM)."""
-    if fh is not None:         # indirect-light precision policy: fp16 shadow taps, fp16 matrix operands
+def _gather_then_decode(tensoIR, f, fh, rec_xyz, light_idx, rec_ray, light_div, dirs, dir_map, n_dirs, n_dev, full=False):
+    """Appearance gather, then the radiance decoder, as two launches (features through HBM).  full: the primary-stage kernels
+    (fp32 taps, split-bf16 x3 decoder) whatever the precision policy says."""
+    if fh is not None and not full:   # indirect-light precision policy: fp16 shadow taps, fp16 matrix operands
         feat = ops.vm_app_h16(f, fh, rec_xyz, light_idx, rec_ray, light_div, n_dev)
     else:
         feat = ops.vm_app(f, rec_xyz, light_idx, rec_ray, True, False, None, light_div, n_dev)[0]
     # view direction of a record = that of its ray (ray id -> direction via aux_mod on the dense [point][direction] grid)
     return ops.mlp(tensoIR.renderModule.packed(), feat, dirs, rec_ray if dir_map is None else
-                   dir_map[rec_ray.long().clamp_(0, dir_map.numel() - 1)].contiguous(), ops.secondary_mlp_impl(),
+                   dir_map[rec_ray.long().clamp_(0, dir_map.numel() - 1)].contiguous(), None if full else ops.secondary_mlp_impl(),
                    n_dirs if dir_map is None else 0, n_dev)
 
 
+def _indirect_state(tensoIR):
+    return tensoIR.__dict__.setdefault("_indirect_state", {"verdict": None, "key": None, "storage": None, "age": 0, "why": None,
+                                                           "stats": None, "probes": 0, "fallbacks": 0})
+
+
+def _indirect_key(tensoIR):
+    """(parameter versions, parameter storage) of everything the indirect-light kernels read: appearance field + radiance decoder."""
+    tensoIR.packed_field()
+    tensoIR.renderModule.packed()
+    fk = tensoIR._field_key[0]
+    key = (fk, tensoIR.renderModule._key)
+    storage = (tuple((a, c) for a, _, c in fk), tuple(a for a, _ in tensoIR.renderModule._key))
+    return key, storage
+
+
+def _indirect_mode(tensoIR, training=False):
+    """Which kernels decode this pass's secondary-ray records: "full" (primary-stage kernels), "f16" (the precision policy's
+    kernels) or "probe" (auto policy, no valid verdict for the current parameters: run f16, self-check against full, decide).
+
+    auto (ops.INDIRECT_GUARD): a verdict belongs to one parameter version.  Inference passes always use a verdict of exactly
+    the current version (so the same parameters render the same image whatever was rendered before).  TRAINING passes
+    (`training`: the forward of an optimizer step, where indirect light is a no_grad constant of the loss) carry it over to later
+    versions of the SAME storage -- an optimizer step moves a parameter by at most the learning rate -- for
+    ops.INDIRECT_PROBE["interval"] versions, then re-establish it; new storage (load, upsample, shrink) re-establishes it at
+    once.  The range guard is evaluated for EVERY version (HalfRange, no extra synchronisation) by the caller."""
+    if ops.secondary_app_impl() != "h16" and ops.secondary_mlp_impl() is None:
+        return "full"
+    if not ops.INDIRECT_GUARD:
+        return "f16"
+    st = _indirect_state(tensoIR)
+    key, storage = _indirect_key(tensoIR)
+    if st["verdict"] is not None and st["key"] == key:
+        return st["verdict"]
+    if training and st["verdict"] is not None and st["storage"] == storage and st["age"] < ops.INDIRECT_PROBE["interval"]:
+        st["age"] += 1
+        st["key"] = key
+        return st["verdict"]
+    return "probe"
+
+
+def _set_verdict(tensoIR, verdict, why, stats=None):
+    st = _indirect_state(tensoIR)
+    key, storage = _indirect_key(tensoIR)
+    if verdict == "full" and st["verdict"] != "full":
+        st["fallbacks"] += 1
+    st.update(verdict=verdict, key=key, storage=storage, age=0, why=why)
+    if stats is not None:
+        st["stats"] = stats
+
+
+def _probe_indirect(tensoIR, f, rgb, n_valid, rec_xyz, light_idx, rec_ray, light_div, dirs, dir_map, n_dirs):
+    """The self-check of the auto policy: an evenly strided subset of this pass's records decoded by the primary-stage kernels
+    and compared with the f16 path's `rgb` rows.  One host synchronisation (only in passes that establish a verdict)."""
+    lim = ops.INDIRECT_PROBE
+    n_valid = min(int(n_valid), rgb.shape[0])
+    if n_valid <= 0:
+        return True, {"records": 0}
+    step = max(1, n_valid // lim["records"])
+    sel = torch.arange(0, n_valid, step, device=rgb.device)[:lim["records"]]
+    ref = _gather_then_decode(tensoIR, f, None, rec_xyz[sel].contiguous(), light_idx, rec_ray[sel].contiguous(), light_div, dirs,
+                              dir_map, n_dirs, None, full=True)
+    d = (rgb[sel] - ref).double()
+    v = torch.stack([d.mean(0).abs().max(), d.pow(2).mean().sqrt(), d.abs().max(), ref.double().pow(2).mean().sqrt()]).tolist()
+    stats = {"records": int(sel.numel()), "of": n_valid, "bias": v[0], "rms": v[1], "max": v[2], "radiance_rms": v[3]}
+    ok = v[0] <= lim["bias"] and v[1] <= lim["rms"] and v[2] <= lim["max"]        # (NaN fails)
+    _indirect_state(tensoIR)["probes"] += 1
+    return bool(ok), stats
+
+
 def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, light_idx, light_div,
-               want_indirect, want_nerfactor=False, n_dirs=0, keep_records=False, ids=None, defer=False):
+               want_indirect, want_nerfactor=False, n_dirs=0, keep_records=False, ids=None, defer=False, training=False):
     """Shared driver of compute_transmittance / compute_radiance / render_with_BRDF:
     march (+ record the w > thres samples) -> appearance gather -> radiance decoder -> per-ray sum.
 
@@ -79,6 +149,7 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
         cap = _rec_capacity(n_rays)
     # a record counter the primary march of this pass has already zeroed on the device (no fill launch); first attempt only
     armed = tensoIR.__dict__.pop("_rec_counter_armed", None)
+    force_full = False
     while True:
         extra = {} if ids is None else dict(ray_ids=ids["pair_ids"], n_ids_dev=ids["n_active"], vis=ids["vis"],
                                             rec_cnt=ids["rec_cnt"])
@@ -99,40 +170,77 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
         else:
             n_rows = cap
         indirect = None
+        mode = "full" if force_full else _indirect_mode(tensoIR, training)
+        if mode == "probe" and capture is not None:
+            raise ops._lib.TensoirHipError("graph capture needs an established indirect-light precision verdict (run the pass eagerly first)")
+        rng = None
         if n_rows > 0:
             rec_ray, rec_w, rec_xyz = rec["ray"][:n_rows], rec["w"][:n_rows], rec["xyz"][:n_rows]
             # light index / view direction of a record = those of its ray (ray id -> point via idx_div,
             # ray id -> direction via aux_mod on the dense [point][direction] grid)
-            fh = tensoIR.packed_field_half() if ops.secondary_app_impl() == "h16" else None
-            if fh is not None and dir_map is None and n_dirs > 0 and ops.fused_indirect() and dirs.shape[0] * 8 <= max(n_rows, 1) \
-                    and int(f.app_dim) == 27:
-                # gather -> basis contraction -> radiance decoder in ONE launch, the feature rows never reach HBM
-                rgb = ops.indirect_fused(f, fh, tensoIR.renderModule.packed(), rec_xyz, light_idx, rec_ray, light_div, dirs, n_dirs, n_dev)
-            else:
-                rgb = _gather_then_decode(tensoIR, f, fh, rec_xyz, light_idx, rec_ray, light_div, dirs, dir_map, n_dirs, n_dev)
+            fh = tensoIR.packed_field_half() if (mode != "full" and ops.secondary_app_impl() == "h16") else None
+            rng = tensoIR.half_range() if (fh is not None and ops.INDIRECT_GUARD) else None
+            if rng is not None and (mode == "probe" or rng.ready()) and not rng.ok():
+                # range guard (tir_pack_half_checked's contract): an fp16 product could overflow -> the primary-stage kernels
+                _set_verdict(tensoIR, "full", "range", {"bound": rng.bound, "maxima": rng.maxima})
+                mode, fh, rng = "full", None, None
+            if capture is not None and rng is not None and not rng.ready():
+                raise ops._lib.TensoirHipError("graph capture needs a finished range check of the fp16 field shadow (run the pass eagerly first)")
+
+            def decode(full, fh=fh):
+                if not full and fh is not None and dir_map is None and n_dirs > 0 and ops.fused_indirect() \
+                        and dirs.shape[0] * 8 <= max(n_rows, 1) and int(f.app_dim) == 27:
+                    # gather -> basis contraction -> radiance decoder in ONE launch, the feature rows never reach HBM
+                    return ops.indirect_fused(f, fh, tensoIR.renderModule.packed(), rec_xyz, light_idx, rec_ray, light_div, dirs, n_dirs, n_dev)
+                return _gather_then_decode(tensoIR, f, fh, rec_xyz, light_idx, rec_ray, light_div, dirs, dir_map, n_dirs, n_dev, full=full)
+
+            rgb = decode(mode == "full")
+            if mode == "probe":        # auto policy, no verdict for these parameters yet: self-check on this pass's own records
+                n_valid = total if first else total_host.get()
+                ok, stats = _probe_indirect(tensoIR, f, rgb, min(n_valid, n_rows), rec_xyz, light_idx, rec_ray, light_div, dirs, dir_map, n_dirs)
+                _set_verdict(tensoIR, "f16" if ok else "full", "probe", stats)
+                if not ok:
+                    rgb = decode(True)
+                rng = None             # (evaluated above)
             if keep_records:       # the caller's integration kernel sums the records itself (tir_shade_integrate_records)
                 indirect = {"off": rec["off"], "cnt": rec["cnt"], "w": rec_w, "rgb": rgb}
             else:
                 indirect = ops.accumulate_records(rec["off"], rec["cnt"], rec_w, rgb, n_rays)
         else:
             indirect = torch.zeros((n_rays, 3), dtype=torch.float32, device=dev)
+
+        def range_failed(rng=rng):
+            """The range guard of a carried-over verdict, evaluated once the maxima of THIS version's shadow have arrived."""
+            if rng is None or rng.ok():
+                return False
+            _set_verdict(tensoIR, "full", "range", {"bound": rng.bound, "maxima": rng.maxima})
+            return True
+
         if first:
+            if range_failed():
+                force_full = True
+                continue
             break
         if capture is not None:                        # HIP-graph capture: the graph owner reads the counter after replay
+            if rng is not None and not rng.ok():
+                raise ops._lib.TensoirHipError("graph capture: the fp16 field shadow fails the range guard")
             capture.append((n_total, cap, ("secondary", n_rays)))
             return vis, oma, indirect
         if defer:                                      # the caller checks after ITS remaining launches are queued too
-            def check(total_host=total_host, cap=cap):
+            def check(total_host=total_host, cap=cap, range_failed=range_failed):
                 total = total_host.get()
                 if total > cap:
                     hints.pop(n_rays, None)            # the re-run learns the count first
                     return False
                 hints[n_rays] = max(int(total * 1.5) + 4096, 1 << 14, int(0.97 * hints.get(n_rays, 0)))
-                return True
+                return not range_failed()              # (a failed range guard: the re-run decodes with the primary-stage kernels)
             tensoIR.__dict__.setdefault("_pending_checks", []).append(check)
             return vis, oma, indirect
         total = total_host.get()                       # waits for the march only, not for what was queued behind it
         if total <= cap:
+            if range_failed():
+                force_full = True
+                continue
             break
         cap = int(total * 1.25) + 1024                 # overflow: some rays were dropped -> redo with room
     if len(hints) > 32:
@@ -240,7 +348,7 @@ def shade_from_maps(tensoIR, maps, rays, light_idx, sample_method="fixed_envirma
         ids = {"pair_ids": pair_ids, "n_active": n_active, "vis": vis0, "rec_cnt": cnt0}
         try:
             vis, _, ind = _secondary(tensoIR, surf, dirs, M * D, z, None, None, None, li, D, True, False, D,
-                                     keep_records=fuse, ids=ids, defer=_defer_check)
+                                     keep_records=fuse, ids=ids, defer=_defer_check, training=train)
         except BaseException:
             # the pair counter is re-armed by the integration kernel at the end of the pass; if the pass is abandoned
             # in between (capacity error under capture, OOM ...) it must not stay non-zero for the next call

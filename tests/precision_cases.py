@@ -1,0 +1,134 @@
+"""Cases of the indirect-light precision policy, shared by tests/test_gpu_precision_policy.py and
+tools/r05_precision.py (which writes profiles/r05_precision_*.json).  Reference stage: models/relight_utils.py:777-834
+(compute_radiance: compute_appfeature -> renderModule on the secondary-ray records, fp32 throughout).
+
+  * trained(): a checkpoint TRAINED through the product API (tests/train_sequence.py: 450 iterations incl. updateAlphaMask /
+    shrink / upsample, 330 of them with the relighting losses), rendered with the default policy and compared with the oracle;
+  * sweep(): the synthetic scene with its appearance planes / radiance-decoder weights / light rows scaled up (decoder weight
+    norms and feature magnitudes grow in training) -- what the f16 kernels would do unguarded, what the policy decides."""
+import contextlib
+import io
+import types
+
+import torch
+
+MAPS = ["rgb_map", "depth_map", "normal_map", "albedo_map", "roughness_map", "fresnel_map", "acc_map", "normals_diff_map",
+        "normals_orientation_loss_map"]
+NAMES = MAPS + ["acc_mask", "albedo_smoothness_loss", "roughness_smoothness_loss"]
+ARGS = types.SimpleNamespace(second_nSample=96, second_near=0.05, second_far=1.5)
+
+
+@contextlib.contextmanager
+def policy(guard, mlp="f16", app="h16"):
+    """Temporarily select the indirect-light policy: guard=True -> auto, guard=False + (f16, h16) -> forced f16,
+    (None, None) -> full."""
+    from tensoir_amd import ops
+    old = ops.INDIRECT_GUARD, ops.SECONDARY_MLP_IMPL, ops.SECONDARY_APP_IMPL
+    ops.INDIRECT_GUARD, ops.SECONDARY_MLP_IMPL, ops.SECONDARY_APP_IMPL = guard, mlp, app
+    try:
+        yield
+    finally:
+        ops.INDIRECT_GUARD, ops.SECONDARY_MLP_IMPL, ops.SECONDARY_APP_IMPL = old
+
+
+@torch.no_grad()
+def render(model, rays, lidx, noise, n_samples):
+    """-> (12-tuple of the primary pass, rgb_with_brdf rows [B,3]) through the checked route of the parity tests."""
+    from tensoir_amd import relight
+    out, maps = model(rays, lidx, N_samples=n_samples, _brdf_jitter_dense=noise, _return_maps=True)
+    brdf = relight.shade_from_maps(model, maps, rays, lidx, "fixed_envirmap", ARGS, acc_thres=0.5)
+    return out, brdf
+
+
+def three_policies(model, rays, lidx, noise, n_samples):
+    """rgb_with_brdf under forced f16, full and auto (+ what auto decided and measured)."""
+    res = {}
+    with policy(False):
+        out, res["f16"] = render(model, rays, lidx, noise, n_samples)
+    with policy(False, None, None):
+        _, res["full"] = render(model, rays, lidx, noise, n_samples)
+    model.__dict__.pop("_indirect_state", None)
+    with policy(True):
+        _, res["auto"] = render(model, rays, lidx, noise, n_samples)
+        res["decision"] = model.indirect_precision()
+    d16 = (res["f16"] - res["full"]).double()
+    res["f16_vs_full"] = {"max_abs": float(d16.abs().max()), "rms": float(d16.pow(2).mean().sqrt()), "mean_signed": float(d16.mean()),
+                          "finite": bool(torch.isfinite(res["f16"]).all())}
+    res["auto_vs_full_max_abs"] = float((res["auto"] - res["full"]).abs().max())
+    return out, res
+
+
+def oracle_compare(sc, out, brdf, rays, lidx, noise, n_samples, sel):
+    """Every map of the HIP render (rows `sel`) against oracle.renderer_train on the same rays -> {map: parity_metrics}."""
+    from oracle import tensoir_oracle as O          # checker only
+    from tests.helpers import parity_metrics
+    with torch.no_grad():
+        ref = O.renderer_train(sc, rays.cpu()[sel], lidx.cpu()[sel], n_samples=n_samples, brdf_jitter=noise[sel], second_n_sample=96)
+    got = dict(zip(NAMES, out))
+    rep = {n: parity_metrics(got[n].cpu()[sel], ref[n]) for n in MAPS}
+    rep["rgb_with_brdf_map"] = parity_metrics(brdf.cpu()[sel], ref["rgb_with_brdf_map"])
+    rep["n_rays"] = int(ref["rgb_map"].shape[0])
+    rep["n_hit"] = int((ref["acc_map"] > 0.5).sum())
+    return rep
+
+
+def trained(n_iters=450):
+    from tests.train_sequence import reconstruct
+    with contextlib.redirect_stdout(io.StringIO()):
+        r = reconstruct("single_light", n_iters=n_iters, batch=1024, upsamp=(200, 300), mask_updates=(120, 250),
+                        model_kw=dict(envmap_h=8, envmap_w=16))
+    return r
+
+
+def trained_case(r, n_rays=2048):
+    """The trained model's own training rays (host tensors, as the script passes them) under the three policies + oracle."""
+    from tests.helpers import scene_from_model
+    m = r.model
+    rays = r.rays_f[:n_rays].cuda()
+    lidx = r.lidx_f[:n_rays].cuda().to(torch.int32).reshape(-1, 1)
+    S = int(m.nSamples)
+    noise = torch.randn(rays.shape[0], S, 3, generator=torch.Generator().manual_seed(5))
+    out, res = three_policies(m, rays, lidx, noise, S)
+    ckpt = {"kwargs": m.get_kwargs(), "state_dict": {k: v.detach().cpu() for k, v in m.state_dict().items()}}
+    sc = scene_from_model(ckpt, m, 8, 16)
+    rep = oracle_compare(sc, out, res["auto"], rays, lidx, noise, S, slice(0, rays.shape[0], 2))
+    return res, rep
+
+
+SWEEP = [dict(name="as initialised"),
+         dict(name="planes x4", plane=4.0), dict(name="planes x16", plane=16.0), dict(name="planes x64", plane=64.0),
+         dict(name="decoder x2", dec=2.0), dict(name="decoder x4", dec=4.0),
+         dict(name="light rows x8", light=8.0),
+         dict(name="planes x16, decoder x2, light x8", plane=16.0, dec=2.0, light=8.0),
+         dict(name="planes x64, decoder x4, light x8", plane=64.0, dec=4.0, light=8.0),
+         dict(name="planes x3000, lines x100 (fp16 range)", plane=3000.0, line=100.0, oracle=False)]
+
+
+def sweep_case(cfg, grid=128, oracle_rays=128):
+    """One adversarially scaled scene: forced-f16 / full / auto renders of the 4096-ray batch + oracle on a subsample."""
+    import tensoir_amd
+    from tensoir_amd import synth
+    from tests.helpers import scene_from_model
+    ck = synth.make_checkpoint(grid=(grid,) * 3, seed=20211202)
+    sd = ck["state_dict"]
+    for i in range(3):
+        sd[f"app_plane.{i}"] = sd[f"app_plane.{i}"] * cfg.get("plane", 1.0)
+        sd[f"app_line.{i}"] = sd[f"app_line.{i}"] * cfg.get("line", 1.0)
+    for layer in (0, 2, 4):
+        sd[f"renderModule.mlp.{layer}.weight"] = sd[f"renderModule.mlp.{layer}.weight"] * cfg.get("dec", 1.0)
+    sd["light_line.weight"] = sd["light_line.weight"] * cfg.get("light", 1.0)
+    model = tensoir_amd.model_from_checkpoint(ck, "cuda", envmap_h=8, envmap_w=16)
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        model.updateAlphaMask((128, 128, 128))
+    rays = synth.make_rays(64, 64).cuda()
+    lidx = torch.zeros(4096, 1, dtype=torch.int32, device="cuda")
+    S = 512 if grid >= 300 else int(model.nSamples)
+    noise = torch.randn(4096, S, 3, generator=torch.Generator().manual_seed(7))
+    out, res = three_policies(model, rays, lidx, noise, S)
+    rep = None
+    if oracle_rays:
+        sc = scene_from_model(ck, model, 8, 16)
+        rep = oracle_compare(sc, out, res["auto"], rays, lidx, noise, S, slice(0, 4096, 4096 // oracle_rays))
+    rng = model.half_range()
+    res["range_bound"] = None if rng is None else (rng.ok(), rng.bound)[1]
+    return res, rep

@@ -14,105 +14,24 @@ import numpy as np
 import pytest
 import torch
 
-from tensoir_amd.optim import Adam       # what tensoir_amd.run binds torch.optim.Adam to (train_tensoIR.py:197)
+from tests.train_sequence import reconstruct
 
 pytestmark = pytest.mark.gpu
-
-
-def n_to_reso(n_voxels, bbox):
-    size = bbox[1] - bbox[0]
-    voxel = (size.prod() / n_voxels).pow(1 / 3)
-    return (size / voxel).long().tolist()
-
-
-def tv(x):
-    h, w = x.shape[2], x.shape[3]
-    ch = x.shape[1] * (h - 1) * w
-    cw = x.shape[1] * h * max(w - 1, 1)
-    return 2 * ((x[:, :, 1:, :] - x[:, :, :-1, :]).pow(2).sum() / ch + (x[:, :, :, 1:] - x[:, :, :, :-1]).pow(2).sum() / cw) / x.shape[0]
 
 
 @pytest.mark.parametrize("variant", ["single_light", "rotated_multi_lights", "general_multi_lights"])
 def test_reconstruction_call_sequence(tmp_path, variant):
     """variant = which of the reference's three training scripts is mirrored: train_tensoIR.py (one light),
     train_tensoIR_rotated_multi_lights.py (one SG set seen under three rotations) or
-    train_tensoIR_general_multi_lights.py (one SG set per light, models/tensoRF_general_multi_lights.py)."""
-    import types
-
-    import tensoir_amd
+    train_tensoIR_general_multi_lights.py (one SG set per light, models/tensoRF_general_multi_lights.py).
+    The loop itself: tests/train_sequence.py."""
     from tensoir_amd import Renderer_TensoIR_train
-    from tensoir_amd.synth_dataset import SyntheticDataset
-    torch.manual_seed(20211202)
-    np.random.seed(20211202)
-    dev = torch.device("cuda:0")
     if variant == "general_multi_lights":
         from tensoir_amd.general_multi_lights import TensorVMSplit
-        light_kw = dict(light_rotation=None, light_name_list=["sunset", "snow", "courtyard"])
-        ds = SyntheticDataset("synthetic:views=4,res=32", "none", split="train", light_name_list=light_kw["light_name_list"])
     else:
         from tensoir_amd import TensorVMSplit
-        rot = ["000"] if variant == "single_light" else ["000", "120", "240"]
-        light_kw = dict(light_rotation=rot)
-        ds = SyntheticDataset("synthetic:views=4,res=32", "none", split="train", light_rotation=rot)
-    args = types.SimpleNamespace(second_nSample=96, second_near=0.05, second_far=1.5)
-    n_iters, batch = 150, 1024
-    upsamp, mask_updates = [100, 130], [60, 110]      # tests/data/synthetic_train.txt (the reference itself
-    # trains this schedule to 26.8 dB on its CPU path: density has emerged well before the first mask update)
-    voxel_list = torch.round(torch.exp(torch.linspace(np.log(32 ** 3), np.log(64 ** 3), len(upsamp) + 1))).long().tolist()[1:]
-    aabb = ds.scene_bbox.to(dev)
-    reso = n_to_reso(32 ** 3, aabb)
-    n_samples = min(10 ** 6, int(np.linalg.norm(reso) / 0.5))
-    m = TensorVMSplit(aabb, reso, dev, density_n_comp=[16, 16, 16], appearance_n_comp=[48, 48, 48], app_dim=27,
-                      near_far=ds.near_far, shadingMode="MLP_Fea", alphaMask_thres=1e-4, density_shift=-10,
-                      distance_scale=25, pos_pe=2, view_pe=2, fea_pe=2, featureC=128, step_ratio=0.5,
-                      fea2denseAct="softplus", normals_kind="derived_plus_predicted", light_kind="sg", dataset=ds,
-                      numLgtSGs=128, **light_kw)
-    lr_factor = 0.1 ** (1 / n_iters)
-    opt = Adam(m.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
-    all_rays, all_rgbs, all_lidx = ds.all_rays, ds.all_rgbs, ds.all_light_idx
-    rays_f, keep = m.filtering_rays(all_rays, bbox_only=True)
-    rgbs_f, lidx_f = all_rgbs[keep], all_lidx[keep]
-    assert 0 < rays_f.shape[0] <= all_rays.shape[0]
-    relight, l1_w, tv_d, tv_a = False, 8e-5, 0.05, 0.005
-    losses, grids = [], [tuple(m.gridSize.tolist())]
-    for it in range(n_iters):
-        idx = torch.from_numpy(np.random.permutation(rays_f.shape[0])[:batch])
-        rays_b, rgb_b, lidx_b = rays_f[idx], rgbs_f[idx].to(dev), lidx_f[idx].to(dev)     # host rays, as the script passes
-        ret = Renderer_TensoIR_train(rays=rays_b, normal_gt=None, light_idx=lidx_b, tensoIR=m, N_samples=n_samples,
-                                     white_bg=ds.white_bg, ndc_ray=0, device=dev, sample_method="stratified_sampling",
-                                     chunk_size=160000, is_train=True, is_relight=relight, args=args)
-        assert set(ret) >= {"rgb_map", "rgb_with_brdf_map", "normals_diff_map", "albedo_smoothness_loss"}
-        loss_rgb = torch.mean((ret["rgb_map"] - rgb_b) ** 2)
-        total = loss_rgb + l1_w * m.density_L1()
-        if tv_d > 0:
-            tv_d *= lr_factor
-            tv_a *= lr_factor
-            total = total + m.TV_loss_density(tv) * tv_d + m.TV_loss_app(tv) * tv_a
-        if relight:
-            total = total + 0.2 * torch.mean((ret["rgb_with_brdf_map"] - rgb_b) ** 2)
-            total = total + 5e-4 * ret["normals_diff_map"].mean() + 1e-3 * ret["normals_orientation_loss_map"].mean()
-            total = total + 1e-3 * ret["roughness_smoothness_loss"] + 1e-3 * ret["albedo_smoothness_loss"]
-        opt.zero_grad()
-        total.backward()
-        opt.step()
-        assert torch.isfinite(total), it
-        losses.append(float(loss_rgb.detach()))
-        for g in opt.param_groups:
-            g["lr"] *= lr_factor
-        if it in mask_updates:
-            new_aabb = m.updateAlphaMask(tuple(reso))
-            if it == mask_updates[0]:
-                m.shrink(new_aabb)
-                l1_w, relight, tv_d, tv_a = 4e-5, True, 0, 0
-            else:
-                rays_f, keep = m.filtering_rays(all_rays, bbox_only=True)
-                rgbs_f, lidx_f = all_rgbs[keep], all_lidx[keep]
-        if it in upsamp:
-            reso = n_to_reso(voxel_list.pop(0), m.aabb)
-            n_samples = min(10 ** 6, int(np.linalg.norm(reso) / 0.5))
-            m.upsample_volume_grid(reso)
-            opt = Adam(m.get_optparam_groups(0.02, 1e-3), betas=(0.9, 0.99))
-            grids.append(tuple(m.gridSize.tolist()))
+    r = reconstruct(variant, n_iters=150, batch=1024, upsamp=(100, 130), mask_updates=(60, 110))
+    m, dev, args, rays_f, lidx_f, losses, grids = r.model, r.device, r.args, r.rays_f, r.lidx_f, r.losses, r.grids
     assert len(grids) == 3 and grids[-1][0] > grids[0][0]                 # two up-samplings happened
     assert m.alphaMask is not None
     psnr = -10 * np.log10(np.mean(losses[-10:]))
