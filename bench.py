@@ -93,6 +93,12 @@ def parse():
     ap.add_argument("--allow-shared-gpu", action="store_true", help="let several ranks share one GPU (gloo plumbing tests only)")
     ap.add_argument("--no-side-workloads", action="store_true",
                     help="batch workload, one GPU: skip the reduced-repetition image / relight / train lines of the `workloads` block")
+    ap.add_argument("--c5-host-masking", action="store_true",
+                    help="relight workload: drive every chunk the way the reference script does (boolean-mask indexing, nonzero, "
+                         "index_put_: one host synchronisation per chunk) instead of the product's sync-free chunk call")
+    ap.add_argument("--simulate-ranks", type=int, default=0,
+                    help="image / relight workload on ONE GPU: render each rank's shard of a W-rank job alone (W = 2, 4, ... up to this), "
+                         "row tiles and interleaved tiles, and report per-shard times, max / mean and the predicted speed-up")
     ap.add_argument("--force-dist", action="store_true",
                     help="single process: create a 1-rank RCCL group anyway and run the multi-rank code path (all-gather per step)")
     return ap.parse_args()
@@ -481,6 +487,18 @@ def sharp_scene_line(a, device, args):
     gr.rays.copy_(rays)
     gr.lidx.copy_(lidx)
     ret = gr(clone_outputs=False)
+    parity = None
+    if not a.no_cpu_baseline:        # the graph-replay maps of this scene against the oracle on every 32nd ray (default policy)
+        from oracle import tensoir_oracle as O          # checker only
+        from tests.helpers import scene_from_model
+        sc = scene_from_model(_ck, model, a.env_h, a.env_w)
+        stride = max(1, B // 128)
+        with torch.no_grad():
+            ref = O.renderer_train(sc, rays.cpu()[::stride], lidx.cpu()[::stride], n_samples=a.samples, second_n_sample=a.second_samples)
+        got = {k: v.clone() for k, v in ret.items() if torch.is_tensor(v)}
+        parity = map_parity(got, ref, MAP_KEYS, slice(0, None, stride))
+        parity["rays_compared"] = int(ref["rgb_map"].shape[0])
+        parity["indirect_precision"] = model.indirect_precision()
     for _ in range(5):
         gr(clone_outputs=False, defer_check=True)
     torch.cuda.synchronize()
@@ -509,7 +527,7 @@ def sharp_scene_line(a, device, args):
             "scene": "blob sigma 0.2, gain 2000 (headline: 0.35 / 20)",
             "surface_points": int((ret["acc_map"] > 0.5).sum()),
             "app_samples_per_ray": round(totals[0] / B, 1) if totals else None,
-            "secondary_records": totals[1] if len(totals) > 1 else None,
+            "secondary_records": totals[1] if len(totals) > 1 else None, "parity": parity,
             "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:8]}}
 
 
@@ -583,6 +601,18 @@ def bench_image(a, embed=False):
         pr[rank] = per_rank[0]
         dist.all_reduce(pr)
         per_rank = pr.tolist()
+    sim = None
+    if a.simulate_ranks >= 2 and world == 1:
+        def render_shard(mine):
+            mine = mine.to(device)
+            with torch.no_grad():
+                for _ in range(4):
+                    parts = tdist._render_chunks(fn, rays, lidx, mine, a.rays)
+                    if fn.validate():
+                        break
+                return torch.cat(parts, dim=0) if parts else None
+        sim = simulate_ranks(render_shard, n, a.rays, elapsed / a.steps, tdist.RECORD * 4, a.simulate_ranks,
+                             local_exchange_s=sum(exch) / len(exch))
     roofline = parity = cpu = kernels = None
     if rank == 0 and not a.no_cpu_baseline:
         # dominant kernel, in-run parity and CPU baseline on ONE chunk of the image (the middle one: rays cross the object)
@@ -630,6 +660,8 @@ def bench_image(a, embed=False):
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "kernels_middle_chunk": kernels,
             "roofline_note": "dominant kernel of the image's middle chunk, one eager pass bracketed by events (calibrated)",
         }
+        if sim is not None:
+            line["simulated_ranks"] = sim
         if embed:
             return line
         print(json.dumps(line), flush=True)
@@ -637,6 +669,52 @@ def bench_image(a, embed=False):
             raise SystemExit(f"[bench] PARITY FAILURE vs the oracle (image workload): {parity}")
     if use_dist:
         dist.destroy_process_group()
+
+
+def simulate_ranks(render_shard, n_rays, chunk, t1_s, record_bytes, max_world, passes=2, tiles=None, local_exchange_s=0.0):
+    """The multi-GPU row on ONE GPU: for W = 2, 4, ... <= max_world and every sharding (contiguous row
+    tiles; interleaved tiles of 1, 2, 4 chunks) render each rank's shard of the W-rank job ALONE on this GPU -- what rank r would
+    do on its own device, the field being replicated -- and time it (device drained around each shard; best of `passes` after
+    one untimed pass that lets the captured capacities settle).  Predicted time of the W-rank job = max_r t_r + exchange, where
+    exchange = the measured local reassembly of the gathered records (`local_exchange_s`, the world = 1 figure) + the wire time
+    of ONE all_gather_into_tensor over xGMI modelled at 60 % of the 153 GB/s per-link peak, every rank receiving (W - 1) shards
+    over W - 1 links in parallel (MI355X_MICROARCH.md: fully connected, 7 links per GPU).  Predicted speed-up = t(1) / that.
+    RCCL itself has still not run with N > 1: this bounds the load-balance part of the scaling curve, not the collective."""
+    from tensoir_amd import dist as tdist
+    if tiles is None:
+        tiles = [0, chunk, 2 * chunk, 4 * chunk]
+    worlds = [w for w in (2, 4, 8, 16) if w <= max_world]
+    out = {"method": simulate_ranks.__doc__.split("\n")[0].strip(), "t1_ms": round(1e3 * t1_s, 3), "record_bytes_per_ray": record_bytes,
+           "link_GBps_assumed": round(0.6 * 153.0, 1), "local_reassembly_ms": round(1e3 * local_exchange_s, 3), "configs": []}
+    for w in worlds:
+        for tile in tiles:
+            per = []
+            for r in range(w):
+                mine = tdist.shard_rows(n_rays, r, w, tile)
+                render_shard(mine)                       # untimed: capacities / caches of this shard's chunking
+                best = None
+                for _ in range(passes):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    render_shard(mine)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    best = dt if best is None else min(best, dt)
+                per.append(best)
+            wire = (w - 1) / w * n_rays * record_bytes / (0.6 * 153e9 * (w - 1))
+            t_w = max(per) + local_exchange_s + wire
+            out["configs"].append({"world": w, "sharding": "row tiles" if tile <= 0 else f"interleaved tiles of {tile // chunk} chunk(s)",
+                                   "tile": tile, "per_shard_ms": [round(1e3 * x, 3) for x in per], "max_ms": round(1e3 * max(per), 3),
+                                   "mean_ms": round(1e3 * sum(per) / w, 3), "imbalance_max_over_mean": round(max(per) / (sum(per) / w), 3),
+                                   "sum_over_t1": round(sum(per) / t1_s, 3), "exchange_model_ms": round(1e3 * (local_exchange_s + wire), 3),
+                                   "predicted_ms": round(1e3 * t_w, 3), "predicted_speedup": round(t1_s / t_w, 2)})
+    best = {}
+    for c in out["configs"]:
+        if c["world"] not in best or c["predicted_speedup"] > best[c["world"]]["predicted_speedup"]:
+            best[c["world"]] = c
+    out["best_per_world"] = {str(w): {"sharding": c["sharding"], "predicted_speedup": c["predicted_speedup"], "imbalance_max_over_mean": c["imbalance_max_over_mean"]}
+                             for w, c in best.items()}
+    return out
 
 
 def synthetic_hdr_maps(n_maps, H=1024, W=2048):
@@ -686,8 +764,10 @@ def bench_relight(a, embed=False):
     mine = tdist.shard_rows(n, rank, gw, tile).to(device)
 
     @torch.no_grad()
-    def chunk_pass(c, names, counts=None):
-        """One chunk: primary maps, then per environment map the relit colours [len(c), 3] (background where acc <= 0.5)."""
+    def chunk_pass_host(c, names, counts=None):
+        """One chunk the way the reference script drives it (scripts/relight_importance.py:99-113, :166-171): boolean-mask
+        indexing of the hit rows on the host side of the call (a synchronisation + ~12 indexing launches per chunk), per
+        environment map the relit colours, get_light + index_put_ for the background.  --c5-host-masking times this."""
         r, l = rays[c], lidx[c]
         out = model(r, l, N_samples=-1)
         depth, normal, albedo, rough, fres, acc = out[1:7]
@@ -702,10 +782,27 @@ def bench_relight(a, embed=False):
             rgb = relight.relight_importance_sampled(model, env, name, surf, nrm, alb, rgh, fr, rd, num_samples=Ns)
             img = env.get_light(name, r[:, 3:]).index_put_((rows_hit,), rgb)      # (scripts/relight_importance.py:166-171
             cols.append(img)                                                          #  tone-maps the background too: host side)
-        return (torch.cat(cols, dim=1) if cols else None), (surf, nrm, alb, rgh, fr, rd)
+        return (torch.cat(cols, dim=1) if cols else None), (surf, nrm, alb, rgh, fr, rd, r[mask], l[mask])
+
+    @torch.no_grad()
+    def chunk_pass(c, names, counts=None):
+        """One chunk through the product's chunk call (relight.relight_chunk): primary maps, device-side compaction of the hit
+        rows, per environment map the relit colours, background composed in -- no host round trip between the launches.
+        counts[1] collects the device-side hit counters (summed once per view)."""
+        if a.c5_host_masking:
+            return chunk_pass_host(c, names, counts)
+        r, l = rays[c], lidx[c]
+        out, _prim, cc = relight.relight_chunk(model, env, names, r, l, num_samples=Ns)
+        if counts is not None:
+            counts[1].append(cc["n_hit"])
+        return (out if names else None), cc
 
     def view(counts=None):
+        if counts is not None:
+            counts[1] = []
         parts = [chunk_pass(c, list(maps), counts)[0] for c in torch.split(mine, a.rays) if c.numel()]
+        if counts is not None and counts[1]:
+            counts[0] += int(torch.cat(counts[1]).sum().item())       # one read-back per view, after every chunk is queued
         local_rec = torch.cat(parts, dim=0) if parts else torch.zeros((0, 3 * len(maps)), device=device)
         return tdist.gather_records(local_rec, n, rank, gw, tile)
 
@@ -715,7 +812,7 @@ def bench_relight(a, embed=False):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    counts = [0]
+    counts = [0, []]
     for _ in range(a.steps):
         img = view(counts)
     torch.cuda.synchronize()
@@ -728,16 +825,23 @@ def bench_relight(a, embed=False):
         pr[rank] = elapsed / a.steps
         dist.all_reduce(pr)
         per_rank, elapsed = pr.tolist(), float(pr.max().item()) * a.steps
-        cnt = torch.tensor(counts, dtype=torch.float64, device=device)
+        cnt = torch.tensor(counts[:1], dtype=torch.float64, device=device)
         dist.all_reduce(cnt)
-        counts = [int(cnt.item())]
+        counts = [int(cnt.item()), []]
+    sim = None
+    if a.simulate_ranks >= 2 and world == 1:
+        def render_shard(mine_r):
+            mine_r = mine_r.to(device)
+            parts = [chunk_pass(c, list(maps))[0] for c in torch.split(mine_r, a.rays) if c.numel()]
+            return torch.cat(parts, dim=0) if parts else None
+        sim = simulate_ranks(render_shard, n, a.rays, elapsed / a.steps, 12 * len(maps), a.simulate_ranks, passes=1, tiles=[0, a.rays])
     roofline = parity = cpu = kernels = None
     if rank == 0 and not a.no_cpu_baseline:
         from oracle import tensoir_oracle as O          # checker / CPU baseline only
         from tests.helpers import parity_metrics, scene_from_model
         c0 = (n // a.rays // 2) * a.rays
         c = torch.arange(c0, c0 + a.rays, device=device)
-        _, (surf, nrm, alb, rgh, fr, rd) = chunk_pass(c, [])
+        _, (surf, nrm, alb, rgh, fr, rd, r_hit, l_hit) = chunk_pass_host(c, [])
         M = int(surf.shape[0])
         rows, gpu_ms, ev_over = attribute_kernels(lambda: chunk_pass(c, list(maps)), 1,
                                                   a.rays * 40 + a.rays * model.nSamples * 4, 0, device)
@@ -767,10 +871,16 @@ def bench_relight(a, embed=False):
                   "surface_points_compared": pts, "note": "every k-th surface point of the view's middle chunk, environment map 0, the "
                   "device-drawn cells fed to the oracle's restatement of scripts/relight_importance.py:119-170"}
         vis_rays = pts * Ns
-        cpu = {"value": round(vis_rays / med, 1), "unit": "importance-sampled (point, direction) pairs/s", "cores": torch.get_num_threads(),
-               "kind": "port", "sample": f"{pts} surface points x {Ns} samples x 96 visibility steps, one map, 1 warm-up + {len(ts)} timed "
-               f"calls, median; host nproc={os.cpu_count()}",
-               "gpu_same_unit": round(counts[0] * Ns * len(maps) / elapsed, 1)}
+        # the same unit as `value` (camera rays/s of a whole view): the oracle's primary pass on the rays of those surface points
+        # + its relight loop body once per environment map; the view's background rays (1 - hit fraction of the rays) are
+        # counted as free for the CPU (their primary pass is a bounding-box miss) -- which can only flatter the CPU figure
+        _, med_p, _ = timed_cpu(lambda: O.forward_primary(sc, cc(r_hit), cc(l_hit).to(torch.int32), -1, True, True, None, None, "aten"), 0, 1)
+        hit_frac = counts[0] / max(1, a.steps) / n
+        cpu = {"value": round((pts / max(hit_frac, 1e-9)) / (med_p + len(maps) * med), 2), "unit": "rays/s", "cores": torch.get_num_threads(),
+               "kind": "port", "sample": f"{pts} surface points of the middle chunk: primary pass of their camera rays ({med_p:.2f} s) + the relight loop "
+               f"body ({Ns} samples x 96 visibility steps, {med:.2f} s per map, 1 warm-up + {len(ts)} timed calls, median) x {len(maps)} maps; scaled "
+               f"to camera rays by the view's hit fraction {hit_frac:.3f} (background rays free); host nproc={os.cpu_count()}",
+               "pairs_per_s": round(vis_rays / med, 1), "gpu_pairs_per_s": round(counts[0] * Ns * len(maps) / elapsed, 1)}
     if rank == 0:
         line = {
             "metric": "relit camera rays/sec: one 800x800 view under 2048x1024 HDR maps, 512 importance samples per surface point",
@@ -781,7 +891,9 @@ def bench_relight(a, embed=False):
                                    f"2048x1024, {Ns} importance samples per surface point, 96 visibility samples per pair",
                        "sharding": ("contiguous row tiles" if tile <= 0 else f"interleaved tiles of {tile} rays") +
                                    f", one all_gather_into_tensor of {12 * len(maps)} B/ray relit colours per view",
-                       "launch": "eager per chunk (primary pass + per-map relight kernels)",
+                       "launch": "eager per chunk (primary pass + per-map relight kernels); " + ("host-side masking per chunk as the reference script "
+                                 "does (--c5-host-masking)" if a.c5_host_masking else "relight.relight_chunk: hit rows compacted on the device, no host round "
+                                 "trip per chunk (one hit-count read-back per view)"),
                        "visibility_pairs": "{} (bins {}x{}, blocks of {} pairs): only the pairs that pass the cosine mask are marched "
                                            "(scripts/relight_importance.py:127-131); TENSOIR_C5_PAIRS".format(
                                                pair_order[0], pair_order[1][0], pair_order[1][1], pair_order[2])},
@@ -792,6 +904,8 @@ def bench_relight(a, embed=False):
             "per_rank_ms_per_step": [round(1e3 * x, 3) for x in per_rank],
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "kernels_middle_chunk": kernels,
         }
+        if sim is not None:
+            line["simulated_ranks"] = sim
         if embed:
             return line
         print(json.dumps(line), flush=True)
@@ -1091,10 +1205,10 @@ def train_parity_and_cpu(a, ckpt, model, rays, lidx, gt, args, device, n_sub=128
     dense = {k: v for k, v in worst.items() if k not in l2}
     gmax = max(dense.values()) if dense else 0.0
     l2max, omax = (max(l2.values()) if l2 else 0.0), (max(outl.values()) if outl else 0.0)
-    parity = {"ok": abs(float(loss) - float(loss_ref)) < 1e-5 and max(maps.values()) < 1e-4 and gmax < 5e-3 and ((l2max < 1e-2 and omax < 5e-3) or bool(flips)),
-              "tolerance": "maps 1e-4 abs; decoder / basis / light gradients: max |hip - ref| / max |ref| per tensor < 5e-3 (the fp32 oracle itself is "
-                           "1e-4 ... 2e-3 from its fp64 self on this trained scene; golden-scene unit tests: 2e-3, measured 1.6e-4); VM plane / line "
-                           "gradients (sparse sums on a sharp, ill-conditioned scene): relative L2 error < 1e-2 and < 5e-3 of the elements off by "
+    parity = {"ok": abs(float(loss) - float(loss_ref)) < 1e-5 and max(maps.values()) < 1e-4 and gmax < 2e-3 and ((l2max < 3e-3 and omax < 2e-3) or bool(flips)),
+              "tolerance": "maps 1e-4 abs; decoder / basis / light gradients: max |hip - ref| / max |ref| per tensor < 2e-3 (the bound of the golden-scene "
+                           "unit tests; measured 6e-5 here, 1.6e-4 there; the fp32 oracle itself is 1e-4 ... 2e-3 from its fp64 self); VM plane / line "
+                           "gradients (sparse sums on a sharp, ill-conditioned scene): relative L2 error < 3e-3 (measured 3.4e-4) and < 2e-3 of the elements off by "
                            "more than 2e-3 of the largest -- waived (and reported) when a sample is a record on one side only (`record_mask_mismatches`); "
                            "unit tests on the golden scene keep the max-norm",
               "loss_abs_diff": float(f"{abs(float(loss) - float(loss_ref)):.3e}"), "maps_max_abs": maps,
@@ -1518,6 +1632,24 @@ def main():
                              f" x {a.samples} samples, {D} dirs x {a.second_samples}), 1 warm-up + {len(times)} timed calls, median "
                              f"(min {min(times):.2f} s, max {max(times):.2f} s); host nproc={os.cpu_count()}"}
             cpu["vs_reference"] = port_vs_reference(cpu["value"])
+            # ... and the port once more at the thread count that ratio was calibrated with: the
+            # reference-equivalent figure below is then port x ratio at EQUAL threads, with no cross-thread-count extrapolation
+            try:
+                cal = json.load(open(os.path.join(ROOT, "profiles", "port_over_reference.json")))
+                cal_thr, n_thr = int(cal["threads"]), torch.get_num_threads()
+                sub = max(1, B // 512)
+                r_s, l_s = rays.cpu()[::sub], lidx.cpu()[::sub]
+                torch.set_num_threads(cal_thr)
+                try:
+                    _, med_c, ts_c = timed_cpu(lambda: O.renderer_train(sc, r_s, l_s, n_samples=a.samples, second_n_sample=a.second_samples), 1, 2)
+                finally:
+                    torch.set_num_threads(n_thr)
+                cpu["vs_reference"]["at_calibration_threads"] = {
+                    "threads": cal_thr, "port_rays_per_s": round(r_s.shape[0] / med_c, 2),
+                    "reference_equivalent_rays_per_s": round(r_s.shape[0] / med_c * cal["port_over_reference"], 2),
+                    "sample": f"every {sub}th ray of the batch ({r_s.shape[0]} rays), 1 warm-up + {len(ts_c)} timed calls, median"}
+            except Exception as e:                   # the calibration file is optional
+                cpu["vs_reference"]["at_calibration_threads"] = {"error": f"{type(e).__name__}: {e}"}
         # parity of the timed HIP path (graph replay outputs `ret`) against those oracle rows
         maps = ["rgb_map", "depth_map", "normal_map", "albedo_map", "roughness_map", "fresnel_map", "acc_map",
                 "rgb_with_brdf_map", "normals_diff_map", "normals_orientation_loss_map"]
@@ -1638,12 +1770,14 @@ def main():
         "pmc": pmc_meta,
         "library": library_info(),
         "settle_steps": SETTLE_STEPS,
-        "precision_policy": {"indirect": "f16" if ops.secondary_mlp_impl() == "f16" else "full",
+        "precision_policy": {"indirect": model.indirect_precision(),
                              "secondary_gather": ops.secondary_app_impl() or "fp32", "secondary_decoder": ops.secondary_mlp_impl() or a.decoder,
-                             "fused_gather_decoder": bool(ops.fused_indirect()),
-                             "note": "radiance of the secondary-ray records (indirect light) from fp16 shadow planes + single-product fp16 "
-                                     "decoder, fp32 accumulation; every launch whose output is composited directly stays fp32 / split-bf16 x3 "
-                                     "(DESIGN 4.1, profiles/r04_precision_policy.json); TENSOIR_INDIRECT_PRECISION=full switches it off"},
+                             "fused_gather_decoder": bool(ops.fused_indirect()), "limits": dict(ops.INDIRECT_PROBE),
+                             "note": "auto (default): radiance of the secondary-ray records (indirect light) from fp16 shadow planes + single-product "
+                                     "fp16 decoder, fp32 accumulation, ONLY while this field / decoder version passes the range guard and the "
+                                     "self-check probe against the full-precision kernels (`indirect.probe`; otherwise `mode` = full); every launch "
+                                     "whose output is composited directly stays fp32 / split-bf16 x3 (DESIGN 4.1, profiles/r05_precision_*.json); "
+                                     "TENSOIR_INDIRECT_PRECISION=full|f16 forces either"},
         "boundary_call": boundary,
         "cpu_baseline": cpu,
         "parity": parity,

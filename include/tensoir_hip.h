@@ -523,6 +523,32 @@ int tir_relight_importance_cells_packed(const float* normal, const float* albedo
                                         float* out_rgb, void* stream);
 int tir_env_lookup(const float* env_rgb, int32_t H, int32_t W, const float* dirs, int64_t n, float* out, void* stream);
 
+/* A relight chunk without a host round trip (scripts/relight_importance.py:99-113 selects the acc > 0.5 rows with boolean
+ * masks -- a device-to-host synchronisation per chunk -- and :166-171 puts the relit colours back with index_put_):
+ * tir_surface_compact: the rows of a chunk's primary maps [B][20] (tir_composite_primary layout) with acc > acc_thres as
+ *   compacted surface-point arrays in ascending row order -- surf = o + depth d (:104), normal, albedo, rough [.], fresnel,
+ *   rays_d (capacity B rows each; rows >= the count are left untouched) --, slot [B] = compacted index of a row or -1, and
+ *   n_hit [1] = the count, all on the device.
+ * tir_env_sample_setup_list_n / tir_relight_importance_cells_packed_n: the entries above with the number of surface points
+ *   read from device memory (m_dev [1], clamped to M = the arrays' capacity; NULL = M): what tir_surface_compact produced.
+ *   Same Philox counters per (point, sample) as the host-compacted call, hence the same cells and colours.
+ * tir_env_compose: out[i] (rows of out_stride floats) = fg_rgb[slot[i]] where slot[i] >= 0, else the background lookup of
+ *   tir_env_lookup at dirs[i] (rows of dir_stride floats: 6 with dirs = rays + 3). */
+int tir_surface_compact(const float* maps, const float* rays, int32_t B, float acc_thres, float* surf, float* normal,
+                        float* albedo, float* rough, float* fresnel, float* rays_d, int32_t* slot, int32_t* n_hit,
+                        void* stream);
+int tir_env_sample_setup_list_n(const float* row_cdf, const float* col_cdf, int32_t H, int32_t W, const float* env_dir,
+                                int32_t dir_stride, const float* normal, int32_t M, int32_t Ns, uint64_t seed, uint64_t offset,
+                                int32_t bins_r, int32_t bins_c, int32_t block_pairs, const int32_t* row_guide,
+                                const uint16_t* col_guide, int32_t guide_rows, int32_t guide_cols, int32_t* cell,
+                                float* vis, int32_t* pair_ids, int32_t* n_active, const int32_t* m_dev, void* stream);
+int tir_relight_importance_cells_packed_n(const float* normal, const float* albedo, const float* rough,
+                                          const float* fresnel, const float* rays_d, const int32_t* cell,
+                                          const float* env_cell, const float* vis, int32_t M, int32_t Ns,
+                                          float* out_rgb, const int32_t* m_dev, void* stream);
+int tir_env_compose(const float* env_rgb, int32_t H, int32_t W, const float* dirs, int32_t dir_stride, int64_t n,
+                    const int32_t* slot, const float* fg_rgb, float* out, int32_t out_stride, void* stream);
+
 /* GGX_specular alone (models/relight_utils.py:17-50): normal/v [M][3], l [M][D][3],
  * rough/fresnel [M][3] -> spec [M][D][3]. */
 int tir_ggx_specular(const float* normal, const float* v, const float* l, const float* rough,

@@ -119,6 +119,10 @@ SIGNATURES = {
     "tir_relight_importance_cells": (C.c_int, [P, P, P, P, P, P, P, P, P, P, I32, I32, P, P]),
     "tir_relight_importance_cells_packed": (C.c_int, [P, P, P, P, P, P, P, P, I32, I32, P, P]),
     "tir_env_lookup": (C.c_int, [P, I32, I32, P, I64, P, P]),
+    "tir_surface_compact": (C.c_int, [P, P, I32, C.c_float, P, P, P, P, P, P, P, P, P]),
+    "tir_env_sample_setup_list_n": (C.c_int, [P, P, I32, I32, P, I32, P, I32, I32, C.c_uint64, C.c_uint64, I32, I32, I32, P, P, I32, I32, P, P, P, P, P, P]),
+    "tir_relight_importance_cells_packed_n": (C.c_int, [P, P, P, P, P, P, P, P, I32, I32, P, P, P]),
+    "tir_env_compose": (C.c_int, [P, I32, I32, P, I32, I64, P, P, P, I32, P]),
     "tir_ggx_specular": (C.c_int, [P, P, P, P, P, I32, I32, P, P]),
     # ---- training (backward) entry points ----
     "tir_march_primary_train_fwd": (C.c_int, [C.POINTER(TirField), P, P, I32, I32, F32, P, P, P, P, P, P, P]),

@@ -324,13 +324,15 @@ k_env_sample_list(const float* __restrict__ row_cdf, const float* __restrict__ c
                     unsigned long long seed, unsigned long long offset, int bins_r, int bins_c, int block_pairs,
                     const int32_t* __restrict__ row_guide, const uint16_t* __restrict__ col_guide, int g_rows, int g_cols,
                     int32_t* __restrict__ cell, float* __restrict__ vis, int32_t* __restrict__ pair_ids,
-                    int32_t* __restrict__ n_active) {
+                    int32_t* __restrict__ n_active, const int32_t* __restrict__ m_dev) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sb_lds[];
+    if (m_dev) M = min(M, max(*m_dev, 0));        // device-side point count (tir_surface_compact): blocks past it have nothing to do
     uint16_t* const list = reinterpret_cast<uint16_t*>(sb_lds);                  // [block_pairs] local pair index, bin-major
     uint8_t* const keys = sb_lds + (size_t)block_pairs * 2;                      // [block_pairs] bin, 255 = masked
     __shared__ int s_hist[256], s_cursor[256], s_base;
     const int64_t n = (int64_t)M * Ns;
     const int64_t base = (int64_t)blockIdx.x * block_pairs;
+    if (base >= n) return;                        // (block-uniform)
     const int cnt = (int)min((int64_t)block_pairs, n - base);
     const int n_bins = bins_r * bins_c;
     s_hist[threadIdx.x] = 0;
@@ -399,9 +401,10 @@ k_relight_importance_cells(const float* __restrict__ normal, const float* __rest
                            const float* __restrict__ rays_d, const int32_t* __restrict__ cell,
                            const float* __restrict__ env_dir, const float* __restrict__ env_rgb,
                            const float* __restrict__ env_pdf, const float* __restrict__ vis, int M, int Ns,
-                           float* __restrict__ out) {
+                           float* __restrict__ out, const int32_t* __restrict__ m_dev) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (m_dev) M = min(M, max(*m_dev, 0));
     if (m >= M) return;
     float view[3] = {-rays_d[3 * (size_t)m], -rays_d[3 * (size_t)m + 1], -rays_d[3 * (size_t)m + 2]};
     normalize3(view[0], view[1], view[2], 1e-6f);
@@ -439,11 +442,19 @@ k_relight_importance_cells(const float* __restrict__ normal, const float* __rest
 // Environment_Light.get_light (models/relight_utils.py:191-205): bilinear lookup of the map at a direction,
 // F.grid_sample(align_corners=True, zero padding) of qx = -theta / pi, qy = 2 (acos(z) - 1e-6) / pi - 1
 __global__ void __launch_bounds__(256)
-k_env_lookup(const float* __restrict__ env_rgb, int H, int W, const float* __restrict__ dirs, int64_t n,
-             float* __restrict__ out) {
+k_env_lookup(const float* __restrict__ env_rgb, int H, int W, const float* __restrict__ dirs, int dir_stride, int64_t n,
+             float* __restrict__ out, int out_stride, const int32_t* __restrict__ slot, const float* __restrict__ fg) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float dx = dirs[3 * i], dy = dirs[3 * i + 1], dz = dirs[3 * i + 2];
+    if (slot) {        // tir_env_compose: a foreground row takes its relit colour (the index_put_ of scripts/relight_importance.py:166-171)
+        const int sl = slot[i];
+        if (sl >= 0) {
+            out[(size_t)out_stride * i] = fg[3 * (size_t)sl]; out[(size_t)out_stride * i + 1] = fg[3 * (size_t)sl + 1];
+            out[(size_t)out_stride * i + 2] = fg[3 * (size_t)sl + 2];
+            return;
+        }
+    }
+    const float dx = dirs[(size_t)dir_stride * i], dy = dirs[(size_t)dir_stride * i + 1], dz = dirs[(size_t)dir_stride * i + 2];
     // |dz| can exceed 1 by an ulp after the rotation / normalisation: acosf would return NaN and the (int) conversion of the
     // NaN row index is undefined; the reference has the same NaN at the source, reproducing it buys nothing
     const float phi = acosf(fminf(fmaxf(dz, -1.0f), 1.0f)) - 1e-6f;
@@ -464,7 +475,53 @@ k_env_lookup(const float* __restrict__ env_rgb, int H, int W, const float* __res
             c[0] = fmaf(w, p[0], c[0]); c[1] = fmaf(w, p[1], c[1]); c[2] = fmaf(w, p[2], c[2]);
         }
     }
-    out[3 * i] = c[0]; out[3 * i + 1] = c[1]; out[3 * i + 2] = c[2];
+    out[(size_t)out_stride * i] = c[0]; out[(size_t)out_stride * i + 1] = c[1]; out[(size_t)out_stride * i + 2] = c[2];
+}
+
+// The acc > thres rows of a chunk's primary maps as compacted surface-point arrays, in ascending row order (= the boolean-mask
+// indexing of scripts/relight_importance.py:99-113 without a host round trip): surf = o + depth d (:104), normal / albedo /
+// roughness / fresnel / ray direction rows, slot[row] = compacted index or -1, n_hit[0] = their count.  One block walks the
+// chunk in slabs of 1024 rows (ordered: wave ballots + a 16-entry scan per slab); rows >= n_hit of the outputs are not written.
+__global__ void __launch_bounds__(1024)
+k_surface_compact(const float* __restrict__ maps, const float* __restrict__ rays, int B, float acc_thres, float* __restrict__ surf,
+                  float* __restrict__ nrm, float* __restrict__ alb, float* __restrict__ rgh, float* __restrict__ fr,
+                  float* __restrict__ rd, int32_t* __restrict__ slot, int32_t* __restrict__ n_hit) {
+    __shared__ int s_wcnt[16];
+    __shared__ int s_run;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    for (int base = 0; base < B; base += 1024) {
+        const int row = base + threadIdx.x;
+        const float* mp = maps + (size_t)(row < B ? row : 0) * TIR_MAP_STRIDE;
+        const bool hit = row < B && mp[14] > acc_thres;
+        const unsigned long long mask = __ballot(hit);
+        if (lane == 0) s_wcnt[wv] = __popcll(mask);
+        __syncthreads();
+        int before = s_run;
+        for (int q = 0; q < wv; ++q) before += s_wcnt[q];
+        if (hit) {
+            const int sl = before + __popcll(mask & ((1ull << lane) - 1ull));
+            const float* r = rays + 6 * (size_t)row;
+            const float depth = mp[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                surf[3 * (size_t)sl + a] = add_rn(r[a], mul_rn(depth, r[3 + a]));
+                nrm[3 * (size_t)sl + a] = mp[4 + a];
+                alb[3 * (size_t)sl + a] = mp[7 + a];
+                fr[3 * (size_t)sl + a] = mp[11 + a];
+                rd[3 * (size_t)sl + a] = r[3 + a];
+            }
+            rgh[sl] = mp[10];
+            slot[row] = sl;
+        } else if (row < B) {
+            slot[row] = -1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { int t = 0; for (int q = 0; q < 16; ++q) t += s_wcnt[q]; s_run += t; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) n_hit[0] = s_run;
 }
 
 // get_light_rgbs for light_kind == 'pixel' (models/tensorBase_rotated_lights.py:585-605): the environment map is a learnable
@@ -654,11 +711,11 @@ extern "C" int tir_env_sample_setup(const float* row_cdf, const float* col_cdf, 
     return TIR_OK;
 }
 
-extern "C" int tir_env_sample_setup_list(const float* row_cdf, const float* col_cdf, int32_t H, int32_t W, const float* env_dir,
+extern "C" int tir_env_sample_setup_list_n(const float* row_cdf, const float* col_cdf, int32_t H, int32_t W, const float* env_dir,
                                            int32_t dir_stride, const float* normal, int32_t M, int32_t Ns, uint64_t seed, uint64_t offset,
                                            int32_t bins_r, int32_t bins_c, int32_t block_pairs, const int32_t* row_guide,
                                            const uint16_t* col_guide, int32_t guide_rows, int32_t guide_cols, int32_t* cell,
-                                           float* vis, int32_t* pair_ids, int32_t* n_active, void* stream) {
+                                           float* vis, int32_t* pair_ids, int32_t* n_active, const int32_t* m_dev, void* stream) {
     if (M < 0 || Ns <= 0 || H <= 0 || W <= 0 || bins_r <= 0 || bins_c <= 0 || dir_stride < 3) return TIR_ERR_ARG;
     if ((row_guide == nullptr) != (col_guide == nullptr)) return TIR_ERR_ARG;
     if (row_guide) {        // power-of-two guide sizes (exact k / G thresholds), column indices in 16 bits
@@ -675,9 +732,18 @@ extern "C" int tir_env_sample_setup_list(const float* row_cdf, const float* col_
     hipLaunchKernelGGL(k_env_sample_list, dim3((unsigned)((n + block_pairs - 1) / block_pairs)), dim3(256), lds,
                        tir_stream(stream), row_cdf, col_cdf, H, W, env_dir, dir_stride, normal, M, Ns, (unsigned long long)seed,
                        (unsigned long long)offset, bins_r, bins_c, block_pairs, row_guide, col_guide, guide_rows, guide_cols, cell,
-                       vis, pair_ids, n_active);
+                       vis, pair_ids, n_active, m_dev);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
+}
+
+extern "C" int tir_env_sample_setup_list(const float* row_cdf, const float* col_cdf, int32_t H, int32_t W, const float* env_dir,
+                                         int32_t dir_stride, const float* normal, int32_t M, int32_t Ns, uint64_t seed, uint64_t offset,
+                                         int32_t bins_r, int32_t bins_c, int32_t block_pairs, const int32_t* row_guide,
+                                         const uint16_t* col_guide, int32_t guide_rows, int32_t guide_cols, int32_t* cell,
+                                         float* vis, int32_t* pair_ids, int32_t* n_active, void* stream) {
+    return tir_env_sample_setup_list_n(row_cdf, col_cdf, H, W, env_dir, dir_stride, normal, M, Ns, seed, offset, bins_r, bins_c, block_pairs,
+                                       row_guide, col_guide, guide_rows, guide_cols, cell, vis, pair_ids, n_active, nullptr, stream);
 }
 
 extern "C" int tir_relight_importance_cells(const float* normal, const float* albedo, const float* rough,
@@ -689,7 +755,21 @@ extern "C" int tir_relight_importance_cells(const float* normal, const float* al
     if (!normal || !albedo || !rough || !fresnel || !rays_d || !cell || !env_dir || !env_rgb || !env_pdf || !vis || !out_rgb)
         return TIR_ERR_ARG;
     hipLaunchKernelGGL(k_relight_importance_cells<false>, dim3((M + 3) / 4), dim3(256), 0, tir_stream(stream), normal, albedo,
-                       rough, fresnel, rays_d, cell, env_dir, env_rgb, env_pdf, vis, M, Ns, out_rgb);
+                       rough, fresnel, rays_d, cell, env_dir, env_rgb, env_pdf, vis, M, Ns, out_rgb, nullptr);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_relight_importance_cells_packed_n(const float* normal, const float* albedo, const float* rough,
+                                                     const float* fresnel, const float* rays_d, const int32_t* cell,
+                                                     const float* env_cell, const float* vis, int32_t M, int32_t Ns,
+                                                     float* out_rgb, const int32_t* m_dev, void* stream) {
+    if (M < 0 || Ns <= 0) return TIR_ERR_ARG;
+    if (M == 0) return TIR_OK;
+    if (!normal || !albedo || !rough || !fresnel || !rays_d || !cell || !env_cell || !vis || !out_rgb) return TIR_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(env_cell) % 16 != 0) return TIR_ERR_ARG;
+    hipLaunchKernelGGL(k_relight_importance_cells<true>, dim3((M + 3) / 4), dim3(256), 0, tir_stream(stream), normal, albedo,
+                       rough, fresnel, rays_d, cell, env_cell, nullptr, nullptr, vis, M, Ns, out_rgb, m_dev);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }
@@ -698,14 +778,7 @@ extern "C" int tir_relight_importance_cells_packed(const float* normal, const fl
                                                    const float* fresnel, const float* rays_d, const int32_t* cell,
                                                    const float* env_cell, const float* vis, int32_t M, int32_t Ns,
                                                    float* out_rgb, void* stream) {
-    if (M < 0 || Ns <= 0) return TIR_ERR_ARG;
-    if (M == 0) return TIR_OK;
-    if (!normal || !albedo || !rough || !fresnel || !rays_d || !cell || !env_cell || !vis || !out_rgb) return TIR_ERR_ARG;
-    if (reinterpret_cast<uintptr_t>(env_cell) % 16 != 0) return TIR_ERR_ARG;
-    hipLaunchKernelGGL(k_relight_importance_cells<true>, dim3((M + 3) / 4), dim3(256), 0, tir_stream(stream), normal, albedo,
-                       rough, fresnel, rays_d, cell, env_cell, nullptr, nullptr, vis, M, Ns, out_rgb);
-    TIR_CHECK_LAUNCH();
-    return TIR_OK;
+    return tir_relight_importance_cells_packed_n(normal, albedo, rough, fresnel, rays_d, cell, env_cell, vis, M, Ns, out_rgb, nullptr, stream);
 }
 
 extern "C" int tir_env_lookup(const float* env_rgb, int32_t H, int32_t W, const float* dirs, int64_t n, float* out,
@@ -714,7 +787,29 @@ extern "C" int tir_env_lookup(const float* env_rgb, int32_t H, int32_t W, const 
     if (n == 0) return TIR_OK;
     if (!env_rgb || !dirs || !out) return TIR_ERR_ARG;
     hipLaunchKernelGGL(k_env_lookup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tir_stream(stream), env_rgb, H, W,
-                       dirs, n, out);
+                       dirs, 3, n, out, 3, nullptr, nullptr);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_env_compose(const float* env_rgb, int32_t H, int32_t W, const float* dirs, int32_t dir_stride, int64_t n,
+                               const int32_t* slot, const float* fg_rgb, float* out, int32_t out_stride, void* stream) {
+    if (n < 0 || H <= 0 || W <= 0 || dir_stride < 3 || out_stride < 3) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    if (!env_rgb || !dirs || !out || !slot || !fg_rgb) return TIR_ERR_ARG;
+    hipLaunchKernelGGL(k_env_lookup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tir_stream(stream), env_rgb, H, W,
+                       dirs, dir_stride, n, out, out_stride, slot, fg_rgb);
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
+extern "C" int tir_surface_compact(const float* maps, const float* rays, int32_t B, float acc_thres, float* surf, float* normal,
+                                   float* albedo, float* rough, float* fresnel, float* rays_d, int32_t* slot, int32_t* n_hit,
+                                   void* stream) {
+    if (B < 0) return TIR_ERR_ARG;
+    if (!n_hit || (B > 0 && (!maps || !rays || !surf || !normal || !albedo || !rough || !fresnel || !rays_d || !slot))) return TIR_ERR_ARG;
+    hipLaunchKernelGGL(k_surface_compact, dim3(1), dim3(1024), 0, tir_stream(stream), maps, rays, B, acc_thres, surf, normal, albedo,
+                       rough, fresnel, rays_d, slot, n_hit);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

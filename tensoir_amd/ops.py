@@ -517,10 +517,17 @@ if _IND not in ("auto", "f16", "full"):
 SECONDARY_MLP_IMPL = "f16" if _IND != "full" else None       # None | "f16" | "bf16" (probe only) | "bf16x3"
 SECONDARY_APP_IMPL = "h16" if _IND != "full" else None       # None | "h16"
 INDIRECT_GUARD = _IND == "auto"        # False: the settings above apply unconditionally (f16: the caller vouches for range and precision)
-# Limits of the self-check (differences of the decoded radiance, f16 path - full path, over the probe records; calibrated on
-# trained and adversarially scaled fields so that passing implies |d rgb_with_brdf_map| < 2.5e-5, a quarter of the 1e-4
-# budget: profiles/r05_precision_sweep.json) and of the range guard (largest finite fp16 = 65504).
-INDIRECT_PROBE = {"records": 32768, "interval": 64, "bias": 4e-6, "rms": 4e-5, "max": 1e-3, "range": 6.0e4}
+# The self-check (relight._probe_indirect) measures, over the probe records, the signed mean ("bias", max over the colour
+# channels), the rms and the max of (f16 path - full path) of the decoded radiance.  On rgb_with_brdf_map the bias survives the
+# averaging over a ray's records and the light directions, the random part shrinks: across the scaling sweep of
+# tests/precision_cases.py (decoder weights x1..x4, planes x1..x64, light rows x8) the map's max error was 0.45 bias + 0.2 rms
+# within 15 % (profiles/r05_precision_sweep.json: 3.3e-6 as initialised, 3.0e-5 with the decoder weights doubled, 2.0e-4 with
+# x4 -- unguarded fp16 leaves the 1e-4 budget there).  The policy keeps the f16 kernels while
+#     w_bias * bias + w_rms * rms <= limit   and   max <= max
+# i.e. while the estimated map error stays under HALF of the 2.5e-5 the policy promises against the full-precision kernels
+# (a quarter of the 1e-4 budget; the factor two covers scenes darker than the calibration scenes, where the sRGB curve
+# amplifies more).  range: the largest |product| the range guard accepts (largest finite fp16 = 65504).
+INDIRECT_PROBE = {"records": 32768, "interval": 64, "w_bias": 0.5, "w_rms": 0.25, "limit": 1.25e-5, "max": 2e-3, "range": 6.0e4}
 
 
 # TENSOIR_FUSED_INDIRECT=0: gather and decoder of the secondary-ray records as two launches (tir_vm_app_fwd_h16 +
@@ -969,10 +976,11 @@ def cdf_guide_tables(row_cdf, col_cdf):
     return rg.contiguous(), packed.contiguous(), gr, gc
 
 
-def env_sample_setup_list(row_cdf, col_cdf, env_dir, normal, n_samples, seed, offset, bins=(1, 1), block_pairs=256, guide=None):
-    """tir_env_sample_setup_list: cells of every (point, sample) + the list of the pairs that pass the cosine mask.
+def env_sample_setup_list(row_cdf, col_cdf, env_dir, normal, n_samples, seed, offset, bins=(1, 1), block_pairs=256, guide=None,
+                          m_dev=None):
+    """tir_env_sample_setup_list[_n]: cells of every (point, sample) + the list of the pairs that pass the cosine mask.
     Returns cell [M, Ns] int32, vis [M, Ns] fp32 (0 where masked, the rest for the march to fill), pair_ids [M*Ns] int32,
-    n_active [1] int32 (device)."""
+    n_active [1] int32 (device).  m_dev (int32 device scalar): only the first min(M, m_dev) points exist."""
     H, W = col_cdf.shape
     normal = f32(normal, "normal", 3)
     M, dev = normal.shape[0], normal.device
@@ -983,12 +991,12 @@ def env_sample_setup_list(row_cdf, col_cdf, env_dir, normal, n_samples, seed, of
     stride = int(env_dir.shape[-1])                    # [H*W, 3] directions or the [H*W, 8] records of pack_env_cells
     if stride not in (3, 8):
         raise ValueError(f"env_dir: expected [H*W, 3] directions or [H*W, 8] cell records, got {tuple(env_dir.shape)}")
-    _call("tir_env_sample_setup_list", _ptr(f32(row_cdf, "row_cdf")), _ptr(f32(col_cdf, "col_cdf")), H, W,
+    _call("tir_env_sample_setup_list_n", _ptr(f32(row_cdf, "row_cdf")), _ptr(f32(col_cdf, "col_cdf")), H, W,
           _ptr(f32(env_dir, "env_dir", stride)), stride, _ptr(normal), M, int(n_samples), int(seed) & (2 ** 64 - 1),
           int(offset) & (2 ** 64 - 1), int(bins[0]), int(bins[1]), int(block_pairs),
           *((None, None, 0, 0) if guide is None else (_ptr(_req(guide[0], torch.int32, "row_guide")),
                                                       _ptr(_req(guide[1], torch.int32, "col_guide")), int(guide[2]), int(guide[3]))),
-          _ptr(cell), _ptr(vis), _ptr(pair_ids), _ptr(n_active), _stream())
+          _ptr(cell), _ptr(vis), _ptr(pair_ids), _ptr(n_active), _ptr(m_dev), _stream())
     return cell, vis, pair_ids, n_active
 
 
@@ -998,9 +1006,10 @@ def pack_env_cells(env_dir, env_rgb, env_pdf):
     return torch.cat([d, p, c, torch.zeros_like(p)], dim=1).contiguous()
 
 
-def relight_importance_cells(normal, albedo, rough, fresnel, rays_d, cell, env_dir, env_rgb, env_pdf, vis, env_cell=None):
+def relight_importance_cells(normal, albedo, rough, fresnel, rays_d, cell, env_dir, env_rgb, env_pdf, vis, env_cell=None, m_dev=None):
     """BRDF x radiance x cosine / pdf mean over a point's samples -> sRGB (scripts/relight_importance.py:133-160).  env_cell
-    (pack_env_cells of the same three tables): one 32-byte record per sample instead of three gathers; same result."""
+    (pack_env_cells of the same three tables): one 32-byte record per sample instead of three gathers; same result.
+    m_dev (int32 device scalar, packed form only): only the first min(M, m_dev) points exist (rows beyond: not written)."""
     normal, albedo = f32(normal, "normal", 3), f32(albedo, "albedo", 3)
     rough = f32(rough, "roughness").view(-1)
     fresnel, rays_d = f32(fresnel, "fresnel", 3), f32(rays_d, "rays_d", 3)
@@ -1009,9 +1018,11 @@ def relight_importance_cells(normal, albedo, rough, fresnel, rays_d, cell, env_d
     vis = f32(vis, "vis").view(M, Ns)
     out = torch.empty((M, 3), dtype=torch.float32, device=normal.device)
     if env_cell is not None:
-        _call("tir_relight_importance_cells_packed", _ptr(normal), _ptr(albedo), _ptr(rough), _ptr(fresnel), _ptr(rays_d), _ptr(cell),
-              _ptr(f32(env_cell, "env_cell", 8)), _ptr(vis), M, Ns, _ptr(out), _stream())
+        _call("tir_relight_importance_cells_packed_n", _ptr(normal), _ptr(albedo), _ptr(rough), _ptr(fresnel), _ptr(rays_d), _ptr(cell),
+              _ptr(f32(env_cell, "env_cell", 8)), _ptr(vis), M, Ns, _ptr(out), _ptr(m_dev), _stream())
         return out
+    if m_dev is not None:
+        raise ValueError("relight_importance_cells: a device-side point count needs the packed cell records (env_cell)")
     _call("tir_relight_importance_cells", _ptr(normal), _ptr(albedo), _ptr(rough), _ptr(fresnel), _ptr(rays_d), _ptr(cell),
           _ptr(f32(env_dir, "env_dir", 3)), _ptr(f32(env_rgb, "env_rgb", 3)), _ptr(f32(env_pdf, "env_pdf")), _ptr(vis),
           M, Ns, _ptr(out), _stream())
@@ -1025,6 +1036,33 @@ def env_lookup(env_rgb, dirs):
     dirs = f32(dirs, "dirs", 3).view(-1, 3)
     out = torch.empty_like(dirs)
     _call("tir_env_lookup", _ptr(env_rgb), H, W, _ptr(dirs), dirs.shape[0], _ptr(out), _stream())
+    return out
+
+
+def surface_compact(maps, rays, acc_thres=0.5):
+    """tir_surface_compact: the acc > acc_thres rows of a chunk's primary maps [B, 20] as compacted surface-point arrays
+    (capacity B, ascending row order) -> dict(surf, normal, albedo, rough, fresnel, rays_d, slot [B] int32, n_hit [1] int32)."""
+    maps = f32(maps, "maps", MAP_STRIDE)
+    rays = f32(rays, "rays", 6)
+    B, dev = rays.shape[0], rays.device
+    v3 = lambda: torch.empty((B, 3), dtype=torch.float32, device=dev)
+    out = {"surf": v3(), "normal": v3(), "albedo": v3(), "rough": torch.empty((B,), dtype=torch.float32, device=dev), "fresnel": v3(),
+           "rays_d": v3(), "slot": torch.empty((B,), dtype=torch.int32, device=dev), "n_hit": torch.empty((1,), dtype=torch.int32, device=dev)}
+    _call("tir_surface_compact", _ptr(maps), _ptr(rays), B, float(acc_thres), _ptr(out["surf"]), _ptr(out["normal"]), _ptr(out["albedo"]),
+          _ptr(out["rough"]), _ptr(out["fresnel"]), _ptr(out["rays_d"]), _ptr(out["slot"]), _ptr(out["n_hit"]), _stream())
+    return out
+
+
+def env_compose(env_rgb, rays, slot, fg_rgb, out, col=0):
+    """tir_env_compose: out[:, col:col+3] = the relit colour fg_rgb[slot[i]] of a foreground row, the background lookup of the
+    map at the ray direction rays[i, 3:6] otherwise.  out [B, >= col + 3] fp32, written in place."""
+    env_rgb = f32(env_rgb, "env_rgb", 3)
+    rays = f32(rays, "rays", 6)
+    B = rays.shape[0]
+    if out.dtype != torch.float32 or not out.is_contiguous() or out.shape[0] != B or out.shape[1] < col + 3:
+        raise ValueError("env_compose: out must be a contiguous fp32 [B, >= col + 3] tensor")
+    _call("tir_env_compose", _ptr(env_rgb), env_rgb.shape[0], env_rgb.shape[1], C.c_void_p(rays.data_ptr() + 12), 6, B,
+          _ptr(i32(slot, "slot")), _ptr(f32(fg_rgb, "fg_rgb", 3)), C.c_void_p(out.data_ptr() + 4 * col), int(out.shape[1]), _stream())
     return out
 
 

@@ -119,8 +119,9 @@ def _probe_indirect(tensoIR, f, rgb, n_valid, rec_xyz, light_idx, rec_ray, light
                               dir_map, n_dirs, None, full=True)
     d = (rgb[sel] - ref).double()
     v = torch.stack([d.mean(0).abs().max(), d.pow(2).mean().sqrt(), d.abs().max(), ref.double().pow(2).mean().sqrt()]).tolist()
-    stats = {"records": int(sel.numel()), "of": n_valid, "bias": v[0], "rms": v[1], "max": v[2], "radiance_rms": v[3]}
-    ok = v[0] <= lim["bias"] and v[1] <= lim["rms"] and v[2] <= lim["max"]        # (NaN fails)
+    est = lim["w_bias"] * v[0] + lim["w_rms"] * v[1]          # estimated max error on rgb_with_brdf_map (ops.INDIRECT_PROBE)
+    stats = {"records": int(sel.numel()), "of": n_valid, "bias": v[0], "rms": v[1], "max": v[2], "radiance_rms": v[3], "estimate": est}
+    ok = est <= lim["limit"] and v[2] <= lim["max"]            # (NaN fails)
     _indirect_state(tensoIR)["probes"] += 1
     return bool(ok), stats
 
@@ -463,7 +464,7 @@ class Environment_Light:
                                     torch.cuda.initial_seed(), self._draws)
 
     @torch.no_grad()
-    def sample_cells_listed(self, light_name, normal, num_samples, bins=(1, 1), block_pairs=256):
+    def sample_cells_listed(self, light_name, normal, num_samples, bins=(1, 1), block_pairs=256, m_dev=None):
         """sample_cells with the same draws (same Philox counters) + the compacted list of the unmasked pairs, optionally
         direction-binned inside blocks of `block_pairs` pairs (tir_env_sample_setup_list).  Returns (cell [M, Ns],
         vis [M, Ns] with the masked pairs' zeros, pair_ids [M * Ns], n_active [1] on the device)."""
@@ -472,7 +473,7 @@ class Environment_Light:
         return ops.env_sample_setup_list(self.hdr_row_cdf[light_name], self.hdr_col_cdf[light_name],
                                            self.hdr_dir[light_name].view(-1, 3) if rec is None else rec, normal, num_samples,
                                            torch.cuda.initial_seed(), self._draws, bins, block_pairs,
-                                           self.hdr_cdf_guide.get(light_name))
+                                           self.hdr_cdf_guide.get(light_name), m_dev)
 
     def cell_records(self, light_name):
         """[H*W, 8] records {direction, pdf_return, radiance, 0} of a map (ops.pack_env_cells), built on first use: the
@@ -526,23 +527,29 @@ def relight_with_envmap(tensoIR, surface_xyz, normal, albedo, roughness, fresnel
 
 @torch.no_grad()
 def relight_importance_sampled(tensoIR, env, light_name, surface_xyz, normal, albedo, roughness, fresnel, rays_d,
-                               num_samples=512, nSample=96, vis_near=0.05, vis_far=1.5):
+                               num_samples=512, nSample=96, vis_near=0.05, vis_far=1.5, m_dev=None):
     """The loop body of scripts/relight_importance.py:119-170 for one environment map, entirely on the device:
     importance sampling + cosine mask (tir_env_sample_setup) -> visibility march of the unmasked (point, cell) pairs with
     the map's direction table as `dirs` and the cell index as `dir_map` -> BRDF x radiance x cosine / pdf mean -> sRGB
-    (tir_relight_importance_cells).  Per sample 5 bytes of bookkeeping instead of the reference's 28 + masks."""
+    (tir_relight_importance_cells).  Per sample 5 bytes of bookkeeping instead of the reference's 28 + masks.
+    m_dev (int32 device scalar): the arrays have capacity M rows of which only the first m_dev are surface points
+    (ops.surface_compact); rows beyond are neither sampled nor marched, their output rows are left unwritten."""
     dev = surface_xyz.device
     normal = normal.to(torch.float32).contiguous()
     M = normal.shape[0]
     if M == 0:
-        return torch.zeros((0, 3), dtype=torch.float32, device=dev)
+        env._draws += 1          # a call consumes one draw counter whatever M is: the device-compacted chunk call (relight_chunk)
+        return torch.zeros((0, 3), dtype=torch.float32, device=dev)      # cannot know that a chunk is all background
     order, bins, block_pairs = ops.c5_pair_order()
+    if m_dev is not None and (order == "mask" or env.cell_records(light_name) is None):
+        raise ops._lib.TensoirHipError("a device-side surface-point count needs the pair-list sampler and the packed cell records "
+                                       "(TENSOIR_C5_PAIRS != mask, TENSOIR_ENV_RECORDS != 0)")
     if order == "mask":
         cell, active = env.sample_cells(light_name, normal, num_samples)
         listed = {}
     else:
         # :127-131 query visibility for the unmasked pairs only: so does the march, from a compacted list
-        cell, vis0, pair_ids, n_active = env.sample_cells_listed(light_name, normal, num_samples, bins, block_pairs)
+        cell, vis0, pair_ids, n_active = env.sample_cells_listed(light_name, normal, num_samples, bins, block_pairs, m_dev)
         active = None
         listed = dict(ray_ids=pair_ids, n_ids_dev=n_active, vis=vis0.view(-1))
     key = ("orgmap", M, num_samples, str(dev))
@@ -560,4 +567,28 @@ def relight_importance_sampled(tensoIR, env, light_name, surface_xyz, normal, al
                                     tensoIR.march_t_stop, False, 0, False, **listed)
     return ops.relight_importance_cells(normal, albedo, roughness, fresnel, rays_d, cell, env_dir,
                                         env.hdr_rgbs[light_name].view(-1, 3), env.hdr_pdf_return[light_name].view(-1),
-                                        vis.view(M, num_samples), env_cell=env.cell_records(light_name))
+                                        vis.view(M, num_samples), env_cell=env.cell_records(light_name), m_dev=m_dev)
+
+
+@torch.no_grad()
+def relight_chunk(tensoIR, env, light_names, rays, light_idx, num_samples=512, nSample=96, vis_near=0.05, vis_far=1.5,
+                  N_samples=-1, out=None):
+    """One chunk of scripts/relight_importance.py:93-185 for ALL environment maps without a host round trip: primary pass ->
+    the acc > 0.5 rows compacted ON THE DEVICE (the script's boolean-mask indexing, :99-113, is a synchronisation per chunk
+    plus ~12 indexing launches) -> per map: importance sampling, visibility march and BRDF integration bounded by the
+    device-side point count -> relit colour where a ray hit, background lookup elsewhere (:166-171), written side by side into
+    ONE [B, 3 * n_maps] buffer.  Same Philox counters per (point, sample) as the host-compacted sequence: identical colours.
+    Returns (out [B, 3 n_maps], primary-pass tuple, compacted surface dict)."""
+    dev = rays.device
+    rays = rays.to(torch.float32).contiguous()
+    B = rays.shape[0]
+    names = list(light_names)
+    prim, maps = tensoIR(rays, light_idx, N_samples=N_samples, _return_maps=True)
+    c = ops.surface_compact(maps, rays, 0.5)
+    if out is None:
+        out = torch.empty((B, 3 * max(len(names), 1)), dtype=torch.float32, device=dev)
+    for i, name in enumerate(names):
+        rgb = relight_importance_sampled(tensoIR, env, name, c["surf"], c["normal"], c["albedo"], c["rough"], c["fresnel"], c["rays_d"],
+                                         num_samples, nSample, vis_near, vis_far, m_dev=c["n_hit"])
+        ops.env_compose(env.hdr_rgbs[name], rays, c["slot"], rgb, out, 3 * i)
+    return out, prim, c

@@ -89,7 +89,8 @@ def trained_case(r, n_rays=2048):
     S = int(m.nSamples)
     noise = torch.randn(rays.shape[0], S, 3, generator=torch.Generator().manual_seed(5))
     out, res = three_policies(m, rays, lidx, noise, S)
-    ckpt = {"kwargs": m.get_kwargs(), "state_dict": {k: v.detach().cpu() for k, v in m.state_dict().items()}}
+    to_cpu = lambda v: v.detach().cpu() if torch.is_tensor(v) else v
+    ckpt = {"kwargs": {k: to_cpu(v) for k, v in m.get_kwargs().items()}, "state_dict": {k: to_cpu(v) for k, v in m.state_dict().items()}}
     sc = scene_from_model(ckpt, m, 8, 16)
     rep = oracle_compare(sc, out, res["auto"], rays, lidx, noise, S, slice(0, rays.shape[0], 2))
     return res, rep

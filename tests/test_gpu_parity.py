@@ -973,6 +973,47 @@ def test_c5_pair_list_orders_are_bit_identical(full3, monkeypatch, ns):
 
 
 @torch.no_grad()
+def test_c5_chunk_call_is_bit_identical_to_host_masking(full3):
+    """relight.relight_chunk (device-side compaction of the acc > 0.5 rows, kernels bounded by the device-side point count,
+    colours and background composed into one buffer: no host round trip) against the script's own sequence around
+    relight_importance_sampled -- boolean-mask indexing, per-map relight, get_light + index_put_ (scripts/relight_importance.py:
+    99-113, :166-171) -- on a chunk with hit and background rows, two maps: bit-identical, also for an all-background chunk."""
+    from tensoir_amd import ops, relight, synth
+    m = full3.model
+    env = relight.Environment_Light("synthetic:h=64,w=128", device="cuda")
+    names = list(env.hdr_rgbs)[:2]
+    rays = synth.make_rays(48, 48, narrow=1.0).cuda()            # full field of view: about half of the rays miss the object
+    lidx = torch.zeros(rays.shape[0], 1, dtype=torch.int32, device="cuda")
+    for case in ("mixed", "background"):
+        r = rays.clone()
+        if case == "background":
+            r[:, 3:] = torch.tensor([0.0, 1.0, 0.0], device="cuda")          # every ray leaves the box sideways
+        draws = env._draws
+        out = m(r, lidx, N_samples=-1)
+        depth, normal, albedo, rough, fres, acc = out[1:7]
+        mask = acc > 0.5
+        if case == "mixed":
+            assert 100 < int(mask.sum()) < r.shape[0] - 100
+        else:
+            assert int(mask.sum()) == 0
+        surf = (r[:, :3] + depth.unsqueeze(-1) * r[:, 3:])[mask]
+        rows = mask.nonzero()[:, 0]
+        want = []
+        for name in names:
+            rgb = relight.relight_importance_sampled(m, env, name, surf, normal[mask], albedo[mask], rough[mask], fres[mask], r[:, 3:][mask],
+                                                     num_samples=128)
+            want.append(env.get_light(name, r[:, 3:]).index_put_((rows,), rgb))
+        want = torch.cat(want, dim=1)
+        env._draws = draws
+        got, prim, c = relight.relight_chunk(m, env, names, r, lidx, num_samples=128)
+        assert int(c["n_hit"].item()) == int(mask.sum())
+        assert torch.equal(c["slot"][mask].long(), torch.arange(int(mask.sum()), device="cuda")) and bool((c["slot"][~mask] == -1).all())
+        assert torch.equal(c["surf"][:surf.shape[0]], surf)
+        assert torch.equal(got, want), case
+        assert torch.equal(prim[6], acc)
+
+
+@torch.no_grad()
 def test_graphed_chunk_renderer_matches_eager_image(env):
     """render_sharded through GraphedChunkRenderer (one captured graph replayed per full chunk, capacity checks
     deferred to one validate() per image, ragged tail eager) gives the image of the eager per-chunk renderer, also
