@@ -96,6 +96,29 @@ def test_two_ranks_rccl(tmp_path):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL with one rank per GPU)")
+@pytest.mark.parametrize("workload", ["batch", "image"])
+def test_two_ranks_rccl_bench_path(workload):
+    """The first multi-GPU box exercises the driver's command too: `bench.py --gpus 2` (self-launched ranks, RCCL) prints one
+    JSON line of a 2-rank job -- rccl_version set, world_size 2, one per-rank time each."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--workload", workload]
+    if workload == "batch":
+        cmd += ["--no-side-workloads", "--no-sharp-scene", "--no-exact-pass", "--boundary-calls", "3", "--sustained-steps", "5", "--profile-steps", "1"]
+    else:
+        cmd += ["--image-side", "256"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="8")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=800, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["value"] > 0
+    assert line.get("rccl_version") or line.get("backend") == "nccl"
+    per_rank = line.get("per_rank_ms_per_step") or line.get("per_rank_render_ms")
+    assert per_rank is not None and len(per_rank) == 2
+
+
+@pytest.mark.timeout(900)
 def test_two_ranks_share_one_gpu_gloo(tmp_path):
     assert torch.cuda.is_available()
     res = _launch("gloo", tmp_path, shared=True)
