@@ -72,9 +72,25 @@ namespace tir {
 
 // ---- exactly-rounded fp32 steps where the reference's decision points (floor / compare) depend on
 // them; everything else may contract to FMA.
-__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
-__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+// `#pragma clang fp contract(off)` inside each helper, NOT __fmul_rn / __fadd_rn: hipcc lowers those intrinsics to plain
+// `a * b` / `a + b` that still carry the `contract` flag, and add_rn(o, mul_rn(d, z)) became ONE v_fma_f32 (rounds 1-4 shipped
+// that).  The reference rounds the product and the sum separately (rays_o + rays_d * z: two ATen kernels,
+// models/tensorBase_rotated_lights.py:722); a sample position that differs in its last bit flips the in-box test of a sample
+// sitting exactly on the box -- after shrink() the box IS aligned with voxel boundaries and every ray's first sample sits on
+// it -- and moved rendered maps of a trained checkpoint by up to 1.6e-3 (profiles/r05_fma_contraction.json).  An operation
+// without the flag cannot be fused with its neighbours, whatever the caller's contraction mode is.
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
 
 // normalize_coord: (x - aabb0) * invaabbSize - 1   (models/tensorBase_rotated_lights.py:640-641)
 __device__ __forceinline__ float norm_coord(float x, float mn, float inv) {
