@@ -60,6 +60,8 @@ static inline bool tir_app_index_ok(const TirField* f) {
     for (int i = 0; i < 3; ++i)
         for (int j = i + 1; j < 3; ++j)
             if ((int64_t)f->grid[i] * f->grid[j] * f->n_acomp >= ((int64_t)1 << 31)) return false;
+    for (int i = 0; i < 3; ++i)      // 24-bit index multiplies: every index and every row pitch in elements below 2^24
+        if ((int64_t)f->grid[i] * f->n_acomp >= (1 << 24)) return false;
     return true;
 }
 
@@ -400,6 +402,32 @@ __device__ __forceinline__ uint4 h16_chunk(const uint4& a, const uint4& b, const
         ll = fma_mix_lo(G[p], l1, ll);   lh = fma_mix_hi(G[p], l1, lh);
         const tir_f2 v2 = {(pl * ll) * lr[2 * p], (ph * lh) * lr[2 * p + 1]};
         pk[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, tir_h2));
+    }
+    return make_uint4(pk[0], pk[1], pk[2], pk[3]);
+}
+
+// The same chunk entirely on the PACKED fp16 pipe (v_pk_mul_f16 / v_pk_fma_f16: two channels per instruction, fp16 rounding after
+// every step instead of once): 8 VALU instructions per channel pair instead of 15 (12 v_fma_mix_f32 + 2 v_pk_mul_f32 + 1
+// conversion) -- the gather arithmetic is half of the fused indirect kernel's VALU work.  Weights and light row arrive as fp16
+// pairs.  ~2x the rounding error of h16_chunk on a product (measured on the maps: profiles/r05_fused_pk16.json); the indirect
+// policy's self-check covers it like every other fp16 effect.  Range: (plane x line) is formed BEFORE the light row is applied,
+// so the range guard bounds max|plane| max|line| max(1, max|light row|) (ops.HalfRange).
+__device__ __forceinline__ uint4 h16_chunk_pk(const uint4& a, const uint4& b, const uint4& c, const uint4& d, const uint4& e,
+                                              const uint4& g, tir_h2 w00, tir_h2 w01, tir_h2 w10, tir_h2 w11, tir_h2 l0, tir_h2 l1,
+                                              const uint4& lr) {
+    const unsigned A[4] = {a.x, a.y, a.z, a.w}, B[4] = {b.x, b.y, b.z, b.w}, Cc[4] = {c.x, c.y, c.z, c.w}, D[4] = {d.x, d.y, d.z, d.w};
+    const unsigned E[4] = {e.x, e.y, e.z, e.w}, G[4] = {g.x, g.y, g.z, g.w}, LR[4] = {lr.x, lr.y, lr.z, lr.w};
+    unsigned pk[4];
+    auto H = [](unsigned u) { return __builtin_bit_cast(tir_h2, u); };
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        tir_h2 pl = H(A[p]) * w00;
+        pl = __builtin_elementwise_fma(H(B[p]), w01, pl);
+        pl = __builtin_elementwise_fma(H(Cc[p]), w10, pl);
+        pl = __builtin_elementwise_fma(H(D[p]), w11, pl);
+        tir_h2 ll = H(E[p]) * l0;
+        ll = __builtin_elementwise_fma(H(G[p]), l1, ll);
+        pk[p] = __builtin_bit_cast(unsigned, (pl * ll) * H(LR[p]));
     }
     return make_uint4(pk[0], pk[1], pk[2], pk[3]);
 }

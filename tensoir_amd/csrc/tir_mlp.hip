@@ -810,10 +810,15 @@ __device__ __forceinline__ float fus_input(const float (&fo)[16]) {
         const float kr = rintf(fo[j] * c_hi);
         float t = fmaf(fo[j], c_hi, -kr);
         t = fmaf(fo[j], c_lo, t);
-        if constexpr (kind == 0) return __builtin_amdgcn_sinf(t);
-        else if constexpr (kind == 1) return __builtin_amdgcn_sinf(t + t);
-        else if constexpr (kind == 2) return __builtin_amdgcn_sinf(t + 0.25f);
-        else return __builtin_amdgcn_sinf(fmaf(t, 2.0f, 0.25f));
+        // sin f and cos f on the transcendental unit (quarter rate), the double angle by the addition theorems on the full-rate
+        // FMA pipe: sin 2f = 2 sin f cos f, cos 2f = 1 - 2 sin^2 f (28 v_sin_f32 per record instead of 56).  The values are
+        // rounded to fp16 operands (2^-11) next: the ~2e-7 the identities add is far below that.  (CSE shares s / c between
+        // the slots of a feature.)
+        const float sn = __builtin_amdgcn_sinf(t), cs = __builtin_amdgcn_sinf(t + 0.25f);
+        if constexpr (kind == 0) return sn;
+        else if constexpr (kind == 1) return (sn + sn) * cs;
+        else if constexpr (kind == 2) return cs;
+        else return fmaf(-(sn + sn), sn, 1.0f);
     }
 }
 
@@ -876,8 +881,13 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
         for (int q = 0; q < 8; ++q) hv[q] = feat >= 0 ? sat_half(f.basis_t[(size_t)(k * CA + 16 * t + 8 * kg + q) * 32 + feat]) : (_Float16)0.0f;
         Wh[e] = hv;
     }
+#ifdef TIR_H16_PK      // the light rows as fp16 pairs (saturating), same element order: LT16[row][144] in the space of the fp32 table
+    _Float16* LT16 = reinterpret_cast<_Float16*>(LT);
+    for (int i = threadIdx.x; i < n_lt * 3 * CA; i += NW * 64) LT16[i] = sat_half(f.light_line[i]);
+#else
     for (int i = threadIdx.x * 4; i < n_lt * 3 * CA; i += NW * 64 * 4)
         *reinterpret_cast<float4*>(LT + i) = *reinterpret_cast<const float4*>(f.light_line + i);
+#endif
     for (int i = threadIdx.x * 4; i < 3 * CA; i += NW * 64 * 4)
         *reinterpret_cast<float4*>(LT + n_lt * 3 * CA + i) = *reinterpret_cast<const float4*>(f.light_mean + i);
     __syncthreads();
@@ -900,12 +910,18 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
         const int64_t sg = r0 + gj, sgc = sg < n ? sg : n - 1;
         const float p[3] = {xyz[3 * sgc], xyz[3 * sgc + 1], xyz[3 * sgc + 2]};
         const float* lrow;
+#ifdef TIR_H16_PK
+        const _Float16* lrow16;
+#endif
         {
             unsigned lsel = rec_map ? (unsigned)rec_map[sgc] : (unsigned)sgc, rem_;      // record -> ray: / idx_div (n < 2^31, launcher)
             lsel = udiv(lsel, by_div, rem_);
             int li = light_idx[lsel];
             li = min(max(li, 0), f.n_lights - 1);
             lrow = n_lt ? LT + li * (3 * CA) : f.light_line + (size_t)li * (3 * CA);
+#ifdef TIR_H16_PK
+            lrow16 = LT16 + li * (3 * CA);
+#endif
         }
         // decoder role: this lane's record and its aux-table row
         const int64_t sd = r0 + sl, sdc = sd < n ? sd : n - 1;
@@ -933,14 +949,17 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
             const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
             const _Float16* pl = reinterpret_cast<const _Float16*>(fh.aplane[k]);
             const _Float16* ln = reinterpret_cast<const _Float16*>(fh.aline[k]);
-            const unsigned q0 = (unsigned)(ty.i0 * W) * CA, q1 = (unsigned)(ty.i1 * W) * CA;
-            const unsigned x0 = (unsigned)tx.i0 * CA + 8 * gc, x1 = (unsigned)tx.i1 * CA + 8 * gc;
+            // element offsets on the full-rate 24-bit multiplier (v_mul_lo_u32 issues at a quarter of the rate: 18 of them per tile
+            // were 5 % of the kernel's VALU slots): indices < 2^24, row pitch W * CA < 2^24 and products < 2^31 (tir_app_index_ok)
+            const unsigned pitch = (unsigned)(W * CA);                                    // wave-uniform
+            const unsigned q0 = mul_u24((unsigned)ty.i0, pitch), q1 = mul_u24((unsigned)ty.i1, pitch);
+            const unsigned x0 = mul_u24((unsigned)tx.i0, CA) + 8 * gc, x1 = mul_u24((unsigned)tx.i1, CA) + 8 * gc;
             const _Float16* p00 = pl + (q0 + x0);
             const _Float16* p01 = pl + (q0 + x1);
             const _Float16* p10 = pl + (q1 + x0);
             const _Float16* p11 = pl + (q1 + x1);
-            const _Float16* l0 = ln + ((unsigned)tl.i0 * CA + 8 * gc);
-            const _Float16* l1 = ln + ((unsigned)tl.i1 * CA + 8 * gc);
+            const _Float16* l0 = ln + (mul_u24((unsigned)tl.i0, CA) + 8 * gc);
+            const _Float16* l1 = ln + (mul_u24((unsigned)tl.i1, CA) + 8 * gc);
             uint4 ta[NQ], tb[NQ], tc[NQ], td[NQ], te[NQ], tg[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -950,12 +969,22 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
             }
             if (!PACK && k == 2) load_table();      // two waves per SIMD: in flight behind the last gather group
             __builtin_amdgcn_sched_barrier(0);
+#ifdef TIR_H16_PK
+            const tir_h2 hw00 = {(_Float16)w00, (_Float16)w00}, hw01 = {(_Float16)w01, (_Float16)w01}, hw10 = {(_Float16)w10, (_Float16)w10},
+                         hw11 = {(_Float16)w11, (_Float16)w11}, hl0 = {(_Float16)tl.w0, (_Float16)tl.w0}, hl1 = {(_Float16)tl.w1, (_Float16)tl.w1};
+#endif
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int ch0 = 16 * q + 8 * gc;
+#ifdef TIR_H16_PK
+                *reinterpret_cast<uint4*>(X + gj * FUS_XH + ch0) =
+                    h16_chunk_pk(ta[q], tb[q], tc[q], td[q], te[q], tg[q], hw00, hw01, hw10, hw11, hl0, hl1,
+                                 *reinterpret_cast<const uint4*>(lrow16 + k * CA + ch0));
+#else
                 *reinterpret_cast<uint4*>(X + gj * FUS_XH + ch0) =
                     h16_chunk(ta[q], tb[q], tc[q], td[q], te[q], tg[q], w00, w01, w10, w11, tl.w0, tl.w1,
                               *reinterpret_cast<const float4*>(lrow + k * CA + ch0), *reinterpret_cast<const float4*>(lrow + k * CA + ch0 + 4));
+#endif
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -2220,6 +2249,9 @@ extern "C" int tir_indirect_fused_fwd(const TirField* f, const TirFieldHalf* fh,
     if (n == 0) return TIR_OK;
     if (n >= (int64_t)1 << 31 || idx_div < 0 || aux_mod < 0) return TIR_ERR_UNSUPPORTED;       // 32-bit record / ray arithmetic in the kernel
     const int lt_rows = f->n_lights <= 16 ? f->n_lights : 0;
+#ifdef TIR_H16_PK
+    if (lt_rows == 0) return TIR_ERR_UNSUPPORTED;      // the packed-fp16 gather reads the light rows from their fp16 image in LDS
+#endif
 #if defined(EXP_FUSED_W8)   // limit study: two waves per SIMD, aux-table row prefetched during the gather, fp32 layer-1 accumulators kept through layer 2
     constexpr int NW = 8; constexpr bool PACK = false;
 #elif defined(EXP_FUSED_NW)

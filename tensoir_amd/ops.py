@@ -517,17 +517,22 @@ if _IND not in ("auto", "f16", "full"):
 SECONDARY_MLP_IMPL = "f16" if _IND != "full" else None       # None | "f16" | "bf16" (probe only) | "bf16x3"
 SECONDARY_APP_IMPL = "h16" if _IND != "full" else None       # None | "h16"
 INDIRECT_GUARD = _IND == "auto"        # False: the settings above apply unconditionally (f16: the caller vouches for range and precision)
-# The self-check (relight._probe_indirect) measures, over the probe records, the signed mean ("bias", max over the colour
-# channels), the rms and the max of (f16 path - full path) of the decoded radiance.  On rgb_with_brdf_map the bias survives the
-# averaging over a ray's records and the light directions, the random part shrinks: across the scaling sweep of
-# tests/precision_cases.py (decoder weights x1..x4, planes x1..x64, light rows x8) the map's max error was 0.45 bias + 0.2 rms
-# within 15 % (profiles/r05_precision_sweep.json: 3.3e-6 as initialised, 3.0e-5 with the decoder weights doubled, 2.0e-4 with
-# x4 -- unguarded fp16 leaves the 1e-4 budget there).  The policy keeps the f16 kernels while
-#     w_bias * bias + w_rms * rms <= limit   and   max <= max
-# i.e. while the estimated map error stays under HALF of the 2.5e-5 the policy promises against the full-precision kernels
-# (a quarter of the 1e-4 budget; the factor two covers scenes darker than the calibration scenes, where the sRGB curve
-# amplifies more).  range: the largest |product| the range guard accepts (largest finite fp16 = 65504).
-INDIRECT_PROBE = {"records": 32768, "interval": 64, "w_bias": 0.5, "w_rms": 0.25, "limit": 1.25e-5, "max": 2e-3, "range": 6.0e4}
+# The self-check.  Through render_with_BRDF / Renderer_TensoIR_train (relight.shade_from_maps) it is a MEASUREMENT of the
+# quantity the tolerance is stated on: all secondary-ray records of the pass are decoded by both paths, the integration kernel
+# renders rgb_with_brdf_map from both, and the f16 kernels are kept while
+#     max over the pass's rays of |rgb_with_brdf_map(f16) - rgb_with_brdf_map(full)|  <=  map_limit  (2.5e-5)
+# -- a quarter of the 1e-4 budget; other batches of the same parameters can be worse than the probed one, measured up to 2x
+# (profiles/r05_precision_trained.json), which leaves the policy's contribution under half of the budget.
+# The bare compute_radiance / compute_secondary_shading_effects entry points have no map to measure: there
+# (relight._probe_indirect) an evenly strided subset of the records is decoded by both paths and the map error is ESTIMATED from
+# the signed mean ("bias", max over the colour channels), the rms and the max of the difference:
+#     max(w_bias * bias + w_rms * rms, w_max * max) <= limit
+# calibrated on the scaling sweep and the trained checkpoint of tests/precision_cases.py, where the measured map error was
+# 0.45 bias + 0.2 rms within 15 % on the smooth scenes and 0.2 max on the trained one (profiles/r05_precision_sweep.json: 3.3e-6 as
+# initialised, 3.0e-5 with the radiance decoder's weights doubled, 2.0e-4 with x4 -- unguarded fp16 leaves the budget there).
+# range: the largest |product| the range guard accepts (largest finite fp16 = 65504).
+INDIRECT_PROBE = {"map_limit": 2.5e-5, "records": 32768, "interval": 64, "w_bias": 0.5, "w_rms": 0.25, "w_max": 0.25, "limit": 2.5e-5,
+                  "range": 6.0e4}
 
 
 # TENSOIR_FUSED_INDIRECT=0: gather and decoder of the secondary-ray records as two launches (tir_vm_app_fwd_h16 +

@@ -119,15 +119,17 @@ def _probe_indirect(tensoIR, f, rgb, n_valid, rec_xyz, light_idx, rec_ray, light
                               dir_map, n_dirs, None, full=True)
     d = (rgb[sel] - ref).double()
     v = torch.stack([d.mean(0).abs().max(), d.pow(2).mean().sqrt(), d.abs().max(), ref.double().pow(2).mean().sqrt()]).tolist()
-    est = lim["w_bias"] * v[0] + lim["w_rms"] * v[1]          # estimated max error on rgb_with_brdf_map (ops.INDIRECT_PROBE)
-    stats = {"records": int(sel.numel()), "of": n_valid, "bias": v[0], "rms": v[1], "max": v[2], "radiance_rms": v[3], "estimate": est}
-    ok = est <= lim["limit"] and v[2] <= lim["max"]            # (NaN fails)
+    est = max(lim["w_bias"] * v[0] + lim["w_rms"] * v[1], lim["w_max"] * v[2])     # estimated max error on rgb_with_brdf_map (ops.INDIRECT_PROBE)
+    stats = {"kind": "records", "records": int(sel.numel()), "of": n_valid, "bias": v[0], "rms": v[1], "max": v[2], "radiance_rms": v[3],
+             "estimate": est}
+    ok = est <= lim["limit"]                                   # (NaN fails)
     _indirect_state(tensoIR)["probes"] += 1
     return bool(ok), stats
 
 
 def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, light_idx, light_div,
-               want_indirect, want_nerfactor=False, n_dirs=0, keep_records=False, ids=None, defer=False, training=False):
+               want_indirect, want_nerfactor=False, n_dirs=0, keep_records=False, ids=None, defer=False, training=False,
+               probe_map=None):
     """Shared driver of compute_transmittance / compute_radiance / render_with_BRDF:
     march (+ record the w > thres samples) -> appearance gather -> radiance decoder -> per-ray sum.
 
@@ -190,23 +192,38 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
 
             def decode(full, fh=fh):
                 if not full and fh is not None and dir_map is None and n_dirs > 0 and ops.fused_indirect() \
-                        and dirs.shape[0] * 8 <= max(n_rows, 1) and int(f.app_dim) == 27:
+                        and dirs.shape[0] * 8 <= max(n_rows, 1) and int(f.app_dim) == 27 and int(f.n_lights) <= 16:
                     # gather -> basis contraction -> radiance decoder in ONE launch, the feature rows never reach HBM
                     return ops.indirect_fused(f, fh, tensoIR.renderModule.packed(), rec_xyz, light_idx, rec_ray, light_div, dirs, n_dirs, n_dev)
                 return _gather_then_decode(tensoIR, f, fh, rec_xyz, light_idx, rec_ray, light_div, dirs, dir_map, n_dirs, n_dev, full=full)
 
+            def packed(rgb):
+                if keep_records:       # the caller's integration kernel sums the records itself (tir_shade_integrate_records)
+                    return {"off": rec["off"], "cnt": rec["cnt"], "w": rec_w, "rgb": rgb}
+                return ops.accumulate_records(rec["off"], rec["cnt"], rec_w, rgb, n_rays)
+
             rgb = decode(mode == "full")
             if mode == "probe":        # auto policy, no verdict for these parameters yet: self-check on this pass's own records
-                n_valid = total if first else total_host.get()
-                ok, stats = _probe_indirect(tensoIR, f, rgb, min(n_valid, n_rows), rec_xyz, light_idx, rec_ray, light_div, dirs, dir_map, n_dirs)
+                n_valid = min(total if first else total_host.get(), n_rows)
+                if probe_map is not None:
+                    # the caller renders rgb_with_brdf_map from BOTH decodes of ALL records of this pass: the quantity the
+                    # tolerance is stated on, measured -- not estimated
+                    rgb_full = decode(True)
+                    d = (rgb[:n_valid] - rgb_full[:n_valid]).double()
+                    delta = probe_map(vis, packed(rgb), packed(rgb_full))
+                    v = (torch.stack([d.mean(0).abs().max(), d.pow(2).mean().sqrt(), d.abs().max()]).tolist() if n_valid else [0.0, 0.0, 0.0])
+                    stats = {"kind": "map", "map_max_abs": delta, "records": n_valid, "rays": n_rays, "bias": v[0], "rms": v[1], "max": v[2]}
+                    ok = delta <= ops.INDIRECT_PROBE["map_limit"]          # (NaN fails)
+                    _indirect_state(tensoIR)["probes"] += 1
+                    if not ok:
+                        rgb = rgb_full
+                else:
+                    ok, stats = _probe_indirect(tensoIR, f, rgb, n_valid, rec_xyz, light_idx, rec_ray, light_div, dirs, dir_map, n_dirs)
+                    if not ok:
+                        rgb = decode(True)
                 _set_verdict(tensoIR, "f16" if ok else "full", "probe", stats)
-                if not ok:
-                    rgb = decode(True)
                 rng = None             # (evaluated above)
-            if keep_records:       # the caller's integration kernel sums the records itself (tir_shade_integrate_records)
-                indirect = {"off": rec["off"], "cnt": rec["cnt"], "w": rec_w, "rgb": rgb}
-            else:
-                indirect = ops.accumulate_records(rec["off"], rec["cnt"], rec_w, rgb, n_rays)
+            indirect = packed(rgb)
         else:
             indirect = torch.zeros((n_rays, 3), dtype=torch.float32, device=dev)
 
@@ -347,9 +364,26 @@ def shade_from_maps(tensoIR, maps, rays, light_idx, sample_method="fixed_envirma
             n_active = tensoIR.__dict__["_pair_counter"] = torch.zeros((1,), dtype=torch.int32, device=dev)
         surf, active, pair_ids, vis0, cnt0 = ops.shade_setup_compact(maps.detach(), rays, dirs, acc_thres, n_active)
         ids = {"pair_ids": pair_ids, "n_active": n_active, "vis": vis0, "rec_cnt": cnt0}
+        equal_area = sample_method == "stratifed_sample_equal_areas"
+        w_d = None if equal_area else area
+
+        def probe_map(vis_p, ind_a, ind_b):
+            """max |d rgb_with_brdf_map| over this pass's rays between two decodes of the secondary records (auto policy):
+            the integration kernel run on both (no_grad; the pair counter is left alone).  One host synchronisation."""
+            env_p = tensoIR.get_light_rgbs(dirs, device=dev).detach()
+            outs = []
+            for ind in (ind_a, ind_b):
+                if isinstance(ind, dict):
+                    outs.append(ops.shade_integrate_records(maps.detach(), rays, dirs, li, vis_p.view(M, D), ind["off"], ind["cnt"], ind["w"],
+                                                            ind["rgb"], env_p, w_d, equal_area, use_linear2srgb, acc_thres, reset_counter=None))
+                else:
+                    outs.append(ops.shade_integrate(maps.detach(), rays, dirs, li, vis_p.view(M, D), ind.view(M, D, 3), env_p, w_d, equal_area,
+                                                    use_linear2srgb, acc_thres))
+            return float((outs[0] - outs[1]).abs().max())
+
         try:
             vis, _, ind = _secondary(tensoIR, surf, dirs, M * D, z, None, None, None, li, D, True, False, D,
-                                     keep_records=fuse, ids=ids, defer=_defer_check, training=train)
+                                     keep_records=fuse, ids=ids, defer=_defer_check, training=train, probe_map=probe_map)
         except BaseException:
             # the pair counter is re-armed by the integration kernel at the end of the pass; if the pass is abandoned
             # in between (capacity error under capture, OOM ...) it must not stay non-zero for the next call
@@ -359,8 +393,6 @@ def shade_from_maps(tensoIR, maps, rays, light_idx, sample_method="fixed_envirma
                 tensoIR.__dict__.pop("_pair_counter", None)
             raise
     env = tensoIR.get_light_rgbs(dirs, device=dev)
-    equal_area = sample_method == "stratifed_sample_equal_areas"
-    w_d = None if equal_area else area
     if not isinstance(ind, dict):
         ids["n_active"].zero_()            # the fused integration kernel (which re-arms the pair counter) is not on this route
     if train:
