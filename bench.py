@@ -455,13 +455,20 @@ def timed_cpu(fn, warm, calls):
     return out, ts[len(ts) // 2], ts
 
 
-def map_parity(got, ref, keys, sel=None):
-    """max |hip - oracle| / max(|oracle|, 1) over the named maps (the test metric), per map and worst."""
-    from tests.helpers import parity_metrics
+def map_parity(got, ref, keys, sel=None, rays=None):
+    """max |hip - oracle| / max(|oracle|, 1) over the named maps (the test metric), per map and worst.  rays (the oracle's rows):
+    rgb_with_brdf_map is compared on the rays where the reference's GGX normal flip is not within fp32 noise of its
+    discontinuity (tests/helpers.py ggx_flip_rays)."""
+    from tests.helpers import ggx_flip_rays, parity_metrics
     per, worst = {}, 0.0
+    keep = ~ggx_flip_rays(ref["normal_map"], rays) if rays is not None and "normal_map" in ref else None
     for k in keys:
         g = got[k].detach().cpu()
-        m = parity_metrics(g[sel] if sel is not None else g, ref[k])
+        g = g[sel] if sel is not None else g
+        r = ref[k]
+        if keep is not None and k == "rgb_with_brdf_map":
+            g, r = g[keep], r[keep]
+        m = parity_metrics(g, r)
         per[k] = {kk: float(f"{vv:.3e}") for kk, vv in m.items()}
         worst = max(worst, m["max_rel_floor1"])
     worst_px = max(v["max_rel_pixel"] for v in per.values()) if per else 0.0
@@ -496,7 +503,7 @@ def sharp_scene_line(a, device, args):
         with torch.no_grad():
             ref = O.renderer_train(sc, rays.cpu()[::stride], lidx.cpu()[::stride], n_samples=a.samples, second_n_sample=a.second_samples)
         got = {k: v.clone() for k, v in ret.items() if torch.is_tensor(v)}
-        parity = map_parity(got, ref, MAP_KEYS, slice(0, None, stride))
+        parity = map_parity(got, ref, MAP_KEYS, slice(0, None, stride), rays.cpu()[::stride])
         parity["rays_compared"] = int(ref["rgb_map"].shape[0])
         parity["indirect_precision"] = model.indirect_precision()
     for _ in range(5):
@@ -635,7 +642,7 @@ def bench_image(a, embed=False):
         stride = max(1, a.rays // 128)
         r_cpu, l_cpu = rc.cpu()[::stride], lc.cpu()[::stride]
         ref, med, ts = timed_cpu(lambda: O.renderer_train(sc, r_cpu, l_cpu, n_samples=-1, second_n_sample=a.second_samples), 1, 3)
-        parity = map_parity(ret_c, ref, MAP_KEYS, slice(0, None, stride))
+        parity = map_parity(ret_c, ref, MAP_KEYS, slice(0, None, stride), r_cpu)
         parity["rays_compared"] = int(r_cpu.shape[0])
         cpu = {"value": round(r_cpu.shape[0] / med, 2), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
                "sample": f"every {stride}th ray of the image's middle chunk ({r_cpu.shape[0]} rays x {model.nSamples} samples, "
@@ -1655,16 +1662,27 @@ def main():
                 "rgb_with_brdf_map", "normals_diff_map", "normals_orientation_loss_map"]
         worst = {"max_abs": 0.0, "max_rel_floor1": 0.0, "max_rel_pixel": 0.0}
         per_map = {}
+        # rays on which the reference itself is discontinuous (GGX_specular flips the normal by sign(N.V), models/relight_utils.py:
+        # 30-31: a composited normal perpendicular to the view direction within fp32 noise takes either branch and the specular
+        # term jumps by percents -- tests/helpers.py ggx_flip_rays, profiles/r05_outlier_diag.json): counted and listed, not compared
+        from tests.helpers import ggx_flip_rays
+        flip = ggx_flip_rays(ref["normal_map"], r_cpu)
+        keep = ~flip
         for k in maps:
-            m = parity_metrics(ret[k].detach().cpu()[::stride][: a.cpu_rays], ref[k])
+            kk_ = keep if k == "rgb_with_brdf_map" else slice(None)
+            m = parity_metrics(ret[k].detach().cpu()[::stride][: a.cpu_rays][kk_], ref[k][kk_])
             per_map[k] = {kk: float(f"{vv:.3e}") for kk, vv in m.items()}
             for kk in worst:
                 worst[kk] = max(worst[kk], m[kk])
         # how many rays carry the worst figure: a decision flip (one secondary sample on the other side of an occupancy-cell
         # boundary because the surface point differs in its last bits) shows up as ONE ray far above the rest
-        d_b = (ret["rgb_with_brdf_map"].detach().cpu()[::stride][: a.cpu_rays] - ref["rgb_with_brdf_map"]).abs().max(dim=-1).values
+        d_all = (ret["rgb_with_brdf_map"].detach().cpu()[::stride][: a.cpu_rays] - ref["rgb_with_brdf_map"]).abs().max(dim=-1).values
+        d_b = d_all[keep]
         top2 = torch.topk(d_b, min(2, d_b.numel())).values.tolist()
-        parity = {"ok": worst["max_rel_floor1"] < 1e-4 and worst["max_rel_pixel"] < 1e-4, "tolerance": 1e-4,
+        parity = {"ok": worst["max_rel_floor1"] < 1e-4 and worst["max_rel_pixel"] < 1e-4 and int(flip.sum()) <= max(2, flip.numel() // 500),
+                  "tolerance": 1e-4,
+                  "ggx_normal_flip_rays": {"count": int(flip.sum()), "criterion": "|N.V| < 1e-5 for the oracle's composited normal",
+                                           "rgb_with_brdf_abs_diff_there": [float(f"{v:.3e}") for v in d_all[flip].tolist()[:8]]},
                   "rgb_with_brdf_rays_over_1e-5": int((d_b > 1e-5).sum()), "rgb_with_brdf_second_worst_abs": float(f"{top2[-1]:.3e}"),
                   "metric": "BOTH asserted < 1e-4: max |hip - oracle| / max(|oracle|, 1) per map (maps live in [0,1], unit normals, "
                             "depth ~4) and max_rel = the true per-pixel relative error ||d|| / ||ref|| over pixels with ||ref|| > 1e-2 "

@@ -220,14 +220,15 @@ int tir_mlp_fwd_bf16x3(const TirMlp* m, const float* feat, int32_t feat_stride, 
  *      TIR_HALF_MAX_JOBS tables in one launch; srcs / dsts / counts are HOST arrays, tables 16-byte aligned.
  *      tir_pack_half_checked: the same, and absmax[i] (DEVICE floats, zeroed by the caller before the call) receives max |x| of
  *      table i (a NaN anywhere in the table is reported as NaN); dsts[i] == NULL scans table i without writing a copy (light
- *      rows, basis_mat).  RANGE CONTRACT of the fp16 gather below: the products plane * line * light-row are rounded to fp16
- *      WITHOUT a saturation test in the hot loop, so the caller must establish max|plane_i| * max|line_i| * max|light row| < 65504
- *      for i = 0..2 and max|basis_mat| < 65504 from these maxima (bilinear taps are convex combinations, so the bound is
- *      rigorous) and use the fp32 gather (tir_vm_app_fwd) otherwise -- the host mirror does exactly that
- *      (tensoir_amd/relight.py: _indirect_mode).
+ *      rows, basis_mat).  RANGE CONTRACT of the fp16 gather below: interpolation and the products (plane * line) * light-row run
+ *      on the packed fp16 pipe WITHOUT a saturation test in the hot loop, so the caller must establish
+ *      max|plane_i| * max|line_i| * max(1, max|light row|) < 65504 for i = 0..2 and max|basis_mat| < 65504 from these maxima
+ *      (bilinear taps are convex combinations, so the bound is rigorous) and use the fp32 gather (tir_vm_app_fwd) otherwise --
+ *      the host mirror does exactly that (tensoir_amd/relight.py: _indirect_mode, ops.HalfRange).
  *      tir_vm_app_fwd_h16 = tir_vm_app_fwd(rad_feat only) for n_acomp == 48 on the fp16 shadow `fh` of f->aplane / f->aline:
- *      half the bytes through the vector L1 (the bound of the fp32 gather), interpolation and light-row product in fp32, the
- *      basis_mat contraction on v_mfma_f32_32x32x16_f16 (operands rounded to 11 bits, fp32 accumulate).  ~2e-4 relative on a
+ *      half the bytes through the vector L1 (the bound of the fp32 gather), interpolation and light-row product on the packed
+ *      fp16 pipe (v_pk_fma_f16: two channels per instruction, rounded after every step), the basis_mat contraction on
+ *      v_mfma_f32_32x32x16_f16 (fp32 accumulate).  ~5e-4 relative on a
  *      feature: NOT parity grade on its own -- the product path uses it only for the secondary-ray records, whose radiance is
  *      averaged over a ray's records and the light directions before it reaches rgb_with_brdf_map.  Other arguments as
  *      tir_vm_app_fwd. */

@@ -432,6 +432,15 @@ __device__ __forceinline__ uint4 h16_chunk_pk(const uint4& a, const uint4& b, co
     return make_uint4(pk[0], pk[1], pk[2], pk[3]);
 }
 
+// 8 consecutive fp32 values as 8 saturating fp16 (the light row of a record when the rows are not staged in LDS)
+__device__ __forceinline__ uint4 pack8_half(const float* __restrict__ p) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    const tir_h2 h0 = {sat_half(a.x), sat_half(a.y)}, h1 = {sat_half(a.z), sat_half(a.w)}, h2 = {sat_half(b.x), sat_half(b.y)},
+                 h3 = {sat_half(b.z), sat_half(b.w)};
+    return make_uint4(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1), __builtin_bit_cast(unsigned, h2),
+                      __builtin_bit_cast(unsigned, h3));
+}
+
 // DPP helper: value of lane (l - shift) within a 16-lane row, `ident` where that lane is outside the row
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_f(float ident, float v) {

@@ -881,7 +881,7 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
         for (int q = 0; q < 8; ++q) hv[q] = feat >= 0 ? sat_half(f.basis_t[(size_t)(k * CA + 16 * t + 8 * kg + q) * 32 + feat]) : (_Float16)0.0f;
         Wh[e] = hv;
     }
-#ifdef TIR_H16_PK      // the light rows as fp16 pairs (saturating), same element order: LT16[row][144] in the space of the fp32 table
+#ifndef TIR_H16_FP32MIX      // the light rows as fp16 pairs (saturating), same element order: LT16[row][144] in the space of the fp32 table
     _Float16* LT16 = reinterpret_cast<_Float16*>(LT);
     for (int i = threadIdx.x; i < n_lt * 3 * CA; i += NW * 64) LT16[i] = sat_half(f.light_line[i]);
 #else
@@ -910,7 +910,7 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
         const int64_t sg = r0 + gj, sgc = sg < n ? sg : n - 1;
         const float p[3] = {xyz[3 * sgc], xyz[3 * sgc + 1], xyz[3 * sgc + 2]};
         const float* lrow;
-#ifdef TIR_H16_PK
+#ifndef TIR_H16_FP32MIX
         const _Float16* lrow16;
 #endif
         {
@@ -919,7 +919,7 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
             int li = light_idx[lsel];
             li = min(max(li, 0), f.n_lights - 1);
             lrow = n_lt ? LT + li * (3 * CA) : f.light_line + (size_t)li * (3 * CA);
-#ifdef TIR_H16_PK
+#ifndef TIR_H16_FP32MIX
             lrow16 = LT16 + li * (3 * CA);
 #endif
         }
@@ -969,17 +969,17 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
             }
             if (!PACK && k == 2) load_table();      // two waves per SIMD: in flight behind the last gather group
             __builtin_amdgcn_sched_barrier(0);
-#ifdef TIR_H16_PK
+#ifndef TIR_H16_FP32MIX
             const tir_h2 hw00 = {(_Float16)w00, (_Float16)w00}, hw01 = {(_Float16)w01, (_Float16)w01}, hw10 = {(_Float16)w10, (_Float16)w10},
                          hw11 = {(_Float16)w11, (_Float16)w11}, hl0 = {(_Float16)tl.w0, (_Float16)tl.w0}, hl1 = {(_Float16)tl.w1, (_Float16)tl.w1};
 #endif
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int ch0 = 16 * q + 8 * gc;
-#ifdef TIR_H16_PK
+#ifndef TIR_H16_FP32MIX
                 *reinterpret_cast<uint4*>(X + gj * FUS_XH + ch0) =
                     h16_chunk_pk(ta[q], tb[q], tc[q], td[q], te[q], tg[q], hw00, hw01, hw10, hw11, hl0, hl1,
-                                 *reinterpret_cast<const uint4*>(lrow16 + k * CA + ch0));
+                                 n_lt ? *reinterpret_cast<const uint4*>(lrow16 + k * CA + ch0) : pack8_half(lrow + k * CA + ch0));
 #else
                 *reinterpret_cast<uint4*>(X + gj * FUS_XH + ch0) =
                     h16_chunk(ta[q], tb[q], tc[q], td[q], te[q], tg[q], w00, w01, w10, w11, tl.w0, tl.w1,
@@ -2249,9 +2249,6 @@ extern "C" int tir_indirect_fused_fwd(const TirField* f, const TirFieldHalf* fh,
     if (n == 0) return TIR_OK;
     if (n >= (int64_t)1 << 31 || idx_div < 0 || aux_mod < 0) return TIR_ERR_UNSUPPORTED;       // 32-bit record / ray arithmetic in the kernel
     const int lt_rows = f->n_lights <= 16 ? f->n_lights : 0;
-#ifdef TIR_H16_PK
-    if (lt_rows == 0) return TIR_ERR_UNSUPPORTED;      // the packed-fp16 gather reads the light rows from their fp16 image in LDS
-#endif
 #if defined(EXP_FUSED_W8)   // limit study: two waves per SIMD, aux-table row prefetched during the gather, fp32 layer-1 accumulators kept through layer 2
     constexpr int NW = 8; constexpr bool PACK = false;
 #elif defined(EXP_FUSED_NW)

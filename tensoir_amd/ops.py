@@ -202,7 +202,8 @@ class AsyncFloats:
 class HalfRange:
     """Range guard of one fp16 shadow of the field (tir_pack_half_checked's RANGE CONTRACT): the abs-maxima of the three
     appearance planes, the three lines, the light rows and basis_mat^T travel to the host behind the pack launch; ok() is
-    True when no plane * line * light-row product and no basis_mat element can leave the finite fp16 range."""
+    True when no plane * line product, no plane * line * light-row product and no basis_mat element can leave the finite fp16
+    range: bound = max_i (max|plane_i| max|line_i|) max(1, max|light row|) < INDIRECT_PROBE["range"]."""
 
     def __init__(self, absmax):
         self.pending = AsyncFloats(absmax)
@@ -215,7 +216,8 @@ class HalfRange:
         if self.result is None:
             m = self.pending.get()
             self.maxima = {"plane": m[0:3], "line": m[3:6], "light": m[6], "basis": m[7]}
-            self.bound = max(m[i] * m[3 + i] for i in range(3)) * m[6]
+            # the packed-fp16 gather forms (plane x line) in fp16 BEFORE the light row is applied (h16_chunk_pk)
+            self.bound = max(m[i] * m[3 + i] for i in range(3)) * max(1.0, m[6])
             lim = INDIRECT_PROBE["range"]
             # (a NaN maximum fails both comparisons)
             self.result = bool(self.bound < lim and m[7] < lim and all(v < lim for v in m[:7]))

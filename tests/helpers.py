@@ -86,3 +86,16 @@ def parity_metrics(a, b):
     relpix = float((d2.norm(dim=-1)[sel] / nb[sel]).max()) if bool(sel.any()) else 0.0
     return {"max_abs": float(d.max()), "max_rel_floor1": float((d / b.abs().clamp(min=1.0)).max()),
             "max_rel_pixel": relpix}
+
+
+def ggx_flip_rays(ref_normal_map, rays, eps=1e-5):
+    """Rays on which the reference's physically-based colour is DISCONTINUOUS in its inputs: GGX_specular flips the normal by
+    sign(N.V) (models/relight_utils.py:30-31: ``N = N * NoV.sign()``), so a ray whose composited normal is perpendicular to the
+    view direction within fp32 noise (|N.V| < eps; the maps themselves agree to ~1e-5) takes either branch -- the specular
+    term, hence rgb_with_brdf_map, jumps by percents (measured: one ray of the 4096-ray bench batch, oracle N.V = +1.0e-6, split-bf16
+    decoders -8e-8, exact fp32 decoders +1.0e-6: profiles/r05_outlier_diag.json).  Such rays are reported, not compared."""
+    n = torch.as_tensor(ref_normal_map).detach().double().cpu()
+    d = torch.as_tensor(rays).detach().double().cpu()[:, 3:6]
+    n = n / n.norm(dim=-1, keepdim=True).clamp(min=1e-6)
+    v = -d / d.norm(dim=-1, keepdim=True).clamp(min=1e-6)
+    return (n * v).sum(-1).abs() < eps

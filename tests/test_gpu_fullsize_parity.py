@@ -80,11 +80,20 @@ def c23():
                                  args=types.SimpleNamespace(second_nSample=96, second_near=0.05, second_far=1.5))
 
 
-def _check_maps(case, out, brdf, ref, sel):
+def _check_maps(case, out, brdf, ref, sel, rays=None):
     names = ["rgb_map", "depth_map", "normal_map", "albedo_map", "roughness_map", "fresnel_map", "acc_map",
              "normals_diff_map", "normals_orientation_loss_map", "acc_mask", "albedo_smoothness_loss",
              "roughness_smoothness_loss"]
     got = dict(zip(names, out))
+    # rays whose composited normal is perpendicular to the view direction within fp32 noise: the reference's GGX term is
+    # discontinuous there (tests/helpers.py: ggx_flip_rays) -- reported, excluded from the rgb_with_brdf_map comparison
+    keep = torch.ones(ref["rgb_map"].shape[0], dtype=torch.bool)
+    if rays is not None:
+        from tests.helpers import ggx_flip_rays
+        flip = ggx_flip_rays(ref["normal_map"], rays.cpu()[sel])
+        keep = ~flip
+        REPORT.setdefault(case, {})["ggx_normal_flip_rays"] = int(flip.sum())
+        assert int(flip.sum()) <= max(2, keep.numel() // 500), (case, int(flip.sum()))
     mask_ref = ref["acc_map"] > 0.5
     near_half = (ref["acc_map"] - 0.5).abs() < 1e-4          # acc within rounding of the 0.5 threshold may flip
     assert bool(((got["acc_mask"].cpu()[sel] == mask_ref) | near_half).all())
@@ -93,7 +102,7 @@ def _check_maps(case, out, brdf, ref, sel):
         m = _record(case, n, got[n].cpu()[sel], ref[n])
         worst[n] = m
         assert m["max_rel_floor1"] < TOL, (case, n, m)
-    m = _record(case, "rgb_with_brdf_map", brdf.cpu()[sel], ref["rgb_with_brdf_map"])
+    m = _record(case, "rgb_with_brdf_map", brdf.cpu()[sel][keep], ref["rgb_with_brdf_map"][keep])
     assert m["max_rel_floor1"] < TOL, (case, "rgb_with_brdf_map", m)
     worst["rgb_with_brdf_map"] = m
     for n in ("rgb_map", "normal_map", "rgb_with_brdf_map"):      # north_star: relative on rendered RGB / normals
@@ -116,7 +125,7 @@ def test_c2_c3_headline_batch_vs_oracle(c23, impl, t_stop):
         out, maps = m(rays, lidx, N_samples=512, _brdf_jitter_dense=c23.noise, _return_maps=True)
         brdf = relight.shade_from_maps(m, maps, rays, lidx, "fixed_envirmap", c23.args, acc_thres=0.5)
         case = f"C2+C3/{impl}/t_stop={t_stop:g}"
-        got = _check_maps(case, out, brdf, c23.ref, c23.sel)
+        got = _check_maps(case, out, brdf, c23.ref, c23.sel, rays)
         # the smoothness losses are means over ALL rays of the batch: compare the subsample's per-ray rows instead
         for col, key in ((17, "albedo_smoothness_loss"), (18, "roughness_smoothness_loss")):
             sub = float(maps[:, col].cpu()[c23.sel].mean())
@@ -134,9 +143,12 @@ def test_c2_c3_boundary_call_equals_checked_route(c23):
     the checked route above wherever the jitter does not enter (everything but the two smoothness losses)."""
     from tensoir_amd import Renderer_TensoIR_train
     m = c23.model
+    from tests.helpers import ggx_flip_rays
     ret = Renderer_TensoIR_train(c23.rays, None, c23.lidx, m, N_samples=512, args=c23.args, device="cuda")
+    keep = ~ggx_flip_rays(c23.ref["normal_map"], c23.rays[c23.sel])          # (see _check_maps)
     for n in MAPS + ["rgb_with_brdf_map"]:
-        r = _record("C2+C3/boundary-call", n, ret[n].cpu()[c23.sel], c23.ref[n])
+        k = keep if n == "rgb_with_brdf_map" else slice(None)
+        r = _record("C2+C3/boundary-call", n, ret[n].cpu()[c23.sel][k], c23.ref[n][k])
         assert r["max_rel_floor1"] < TOL, (n, r)
         if n in ("rgb_map", "normal_map", "rgb_with_brdf_map"):
             assert r["max_rel_pixel"] < TOL_PIXEL, (n, r)
@@ -164,7 +176,7 @@ def test_c4_three_lights_1036_samples_vs_oracle():
         model.march_t_stop = t_stop
         out, maps = model(rays.cuda(), lidx.cuda(), N_samples=-1, _brdf_jitter_dense=noise, _return_maps=True)
         brdf = relight.shade_from_maps(model, maps, rays.cuda(), lidx.cuda(), "fixed_envirmap", args, acc_thres=0.5)
-        _check_maps(f"C4/bf16x3/t_stop={t_stop:g}", out, brdf, ref, sel)
+        _check_maps(f"C4/bf16x3/t_stop={t_stop:g}", out, brdf, ref, sel, rays)
 
 
 @torch.no_grad()

@@ -148,8 +148,9 @@ def test_indirect_precision_policy_kernels(env):
     * tir_mlp_fwd_auxtab_f16 (single-product fp16 decoder, operands rounded to 11 bits): |rgb - exact| < 2e-4 on every row
       (measured ~4e-5 max, 7e-6 rms), unbiased (|mean| < 2e-6), finite for feature / activation magnitudes beyond the fp16
       range (operands saturate at 65504 instead of turning into inf), ragged and device-side row counts;
-    * tir_vm_app_fwd_h16 (fp16 shadow of the appearance planes / lines, fp16 basis contraction): |feat - fp32 gather| <
-      2e-3 of the feature scale on every element, padding columns zero, index-map / idx_div / n_dev forms;
+    * tir_vm_app_fwd_h16 (fp16 shadow of the appearance planes / lines, interpolation and products on the packed fp16 pipe,
+      fp16 basis contraction): |feat - fp32 gather| < 4e-3 of the feature scale on every element (measured 1e-3), padding
+      columns zero, index-map / idx_div / n_dev forms;
     and the policy switch itself: `full` reproduces the primary-stage kernels bit for bit."""
     from tensoir_amd import ops
     m = env.model
@@ -177,15 +178,15 @@ def test_indirect_precision_policy_kernels(env):
     r32 = ops.vm_app(fld, xyz, li, None, True, False)[0]
     r16 = ops.vm_app_h16(fld, fh, xyz, li)
     scale = float(r32[:, :27].abs().max())
-    assert float((r16 - r32)[:, :27].abs().max()) < 2e-3 * scale and bool((r16[:, 27:] == 0).all())
-    assert rel(r16[:, :27], env.g["feat/app"]) < 2e-3 * max(1.0, scale)          # and against the reference's own features
+    assert float((r16 - r32)[:, :27].abs().max()) < 4e-3 * scale and bool((r16[:, 27:] == 0).all())
+    assert rel(r16[:, :27], env.g["feat/app"]) < 4e-3 * max(1.0, scale)          # and against the reference's own features
     pts = (torch.rand(5003, 3, generator=gen) * 1.9 - 0.95).cuda()              # incl. points near / outside the borders
     npt = 40
     lpt = torch.randint(0, m.light_num, (npt,), generator=gen).int().cuda()
     imap = torch.randint(0, npt * 7, (5003,), generator=gen).int().cuda()        # pair ids: light index of point id // 7
     a32 = ops.vm_app(fld, pts, lpt, imap, True, False, None, 7)[0]
     a16 = ops.vm_app_h16(fld, fh, pts, lpt, imap, 7)
-    assert float((a16 - a32).abs().max()) < 2e-3 * max(float(a32.abs().max()), 1e-6)
+    assert float((a16 - a32).abs().max()) < 4e-3 * max(float(a32.abs().max()), 1e-6)
     n_dev = torch.tensor([4000], dtype=torch.int32, device="cuda")
     assert torch.equal(ops.vm_app_h16(fld, fh, pts, lpt, imap, 7, n_dev)[:4000], a16[:4000])
     # ---- the fused launch (gather -> basis contraction -> decoder, features in registers) against the two launches it replaces
