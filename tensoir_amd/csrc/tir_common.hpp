@@ -553,6 +553,13 @@ __device__ __forceinline__ float wave_sigma(const TirField& f, bool valid, float
     }
 }
 
+// exp(-x), x >= 0, for the SECONDARY marches (visibility / indirect light; models/relight_utils.py:690-697, :811-817): one
+// multiply + v_exp_f32 (exp2, 1 ulp) instead of libm's expf (~18 VALU instructions with its range handling) in a kernel that is
+// VALU-issue bound.  |x| 2^-24 of argument rounding -> a relative error of the result <= 6e-8 (1 + |x|): three orders of magnitude
+// below what the transmittance needs (T < 1e-4 ends a ray's contribution).  The primary march keeps expf: its weights decide the
+// record set the decoders see.
+__device__ __forceinline__ float exp_neg_fast(float x) { return __builtin_amdgcn_exp2f(x * -1.4426950408889634f); }
+
 // cull of one world-space sample (bbox + occupancy, models/tensorBase_rotated_lights.py:892-897) and its
 // normalised coordinates (:916)
 __device__ __forceinline__ bool sample_valid(const TirField& f, float px, float py, float pz, float& x, float& y, float& z) {

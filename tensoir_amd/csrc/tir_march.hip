@@ -596,7 +596,7 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
                 float w = 0.0f, v = 1.0f;
                 if (on) {
                     float dist = (k + 1 < n_sample) ? sub_rn(zt[k + 1], z) : 0.0f;
-                    float alpha = 1.0f - expf(-sigma * mul_rn(dist, f.distance_scale));
+                    float alpha = 1.0f - exp_neg_fast(sigma * mul_rn(dist, f.distance_scale));
                     v = add_rn(sub_rn(1.0f, alpha), 1e-10f);
                     w = alpha;
                 }
@@ -838,7 +838,7 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins_a, const int
                         float w = 0.0f, v = 1.0f;
                         if (on) {
                             float dist = (k + 1 < n_sample) ? sub_rn(zt[k + 1], z) : 0.0f;
-                            float alpha = 1.0f - expf(-sigma * mul_rn(dist, f.distance_scale));
+                            float alpha = 1.0f - exp_neg_fast(sigma * mul_rn(dist, f.distance_scale));
                             v = add_rn(sub_rn(1.0f, alpha), 1e-10f);
                             w = alpha;
                         }

@@ -533,7 +533,9 @@ INDIRECT_GUARD = _IND == "auto"        # False: the settings above apply uncondi
 # 0.45 bias + 0.2 rms within 15 % on the smooth scenes and 0.2 max on the trained one (profiles/r05_precision_sweep.json: 3.3e-6 as
 # initialised, 3.0e-5 with the radiance decoder's weights doubled, 2.0e-4 with x4 -- unguarded fp16 leaves the budget there).
 # range: the largest |product| the range guard accepts (largest finite fp16 = 65504).
-INDIRECT_PROBE = {"map_limit": 2.5e-5, "records": 32768, "interval": 64, "w_bias": 0.5, "w_rms": 0.25, "w_max": 0.25, "limit": 2.5e-5,
+# TENSOIR_INDIRECT_MAP_LIMIT overrides map_limit (a trained analytic scene measured 2.0e-5 ... 3.1e-5 on its own training rays:
+# around the default, so such a checkpoint may run either way; both are within the budget).
+INDIRECT_PROBE = {"map_limit": float(os.environ.get("TENSOIR_INDIRECT_MAP_LIMIT", "2.5e-5")), "records": 32768, "interval": 64, "w_bias": 0.5, "w_rms": 0.25, "w_max": 0.25, "limit": 2.5e-5,
                   "range": 6.0e4}
 
 

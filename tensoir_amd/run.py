@@ -64,12 +64,15 @@ def install(reference_root: str):
         from tensoir_amd import optim
         torch.optim.Adam = optim.LauncherAdam       # the script's optimizer: one launch; anything unsupported: torch's own step
         done["torch.optim"] = ["Adam"]
-    # TENSOIR_DEVICE_DATASET=1: the training rays stay resident in HBM (batches are gathered on the device)
+    # The training rays stay resident in HBM (batches are gathered on the device: only the 32 KB index tensor crosses PCIe per
+    # step) whenever the ray table fits -- TENSOIR_DEVICE_DATASET = auto (default: rays + colours + light indices below a quarter
+    # of the free HBM; 100 views of 800 x 800 are 2.6 GB of 288), 1 (always), 0 (the script's host tensors)
     dev = None
-    if os.environ.get("TENSOIR_DEVICE_DATASET", "0") == "1":
+    mode = os.environ.get("TENSOIR_DEVICE_DATASET", "auto")
+    if mode in ("1", "auto"):
         import torch
         dev = "cuda" if torch.cuda.is_available() else None
-    synth_dataset.wrap_dataset_dict(importlib.import_module("dataLoader").dataset_dict, device=dev)
+    synth_dataset.wrap_dataset_dict(importlib.import_module("dataLoader").dataset_dict, device=dev, only_if_fits=(mode == "auto"))
     _allow_numpy_in_checkpoints()
     return done
 

@@ -112,6 +112,16 @@ class SyntheticDataset(torch.utils.data.Dataset):
                 "rays": fs[0]["rays"], "normals": fs[0]["normals"], "albedo": fs[0]["albedo"]}
 
 
+def _fits(ds, device, share=0.25):
+    """The training table (rays, colours, light indices) against `share` of the device's free memory."""
+    need = sum(t.numel() * t.element_size() for t in (getattr(ds, n, None) for n in ("all_rays", "all_rgbs", "all_light_idx")) if torch.is_tensor(t))
+    try:
+        free, _ = torch.cuda.mem_get_info(torch.device(device))
+    except Exception:
+        return False
+    return need <= share * free
+
+
 def _to_device(ds, device):
     """Training-loop residency: keep the training rays / colours / light indices of a dataset in HBM, so that
     the unmodified loop's ``rays_filtered[rays_idx]`` (train_tensoIR.py:239-242) gathers on the device and only the 32 KB
@@ -133,9 +143,10 @@ def _light_defaults(cls):
             if k in ("light_name_list", "light_rotation", "light_names", "light_name") and p.default is not inspect.Parameter.empty}
 
 
-def wrap_dataset_dict(dataset_dict, device=None):
+def wrap_dataset_dict(dataset_dict, device=None, only_if_fits=False):
     """Every entry keeps its reference class for real data directories and builds the analytic dataset when
-    ``datadir`` starts with ``synthetic``.  device (e.g. 'cuda'): training splits are moved to that device once."""
+    ``datadir`` starts with ``synthetic``.  device (e.g. 'cuda'): training splits are moved to that device once
+    (only_if_fits: when the table takes less than a quarter of the free device memory)."""
     for name, cls in list(dataset_dict.items()):
         if getattr(cls, "__tensoir_wrapped__", False):
             continue
@@ -146,7 +157,7 @@ def wrap_dataset_dict(dataset_dict, device=None):
                 # train_tensoIR_general_multi_lights.py:74) gets THAT reference class's default, not ours
                 k = {**_light_defaults(_cls), **k}
             ds = SyntheticDataset(root_dir, *a, **k) if is_synthetic(root_dir) else _cls(root_dir, *a, **k)
-            if device is not None and k.get("split", "train") == "train":
+            if device is not None and k.get("split", "train") == "train" and (not only_if_fits or _fits(ds, device)):
                 _to_device(ds, device)
             return ds
         factory.__tensoir_wrapped__ = True

@@ -237,6 +237,21 @@ def test_unmodified_train_script_variants_run_end_to_end(tmp_path, monkeypatch, 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not HAVE_REF, reason="reference checkout not present on this box")
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_unmodified_train_script_dataset_residency_modes(tmp_path, monkeypatch, mode):
+    """TENSOIR_DEVICE_DATASET (launcher default `auto` = resident in HBM when the ray table fits, tensoir_amd/run.py): the
+    unmodified loop's rays_filtered[rays_idx] (train_tensoIR.py:239-242) works on the host table (0) and on the device table (1),
+    and trains to the same quality either way."""
+    monkeypatch.setenv("TENSOIR_DEVICE_DATASET", mode)
+    r = run_script(tmp_path, script="train_tensoIR.py")
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    m = re.findall(r"train_rgb = ([0-9.]+)", out) or re.findall(r"train_rgb_brdf = ([0-9.]+)", out)
+    assert m and float(m[-1]) > 15.0, (m[-3:], out[-1500:])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not HAVE_REF, reason="reference checkout not present on this box")
 def test_unmodified_train_script_with_evaluation_loops(tmp_path, monkeypatch):
     """The same run with the reference's evaluation loops on (renderer.py:135-519): `evaluation_iter_TensoIR` at
     iteration 139 (N_vis views) and over the whole test split after training (render_test, test_all=True incl.
