@@ -11,7 +11,9 @@ for step in "$@"; do
   name="${step%%:*}"; arg=""; [ "$name" != "$step" ] && arg="${step#*:}"
   t0=$(date +%s)
   case "$name" in
-    tests) timeout -k 5 1500 python -m pytest tests -m gpu -q ${arg:-} > "$OUT/${TAG}_tests.log" 2>&1; echo "tests rc=$?" >> "$OUT/${TAG}_tests.log"; tail -4 "$OUT/${TAG}_tests.log";;
+    tests) # arg = pytest arguments (files, -k 'a or b' with its own quotes); none = the whole -m gpu suite
+           if [ -z "$arg" ]; then arg="tests"; fi
+           eval "timeout -k 5 1500 python -m pytest -m gpu -q $arg" > "$OUT/${TAG}_tests.log" 2>&1; echo "tests rc=$?" >> "$OUT/${TAG}_tests.log"; tail -4 "$OUT/${TAG}_tests.log";;
     precision) timeout -k 5 1200 python tools/r05_precision.py ${arg:-} > "$OUT/${TAG}_precision.log" 2>&1; echo "precision rc=$?"; tail -25 "$OUT/${TAG}_precision.log";;
     bench) timeout -k 5 900 python bench.py ${arg:-} > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"; echo "bench rc=$?"; tail -c 700 "$OUT/${TAG}_bench.json"; echo; tail -3 "$OUT/${TAG}_bench.err";;
     cmd) bash -c "$arg" > "$OUT/${TAG}_cmd.log" 2>&1; echo "cmd rc=$?"; tail -30 "$OUT/${TAG}_cmd.log";;
