@@ -535,7 +535,10 @@ INDIRECT_GUARD = _IND == "auto"        # False: the settings above apply uncondi
 # range: the largest |product| the range guard accepts (largest finite fp16 = 65504).
 # TENSOIR_INDIRECT_MAP_LIMIT overrides map_limit (a trained analytic scene measured 2.0e-5 ... 3.1e-5 on its own training rays:
 # around the default, so such a checkpoint may run either way; both are within the budget).
-INDIRECT_PROBE = {"map_limit": float(os.environ.get("TENSOIR_INDIRECT_MAP_LIMIT", "2.5e-5")), "records": 32768, "interval": 64, "w_bias": 0.5, "w_rms": 0.25, "w_max": 0.25, "limit": 2.5e-5,
+# train_map_limit: what a TRAINING forward accepts (is_train renders feed the loss only, and the secondary stage is a no_grad
+# constant there, models/relight_utils.py:344): the contract's tolerance itself.  A verdict taken with it never serves an
+# inference pass (relight._indirect_mode re-probes with the strict limit).
+INDIRECT_PROBE = {"map_limit": float(os.environ.get("TENSOIR_INDIRECT_MAP_LIMIT", "2.5e-5")), "train_map_limit": 1.0e-4, "records": 32768, "interval": 64, "w_bias": 0.5, "w_rms": 0.25, "w_max": 0.25, "limit": 2.5e-5,
                   "range": 6.0e4}
 
 

@@ -87,8 +87,8 @@ def _indirect_mode(tensoIR, training=False):
         return "f16"
     st = _indirect_state(tensoIR)
     key, storage = _indirect_key(tensoIR)
-    if st["verdict"] is not None and st["key"] == key:
-        return st["verdict"]
+    if st["verdict"] is not None and st["key"] == key and (training or not st.get("train_limit")):
+        return st["verdict"]         # (an inference pass never rides on a verdict taken with the training limit)
     if training and st["verdict"] is not None and st["storage"] == storage and st["age"] < ops.INDIRECT_PROBE["interval"]:
         st["age"] += 1
         st["key"] = key
@@ -96,12 +96,12 @@ def _indirect_mode(tensoIR, training=False):
     return "probe"
 
 
-def _set_verdict(tensoIR, verdict, why, stats=None):
+def _set_verdict(tensoIR, verdict, why, stats=None, train_limit=False):
     st = _indirect_state(tensoIR)
     key, storage = _indirect_key(tensoIR)
     if verdict == "full" and st["verdict"] != "full":
         st["fallbacks"] += 1
-    st.update(verdict=verdict, key=key, storage=storage, age=0, why=why)
+    st.update(verdict=verdict, key=key, storage=storage, age=0, why=why, train_limit=bool(train_limit))
     if stats is not None:
         st["stats"] = stats
 
@@ -213,7 +213,11 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
                     delta = probe_map(vis, packed(rgb), packed(rgb_full))
                     v = (torch.stack([d.mean(0).abs().max(), d.pow(2).mean().sqrt(), d.abs().max()]).tolist() if n_valid else [0.0, 0.0, 0.0])
                     stats = {"kind": "map", "map_max_abs": delta, "records": n_valid, "rays": n_rays, "bias": v[0], "rms": v[1], "max": v[2]}
-                    ok = delta <= ops.INDIRECT_PROBE["map_limit"]          # (NaN fails)
+                    # a TRAINING pass renders the map as a no_grad constant of the loss (models/relight_utils.py:344): there the
+                    # policy accepts up to the contract's own tolerance; inference / export use the strict limit
+                    map_limit = ops.INDIRECT_PROBE["train_map_limit" if training else "map_limit"]
+                    stats["limit"] = map_limit
+                    ok = delta <= map_limit                                  # (NaN fails)
                     _indirect_state(tensoIR)["probes"] += 1
                     if not ok:
                         rgb = rgb_full
@@ -221,7 +225,7 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
                     ok, stats = _probe_indirect(tensoIR, f, rgb, n_valid, rec_xyz, light_idx, rec_ray, light_div, dirs, dir_map, n_dirs)
                     if not ok:
                         rgb = decode(True)
-                _set_verdict(tensoIR, "f16" if ok else "full", "probe", stats)
+                _set_verdict(tensoIR, "f16" if ok else "full", "probe", stats, train_limit=training and probe_map is not None)
                 rng = None             # (evaluated above)
             indirect = packed(rgb)
         else:
