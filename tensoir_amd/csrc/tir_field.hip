@@ -802,25 +802,33 @@ typedef float app_f32x2 __attribute__((ext_vector_type(2)));
 // abs-max (bit pattern of |x|: non-negative floats order like unsigned integers, a NaN sorts above inf and is reported as
 // such) -- the range guard of the indirect-light precision policy reads it (ops.pack_half, relight._indirect_mode).
 // dst == NULL: scan only (light rows, basis_mat: tables the gather reads as fp32 / casts in-kernel).
-__global__ void k_pack_half(TirHalfJobs jobs) {
+// A workgroup of 256 threads owns TIR_PACK_CHUNKS x 2048 consecutive elements of one table (four 16-byte stores per thread:
+// the reduction / atomic tail is paid once per 8192 elements); workgroups past the end of a shorter table leave at once.
+#define TIR_PACK_CHUNKS 4
+__global__ void __launch_bounds__(256) k_pack_half(TirHalfJobs jobs) {
     const TirHalfJob jb = jobs.job[blockIdx.y];
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const int64_t base = (int64_t)blockIdx.x * (2048 * TIR_PACK_CHUNKS);
+    if (base >= jb.n) return;                                   // (block-uniform)
     _Float16* dst = reinterpret_cast<_Float16*>(jb.dst);
     unsigned m = 0;
-    if (i + 8 <= jb.n) {
-        const float4 a = ld4(jb.src + i), b = ld4(jb.src + i + 4);
-        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-        for (int q = 0; q < 8; ++q) m = max(m, __builtin_bit_cast(unsigned, v[q]) & 0x7fffffffu);
-        if (dst) {
-            app_f16x8 h = {sat_half(a.x), sat_half(a.y), sat_half(a.z), sat_half(a.w), sat_half(b.x), sat_half(b.y), sat_half(b.z), sat_half(b.w)};
-            *reinterpret_cast<app_f16x8*>(dst + i) = h;
-        }
-    } else {
-        for (int64_t e = i; e < jb.n; ++e) {
-            const float x = jb.src[e];
-            m = max(m, __builtin_bit_cast(unsigned, x) & 0x7fffffffu);
-            if (dst) dst[e] = sat_half(x);
+    for (int ch = 0; ch < TIR_PACK_CHUNKS; ++ch) {
+        const int64_t i = base + (int64_t)ch * 2048 + (int64_t)threadIdx.x * 8;
+        if (i + 8 <= jb.n) {
+            const float4 a = ld4(jb.src + i), b = ld4(jb.src + i + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m = max(m, __builtin_bit_cast(unsigned, v[q]) & 0x7fffffffu);
+            if (dst) {
+                app_f16x8 h = {sat_half(a.x), sat_half(a.y), sat_half(a.z), sat_half(a.w), sat_half(b.x), sat_half(b.y), sat_half(b.z), sat_half(b.w)};
+                *reinterpret_cast<app_f16x8*>(dst + i) = h;
+            }
+        } else {
+            for (int64_t e = i; e < jb.n; ++e) {
+                const float x = jb.src[e];
+                m = max(m, __builtin_bit_cast(unsigned, x) & 0x7fffffffu);
+                if (dst) dst[e] = sat_half(x);
+            }
         }
     }
     if (jb.absmax) {      // (block-uniform branch)
@@ -1111,7 +1119,8 @@ static int pack_half_launch(const float* const* srcs, void* const* dsts, const i
         most = counts[i] > most ? counts[i] : most;
     }
     if (most == 0) return TIR_OK;
-    hipLaunchKernelGGL(k_pack_half, dim3((unsigned)((most + 2047) / 2048), (unsigned)n_tables), dim3(256), 0, tir_stream(stream), jobs);
+    const int64_t per_block = 2048 * TIR_PACK_CHUNKS;
+    hipLaunchKernelGGL(k_pack_half, dim3((unsigned)((most + per_block - 1) / per_block), (unsigned)n_tables), dim3(256), 0, tir_stream(stream), jobs);
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

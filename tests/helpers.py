@@ -71,10 +71,10 @@ def scene_from_model(ckpt, model, envmap_h, envmap_w):
     return scene_from_checkpoint(ck, envmap_h, envmap_w)
 
 
-def parity_metrics(a, b):
+def parity_metrics(a, b, min_norm=1e-2):
     """The three error figures reported for a rendered map (hip a vs reference b):
     max_abs, max |d| / max(|ref|, 1) (the test metric; maps live in [0,1] / unit normals / depth ~4) and the
-    true per-pixel relative error ||d|| / ||ref|| over pixels with ||ref|| > 1e-2 (vector maps: L2 over channels)."""
+    true per-pixel relative error ||d|| / ||ref|| over pixels with ||ref|| > min_norm (vector maps: L2 over channels)."""
     a = torch.as_tensor(a).detach().double().cpu()
     b = torch.as_tensor(b).detach().double().cpu()
     if a.numel() == 0:
@@ -82,7 +82,7 @@ def parity_metrics(a, b):
     d = (a - b).abs()
     a2, b2, d2 = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1), (a - b).reshape(a.shape[0], -1)
     nb = b2.norm(dim=-1)
-    sel = nb > 1e-2
+    sel = nb > min_norm
     relpix = float((d2.norm(dim=-1)[sel] / nb[sel]).max()) if bool(sel.any()) else 0.0
     return {"max_abs": float(d.max()), "max_rel_floor1": float((d / b.abs().clamp(min=1.0)).max()),
             "max_rel_pixel": relpix}

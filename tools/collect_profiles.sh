@@ -1,10 +1,10 @@
 #!/bin/bash
-# Copy one GPU visit's evidence (tools/r04_final.sh <tag> -> gpurun_out/) into the tracked profiles/ directory.
+# Copy one GPU visit's evidence (tools/r05_final.sh <tag> -> gpurun_out/) into the tracked profiles/ directory.
 # usage: tools/collect_profiles.sh <tag>
 set -u
 TAG="${1:?tag}"
 REPO="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"; G="$REPO/gpurun_out"; P="$REPO/profiles"; D="$G/prof_$TAG"
-for f in bench.json breakdown.json image_bench.json relight_bench.json train_bench.json parity_fullsize.json; do
+for f in bench.json breakdown.json image_bench.json relight_bench.json relight_host_masking_bench.json train_bench.json parity_fullsize.json precision_policy_tests.json script_hip.json bench_refcpu.json; do
   [ -f "$G/${TAG}_$f" ] && cp "$G/${TAG}_$f" "$P/${TAG}_$f"
 done
 [ -f "$G/${TAG}_tests.log" ] && cp "$G/${TAG}_tests.log" "$P/${TAG}_gpu_tests.log"
