@@ -678,11 +678,11 @@ def bench_image(a, embed=False):
         dist.destroy_process_group()
 
 
-def simulate_ranks(render_shard, n_rays, chunk, t1_s, record_bytes, max_world, passes=2, tiles=None, local_exchange_s=0.0):
+def simulate_ranks(render_shard, n_rays, chunk, t1_s, record_bytes, max_world, passes=3, tiles=None, local_exchange_s=0.0):
     """The multi-GPU row on ONE GPU: for W = 2, 4, ... <= max_world and every sharding (contiguous row
     tiles; interleaved tiles of 1, 2, 4 chunks) render each rank's shard of the W-rank job ALONE on this GPU -- what rank r would
     do on its own device, the field being replicated -- and time it (device drained around each shard; best of `passes` after
-    one untimed pass that lets the captured capacities settle).  Predicted time of the W-rank job = max_r t_r + exchange, where
+    two untimed passes that let the captured capacities settle).  Predicted time of the W-rank job = max_r t_r + exchange, where
     exchange = the measured local reassembly of the gathered records (`local_exchange_s`, the world = 1 figure) + the wire time
     of ONE all_gather_into_tensor over xGMI modelled at 60 % of the 153 GB/s per-link peak, every rank receiving (W - 1) shards
     over W - 1 links in parallel (MI355X_MICROARCH.md: fully connected, 7 links per GPU).  Predicted speed-up = t(1) / that.
@@ -698,7 +698,8 @@ def simulate_ranks(render_shard, n_rays, chunk, t1_s, record_bytes, max_world, p
             per = []
             for r in range(w):
                 mine = tdist.shard_rows(n_rays, r, w, tile)
-                render_shard(mine)                       # untimed: capacities / caches of this shard's chunking
+                render_shard(mine)                       # untimed, twice: capacities / caches / re-captures of this shard's chunking
+                render_shard(mine)
                 best = None
                 for _ in range(passes):
                     torch.cuda.synchronize()
@@ -841,7 +842,7 @@ def bench_relight(a, embed=False):
             mine_r = mine_r.to(device)
             parts = [chunk_pass(c, list(maps))[0] for c in torch.split(mine_r, a.rays) if c.numel()]
             return torch.cat(parts, dim=0) if parts else None
-        sim = simulate_ranks(render_shard, n, a.rays, elapsed / a.steps, 12 * len(maps), a.simulate_ranks, passes=1, tiles=[0, a.rays])
+        sim = simulate_ranks(render_shard, n, a.rays, elapsed / a.steps, 12 * len(maps), a.simulate_ranks, passes=2, tiles=[0, a.rays])
     roofline = parity = cpu = kernels = None
     if rank == 0 and not a.no_cpu_baseline:
         from oracle import tensoir_oracle as O          # checker / CPU baseline only

@@ -592,13 +592,14 @@ class TensorVMSplit(nn.Module):
         self._field_cache, self._field_key = keep, key
         return f
 
-    def packed_field_half(self):
+    def packed_field_half(self, _fresh=False):
         """TirFieldHalf: fp16 shadow (saturating casts) of the appearance planes / lines for the indirect-light gather
         (ops.vm_app_h16 / ops.indirect_fused), or None when the field is not 48 components wide.  Built with one launch, cached
         with the packed field (same key: any optimizer step, upsample, shrink or load rebuilds it).  The same launch measures
-        the abs-maxima the range guard needs (half_range())."""
+        the abs-maxima the range guard needs (half_range()).  _fresh: the caller has just called packed_field()."""
         from ._lib import TirFieldHalf
-        self.packed_field()
+        if not _fresh:
+            self.packed_field()
         keep = self._field_cache
         if "half" not in keep:
             if self.app_n_comp[0] != 48:
@@ -613,9 +614,10 @@ class TensorVMSplit(nn.Module):
                 keep["half_range"] = ops.HalfRange(absmax)
         return keep["half"][0] if keep["half"] is not None else None
 
-    def half_range(self):
-        """ops.HalfRange of the current fp16 shadow (None without one)."""
-        return self._field_cache.get("half_range") if self.packed_field_half() is not None else None
+    def half_range(self, _fresh=False):
+        """ops.HalfRange of the current fp16 shadow (None without one).  _fresh: the caller has just called packed_field() (the
+        key walk over the parameters is not repeated)."""
+        return self._field_cache.get("half_range") if self.packed_field_half(_fresh) is not None else None
 
     def indirect_precision(self):
         """What the indirect-light precision policy decided for this model so far (ops.INDIRECT_GUARD, relight._indirect_mode):

@@ -179,12 +179,15 @@ class AsyncCount:
 
 
 class AsyncFloats:
-    """A few device floats on their way to the host (AsyncCount for float tables): copy into pinned memory + event queued NOW."""
+    """A few device floats on their way to the host (AsyncCount for float tables): copy into pinned memory + event queued NOW.
+    Pinned buffers and events are recycled (a training step creates one of these per parameter version)."""
+    _free = []
 
     def __init__(self, t):
-        self.pin = torch.empty(t.numel(), dtype=torch.float32, pin_memory=True)
+        n = t.numel()
+        slot = next((k for k, (p, _) in enumerate(AsyncFloats._free) if p.numel() == n), None)
+        self.pin, self.ev = AsyncFloats._free.pop(slot) if slot is not None else (torch.empty(n, dtype=torch.float32, pin_memory=True), torch.cuda.Event())
         self.pin.copy_(t.view(-1), non_blocking=True)
-        self.ev = torch.cuda.Event()
         self.ev.record(torch.cuda.current_stream(t.device))
         self.value = None
 
@@ -194,8 +197,10 @@ class AsyncFloats:
     def get(self):
         if self.value is None:
             self.ev.synchronize()
-            self.value = [float(v) for v in self.pin]
-            self.pin = None
+            self.value = self.pin.tolist()
+            if len(AsyncFloats._free) < 8:
+                AsyncFloats._free.append((self.pin, self.ev))
+            self.pin = self.ev = None
         return self.value
 
 

@@ -63,7 +63,8 @@ def _indirect_state(tensoIR):
 
 def _indirect_key(tensoIR):
     """(parameter versions, parameter storage) of everything the indirect-light kernels read: appearance field + radiance decoder."""
-    tensoIR.packed_field()
+    if tensoIR._field_key is None:          # (callers inside a pass have just refreshed it: the key walk over ~35 parameters
+        tensoIR.packed_field()              #  costs ~70 us of host time, and the training loop is host-bound)
     tensoIR.renderModule.packed()
     fk = tensoIR._field_key[0]
     key = (fk, tensoIR.renderModule._key)
@@ -181,8 +182,8 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
             rec_ray, rec_w, rec_xyz = rec["ray"][:n_rows], rec["w"][:n_rows], rec["xyz"][:n_rows]
             # light index / view direction of a record = those of its ray (ray id -> point via idx_div,
             # ray id -> direction via aux_mod on the dense [point][direction] grid)
-            fh = tensoIR.packed_field_half() if (mode != "full" and ops.secondary_app_impl() == "h16") else None
-            rng = tensoIR.half_range() if (fh is not None and ops.INDIRECT_GUARD) else None
+            fh = tensoIR.packed_field_half(_fresh=True) if (mode != "full" and ops.secondary_app_impl() == "h16") else None
+            rng = tensoIR.half_range(_fresh=True) if (fh is not None and ops.INDIRECT_GUARD) else None
             if rng is not None and (mode == "probe" or rng.ready()) and not rng.ok():
                 # range guard (tir_pack_half_checked's contract): an fp16 product could overflow -> the primary-stage kernels
                 _set_verdict(tensoIR, "full", "range", {"bound": rng.bound, "maxima": rng.maxima})
