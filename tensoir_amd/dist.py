@@ -57,21 +57,41 @@ def unpack_records(rec: torch.Tensor) -> dict:
             "normals_orientation_loss_map": rec[:, 16:17], "rgb_with_brdf_map": rec[:, 20:23]}
 
 
+_LAYOUT = {}
+
+
+def _layout(n_rays: int, world: int, tile: int, device):
+    """(capacity, gather index [n_rays]) of a sharding, built once per (image size, world, tile, device) and kept on the device:
+    row i of the image is row `index[i]` of the all-gathered [world * capacity] record block.  (Rebuilding the per-rank index
+    tensors on the host for every image cost 0.5 - 4.7 ms of host arithmetic and pageable copies per image.)"""
+    key = (int(n_rays), int(world), int(tile), str(device))
+    hit = _LAYOUT.get(key)
+    if hit is None:
+        cap = shard_capacity(n_rays, world, tile)
+        index = torch.empty((n_rays,), dtype=torch.int64)
+        for r in range(world):
+            idx = shard_rows(n_rays, r, world, tile)
+            index[idx] = r * cap + torch.arange(idx.numel(), dtype=torch.int64)
+        if len(_LAYOUT) > 16:
+            _LAYOUT.clear()
+        hit = _LAYOUT[key] = (cap, index.to(device))
+    return hit
+
+
 def gather_records(local: torch.Tensor, n_rays: int, rank: int, world: int, tile: int = 0, group=None):
     """All-gather the per-rank record rows and put them back in image order.  local: [n_local, RECORD]."""
-    cap = shard_capacity(n_rays, world, tile)
-    buf = torch.zeros((cap, local.shape[1]), dtype=local.dtype, device=local.device)
-    buf[: local.shape[0]] = local
-    if world == 1:
-        gathered = buf.unsqueeze(0)
+    cap, index = _layout(n_rays, world, tile, local.device)
+    if world == 1 and local.shape[0] == cap:
+        gathered = local
     else:
-        gathered = torch.empty((world, cap, local.shape[1]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(gathered.view(world * cap, -1), buf, group=group)
-    out = torch.empty((n_rays, local.shape[1]), dtype=local.dtype, device=local.device)
-    for r in range(world):
-        idx = shard_rows(n_rays, r, world, tile).to(local.device)
-        out[idx] = gathered[r, : idx.numel()]
-    return out
+        buf = torch.zeros((cap, local.shape[1]), dtype=local.dtype, device=local.device)
+        buf[: local.shape[0]] = local
+        if world == 1:
+            gathered = buf
+        else:
+            gathered = torch.empty((world * cap, local.shape[1]), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(gathered, buf, group=group)
+    return gathered.index_select(0, index)
 
 
 def _render_chunks(render_fn, rays, light_idx, mine, chunk):

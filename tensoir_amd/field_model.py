@@ -156,8 +156,8 @@ class _Decoder(nn.Module):
         self._key = None
 
     def packed(self):
-        ps = [self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias,
-              self.mlp[4].weight, self.mlp[4].bias]
+        mods = self.__dict__["_modules"]["mlp"]._modules            # (plain dictionary lookups: see _field_params)
+        ps = [mods[i]._parameters[n] for i in ("0", "2", "4") for n in ("weight", "bias")]
         key = tuple((p.data_ptr(), p._version) for p in ps)
         if key != self._key:
             if self.feape != self.pe_aux:
@@ -535,8 +535,15 @@ class TensorVMSplit(nn.Module):
 
     # ---- packed shadow of the parameters -----------------------------------------------------------
     def _field_params(self):
-        return (list(self.density_plane) + list(self.density_line) + list(self.app_plane) +
-                list(self.app_line) + [self.basis_mat.weight, self.light_line.weight])
+        # (the ParameterLists' own dictionaries: iterating a ParameterList goes through nn.Module.__getattr__ and string index
+        #  conversions per element -- 26 slow lookups per call, three calls per training step: 0.38 ms of host time per step)
+        d = self.__dict__["_parameters"], self.__dict__["_modules"]
+        out = []
+        for name in ("density_plane", "density_line", "app_plane", "app_line"):
+            out.extend(d[1][name]._parameters.values())
+        out.append(d[1]["basis_mat"]._parameters["weight"])
+        out.append(d[1]["light_line"]._parameters["weight"])
+        return out
 
     def packed_field(self) -> TirField:
         """The TirField descriptor (+ the small derived tables: basis_mat^T, mean light row, occupancy bits); rebuilt
