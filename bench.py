@@ -698,14 +698,15 @@ def simulate_ranks(render_shard, n_rays, chunk, t1_s, record_bytes, max_world, p
             per = []
             for r in range(w):
                 mine = tdist.shard_rows(n_rays, r, w, tile)
+                drain = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)
                 render_shard(mine)                       # untimed, twice: capacities / caches / re-captures of this shard's chunking
                 render_shard(mine)
                 best = None
                 for _ in range(passes):
-                    torch.cuda.synchronize()
+                    drain()
                     t0 = time.perf_counter()
                     render_shard(mine)
-                    torch.cuda.synchronize()
+                    drain()
                     dt = time.perf_counter() - t0
                     best = dt if best is None else min(best, dt)
                 per.append(best)

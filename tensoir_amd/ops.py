@@ -217,15 +217,19 @@ class HalfRange:
     def ready(self):
         return self.result is not None or self.pending.ready()
 
+    @staticmethod
+    def judge(m, lim):
+        """m = [max|plane_0..2|, max|line_0..2|, max|light rows|, max|basis_mat|] -> (ok, bound).  The packed-fp16 gather forms
+        (plane x line) in fp16 BEFORE the light row is applied (h16_chunk_pk), so the bound carries max(1, light).  A NaN maximum
+        fails every comparison."""
+        bound = max(m[i] * m[3 + i] for i in range(3)) * max(1.0, m[6])
+        return bool(bound < lim and m[7] < lim and all(v < lim for v in m[:7])), bound
+
     def ok(self):
         if self.result is None:
             m = self.pending.get()
             self.maxima = {"plane": m[0:3], "line": m[3:6], "light": m[6], "basis": m[7]}
-            # the packed-fp16 gather forms (plane x line) in fp16 BEFORE the light row is applied (h16_chunk_pk)
-            self.bound = max(m[i] * m[3 + i] for i in range(3)) * max(1.0, m[6])
-            lim = INDIRECT_PROBE["range"]
-            # (a NaN maximum fails both comparisons)
-            self.result = bool(self.bound < lim and m[7] < lim and all(v < lim for v in m[:7]))
+            self.result, self.bound = HalfRange.judge(m, INDIRECT_PROBE["range"])
         return self.result
 
 
