@@ -834,12 +834,6 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins_a, const int
                             float pz = add_rn(o[2], mul_rn(d[2], z));
                             valid = sample_valid(f, px, py, pz, x, y, zz);
                         }
-#ifndef TIR_NO_EMPTY_SKIP
-                        // no sample of either ray passes the box / occupancy cull: every alpha of this step is 0, i.e. v = 1 - 0 + 1e-10 == 1
-                        // in fp32, the prefix product is 1, T, the sums, the record count and `done` stay as they are (wreg is already
-                        // 0): the softplus / exp / scan / ballot tail of the step (~55 VALU) is skipped -- same results bit for bit
-                        if (!__any(valid)) continue;
-#endif
                         const float sigma = wave_sigma_lds<C4>(f, ll, valid, x, y, zz, ws);
                         float w = 0.0f, v = 1.0f;
                         if (on) {
