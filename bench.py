@@ -87,7 +87,7 @@ def parse():
                          "(3 light rotations, 1036 samples per ray) sharded over the ranks, one all-gather per image (strong scaling)")
     ap.add_argument("--tile", type=int, default=-1,
                     help="image workload: 0 = contiguous row tiles, >0 = interleaved tiles of that many rays, -1 (default) = "
-                         "interleaved tiles of two chunks when there is more than one rank (background rows finish early: with "
+                         "interleaved tiles of one chunk when there is more than one rank (background rows finish early: with "
                          "row tiles the ranks that hold the object set the pace, SURVEY 8e), row tiles on one rank")
     ap.add_argument("--image-side", type=int, default=800)
     ap.add_argument("--allow-shared-gpu", action="store_true", help="let several ranks share one GPU (gloo plumbing tests only)")
@@ -555,8 +555,8 @@ def bench_image(a, embed=False):
     local = local_device(a)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if a.tile < 0:      # auto: interleaved tiles of two chunks as soon as the image is shared (profiles/r05_predicted_scaling.json:
-        a.tile = 2 * a.rays if world > 1 else 0      # 8 ranks -> 7.3x predicted; one chunk 6.9x, four 6.7x, row tiles 5.5x)
+    if a.tile < 0:      # auto: interleaved chunk-sized tiles as soon as the image is shared (profiles/r05_predicted_scaling.json:
+        a.tile = a.rays if world > 1 else 0          # 8 ranks -> 7.5-7.8x predicted; two chunks 7.5-7.6x, four 7.3x, row tiles 5.6x)
     assert _lib.lib().tir_device_check() == 0
     use_dist = world > 1 or a.force_dist
     ck = synth.make_checkpoint(grid=(a.grid,) * 3, seed=20211202, light_rotation=("000", "120", "240"))
