@@ -386,6 +386,10 @@ def roofline_object(r, pmc_traffic, pmc_issue, pmc_meta=None):
     elif r["bound"] == "valu":
         o["peak_source"] = (f"VALU issue ceiling {VALU_PEAK_WAVE_INSTR / 1e9:.1f} G wave64 instructions/s (256 CUs x 4 SIMDs x 2.4 GHz / 4) over the "
                             f"algorithm's {VALU_FLOOR_PER_DENSITY_SAMPLE:.2f} FMA instructions per valid sample (3 planes x 16 channels x 7 / 64 lanes)")
+        # the same ceiling if every FMA of the floor were a packed v_pk_fma_f32 (two channels per instruction: the kernel's
+        # interpolation IS packed; the product-sum and everything per sample is not) -- the stricter yardstick
+        o["packed_fma_floor"] = {"peak": round(o["peak"] * 2.0, 2), "frac": round(o["frac"] / 2.0, 4), "unit": o.get("unit"),
+                                 "note": f"{VALU_FLOOR_PER_DENSITY_SAMPLE / 2:.3f} packed instructions per valid sample (42 per 16-sample pass)"}
         o["l2_model"] = {"bound": "l2", "achieved": round(r["gather_GBps"], 2), "peak": L2_PEAK_GBS, "unit": "GB/s",
                          "frac": round(r["gather_GBps"] / L2_PEAK_GBS, 4), "note": "gather bytes through the vector L1s (density lines staged in LDS "
                          "are counted although they never reach the L1)"}
