@@ -120,6 +120,45 @@ def test_bare_compute_radiance_uses_the_record_level_estimate():
     assert "f16" in seen, seen           # (as initialised the estimate is ~4e-6)
 
 
+@torch.no_grad()
+def test_graph_replay_follows_the_verdict():
+    """GraphedRenderer under the auto policy: the eager warm-up passes establish the verdict, the capture bakes the kernels of
+    that verdict in, and a parameter change (new version -> new verdict -> stale graph) re-captures.  Scene as initialised: f16;
+    radiance decoder x4: the self-check fails and the graph replays the primary-stage kernels -- in both cases the replayed maps
+    equal the eager call's, and equal the forced-policy render of the verdict."""
+    import contextlib
+    import io
+
+    import tensoir_amd
+    from tensoir_amd import Renderer_TensoIR_train, synth
+    from tensoir_amd.graph import GraphedRenderer
+    ck = synth.make_checkpoint(grid=(96,) * 3, seed=20211202)
+    m = tensoir_amd.model_from_checkpoint(ck, "cuda", envmap_h=8, envmap_w=16)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m.updateAlphaMask((96, 96, 96))
+    rays = synth.make_rays(48, 48).cuda()
+    lidx = torch.zeros(rays.shape[0], 1, dtype=torch.int32, device="cuda")
+    kw = dict(N_samples=-1, white_bg=True, is_train=False, is_relight=True, sample_method="fixed_envirmap", device="cuda", args=P.ARGS)
+    with P.policy(True):
+        gr = GraphedRenderer(m, rays.shape[0], args=P.ARGS)
+        seen = []
+        for scale in (1.0, 4.0):
+            if scale != 1.0:
+                for layer in (0, 2, 4):
+                    m.renderModule.mlp[layer].weight.mul_(scale)                  # in place: same storage, next version
+            got = gr(rays, lidx)
+            dec = m.indirect_precision()
+            seen.append(dec["mode"])
+            want = Renderer_TensoIR_train(rays, None, lidx, m, **kw)
+            assert torch.equal(got["rgb_with_brdf_map"], want["rgb_with_brdf_map"]) and torch.equal(got["rgb_map"], want["rgb_map"]), scale
+            assert torch.equal(gr(rays, lidx)["rgb_with_brdf_map"], want["rgb_with_brdf_map"])          # a second replay of the same graph
+            with P.policy(False, *(("f16", "h16") if dec["mode"] == "f16" else (None, None))):
+                forced = Renderer_TensoIR_train(rays, None, lidx, m, **kw)
+            assert torch.equal(forced["rgb_with_brdf_map"], want["rgb_with_brdf_map"]), (scale, dec)
+            REPORT[f"graph replay, decoder x{scale:g}"] = dec
+        assert seen == ["f16", "full"] and gr.captures >= 2, (seen, gr.captures)
+
+
 def test_pack_half_saturates_and_reports_maxima():
     """tir_pack_half_checked: saturating casts, per-table abs-maxima, scan-only tables, NaN reporting."""
     from tensoir_amd import ops
