@@ -85,6 +85,48 @@ def test_version_and_errors(lib):
     assert lib.tir_mlp_packed_floats(27, 2, 64, 3) == -1002
 
 
+def test_round5_entry_points_validate_before_any_device_work(lib):
+    """The entries added in round 5 (and the guards ADVICE r4 asked for) reject bad arguments on the host: plane element
+    offsets of the fp16 gathers (32-bit, 24-bit index multiplies), tir_pack_half_checked's report buffer, the device-bounded C5
+    entries and the compaction / compose kernels."""
+    from tensoir_amd import _lib
+    import torch
+    # a field whose plane would need > 2^31 element offsets / a row pitch beyond the 24-bit multiplier: UNSUPPORTED, not garbage
+    keep = torch.zeros(64, dtype=torch.float32)                       # any non-null, 16-byte aligned host address: never dereferenced
+    ptr = keep.data_ptr()
+    assert ptr % 16 == 0
+    m = _lib.TirMlp(ptr, 27, 2, 128, 3, 0, 0)
+    for grid, want in (((70000, 70000, 8), -1002), ((400000, 8, 8), -1002)):
+        f = _lib.TirField()
+        f.grid[:] = grid
+        f.n_dcomp, f.n_acomp, f.app_dim, f.n_lights = 16, 48, 27, 1
+        f.basis_t = f.light_line = f.light_mean = ptr
+        fh = _lib.TirFieldHalf()
+        for i in range(3):
+            fh.aplane[i] = fh.aline[i] = ptr
+        assert lib.tir_vm_app_fwd_h16(C.byref(f), C.byref(fh), ptr, ptr, None, ptr, 32, 0, 10, None, None) == want, grid
+        assert lib.tir_indirect_fused_fwd(C.byref(f), C.byref(fh), C.byref(m), ptr, ptr, None, 1, 1, ptr, ptr, 10, None, None) == want, grid
+    # tir_pack_half_checked: the report buffer is mandatory, a scan-only table needs it, at most TIR_HALF_MAX_JOBS tables
+    one = (C.c_void_p * 1)(ptr)
+    none = (C.c_void_p * 1)(None)
+    cnt = (C.c_int64 * 1)(8)
+    assert lib.tir_pack_half_checked(one, one, cnt, 1, None, None) == -1001
+    assert lib.tir_pack_half(one, none, cnt, 1, None) == -1001                    # nothing to write, nowhere to report
+    nine = (C.c_void_p * 9)(*([ptr] * 9))
+    assert lib.tir_pack_half_checked(nine, nine, (C.c_int64 * 9)(*([8] * 9)), 9, ptr, None) == -1001
+    assert lib.tir_pack_half_checked(one, one, (C.c_int64 * 1)(0), 1, ptr, None) == 0          # empty tables: nothing to do
+    # C5 chunk entries
+    assert lib.tir_surface_compact(None, None, 4, 0.5, None, None, None, None, None, None, None, None, None) == -1001
+    assert lib.tir_surface_compact(ptr, ptr, -1, 0.5, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, None) == -1001
+    assert lib.tir_env_compose(ptr, 8, 16, ptr, 2, 4, ptr, ptr, ptr, 3, None) == -1001        # dir_stride < 3
+    assert lib.tir_env_compose(ptr, 8, 16, ptr, 6, 4, None, ptr, ptr, 3, None) == -1001       # no slot map
+    assert lib.tir_env_compose(ptr, 8, 16, ptr, 6, 0, ptr, ptr, ptr, 3, None) == 0            # n = 0
+    assert lib.tir_relight_importance_cells_packed_n(ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, 0, 512, ptr, None, None) == 0
+    assert lib.tir_relight_importance_cells_packed_n(ptr, ptr, ptr, ptr, ptr, ptr, None, ptr, 4, 512, ptr, None, None) == -1001
+    assert lib.tir_env_sample_setup_list_n(ptr, ptr, 8, 16, ptr, 8, ptr, 4, 512, 1, 1, 16, 17, 512, None, None, 0, 0, ptr, ptr, ptr, ptr,
+                                           None, None) == -1002                                # 16 x 17 = 272 bins > 255
+
+
 def test_no_gpu_no_fallback(lib):
     import torch
     if torch.cuda.is_available():
