@@ -68,6 +68,54 @@ static void run(const char* name, const float* tab, unsigned cells, int coherent
            taps * 192 / ms / 1e9);
 }
 
+// Round 5: the same question for the fp16 shadow taps of the fused indirect kernel (96 B per tap, 48 halves):
+//   E  2 lanes x 16 B per sample, 3 instructions per tap (32 samples x 32 B per instruction)   -- k_indirect_fused today
+//   F  6 of 8 lanes x 16 B per sample, 1 instruction per tap (8 samples x 96 B per instruction)
+// 32 samples per wave iteration, 4 taps each; cells of 96 bytes.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_gather_h(const uint4* __restrict__ tab, unsigned cells, int iters, int coherent,
+                                                  float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    unsigned acc = 0;
+    constexpr int LPS = MODE == 0 ? 2 : 8, SPI = 64 / LPS;
+    const int sl = lane / LPS, c = lane % LPS;
+    for (int it = 0; it < iters; ++it) {
+        for (int sb = 0; sb < 32; sb += SPI) {
+            const unsigned sidx = (wave * 4096u + it) * 32u + sb + sl;
+            unsigned cell = coherent ? (hash(wave) + (sidx & 0xffffu) / 2u) % (cells - 400u) : hash(sidx) % (cells - 400u);
+            const unsigned offs[4] = {cell, cell + 1u, cell + 300u, cell + 301u};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint4* p = tab + (size_t)offs[t] * 6u;          // 6 x 16 B per cell
+                if (MODE == 0) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) { const uint4 v = p[2 * q + c]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+                } else if (c < 6) { const uint4 v = p[c]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+            }
+        }
+    }
+    if (acc == 0x12345678u) out[0] = (float)acc;
+}
+
+template <int MODE>
+static void run_h(const char* name, const uint4* tab, unsigned cells, int coherent, float* out) {
+    const int blocks = 2048, iters = 24;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k_gather_h<MODE>), dim3(blocks), dim3(256), 0, 0, tab, cells, 2, coherent, out);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k_gather_h<MODE>), dim3(blocks), dim3(256), 0, 0, tab, cells, iters, coherent, out);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double taps = (double)blocks * 4 * iters * 32 * 4;
+    printf("%-44s coherent=%d %8.3f ms  %7.2f G taps/s  %7.2f TB/s of tap bytes\n", name, coherent, ms, taps / ms / 1e6,
+           taps * 96 / ms / 1e9);
+}
+
 int main() {
     const unsigned cells = 300u * 300u * 3u;        // three 300x300 planes of 48 channels = 52 MB
     float *tab, *out;
@@ -79,6 +127,10 @@ int main() {
         run<1>("B  12/16 lanes x float4, 1 instr/tap", tab, cells, coh, out);
         run<2>("C  16 lanes x dword, 3 instr/tap", tab, cells, coh, out);
         run<3>("D  8 lanes x float4, 128 B + 64 B", tab, cells, coh, out);
+    }
+    for (int coh = 0; coh < 2; ++coh) {            // fp16 taps: the same table read as 96-B cells (twice as many)
+        run_h<0>("E  fp16: 2 lanes x 16 B, 3 instr/tap", reinterpret_cast<const uint4*>(tab), cells * 2u, coh, out);
+        run_h<1>("F  fp16: 6/8 lanes x 16 B, 1 instr/tap", reinterpret_cast<const uint4*>(tab), cells * 2u, coh, out);
     }
     (void)hipFree(tab); (void)hipFree(out);
     return 0;
