@@ -78,7 +78,9 @@ __global__ void __launch_bounds__(256) k_gather_h(const uint4* __restrict__ tab,
     const int lane = threadIdx.x & 63;
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     unsigned acc = 0;
-    constexpr int LPS = MODE == 0 ? 2 : 8, SPI = 64 / LPS;
+    //   G  4 lanes x 16 B (64 B of the tap) + lanes 0-1 x 16 B (the remaining 32 B): 16 samples per instruction
+    //   H  8 lanes x 12 B (global_load_dwordx3): the whole tap per instruction, every lane active, 8 samples per instruction
+    constexpr int LPS = MODE == 0 ? 2 : (MODE == 2 ? 4 : 8), SPI = 64 / LPS;
     const int sl = lane / LPS, c = lane % LPS;
     for (int it = 0; it < iters; ++it) {
         for (int sb = 0; sb < 32; sb += SPI) {
@@ -91,7 +93,15 @@ __global__ void __launch_bounds__(256) k_gather_h(const uint4* __restrict__ tab,
                 if (MODE == 0) {
 #pragma unroll
                     for (int q = 0; q < 3; ++q) { const uint4 v = p[2 * q + c]; acc += v.x ^ v.y ^ v.z ^ v.w; }
-                } else if (c < 6) { const uint4 v = p[c]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+                } else if (MODE == 1) {
+                    if (c < 6) { const uint4 v = p[c]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+                } else if (MODE == 2) {
+                    { const uint4 v = p[c]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+                    if (c < 2) { const uint4 v = p[4 + c]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+                } else {
+                    const uint3 v = *reinterpret_cast<const uint3*>(reinterpret_cast<const unsigned*>(p) + 3 * c);
+                    acc += v.x ^ v.y ^ v.z;
+                }
             }
         }
     }
@@ -131,6 +141,8 @@ int main() {
     for (int coh = 0; coh < 2; ++coh) {            // fp16 taps: the same table read as 96-B cells (twice as many)
         run_h<0>("E  fp16: 2 lanes x 16 B, 3 instr/tap", reinterpret_cast<const uint4*>(tab), cells * 2u, coh, out);
         run_h<1>("F  fp16: 6/8 lanes x 16 B, 1 instr/tap", reinterpret_cast<const uint4*>(tab), cells * 2u, coh, out);
+        run_h<2>("G  fp16: 4 lanes x 16 B + 2 lanes x 16 B", reinterpret_cast<const uint4*>(tab), cells * 2u, coh, out);
+        run_h<3>("H  fp16: 8 lanes x 12 B, 1 instr/tap", reinterpret_cast<const uint4*>(tab), cells * 2u, coh, out);
     }
     (void)hipFree(tab); (void)hipFree(out);
     return 0;
