@@ -923,27 +923,6 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
             lrow16 = LT16 + li * (3 * CA);
 #endif
         }
-#ifdef TIR_FUS_G4
-        // G4 lane mapping of the gather (round 5, tools/gather_bench.hip modes E / G): FOUR lanes per record, each instruction reads
-        // 64 contiguous bytes of 16 records' taps (chunks 0-3), a second one the remaining 32 B on lanes 0-1 (chunks 4-5) -- the
-        // texture path serves such an instruction ~3.6x faster than one that touches 32 records x 32 B (the two-lane mapping).  Two
-        // passes of 16 records per wave and tile.
-        const int g4q = lane >> 2, g4c = lane & 3;
-        float pp[2][3];
-        const _Float16* lrow16p[2];
-        const float* lrowp[2];
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            const int64_t s4 = r0 + 16 * ps + g4q, s4c = s4 < n ? s4 : n - 1;
-            pp[ps][0] = xyz[3 * s4c]; pp[ps][1] = xyz[3 * s4c + 1]; pp[ps][2] = xyz[3 * s4c + 2];
-            unsigned lsel = rec_map ? (unsigned)rec_map[s4c] : (unsigned)s4c, rem_;
-            lsel = udiv(lsel, by_div, rem_);
-            int li = light_idx[lsel];
-            li = min(max(li, 0), f.n_lights - 1);
-            lrowp[ps] = n_lt ? LT + li * (3 * CA) : f.light_line + (size_t)li * (3 * CA);
-            lrow16p[ps] = LT16 + li * (3 * CA);
-        }
-#endif
         // decoder role: this lane's record and its aux-table row
         const int64_t sd = r0 + sl, sdc = sd < n ? sd : n - 1;
         unsigned ai = rec_map ? (unsigned)rec_map[sdc] : (unsigned)sdc;
@@ -964,61 +943,6 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
         };
 #pragma unroll
         for (int k = 0; k < 3; ++k) {      // unrolled: with a run-time k the coordinate selects below become a scratch table (72 B stored per lane and tile = 0.4 GB of HBM writes per launch, measured)
-#ifdef TIR_FUS_G4
-            {
-                const int H = f.grid[(k == 0) ? 1 : 2], W = f.grid[(k == 2) ? 1 : 0], R = f.grid[2 - k];
-                const _Float16* pl = reinterpret_cast<const _Float16*>(fh.aplane[k]);
-                const _Float16* ln = reinterpret_cast<const _Float16*>(fh.aline[k]);
-                const unsigned pitch = (unsigned)(W * CA);                                    // wave-uniform
-#pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {      // the two passes one after the other: 12 tap registers x 4 in flight (both at once spilled)
-                    const float* p = pp[ps];
-                    const float u = (k == 2) ? p[1] : p[0], v = (k == 0) ? p[1] : p[2], w = (k == 0) ? p[2] : ((k == 1) ? p[1] : p[0]);
-                    Tap1 tx = make_tap(u, W), ty = make_tap(v, H), tl = make_tap(w, R);
-                    const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
-                    const unsigned q0 = mul_u24((unsigned)ty.i0, pitch), q1 = mul_u24((unsigned)ty.i1, pitch);
-                    const unsigned x0 = mul_u24((unsigned)tx.i0, CA) + 8 * g4c, x1 = mul_u24((unsigned)tx.i1, CA) + 8 * g4c;
-                    const _Float16* p00 = pl + (q0 + x0);
-                    const _Float16* p01 = pl + (q0 + x1);
-                    const _Float16* p10 = pl + (q1 + x0);
-                    const _Float16* p11 = pl + (q1 + x1);
-                    const _Float16* l0 = ln + (mul_u24((unsigned)tl.i0, CA) + 8 * g4c);
-                    const _Float16* l1 = ln + (mul_u24((unsigned)tl.i1, CA) + 8 * g4c);
-                    uint4 ta[2], tb[2], tc[2], td[2], te[2], tg[2];                         // [first 64 B of the tap | remaining 32 B]
-                    ta[0] = *reinterpret_cast<const uint4*>(p00); tb[0] = *reinterpret_cast<const uint4*>(p01);
-                    tc[0] = *reinterpret_cast<const uint4*>(p10); td[0] = *reinterpret_cast<const uint4*>(p11);
-                    te[0] = *reinterpret_cast<const uint4*>(l0);  tg[0] = *reinterpret_cast<const uint4*>(l1);
-                    ta[1] = tb[1] = tc[1] = td[1] = te[1] = tg[1] = make_uint4(0u, 0u, 0u, 0u);
-                    if (g4c < 2) {                                                         // chunks 4 and 5: 32 halves further
-                        ta[1] = *reinterpret_cast<const uint4*>(p00 + 32); tb[1] = *reinterpret_cast<const uint4*>(p01 + 32);
-                        tc[1] = *reinterpret_cast<const uint4*>(p10 + 32); td[1] = *reinterpret_cast<const uint4*>(p11 + 32);
-                        te[1] = *reinterpret_cast<const uint4*>(l0 + 32);  tg[1] = *reinterpret_cast<const uint4*>(l1 + 32);
-                    }
-                    const tir_h2 hw00 = {(_Float16)w00, (_Float16)w00}, hw01 = {(_Float16)w01, (_Float16)w01}, hw10 = {(_Float16)w10, (_Float16)w10},
-                                 hw11 = {(_Float16)w11, (_Float16)w11}, hl0 = {(_Float16)tl.w0, (_Float16)tl.w0}, hl1 = {(_Float16)tl.w1, (_Float16)tl.w1};
-                    __builtin_amdgcn_sched_barrier(0);
-                    _Float16* xr = X + (16 * ps + g4q) * FUS_XH;
-                    const int ch0 = 8 * g4c;
-                    *reinterpret_cast<uint4*>(xr + ch0) =
-                        h16_chunk_pk(ta[0], tb[0], tc[0], td[0], te[0], tg[0], hw00, hw01, hw10, hw11, hl0, hl1,
-                                     n_lt ? *reinterpret_cast<const uint4*>(lrow16p[ps] + k * CA + ch0) : pack8_half(lrowp[ps] + k * CA + ch0));
-                    if (g4c < 2)
-                        *reinterpret_cast<uint4*>(xr + 32 + ch0) =
-                            h16_chunk_pk(ta[1], tb[1], tc[1], td[1], te[1], tg[1], hw00, hw01, hw10, hw11, hl0, hl1,
-                                         n_lt ? *reinterpret_cast<const uint4*>(lrow16p[ps] + k * CA + 32 + ch0)
-                                              : pack8_half(lrowp[ps] + k * CA + 32 + ch0));
-                }
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const f16x8 a = Wh[((k * 3 + t) * 2 + h) * 32 + sl];
-                    const f16x8 b = *reinterpret_cast<const f16x8*>(X + sl * FUS_XH + 16 * t + 8 * h);
-                    facc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, facc, 0, 0, 0);
-                }
-                __builtin_amdgcn_wave_barrier();
-                continue;
-            }
-#endif
             const int H = f.grid[(k == 0) ? 1 : 2], W = f.grid[(k == 2) ? 1 : 0], R = f.grid[2 - k];
             const float u = (k == 2) ? p[1] : p[0], v = (k == 0) ? p[1] : p[2], w = (k == 0) ? p[2] : ((k == 1) ? p[1] : p[0]);
             Tap1 tx = make_tap(u, W), ty = make_tap(v, H), tl = make_tap(w, R);
