@@ -41,7 +41,9 @@ head -24 "$P/summary.txt"
 prune; du -sh "$P" "$OUT"
 cd "$REPO"
 timeout -k 5 600 python tools/r05_precision.py > "$OUT/${TAG}_precision.log" 2>&1; echo "precision rc=$?"
-timeout -k 5 900 python bench.py --breakdown "$OUT/${TAG}_breakdown.json" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
+# (the default line as the driver runs it: no checkout -> the oracle is the CPU baseline; the line with the staged reference as
+#  baseline follows at the end as ${TAG}_bench_refcpu.json)
+env -u TENSOIR_REFERENCE timeout -k 5 900 python bench.py --breakdown "$OUT/${TAG}_breakdown.json" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err"
 echo "bench rc=$?"; tail -c 500 "$OUT/${TAG}_bench.json"; echo; tail -3 "$OUT/${TAG}_bench.err"
 timeout -k 5 500 python bench.py --workload image --simulate-ranks 8 > "$OUT/${TAG}_image_bench.json" 2> "$OUT/${TAG}_image_bench.err"; echo "image rc=$?"
 timeout -k 5 500 python bench.py --workload relight --simulate-ranks 8 > "$OUT/${TAG}_relight_bench.json" 2> "$OUT/${TAG}_relight_bench.err"; echo "relight rc=$?"
