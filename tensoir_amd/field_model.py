@@ -8,6 +8,7 @@ up-sampling / shrinking, checkpoint I/O.
 """
 from __future__ import annotations
 
+import functools
 import math
 import time
 
@@ -344,9 +345,11 @@ class TensorVMSplit(nn.Module):
                                                       act_net=nn.Sigmoid()).to(device)
 
     @staticmethod
+    @functools.lru_cache(maxsize=16)
     def _equirect_cells(rows, cols, row_hi, row_step):
         """Cell centres of a rows x cols equirect grid: the row coordinate runs row_hi - step/2 .. -row_hi + step/2, the azimuth
-        pi - lng/2 .. -pi + lng/2 (the reference's orientation, models/tensorBase_rotated_lights.py:437-441)."""
+        pi - lng/2 .. -pi + lng/2 (the reference's orientation, models/tensorBase_rotated_lights.py:437-441).  Host tensors,
+        the same for every call with the same grid (the stratified sampler asks once per training step): cached, never written to."""
         lng = 2 * np.pi / cols
         return torch.meshgrid([torch.linspace(row_hi - 0.5 * row_step, -row_hi + 0.5 * row_step, rows),
                                torch.linspace(np.pi - 0.5 * lng, -np.pi + 0.5 * lng, cols)], indexing="ij") + (lng,)

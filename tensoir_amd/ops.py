@@ -1330,6 +1330,22 @@ def adam_step(entries, beta1, beta2, eps):
           FA(*[e[6] for e in entries]), float(beta1), float(beta2), float(eps), _stream())
 
 
+def adam_tables(triples):
+    """The argument tables of tir_adam_step for a FIXED parameter list [(p, m, v)]: parameter / moment pointers and element counts
+    filled in, gradient pointers and the three per-step float columns left for the caller (tensoir_amd.optim.Adam._fast_step).
+    -> (p, m, v, numel, g, lr, bias_correction1, bias_correction2) ctypes arrays."""
+    n = len(triples)
+    PA, FA, LA = C.c_void_p * n, C.c_float * n, C.c_int64 * n
+    return (PA(*[t[0].data_ptr() for t in triples]), PA(*[t[1].data_ptr() for t in triples]), PA(*[t[2].data_ptr() for t in triples]),
+            LA(*[t[0].numel() for t in triples]), PA(), FA(), FA(), FA())
+
+
+def adam_step_tables(n, tables, beta1, beta2, eps):
+    """tir_adam_step on prepared tables (adam_tables; the library copies them into the launch: they can be refilled at once)."""
+    p, m, v, numel, g, lr, b1, b2 = tables
+    _call("tir_adam_step", n, p, g, m, v, numel, lr, b1, b2, float(beta1), float(beta2), float(eps), _stream())
+
+
 def shade_integrate_bwd(maps, rays, dirs, light_idx, vis, indirect, env, weight_d, equal_area, use_srgb, acc_thres,
                         g_out):
     maps = f32(maps, "maps", MAP_STRIDE)

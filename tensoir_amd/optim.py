@@ -37,6 +37,17 @@ def _dense_key(t):
     return _dense_key_of(tuple(t.shape), t.stride())
 
 
+class _Rec:
+    """What `Adam.step` knows about one parameter after a first (fully checked) step."""
+    __slots__ = ("p", "ptr", "stride", "state", "step_t", "step_np", "m", "v")
+
+
+class _Plan:
+    """The optimizer's parameter list as of its last fully checked step: static pointer tables of the one-launch kernel and the
+    identities that must still hold for them to be valid (see Adam._fast_step)."""
+    __slots__ = ("state_obj", "recs", "betas", "eps", "tables", "touched")
+
+
 class Adam(_TorchAdam):
     """torch.optim.Adam with a single-launch HIP `step()` (see the module docstring)."""
 
@@ -46,8 +57,68 @@ class Adam(_TorchAdam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if not self._fast_step():
+            self._checked_step()
+        return loss
+
+    def _fast_step(self) -> bool:
+        """The steady state of a training loop: the same parameters, moments and options as in the last fully checked step, fresh
+        gradients.  The host side of a step is then ~35 identity checks and the gradient pointers (the loop is host-bound: the
+        checked path costs 0.35 ms per step on the reference's ~35 per-tensor groups).  False = something differs (a parameter
+        without gradient, another layout, a reloaded state, an option) and NOTHING has been changed: the caller takes the checked
+        path, which also rebuilds the plan."""
+        plan = self.__dict__.get("_tir_plan")
+        if plan is None or plan.state_obj is not self.state:
+            return False
+        recs, betas, eps = plan.recs, plan.betas, plan.eps
+        n_rec, i = len(recs), 0
+        f32, strided = torch.float32, torch.strided
+        grads, lrs = [], []
+        for group in self.param_groups:
+            if (group.get("amsgrad") or group.get("maximize") or group.get("capturable") or group.get("differentiable")
+                    or group.get("weight_decay", 0) != 0 or group["eps"] != eps):
+                return False
+            b = group["betas"]
+            if b is not betas and tuple(b) != betas:
+                return False
+            lr = float(group["lr"])
+            for p in group["params"]:
+                if i >= n_rec:
+                    return False
+                rec = recs[i]
+                i += 1
+                g = p.grad
+                if (rec.p is not p or g is None or g.dtype is not f32 or g.layout is not strided or not g.is_cuda
+                        or g.stride() != rec.stride or p.stride() != rec.stride or p.data_ptr() != rec.ptr):
+                    return False
+                st = rec.state
+                if st.get("step") is not rec.step_t or st.get("exp_avg") is not rec.m or st.get("exp_avg_sq") is not rec.v:
+                    return False
+                grads.append(g)
+                lrs.append(lr)
+        if i != n_rec:
+            return False
+        # ---- every check has passed: step counts, the three per-step columns of the kernel's table, the launch ----
+        PA_g, F_lr, F_b1, F_b2 = plan.tables[4:]
+        b1, b2 = betas
+        corr = {}
+        for j, rec in enumerate(recs):
+            t = float(rec.step_np) + 1.0
+            rec.step_np[()] = t                       # state["step"] += 1, through the tensor's own memory
+            c = corr.get(t)
+            if c is None:
+                c = corr[t] = (1.0 - b1 ** t, 1.0 - b2 ** t)
+            PA_g[j] = grads[j].data_ptr()
+            F_lr[j] = lrs[j]
+            F_b1[j], F_b2[j] = c
+        ops.adam_step_tables(n_rec, plan.tables, b1, b2, eps)
+        torch.autograd.graph.increment_version(plan.touched)
+        return True
+
+    def _checked_step(self):
         # pass 1 validates EVERY group and parameter and mutates nothing: an unsupported option or tensor on a later
         # parameter must not leave earlier ones with an advanced step count and no update
+        self.__dict__["_tir_plan"] = None
         todo = []
         betas = eps = None
         for group in self.param_groups:
@@ -61,9 +132,11 @@ class Adam(_TorchAdam):
                 betas, eps = b, e
             elif (b, e) != (betas, eps):
                 raise NotImplementedError("tensoir_amd.optim.Adam: betas / eps must be the same in every parameter group")
+        n_params = 0
         for group in self.param_groups:
             lr = float(group["lr"])
             for p in group["params"]:
+                n_params += 1
                 if p.grad is None:
                     continue
                 g = p.grad
@@ -77,19 +150,24 @@ class Adam(_TorchAdam):
                 todo.append((p, g, key, lr))
         # pass 2: state creation / layout fixes / step counts, then the one launch
         entries = []
+        plain = True                    # every gradient and moment already in its parameter's own layout (what the plan assumes)
         for p, g, key, lr in todo:
             ps = p.stride()
-            if g.stride() != ps and _dense_key(g) != key:
-                g = torch.empty_like(p).copy_(g)          # autograd's layout contract makes this the rare case
+            if g.stride() != ps:
+                plain = False
+                if _dense_key(g) != key:
+                    g = torch.empty_like(p).copy_(g)          # autograd's layout contract makes this the rare case
             state = self.state[p]
             if len(state) == 0:
                 state["step"] = torch.tensor(0.0, dtype=torch.float32)
                 state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             m, v = state["exp_avg"], state["exp_avg_sq"]
-            if (m.stride() != ps and _dense_key(m) != key) or (v.stride() != ps and _dense_key(v) != key):      # e.g. a state_dict loaded into another layout
-                m = state["exp_avg"] = torch.empty_like(p).copy_(m)
-                v = state["exp_avg_sq"] = torch.empty_like(p).copy_(v)
+            if m.stride() != ps or v.stride() != ps:
+                plain = False
+                if _dense_key(m) != key or _dense_key(v) != key:      # e.g. a state_dict loaded into another layout
+                    m = state["exp_avg"] = torch.empty_like(p).copy_(m)
+                    v = state["exp_avg_sq"] = torch.empty_like(p).copy_(v)
             state["step"] += 1
             t = float(state["step"])
             entries.append((p, g, m, v, lr, 1.0 - betas[0] ** t, 1.0 - betas[1] ** t))
@@ -98,7 +176,26 @@ class Adam(_TorchAdam):
             # the kernel wrote parameters and moments through raw pointers: tell autograd (saved-tensor checks) and every
             # cache keyed by Tensor._version (the model's packed decoder images, light means, descriptors) that they changed
             torch.autograd.graph.increment_version([t for e in entries for t in (e[0], e[2], e[3])])
-        return loss
+        if plain and entries and len(entries) == n_params:
+            self._make_plan(entries, betas, eps)
+
+    def _make_plan(self, entries, betas, eps):
+        """After a fully checked step over ALL parameters in their plain layout: remember them for _fast_step."""
+        recs = []
+        for p, _g, m, v, *_ in entries:
+            st = self.state[p]
+            step_t = st["step"]
+            if not torch.is_tensor(step_t) or step_t.is_cuda or step_t.dtype != torch.float32 or step_t.dim() != 0 or step_t.requires_grad:
+                return
+            rec = _Rec()
+            rec.p, rec.ptr, rec.stride, rec.state = p, p.data_ptr(), p.stride(), st
+            rec.step_t, rec.step_np, rec.m, rec.v = step_t, step_t.numpy(), m, v
+            recs.append(rec)
+        plan = _Plan()
+        plan.state_obj, plan.recs, plan.betas, plan.eps = self.state, recs, betas, eps
+        plan.tables = ops.adam_tables([(r.p, r.m, r.v) for r in recs])
+        plan.touched = [t for r in recs for t in (r.p, r.m, r.v)]
+        self.__dict__["_tir_plan"] = plan
 
 
 def _supported(opt) -> bool:
@@ -128,6 +225,11 @@ class LauncherAdam(Adam):
 
     @torch.no_grad()
     def step(self, closure=None):
+        # the steady state first: a plan only exists after a step that _supported() accepted, and Adam._fast_step re-checks
+        # every condition of _supported() that can change between two steps
+        if closure is None and self.__dict__.get("_tir_plan") is not None and self._fast_step():
+            return None
         if _supported(self):
             return Adam.step(self, closure)
+        self.__dict__["_tir_plan"] = None
         return _TorchAdam.step(self, closure)

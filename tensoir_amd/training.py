@@ -123,7 +123,12 @@ class _LeafStream:
         self.keep.clear()
 
 
-def _decoder_backward(dec, calls, impl=None, leaf=None, bwd=None, wg=None, keep_dz1=None):
+_DEC_GRAD_SIZES = (128 * 150, 128, 128 * 128, 128, 4 * 128, 4)
+_DEC_GRAD_SHAPES = ((128, 150), (128,), (128, 128), (128,), (4, 128), (4,))
+_DEC_GRAD_FLOATS = sum(_DEC_GRAD_SIZES)
+
+
+def _decoder_backward(dec, calls, impl=None, leaf=None, bwd=None, wg=None, keep_dz1=None, flat=None):
     """Backward of every recorded invocation of one decoder.  Returns ([g_feat per call], 6 parameter grads).
     bwd: the (g_feat, dz1, dz2, dz3) of each call when the backward-data kernel has already run (merged launch).
     wg: a list -- the weight-gradient work of every call is appended to it as a job of ops.mlp_wgrad_multi (the caller
@@ -131,11 +136,11 @@ def _decoder_backward(dec, calls, impl=None, leaf=None, bwd=None, wg=None, keep_
     pm, pb = dec.packed(), _packed_bwd(dec)
     dev = calls[0].feat.device
     od = pm.out_dim
-    # one zeroed buffer, carved into the six exact-shape (contiguous) gradients: autograd takes them as they are
-    sizes = (128 * 150, 128, 128 * 128, 128, 4 * 128, 4)
-    flat = torch.zeros((sum(sizes),), dtype=torch.float32, device=dev)
-    dW0, db0, dW1, db1, dW2, db2 = (t.view(shape) for t, shape in zip(
-        torch.split(flat, sizes), ((128, 150), (128,), (128, 128), (128,), (4, 128), (4,))))
+    # one zeroed buffer (flat: the caller's, zeroed for all of the stage's decoders with one fill launch), carved into the six
+    # exact-shape (contiguous) gradients: autograd takes them as they are
+    if flat is None:
+        flat = torch.zeros((_DEC_GRAD_FLOATS,), dtype=torch.float32, device=dev)
+    dW0, db0, dW1, db1, dW2, db2 = (t.view(shape) for t, shape in zip(torch.split(flat, _DEC_GRAD_SIZES), _DEC_GRAD_SHAPES))
     g_feats = []
     for ci, c in enumerate(calls):
         if bwd is None:
@@ -357,7 +362,12 @@ class PrimaryRenderFn(torch.autograd.Function):
             st.S, st.white_bg, st.is_relight, model.fixed_fresnel, g_maps)
         dec_grads = {}
         leaf = _LeafStream(dev)
-        d_basis = torch.zeros((model.app_dim, 3 * f.n_acomp), dtype=torch.float32, device=dev)
+        # the basis-matrix gradient and the three decoders' gradient blocks: ONE allocation, one fill launch
+        nbm = model.app_dim * 3 * f.n_acomp
+        nbm_pad = (nbm + 3) // 4 * 4
+        small = torch.zeros((nbm_pad + 3 * _DEC_GRAD_FLOATS,), dtype=torch.float32, device=dev)
+        d_basis = small[:nbm].view(model.app_dim, 3 * f.n_acomp)
+        dflat = [small[nbm_pad + i * _DEC_GRAD_FLOATS: nbm_pad + (i + 1) * _DEC_GRAD_FLOATS] for i in range(3)]
         if st.A > 0:
             c = st.calls["rgb"]
             c.g_out = g_rgb
@@ -370,18 +380,18 @@ class PrimaryRenderFn(torch.autograd.Function):
             # the stage's weight gradients in ONE launch on the leaf stream (TENSOIR_FUSED_WGRAD=0: per call, per layer)
             wg = [] if (ops.MLP_IMPL == "bf16x3" and os.environ.get("TENSOIR_FUSED_WGRAD", "1") != "0" and
                         all(cc.feat.shape[1] == ops.FEAT_STRIDE for cc in st.calls.values())) else None
-            (g_rad,), dec_grads["rgb"] = _decoder_backward(model.renderModule, [c], leaf=leaf, bwd=pick("rgb"), wg=wg)
+            (g_rad,), dec_grads["rgb"] = _decoder_backward(model.renderModule, [c], leaf=leaf, bwd=pick("rgb"), wg=wg, flat=dflat[0])
             g_int = g_int_j = None
             if st.is_relight:
                 cb, cj = st.calls["brdf"], st.calls["brdf_j"]
                 (g_int, g_int_j), dec_grads["brdf"] = _decoder_backward(model.renderModule_brdf, [cb, cj], leaf=leaf,
-                                                                        bwd=pick("brdf", "brdf_j"), wg=wg)
+                                                                        bwd=pick("brdf", "brdf_j"), wg=wg, flat=dflat[1])
                 if "normal" in st.calls:
                     cn = st.calls["normal"]
                     residue = model.normals_kind == "residue_prediction"
                     dz1 = [] if residue else None
                     (g_n,), dec_grads["normal"] = _decoder_backward(model.renderModule_normal, [cn], leaf=leaf, bwd=pick("normal"),
-                                                                    wg=wg, keep_dz1=dz1)
+                                                                    wg=wg, keep_dz1=dz1, flat=dflat[2])
                     g_int = g_int + g_n
                     if residue:
                         # the three derived-normal columns of layer 1 ride outside the kernels (they entered through the per-row

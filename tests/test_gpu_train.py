@@ -854,6 +854,40 @@ def test_single_launch_adam_matches_torch_adam():
     for k in sa["state"]:
         assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
         assert torch.allclose(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+    # ---- the steady state of a training loop: every gradient in its parameter's own layout (what autograd hands back) -> after
+    # one fully checked step the optimizer keeps a plan and a step costs identity checks only (Adam._fast_step); it must
+    # notice everything that invalidates the plan: an lr change (no invalidation, new value used), a missing gradient, a
+    # reloaded state
+    def grads(step):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            gr = torch.empty_like(a).copy_(torch.randn(a.shape, generator=g).cuda() * (10.0 ** ((i % 3) - 1)))
+            assert gr.stride() == a.stride()
+            a.grad, b.grad = gr.clone(), gr.clone()
+    fast = []
+    for step in range(12):
+        grads(step)
+        if step == 5:
+            for o in (oa, ob):
+                for grp in o.param_groups:
+                    grp["lr"] = grp["lr"] * 0.5
+        if step == 7:
+            pa[3].grad = pb[3].grad = None               # back to the checked path for this step, then a fresh plan
+        if step == 9:
+            oa.load_state_dict(oa.state_dict())          # new state tensors: the plan's identities no longer hold
+        had_plan = oa.__dict__.get("_tir_plan") is not None
+        v0, s0 = pa[0]._version, float(oa.state[pa[0]]["step"])
+        oa.step(); ob.step()
+        fast.append(had_plan and oa.__dict__.get("_tir_plan") is not None and step not in (7, 9))
+        assert pa[0]._version > v0 and float(oa.state[pa[0]]["step"]) == s0 + 1
+    assert fast == [False, True, True, True, True, True, True, False, False, False, True, True], fast
+    for a, b in zip(pa, pb):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
+    sa, sb = oa.state_dict(), ob.state_dict()
+    for k in sa["state"]:
+        assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
+        ea, eb = sa["state"][k]["exp_avg"], sb["state"][k]["exp_avg"]
+        assert float((ea - eb).abs().max()) <= 2e-6 * float(eb.abs().max())
+        assert torch.allclose(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
     ob2 = optim.Adam([{"params": p, "lr": lr} for p, lr in zip(pb, lrs)], betas=(0.9, 0.99))
     ob2.load_state_dict(sb)                               # a torch.optim.Adam state continues under ours
     for b in pb:

@@ -1,7 +1,8 @@
 """Evidence for the indirect-light precision policy: the TRAINED checkpoint and the adversarial scaling
 sweep of tests/precision_cases.py with every number recorded (nothing asserted -- the tests do that):
   gpurun_out/r05_precision_trained.json, gpurun_out/r05_precision_sweep.json   (copied to profiles/ by hand)
-Usage (GPU box): python tools/r05_precision.py [--grid 128] [--iters 450]"""
+Usage (GPU box): python tools/r05_precision.py [--grid 128] [--iters 450] [--skip-sweep] [--tag long]
+(--tag X writes r05_precision_trained_X.json: e.g. the same schedule trained three times as long, sweep skipped)"""
 import argparse
 import json
 import os
@@ -23,6 +24,8 @@ def main():
     ap.add_argument("--grid", type=int, default=128)
     ap.add_argument("--iters", type=int, default=450)
     ap.add_argument("--oracle-rays", type=int, default=128)
+    ap.add_argument("--skip-sweep", action="store_true")
+    ap.add_argument("--tag", default="")
     a = ap.parse_args()
     from tests import precision_cases as P
     from tensoir_amd import _lib, ops
@@ -41,10 +44,13 @@ def main():
     trained["magnitudes"] = {"app_plane_absmax": [float(p.abs().max()) for p in m.app_plane], "app_line_absmax": [float(p.abs().max()) for p in m.app_line],
                              "light_line_absmax": float(m.light_line.weight.abs().max()), "basis_absmax": float(m.basis_mat.weight.abs().max()),
                              "radiance_decoder_weight_rms": [float(m.renderModule.mlp[i].weight.pow(2).mean().sqrt()) for i in (0, 2, 4)]}
-    with open(os.path.join(out, "r05_precision_trained.json"), "w") as fh:
+    trained["radiance_decoder_weight_absmax"] = [float(m.renderModule.mlp[i].weight.abs().max()) for i in (0, 2, 4)]
+    with open(os.path.join(out, f"r05_precision_trained{'_' + a.tag if a.tag else ''}.json"), "w") as fh:
         json.dump(trained, fh, indent=1, default=str)
     print("trained:", json.dumps({k: trained[k] for k in ("psnr_last10", "policy_during_training", "policy")}, default=str)[:1500], flush=True)
     print("trained oracle:", json.dumps({k: v for k, v in rep.items()}, default=str)[:1500], flush=True)
+    if a.skip_sweep:
+        return
     sweep = {**stamp, "grid": a.grid, "cases": {}}
     for cfg in P.SWEEP:
         t0 = time.time()

@@ -19,6 +19,8 @@ ap.add_argument("--samples", type=int, default=512)
 ap.add_argument("--grid", type=int, default=300)
 ap.add_argument("--relight", type=int, default=1)
 ap.add_argument("--cprofile", type=int, default=0, help="print the N hottest host functions of 10 steps (stderr)")
+ap.add_argument("--census", default="", help="write a census of the framework (ATen) operators of one step to this JSON file: which "
+                                             "phase issues them, and whether product code or the caller's loss expression / autograd does")
 a = ap.parse_args()
 a.env_h, a.env_w, a.second_samples = 8, 16, 96
 dev = torch.device("cuda", 0)
@@ -80,6 +82,78 @@ if a.cprofile:
     st = pstats.Stats(pr, stream=sys.stderr)
     st.sort_stats("tottime").print_stats(a.cprofile)
     st.sort_stats("cumtime").print_stats(a.cprofile)
+census = None
+if a.census:
+    # Every operator that reaches the dispatcher during 4 steps, by phase.  "product" = issued from tensoir_amd code (the forward
+    # call, the backward of its autograd functions, the optimizer); "caller" = the loss expression the training script writes
+    # (train_tensoIR.py:262-311) and what autograd derives from it (slice / mean / pow backward, gradient accumulation).
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from tensoir_amd import training as _tr
+    torch.autograd.set_multithreading_enabled(False)       # backward on this thread: the dispatch mode is thread-local
+    NO_LAUNCH = {"empty", "empty_like", "empty_strided", "view", "_unsafe_view", "reshape", "as_strided", "slice", "select", "expand",
+                 "permute", "t", "transpose", "squeeze", "unsqueeze", "detach", "alias", "split", "split_with_sizes", "unbind", "narrow",
+                 "_local_scalar_dense", "is_pinned", "record_stream", "is_same_size", "sym_size", "stride", "_to_copy_noop", "lift_fresh",
+                 "result_type", "can_cast", "unsafe_split", "chunk", "unsafe_chunk", "resize_", "set_", "_reshape_alias", "new_empty",
+                 "new_empty_strided", "view_as", "expand_as", "contiguous_noop", "_pin_memory"}
+    cur = {"phase": "forward", "product": 1}
+    hist = {}
+
+    class Census(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = getattr(getattr(func, "overloadpacket", func), "__name__", str(func))
+            key = f"{cur['phase']}/{'product' if cur['product'] else 'caller'}"
+            h = hist.setdefault(key, {})
+            h[name] = h.get(name, 0) + 1
+            return func(*args, **(kwargs or {}))
+
+    def flagged(fn):
+        def wrapped(*x, **k):
+            old, cur["product"] = cur["product"], 1
+            try:
+                return fn(*x, **k)
+            finally:
+                cur["product"] = old
+        return staticmethod(wrapped)
+    saved = {c: c.backward for c in (_tr.PrimaryRenderFn, _tr.EnvSGFn, _tr.EnvPixelFn, _tr.ShadeFn)}
+    for c, b in saved.items():
+        c.backward = flagged(b)
+
+    def census_step():
+        cur.update(phase="forward", product=1)
+        ret = Renderer_TensoIR_train(rays, None, lidx, model, N_samples=a.samples, white_bg=True, is_train=True,
+                                     is_relight=bool(a.relight), sample_method="stratified_sampling", device=dev, args=args)
+        cur.update(phase="loss", product=0)
+        loss = torch.mean((ret["rgb_map"] - gt) ** 2)
+        if a.relight:
+            loss = loss + W["rgb_brdf"] * torch.mean((ret["rgb_with_brdf_map"] - gt) ** 2) \
+                + W["normals_diff"] * ret["normals_diff_map"].mean() \
+                + W["normals_orientation"] * ret["normals_orientation_loss_map"].mean() \
+                + W["roughness_smoothness"] * ret["roughness_smoothness_loss"] + W["albedo_smoothness"] * ret["albedo_smoothness_loss"]
+        cur.update(phase="backward", product=0)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        cur.update(phase="optimizer", product=1)
+        opt.step()
+    N_CENSUS = 4
+    with Census():
+        for _ in range(N_CENSUS):
+            census_step()
+    torch.cuda.synchronize()
+    for c, b in saved.items():
+        c.backward = staticmethod(b)
+    torch.autograd.set_multithreading_enabled(True)
+    rows_c = {}
+    for key, h in sorted(hist.items()):
+        launching = {n: round(v / N_CENSUS, 2) for n, v in sorted(h.items(), key=lambda kv: -kv[1]) if n not in NO_LAUNCH}
+        rows_c[key] = {"operators_that_launch_per_step": round(sum(launching.values()), 2), "by_operator": launching,
+                       "views_and_allocations_per_step": round(sum(v for n, v in h.items() if n in NO_LAUNCH) / N_CENSUS, 2)}
+    census = {"steps": N_CENSUS, "note": "operators seen by a TorchDispatchMode (backward on the calling thread); an operator that launches "
+              "is one ATen kernel or copy in almost every case; product = issued by tensoir_amd code, caller = the script's loss expression "
+              "and the autograd nodes derived from it", "by_phase": rows_c,
+              "launching_operators_per_step": {"product": round(sum(r["operators_that_launch_per_step"] for k, r in rows_c.items() if k.endswith("product")), 2),
+                                               "caller": round(sum(r["operators_that_launch_per_step"] for k, r in rows_c.items() if k.endswith("caller")), 2)}}
+    with open(a.census, "w") as fh:
+        json.dump(census, fh, indent=1)
 ops.TIMING = []
 for _ in range(3):
     step()
