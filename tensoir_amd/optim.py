@@ -12,6 +12,7 @@ non-fp32 or non-CUDA parameters) raise -- nothing falls back silently.
 from __future__ import annotations
 
 import functools
+import os
 
 import torch
 
@@ -19,6 +20,7 @@ from . import ops
 from ._lib import TensoirHipError
 
 _TorchAdam = torch.optim.Adam
+FAST_STEP = os.environ.get("TENSOIR_FAST_ADAM", "1") != "0"        # 0: every step takes the fully checked path
 
 
 @functools.lru_cache(maxsize=512)
@@ -68,7 +70,7 @@ class Adam(_TorchAdam):
         without gradient, another layout, a reloaded state, an option) and NOTHING has been changed: the caller takes the checked
         path, which also rebuilds the plan."""
         plan = self.__dict__.get("_tir_plan")
-        if plan is None or plan.state_obj is not self.state:
+        if plan is None or plan.state_obj is not self.state or not FAST_STEP:
             return False
         recs, betas, eps = plan.recs, plan.betas, plan.eps
         n_rec, i = len(recs), 0

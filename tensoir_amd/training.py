@@ -365,9 +365,13 @@ class PrimaryRenderFn(torch.autograd.Function):
         # the basis-matrix gradient and the three decoders' gradient blocks: ONE allocation, one fill launch
         nbm = model.app_dim * 3 * f.n_acomp
         nbm_pad = (nbm + 3) // 4 * 4
-        small = torch.zeros((nbm_pad + 3 * _DEC_GRAD_FLOATS,), dtype=torch.float32, device=dev)
-        d_basis = small[:nbm].view(model.app_dim, 3 * f.n_acomp)
-        dflat = [small[nbm_pad + i * _DEC_GRAD_FLOATS: nbm_pad + (i + 1) * _DEC_GRAD_FLOATS] for i in range(3)]
+        if os.environ.get("TENSOIR_MERGED_ZEROS", "1") != "0":
+            small = torch.zeros((nbm_pad + 3 * _DEC_GRAD_FLOATS,), dtype=torch.float32, device=dev)
+            d_basis = small[:nbm].view(model.app_dim, 3 * f.n_acomp)
+            dflat = [small[nbm_pad + i * _DEC_GRAD_FLOATS: nbm_pad + (i + 1) * _DEC_GRAD_FLOATS] for i in range(3)]
+        else:
+            d_basis = torch.zeros((model.app_dim, 3 * f.n_acomp), dtype=torch.float32, device=dev)
+            dflat = [None, None, None]
         if st.A > 0:
             c = st.calls["rgb"]
             c.g_out = g_rgb
