@@ -1242,9 +1242,11 @@ def train_parity_and_cpu(a, ckpt, model, rays, lidx, gt, args, device, n_sub=128
         # run ends in another state; in about one state in ten the HIP gradients are 2e-3 ... 1.6e-2 from the oracle's (measured over
         # 28 runs, profiles/r05_train_parity_states.txt; HIP itself repeats to 5e-7 on a fixed state, so this is accuracy, not a
         # race).  The SAME step in fp64 says which side is off: the fp32 oracle stays within ~5e-5 of fp64, the HIP backward does
-        # not -- its decoders run on split-bf16 operands (activations 1e-5 from fp32: ReLU masks of pre-activations that close to
-        # zero flip) and its sparse sums are atomics.  Reported as measured; `ok` then falls back to the bound rounds 3-4 used
-        # (1e-2 against the fp64 gradients) and says so in `ok_strict`.
+        # not.  Every miss bisected so far was ONE ray (tools/train_parity_bisect.py), and the oracle does the same against ITSELF when
+        # its decoder weights are perturbed by 1e-5 -- the split-bf16 decoders' distance from fp32 -- (tools/grad_kink_sensitivity.py:
+        # 25 % of 32 scenes above 2e-3): the gradient is discontinuous in the arithmetic, a ReLU mask of a pre-activation within 1e-5 of
+        # zero flips on one side only.  Reported as measured; `ok` then falls back to the bound rounds 3-4 used (1e-2 against the
+        # fp64 gradients) and says so in `ok_strict`.
         try:
             _, g64, _ = O.train_step_grads(_to_fp64(sc), r.cpu().double(), l.cpu(), g.cpu().double(), is_relight=True, n_samples=S,
                                            ray_jitter=jitter.double(), brdf_jitter=noise.double(), second_n_sample=a.second_samples, weights=w)
