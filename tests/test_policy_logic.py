@@ -153,3 +153,28 @@ def test_simulate_ranks_arithmetic(monkeypatch):
         wire = (c["world"] - 1) / c["world"] * n * 96 / (0.6 * 153e9 * (c["world"] - 1))
         assert c["exchange_model_ms"] == pytest.approx(1e3 * wire, abs=1e-3)
     assert set(sim["best_per_world"]) == {"2", "4"}
+
+
+def test_single_ray_bisect_finds_the_ray():
+    """bench.single_ray_bisect / grad_deviation (the follow-up of a strict miss of the train workload's gradient check): per-ray
+    gradients whose mean is the batch gradient, one ray deviating -> that ray is found, the others agree."""
+    import bench
+    gen = torch.Generator().manual_seed(3)
+    n = 128
+    per_ray = {"renderModule.mlp.0.weight": torch.randn(n, 16, 10, generator=gen), "app_plane.0": torch.randn(n, 1, 4, 9, 9, generator=gen),
+               "basis_mat.weight": torch.randn(n, 5, 12, generator=gen)}
+    bad = {k: v.clone() for k, v in per_ray.items()}
+    bad["renderModule.mlp.0.weight"][37] *= 1.6                      # one unit's share of one ray
+    bad["app_plane.0"][37] += 0.3 * torch.randn(1, 4, 9, 9, generator=gen)
+    calls = []
+
+    def dev_of(idx):
+        calls.append(int(idx.numel()))
+        return bench.grad_deviation({k: v[idx].mean(0) for k, v in bad.items()}, {k: v[idx].mean(0) for k, v in per_ray.items()})
+    full = dev_of(torch.arange(n))
+    assert full["dense"] > 2e-3 and full["l2"] > 3e-3
+    ray, alone, rest = bench.single_ray_bisect(n, dev_of)
+    assert ray == 37
+    assert alone["dense"] > 0.3 and rest["dense"] == 0.0 and rest["l2"] == 0.0 and rest["abs"] == 0.0
+    assert sum(calls[1:]) == 2 * (n - 1) + (n - 1)                   # rays evaluated: every level's two halves + all rays but one
+    assert bench.single_ray_bisect(1, dev_of)[0] == 0
