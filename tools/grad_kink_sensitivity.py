@@ -42,6 +42,7 @@ def main():
     S, B = 128, 48
     rays_all = synth.make_rays(64, 64)
     res = {1e-5: [], 1e-7: []}
+    single = []
     t0 = time.time()
     for seed in range(n_scenes):
         ck = synth.make_checkpoint(grid=(48,) * 3, seed=100 + seed)
@@ -55,7 +56,17 @@ def main():
             for k in list(sd):
                 if ".mlp." in k and k.endswith("weight"):
                     sd[k] = sd[k] * (1 + eps * torch.randn(sd[k].shape, generator=gen))
-            res[eps].append(deviation(g0, grads({**ck, "state_dict": sd}, rays, lidx, gt, jit, noi, S)))
+            ck2 = {**ck, "state_dict": sd}
+            d = deviation(g0, grads(ck2, rays, lidx, gt, jit, noi, S))
+            res[eps].append(d)
+            if d[0] > 2e-3 and len(single) < 6:
+                # is it ONE ray here too?  (the loss is a mean over rays: bench.single_ray_bisect)
+                import bench
+                dev_of = lambda ix: bench.grad_deviation(grads(ck2, rays[ix], lidx[ix], gt[ix], jit[ix], noi[ix], S),
+                                                         grads(ck, rays[ix], lidx[ix], gt[ix], jit[ix], noi[ix], S))
+                ray, alone, rest = bench.single_ray_bisect(B, dev_of)
+                single.append({"scene": seed, "eps": eps, "all_rays": float(f"{d[0]:.2e}"), "ray": ray, "that_ray_alone": float(f"{alone['dense']:.2e}"),
+                               "all_rays_but_it": float(f"{rest['dense']:.2e}")})
     report = {"what": "max over the decoder / basis / light gradient tensors of max|g(perturbed) - g| / max|g|, one training step of the ORACLE "
                       f"on {B} rays x {S} samples of a seeded 48^3 scene, decoder weights x (1 + eps N(0,1))", "scenes": n_scenes, "seconds": round(time.time() - t0, 1)}
     for eps, v in res.items():
@@ -64,6 +75,7 @@ def main():
                                   "share_over_2e-3": round(sum(x > 2e-3 for x in vals) / len(vals), 3),
                                   "median_over_eps": round(vals[len(vals) // 2] / eps, 1), "max_over_eps": round(vals[-1] / eps, 1),
                                   "sorted": [float(f"{x:.2e}") for x in vals], "worst_tensor": max(v, key=lambda t: t[0])[1]}
+    report["single_ray_bisection_of_the_scenes_over_2e-3"] = single
     print(json.dumps(report, indent=1))
     if out:
         with open(out, "w") as fh:
