@@ -454,3 +454,27 @@ def test_c5_pair_order_switches(monkeypatch):
     monkeypatch.setenv("TENSOIR_C5_PAIRS", "sorted")
     with pytest.raises(ValueError):
         ops.c5_pair_order()
+
+
+def test_density_l1_multi_tensor_node_matches_the_plain_expression():
+    """TensorVMSplit.density_L1 (one autograd node over multi-tensor kernels) against the reference's per-tensor expression
+    (models/tensoRF_rotated_lights.py:74-78): value to a few ulp, gradients sign(x) / numel (zero at zero), parameter layout kept."""
+    from tensoir_amd import field_model as fm
+    gen = torch.Generator().manual_seed(4)
+    shapes = [(1, 16, 30, 31), (1, 16, 29, 1), (1, 16, 28, 30), (1, 16, 31, 1), (1, 16, 31, 29), (1, 16, 30, 1)]
+    ts = [torch.nn.Parameter(torch.randn(s, generator=gen).contiguous(memory_format=torch.channels_last)) for s in shapes]
+    with torch.no_grad():
+        ts[0][0, 0, 0, :5] = 0.0
+    a = fm._DensityL1Fn.apply(*ts)
+    b = 0
+    for i in range(0, 6, 2):
+        b = b + ts[i].abs().mean() + ts[i + 1].abs().mean()
+    assert abs(float(a.detach()) - float(b.detach())) <= 1e-6 * float(b.detach())
+    (0.37 * a).backward()
+    ga = [t.grad.clone() for t in ts]
+    for t in ts:
+        t.grad = None
+    (0.37 * b).backward()
+    for x, t in zip(ga, ts):
+        assert x.stride() == t.stride() and float((x - t.grad).abs().max()) <= 1e-9
+    assert float(ga[0][0, 0, 0, :5].abs().max()) == 0.0
