@@ -469,7 +469,8 @@ def test_density_l1_multi_tensor_node_matches_the_plain_expression():
     b = 0
     for i in range(0, 6, 2):
         b = b + ts[i].abs().mean() + ts[i + 1].abs().mean()
-    assert abs(float(a.detach()) - float(b.detach())) <= 1e-6 * float(b.detach())
+    # (on the CPU the norm of a channel-last tensor is summed sequentially: 5e-6 relative; the device kernels reduce in trees)
+    assert abs(float(a.detach()) - float(b.detach())) <= 1e-5 * float(b.detach())
     (0.37 * a).backward()
     ga = [t.grad.clone() for t in ts]
     for t in ts:
