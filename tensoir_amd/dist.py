@@ -242,6 +242,36 @@ class GraphedChunkRenderer:
 
 
 # ---- data-parallel training (the reference itself never all-reduces: section 2.1) ----------
+# The unmodified training scripts under `torchrun` / WORLD_SIZE > 1 (train_tensoIR.py:22-27 create the process group and then
+# run N identical trainers: same seeds, same batches, no gradient exchange).  `python -m tensoir_amd.run` switches LAUNCHER_DP
+# on: TensorVMSplit.filtering_rays then hands every rank a disjoint 1/world of the kept training rays (the k-th kept ray goes to
+# rank k mod world -- the mask it returns selects the same rows of the colour / light-index tables, train_tensoIR.py:228-231) and
+# LauncherAdam.step() averages the gradients over the ranks (bucketed all-reduce below) before the one-launch update: batch_size
+# rays per rank and step, `world * batch_size` per optimizer step, identical parameters on every rank.
+LAUNCHER_DP = {"on": False}
+
+
+def launcher_dp():
+    """(rank, world) when the launcher's data-parallel mode is active in this process (enabled by tensoir_amd.run, process group
+    initialised by the script, more than one rank), else None."""
+    if not LAUNCHER_DP["on"] or not dist.is_available() or not dist.is_initialized():
+        return None
+    world = dist.get_world_size()
+    return (dist.get_rank(), world) if world > 1 else None
+
+
+def shard_filter_mask(mask: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """The rows of a boolean keep-mask that belong to `rank`: the k-th True goes to rank k mod world (shards differ by at most
+    one ray; their union is the mask, they are pairwise disjoint)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    flat = mask.reshape(-1)
+    kept = flat.nonzero(as_tuple=False).reshape(-1)
+    out = torch.zeros_like(flat)
+    out[kept[rank::world]] = True
+    return out.view(mask.shape)
+
+
 def shard_batch(n_rays: int, rank: int, world: int):
     """Training batches are split `rays[rank::world]` (SURVEY 8e): every rank marches batch/world rays."""
     return torch.arange(rank, n_rays, world, dtype=torch.int64)

@@ -751,6 +751,11 @@ class TensorVMSplit(nn.Module):
             masks.append(ops.filter_rays(f, rays_chunk, N_samples, bbox_only).to(all_rays.device))
         mask = torch.cat(masks).view(all_rays.shape[:-1]) if masks else torch.zeros(all_rays.shape[:-1], dtype=torch.bool)
         print(f"Ray filtering done! takes {time.time() - tt} s. ray mask ratio: {torch.sum(mask) / N}")
+        from . import dist as tdist
+        dp = tdist.launcher_dp()
+        if dp is not None:      # the unmodified script under torchrun (tensoir_amd.run): this rank trains on its 1/world of the kept rays
+            mask = tdist.shard_filter_mask(mask, *dp)
+            print(f"[tensoir_amd] data-parallel launcher: rank {dp[0]} of {dp[1]} keeps {int(mask.sum())} training rays")
         return all_rays[mask], mask
 
     def sample_ray(self, rays_o, rays_d, is_train=True, N_samples=-1):

@@ -41,7 +41,7 @@ def _dense_key(t):
 
 class _Rec:
     """What `Adam.step` knows about one parameter after a first (fully checked) step."""
-    __slots__ = ("p", "ptr", "stride", "state", "step_t", "step_np", "m", "v")
+    __slots__ = ("p", "ptr", "stride", "state", "step_t", "step_np", "m", "v", "m_ptr", "v_ptr")
 
 
 class _Plan:
@@ -94,7 +94,12 @@ class Adam(_TorchAdam):
                         or g.stride() != rec.stride or p.stride() != rec.stride or p.data_ptr() != rec.ptr):
                     return False
                 st = rec.state
-                if st.get("step") is not rec.step_t or st.get("exp_avg") is not rec.m or st.get("exp_avg_sq") is not rec.v:
+                m, v = st.get("exp_avg"), st.get("exp_avg_sq")
+                if st.get("step") is not rec.step_t or m is not rec.m or v is not rec.v:
+                    return False
+                # the same tensor objects may have been given other storage (`m.data = ...`, `set_`): the kernel's table holds
+                # raw pointers, so storage and layout are re-checked too
+                if m.data_ptr() != rec.m_ptr or v.data_ptr() != rec.v_ptr or m.stride() != rec.stride or v.stride() != rec.stride:
                     return False
                 grads.append(g)
                 lrs.append(lr)
@@ -106,14 +111,15 @@ class Adam(_TorchAdam):
         corr = {}
         for j, rec in enumerate(recs):
             t = float(rec.step_np) + 1.0
-            rec.step_np[()] = t                       # state["step"] += 1, through the tensor's own memory
             c = corr.get(t)
             if c is None:
                 c = corr[t] = (1.0 - b1 ** t, 1.0 - b2 ** t)
             PA_g[j] = grads[j].data_ptr()
             F_lr[j] = lrs[j]
             F_b1[j], F_b2[j] = c
-        ops.adam_step_tables(n_rec, plan.tables, b1, b2, eps)
+        ops.adam_step_tables(n_rec, plan.tables, b1, b2, eps)      # raises -> no step count has moved, nothing was updated
+        for rec in recs:
+            rec.step_np[()] = float(rec.step_np) + 1.0    # state["step"] += 1, through the tensor's own memory
         torch.autograd.graph.increment_version(plan.touched)
         return True
 
@@ -192,6 +198,7 @@ class Adam(_TorchAdam):
             rec = _Rec()
             rec.p, rec.ptr, rec.stride, rec.state = p, p.data_ptr(), p.stride(), st
             rec.step_t, rec.step_np, rec.m, rec.v = step_t, step_t.numpy(), m, v
+            rec.m_ptr, rec.v_ptr = m.data_ptr(), v.data_ptr()
             recs.append(rec)
         plan = _Plan()
         plan.state_obj, plan.recs, plan.betas, plan.eps = self.state, recs, betas, eps
@@ -227,6 +234,15 @@ class LauncherAdam(Adam):
 
     @torch.no_grad()
     def step(self, closure=None):
+        # the launcher's data-parallel mode (dist.LAUNCHER_DP: the unmodified script under torchrun): average the gradients over
+        # the ranks first -- bucketed all-reduce in the parameters' own memory order; every rank issues the same collectives
+        from . import dist as tdist
+        if tdist.launcher_dp() is not None:
+            if closure is not None:
+                with torch.enable_grad():
+                    closure()
+                closure = None
+            tdist.allreduce_gradients([p for g in self.param_groups for p in g["params"]])
         # the steady state first: a plan only exists after a step that _supported() accepted, and Adam._fast_step re-checks
         # every condition of _supported() that can change between two steps
         if closure is None and self.__dict__.get("_tir_plan") is not None and self._fast_step():

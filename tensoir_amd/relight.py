@@ -88,12 +88,17 @@ def _indirect_mode(tensoIR, training=False):
         return "f16"
     st = _indirect_state(tensoIR)
     key, storage = _indirect_key(tensoIR)
+    # `key` is the version a probe MEASURED; `carried_key` the latest version a training pass carried that verdict over to.
+    # Only a training pass may ride on a carried verdict: an inference pass at a version that was never probed probes.
     if st["verdict"] is not None and st["key"] == key and (training or not st.get("train_limit")):
         return st["verdict"]         # (an inference pass never rides on a verdict taken with the training limit)
-    if training and st["verdict"] is not None and st["storage"] == storage and st["age"] < ops.INDIRECT_PROBE["interval"]:
-        st["age"] += 1
-        st["key"] = key
-        return st["verdict"]
+    if training and st["verdict"] is not None and st["storage"] == storage:
+        if st.get("carried_key") == key:
+            return st["verdict"]     # (another pass at a version already counted)
+        if st["age"] < ops.INDIRECT_PROBE["interval"]:
+            st["age"] += 1
+            st["carried_key"] = key
+            return st["verdict"]
     return "probe"
 
 
@@ -102,7 +107,7 @@ def _set_verdict(tensoIR, verdict, why, stats=None, train_limit=False):
     key, storage = _indirect_key(tensoIR)
     if verdict == "full" and st["verdict"] != "full":
         st["fallbacks"] += 1
-    st.update(verdict=verdict, key=key, storage=storage, age=0, why=why, train_limit=bool(train_limit))
+    st.update(verdict=verdict, key=key, carried_key=None, storage=storage, age=0, why=why, train_limit=bool(train_limit))
     if stats is not None:
         st["stats"] = stats
 

@@ -71,10 +71,29 @@ def install(reference_root: str):
     mode = os.environ.get("TENSOIR_DEVICE_DATASET", "auto")
     if mode in ("1", "auto"):
         import torch
-        dev = "cuda" if torch.cuda.is_available() else None
+        # the device the script will select (`cuda:{args.local_rank}`, train_tensoIR.py:25-29; main() passes LOCAL_RANK on as
+        # --local_rank), not whatever is current while the dataset is built: several ranks must not all allocate on GPU 0
+        dev = f"cuda:{_local_rank()}" if torch.cuda.is_available() else None
     synth_dataset.wrap_dataset_dict(importlib.import_module("dataLoader").dataset_dict, device=dev, only_if_fits=(mode == "auto"))
+    # data-parallel training of the unmodified script under torchrun (tensoir_amd/dist.py LAUNCHER_DP); TENSOIR_LAUNCHER_DP=0 keeps
+    # the reference's behaviour (N identical trainers, train_tensoIR.py:22-27)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("TENSOIR_LAUNCHER_DP", "1") != "0":
+        from tensoir_amd import dist as tdist
+        tdist.LAUNCHER_DP["on"] = True
+        done["tensoir_amd.dist"] = ["LAUNCHER_DP"]
     _allow_numpy_in_checkpoints()
     return done
+
+
+def _local_rank(argv=None) -> int:
+    """--local_rank of the script's command line if given, else LOCAL_RANK (torchrun), else 0."""
+    argv = sys.argv if argv is None else argv
+    for i, a in enumerate(argv):
+        if a == "--local_rank" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--local_rank="):
+            return int(a.split("=", 1)[1])
+    return int(os.environ.get("LOCAL_RANK", "0"))
 
 
 def _host_threads():
@@ -119,8 +138,12 @@ def main(argv=None):
     root = os.path.dirname(script)
     if os.path.basename(root) == "scripts":
         root = os.path.dirname(root)
+    rest = argv[1:]
+    # torchrun exports LOCAL_RANK; the scripts read args.local_rank (opt.py:21, the older torch.distributed.launch convention)
+    if "LOCAL_RANK" in os.environ and not any(a == "--local_rank" or a.startswith("--local_rank=") for a in rest):
+        rest = rest + ["--local_rank", os.environ["LOCAL_RANK"]]
+    sys.argv = [script] + rest
     install(root)
-    sys.argv = [script] + argv[1:]
     runpy.run_path(script, run_name="__main__")
 
 

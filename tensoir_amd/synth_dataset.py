@@ -126,10 +126,14 @@ def _to_device(ds, device):
     """Training-loop residency: keep the training rays / colours / light indices of a dataset in HBM, so that
     the unmodified loop's ``rays_filtered[rays_idx]`` (train_tensoIR.py:239-242) gathers on the device and only the 32 KB
     index tensor crosses PCIe per step (the script builds its permutation on the host with numpy, :49)."""
+    moved = 0
     for name in ("all_rays", "all_rgbs", "all_light_idx"):
         t = getattr(ds, name, None)
         if torch.is_tensor(t):
             setattr(ds, name, t.to(device))
+            moved += t.numel() * t.element_size()
+    print(f"[tensoir_amd] training table resident on {device}: {moved / 2 ** 20:.1f} MiB (rays, colours, light indices; "
+          f"TENSOIR_DEVICE_DATASET=0 keeps it on the host)", flush=True)
     return ds
 
 

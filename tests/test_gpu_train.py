@@ -864,7 +864,7 @@ def test_single_launch_adam_matches_torch_adam():
             assert gr.stride() == a.stride()
             a.grad, b.grad = gr.clone(), gr.clone()
     fast = []
-    for step in range(12):
+    for step in range(15):
         grads(step)
         if step == 5:
             for o in (oa, ob):
@@ -874,12 +874,27 @@ def test_single_launch_adam_matches_torch_adam():
             pa[3].grad = pb[3].grad = None               # back to the checked path for this step, then a fresh plan
         if step == 9:
             oa.load_state_dict(oa.state_dict())          # new state tensors: the plan's identities no longer hold
+        if step == 12:                                   # the SAME moment tensor object on other storage: the plan holds raw pointers
+            mom = oa.state[pa[1]]["exp_avg"]
+            mom.data = mom.data.clone()
         had_plan = oa.__dict__.get("_tir_plan") is not None
         v0, s0 = pa[0]._version, float(oa.state[pa[0]]["step"])
+        if step == 13:                                   # a launch that fails must leave the step counts where they were
+            from tensoir_amd import ops as _ops
+            real = _ops.adam_step_tables
+            def boom(*a, **k):
+                raise RuntimeError("launch failed")
+            _ops.adam_step_tables = boom
+            try:
+                with pytest.raises(RuntimeError):
+                    oa.step()
+            finally:
+                _ops.adam_step_tables = real
+            assert float(oa.state[pa[0]]["step"]) == s0 and pa[0]._version == v0
         oa.step(); ob.step()
-        fast.append(had_plan and oa.__dict__.get("_tir_plan") is not None and step not in (7, 9))
+        fast.append(had_plan and oa.__dict__.get("_tir_plan") is not None and step not in (7, 9, 12))
         assert pa[0]._version > v0 and float(oa.state[pa[0]]["step"]) == s0 + 1
-    assert fast == [False, True, True, True, True, True, True, False, False, False, True, True], fast
+    assert fast == [False, True, True, True, True, True, True, False, False, False, True, True, False, True, True], fast
     for a, b in zip(pa, pb):
         assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
     sa, sb = oa.state_dict(), ob.state_dict()

@@ -65,6 +65,14 @@ def test_verdict_state_machine(auto_policy):
         assert relight._indirect_mode(m, training=True) == "f16"         # (asking twice for one version does not age it twice)
         m.step()
     assert relight._indirect_mode(m, training=True) == "probe"
+    # ... and an inference pass never inherits a CARRIED verdict: strict verdict at v0, five training steps, inference at v5 probes
+    m2 = _Model()
+    relight._set_verdict(m2, "f16", "probe", {"map_max_abs": 1e-6})
+    for _ in range(5):
+        m2.step()
+        assert relight._indirect_mode(m2, training=True) == "f16"
+    assert relight._indirect_mode(m2) == "probe"
+    assert relight._indirect_mode(m2, training=True) == "f16"            # (the training loop still rides on it)
     relight._set_verdict(m, "full", "probe", {"map_max_abs": 9e-5})
     assert relight._indirect_state(m)["fallbacks"] == 1
     m.step()
