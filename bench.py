@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--decoder", type=str, default="bf16x3", choices=["mfma", "bf16x3"],
                     help="decoder matrix-core mode: bf16x3 = split-bf16 (parity grade), mfma = exact fp32")
     ap.add_argument("--no-exact-pass", action="store_true", help="skip the extra timed pass with the exact fp32 decoders")
+    ap.add_argument("--no-full-pass", action="store_true", help="skip the extra timed pass with the indirect-light policy forced to `full`")
     ap.add_argument("--breakdown", type=str, default="", help="write the per-kernel table to this file")
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly instead of replaying the HIP graph")
     ap.add_argument("--in-flight", type=int, default=2,
@@ -425,6 +426,21 @@ def dominant_roofline(rows):
     pmc_traffic, pmc_issue, pmc_meta = load_pmc()
     dom = next((r for r in rows if "achieved" in r), None)
     return roofline_object(dom, pmc_traffic, pmc_issue, pmc_meta) if dom else None
+
+
+def trained_300_verdict():
+    """What the auto policy decided on a checkpoint TRAINED to 300^3 through the product API (tools/precision_300.py, run on a
+    GPU box; the JSON is committed evidence, stamped with the library hash it was measured with)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r06_precision_trained_300.json")))
+        dec = d["policy"]["decision"]
+        return {"mode": dec["mode"], "why": dec["why"], "map_max_abs_f16_vs_full": dec["probe"].get("map_max_abs"), "limit": dec["probe"].get("limit"),
+                "iterations": d.get("iterations"), "grids": d.get("grids"), "library_source_hash": d.get("library_source_hash"),
+                "stale": d.get("library_source_hash") != library_info().get("source_hash"),
+                "worst_map_vs_oracle": max(v["max_rel_floor1"] for v in d["oracle"].values() if isinstance(v, dict) and "max_rel_floor1" in v),
+                "source": "profiles/r06_precision_trained_300.json"}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def port_vs_reference(port_value):
@@ -1266,9 +1282,9 @@ def train_parity_and_cpu(a, ckpt, model, rays, lidx, gt, args, device, n_sub=128
                            "unit tests; typically 2e-5 ... 2e-4 here, 1.6e-4 there); VM plane / line "
                            "gradients (sparse sums on a sharp, ill-conditioned scene): relative L2 error < 3e-3 (measured 3.4e-4) and < 2e-3 of the elements off by "
                            "more than 2e-3 of the largest -- waived (and reported) when a sample is a record on one side only (`record_mask_mismatches`); "
-                           "unit tests on the golden scene keep the max-norm.  A state that misses this strict bound is re-evaluated against the "
-                           "oracle in fp64 (`against_fp64_oracle`, `ok_strict`) and bisected over its rays (`single_ray`: the ray that carries the deviation, "
-                           "the figures of the other rays -- which must keep the strict bound)",
+                           "unit tests on the golden scene keep the max-norm.  ONE rule for `ok`: this strict bound on all rays (`ok_strict`), or -- "
+                           "when it is missed -- on all rays but ONE, found by bisection over the rays and reported with its own (bounded) deviation "
+                           "(`single_ray`); the same step against the oracle in fp64 is reported (`against_fp64_oracle`) and decides nothing",
               "loss_abs_diff": float(f"{abs(float(loss) - float(loss_ref)):.3e}"), "maps_max_abs": maps,
               "grad_max_rel": float(f"{gmax:.3e}"), "field_grad_rel_l2": float(f"{l2max:.3e}"), "field_grad_outlier_share": float(f"{omax:.3e}"),
               "field_grad_max_rel": float(f"{max([worst[k] for k in l2] or [0.0]):.3e}"), "grad_tensors_compared": len(worst),
@@ -1285,8 +1301,8 @@ def train_parity_and_cpu(a, ckpt, model, rays, lidx, gt, args, device, n_sub=128
         # not.  Every miss bisected so far was ONE ray (tools/train_parity_bisect.py), and the oracle does the same against ITSELF when
         # its decoder weights are perturbed by 1e-5 -- the split-bf16 decoders' distance from fp32 -- (tools/grad_kink_sensitivity.py:
         # 25 % of 32 scenes above 2e-3): the gradient is discontinuous in the arithmetic, a ReLU mask of a pre-activation within 1e-5 of
-        # zero flips on one side only.  Reported as measured; `ok` then falls back to the bound rounds 3-4 used (1e-2 against the
-        # fp64 gradients) and says so in `ok_strict`.
+        # zero flips on one side only.  The fp64 figures are reported as measured and decide nothing: `ok` follows the one rule
+        # below (strict on all rays, or on all rays but one).
         try:
             _, g64, _ = O.train_step_grads(_to_fp64(sc), r.cpu().double(), l.cpu(), g.cpu().double(), is_relight=True, n_samples=S,
                                            ray_jitter=jitter.double(), brdf_jitter=noise.double(), second_n_sample=a.second_samples, weights=w)
@@ -1311,11 +1327,10 @@ def train_parity_and_cpu(a, ckpt, model, rays, lidx, gt, args, device, n_sub=128
             parity["against_fp64_oracle"] = {"hip": fmt(h), "fp32_oracle": fmt(o),
                                              "loose_bound": "decoder / basis / light max-norm < 1e-2, VM planes / lines relative L2 < 1e-2 and outlier share < 5e-3, against the fp64 gradients",
                                              "within_loose_bound": bool(loose)}
-            parity["ok_strict"] = bool(parity["ok"])
-            parity["ok"] = bool(parity["ok"] or loose)
         except Exception as e:
             parity["against_fp64_oracle"] = {"error": f"{type(e).__name__}: {e}"}
-        if not parity.get("ok_strict", parity["ok"]):
+        parity["ok_strict"] = bool(parity["ok"])
+        if not parity["ok_strict"]:
             # Every strict miss bisected so far was ONE ray (a ReLU mask of a near-zero pre-activation on a dominant record: the
             # reference's own gradient jumps the same way, tools/grad_kink_sensitivity.py).  Find it; the other rays must keep the
             # strict bound -- a defect of a kernel would not sit in one ray.
@@ -1348,11 +1363,14 @@ def train_parity_and_cpu(a, ckpt, model, rays, lidx, gt, args, device, n_sub=128
                                               ray_jitter=jitter[idx], brdf_jitter=noise[idx], second_n_sample=a.second_samples, weights=w)[1]
                 ray, alone, rest = single_ray_bisect(Bs, lambda idx: grad_deviation(hip_step(idx), oracle_step(idx)))
                 rest_ok = rest["dense"] < 2e-3 and ((rest["l2"] < 3e-3 and rest["outl"] < 2e-3) or bool(flips))
+                # the excluded ray is bounded too: a flipped ReLU mask moves a ray's own gradient by its unit's share (5 % ... 160 %
+                # observed); anything beyond 2x the ray's gradient is not that mechanism
+                rest_ok = rest_ok and alone is not None and alone["dense"] < 2.0 and alone["l2"] < 2.0
                 short = lambda t: None if t is None else {k: float(f"{v:.3e}") for k, v in t.items() if k != "abs"}
                 parity["single_ray"] = {"ray_of_the_subsample": ray, "that_ray_alone": short(alone), "all_rays_but_it": short(rest),
                                         "others_keep_the_strict_bound": bool(rest_ok),
                                         "note": "bisection over the rays (the loss is a mean over rays); DESIGN 5: a ReLU-mask flip on one record"}
-                parity["ok"] = bool(parity["ok"] or rest_ok)
+                parity["ok"] = bool(rest_ok)       # THE rule: strict on all rays, or strict on all rays but one (reported, bounded)
             except Exception as e:
                 parity["single_ray"] = {"error": f"{type(e).__name__}: {e}"}
     cpu = {"value": round(Bs / med, 2), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
@@ -1654,6 +1672,33 @@ def main():
                  "ms_per_step": round(1e3 * el2 / n2, 4)}
         ops.MLP_IMPL = a.decoder
 
+    # ---- the same steps with the indirect-light policy forced to `full` (TENSOIR_INDIRECT_PRECISION=full): what a checkpoint
+    #      pays whose self-check rejects the fp16 kernels -- a 300^3 TRAINED checkpoint does (profiles/r06_precision_trained_300.json),
+    #      the freshly initialised field of this bench does not.  Same graphs, re-captured under the forced policy; single process
+    #      only (a re-capture must not run next to live RCCL threads).
+    full_line = None
+    if not use_dist and not a.no_graph and not a.no_full_pass and graphed.get(a.decoder) and ops.secondary_mlp_impl() is not None:
+        saved = (ops.INDIRECT_GUARD, ops.SECONDARY_MLP_IMPL, ops.SECONDARY_APP_IMPL)
+        try:
+            ops.INDIRECT_GUARD, ops.SECONDARY_MLP_IMPL, ops.SECONDARY_APP_IMPL = False, None, None
+            for gr in graphed[a.decoder]:
+                for b in batches:                            # re-capture + record capacities of every pose
+                    gr(rays=b, clone_outputs=False)
+            state["b"] = 0
+            elf, _ = timed(a.warmup, a.steps)
+            with torch.no_grad():
+                ret_full = graphed[a.decoder][0](rays=batches[0], clone_outputs=True)
+            full_line = {"policy": "full", "steps": a.steps, "value": round(n_gpus * B * a.steps / elf, 1),
+                         "ms_per_step": round(1e3 * elf / a.steps, 4), "in_flight": lanes,
+                         "kernels": "secondary-ray records through the primary-stage precision: " + ops.full_indirect_route(),
+                         "rgb_with_brdf_max_abs_vs_default_policy": float(f"{float((ret_full['rgb_with_brdf_map'] - ret['rgb_with_brdf_map']).abs().max()):.3e}")}
+        finally:
+            ops.INDIRECT_GUARD, ops.SECONDARY_MLP_IMPL, ops.SECONDARY_APP_IMPL = saved
+            for gr in graphed[a.decoder]:                    # back under the default policy for everything that follows
+                for b in batches:
+                    gr(rays=b, clone_outputs=False)
+        torch.cuda.synchronize()
+
     M = int((ret["acc_map"] > 0.5).sum())
     D = a.env_h * a.env_w
     # every pose once per round: the per-kernel durations are averages over the same rotation the timed region and a rocprofv3
@@ -1924,7 +1969,7 @@ def main():
         "pmc": pmc_meta,
         "library": library_info(),
         "settle_steps": SETTLE_STEPS,
-        "precision_policy": {"indirect": model.indirect_precision(),
+        "precision_policy": {"indirect": model.indirect_precision(), "full": full_line, "trained_300": trained_300_verdict(),
                              "secondary_gather": ops.secondary_app_impl() or "fp32", "secondary_decoder": ops.secondary_mlp_impl() or a.decoder,
                              "fused_gather_decoder": bool(ops.fused_indirect()), "limits": dict(ops.INDIRECT_PROBE),
                              "note": "auto (default): radiance of the secondary-ray records (indirect light) from fp16 shadow planes + single-product "

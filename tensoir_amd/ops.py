@@ -560,6 +560,11 @@ def fused_indirect():
     return FUSED_INDIRECT and AUX_TABLE and secondary_app_impl() == "h16" and secondary_mlp_impl() == "f16"
 
 
+def full_indirect_route():
+    """Which launches decode the secondary-ray records when the indirect-light policy says `full` (reported by bench.py)."""
+    return "tir_vm_app_fwd (fp32 taps, fp32 MFMA contraction) + tir_mlp_fwd_auxtab_bf16x3 (split-bf16 x3), feature rows through HBM"
+
+
 def secondary_app_impl():
     """Gather mode of the secondary-record radiance features under the current settings."""
     return SECONDARY_APP_IMPL if (MLP_IMPL == "bf16x3" and SECONDARY_APP_IMPL) else None

@@ -480,18 +480,29 @@ class Environment_Light:
             # guide tables of that search (ops.cdf_guide_tables): ~4 dependent loads per draw instead of log2(H) + log2(W)
             self.hdr_cdf_guide[name] = (ops.cdf_guide_tables(self.hdr_row_cdf[name], self.hdr_col_cdf[name])
                                         if os.environ.get("TENSOIR_CDF_GUIDE", "1") != "0" else None)
+            # :144-146, the tables of sample_type="uniform" (solid-angle-uniform cells; like the reference they belong to the
+            # size of the LAST map read)
+            updf = torch.ones(H, W, 1) * sin_theta.view(-1, 1, 1) / (H * W)
+            updf = updf / torch.sum(updf)
+            self.envir_map_uniform_pdf = updf.to(device)
+            self.envir_map_uniform_pdf_return = (updf * H * W / (2 * np.pi * np.pi * sin_theta.view(-1, 1, 1))).to(device)
 
     @torch.no_grad()
     def sample_light(self, light_name, bs, num_samples, sample_type="importance"):
         """:150-188.  The reference draws torch.multinomial over an expanded [bs, H*W] pdf; sampling bs*num
         indices from the 1-D pdf is the same distribution without materialising bs copies."""
-        if sample_type != "importance":
-            raise NotImplementedError("only importance sampling is used by scripts/relight_importance.py")
-        pdf = self.hdr_pdf_sample[light_name].view(-1)
+        if sample_type == "importance":
+            pdf, pdf_ret = self.hdr_pdf_sample[light_name].view(-1), self.hdr_pdf_return[light_name].view(-1)
+        elif sample_type == "uniform":                   # :174-188 (no caller in the reference's scripts)
+            pdf, pdf_ret = self.envir_map_uniform_pdf.view(-1), self.envir_map_uniform_pdf_return.view(-1)
+            if pdf.numel() != self.hdr_dir[light_name].shape[0] * self.hdr_dir[light_name].shape[1]:
+                raise ValueError(f"sample_light(uniform): map {light_name!r} has another size than the uniform tables (built for the last map read)")
+        else:
+            raise ValueError(f"sample_light: unknown sample_type {sample_type!r}")
         idx = torch.multinomial(pdf, bs * num_samples, replacement=True).view(bs, num_samples)
         d = self.hdr_dir[light_name].view(-1, 3)[idx]
         rgb = self.hdr_rgbs[light_name].view(-1, 3)[idx]
-        p = self.hdr_pdf_return[light_name].view(-1)[idx].unsqueeze(-1)
+        p = pdf_ret[idx].unsqueeze(-1)
         return d, rgb, p
 
     @torch.no_grad()

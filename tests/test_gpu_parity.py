@@ -430,6 +430,17 @@ def test_hdr_relight_vs_reference(env):
     d, rgb, pdf = el.sample_light("syn", 7, 64)
     assert d.shape == (7, 64, 3) and rgb.shape == (7, 64, 3) and pdf.shape == (7, 64, 1)
     assert rel(el.get_light("syn", G(env, "rays/rays")[:, 3:]), env.g["hdr/bg"], 1e-2) < 1e-4
+    # sample_type="uniform" (models/relight_utils.py:144-146, :174-188): cells drawn uniformly in SOLID ANGLE, returned pdf 1 / 4 pi
+    # (exactly: 1 / (2 pi^2 mean(sin theta)) on the map's rows); directions average to zero, z^2 to 1/3
+    torch.manual_seed(0)
+    d, rgb, pdf = el.sample_light("syn", 64, 512, sample_type="uniform")
+    assert d.shape == (64, 512, 3) and rgb.shape == (64, 512, 3) and pdf.shape == (64, 512, 1)
+    H = int(env.g["hdr/map"].shape[0])
+    want = 1.0 / (2.0 * np.pi ** 2 * float(torch.sin(torch.linspace(0.5 / H, np.pi - 0.5 / H, H)).mean()))      # -> 1 / 4 pi as H grows
+    assert float((pdf - want).abs().max()) < 1e-5 * want and abs(want - 1.0 / (4.0 * np.pi)) < 0.06 / (4.0 * np.pi)
+    assert float(d.mean(dim=(0, 1)).abs().max()) < 2e-2 and abs(float(d[..., 2].pow(2).mean()) - 1.0 / 3.0) < 3e-2
+    with pytest.raises(ValueError):
+        el.sample_light("syn", 1, 1, sample_type="nope")
 
 
 # ---------------------------------------------------------------- oracle on seeded inputs (mid size)
