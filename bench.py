@@ -542,7 +542,7 @@ def sharp_scene_line(a, device, args):
     with torch.no_grad():
         for _ in range(3):
             Renderer_TensoIR_train(rays, None, lidx, model, N_samples=a.samples, white_bg=True, is_train=False,
-                                   is_relight=True, sample_method="fixed_envirmap", chunk_size=160000, device=device, args=args)
+                                   is_relight=True, sample_method="fixed_envirmap", chunk_size=160000, device=device, args=args, _no_graph=True)
     torch.cuda.synchronize()
     agg = {}
     for name, e0, e1 in ops.TIMING:
@@ -652,7 +652,7 @@ def bench_image(a, embed=False):
         def run():
             with torch.no_grad():
                 return Renderer_TensoIR_train(rc, None, lc, model, N_samples=-1, white_bg=True, is_train=False, is_relight=True,
-                                              sample_method="fixed_envirmap", chunk_size=160000, device=device, args=args)
+                                              sample_method="fixed_envirmap", chunk_size=160000, device=device, args=args, _no_graph=True)
         ret_c = run()
         Mc, Dn = int((ret_c["acc_map"] > 0.5).sum()), a.env_h * a.env_w
         rows, gpu_ms, ev_over = attribute_kernels(run, 2, a.rays * 40 + a.rays * model.nSamples * 4, Mc * Dn * 40, device)
@@ -1551,10 +1551,10 @@ def main():
     def step_on(lane, eager, bi=0):
         rays = batches[bi]
         with torch.no_grad():
-            if a.no_graph or eager:
+            if a.no_graph or eager:       # (_no_graph: the per-kernel attribution needs the launches themselves, not the boundary's cached graph)
                 ret = Renderer_TensoIR_train(rays, None, lidx, model, N_samples=a.samples, white_bg=True,
                                              is_train=False, is_relight=True, sample_method="fixed_envirmap",
-                                             chunk_size=160000, device=device, args=args)
+                                             chunk_size=160000, device=device, args=args, _no_graph=True)
             else:           # the same launches, replayed as one HIP graph per decoder mode (tensoir_amd/graph.py)
                 try:
                     if ops.MLP_IMPL not in graphed:
@@ -1676,22 +1676,25 @@ def main():
     #      pays whose self-check rejects the fp16 kernels -- a 300^3 TRAINED checkpoint does (profiles/r06_precision_trained_300.json),
     #      the freshly initialised field of this bench does not.  Same graphs, re-captured under the forced policy; single process
     #      only (a re-capture must not run next to live RCCL threads).
-    full_line = None
+    #      `hp` = the auto policy's first fallback (round 6: one launch, fp32 taps, fp16 + fp8-residue decoder weights), `full` its last.
+    forced_lines = {}
     if not use_dist and not a.no_graph and not a.no_full_pass and graphed.get(a.decoder) and ops.secondary_mlp_impl() is not None:
         saved = (ops.INDIRECT_GUARD, ops.SECONDARY_MLP_IMPL, ops.SECONDARY_APP_IMPL)
         try:
-            ops.INDIRECT_GUARD, ops.SECONDARY_MLP_IMPL, ops.SECONDARY_APP_IMPL = False, None, None
-            for gr in graphed[a.decoder]:
-                for b in batches:                            # re-capture + record capacities of every pose
-                    gr(rays=b, clone_outputs=False)
-            state["b"] = 0
-            elf, _ = timed(a.warmup, a.steps)
-            with torch.no_grad():
-                ret_full = graphed[a.decoder][0](rays=batches[0], clone_outputs=True)
-            full_line = {"policy": "full", "steps": a.steps, "value": round(n_gpus * B * a.steps / elf, 1),
-                         "ms_per_step": round(1e3 * elf / a.steps, 4), "in_flight": lanes,
-                         "kernels": "secondary-ray records through the primary-stage precision: " + ops.full_indirect_route(),
-                         "rgb_with_brdf_max_abs_vs_default_policy": float(f"{float((ret_full['rgb_with_brdf_map'] - ret['rgb_with_brdf_map']).abs().max()):.3e}")}
+            rets = {}
+            for pol, flags, route in (("full", (False, None, None), ops.full_indirect_route()), ("hp", (False, "hp", None), ops.hp_indirect_route())):
+                ops.INDIRECT_GUARD, ops.SECONDARY_MLP_IMPL, ops.SECONDARY_APP_IMPL = flags
+                for gr in graphed[a.decoder]:
+                    for b in batches:                        # re-capture + record capacities of every pose
+                        gr(rays=b, clone_outputs=False)
+                state["b"] = 0
+                elf, _ = timed(a.warmup, a.steps)
+                with torch.no_grad():
+                    rets[pol] = graphed[a.decoder][0](rays=batches[0], clone_outputs=True)["rgb_with_brdf_map"]
+                forced_lines[pol] = {"policy": pol, "steps": a.steps, "value": round(n_gpus * B * a.steps / elf, 1),
+                                     "ms_per_step": round(1e3 * elf / a.steps, 4), "in_flight": lanes, "kernels": route,
+                                     "rgb_with_brdf_max_abs_vs_default_policy": float(f"{float((rets[pol] - ret['rgb_with_brdf_map']).abs().max()):.3e}")}
+            forced_lines["hp"]["rgb_with_brdf_max_abs_vs_full"] = float(f"{float((rets['hp'] - rets['full']).abs().max()):.3e}")
         finally:
             ops.INDIRECT_GUARD, ops.SECONDARY_MLP_IMPL, ops.SECONDARY_APP_IMPL = saved
             for gr in graphed[a.decoder]:                    # back under the default policy for everything that follows
@@ -1748,8 +1751,10 @@ def main():
         med = sorted(ts)[len(ts) // 2]
         boundary = {"rays_per_s": round(B / (med * 1e-3), 1), "ms": round(med, 4), "min_ms": round(min(ts), 4),
                     "max_ms": round(max(ts), 4),
-                    "protocol": f"BASELINE.md 2.1: eager Renderer_TensoIR_train(host rays) incl. H2D of rays, hipEvent pair per call, "
-                                f"10 warm-ups, median of {len(ts)}; call i renders pose i mod {len(r_hosts)}"}
+                    "protocol": f"BASELINE.md 2.1: Renderer_TensoIR_train(host rays) as the unmodified scripts call it, incl. H2D of rays, hipEvent pair "
+                                f"per call, 10 warm-ups, median of {len(ts)}; call i renders pose i mod {len(r_hosts)}; the boundary replays its cached "
+                                f"HIP graph of this call shape (tensoir_amd/renderer.py, round 6; TENSOIR_BOUNDARY_GRAPHS=0: eager launches)",
+                    "boundary_graphs": bool(__import__("tensoir_amd.renderer", fromlist=["x"]).BOUNDARY_GRAPHS)}
 
     # ---- CPU baseline: the oracle (same algorithm, ATen CPU ops) on a bounded sample; its outputs double as a
     #      full-size parity check of the HIP maps (rays are independent; sharding is bit-exact) --------------
@@ -1969,7 +1974,8 @@ def main():
         "pmc": pmc_meta,
         "library": library_info(),
         "settle_steps": SETTLE_STEPS,
-        "precision_policy": {"indirect": model.indirect_precision(), "full": full_line, "trained_300": trained_300_verdict(),
+        "precision_policy": {"indirect": model.indirect_precision(), "full": forced_lines.get("full"), "hp": forced_lines.get("hp"),
+                             "trained_300": trained_300_verdict(),
                              "secondary_gather": ops.secondary_app_impl() or "fp32", "secondary_decoder": ops.secondary_mlp_impl() or a.decoder,
                              "fused_gather_decoder": bool(ops.fused_indirect()), "limits": dict(ops.INDIRECT_PROBE),
                              "note": "auto (default): radiance of the secondary-ray records (indirect light) from fp16 shadow planes + single-product "

@@ -248,6 +248,17 @@ int tir_indirect_fused_fwd(const TirField* f, const TirFieldHalf* fh, const TirM
                            const int32_t* light_idx, const int32_t* rec_map, int32_t idx_div, int32_t aux_mod,
                            const float* table, float* out, int64_t n, const int32_t* n_dev, void* stream);
 
+/* The same stage (models/relight_utils.py:818-829: compute_appfeature -> renderModule on the secondary-ray records) in one
+ * launch at the precision a TRAINED checkpoint needs (the auto policy's fallback when its self-check rejects the fp16 kernel;
+ * before round 6 that fallback was tir_vm_app_fwd + tir_mlp_fwd_auxtab_bf16x3 with the feature rows through HBM): fp32 taps from
+ * the parameters themselves (no shadow), fp32 interpolation, basis_mat contraction on fp16 hi + lo operands (three products),
+ * decoder with fp16 activations and weights as fp16 + fp8 residue (tir_pack_mlp's OFF_F8 image; fp32 accumulation, layer 3
+ * exact).  Arguments as tir_indirect_fused_fwd without the shadow.  Deviation from the exact decoder on rgb_with_brdf_map:
+ * measured per checkpoint by the policy's self-check (profiles/r06_*). */
+int tir_indirect_fused_hp_fwd(const TirField* f, const TirMlp* m, const float* xyz, const int32_t* light_idx,
+                              const int32_t* rec_map, int32_t idx_div, int32_t aux_mod, const float* table, float* out,
+                              int64_t n, const int32_t* n_dev, void* stream);
+
 /* Up to four decoders over the SAME n rows in one launch (split-bf16 matrix cores): the primary stage evaluates the
  * radiance, BRDF, jittered-BRDF and normal decoders (models/tensorBase_rotated_lights.py:927-955) on the same records.
  * mlps / feats / auxs / aux_maps / outs are HOST arrays of n_jobs entries (aux_maps or its entries may be NULL); feature

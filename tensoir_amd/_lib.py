@@ -79,6 +79,7 @@ SIGNATURES = {
     "tir_pack_half_checked": (C.c_int, [P, P, P, I32, P, P]),
     "tir_vm_app_fwd_h16": (C.c_int, [C.POINTER(TirField), C.POINTER(TirFieldHalf), P, P, P, P, I32, I32, I64, P, P]),
     "tir_indirect_fused_fwd": (C.c_int, [C.POINTER(TirField), C.POINTER(TirFieldHalf), C.POINTER(TirMlp), P, P, P, I32, I32, P, P, I64, P, P]),
+    "tir_indirect_fused_hp_fwd": (C.c_int, [C.POINTER(TirField), C.POINTER(TirMlp), P, P, P, I32, I32, P, P, I64, P, P]),
     "tir_vm_app_fwd_valu": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I32, I64, P, P]),
     "tir_mlp_fwd": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P, P]),
     "tir_mlp_fwd_bf16x3": (C.c_int, [C.POINTER(TirMlp), P, I32, P, P, I32, P, I64, P, P]),

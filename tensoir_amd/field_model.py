@@ -656,7 +656,10 @@ class TensorVMSplit(nn.Module):
         """What the indirect-light precision policy decided for this model so far (ops.INDIRECT_GUARD, relight._indirect_mode):
         {"policy": auto|f16|full, "mode": f16|full|None, "why": ..., "probe": {...}} -- also written into checkpoints."""
         st = self.__dict__.get("_indirect_state") or {}
-        pol = "full" if (ops.secondary_mlp_impl() is None and ops.secondary_app_impl() is None) else ("auto" if ops.INDIRECT_GUARD else "f16")
+        if ops.secondary_app_impl() is None and ops.secondary_mlp_impl() in (None, "hp"):
+            pol = "hp" if ops.secondary_mlp_impl() == "hp" else "full"
+        else:
+            pol = "auto" if ops.INDIRECT_GUARD else "f16"
         return {"policy": pol, "mode": st.get("verdict") if pol == "auto" else pol, "why": st.get("why"), "probe": st.get("stats"),
                 "probes_run": st.get("probes", 0), "fallbacks": st.get("fallbacks", 0)}
 

@@ -98,7 +98,7 @@ class GraphedRenderer:
 
     def _eager(self):
         with torch.no_grad(), self._own_state():
-            return Renderer_TensoIR_train(self.rays, None, self.lidx, self.model, **self.kw)
+            return Renderer_TensoIR_train(self.rays, None, self.lidx, self.model, _no_graph=True, **self.kw)
 
     def _capture(self):
         self._eager()                                     # learns the capacities, fills every cache, sets kernel attributes
@@ -128,7 +128,7 @@ class GraphedRenderer:
         try:
             ops.CAPTURE_KEEPALIVE = self._keepalive
             with torch.no_grad(), self._own_state(), torch.cuda.graph(g):
-                self.out = Renderer_TensoIR_train(self.rays, None, self.lidx, self.model, **self.kw)
+                self.out = Renderer_TensoIR_train(self.rays, None, self.lidx, self.model, _no_graph=True, **self.kw)
                 if self.checks:
                     # the record counters, their running maxima and a sticky overflow flag (never cleared by a replay)
                     # leave the device as part of the graph: one single-thread kernel writing pinned host memory.

@@ -498,6 +498,24 @@ def indirect_fused(field: TirField, fh: TirFieldHalf, m: "PackedMlp", xyz, light
     return out
 
 
+def indirect_fused_hp(field: TirField, m: "PackedMlp", xyz, light_idx, rec_map, idx_div, dirs, n_dirs, n_dev=None):
+    """indirect_fused at the precision a trained checkpoint needs (tir_indirect_fused_hp_fwd): fp32 taps, fp16 hi + lo contraction,
+    decoder weights as fp16 + fp8 residue -- the auto policy's first fallback, one launch instead of gather + decoder with the
+    feature rows through HBM."""
+    xyz = f32(xyz, "xyz", 3).view(-1, 3)
+    n = xyz.shape[0]
+    light_idx = i32(light_idx, "light_idx").view(-1)
+    rec_map = i32(rec_map, "rec_map").view(-1)
+    if rec_map.numel() != n:
+        raise ValueError("rec_map must have one entry per record")
+    dirs = f32(dirs, "dirs", 3)
+    table = _aux_table_cached(m, dirs)
+    out = torch.empty((n, m.out_dim), dtype=torch.float32, device=xyz.device)
+    _call("tir_indirect_fused_hp_fwd", C.byref(field), C.byref(m.desc), _ptr(xyz), _ptr(light_idx), _ptr(rec_map), int(idx_div),
+          int(n_dirs), _ptr(table), _ptr(out), n, _ptr(n_dev), _stream())
+    return out
+
+
 # decoder implementations: "mfma" = exact fp32 matrix cores, "bf16x3" = split-bf16 matrix cores (parity
 # grade, ~5x fewer MFMA cycles), "bf16" = single-product reduced precision, "valu" = cross-check kernel
 MLP_ENTRY = {"mfma": "tir_mlp_fwd", "bf16x3": "tir_mlp_fwd_bf16x3", "bf16": "tir_mlp_fwd_bf16",
@@ -522,12 +540,18 @@ if MLP_IMPL not in MLP_ENTRY:
 #                                  versions otherwise (optimizer steps).  Anything else falls back to `full` for that version
 #                                  (relight._indirect_mode; the verdict is kept with the model and written into checkpoints).
 # Applies only while MLP_IMPL is the split-bf16 default (the exact / cross-check decoder modes stay exact end to end).
+#                              = hp (round 6): the high-precision fused kernel unconditionally (tir_indirect_fused_hp_fwd: fp32 taps,
+#                                  decoder weights as fp16 + fp8 residue).  Under `auto` it is the FIRST fallback: a version whose
+#                                  self-check rejects the f16 kernels is checked the same way with the hp kernel (both against the
+#                                  full kernels) and only goes to `full` when that fails too -- a field trained to 300^3 takes
+#                                  this route (profiles/r06_precision_trained_300.json).  TENSOIR_INDIRECT_HP=0 removes the tier.
 _IND = os.environ.get("TENSOIR_INDIRECT_PRECISION", "auto")
-if _IND not in ("auto", "f16", "full"):
-    raise ValueError(f"TENSOIR_INDIRECT_PRECISION={_IND!r}: expected auto, f16 or full")
-SECONDARY_MLP_IMPL = "f16" if _IND != "full" else None       # None | "f16" | "bf16" (probe only) | "bf16x3"
-SECONDARY_APP_IMPL = "h16" if _IND != "full" else None       # None | "h16"
-INDIRECT_GUARD = _IND == "auto"        # False: the settings above apply unconditionally (f16: the caller vouches for range and precision)
+if _IND not in ("auto", "f16", "hp", "full"):
+    raise ValueError(f"TENSOIR_INDIRECT_PRECISION={_IND!r}: expected auto, f16, hp or full")
+SECONDARY_MLP_IMPL = {"full": None, "hp": "hp"}.get(_IND, "f16")       # None | "f16" | "hp" | "bf16" (probe only) | "bf16x3"
+SECONDARY_APP_IMPL = "h16" if _IND in ("auto", "f16") else None        # None | "h16"
+INDIRECT_GUARD = _IND == "auto"        # False: the settings above apply unconditionally (f16 / hp: the caller vouches for range and precision)
+INDIRECT_HP = os.environ.get("TENSOIR_INDIRECT_HP", "1") != "0"        # the hp tier of the auto policy
 # The self-check.  Through render_with_BRDF / Renderer_TensoIR_train (relight.shade_from_maps) it is a MEASUREMENT of the
 # quantity the tolerance is stated on: all secondary-ray records of the pass are decoded by both paths, the integration kernel
 # renders rgb_with_brdf_map from both, and the f16 kernels are kept while
@@ -563,6 +587,11 @@ def fused_indirect():
 def full_indirect_route():
     """Which launches decode the secondary-ray records when the indirect-light policy says `full` (reported by bench.py)."""
     return "tir_vm_app_fwd (fp32 taps, fp32 MFMA contraction) + tir_mlp_fwd_auxtab_bf16x3 (split-bf16 x3), feature rows through HBM"
+
+
+def hp_indirect_route():
+    return ("tir_indirect_fused_hp_fwd: fp32 taps, fp16 hi + lo basis contraction, decoder with fp16 activations and fp16 + fp8-residue "
+            "weights, one launch, feature rows in registers")
 
 
 def secondary_app_impl():

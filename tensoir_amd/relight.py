@@ -73,8 +73,9 @@ def _indirect_key(tensoIR):
 
 
 def _indirect_mode(tensoIR, training=False):
-    """Which kernels decode this pass's secondary-ray records: "full" (primary-stage kernels), "f16" (the precision policy's
-    kernels) or "probe" (auto policy, no valid verdict for the current parameters: run f16, self-check against full, decide).
+    """Which kernels decode this pass's secondary-ray records: "full" (primary-stage kernels), "f16" (the precision policy's fast
+    kernels), "hp" (the high-precision fused kernel, ops.indirect_fused_hp) or "probe" (auto policy, no valid verdict for the
+    current parameters: run f16, self-check against full, if that fails self-check hp against full, decide).
 
     auto (ops.INDIRECT_GUARD): a verdict belongs to one parameter version.  Inference passes always use a verdict of exactly
     the current version (so the same parameters render the same image whatever was rendered before).  TRAINING passes
@@ -82,8 +83,8 @@ def _indirect_mode(tensoIR, training=False):
     versions of the SAME storage -- an optimizer step moves a parameter by at most the learning rate -- for
     ops.INDIRECT_PROBE["interval"] versions, then re-establish it; new storage (load, upsample, shrink) re-establishes it at
     once.  The range guard is evaluated for EVERY version (HalfRange, no extra synchronisation) by the caller."""
-    if ops.secondary_app_impl() != "h16" and ops.secondary_mlp_impl() is None:
-        return "full"
+    if ops.secondary_app_impl() != "h16" and ops.secondary_mlp_impl() in (None, "hp"):
+        return "hp" if ops.secondary_mlp_impl() == "hp" else "full"
     if not ops.INDIRECT_GUARD:
         return "f16"
     st = _indirect_state(tensoIR)
@@ -196,42 +197,66 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
             if capture is not None and rng is not None and not rng.ready():
                 raise ops._lib.TensoirHipError("graph capture needs a finished range check of the fp16 field shadow (run the pass eagerly first)")
 
-            def decode(full, fh=fh):
-                if not full and fh is not None and dir_map is None and n_dirs > 0 and ops.fused_indirect() \
-                        and dirs.shape[0] * 8 <= max(n_rows, 1) and int(f.app_dim) == 27 and int(f.n_lights) <= 16:
+            fusable = dir_map is None and n_dirs > 0 and dirs.shape[0] * 8 <= max(n_rows, 1) and int(f.app_dim) == 27 and int(f.n_acomp) == 48
+
+            def decode(kind, fh=fh):
+                """kind: "f16" (fp16 shadow + fp16 decoder), "hp" (fp32 taps, fp16 + fp8-residue weights) or "full"."""
+                if kind == "f16" and fh is not None and fusable and ops.fused_indirect() and int(f.n_lights) <= 16:
                     # gather -> basis contraction -> radiance decoder in ONE launch, the feature rows never reach HBM
                     return ops.indirect_fused(f, fh, tensoIR.renderModule.packed(), rec_xyz, light_idx, rec_ray, light_div, dirs, n_dirs, n_dev)
-                return _gather_then_decode(tensoIR, f, fh, rec_xyz, light_idx, rec_ray, light_div, dirs, dir_map, n_dirs, n_dev, full=full)
+                if kind == "hp" and fusable and ops.AUX_TABLE and ops.MLP_IMPL == "bf16x3":
+                    return ops.indirect_fused_hp(f, tensoIR.renderModule.packed(), rec_xyz, light_idx, rec_ray, light_div, dirs, n_dirs, n_dev)
+                return _gather_then_decode(tensoIR, f, fh, rec_xyz, light_idx, rec_ray, light_div, dirs, dir_map, n_dirs, n_dev,
+                                           full=kind != "f16")
 
             def packed(rgb):
                 if keep_records:       # the caller's integration kernel sums the records itself (tir_shade_integrate_records)
                     return {"off": rec["off"], "cnt": rec["cnt"], "w": rec_w, "rgb": rgb}
                 return ops.accumulate_records(rec["off"], rec["cnt"], rec_w, rgb, n_rays)
 
-            rgb = decode(mode == "full")
+            rgb = decode("f16" if mode == "probe" else mode)
             if mode == "probe":        # auto policy, no verdict for these parameters yet: self-check on this pass's own records
                 n_valid = min(total if first else total_host.get(), n_rows)
+                verdict = "f16"
                 if probe_map is not None:
                     # the caller renders rgb_with_brdf_map from BOTH decodes of ALL records of this pass: the quantity the
                     # tolerance is stated on, measured -- not estimated
-                    rgb_full = decode(True)
-                    d = (rgb[:n_valid] - rgb_full[:n_valid]).double()
-                    delta = probe_map(vis, packed(rgb), packed(rgb_full))
-                    v = (torch.stack([d.mean(0).abs().max(), d.pow(2).mean().sqrt(), d.abs().max()]).tolist() if n_valid else [0.0, 0.0, 0.0])
-                    stats = {"kind": "map", "map_max_abs": delta, "records": n_valid, "rays": n_rays, "bias": v[0], "rms": v[1], "max": v[2]}
+                    rgb_full = decode("full")
                     # a TRAINING pass renders the map as a no_grad constant of the loss (models/relight_utils.py:344): there the
                     # policy accepts up to the contract's own tolerance; inference / export use the strict limit
                     map_limit = ops.INDIRECT_PROBE["train_map_limit" if training else "map_limit"]
-                    stats["limit"] = map_limit
-                    ok = delta <= map_limit                                  # (NaN fails)
+
+                    def measure(cand):
+                        d = (cand[:n_valid] - rgb_full[:n_valid]).double()
+                        delta = probe_map(vis, packed(cand), packed(rgb_full))
+                        v = (torch.stack([d.mean(0).abs().max(), d.pow(2).mean().sqrt(), d.abs().max()]).tolist() if n_valid else [0.0, 0.0, 0.0])
+                        return delta, {"kind": "map", "map_max_abs": delta, "records": n_valid, "rays": n_rays, "bias": v[0], "rms": v[1], "max": v[2],
+                                       "limit": map_limit}
+                    delta, stats = measure(rgb)
                     _indirect_state(tensoIR)["probes"] += 1
-                    if not ok:
-                        rgb = rgb_full
+                    if not delta <= map_limit:                               # (NaN fails)
+                        verdict = "full"
+                        if ops.INDIRECT_HP:                                  # first fallback: the high-precision fused kernel, checked the same way
+                            rgb_hp = decode("hp")
+                            delta_hp, stats_hp = measure(rgb_hp)
+                            stats = {**stats_hp, "f16": stats}
+                            if delta_hp <= map_limit:
+                                verdict, rgb = "hp", rgb_hp
+                        if verdict == "full":
+                            rgb = rgb_full
                 else:
                     ok, stats = _probe_indirect(tensoIR, f, rgb, n_valid, rec_xyz, light_idx, rec_ray, light_div, dirs, dir_map, n_dirs)
                     if not ok:
-                        rgb = decode(True)
-                _set_verdict(tensoIR, "f16" if ok else "full", "probe", stats, train_limit=training and probe_map is not None)
+                        verdict = "full"
+                        if ops.INDIRECT_HP and fusable and ops.AUX_TABLE and ops.MLP_IMPL == "bf16x3":
+                            rgb_hp = decode("hp")
+                            ok_hp, stats_hp = _probe_indirect(tensoIR, f, rgb_hp, n_valid, rec_xyz, light_idx, rec_ray, light_div, dirs, dir_map, n_dirs)
+                            stats = {**stats_hp, "f16": stats}
+                            if ok_hp:
+                                verdict, rgb = "hp", rgb_hp
+                        if verdict == "full":
+                            rgb = decode("full")
+                _set_verdict(tensoIR, verdict, "probe", stats, train_limit=training and probe_map is not None)
                 rng = None             # (evaluated above)
             indirect = packed(rgb)
         else:

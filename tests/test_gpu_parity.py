@@ -142,6 +142,53 @@ def test_decoder_large_biases(env):
 
 
 @torch.no_grad()
+def test_high_precision_fused_indirect_kernel(env):
+    """tir_indirect_fused_hp_fwd (the auto policy's first fallback, models/relight_utils.py:818-829 in one launch): against the
+    exact route it stands in for -- fp32 gather + exact fp32 decoder -- on random records incl. points near / outside the borders,
+    a multi-light index map, ragged and device-side counts.  Its deviation is the fp16 rounding of the ACTIVATIONS (random, zero
+    mean: |max| < 3e-4, |mean| < 3e-6 per channel); the weight rounding of the fp16 kernel (a fixed perturbation) is gone: with the
+    decoder's weights x8 (where the fp16 kernel's error grows ~8^2-fold) the mean deviation stays below the fp16 kernel's by > 4x."""
+    import tensoir_amd
+    from tensoir_amd import ops
+    from tests.helpers import golden_checkpoint
+    m = env.model
+    gen = torch.Generator().manual_seed(12)
+    D, npt = 16, 40
+    dirs = torch.nn.functional.normalize(torch.randn(D, 3, generator=gen), dim=-1).cuda()
+    lpt = torch.randint(0, m.light_num, (npt,), generator=gen).int().cuda()
+
+    def routes(model, npts):
+        fld, pm = model.packed_field(), model.renderModule.packed()
+        pts = (torch.rand(npts, 3, generator=gen) * 1.9 - 0.95).cuda()
+        pair = torch.randint(0, npt * D, (npts,), generator=gen).int().cuda()            # pair id: point = id // D, direction = id % D
+        exact = ops.mlp(pm, ops.vm_app(fld, pts, lpt, pair, True, False, None, D)[0], dirs, pair, "mfma", D)
+        hp = ops.indirect_fused_hp(fld, pm, pts, lpt, pair, D, dirs, D)
+        return fld, pm, pts, pair, exact, hp
+    for npts in (1, 37, 255, 5003, 70001):
+        fld, pm, pts, pair, exact, hp = routes(m, npts)
+        assert hp.shape == (npts, 3) and bool(torch.isfinite(hp).all())
+        d = (hp - exact).double()
+        assert float(d.abs().max()) < 3e-4, (npts, float(d.abs().max()))
+        if npts > 1000:
+            assert float(d.mean(0).abs().max()) < 3e-6, (npts, d.mean(0))
+        if npts > 10:
+            n_dev = torch.tensor([npts - 7], dtype=torch.int32, device="cuda")
+            part = ops.indirect_fused_hp(fld, pm, pts, lpt, pair, D, dirs, D, n_dev)
+            assert torch.equal(part[:npts - 7], hp[:npts - 7])
+    # larger decoder weights: the fp16 kernel's systematic part (weight rounding) against the hp kernel's
+    ck = golden_checkpoint(env.g)
+    for layer in (0, 2):
+        ck["state_dict"][f"renderModule.mlp.{layer}.weight"] = ck["state_dict"][f"renderModule.mlp.{layer}.weight"] * 8.0
+    eh, ew = [int(x) for x in env.g["scene/envmap_hw"]]
+    m8 = tensoir_amd.model_from_checkpoint(ck, "cuda", envmap_h=eh, envmap_w=ew)
+    fld, pm, pts, pair, exact, hp = routes(m8, 70001)
+    f16 = ops.indirect_fused(fld, m8.packed_field_half(), pm, pts, lpt, pair, D, dirs, D)
+    e_hp, e_16 = (hp - exact).double(), (f16 - exact).double()
+    assert float(e_hp.pow(2).mean().sqrt()) < float(e_16.pow(2).mean().sqrt())
+    assert float(e_hp.mean(0).abs().max()) * 4 < max(float(e_16.mean(0).abs().max()), 4e-6), (e_hp.mean(0), e_16.mean(0))
+
+
+@torch.no_grad()
 def test_indirect_precision_policy_kernels(env):
     """The two launches of the indirect-light precision policy, each against the parity-grade kernel it replaces
     on the secondary-ray records:
@@ -770,6 +817,55 @@ def test_hip_graph_replay_matches_eager(env):
     got3 = gr(rays, lidx)
     for k in keys:
         assert torch.equal(got3[k], want[k]), k
+
+
+@torch.no_grad()
+def test_boundary_call_replays_a_cached_graph(env, monkeypatch):
+    """Renderer_TensoIR_train itself (renderer.py:57-127, what the unmodified scripts' evaluation loops call chunk after chunk,
+    :225-249): from the second call of a shape on, an inference call replays a cached HIP graph -- identical maps, fresh output
+    tensors, host rays accepted; small / training / gradient-enabled calls never use it; a parameter update re-captures; the
+    switch turns it off."""
+    from tensoir_amd import Renderer_TensoIR_train, renderer
+    m = env.model
+    m.__dict__.pop("_boundary_graphs", None)
+    rays0, lidx0 = G(env, "rays/rays"), G(env, "rays/light_idx")
+    rep = (1100 + rays0.shape[0] - 1) // rays0.shape[0]
+    rays = rays0.repeat(rep, 1)[:1100].clone()
+    gen = torch.Generator().manual_seed(3)
+    rays[:, 3:6] = torch.nn.functional.normalize(rays[:, 3:6] + 0.01 * torch.randn(1100, 3, generator=gen).cuda(), dim=-1)
+    lidx = lidx0.repeat(rep, 1)[:1100].contiguous()
+    kw = dict(N_samples=-1, white_bg=True, is_train=False, is_relight=True, sample_method="fixed_envirmap", device="cuda", args=env.args)
+    keys = ("rgb_map", "depth_map", "normal_map", "albedo_map", "acc_map", "rgb_with_brdf_map", "normals_diff_map")
+    want = Renderer_TensoIR_train(rays, None, lidx, m, _no_graph=True, **kw)
+    assert "_boundary_graphs" not in m.__dict__
+    outs = [Renderer_TensoIR_train(rays.cpu(), None, lidx.cpu(), m, **kw) for _ in range(3)]      # host rays, as the scripts pass them
+    cache = m.__dict__["_boundary_graphs"]
+    (entry,) = cache.values()
+    assert entry[0] is not None and entry[0].captures == 1 and entry[2] == 3
+    for o in outs:
+        for k in keys:
+            assert torch.equal(o[k], want[k]), k
+    assert outs[1]["rgb_map"].data_ptr() != outs[2]["rgb_map"].data_ptr()                          # a caller may keep what it got
+    Renderer_TensoIR_train(rays[:100], None, lidx[:100], m, **kw)                                  # too small to be worth a graph
+    with torch.enable_grad():
+        Renderer_TensoIR_train(rays, None, lidx, m, **kw)                                          # gradient mode: the eager route
+    assert len(cache) == 1 and entry[2] == 3
+    saved = m.density_plane[0].detach().clone()
+    try:
+        m.density_plane[0].mul_(1.5)                                                               # new parameter version: captured again
+        want2 = Renderer_TensoIR_train(rays, None, lidx, m, _no_graph=True, **kw)
+        got2 = Renderer_TensoIR_train(rays, None, lidx, m, **kw)
+        assert entry[0].captures == 2
+        for k in keys:
+            assert torch.equal(got2[k], want2[k]), k
+    finally:
+        m.density_plane[0].copy_(saved)
+    monkeypatch.setattr(renderer, "BOUNDARY_GRAPHS", False)
+    off = Renderer_TensoIR_train(rays, None, lidx, m, **kw)
+    assert entry[2] == 4
+    for k in keys:
+        assert torch.equal(off[k], want[k]), k
+    m.__dict__.pop("_boundary_graphs", None)
 
 
 @torch.no_grad()

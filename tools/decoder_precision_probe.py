@@ -9,6 +9,7 @@ model's own rays:
   f16x1   : W, x rounded to fp16 (the shipped fp16 decoder's arithmetic)
   f16x2   : x = hi + lo in fp16 (two products), W rounded to fp16            -- one LDS operand image
   f16x2w  : W = hi + lo in fp16 (two products), x rounded to fp16
+  f16+fp8c: W = fp16 hi + fp8 lo (x 2^17), the lo product on v_mfma_f32_32x32x16_fp8_fp8 operands -- 1.5 LDS images
   f16x3l1 : layer 1 three products (x and W split), layer 2 as f16x2          -- 1.5 LDS images
   f16x3   : three products in both layers
   bf16x3  : the primary-stage scheme
@@ -38,6 +39,11 @@ def prod(x, w, scheme):
     wh, wl = split(w, dt)
     if scheme in ("f16x1",):
         return xh @ wh.t()
+    if scheme == "f16+fp8c":       # W = fp16 hi + fp8(e4m3) lo scaled by 2^17, the lo product on fp8 operands (x rounded to fp8 there)
+        f8 = torch.float8_e4m3fn
+        wl8 = ((w - wh) * 2.0 ** 17).clamp(-448, 448).to(f8).float()
+        x8 = x.clamp(-448, 448).to(f8).float()
+        return xh @ wh.t() + (x8 @ wl8.t()) * 2.0 ** -17
     if scheme == "f16x2":
         return xh @ wh.t() + xl @ wh.t()
     if scheme == "f16x2w":
@@ -46,7 +52,7 @@ def prod(x, w, scheme):
 
 
 SCHEMES = {"exact": ("exact", "exact"), "f16x1": ("f16x1", "f16x1"), "f16x2": ("f16x2", "f16x2"), "f16x2w": ("f16x2w", "f16x2w"),
-           "f16x3l1": ("f16x3", "f16x2"), "f16x3": ("f16x3", "f16x3"), "bf16x3": ("bf16x3", "bf16x3")}
+           "f16+fp8c": ("f16+fp8c", "f16+fp8c"), "f16x3l1": ("f16x3", "f16x2"), "f16x3": ("f16x3", "f16x3"), "bf16x3": ("bf16x3", "bf16x3")}
 
 
 def main():
