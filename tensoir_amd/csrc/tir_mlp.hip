@@ -1118,11 +1118,9 @@ __device__ __forceinline__ long lds_tile8(unsigned base, int byte_off) {
     return *reinterpret_cast<lds_i64*>(base + (unsigned)byte_off);
 }
 
-// 8 floats -> 8 fp8 (e4m3, saturating at +-448), byte e = value e: the B operand of v_mfma_f32_32x32x16_fp8_fp8
-__device__ __forceinline__ long cvt8_fp8(const float (&v)[8]) {
-    float c[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) c[e] = __builtin_amdgcn_fmed3f(v[e], -448.0f, 448.0f);
+// 8 floats (|v| <= 448, the largest finite e4m3: the caller clamps) -> 8 fp8, byte e = value e: the B operand of
+// v_mfma_f32_32x32x16_fp8_fp8
+__device__ __forceinline__ long cvt8_fp8(const float (&c)[8]) {
     int lo = 0, hi = 0;
     lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], lo, false);
     lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
@@ -1131,9 +1129,18 @@ __device__ __forceinline__ long cvt8_fp8(const float (&v)[8]) {
     return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo);
 }
 
+// input slot KK for the fp8 residue product: the PE slots are in [-1, 1] as they are; the raw feature comes from fo8 = fo clamped to
+// +-448 (16 clamps per record instead of one per input)
+template <int KK>
+__device__ __forceinline__ float fus_input8(const float (&fo)[16], const float (&fo8)[16]) {
+    if constexpr (KK % 5 == 4 && KK / 5 < FUS_NF0) return fo8[KK / 5];
+    else return fus_input<KK>(fo);
+}
+
 // layer 1 of the high-precision decoder, k-block KB: fp16 product into acc, fp8 residue product into corr
 template <int KB>
-__device__ __forceinline__ void hp_layer1(unsigned whi, unsigned w8, const float (&fo)[16], f32x16 (&acc)[4], f32x16 (&corr)[4]) {
+__device__ __forceinline__ void hp_layer1(unsigned whi, unsigned w8, const float (&fo)[16], const float (&fo8)[16], f32x16 (&acc)[4],
+                                          f32x16 (&corr)[4]) {
     bf16x8 ah[4];
     long a8[4];
 #pragma unroll
@@ -1143,16 +1150,18 @@ __device__ __forceinline__ void hp_layer1(unsigned whi, unsigned w8, const float
     }
     const float v[8] = {fus_input<KB * 8 + 0>(fo), fus_input<KB * 8 + 1>(fo), fus_input<KB * 8 + 2>(fo), fus_input<KB * 8 + 3>(fo),
                         fus_input<KB * 8 + 4>(fo), fus_input<KB * 8 + 5>(fo), fus_input<KB * 8 + 6>(fo), fus_input<KB * 8 + 7>(fo)};
+    const float v8[8] = {fus_input8<KB * 8 + 0>(fo, fo8), fus_input8<KB * 8 + 1>(fo, fo8), fus_input8<KB * 8 + 2>(fo, fo8), fus_input8<KB * 8 + 3>(fo, fo8),
+                         fus_input8<KB * 8 + 4>(fo, fo8), fus_input8<KB * 8 + 5>(fo, fo8), fus_input8<KB * 8 + 6>(fo, fo8), fus_input8<KB * 8 + 7>(fo, fo8)};
     bf16x8 xh;
     cvt8_f16(v, xh);
-    const long x8 = cvt8_fp8(v);
+    const long x8 = cvt8_fp8(v8);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[mt]), __builtin_bit_cast(f16x8, xh), acc[mt], 0, 0, 0);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) corr[mt] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a8[mt], x8, corr[mt], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (KB + 1 < KB0A) hp_layer1<KB + 1>(whi, w8, fo, acc, corr);
+    if constexpr (KB + 1 < KB0A) hp_layer1<KB + 1>(whi, w8, fo, fo8, acc, corr);
 }
 
 // layer 2 from packed activations: hp[p] = fp16 pair, h8[p] = fp8 quad of relu(h) in accumulator order
@@ -1177,43 +1186,75 @@ __device__ __forceinline__ void hp_layer2(unsigned whi, unsigned w8, const unsig
     if constexpr (KB + 1 < KB1) hp_layer2<KB + 1>(whi, w8, hp, h8, acc, corr);
 }
 
-// the six fp32 taps of one 16-byte quarter of a 64-byte run, bilinear x linear -> 4 channel values
-struct HpTap { unsigned o00, o01, o10, o11, l0, l1; float w00, w01, w10, w11, wl0, wl1; };
+// Per record: the taps of the three axes (computed ONCE, shared by the two planes and the line that use each axis -- the
+// density march's scheme, tir_common.hpp make_tap_q) and the byte offsets of this lane's 16-byte quarter inside row `index`.
+// A texel / line row of the appearance field is 48 channels x 4 B = 192 B.
+constexpr unsigned HP_TB = 192;
+struct HpAxes { tir::TapQ t[3]; unsigned ob[3][2]; };
 
-__device__ __forceinline__ HpTap hp_make_tap(const TirField& f, int k, const float (&p)[3], int c) {
-    using namespace tir;
-    constexpr int CA = 48;
-    const int H = f.grid[(k == 0) ? 1 : 2], W = f.grid[(k == 2) ? 1 : 0], R = f.grid[2 - k];
-    const float u = (k == 2) ? p[1] : p[0], v = (k == 0) ? p[1] : p[2], w = (k == 0) ? p[2] : ((k == 1) ? p[1] : p[0]);
-    const Tap1 tx = make_tap(u, W), ty = make_tap(v, H), tl = make_tap(w, R);
-    HpTap t;
-    t.w00 = tx.w0 * ty.w0; t.w01 = tx.w1 * ty.w0; t.w10 = tx.w0 * ty.w1; t.w11 = tx.w1 * ty.w1;
-    t.wl0 = tl.w0; t.wl1 = tl.w1;
-    // element offsets on the full-rate 24-bit multiplier (tir_app_index_ok: indices and row pitch < 2^24, products < 2^31)
-    const unsigned pitch = (unsigned)(W * CA);
-    const unsigned q0 = mul_u24((unsigned)ty.i0, pitch), q1 = mul_u24((unsigned)ty.i1, pitch);
-    const unsigned x0 = mul_u24((unsigned)tx.i0, CA) + 4 * c, x1 = mul_u24((unsigned)tx.i1, CA) + 4 * c;
-    t.o00 = q0 + x0; t.o01 = q0 + x1; t.o10 = q1 + x0; t.o11 = q1 + x1;
-    t.l0 = mul_u24((unsigned)tl.i0, CA) + 4 * c; t.l1 = mul_u24((unsigned)tl.i1, CA) + 4 * c;
-    return t;
+__device__ __forceinline__ HpAxes hp_axes(const TirField& f, const float (&p)[3], int c) {
+    HpAxes A;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        A.t[a] = tir::make_tap_q(p[a], f.grid[a]);
+        A.ob[a][0] = tir::mul_u24(A.t[a].i0, HP_TB) + 16u * (unsigned)c;
+        A.ob[a][1] = tir::mul_u24(A.t[a].i1, HP_TB) + 16u * (unsigned)c;
+    }
+    return A;
 }
 
-// plane x line x light of 4 channels -> fp16 hi / lo halves (8 B each) of the product tile row
+// the six tap offsets (bytes) and the packed weights of VM group k for one record.  k is a constant after unrolling (a run-time
+// k would turn the axis selects into a scratch table, see k_indirect_fused).
+struct HpGroup { unsigned o00, o01, o10, o11, l0, l1; tir::tir_f2 wa, wb, wl; };
+
+__device__ __forceinline__ HpGroup hp_group(const TirField& f, const HpAxes& A, const int k) {
+    const int m0 = (k == 2) ? 1 : 0, m1 = (k == 0) ? 1 : 2, vi = 2 - k;
+    const tir::TapQ &tx = A.t[m0], &ty = A.t[m1], &tl = A.t[vi];
+    HpGroup g;
+    g.wa = tx.w * tir::tir_f2{ty.w.x, ty.w.x};       // (w00, w01)
+    g.wb = tx.w * tir::tir_f2{ty.w.y, ty.w.y};       // (w10, w11)
+    g.wl = tl.w;
+    // row starts in bytes on the full-rate 24-bit multiplier (row bytes < 2^24 and plane bytes < 2^32: checked by the launcher)
+    const unsigned row_bytes = (unsigned)f.grid[m0] * HP_TB;
+    const unsigned r0 = tir::mul_u24(ty.i0, row_bytes), r1 = tir::mul_u24(ty.i1, row_bytes);
+    g.o00 = r0 + A.ob[m0][0]; g.o01 = r0 + A.ob[m0][1]; g.o10 = r1 + A.ob[m0][0]; g.o11 = r1 + A.ob[m0][1];
+    g.l0 = A.ob[vi][0]; g.l1 = A.ob[vi][1];
+    return g;
+}
+
+// the 12 loads of one 16-channel chunk: six taps x two passes (records gj and 16 + gj), this lane's 16-byte quarter
+struct HpChunk { float4 a0, b0, c0, d0, e0, g0, a1, b1, c1, d1, e1, g1; };
+
+__device__ __forceinline__ void hp_issue(HpChunk& c, const float* __restrict__ pl, const float* __restrict__ ln, const HpGroup& tA,
+                                         const HpGroup& tB, const int q) {
+    const unsigned o = 64u * (unsigned)q;            // (a constant after unrolling: the instruction's immediate offset)
+    c.a0 = tir::ld4b(pl, tA.o00 + o); c.b0 = tir::ld4b(pl, tA.o01 + o); c.c0 = tir::ld4b(pl, tA.o10 + o);
+    c.d0 = tir::ld4b(pl, tA.o11 + o); c.e0 = tir::ld4b(ln, tA.l0 + o);  c.g0 = tir::ld4b(ln, tA.l1 + o);
+    c.a1 = tir::ld4b(pl, tB.o00 + o); c.b1 = tir::ld4b(pl, tB.o01 + o); c.c1 = tir::ld4b(pl, tB.o10 + o);
+    c.d1 = tir::ld4b(pl, tB.o11 + o); c.e1 = tir::ld4b(ln, tB.l0 + o);  c.g1 = tir::ld4b(ln, tB.l1 + o);
+}
+
+// plane x line x light of 4 channels -> fp16 hi / lo halves (8 B each) of the product-tile row.  Scalar fp32 chains (the
+// arithmetic of k_vm_app_mfma).  NOT the packed-fp32 form of the density march: with v_pk_mul_f32 / v_pk_fma_f32 here, results of
+// the last 16 lanes of a wave changed from run to run (a few records in 10^4, 1e-4 off; found with tools/hp_debug.py, bisected to
+// exactly this choice by build variants -- waits, issue order, inline-asm helpers and the LDS light rows all ruled out); the scalar
+// form is bit-reproducible.
 __device__ __forceinline__ void hp_products(const float4& a, const float4& b, const float4& cc, const float4& d, const float4& e,
-                                            const float4& g, const HpTap& t, const float4& lr, _Float16* __restrict__ xh,
+                                            const float4& g, const HpGroup& t, const float4& lr, _Float16* __restrict__ xh,
                                             _Float16* __restrict__ xl) {
     float val[4];
-    val[0] = fmaf(d.x, t.w11, fmaf(cc.x, t.w10, fmaf(b.x, t.w01, a.x * t.w00))) * fmaf(g.x, t.wl1, e.x * t.wl0) * lr.x;
-    val[1] = fmaf(d.y, t.w11, fmaf(cc.y, t.w10, fmaf(b.y, t.w01, a.y * t.w00))) * fmaf(g.y, t.wl1, e.y * t.wl0) * lr.y;
-    val[2] = fmaf(d.z, t.w11, fmaf(cc.z, t.w10, fmaf(b.z, t.w01, a.z * t.w00))) * fmaf(g.z, t.wl1, e.z * t.wl0) * lr.z;
-    val[3] = fmaf(d.w, t.w11, fmaf(cc.w, t.w10, fmaf(b.w, t.w01, a.w * t.w00))) * fmaf(g.w, t.wl1, e.w * t.wl0) * lr.w;
+    val[0] = fmaf(d.x, t.wb.y, fmaf(cc.x, t.wb.x, fmaf(b.x, t.wa.y, a.x * t.wa.x))) * fmaf(g.x, t.wl.y, e.x * t.wl.x) * lr.x;
+    val[1] = fmaf(d.y, t.wb.y, fmaf(cc.y, t.wb.x, fmaf(b.y, t.wa.y, a.y * t.wa.x))) * fmaf(g.y, t.wl.y, e.y * t.wl.x) * lr.y;
+    val[2] = fmaf(d.z, t.wb.y, fmaf(cc.z, t.wb.x, fmaf(b.z, t.wa.y, a.z * t.wa.x))) * fmaf(g.z, t.wl.y, e.z * t.wl.x) * lr.z;
+    val[3] = fmaf(d.w, t.wb.y, fmaf(cc.w, t.wb.x, fmaf(b.w, t.wa.y, a.w * t.wa.x))) * fmaf(g.w, t.wl.y, e.w * t.wl.x) * lr.w;
     unsigned hi[2], lo[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const f32x2_t x = {__builtin_amdgcn_fmed3f(val[2 * q], -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(val[2 * q + 1], -65504.0f, 65504.0f)};
-        const f16x2_t h2 = __builtin_convertvector(x, f16x2_t);
-        const f32x2_t r = x - __builtin_convertvector(h2, f32x2_t);
-        hi[q] = __builtin_bit_cast(unsigned, h2);
+        const float x0 = __builtin_amdgcn_fmed3f(val[2 * q], -65504.0f, 65504.0f), x1 = __builtin_amdgcn_fmed3f(val[2 * q + 1], -65504.0f, 65504.0f);
+        const f32x2_t x = {x0, x1};
+        hi[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, f16x2_t));
+        // residue x - float(hi) in one v_fma_mix_f32 per value (the fp16 operand is read in place)
+        const f32x2_t r = {tir::fma_mix_lo(hi[q], -1.0f, x0), tir::fma_mix_hi(hi[q], -1.0f, x1)};
         lo[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
     }
     *reinterpret_cast<uint2*>(xh) = make_uint2(hi[0], hi[1]);
@@ -1281,8 +1322,8 @@ k_indirect_fused_hp(TirField f, const float* __restrict__ packed, const float* _
             la = udiv(la, by_div, rem_); lb = udiv(lb, by_div, rem_);
             int lia = light_idx[la], lib = light_idx[lb];
             lia = min(max(lia, 0), f.n_lights - 1); lib = min(max(lib, 0), f.n_lights - 1);
-            lrA = n_lt ? LT + lia * (3 * CA) : f.light_line + (size_t)lia * (3 * CA);
-            lrB = n_lt ? LT + lib * (3 * CA) : f.light_line + (size_t)lib * (3 * CA);
+            lrA = LT + lia * (3 * CA);         // (the launcher stages every light row in LDS: n_lights <= 16)
+            lrB = LT + lib * (3 * CA);
         }
         // decoder role: this lane's record and its aux-table row
         const int64_t sd = r0 + sl, sdc = sd < n ? sd : n - 1;
@@ -1291,28 +1332,27 @@ k_indirect_fused_hp(TirField f, const float* __restrict__ packed, const float* _
         f32x16 facc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) facc[r] = 0.0f;
+        {
+            // nine 16-channel chunks (3 VM groups x 3), software-pipelined two deep: while chunk i is interpolated and contracted,
+            // the 12 loads of chunks i + 1 (and, once i is consumed, i + 2) are in flight -- no bubble at the group boundaries
+            const HpAxes axA = hp_axes(f, pA, gc), axB = hp_axes(f, pB, gc);
+            HpGroup GA[3], GB[3];
+            HpChunk ck[2];
+            GA[0] = hp_group(f, axA, 0); GB[0] = hp_group(f, axB, 0);
+            hp_issue(ck[0], f.aplane[0], f.aline[0], GA[0], GB[0], 0);
+            hp_issue(ck[1], f.aplane[0], f.aline[0], GA[0], GB[0], 1);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {      // unrolled: a run-time k turns the coordinate selects into a scratch table (see k_indirect_fused)
-            const HpTap tA = hp_make_tap(f, k, pA, gc), tB = hp_make_tap(f, k, pB, gc);
-            const float* pl = f.aplane[k];
-            const float* ln = f.aline[k];
-            float4 a0[3], b0[3], c0[3], d0[3], e0[3], g0[3], a1[3], b1[3], c1[3], d1[3], e1[3], g1[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                a0[q] = ld4(pl + tA.o00 + 16 * q); b0[q] = ld4(pl + tA.o01 + 16 * q); c0[q] = ld4(pl + tA.o10 + 16 * q);
-                d0[q] = ld4(pl + tA.o11 + 16 * q); e0[q] = ld4(ln + tA.l0 + 16 * q);  g0[q] = ld4(ln + tA.l1 + 16 * q);
-            }
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                a1[q] = ld4(pl + tB.o00 + 16 * q); b1[q] = ld4(pl + tB.o01 + 16 * q); c1[q] = ld4(pl + tB.o10 + 16 * q);
-                d1[q] = ld4(pl + tB.o11 + 16 * q); e1[q] = ld4(ln + tB.l0 + 16 * q);  g1[q] = ld4(ln + tB.l1 + 16 * q);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int i = 0; i < 9; ++i) {
+                const int k = i / 3, q = i % 3;
+                HpChunk& c = ck[i & 1];
                 const int ch = k * CA + 16 * q + 4 * gc;
-                hp_products(a0[q], b0[q], c0[q], d0[q], e0[q], g0[q], tA, ld4(lrA + ch), Xh + gj * HP_XS + 4 * gc, Xl + gj * HP_XS + 4 * gc);
-                hp_products(a1[q], b1[q], c1[q], d1[q], e1[q], g1[q], tB, ld4(lrB + ch), Xh + (16 + gj) * HP_XS + 4 * gc, Xl + (16 + gj) * HP_XS + 4 * gc);
+                hp_products(c.a0, c.b0, c.c0, c.d0, c.e0, c.g0, GA[k], tir::ld4(lrA + ch), Xh + gj * HP_XS + 4 * gc, Xl + gj * HP_XS + 4 * gc);
+                hp_products(c.a1, c.b1, c.c1, c.d1, c.e1, c.g1, GB[k], tir::ld4(lrB + ch), Xh + (16 + gj) * HP_XS + 4 * gc, Xl + (16 + gj) * HP_XS + 4 * gc);
+                if (i + 2 < 9) {
+                    const int k2 = (i + 2) / 3, q2 = (i + 2) % 3;
+                    if (q2 == 0) { GA[k2] = hp_group(f, axA, k2); GB[k2] = hp_group(f, axB, k2); }
+                    hp_issue(c, f.aplane[k2], f.aline[k2], GA[k2], GB[k2], q2);
+                }
                 __builtin_amdgcn_wave_barrier();
                 const f16x8 ah = Wh[((k * 3 + q) * 2 + h) * 32 + sl], al = Wl[((k * 3 + q) * 2 + h) * 32 + sl];
                 const f16x8 bh = *reinterpret_cast<const f16x8*>(Xh + sl * HP_XS + 8 * h);
@@ -1342,7 +1382,10 @@ k_indirect_fused_hp(TirField f, const float* __restrict__ packed, const float* _
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) corr[mt][r] = 0.0f;
-        hp_layer1<0>(w0hi, w0f8, fo, acc, corr);
+        float fo8[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fo8[r] = __builtin_amdgcn_fmed3f(fo[r], -448.0f, 448.0f);
+        hp_layer1<0>(w0hi, w0f8, fo, fo8, acc, corr);
         unsigned hp[32], h8[16];
 #pragma unroll
         for (int q = 0; q < 64; q += 4) {
@@ -2616,11 +2659,16 @@ extern "C" int tir_indirect_fused_hp_fwd(const TirField* f, const TirMlp* m, con
             reinterpret_cast<uintptr_t>(f->aline[i]) % 16 != 0) return TIR_ERR_ARG;
     if (!f->basis_t || !f->light_line) return TIR_ERR_ARG;
     if (f->n_acomp != 48 || f->app_dim != F || !tir_app_index_ok(f)) return TIR_ERR_UNSUPPORTED;
+    for (int i = 0; i < 3; ++i)           // 32-bit byte offsets on the 24-bit multiplier: row bytes < 2^24, plane bytes < 2^32
+        for (int j = i + 1; j < 3; ++j)
+            if ((int64_t)f->grid[i] * HP_TB >= (1 << 24) || (int64_t)f->grid[j] * HP_TB >= (1 << 24) ||
+                (int64_t)f->grid[i] * f->grid[j] * HP_TB >= ((int64_t)1 << 32)) return TIR_ERR_UNSUPPORTED;
     if (n < 0 || (n > 0 && (!xyz || !light_idx || !table || !out))) return TIR_ERR_ARG;
     if (reinterpret_cast<uintptr_t>(table) % 16 != 0) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
     if (n >= (int64_t)1 << 31 || idx_div < 0 || aux_mod < 0) return TIR_ERR_UNSUPPORTED;       // 32-bit record / ray arithmetic in the kernel
-    const int lt_rows = f->n_lights <= 16 ? f->n_lights : 0;      // light rows in LDS (576 B each; 16 rows: 159.9 KB in all)
+    if (f->n_lights < 1 || f->n_lights > 16) return TIR_ERR_UNSUPPORTED;       // every light row is staged in LDS (576 B each; 16 rows: 159.9 KB in all)
+    const int lt_rows = f->n_lights;
     constexpr int NW = 8;
     const size_t lds = (size_t)FH_BYTES + (size_t)F8_FLOATS * 4 + 2 * (size_t)FUS_WH_BYTES + (size_t)lt_rows * 144 * sizeof(float) +
                        (size_t)NW * HP_X_HALVES * 2;

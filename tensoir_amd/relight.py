@@ -106,7 +106,7 @@ def _indirect_mode(tensoIR, training=False):
 def _set_verdict(tensoIR, verdict, why, stats=None, train_limit=False):
     st = _indirect_state(tensoIR)
     key, storage = _indirect_key(tensoIR)
-    if verdict == "full" and st["verdict"] != "full":
+    if verdict != "f16" and st["verdict"] != verdict:       # (a version that left the fast kernels: to hp, or all the way to full)
         st["fallbacks"] += 1
     st.update(verdict=verdict, key=key, carried_key=None, storage=storage, age=0, why=why, train_limit=bool(train_limit))
     if stats is not None:
@@ -204,7 +204,7 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
                 if kind == "f16" and fh is not None and fusable and ops.fused_indirect() and int(f.n_lights) <= 16:
                     # gather -> basis contraction -> radiance decoder in ONE launch, the feature rows never reach HBM
                     return ops.indirect_fused(f, fh, tensoIR.renderModule.packed(), rec_xyz, light_idx, rec_ray, light_div, dirs, n_dirs, n_dev)
-                if kind == "hp" and fusable and ops.AUX_TABLE and ops.MLP_IMPL == "bf16x3":
+                if kind == "hp" and fusable and ops.AUX_TABLE and ops.MLP_IMPL == "bf16x3" and int(f.n_lights) <= 16:
                     return ops.indirect_fused_hp(f, tensoIR.renderModule.packed(), rec_xyz, light_idx, rec_ray, light_div, dirs, n_dirs, n_dev)
                 return _gather_then_decode(tensoIR, f, fh, rec_xyz, light_idx, rec_ray, light_div, dirs, dir_map, n_dirs, n_dev,
                                            full=kind != "f16")
