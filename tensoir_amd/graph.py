@@ -50,6 +50,28 @@ class _OwnState:
         self.saved = None
 
 
+def _clone_grouped(out):
+    """Fresh copies of a replay's outputs with ONE copy per underlying buffer: the map columns are views of one [B, 20] block, so
+    twelve outputs cost two or three copy launches instead of twelve (the boundary call hands out fresh tensors on every replay)."""
+    bases, res = {}, {}
+    for k, v in out.items():
+        if not torch.is_tensor(v):
+            res[k] = v
+            continue
+        st = v.untyped_storage()
+        key = st.data_ptr()
+        if key not in bases:
+            nbytes = st.nbytes()
+            if nbytes > 8 * v.numel() * v.element_size() + (1 << 16):     # a small view of a large buffer: copy the view only
+                bases[key] = None
+            else:
+                bases[key] = torch.empty(0, dtype=torch.uint8, device=v.device).set_(st, 0, (nbytes,), (1,)).clone()
+        b = bases[key]
+        res[k] = v.clone() if b is None else torch.empty(0, dtype=v.dtype, device=v.device).set_(
+            b.untyped_storage(), v.storage_offset(), v.shape, v.stride())
+    return res
+
+
 class GraphedRenderer:
     def __init__(self, tensoIR, n_rays, N_samples=-1, white_bg=True, is_relight=True, sample_method="fixed_envirmap",
                  args=None, device="cuda"):
@@ -218,12 +240,11 @@ class GraphedRenderer:
             self.graph.replay()
             if defer_check:
                 self._deferred += 1
-                return dict(self.out) if not clone_outputs else {k: (v.clone() if torch.is_tensor(v) else v)
-                                                                 for k, v in self.out.items()}
+                return dict(self.out) if not clone_outputs else _clone_grouped(self.out)
             if not self._overflowed():
                 if not clone_outputs:
                     return dict(self.out)
-                return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.out.items()}
+                return _clone_grouped(self.out)
             self._clear_sticky()
             self.graph = None                            # capacity too small for this batch: re-capture with room
         raise TensoirHipError("record capacity kept overflowing while re-capturing the HIP graph")

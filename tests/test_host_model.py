@@ -479,3 +479,20 @@ def test_density_l1_multi_tensor_node_matches_the_plain_expression():
     for x, t in zip(ga, ts):
         assert x.stride() == t.stride() and float((x - t.grad).abs().max()) <= 1e-9
     assert float(ga[0][0, 0, 0, :5].abs().max()) == 0.0
+
+
+def test_grouped_output_clone_copies_each_buffer_once():
+    """graph._clone_grouped (what the boundary's cached graph hands out): views of one block stay views of ONE fresh block, a
+    small view of a large buffer is copied alone, non-tensors pass through, nothing aliases the graph's own buffers."""
+    from tensoir_amd.graph import _clone_grouped
+    maps, big = torch.randn(100, 20), torch.randn(1000000)
+    out = {"rgb": maps[:, 0:3], "depth": maps[:, 3], "acc": maps[:, 14], "loss": big[5:6].squeeze(), "x": 3, "other": torch.randn(100, 3)}
+    c = _clone_grouped(out)
+    for k, v in out.items():
+        if torch.is_tensor(v):
+            assert torch.equal(c[k], v) and c[k].shape == v.shape and c[k].stride() == v.stride() and c[k].data_ptr() != v.data_ptr(), k
+    assert c["x"] == 3
+    assert c["rgb"].untyped_storage().data_ptr() == c["depth"].untyped_storage().data_ptr() == c["acc"].untyped_storage().data_ptr()
+    assert c["loss"].untyped_storage().nbytes() == 4
+    maps.zero_()
+    assert float(c["rgb"].abs().sum()) > 0
