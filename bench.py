@@ -333,7 +333,7 @@ def library_info():
 
 def load_pmc():
     """(bytes per launch, issue fractions, meta) from the separate rocprofv3 --pmc passes kept under profiles/ (tools/
-    r04_final.sh + tools/summarize_prof.py).  The files carry the source hash of the library they were collected with; when it
+    tools/round_evidence.sh + tools/summarize_prof.py).  The files carry the source hash of the library they were collected with; when it
     is not the library being timed now, every PMC-derived field of this run is marked `"stale": true`."""
     out = []
     for name in ("pmc_traffic.json", "pmc_issue.json"):
@@ -1765,50 +1765,17 @@ def main():
         sc = scene_from_model(ckpt, model, a.env_h, a.env_w)
         stride = max(1, B // a.cpu_rays)
         r_cpu, l_cpu = rays.cpu()[::stride][: a.cpu_rays], lidx.cpu()[::stride][: a.cpu_rays]
-        # BASELINE.md 2.1 wants the reference's own CPU path timed.  /root/reference does not exist on the GPU box, so the
-        # default run times the oracle (kind "port"); when a checkout is staged and named by TENSOIR_REFERENCE
-        # (tools/stage_reference.sh -> git-ignored gpurun_scratch/reference) the imported reference itself is timed on the
-        # full batch (kind "reference") and the oracle runs once, as the parity checker only.
-        ref_root = os.environ.get("TENSOIR_REFERENCE", "")
-        use_ref = bool(ref_root) and os.path.isfile(os.path.join(ref_root, "renderer.py"))
+        # BASELINE.md 2.1 wants the reference's own CPU path timed.  The reference (Python) cannot travel to the GPU box in any
+        # form, so what is timed here is the oracle (kind "port"); `vs_reference` relates it to the imported reference itself,
+        # measured in the build container where both exist (oracle/calibrate_port.py -> profiles/port_over_reference.json).
         times, ref = [], None
         with torch.no_grad():
-            for i in range(1 if use_ref else 1 + a.cpu_calls):
+            for i in range(1 + a.cpu_calls):
                 t1 = time.perf_counter()
                 ref = O.renderer_train(sc, r_cpu, l_cpu, n_samples=a.samples, second_n_sample=a.second_samples)
                 if i >= 1:
                     times.append(time.perf_counter() - t1)
-        if use_ref:
-            from oracle import ref_loader
-            from oracle.ref_on_gpu import reference_model
-            rf = ref_loader.load()
-            ck = dict(ckpt)
-            vol = model.alphaMask.alpha_volume[0, 0].bool().cpu()
-            ck["alphaMask.shape"], ck["alphaMask.mask"] = tuple(vol.shape), np.packbits(vol.numpy().reshape(-1))
-            ck["alphaMask.aabb"] = model.alphaMask.aabb.cpu()
-            rmodel = reference_model(rf, ck, "cpu", a.env_h, a.env_w)
-            r_all, l_all = batches[0].cpu(), lidx.cpu()
-            rtimes, rout = [], None
-            with torch.no_grad():
-                for i in range(2 + a.cpu_calls):
-                    t1 = time.perf_counter()
-                    rout = rf.renderer.Renderer_TensoIR_train(r_all, None, l_all, rmodel, N_samples=a.samples, white_bg=True,
-                                                              is_train=False, is_relight=True, sample_method="fixed_envirmap",
-                                                              chunk_size=160000, device="cpu", args=args)
-                    if i >= 2:
-                        rtimes.append(time.perf_counter() - t1)
-            med = sorted(rtimes)[len(rtimes) // 2]
-            cpu = {"value": round(B / med, 2), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "reference",
-                   "reference_checkout": True,
-                   "note": "the imported reference (renderer.py:57-127 on models/tensoRF_rotated_lights.py) from the staged checkout "
-                           "named by TENSOIR_REFERENCE, PyTorch CPU kernels, fp32",
-                   "sample": f"the full batch ({B} rays x {a.samples} samples, {D} dirs x {a.second_samples}), 2 warm-ups + "
-                             f"{len(rtimes)} timed calls, median (min {min(rtimes):.2f} s, max {max(rtimes):.2f} s); "
-                             f"host nproc={os.cpu_count()}"}
-            from tests.helpers import parity_metrics as _pm
-            cpu["hip_vs_reference_max_rel_floor1"] = float(f"{max(_pm(ret[k].detach().cpu(), rout[k])['max_rel_floor1'] for k in ('rgb_map', 'depth_map', 'normal_map', 'albedo_map', 'roughness_map', 'acc_map', 'rgb_with_brdf_map')):.3e}")
-            del rmodel
-        else:
+        if True:      # (one CPU baseline kind: the port)
             med = sorted(times)[len(times) // 2]
             cpu = {"value": round(r_cpu.shape[0] / med, 2), "unit": "rays/s", "cores": torch.get_num_threads(),
                    "kind": "port", "reference_checkout": False,

@@ -1,8 +1,9 @@
 """The UNMODIFIED reference, run on the GPU box from a staged checkout.
 
-TEST INFRASTRUCTURE ONLY.  The checkout is staged by tools/stage_reference.sh into the git-ignored
-``gpurun_scratch/reference`` (it travels to the GPU box with the snapshot, never into history) and named by
-``TENSOIR_REFERENCE``; nothing here runs without it.  One invocation does, on the same seeded inputs as bench.py:
+TEST INFRASTRUCTURE ONLY, and since round 6 historical for its GPU legs: the reference may not travel to the GPU box in any form, so
+no checkout is staged any more (rounds 2-5 did, `profiles/r0[2-5]_*ref*`); the helpers below (reference_model, metrics, with_mask)
+are still what oracle/calibrate_port.py uses in the build container, where the checkout exists.  With a checkout named by
+``TENSOIR_REFERENCE`` and a GPU on the same machine one invocation does, on the same seeded inputs as bench.py:
 
   (b) BASELINE.md 2.1: the imported reference ``Renderer_TensoIR_train`` (renderer.py:57-127) timed on the host cores
       at C2+C3 full size (4096 rays x 512 samples, 128 dirs x 96) -- 2 warm-ups, median of >= 5 calls;

@@ -867,13 +867,8 @@ k_vm_app_h16(TirField f, TirFieldHalf fh, const float* __restrict__ xyz, const i
         for (int q = 0; q < 8; ++q) h[q] = sat_half(f.basis_t[(size_t)(k * CA + 16 * t + 8 * kg + q) * 32 + row]);
         Wh[e] = h;
     }
-#ifndef TIR_H16_FP32MIX      // the light rows as saturating fp16, same element order, in the space of the fp32 table (h16_chunk_pk)
     _Float16* LT16 = reinterpret_cast<_Float16*>(LT);
     for (int i = threadIdx.x; i < n_lt * 3 * CA; i += 256) LT16[i] = sat_half(f.light_line[i]);
-#else
-    for (int i = threadIdx.x * 4; i < n_lt * 3 * CA; i += 256 * 4)
-        *reinterpret_cast<float4*>(LT + i) = *reinterpret_cast<const float4*>(f.light_line + i);
-#endif
     for (int i = threadIdx.x * 4; i < 3 * CA; i += 256 * 4)
         *reinterpret_cast<float4*>(LT + n_lt * 3 * CA + i) = *reinterpret_cast<const float4*>(f.light_mean + i);
     __syncthreads();
@@ -918,23 +913,15 @@ k_vm_app_h16(TirField f, TirFieldHalf fh, const float* __restrict__ xyz, const i
                 te[q] = *reinterpret_cast<const uint4*>(l0 + 16 * q);  tg[q] = *reinterpret_cast<const uint4*>(l1 + 16 * q);
             }
             __builtin_amdgcn_sched_barrier(0);
-#ifndef TIR_H16_FP32MIX
             const tir_h2 hw00 = {(_Float16)w00, (_Float16)w00}, hw01 = {(_Float16)w01, (_Float16)w01}, hw10 = {(_Float16)w10, (_Float16)w10},
                          hw11 = {(_Float16)w11, (_Float16)w11}, hl0 = {(_Float16)tl.w0, (_Float16)tl.w0}, hl1 = {(_Float16)tl.w1, (_Float16)tl.w1};
             const _Float16* lrow16 = LT16 + li * (3 * CA);
-#endif
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int ch0 = 16 * q + 8 * c;            // this lane's 8 channels of chunk pair q
-#ifndef TIR_H16_FP32MIX
                 *reinterpret_cast<uint4*>(X + j * TIR_XH + ch0) =
                     h16_chunk_pk(ta[q], tb[q], tc[q], td[q], te[q], tg[q], hw00, hw01, hw10, hw11, hl0, hl1,
                                  n_lt ? *reinterpret_cast<const uint4*>(lrow16 + k * CA + ch0) : pack8_half(lrow + k * CA + ch0));
-#else
-                *reinterpret_cast<uint4*>(X + j * TIR_XH + ch0) =
-                    h16_chunk(ta[q], tb[q], tc[q], td[q], te[q], tg[q], w00, w01, w10, w11, tl.w0, tl.w1,
-                              ld4(lrow + k * CA + ch0), ld4(lrow + k * CA + ch0 + 4));
-#endif
             }
             __builtin_amdgcn_wave_barrier();      // LDS ops of one wave complete in order; keep the compiler from reordering
 #pragma unroll

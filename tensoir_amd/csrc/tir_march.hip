@@ -753,12 +753,6 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins_a, const int
     const int hl = threadIdx.x & 31, hw = threadIdx.x >> 5;     // lane in the half-wave, half-wave in the block (0..15)
     const unsigned half_shift = (threadIdx.x & 32) ? 32 : 0;
     unsigned n_gather = 0;
-#ifdef EXP_COUNT_ITERS
-    unsigned n_iters = 0;
-#endif
-#ifdef EXP_COUNT_STEPS      // limit study: 64-sample steps this wave executes / those in which no sample is valid (low word)
-    unsigned n_steps = 0, n_empty = 0;
-#endif
 
     // this wave's 8 rays of a batch (4 groups x 2 half-waves): set-up slots of 12 floats [o | d | t_in t_out | pair id, flags]
     float* const sw = &s_setup[threadIdx.x >> 6][0][0];
@@ -850,14 +844,6 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins_a, const int
                         const unsigned long long m = __ballot(w > f.weight_thres);
                         cnt += __popc((unsigned)(m >> half_shift));
                         if (stats) n_gather += __popc((unsigned)(__ballot(valid) >> half_shift));
-#ifdef EXP_COUNT_ITERS      // limit study: 16-sample gather iterations of this wave in bits 32.. of the counter (slot fill = samples / 16 / this)
-                        { const unsigned long long vb = __ballot(valid);        // all 64 lanes vote (not inside the branch)
-                          if (stats && half_shift == 0) n_iters += (__popcll(vb) + 15) / 16; }
-#endif
-#ifdef EXP_COUNT_STEPS
-                        { const unsigned long long vb = __ballot(valid);
-                          if (stats && (threadIdx.x & 63) == 0) { n_steps += 1; n_empty += (vb == 0ull); } }
-#endif
                         T = T * __shfl(incl, 31, 32);
                         if (!done && T < t_stop) done = true;
                         all_done = __all(done);
@@ -953,13 +939,7 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins_a, const int
         // the next batch's s_cnt / s_pid writes come after this batch's readers: s_base / s_bb are only rewritten behind
         // the next batch's first __syncthreads, s_pid[rl] / s_cnt[rl] belong to the half-wave that reads them here
     }
-#if defined(EXP_COUNT_STEPS)
-    if (stats && (threadIdx.x & 63) == 0 && n_steps) atomicAdd(s_park.stats, (unsigned long long)n_empty + ((unsigned long long)n_steps << 32));
-#elif defined(EXP_COUNT_ITERS)
-    if (stats && hl == 0 && (n_gather | n_iters)) atomicAdd(s_park.stats, (unsigned long long)n_gather + ((unsigned long long)n_iters << 32));
-#else
     if (stats && hl == 0 && n_gather) atomicAdd(s_park.stats, (unsigned long long)n_gather);
-#endif
 }
 
 

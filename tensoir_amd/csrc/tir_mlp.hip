@@ -435,16 +435,12 @@ __device__ __forceinline__ void fast_sincos(float x, float& s, float& c) {
 // products + two selects (each half used to compute both functions and keep one).  t is the exact fraction of
 // v / 2pi (see fast_sincos), |t| <= 1/2, so 2t + q is exact up to one rounding at magnitude <= 1.25 (6e-8 rev).
 __device__ __forceinline__ void pe_pair(float v, float q, float& p1, float& p2) {
-#ifdef EXP_NO_PE      // limit study: no range reduction, no transcendentals (wrong results)
-    p1 = v + q; p2 = fmaf(v, 2.0f, q);
-#else
     const float c_hi = 0.15915493667125702f, c_lo = 6.4206382432985265e-09f;      // c_hi + c_lo = 1 / (2 pi)
     const float k = rintf(v * c_hi);
     float t = fmaf(v, c_hi, -k);
     t = fmaf(v, c_lo, t);
     p1 = __builtin_amdgcn_sinf(t + q);
     p2 = __builtin_amdgcn_sinf(fmaf(t, 2.0f, q));
-#endif
 }
 
 struct AuxPE { float s[3], c[3], s2[3], c2[3]; };   // sin/cos of aux and of 2*aux
@@ -516,13 +512,6 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
     return v;
 }
 
-// limit-study switch (tools/build_variant.sh ... -DEXP_NO_LDS): every k-block reads the operand tile of block 0, which the
-// compiler then keeps in registers -- wrong results, same MFMA / VALU stream, no LDS operand traffic
-#ifdef EXP_NO_LDS
-#define KBX(kb) 0
-#else
-#define KBX(kb) (kb)
-#endif
 
 // ---- per k-block: [issue the A-tile LDS reads] [build that block's 8 inputs on the VALU] [12 MFMAs].
 // The MFMAs of block kb execute on the matrix pipe while the wave's VALU already builds block kb+1 (intra-wave overlap
@@ -564,8 +553,8 @@ __device__ __forceinline__ void layer1_interleaved(unsigned whi, unsigned wlo, i
     bf16x8 ah[4], al[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        ah[mt] = lds_tile(whi, KBX(KB) * 4096 + mt * 512);
-        if (NPROD == 3) al[mt] = lds_tile(wlo, KBX(KB) * 4096 + mt * 512);
+        ah[mt] = lds_tile(whi, KB * 4096 + mt * 512);
+        if (NPROD == 3) al[mt] = lds_tile(wlo, KB * 4096 + mt * 512);
     }
     float v[8];
     build_pair<KB, 0, AUXT>(ft, ax, ap, h, hq, v);
@@ -591,8 +580,8 @@ __device__ __forceinline__ void layer2_interleaved(unsigned whi, unsigned wlo,
     bf16x8 ah[4], al[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        ah[mt] = lds_tile(whi, KBX(KB) * 4096 + mt * 512);
-        if (NPROD == 3) al[mt] = lds_tile(wlo, KBX(KB) * 4096 + mt * 512);
+        ah[mt] = lds_tile(whi, KB * 4096 + mt * 512);
+        if (NPROD == 3) al[mt] = lds_tile(wlo, KB * 4096 + mt * 512);
     }
     float v[8];
 #pragma unroll
@@ -749,10 +738,6 @@ mlp_bf16_body(const float* __restrict__ packed, const float* __restrict__ feat, 
         f32x4 o4[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) o4[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifdef EXP_NO_L3      // limit study: layer 3 replaced by four adds (wrong results)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) o4[c] = f32x4{acc2[c][0], acc2[c][1], acc2[c][2], acc2[c][3]};
-#else
         {
             const float* wp = lds + BH_W2 + (h * 4 + (lane & 3)) * W2A_STRIDE;
 #pragma unroll
@@ -769,7 +754,6 @@ mlp_bf16_body(const float* __restrict__ packed, const float* __restrict__ feat, 
                 }
             }
         }
-#endif
         float o0 = (o4[0][0] + o4[1][0]) + (o4[2][0] + o4[3][0]);
         float o1 = (o4[0][1] + o4[1][1]) + (o4[2][1] + o4[3][1]);
         float o2 = (o4[0][2] + o4[1][2]) + (o4[2][2] + o4[3][2]);
@@ -858,7 +842,7 @@ template <int KB>
 __device__ __forceinline__ void fus_layer1(unsigned whi, const float (&fo)[16], f32x16 (&acc)[4]) {
     bf16x8 ah[4], al[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) ah[mt] = lds_tile(whi, KBX(KB) * 4096 + mt * 512);
+    for (int mt = 0; mt < 4; ++mt) ah[mt] = lds_tile(whi, KB * 4096 + mt * 512);
     // compile-time slots (a run-time index into pe[][] would send the array to scratch memory)
     const float v[8] = {fus_input<KB * 8 + 0>(fo), fus_input<KB * 8 + 1>(fo), fus_input<KB * 8 + 2>(fo), fus_input<KB * 8 + 3>(fo),
                         fus_input<KB * 8 + 4>(fo), fus_input<KB * 8 + 5>(fo), fus_input<KB * 8 + 6>(fo), fus_input<KB * 8 + 7>(fo)};
@@ -878,12 +862,45 @@ template <int KB>
 __device__ __forceinline__ void fus_layer2p(unsigned whi, const unsigned (&hp)[32], f32x16 (&acc)[4]) {
     bf16x8 ah[4], al[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) ah[mt] = lds_tile(whi, KBX(KB) * 4096 + mt * 512);
+    for (int mt = 0; mt < 4; ++mt) ah[mt] = lds_tile(whi, KB * 4096 + mt * 512);
     const u32x4_t H = {hp[4 * KB], hp[4 * KB + 1], hp[4 * KB + 2], hp[4 * KB + 3]};
     const bf16x8 xh = __builtin_bit_cast(bf16x8, H), xl = {};
     mfma12<1, true>(ah, al, xh, xl, acc);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (KB + 1 < KB1) fus_layer2p<KB + 1>(whi, hp, acc);
+}
+
+// one VM group of the fp16-shadow gather for one record: byte offsets of the six taps (this lane's 16-byte half-chunk) and the
+// interpolation weights as fp16 pairs.  k is a constant after unrolling.
+struct FusGroup { unsigned o00, o01, o10, o11, l0, l1; tir::tir_h2 w00, w01, w10, w11, wl0, wl1; };
+
+__device__ __forceinline__ FusGroup fus_group(const TirField& f, const tir::TapQ (&ax)[3], const unsigned (&xb)[3][2], const int k) {
+    constexpr int CA = 48;
+    const int m0 = (k == 2) ? 1 : 0, m1 = (k == 0) ? 1 : 2, vi = 2 - k;
+    const tir::TapQ &tx = ax[m0], &ty = ax[m1], &tl = ax[vi];
+    FusGroup g;
+    const float w00 = tx.w.x * ty.w.x, w01 = tx.w.y * ty.w.x, w10 = tx.w.x * ty.w.y, w11 = tx.w.y * ty.w.y;
+    g.w00 = tir::tir_h2{(_Float16)w00, (_Float16)w00}; g.w01 = tir::tir_h2{(_Float16)w01, (_Float16)w01};
+    g.w10 = tir::tir_h2{(_Float16)w10, (_Float16)w10}; g.w11 = tir::tir_h2{(_Float16)w11, (_Float16)w11};
+    g.wl0 = tir::tir_h2{(_Float16)tl.w.x, (_Float16)tl.w.x}; g.wl1 = tir::tir_h2{(_Float16)tl.w.y, (_Float16)tl.w.y};
+    // row starts in bytes on the full-rate 24-bit multiplier (fp16 row pitch W * 96 B < 2^24, plane < 2^32 B: checked by the launcher)
+    const unsigned row_bytes = (unsigned)f.grid[m0] * (2 * CA);
+    const unsigned r0 = tir::mul_u24(ty.i0, row_bytes), r1 = tir::mul_u24(ty.i1, row_bytes);
+    g.o00 = r0 + xb[m0][0]; g.o01 = r0 + xb[m0][1]; g.o10 = r1 + xb[m0][0]; g.o11 = r1 + xb[m0][1];
+    g.l0 = xb[vi][0]; g.l1 = xb[vi][1];
+    return g;
+}
+
+struct FusChunk { uint4 a, b, c, d, e, g; };           // the six taps of one 16-channel chunk (this lane's 8 channels)
+
+__device__ __forceinline__ uint4 ld_u4b(const void* base, unsigned byte_off) {
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+__device__ __forceinline__ void fus_issue(FusChunk& c, const void* __restrict__ pl, const void* __restrict__ ln, const FusGroup& g, const int q) {
+    const unsigned o = 32u * (unsigned)q;              // 16 channels x 2 B (a constant after unrolling: the immediate offset)
+    c.a = ld_u4b(pl, g.o00 + o); c.b = ld_u4b(pl, g.o01 + o); c.c = ld_u4b(pl, g.o10 + o); c.d = ld_u4b(pl, g.o11 + o);
+    c.e = ld_u4b(ln, g.l0 + o);  c.g = ld_u4b(ln, g.l1 + o);
 }
 
 // NW waves per workgroup (tile = 32 NW records).  PACK: the three-waves-per-SIMD form -- the aux-table row is loaded at the START of
@@ -896,7 +913,7 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
                  const float* __restrict__ table, float* __restrict__ out, int64_t n, const int32_t* __restrict__ n_dev,
                  int out_dim, int act, int lt_rows) {
     using namespace tir;
-    constexpr int CA = 48, NQ = 3;
+    constexpr int CA = 48;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     for (int i = threadIdx.x * 4; i < FH_FLOATS; i += NW * 64 * 4)
         *reinterpret_cast<float4*>(lds + i) = *reinterpret_cast<const float4*>(packed + OFF_FF + i);
@@ -913,20 +930,12 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
         for (int q = 0; q < 8; ++q) hv[q] = feat >= 0 ? sat_half(f.basis_t[(size_t)(k * CA + 16 * t + 8 * kg + q) * 32 + feat]) : (_Float16)0.0f;
         Wh[e] = hv;
     }
-#ifndef TIR_H16_FP32MIX      // the light rows as fp16 pairs (saturating), same element order: LT16[row][144] in the space of the fp32 table
     _Float16* LT16 = reinterpret_cast<_Float16*>(LT);
     for (int i = threadIdx.x; i < n_lt * 3 * CA; i += NW * 64) LT16[i] = sat_half(f.light_line[i]);
-#else
-    for (int i = threadIdx.x * 4; i < n_lt * 3 * CA; i += NW * 64 * 4)
-        *reinterpret_cast<float4*>(LT + i) = *reinterpret_cast<const float4*>(f.light_line + i);
-#endif
     for (int i = threadIdx.x * 4; i < 3 * CA; i += NW * 64 * 4)
         *reinterpret_cast<float4*>(LT + n_lt * 3 * CA + i) = *reinterpret_cast<const float4*>(f.light_mean + i);
     __syncthreads();
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));
-#ifdef EXP_FUSED_STAGGER      // limit study: start the second wave of every SIMD half a tile late (gather of one over the decoder of the other)
-    if (wave >= NW / 2) for (int i = 0; i < EXP_FUSED_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
     const int sl = lane & 31, h = lane >> 5;               // decoder / MFMA role: record column, lane half (= k group)
     const int gj = lane >> 1, gc = lane & 1;               // gather role: record slot, which of every two 16-byte chunks
     const unsigned lds0 = (unsigned)(size_t)lds;
@@ -942,18 +951,14 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
         const int64_t sg = r0 + gj, sgc = sg < n ? sg : n - 1;
         const float p[3] = {xyz[3 * sgc], xyz[3 * sgc + 1], xyz[3 * sgc + 2]};
         const float* lrow;
-#ifndef TIR_H16_FP32MIX
         const _Float16* lrow16;
-#endif
         {
             unsigned lsel = rec_map ? (unsigned)rec_map[sgc] : (unsigned)sgc, rem_;      // record -> ray: / idx_div (n < 2^31, launcher)
             lsel = udiv(lsel, by_div, rem_);
             int li = light_idx[lsel];
             li = min(max(li, 0), f.n_lights - 1);
             lrow = n_lt ? LT + li * (3 * CA) : f.light_line + (size_t)li * (3 * CA);
-#ifndef TIR_H16_FP32MIX
             lrow16 = LT16 + li * (3 * CA);
-#endif
         }
         // decoder role: this lane's record and its aux-table row
         const int64_t sd = r0 + sl, sdc = sd < n ? sd : n - 1;
@@ -973,59 +978,44 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
                     acc[mt][4 * i] = t4.x; acc[mt][4 * i + 1] = t4.y; acc[mt][4 * i + 2] = t4.z; acc[mt][4 * i + 3] = t4.w;
                 }
         };
+        {
+            // Nine 16-channel chunks (3 VM groups x 3), software-pipelined THREE deep (round 6): the six 16-byte taps of chunks
+            // i + 1 .. i + 3 are in flight while chunk i is interpolated on the packed fp16 pipe and contracted -- as many loads
+            // in flight as the group-at-a-time schedule of round 5 (18), but no load -> wait -> compute -> MFMA sequence per
+            // group any more (waiting was 0.42 of the wave cycles).  The taps of the three axes are computed once per record.
+            TapQ ax[3];
+            unsigned xb[3][2];                                  // byte offset of this lane's 16-byte half-chunk inside fp16 row `index`
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {      // unrolled: with a run-time k the coordinate selects below become a scratch table (72 B stored per lane and tile = 0.4 GB of HBM writes per launch, measured)
-            const int H = f.grid[(k == 0) ? 1 : 2], W = f.grid[(k == 2) ? 1 : 0], R = f.grid[2 - k];
-            const float u = (k == 2) ? p[1] : p[0], v = (k == 0) ? p[1] : p[2], w = (k == 0) ? p[2] : ((k == 1) ? p[1] : p[0]);
-            Tap1 tx = make_tap(u, W), ty = make_tap(v, H), tl = make_tap(w, R);
-            const float w00 = tx.w0 * ty.w0, w01 = tx.w1 * ty.w0, w10 = tx.w0 * ty.w1, w11 = tx.w1 * ty.w1;
-            const _Float16* pl = reinterpret_cast<const _Float16*>(fh.aplane[k]);
-            const _Float16* ln = reinterpret_cast<const _Float16*>(fh.aline[k]);
-            // element offsets on the full-rate 24-bit multiplier (v_mul_lo_u32 issues at a quarter of the rate: 18 of them per tile
-            // were 5 % of the kernel's VALU slots): indices < 2^24, row pitch W * CA < 2^24 and products < 2^31 (tir_app_index_ok)
-            const unsigned pitch = (unsigned)(W * CA);                                    // wave-uniform
-            const unsigned q0 = mul_u24((unsigned)ty.i0, pitch), q1 = mul_u24((unsigned)ty.i1, pitch);
-            const unsigned x0 = mul_u24((unsigned)tx.i0, CA) + 8 * gc, x1 = mul_u24((unsigned)tx.i1, CA) + 8 * gc;
-            const _Float16* p00 = pl + (q0 + x0);
-            const _Float16* p01 = pl + (q0 + x1);
-            const _Float16* p10 = pl + (q1 + x0);
-            const _Float16* p11 = pl + (q1 + x1);
-            const _Float16* l0 = ln + (mul_u24((unsigned)tl.i0, CA) + 8 * gc);
-            const _Float16* l1 = ln + (mul_u24((unsigned)tl.i1, CA) + 8 * gc);
-            uint4 ta[NQ], tb[NQ], tc[NQ], td[NQ], te[NQ], tg[NQ];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                ta[q] = *reinterpret_cast<const uint4*>(p00 + 16 * q); tb[q] = *reinterpret_cast<const uint4*>(p01 + 16 * q);
-                tc[q] = *reinterpret_cast<const uint4*>(p10 + 16 * q); td[q] = *reinterpret_cast<const uint4*>(p11 + 16 * q);
-                te[q] = *reinterpret_cast<const uint4*>(l0 + 16 * q);  tg[q] = *reinterpret_cast<const uint4*>(l1 + 16 * q);
+            for (int a = 0; a < 3; ++a) {
+                ax[a] = make_tap_q(p[a], f.grid[a]);
+                xb[a][0] = mul_u24(ax[a].i0, 2 * CA) + 16u * (unsigned)gc;
+                xb[a][1] = mul_u24(ax[a].i1, 2 * CA) + 16u * (unsigned)gc;
             }
-            if (!PACK && k == 2) load_table();      // two waves per SIMD: in flight behind the last gather group
-            __builtin_amdgcn_sched_barrier(0);
-#ifndef TIR_H16_FP32MIX
-            const tir_h2 hw00 = {(_Float16)w00, (_Float16)w00}, hw01 = {(_Float16)w01, (_Float16)w01}, hw10 = {(_Float16)w10, (_Float16)w10},
-                         hw11 = {(_Float16)w11, (_Float16)w11}, hl0 = {(_Float16)tl.w0, (_Float16)tl.w0}, hl1 = {(_Float16)tl.w1, (_Float16)tl.w1};
-#endif
+            FusGroup G[3];
+            FusChunk ck[3];
+            G[0] = fus_group(f, ax, xb, 0);
+            fus_issue(ck[0], fh.aplane[0], fh.aline[0], G[0], 0);
+            fus_issue(ck[1], fh.aplane[0], fh.aline[0], G[0], 1);
+            fus_issue(ck[2], fh.aplane[0], fh.aline[0], G[0], 2);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
+            for (int i = 0; i < 9; ++i) {       // (unrolled: k, q and the ring slot are constants)
+                const int k = i / 3, q = i % 3;
+                FusChunk& c = ck[i % 3];
                 const int ch0 = 16 * q + 8 * gc;
-#ifndef TIR_H16_FP32MIX
                 *reinterpret_cast<uint4*>(X + gj * FUS_XH + ch0) =
-                    h16_chunk_pk(ta[q], tb[q], tc[q], td[q], te[q], tg[q], hw00, hw01, hw10, hw11, hl0, hl1,
+                    h16_chunk_pk(c.a, c.b, c.c, c.d, c.e, c.g, G[k].w00, G[k].w01, G[k].w10, G[k].w11, G[k].wl0, G[k].wl1,
                                  n_lt ? *reinterpret_cast<const uint4*>(lrow16 + k * CA + ch0) : pack8_half(lrow + k * CA + ch0));
-#else
-                *reinterpret_cast<uint4*>(X + gj * FUS_XH + ch0) =
-                    h16_chunk(ta[q], tb[q], tc[q], td[q], te[q], tg[q], w00, w01, w10, w11, tl.w0, tl.w1,
-                              *reinterpret_cast<const float4*>(lrow + k * CA + ch0), *reinterpret_cast<const float4*>(lrow + k * CA + ch0 + 4));
-#endif
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const f16x8 a = Wh[((k * 3 + t) * 2 + h) * 32 + sl];
-                const f16x8 b = *reinterpret_cast<const f16x8*>(X + sl * FUS_XH + 16 * t + 8 * h);
+                if (i + 3 < 9) {
+                    const int k2 = (i + 3) / 3, q2 = (i + 3) % 3;
+                    if (q2 == 0) G[k2] = fus_group(f, ax, xb, k2);
+                    fus_issue(c, fh.aplane[k2], fh.aline[k2], G[k2], q2);
+                }
+                __builtin_amdgcn_wave_barrier();
+                const f16x8 a = Wh[((k * 3 + q) * 2 + h) * 32 + sl];
+                const f16x8 b = *reinterpret_cast<const f16x8*>(X + sl * FUS_XH + 16 * q + 8 * h);
                 facc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, facc, 0, 0, 0);
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
         }
         // ---------------- decoder phase: facc[4 i + r] = this half's feature slot 4 i + r  (half 0: features 0..13, half 1: 14..26)
         float fo[16];
@@ -2630,13 +2620,7 @@ extern "C" int tir_indirect_fused_fwd(const TirField* f, const TirFieldHalf* fh,
     if (n == 0) return TIR_OK;
     if (n >= (int64_t)1 << 31 || idx_div < 0 || aux_mod < 0) return TIR_ERR_UNSUPPORTED;       // 32-bit record / ray arithmetic in the kernel
     const int lt_rows = f->n_lights <= 16 ? f->n_lights : 0;
-#if defined(EXP_FUSED_W8)   // limit study: two waves per SIMD, aux-table row prefetched during the gather, fp32 layer-1 accumulators kept through layer 2
-    constexpr int NW = 8; constexpr bool PACK = false;
-#elif defined(EXP_FUSED_NW)
-    constexpr int NW = EXP_FUSED_NW; constexpr bool PACK = EXP_FUSED_PACK;
-#else
     constexpr int NW = 12; constexpr bool PACK = true;
-#endif
     const size_t lds = (size_t)FH_BYTES + FUS_WH_BYTES + (size_t)(lt_rows + 1) * 144 * sizeof(float) + (size_t)NW * 32 * FUS_XH * 2;
     if (int r2 = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_indirect_fused<NW, PACK>), (int)lds)) return r2;
     const int64_t tiles = (n + NW * 32 - 1) / (NW * 32);

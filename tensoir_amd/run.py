@@ -44,7 +44,7 @@ def install(reference_root: str):
     done = {}
     _host_threads()
     if os.environ.get("TENSOIR_LAUNCH_MODE", "hip") == "reference":
-        # A/B aid (tools/script_head_to_head.sh): the same launcher, stand-ins and analytic dataset, but NOTHING rebound --
+        # A/B aid (TENSOIR_LAUNCH_MODE=reference): the same launcher, stand-ins and analytic dataset, but NOTHING rebound --
         # the script runs the reference's own PyTorch implementation (on the GPU through PyTorch-ROCm, or on the host)
         synth_dataset.wrap_dataset_dict(importlib.import_module("dataLoader").dataset_dict, device=None)
         _allow_numpy_in_checkpoints()

@@ -27,6 +27,7 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         if n:
             terminalreporter.write_line(
                 f"SKIPPED: {n} tests/test_launcher.py tests -- no TensoIR checkout on this box (TENSOIR_REFERENCE={ref} has no "
-                "train_tensoIR.py).  To run the unmodified reference scripts on this library: tools/stage_reference.sh in a container "
-                "that has the checkout, then TENSOIR_REFERENCE=$PWD/gpurun_scratch/reference python -m pytest tests/test_launcher.py -m gpu "
-                "(builder-run evidence: profiles/r05_launcher_tests.log)")
+                "train_tensoIR.py; the reference is Python and does not travel to the GPU box).  Where a checkout and a GPU exist "
+                "together: TENSOIR_REFERENCE=<checkout> python -m pytest tests/test_launcher.py -m gpu.  The CPU leg of those tests "
+                "(launcher rebinding, argument plumbing up to the first kernel call) runs in the build container; the same call "
+                "sequence without the scripts: tests/test_gpu_train_loop.py (evidence of earlier rounds: profiles/r05_launcher_tests.log)")

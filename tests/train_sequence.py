@@ -1,6 +1,6 @@
 """The call sequence of ``reconstruction()`` (train_tensoIR.py:110-461) driven through the PRODUCT API only, as a reusable
 function: tests/test_gpu_train_loop.py (the script-level drop-in evidence), tests/test_gpu_precision_policy.py and
-tools/r05_precision.py (a TRAINED checkpoint for the indirect-light precision policy) all run it.
+tools/precision_sweep.py (a TRAINED checkpoint for the indirect-light precision policy) all run it.
 
   analytic dataset -> TensorVMSplit(aabb, reso, device, **script kwargs) (:170-192) -> get_optparam_groups + Adam (:196,
   :206) -> filtering_rays(bbox_only=True) on the host ray tensor (:228) -> iterations (:237-317): host batch indexing,

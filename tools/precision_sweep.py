@@ -1,7 +1,7 @@
 """Evidence for the indirect-light precision policy: the TRAINED checkpoint and the adversarial scaling
 sweep of tests/precision_cases.py with every number recorded (nothing asserted -- the tests do that):
   gpurun_out/r05_precision_trained.json, gpurun_out/r05_precision_sweep.json   (copied to profiles/ by hand)
-Usage (GPU box): python tools/r05_precision.py [--grid 128] [--iters 450] [--skip-sweep] [--tag long]
+Usage (GPU box): python tools/precision_sweep.py [--grid 128] [--iters 450] [--skip-sweep] [--tag long]
 (--tag X writes r05_precision_trained_X.json: e.g. the same schedule trained three times as long, sweep skipped)"""
 import argparse
 import json

@@ -1,6 +1,6 @@
 """Train the analytic scene through the product API (tests/precision_cases.trained) and dump what a CPU-side analysis needs:
 the checkpoint (reference layout), the probe rays / jitter noise and the HIP maps of the default policy ->
-gpurun_out/r05_trained_dump.pt.  Usage (GPU box): python tools/r05_trained_dump.py [iters]"""
+gpurun_out/r05_trained_dump.pt.  Usage (GPU box): python tools/trained_dump.py [iters]"""
 import os
 import sys
 
