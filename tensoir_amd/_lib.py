@@ -75,6 +75,7 @@ SIGNATURES = {
     "tir_density_grad_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, I64, P, P]),
     "tir_vm_app_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I32, I64, P, P]),
     "tir_vm_app_fwd_bf16x3": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I32, I64, P, P]),
+    "tir_vm_app_fwd_x3": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I32, I64, P, P]),
     "tir_pack_half": (C.c_int, [P, P, P, I32, P]),
     "tir_pack_half_checked": (C.c_int, [P, P, P, I32, P, P]),
     "tir_vm_app_fwd_h16": (C.c_int, [C.POINTER(TirField), C.POINTER(TirFieldHalf), P, P, P, P, I32, I32, I64, P, P]),
@@ -100,6 +101,7 @@ SIGNATURES = {
     "tir_composite_primary_fused": (C.c_int, [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, F32, P, P, P, P, I64, P]),
     "tir_vm_app_jitter_fwd": (C.c_int, [C.POINTER(TirField), P, I64, P, F32, C.c_uint64, C.c_uint64, P, P, P, I32, P]),
     "tir_vm_app_primary_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I64, P, F32, C.c_uint64, C.c_uint64, P, P, P, P]),
+    "tir_vm_app_primary_x3_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I32, I64, P, F32, C.c_uint64, C.c_uint64, P, P, P, P]),
     "tir_compact_primary": (C.c_int, [C.POINTER(TirField), P, P, P, P, I32, I32, P, P, P, P, P]),
     "tir_composite_primary": (C.c_int, [P, P, P, P, P, P, P, P, P, P, I32, I32, I32, F32, P, P]),
     "tir_march_secondary_fwd": (C.c_int, [C.POINTER(TirField), P, P, P, P, P, I64, I32, I32, P, F32, P, P,

@@ -450,7 +450,36 @@ struct TirJitter {
 
    // padded sample stride of the X tile (bank spread for the quad-strided writes)
 
-template <int C4, bool RAD, bool INTR, bool JIT>
+// HX (round 6): the basis_mat contraction on v_mfma_f32_16x16x32_f16 with BOTH operands split x = hi + lo in fp16 (hi hi + lo hi +
+// hi lo, fp32 accumulate: ~2^-21 relative per product, fp32-grade features: 2e-6 of the feature scale measured) instead of
+// v_mfma_f32_16x16x4_f32, which runs at the vector rate: 12 matrix instructions per VM group and feature vector instead of 24,
+// each half as long -- a quarter of the matrix-pipe time.  Measured on the bench step: 99 -> 96 us for the merged primary gather
+// (the launch is bound by its 1.8 passes per wave and the tap latency, not by the matrix pipe, whatever the static count said);
+// kept as the default for the pipe time and power it frees for the decoders running next to it on the other stream.  The product tile is [16 samples][64 + 8 halves] hi and lo (channels >= CA stay zero), basis_mat^T is pre-split into
+// operand tiles at kernel start (the layout of k_vm_app_bf16 below).  Products beyond +-65504 saturate (no field does that:
+// the fp16 kernels' range guard bounds them).  The exact route (HX = false) stays for TENSOIR_DECODER=mfma / the training forward.
+typedef _Float16 app_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 app_f16x2 __attribute__((ext_vector_type(2)));
+typedef float app_f32x2 __attribute__((ext_vector_type(2)));
+#define TIR_XHX 72      // sample stride of the half-split product tile in halves (64 channels + 8: 144 B rows)
+
+// 4 channel values -> saturating fp16 hi and the fp16 residue, 8 bytes each
+__device__ __forceinline__ void app_split4(const float (&v)[4], _Float16* __restrict__ xh, _Float16* __restrict__ xl) {
+    unsigned hi[2], lo[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float x0 = __builtin_amdgcn_fmed3f(v[2 * q], -65504.0f, 65504.0f), x1 = __builtin_amdgcn_fmed3f(v[2 * q + 1], -65504.0f, 65504.0f);
+        const app_f32x2 x = {x0, x1};
+        const app_f16x2 h2 = __builtin_convertvector(x, app_f16x2);
+        const app_f32x2 r = x - __builtin_convertvector(h2, app_f32x2);
+        hi[q] = __builtin_bit_cast(unsigned, h2);
+        lo[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, app_f16x2));
+    }
+    *reinterpret_cast<uint2*>(xh) = make_uint2(hi[0], hi[1]);
+    *reinterpret_cast<uint2*>(xl) = make_uint2(lo[0], lo[1]);
+}
+
+template <int C4, bool RAD, bool INTR, bool JIT, bool HX = false>
 __device__ __forceinline__ void
 app_mfma_body(const TirField& f, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
               const int32_t* __restrict__ idx_map, float* __restrict__ rad_feat, float* __restrict__ int_feat,
@@ -459,18 +488,40 @@ app_mfma_body(const TirField& f, const float* __restrict__ xyz, const int32_t* _
     if (n_dev) n = min(n, (int64_t)max(*n_dev, 0));        // device-side point count (no host sync needed)
     constexpr int CA = C4 * 4;
     constexpr int NX = (RAD ? 1 : 0) + (INTR ? 1 : 0);
+    static_assert(!HX || CA <= 64, "half-split contraction: one VM group must fit two 32-wide k-steps");
+    constexpr int W_FLOATS = HX ? (2 * 3 * 2 * 2 * 64 * 16) / 4 : 3 * CA * 32;          // operand tiles hi + lo | fp32 basis_mat^T
+    constexpr int X_FLOATS = HX ? (NX * 2 * 16 * TIR_XHX * 2) / 4 : NX * CA * TIR_XLD;   // per wave
     extern __shared__ __attribute__((aligned(16))) float lds_app[];
     float* Wt = lds_app;                                   // [3*CA][32]
+    app_f16x8* Whi = reinterpret_cast<app_f16x8*>(lds_app);    // HX: [group 3][k-step 2][row tile 2][k-group 4][row 16] x 8 halves, hi then lo
+    app_f16x8* Wlo = Whi + 3 * 2 * 2 * 64;
     if (JIT && jt.rng_dev) { jt.seed = (unsigned long long)jt.rng_dev[0]; jt.offset = (unsigned long long)jt.rng_dev[1]; }
     const int wave = threadIdx.x >> 6, L = threadIdx.x & 63;
     // light rows in LDS: [n_lt rows of light_line | light_mean] x 3*CA floats (576 B per row).  Their taps were 9 (RAD) +
     // 9 (INTR) of the 63-72 load instructions of a pass, and the ray-coherent gather is bound by the RATE of load
     // instructions through the texture addresser (profiles/r02_gather_pred_bench.txt), not by bytes.
-    float* LT = lds_app + 3 * CA * 32;
+    float* LT = lds_app + W_FLOATS;
     const int n_lt = lt_rows;                              // light_line rows staged (0: read them from memory)
-    float* X = LT + (n_lt + 1) * (3 * CA) + wave * (NX * CA * TIR_XLD);   // [NX][CA][17]
-    for (int i = threadIdx.x * 4; i < 3 * CA * 32; i += 256 * 4)
-        *reinterpret_cast<float4*>(Wt + i) = *reinterpret_cast<const float4*>(f.basis_t + i);
+    float* X = LT + (n_lt + 1) * (3 * CA) + wave * X_FLOATS;   // [NX][CA][17]  |  HX: [NX][hi, lo][16][TIR_XHX halves]
+    _Float16* XH = reinterpret_cast<_Float16*>(X);
+    if constexpr (HX) {
+        for (int e = threadIdx.x; e < 3 * 2 * 2 * 64; e += 256) {
+            const int row = e & 15, kg = (e >> 4) & 3, mt = (e >> 6) & 1, t = (e >> 7) & 1, k = e >> 8;
+            app_f16x8 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int ch = 32 * t + 8 * kg + q;
+                const float w = (ch < CA) ? f.basis_t[(size_t)(k * CA + ch) * 32 + mt * 16 + row] : 0.0f;
+                hi[q] = (_Float16)__builtin_amdgcn_fmed3f(w, -65504.0f, 65504.0f);
+                lo[q] = (_Float16)(w - (float)hi[q]);
+            }
+            Whi[e] = hi; Wlo[e] = lo;
+        }
+        for (int e = L; e < X_FLOATS; e += 64) X[e] = 0.0f;            // incl. the never-written pad channels
+    } else {
+        for (int i = threadIdx.x * 4; i < 3 * CA * 32; i += 256 * 4)
+            *reinterpret_cast<float4*>(Wt + i) = *reinterpret_cast<const float4*>(f.basis_t + i);
+    }
     for (int i = threadIdx.x * 4; i < n_lt * 3 * CA; i += 256 * 4)
         *reinterpret_cast<float4*>(LT + i) = *reinterpret_cast<const float4*>(f.light_line + i);
     for (int i = threadIdx.x * 4; i < 3 * CA; i += 256 * 4)
@@ -543,20 +594,59 @@ app_mfma_body(const TirField& f, const float* __restrict__ xyz, const int32_t* _
                     val[3] = fmaf(d.w, w11, fmaf(cc.w, w10, fmaf(b.w, w01, a.w * w00))) * fmaf(g.w, tl.w1, e.w * tl.w0);
                     if (RAD) {
                         const float4 lr = ld4(lrow + k * CA + 4 * ch4);
-                        float* xr = X + (4 * ch4) * TIR_XLD + j;
-                        xr[0] = val[0] * lr.x; xr[TIR_XLD] = val[1] * lr.y; xr[2 * TIR_XLD] = val[2] * lr.z; xr[3 * TIR_XLD] = val[3] * lr.w;
+                        if constexpr (HX) {
+                            const float vr[4] = {val[0] * lr.x, val[1] * lr.y, val[2] * lr.z, val[3] * lr.w};
+                            app_split4(vr, XH + j * TIR_XHX + 4 * ch4, XH + 16 * TIR_XHX + j * TIR_XHX + 4 * ch4);
+                        } else {
+                            float* xr = X + (4 * ch4) * TIR_XLD + j;
+                            xr[0] = val[0] * lr.x; xr[TIR_XLD] = val[1] * lr.y; xr[2 * TIR_XLD] = val[2] * lr.z; xr[3 * TIR_XLD] = val[3] * lr.w;
+                        }
                     }
                     if (INTR) {
                         const float4 lm = ld4(lmean + k * CA + 4 * ch4);
-                        float* xi = X + ((RAD ? CA : 0) + 4 * ch4) * TIR_XLD + j;
-                        xi[0] = val[0] * lm.x; xi[TIR_XLD] = val[1] * lm.y; xi[2 * TIR_XLD] = val[2] * lm.z; xi[3 * TIR_XLD] = val[3] * lm.w;
+                        if constexpr (HX) {
+                            const float vi[4] = {val[0] * lm.x, val[1] * lm.y, val[2] * lm.z, val[3] * lm.w};
+                            _Float16* xb = XH + (RAD ? 2 * 16 * TIR_XHX : 0);
+                            app_split4(vi, xb + j * TIR_XHX + 4 * ch4, xb + 16 * TIR_XHX + j * TIR_XHX + 4 * ch4);
+                        } else {
+                            float* xi = X + ((RAD ? CA : 0) + 4 * ch4) * TIR_XLD + j;
+                            xi[0] = val[0] * lm.x; xi[TIR_XLD] = val[1] * lm.y; xi[2 * TIR_XLD] = val[2] * lm.z; xi[3 * TIR_XLD] = val[3] * lm.w;
+                        }
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();      // LDS ops of one wave complete in order; keep the compiler from reordering
+            if constexpr (HX) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (32 * t >= CA) break;
+                    const int wi = ((k * 2 + t) * 2) * 64 + kq * 16 + jj;
+                    const app_f16x8 ah0 = Whi[wi], ah1 = Whi[wi + 64], al0 = Wlo[wi], al1 = Wlo[wi + 64];
+                    if (RAD) {
+                        const _Float16* xr = XH + jj * TIR_XHX + 32 * t + 8 * kq;
+                        const app_f16x8 bh = *reinterpret_cast<const app_f16x8*>(xr), bl = *reinterpret_cast<const app_f16x8*>(xr + 16 * TIR_XHX);
+                        accr[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, accr[0], 0, 0, 0);
+                        accr[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, accr[1], 0, 0, 0);
+                        accr[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, accr[0], 0, 0, 0);
+                        accr[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, accr[1], 0, 0, 0);
+                        accr[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl, accr[0], 0, 0, 0);
+                        accr[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl, accr[1], 0, 0, 0);
+                    }
+                    if (INTR) {
+                        const _Float16* xi = XH + (RAD ? 2 * 16 * TIR_XHX : 0) + jj * TIR_XHX + 32 * t + 8 * kq;
+                        const app_f16x8 bh = *reinterpret_cast<const app_f16x8*>(xi), bl = *reinterpret_cast<const app_f16x8*>(xi + 16 * TIR_XHX);
+                        acci[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, acci[0], 0, 0, 0);
+                        acci[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, acci[1], 0, 0, 0);
+                        acci[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, acci[0], 0, 0, 0);
+                        acci[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, acci[1], 0, 0, 0);
+                        acci[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl, acci[0], 0, 0, 0);
+                        acci[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl, acci[1], 0, 0, 0);
+                    }
+                }
+            }
             const float* wk = Wt + (size_t)(k * CA) * 32;
 #pragma unroll 4
-            for (int t = 0; t < CA / 4; ++t) {
+            for (int t = 0; t < (HX ? 0 : CA / 4); ++t) {
                 const float a0 = wk[(4 * t + kq) * 32 + jj], a1 = wk[(4 * t + kq) * 32 + 16 + jj];
                 if (RAD) {
                     const float br = X[(4 * t + kq) * TIR_XLD + jj];
@@ -592,20 +682,20 @@ app_mfma_body(const TirField& f, const float* __restrict__ xyz, const int32_t* _
     }
 }
 
-template <int C4, bool RAD, bool INTR, bool JIT = false>
+template <int C4, bool RAD, bool INTR, bool JIT = false, bool HX = false>
 __global__ void __launch_bounds__(256)
 k_vm_app_mfma(TirField f, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
               const int32_t* __restrict__ idx_map, float* __restrict__ rad_feat, float* __restrict__ int_feat,
               int out_stride, int idx_div, int64_t n, const int32_t* __restrict__ n_dev, int xcd_on, TirJitter jt, int lt_rows) {
-    app_mfma_body<C4, RAD, INTR, JIT>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, xcd_on, jt,
-                                      lt_rows, (int)blockIdx.x, (int)gridDim.x);
+    app_mfma_body<C4, RAD, INTR, JIT, HX>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, xcd_on, jt,
+                                          lt_rows, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // The two appearance gathers of the primary stage in ONE launch: workgroups [0, nb0) compute the radiance + intrinsic
 // features of the records (models/tensoRF_rotated_lights.py:132-165), workgroups [nb0, nb0 + nb1) the intrinsic features of
 // the JITTERED records (:937-938, noise drawn in the kernel).  Both are 230 k-row launches of 1.8 passes per wave on
 // their own: merged they fill the chip once instead of twice.
-template <int C4>
+template <int C4, bool HX = false>
 __global__ void __launch_bounds__(256)
 k_vm_app_primary(TirField f, const float* __restrict__ xyz, const int32_t* __restrict__ light_idx,
                  const int32_t* __restrict__ idx_map, float* __restrict__ rad_feat, float* __restrict__ int_feat,
@@ -613,11 +703,11 @@ k_vm_app_primary(TirField f, const float* __restrict__ xyz, const int32_t* __res
                  TirJitter jt, int lt_rows, int nb0) {
     if ((int)blockIdx.x < nb0) {
         TirJitter none{0.0f, 0ull, 0ull, nullptr, nullptr};
-        app_mfma_body<C4, true, true, false>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, 0, n, n_dev, xcd_on, none,
-                                             lt_rows, (int)blockIdx.x, nb0);
+        app_mfma_body<C4, true, true, false, HX>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, 0, n, n_dev, xcd_on, none,
+                                                 lt_rows, (int)blockIdx.x, nb0);
     } else {
-        app_mfma_body<C4, false, true, true>(f, xyz, nullptr, nullptr, nullptr, int_feat_jit, out_stride, 0, n, n_dev, xcd_on, jt,
-                                             lt_rows, (int)blockIdx.x - nb0, (int)gridDim.x - nb0);
+        app_mfma_body<C4, false, true, true, HX>(f, xyz, nullptr, nullptr, nullptr, int_feat_jit, out_stride, 0, n, n_dev, xcd_on, jt,
+                                                 lt_rows, (int)blockIdx.x - nb0, (int)gridDim.x - nb0);
     }
 }
 
@@ -963,6 +1053,29 @@ static int launch_app_bf16(const TirField* f, const float* xyz, const int32_t* l
     return TIR_OK;
 }
 
+// the half-split contraction (app_mfma_body HX) for the plain gather: radiance only, both, or intrinsic only
+template <int C4>
+static int launch_app_hx(const TirField* f, const float* xyz, const int32_t* li, const int32_t* map,
+                         float* rad, float* intr, int stride, int idx_div, int64_t n, const int32_t* n_dev, hipStream_t s) {
+    constexpr int CA = C4 * 4;
+    const int nx = (rad ? 1 : 0) + (intr ? 1 : 0);
+    const int lt_rows = (rad && f->n_lights <= 16) ? f->n_lights : 0;
+    const size_t lds = ((size_t)(2 * 3 * 2 * 2 * 64 * 16) / 4 + (size_t)(lt_rows + 1) * 3 * CA + 4 * (size_t)(nx * 2 * 16 * TIR_XHX * 2) / 4) * sizeof(float);
+    int64_t blocks = (n + 63) / 64;
+    if (blocks > 2048) blocks = 2048;
+    const int xcd_on = tir_xcd_mapping(f);
+    if (xcd_on) blocks = (blocks + 7) / 8 * 8;
+    dim3 g((unsigned)blocks), b(256);
+    const TirJitter jt{0.0f, 0ull, 0ull, nullptr, nullptr};
+    if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_vm_app_mfma<C4, true, true, false, true>), 160 * 1024)) return rc;
+    if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_vm_app_mfma<C4, true, false, false, true>), 160 * 1024)) return rc;
+    if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_vm_app_mfma<C4, false, true, false, true>), 160 * 1024)) return rc;
+    if (rad && intr) hipLaunchKernelGGL((k_vm_app_mfma<C4, true, true, false, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on, jt, lt_rows);
+    else if (rad)    hipLaunchKernelGGL((k_vm_app_mfma<C4, true, false, false, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on, jt, lt_rows);
+    else             hipLaunchKernelGGL((k_vm_app_mfma<C4, false, true, false, true>), g, b, lds, s, *f, xyz, li, map, rad, intr, stride, idx_div, n, n_dev, xcd_on, jt, lt_rows);
+    return TIR_OK;
+}
+
 template <int C4>
 static int launch_app(const TirField* f, const float* xyz, const int32_t* li, const int32_t* map,
                       float* rad, float* intr, int stride, int idx_div, int64_t n, const int32_t* n_dev, hipStream_t s, bool valu,
@@ -1052,6 +1165,32 @@ extern "C" int tir_vm_app_jitter_fwd(const TirField* f, const float* xyz, int64_
     return app_fwd(f, xyz, nullptr, nullptr, nullptr, int_feat, out_stride, 0, n, n_dev, stream, false, false, jt);
 }
 
+static int app_primary_launch(const TirField* f, const float* xyz, const int32_t* light_idx, const int32_t* idx_map, float* rad_feat,
+                              float* int_feat, int32_t out_stride, int64_t n, const int32_t* n_dev, float scale, uint64_t seed,
+                              uint64_t offset, const int64_t* rng_state, float* xyz_out, float* int_feat_jit, void* stream, bool hx) {
+    constexpr int C4 = 12, CA = 48;
+    const int lt_rows = f->n_lights <= 16 ? f->n_lights : 0;
+    const size_t w_floats = hx ? (2 * 3 * 2 * 2 * 64 * 16) / 4 : 3 * CA * 32;
+    const size_t x_floats = hx ? (2 * 2 * 16 * TIR_XHX * 2) / 4 : 2 * CA * TIR_XLD;         // per wave, two feature sets
+    const size_t lds = (w_floats + (size_t)(lt_rows + 1) * 3 * CA + 4 * x_floats) * sizeof(float);
+    int64_t nb = (n + 63) / 64;
+    if (nb > 1024) nb = 1024;
+    nb = (nb + 7) / 8 * 8;                                   // both slices start at a multiple of 8 (XCD mapping)
+    const int xcd_on = tir_xcd_mapping(f);
+    TirJitter jt{scale, (unsigned long long)seed, (unsigned long long)offset, reinterpret_cast<const long long*>(rng_state), xyz_out};
+    if (hx) {
+        if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_vm_app_primary<C4, true>), 160 * 1024)) return rc;
+        hipLaunchKernelGGL((k_vm_app_primary<C4, true>), dim3((unsigned)(2 * nb)), dim3(256), lds, tir_stream(stream), *f, xyz, light_idx, idx_map,
+                           rad_feat, int_feat, int_feat_jit, out_stride, n, n_dev, xcd_on, jt, lt_rows, (int)nb);
+    } else {
+        if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_vm_app_primary<C4, false>), 160 * 1024)) return rc;
+        hipLaunchKernelGGL((k_vm_app_primary<C4, false>), dim3((unsigned)(2 * nb)), dim3(256), lds, tir_stream(stream), *f, xyz, light_idx, idx_map,
+                           rad_feat, int_feat, int_feat_jit, out_stride, n, n_dev, xcd_on, jt, lt_rows, (int)nb);
+    }
+    TIR_CHECK_LAUNCH();
+    return TIR_OK;
+}
+
 // tir_vm_app_fwd (both features) + tir_vm_app_jitter_fwd on the same points in one launch (48 appearance components).
 extern "C" int tir_vm_app_primary_fwd(const TirField* f, const float* xyz, const int32_t* light_idx, const int32_t* idx_map,
                                       float* rad_feat, float* int_feat, int32_t out_stride, int64_t n, const int32_t* n_dev,
@@ -1065,17 +1204,47 @@ extern "C" int tir_vm_app_primary_fwd(const TirField* f, const float* xyz, const
     if (out_stride < f->app_dim || out_stride > 32) return TIR_ERR_ARG;
     if (n < 0 || (n > 0 && !xyz)) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
-    constexpr int C4 = 12, CA = 48;
-    const int lt_rows = f->n_lights <= 16 ? f->n_lights : 0;
-    const size_t lds = (size_t)(3 * CA * 32 + (lt_rows + 1) * 3 * CA + 4 * 2 * CA * TIR_XLD) * sizeof(float);
-    int64_t nb = (n + 63) / 64;
-    if (nb > 1024) nb = 1024;
-    nb = (nb + 7) / 8 * 8;                                   // both slices start at a multiple of 8 (XCD mapping)
-    const int xcd_on = tir_xcd_mapping(f);
-    if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_vm_app_primary<C4>), 160 * 1024)) return rc;
-    TirJitter jt{scale, (unsigned long long)seed, (unsigned long long)offset, reinterpret_cast<const long long*>(rng_state), xyz_out};
-    hipLaunchKernelGGL((k_vm_app_primary<C4>), dim3((unsigned)(2 * nb)), dim3(256), lds, tir_stream(stream), *f, xyz, light_idx, idx_map,
-                       rad_feat, int_feat, int_feat_jit, out_stride, n, n_dev, xcd_on, jt, lt_rows, (int)nb);
+    return app_primary_launch(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, n, n_dev, scale, seed, offset, rng_state, xyz_out,
+                              int_feat_jit, stream, false);
+}
+
+// ... with the basis_mat contraction on fp16 hi + lo operands (three products; app_mfma_body HX): the default primary stage of
+// inference under the split-bf16 decoders
+extern "C" int tir_vm_app_primary_x3_fwd(const TirField* f, const float* xyz, const int32_t* light_idx, const int32_t* idx_map,
+                                         float* rad_feat, float* int_feat, int32_t out_stride, int64_t n, const int32_t* n_dev,
+                                         float scale, uint64_t seed, uint64_t offset, const int64_t* rng_state, float* xyz_out,
+                                         float* int_feat_jit, void* stream) {
+    if (!f || !rad_feat || !int_feat || !xyz_out || !int_feat_jit || !light_idx || scale == 0.0f) return TIR_ERR_ARG;
+    for (int i = 0; i < 3; ++i)
+        if (f->grid[i] < 2 || !f->aplane[i] || !f->aline[i]) return TIR_ERR_ARG;
+    if (!f->basis_t || !f->light_mean || !f->light_line) return TIR_ERR_ARG;
+    if (f->n_acomp != 48 || f->app_dim < 1 || f->app_dim > 27) return TIR_ERR_UNSUPPORTED;
+    if (out_stride < f->app_dim || out_stride > 32) return TIR_ERR_ARG;
+    if (n < 0 || (n > 0 && !xyz)) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    return app_primary_launch(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, n, n_dev, scale, seed, offset, rng_state, xyz_out,
+                              int_feat_jit, stream, true);
+}
+
+extern "C" int tir_vm_app_fwd_x3(const TirField* f, const float* xyz, const int32_t* light_idx,
+                                 const int32_t* idx_map, float* rad_feat, float* int_feat, int32_t out_stride,
+                                 int32_t idx_div, int64_t n, const int32_t* n_dev, void* stream) {
+    if (!f) return TIR_ERR_ARG;
+    for (int i = 0; i < 3; ++i)
+        if (f->grid[i] < 2 || !f->aplane[i] || !f->aline[i]) return TIR_ERR_ARG;
+    if (!f->basis_t || !f->light_mean || !f->light_line) return TIR_ERR_ARG;
+    if (f->app_dim < 1 || f->app_dim > 27) return TIR_ERR_UNSUPPORTED;
+    if (out_stride < f->app_dim || out_stride > 32) return TIR_ERR_ARG;
+    if (n < 0 || (n > 0 && !xyz) || (!rad_feat && !int_feat) || (rad_feat && !light_idx)) return TIR_ERR_ARG;
+    if (n == 0) return TIR_OK;
+    int rc;
+    switch (f->n_acomp) {
+        case 48: rc = launch_app_hx<12>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, tir_stream(stream)); break;
+        case 24: rc = launch_app_hx<6>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, tir_stream(stream)); break;
+        case 16: rc = launch_app_hx<4>(f, xyz, light_idx, idx_map, rad_feat, int_feat, out_stride, idx_div, n, n_dev, tir_stream(stream)); break;
+        default: return TIR_ERR_UNSUPPORTED;
+    }
+    if (rc) return rc;
     TIR_CHECK_LAUNCH();
     return TIR_OK;
 }

@@ -678,19 +678,19 @@ class TensorVMSplit(nn.Module):
         """models/tensoRF_rotated_lights.py:197-224 -> tir_vm_app_fwd."""
         _no_grad_only("compute_appfeature", *self._field_params())
         li = light_idx.reshape(-1).to(xyz_sampled.device, torch.int32)
-        return ops.vm_app(self.packed_field(), xyz_sampled.reshape(-1, 3), li, None, True, False)[0][:, :self.app_dim].contiguous()
+        return ops.vm_app(self.packed_field(), xyz_sampled.reshape(-1, 3), li, None, True, False, ops.APP_IMPL)[0][:, :self.app_dim].contiguous()
 
     def compute_bothfeature(self, xyz_sampled, light_idx):
         """models/tensoRF_rotated_lights.py:132-165."""
         _no_grad_only("compute_bothfeature", *self._field_params())
         li = light_idx.reshape(-1).to(xyz_sampled.device, torch.int32)
-        r, i = ops.vm_app(self.packed_field(), xyz_sampled.reshape(-1, 3), li, None, True, True)
+        r, i = ops.vm_app(self.packed_field(), xyz_sampled.reshape(-1, 3), li, None, True, True, ops.APP_IMPL)
         return r[:, :self.app_dim].contiguous(), i[:, :self.app_dim].contiguous()
 
     def compute_intrinfeature(self, xyz_sampled):
         """models/tensoRF_rotated_lights.py:167-195."""
         _no_grad_only("compute_intrinfeature", *self._field_params())
-        return ops.vm_app(self.packed_field(), xyz_sampled.reshape(-1, 3), None, None, False, True)[1][:, :self.app_dim].contiguous()
+        return ops.vm_app(self.packed_field(), xyz_sampled.reshape(-1, 3), None, None, False, True, ops.APP_IMPL)[1][:, :self.app_dim].contiguous()
 
     def compute_derived_normals(self, xyz_locs):
         """models/tensorBase_rotated_lights.py:839-856 -> tir_density_grad_fwd (closed form)."""

@@ -105,7 +105,7 @@ class GraphedRenderer:
         # every light parameter: the general multi-light model keeps one SG set per light in a plain list
         lights = m.light_parameters()
         return (m._field_key, tuple((t.data_ptr(), t._version) for t in lights), tuple(d._key for d in decs),
-                float(m.march_t_stop), ops.MLP_IMPL, ops.secondary_mlp_impl(), ops.secondary_app_impl(), ops.fused_indirect(),
+                float(m.march_t_stop), ops.MLP_IMPL, ops.app_contraction(), ops.secondary_mlp_impl(), ops.secondary_app_impl(), ops.fused_indirect(),
                 ops.INDIRECT_GUARD and (m.__dict__.get("_indirect_state") or {}).get("verdict"))
 
     def _stale(self):

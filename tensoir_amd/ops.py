@@ -433,7 +433,7 @@ def density_grad(field: TirField, xyz, want_sigma=False, want_grad=False, want_n
 
 FEAT_STRIDE = 32     # feature rows are padded to 128 bytes (aligned float4 stores / loads)
 # "mfma" (exact fp32 matrix-core contraction), "bf16x3" (split-bf16 matrix cores, parity grade) or "valu" (cross-check)
-APP_ENTRY = {"mfma": "tir_vm_app_fwd", "bf16x3": "tir_vm_app_fwd_bf16x3", "valu": "tir_vm_app_fwd_valu"}
+APP_ENTRY = {"mfma": "tir_vm_app_fwd", "x3": "tir_vm_app_fwd_x3", "bf16x3": "tir_vm_app_fwd_bf16x3", "valu": "tir_vm_app_fwd_valu"}
 APP_IMPL = os.environ.get("TENSOIR_APP", "mfma")
 
 
@@ -456,7 +456,9 @@ def vm_app(field: TirField, xyz, light_idx=None, idx_map=None, want_rad=True, wa
             raise ValueError("light_idx must have one entry per point")
     rad = torch.empty((n, ad), dtype=torch.float32, device=xyz.device) if want_rad else None
     intr = torch.empty((n, ad), dtype=torch.float32, device=xyz.device) if want_int else None
-    _call(APP_ENTRY[impl or APP_IMPL], C.byref(field), _ptr(xyz),
+    if impl is None:       # the default route follows the contraction setting (x3 unless the exact decoders / fp32 contraction are selected)
+        impl = "x3" if (APP_IMPL == "mfma" and app_contraction() == "x3" and int(field.n_acomp) in (16, 24, 48)) else APP_IMPL
+    _call(APP_ENTRY[impl], C.byref(field), _ptr(xyz),
           _ptr(light_idx) if want_rad else None, _ptr(idx_map) if want_rad else None, _ptr(rad), _ptr(intr),
           ad, int(idx_div), n, _ptr(n_dev), _stream())
     return rad, intr
@@ -586,7 +588,8 @@ def fused_indirect():
 
 def full_indirect_route():
     """Which launches decode the secondary-ray records when the indirect-light policy says `full` (reported by bench.py)."""
-    return "tir_vm_app_fwd (fp32 taps, fp32 MFMA contraction) + tir_mlp_fwd_auxtab_bf16x3 (split-bf16 x3), feature rows through HBM"
+    gather = "tir_vm_app_fwd_x3 (fp32 taps, fp16 hi + lo contraction)" if app_contraction() == "x3" else "tir_vm_app_fwd (fp32 taps, fp32 MFMA contraction)"
+    return gather + " + tir_mlp_fwd_auxtab_bf16x3 (split-bf16 x3), feature rows through HBM"
 
 
 def hp_indirect_route():
@@ -743,9 +746,21 @@ def vm_app_jitter(field: TirField, xyz, scale, seed, offset, rng_state=None, n_d
     return xyz_j, intr
 
 
-def vm_app_primary(field: TirField, xyz, light_idx, idx_map, scale, rng_state, n_dev=None):
-    """The primary stage's two appearance gathers in one launch (tir_vm_app_primary_fwd): returns
-    (rad [n, FEAT_STRIDE], intr, xyz_jittered [n, 3], intr_jittered)."""
+# Contraction of the primary stage's merged gather: "x3" = fp16 hi + lo operands, three matrix products (tir_vm_app_primary_x3_fwd,
+# default while the decoders are the split-bf16 ones), "fp32" = the exact-fp32 matrix instruction (tir_vm_app_primary_fwd).
+APP_CONTRACTION = os.environ.get("TENSOIR_APP_CONTRACTION", "x3")
+if APP_CONTRACTION not in ("x3", "fp32"):
+    raise ValueError(f"TENSOIR_APP_CONTRACTION={APP_CONTRACTION!r}: expected x3 or fp32")
+
+
+def app_contraction():
+    return APP_CONTRACTION if MLP_IMPL == "bf16x3" else "fp32"
+
+
+def vm_app_primary(field: TirField, xyz, light_idx, idx_map, scale, rng_state, n_dev=None, exact=False):
+    """The primary stage's two appearance gathers in one launch (tir_vm_app_primary_x3_fwd / tir_vm_app_primary_fwd): returns
+    (rad [n, FEAT_STRIDE], intr, xyz_jittered [n, 3], intr_jittered).  exact: the fp32 contraction whatever the setting (the
+    training forward: its saved features feed the hand-written backward)."""
     xyz = f32(xyz, "xyz", 3).view(-1, 3)
     n = xyz.shape[0]
     dev = xyz.device
@@ -753,7 +768,8 @@ def vm_app_primary(field: TirField, xyz, light_idx, idx_map, scale, rng_state, n
     intr = torch.empty((n, FEAT_STRIDE), dtype=torch.float32, device=dev)
     intr_j = torch.empty((n, FEAT_STRIDE), dtype=torch.float32, device=dev)
     xyz_j = torch.empty_like(xyz)
-    _call("tir_vm_app_primary_fwd", C.byref(field), _ptr(xyz), _ptr(i32(light_idx, "light_idx").view(-1)),
+    _call("tir_vm_app_primary_fwd" if (exact or app_contraction() == "fp32") else "tir_vm_app_primary_x3_fwd", C.byref(field), _ptr(xyz),
+          _ptr(i32(light_idx, "light_idx").view(-1)),
           _ptr(None if idx_map is None else i32(idx_map, "idx_map").view(-1)), _ptr(rad), _ptr(intr), FEAT_STRIDE, n, _ptr(n_dev),
           float(scale), 0, 0, _ptr(rng_state), _ptr(xyz_j), _ptr(intr_j), _stream())
     return rad, intr, xyz_j, intr_j

@@ -256,14 +256,14 @@ class PrimaryRenderFn(torch.autograd.Function):
                 # counter, record index): the draw does not depend on the record-capacity hint, so a fixed torch seed
                 # reproduces the run
                 rng_state = model._jitter_rng(dev)
-                rad, intr, xyz_j, intr_j = ops.vm_app_primary(f, rec_xyz, lidx, rec_ray, 0.01, rng_state, n_dev)
+                rad, intr, xyz_j, intr_j = ops.vm_app_primary(f, rec_xyz, lidx, rec_ray, 0.01, rng_state, n_dev, exact=True)
                 rng_state[1] += 1
             else:
-                rad, intr = ops.vm_app(f, rec_xyz, lidx, rec_ray, True, bool(is_relight), None, 0, n_dev)
+                rad, intr = ops.vm_app(f, rec_xyz, lidx, rec_ray, True, bool(is_relight), ops.APP_IMPL, 0, n_dev)      # (exact contraction: saved for the backward)
                 if is_relight and noise_dense is not None:
                     noise = noise_dense.to(dev, torch.float32)[rec_ray.long(), rec_k.long()]
                     xyz_j = torch.add(rec_xyz, noise, alpha=0.01)
-                    intr_j = ops.vm_app(f, xyz_j, None, None, False, True, None, 0, n_dev)[1]
+                    intr_j = ops.vm_app(f, xyz_j, None, None, False, True, ops.APP_IMPL, 0, n_dev)[1]
                 elif is_relight:
                     rng_state = model._jitter_rng(dev)
                     xyz_j, intr_j = ops.vm_app_jitter(f, rec_xyz, 0.01, 0, 0, rng_state, n_dev)

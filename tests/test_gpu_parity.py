@@ -869,7 +869,7 @@ def test_boundary_call_replays_a_cached_graph(env, monkeypatch):
 
 
 @torch.no_grad()
-@pytest.mark.parametrize("impl", ["mfma", "valu", "bf16x3"])
+@pytest.mark.parametrize("impl", ["mfma", "valu", "bf16x3", "x3"])
 def test_app_feature_implementations_vs_reference(env, impl):
     """All three appearance-contraction kernels (exact fp32 MFMA, VALU, split-bf16 MFMA) against the golden features,
     with both outputs, one output, an index map and ragged sizes."""
@@ -1200,7 +1200,7 @@ def test_in_kernel_brdf_jitter_noise(env):
     xj, feat = ops.vm_app_jitter(f, xyz, 0.01, 0, 0, state)
     xj2, feat2 = ops.vm_app_jitter(f, xyz, 0.01, 0, 0, state)
     assert torch.equal(xj, xj2) and torch.equal(feat, feat2)
-    ref = ops.vm_app(f, xj, None, None, False, True)[1]
+    ref = ops.vm_app(f, xj, None, None, False, True, "mfma")[1]
     assert torch.equal(feat, ref)                                            # same gather, same points
     z = ((xj - xyz) / 0.01).double().cpu()
     assert float(z.mean().abs()) < 0.01 and abs(float(z.var()) - 1.0) < 0.01
@@ -1220,7 +1220,9 @@ def test_in_kernel_brdf_jitter_noise(env):
 @torch.no_grad()
 def test_merged_primary_app_gather_equals_separate_launches(env):
     """tir_vm_app_primary_fwd (one launch) == tir_vm_app_fwd(both features) + tir_vm_app_jitter_fwd, bit for bit, with and
-    without a ray -> record indirection, for a device-side point count below the buffer size."""
+    without a ray -> record indirection, for a device-side point count below the buffer size; tir_vm_app_primary_x3_fwd (the
+    inference default: basis_mat contraction on fp16 hi + lo operands, three products) agrees with them to 5e-6 of the feature
+    scale, jittered points identical."""
     from tensoir_amd import ops
     m = env.model
     f = m.packed_field()
@@ -1232,12 +1234,19 @@ def test_merged_primary_app_gather_equals_separate_launches(env):
         lidx = torch.randint(0, max(int(f.n_lights), 1), (n_rays,), generator=g).int().cuda()
         n_dev = torch.tensor([n_live], dtype=torch.int32, device="cuda")
         state = torch.tensor([99, 3], dtype=torch.int64, device="cuda")
-        rad0, intr0 = ops.vm_app(f, xyz, lidx, rec_ray, True, True, None, 0, n_dev)
+        rad0, intr0 = ops.vm_app(f, xyz, lidx, rec_ray, True, True, "mfma", 0, n_dev)
         xj0, ij0 = ops.vm_app_jitter(f, xyz, 0.01, 0, 0, state, n_dev)
-        rad, intr, xj, ij = ops.vm_app_primary(f, xyz, lidx, rec_ray, 0.01, state, n_dev)
+        rad, intr, xj, ij = ops.vm_app_primary(f, xyz, lidx, rec_ray, 0.01, state, n_dev, exact=True)
         w = f.app_dim
         assert torch.equal(rad[:n_live, :w], rad0[:n_live, :w]) and torch.equal(intr[:n_live, :w], intr0[:n_live, :w])
         assert torch.equal(xj[:n_live], xj0[:n_live]) and torch.equal(ij[:n_live, :w], ij0[:n_live, :w])
+        assert ops.app_contraction() == "x3"
+        rad3, intr3, xj3, ij3 = ops.vm_app_primary(f, xyz, lidx, rec_ray, 0.01, state, n_dev)
+        assert torch.equal(xj3[:n_live], xj0[:n_live])
+        for got, ref in ((rad3, rad0), (intr3, intr0), (ij3, ij0)):
+            scale = float(ref[:n_live, :w].abs().max())
+            assert float((got[:n_live, :w] - ref[:n_live, :w]).abs().max()) < 5e-6 * max(scale, 1e-3), (n, scale)       # measured 2.1e-6
+            assert bool((got[:n_live, w:] == 0).all())
 
 
 @torch.no_grad()
@@ -1246,7 +1255,7 @@ def test_boundary_call_launch_budget_and_smoothness(full):
     map rows), the jitter state advances once per pass (two calls -> different smoothness noise, same geometry maps)."""
     from tensoir_amd import Renderer_TensoIR_train
     m = full.model
-    kw = dict(N_samples=512, args=full.args, device="cuda")
+    kw = dict(N_samples=512, args=full.args, device="cuda", _no_graph=True)  # the eager route (the cached graph owns a jitter state of its own)
     Renderer_TensoIR_train(full.rays, None, full.lidx, m, **kw)             # learns the capacity hints
     out, maps = m(full.rays, full.lidx, N_samples=512, _return_maps=True)
     want = maps[:, 17:19].double().mean(dim=0)
