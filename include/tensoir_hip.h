@@ -193,7 +193,8 @@ int tir_vm_app_primary_fwd(const TirField* f, const float* xyz, const int32_t* l
 /* the same launch with basis_mat's contraction (models/tensoRF_rotated_lights.py:159-165, :191-195) on v_mfma_f32_16x16x32_f16 and
  * both operands split x = hi + lo in fp16 (three products, fp32 accumulate: ~2^-21 relative per product -- the features agree with
  * the exact-fp32 contraction of tir_vm_app_primary_fwd to ~2e-6 of their scale): a quarter of the matrix-pipe time of the exact-fp32
- * instruction, which runs at the vector rate.  Default of the inference primary stage under the split-bf16 decoders. */
+ * instruction, which runs at the vector rate.  Opt-in (TENSOIR_APP_CONTRACTION=x3): fp16 residues of products below 0.125 are
+ * subnormal, so the features are good to ~1e-6 of their scale, which a trained BRDF decoder amplifies to 1e-4 on the albedo map. */
 int tir_vm_app_primary_x3_fwd(const TirField* f, const float* xyz, const int32_t* light_idx, const int32_t* idx_map,
                               float* rad_feat, float* int_feat, int32_t out_stride, int64_t n, const int32_t* n_dev,
                               float scale, uint64_t seed, uint64_t offset, const int64_t* rng_state, float* xyz_out,

@@ -455,7 +455,9 @@ struct TirJitter {
 // v_mfma_f32_16x16x4_f32, which runs at the vector rate: 12 matrix instructions per VM group and feature vector instead of 24,
 // each half as long -- a quarter of the matrix-pipe time.  Measured on the bench step: 99 -> 96 us for the merged primary gather
 // (the launch is bound by its 1.8 passes per wave and the tap latency, not by the matrix pipe, whatever the static count said);
-// kept as the default for the pipe time and power it frees for the decoders running next to it on the other stream.  The product tile is [16 samples][64 + 8 halves] hi and lo (channels >= CA stay zero), basis_mat^T is pre-split into
+// and the fp16 residue of a product below 0.125 is a subnormal: features good to ~1e-6 of their scale, which the BRDF decoder of a
+// field trained to 300^3 amplifies to 1e-4 on the albedo map (profiles/r06m_precision_trained_300_x3_gather.json).  OPT-IN
+// (TENSOIR_APP_CONTRACTION=x3); the primary stage keeps the exact instruction.  The product tile is [16 samples][64 + 8 halves] hi and lo (channels >= CA stay zero), basis_mat^T is pre-split into
 // operand tiles at kernel start (the layout of k_vm_app_bf16 below).  Products beyond +-65504 saturate (no field does that:
 // the fp16 kernels' range guard bounds them).  The exact route (HX = false) stays for TENSOIR_DECODER=mfma / the training forward.
 typedef _Float16 app_f16x8 __attribute__((ext_vector_type(8)));

@@ -1322,6 +1322,17 @@ k_indirect_fused_hp(TirField f, const float* __restrict__ packed, const float* _
         f32x16 facc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) facc[r] = 0.0f;
+        f32x16 acc[4], corr[4];
+        auto load_table = [&]() {       // layer 1 starts from the aux-table row of the record's direction (sixteen 16-byte loads per lane)
+            const float* tp = table + (size_t)ai * HID + 4 * h;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(tp + mt * 32 + 8 * i);
+                    acc[mt][4 * i] = t4.x; acc[mt][4 * i + 1] = t4.y; acc[mt][4 * i + 2] = t4.z; acc[mt][4 * i + 3] = t4.w;
+                }
+        };
         {
             // nine 16-channel chunks (3 VM groups x 3), software-pipelined two deep: while chunk i is interpolated and contracted,
             // the 12 loads of chunks i + 1 (and, once i is consumed, i + 2) are in flight -- no bubble at the group boundaries
@@ -1342,6 +1353,8 @@ k_indirect_fused_hp(TirField f, const float* __restrict__ packed, const float* _
                     const int k2 = (i + 2) / 3, q2 = (i + 2) % 3;
                     if (q2 == 0) { GA[k2] = hp_group(f, axA, k2); GB[k2] = hp_group(f, axB, k2); }
                     hp_issue(c, f.aplane[k2], f.aline[k2], GA[k2], GB[k2], q2);
+                } else if (i == 7) {
+                    load_table();       // the tap pipeline is draining: the decoder's start values travel behind the last chunk
                 }
                 __builtin_amdgcn_wave_barrier();
                 const f16x8 ah = Wh[((k * 3 + q) * 2 + h) * 32 + sl], al = Wl[((k * 3 + q) * 2 + h) * 32 + sl];
@@ -1357,17 +1370,6 @@ k_indirect_fused_hp(TirField f, const float* __restrict__ packed, const float* _
         float fo[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) fo[r] = __builtin_amdgcn_fmed3f(facc[r], -65504.0f, 65504.0f);
-        f32x16 acc[4], corr[4];
-        {
-            const float* tp = table + (size_t)ai * HID + 4 * h;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(tp + mt * 32 + 8 * i);
-                    acc[mt][4 * i] = t4.x; acc[mt][4 * i + 1] = t4.y; acc[mt][4 * i + 2] = t4.z; acc[mt][4 * i + 3] = t4.w;
-                }
-        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll

@@ -746,9 +746,13 @@ def vm_app_jitter(field: TirField, xyz, scale, seed, offset, rng_state=None, n_d
     return xyz_j, intr
 
 
-# Contraction of the primary stage's merged gather: "x3" = fp16 hi + lo operands, three matrix products (tir_vm_app_primary_x3_fwd,
-# default while the decoders are the split-bf16 ones), "fp32" = the exact-fp32 matrix instruction (tir_vm_app_primary_fwd).
-APP_CONTRACTION = os.environ.get("TENSOIR_APP_CONTRACTION", "x3")
+# Contraction of the primary stage's merged gather: "fp32" = the exact-fp32 matrix instruction (tir_vm_app_primary_fwd, the default),
+# "x3" = fp16 hi + lo operands, three matrix products (tir_vm_app_primary_x3_fwd / tir_vm_app_fwd_x3).  Round 6 built x3 expecting
+# the exact instruction (vector rate) to bind the launch; measured, the launch went from 99 to 96 us only, and on a checkpoint
+# trained to 300^3 the albedo / roughness maps moved to 1.0e-4 / 8.5e-5 from the oracle (2e-6 with fp32): the fp16 RESIDUE of a
+# product below 0.125 is a subnormal, so the features are good to ~1e-6 of their scale, not 2^-21, and the BRDF decoder of a trained
+# field amplifies that ~100-fold (profiles/r06m_precision_trained_300_x3_gather.json).  Opt-in only.
+APP_CONTRACTION = os.environ.get("TENSOIR_APP_CONTRACTION", "fp32")
 if APP_CONTRACTION not in ("x3", "fp32"):
     raise ValueError(f"TENSOIR_APP_CONTRACTION={APP_CONTRACTION!r}: expected x3 or fp32")
 

@@ -615,9 +615,14 @@ def relight_importance_sampled(tensoIR, env, light_name, surface_xyz, normal, al
     dev = surface_xyz.device
     normal = normal.to(torch.float32).contiguous()
     M = normal.shape[0]
+    if m_dev is not None and (not torch.is_tensor(m_dev) or m_dev.numel() != 1 or m_dev.dtype != torch.int32 or m_dev.device != dev):
+        raise ValueError("m_dev: expected one int32 element on the points' device")
     if M == 0:
-        env._draws += 1          # a call consumes one draw counter whatever M is: the device-compacted chunk call (relight_chunk)
-        return torch.zeros((0, 3), dtype=torch.float32, device=dev)      # cannot know that a chunk is all background
+        # A call consumes one draw counter whatever M is (since round 5: the device-compacted chunk call, relight_chunk, cannot know
+        # that a chunk is all background, and both routes must draw the same sequence).  Images rendered by rounds <= 4 with the
+        # host-masked loop are therefore not reproduced bit for bit on views that contain all-background chunks (HISTORY, round 5).
+        env._draws += 1
+        return torch.zeros((0, 3), dtype=torch.float32, device=dev)
     order, bins, block_pairs = ops.c5_pair_order()
     if m_dev is not None and (order == "mask" or env.cell_records(light_name) is None):
         raise ops._lib.TensoirHipError("a device-side surface-point count needs the pair-list sampler and the packed cell records "
@@ -656,7 +661,11 @@ def relight_chunk(tensoIR, env, light_names, rays, light_idx, num_samples=512, n
     plus ~12 indexing launches) -> per map: importance sampling, visibility march and BRDF integration bounded by the
     device-side point count -> relit colour where a ray hit, background lookup elsewhere (:166-171), written side by side into
     ONE [B, 3 * n_maps] buffer.  Same Philox counters per (point, sample) as the host-compacted sequence: identical colours.
-    Returns (out [B, 3 n_maps], primary-pass tuple, compacted surface dict)."""
+    Returns (out [B, 3 n_maps], primary-pass tuple, compacted surface dict).
+    What the caller still applies, as the script does AFTER its loop body (scripts/relight_importance.py:166-176): hit rows hold the
+    relit colour already clamped and sRGB-encoded by the integration kernel; BACKGROUND rows hold the raw environment lookup
+    (Environment_Light.get_light) -- the script's clamp, tone mapping of the background and its `acc > 0.9` blend of the two
+    (`:172-176`) are the caller's (prim[6] is acc_map)."""
     dev = rays.device
     rays = rays.to(torch.float32).contiguous()
     B = rays.shape[0]

@@ -1,5 +1,5 @@
 """Cases of the indirect-light precision policy, shared by tests/test_gpu_precision_policy.py and
-tools/r05_precision.py (which writes profiles/r05_precision_*.json).  Reference stage: models/relight_utils.py:777-834
+tools/precision_sweep.py / tools/precision_300.py (which write profiles/r0N_precision_*.json).  Reference stage: models/relight_utils.py:777-834
 (compute_radiance: compute_appfeature -> renderModule on the secondary-ray records, fp32 throughout).
 
   * trained(): a checkpoint TRAINED through the product API (tests/train_sequence.py: 450 iterations incl. updateAlphaMask /
@@ -95,8 +95,25 @@ def trained(n_iters=450):
     return r
 
 
-def trained_case(r, n_rays=2048):
-    """The trained model's own training rays (host tensors, as the script passes them) under the three policies + oracle."""
+def schedule_300(n_iters):
+    """Mask updates / up-samplings of train_tensoIR.py's default schedule (10k / 15k masks, 10k .. 40k up-samplings of 80k iterations)
+    compressed into n_iters, leaving the last 3/8 at the final grid."""
+    f = n_iters / 2400.0
+    return dict(mask_updates=(int(500 * f), int(800 * f)), upsamp=tuple(int(x * f) for x in (600, 900, 1200, 1500)))
+
+
+def trained_300(n_iters=2400, batch=4096, views=12, res=160):
+    """A checkpoint trained to 300^3 through the product API: 128^3 -> 300^3 in four up-samplings, two mask updates, shrink,
+    relighting losses from the first mask update on (tools/precision_300.py records the full-length run)."""
+    from tests.train_sequence import reconstruct
+    with contextlib.redirect_stdout(io.StringIO()):
+        return reconstruct("single_light", n_iters=n_iters, batch=batch, dataset=f"synthetic:views={views},res={res}", grid0=128, grid1=300,
+                           model_kw=dict(envmap_h=8, envmap_w=16), **schedule_300(n_iters))
+
+
+def trained_case(r, n_rays=2048, stride=2):
+    """The trained model's own training rays (host tensors, as the script passes them) under the three policies + the oracle on every
+    `stride`-th of them."""
     from tests.helpers import scene_from_model
     m = r.model
     rays = r.rays_f[:n_rays].cuda()
@@ -107,7 +124,7 @@ def trained_case(r, n_rays=2048):
     to_cpu = lambda v: v.detach().cpu() if torch.is_tensor(v) else v
     ckpt = {"kwargs": {k: to_cpu(v) for k, v in m.get_kwargs().items()}, "state_dict": {k: to_cpu(v) for k, v in m.state_dict().items()}}
     sc = scene_from_model(ckpt, m, 8, 16)
-    rep = oracle_compare(sc, out, res["auto"], rays, lidx, noise, S, slice(0, rays.shape[0], 2), fp64_floor=True)
+    rep = oracle_compare(sc, out, res["auto"], rays, lidx, noise, S, slice(0, rays.shape[0], stride), fp64_floor=True)
     return res, rep
 
 

@@ -167,6 +167,9 @@ def test_high_precision_fused_indirect_kernel(env):
     for npts in (1, 37, 255, 5003, 70001):
         fld, pm, pts, pair, exact, hp = routes(m, npts)
         assert hp.shape == (npts, 3) and bool(torch.isfinite(hp).all())
+        # bit-reproducible from launch to launch (a packed-fp32 form of the product chains was not: a few records of the last 16
+        # lanes of a wave changed from run to run)
+        assert torch.equal(hp, ops.indirect_fused_hp(fld, pm, pts, lpt, pair, D, dirs, D)), npts
         d = (hp - exact).double()
         assert float(d.abs().max()) < 3e-4, (npts, float(d.abs().max()))
         if npts > 1000:
@@ -1220,8 +1223,8 @@ def test_in_kernel_brdf_jitter_noise(env):
 @torch.no_grad()
 def test_merged_primary_app_gather_equals_separate_launches(env):
     """tir_vm_app_primary_fwd (one launch) == tir_vm_app_fwd(both features) + tir_vm_app_jitter_fwd, bit for bit, with and
-    without a ray -> record indirection, for a device-side point count below the buffer size; tir_vm_app_primary_x3_fwd (the
-    inference default: basis_mat contraction on fp16 hi + lo operands, three products) agrees with them to 5e-6 of the feature
+    without a ray -> record indirection, for a device-side point count below the buffer size; tir_vm_app_primary_x3_fwd (opt-in:
+    basis_mat contraction on fp16 hi + lo operands, three products) agrees with them to 5e-6 of the feature
     scale, jittered points identical."""
     from tensoir_amd import ops
     m = env.model
@@ -1240,12 +1243,17 @@ def test_merged_primary_app_gather_equals_separate_launches(env):
         w = f.app_dim
         assert torch.equal(rad[:n_live, :w], rad0[:n_live, :w]) and torch.equal(intr[:n_live, :w], intr0[:n_live, :w])
         assert torch.equal(xj[:n_live], xj0[:n_live]) and torch.equal(ij[:n_live, :w], ij0[:n_live, :w])
-        assert ops.app_contraction() == "x3"
-        rad3, intr3, xj3, ij3 = ops.vm_app_primary(f, xyz, lidx, rec_ray, 0.01, state, n_dev)
+        assert ops.app_contraction() == "fp32"                                   # x3 is opt-in (TENSOIR_APP_CONTRACTION)
+        old_c = ops.APP_CONTRACTION
+        try:
+            ops.APP_CONTRACTION = "x3"
+            rad3, intr3, xj3, ij3 = ops.vm_app_primary(f, xyz, lidx, rec_ray, 0.01, state, n_dev)
+        finally:
+            ops.APP_CONTRACTION = old_c
         assert torch.equal(xj3[:n_live], xj0[:n_live])
         for got, ref in ((rad3, rad0), (intr3, intr0), (ij3, ij0)):
             scale = float(ref[:n_live, :w].abs().max())
-            assert float((got[:n_live, :w] - ref[:n_live, :w]).abs().max()) < 5e-6 * max(scale, 1e-3), (n, scale)       # measured 2.1e-6
+            assert float((got[:n_live, :w] - ref[:n_live, :w]).abs().max()) < 5e-6 * scale + 1e-7, (n, scale)       # (fp16 residues of small products are subnormal: an absolute floor of ~5e-8)
             assert bool((got[:n_live, w:] == 0).all())
 
 

@@ -64,6 +64,27 @@ def test_trained_checkpoint_default_policy_vs_oracle():
     assert during["probes_run"] >= 3, during           # the self-check really ran while the parameters moved
 
 
+@pytest.mark.timeout(900)
+def test_checkpoint_trained_to_300_cubed_policy_and_oracle():
+    """the bench's grid, TRAINED (1200 iterations through the product API: two mask updates, shrink, four
+    up-samplings 128^3 -> 300^3, relighting losses on; the 2400-iteration run is profiles/r06_precision_trained_300.json).  Whatever
+    the auto policy decides on it -- the full-length run rejects the fp16 kernels (4.4e-5 against the full kernels) and takes the
+    high-precision fused kernel (6e-6) -- the decided render stays within the policy's limit of the full kernels, and every map is
+    < 1e-4 from the oracle on both metrics."""
+    r = P.trained_300(1200)
+    assert r.model.alphaMask is not None and tuple(r.grids[-1]) == (300, 300, 300) and len(r.grids) == 5
+    res, rep = P.trained_case(r, n_rays=4096, stride=16)
+    dec = res["decision"]
+    REPORT["trained to 300^3"] = {"policy": _slim(res), "oracle": rep, "during_training": r.model.indirect_precision(),
+                                   "psnr_last10": float(-10 * torch.log10(torch.tensor(r.losses[-10:]).mean()))}
+    assert rep["n_hit"] > 100, rep
+    _check_oracle("trained to 300^3", rep)
+    assert dec["policy"] == "auto" and dec["mode"] in ("f16", "hp", "full") and dec["why"] == "probe", dec
+    assert res["auto_vs_full_max_abs"] <= POLICY_TOL, _slim(res)
+    if dec["mode"] != "f16":             # the fp16 kernels were measured and rejected; hp was measured next
+        assert dec["probe"]["f16"]["map_max_abs"] > POLICY_TOL and (dec["mode"] == "hp") == (dec["probe"]["map_max_abs"] <= POLICY_TOL), dec
+
+
 @pytest.mark.parametrize("cfg", P.SWEEP, ids=[c["name"] for c in P.SWEEP])
 def test_adversarial_scaling(cfg):
     res, rep = P.sweep_case(cfg, oracle_rays=128 if cfg.get("oracle", True) else 0)

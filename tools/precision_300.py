@@ -20,18 +20,13 @@ sys.path.insert(0, ROOT)
 
 
 def schedule(n_iters):
-    """Mask updates / up-samplings of train_tensoIR.py's default schedule (10k/15k masks, 10k..40k up-samplings of 80k)
-    compressed into n_iters, leaving the last 30 % at the final grid."""
-    f = n_iters / 2400.0
-    return dict(mask_updates=(int(500 * f), int(800 * f)), upsamp=tuple(int(x * f) for x in (600, 900, 1200, 1500)))
+    from tests.precision_cases import schedule_300
+    return schedule_300(n_iters)
 
 
 def train(n_iters, batch, views, res):
-    from tests.train_sequence import reconstruct
-    s = schedule(n_iters)
-    with contextlib.redirect_stdout(io.StringIO()):
-        return reconstruct("single_light", n_iters=n_iters, batch=batch, dataset=f"synthetic:views={views},res={res}", grid0=128, grid1=300,
-                           model_kw=dict(envmap_h=8, envmap_w=16), **s)
+    from tests.precision_cases import trained_300
+    return trained_300(n_iters, batch, views, res)
 
 
 def stats(a, b):
