@@ -241,10 +241,11 @@ class GraphedRenderer:
             if defer_check:
                 self._deferred += 1
                 return dict(self.out) if not clone_outputs else _clone_grouped(self.out)
+            # the copies are queued BEFORE the host waits for the capacity check: nothing is launched behind the wait (a copy made
+            # of an overflowed replay is simply dropped)
+            res = _clone_grouped(self.out) if clone_outputs else dict(self.out)
             if not self._overflowed():
-                if not clone_outputs:
-                    return dict(self.out)
-                return _clone_grouped(self.out)
+                return res
             self._clear_sticky()
             self.graph = None                            # capacity too small for this batch: re-capture with room
         raise TensoirHipError("record capacity kept overflowing while re-capturing the HIP graph")
