@@ -266,8 +266,8 @@ int tir_indirect_fused_fwd(const TirField* f, const TirFieldHalf* fh, const TirM
  * launch at the precision a TRAINED checkpoint needs (the auto policy's fallback when its self-check rejects the fp16 kernel;
  * before round 6 that fallback was tir_vm_app_fwd + tir_mlp_fwd_auxtab_bf16x3 with the feature rows through HBM): fp32 taps from
  * the parameters themselves (no shadow), fp32 interpolation, basis_mat contraction on fp16 hi + lo operands (three products),
- * decoder with fp16 activations and weights as fp16 + fp8 residue (tir_pack_mlp's OFF_F8 image; fp32 accumulation, layer 3
- * exact).  Arguments as tir_indirect_fused_fwd without the shadow.  Deviation from the exact decoder on rgb_with_brdf_map:
+ * decoder with fp16 activations and weights as fp16 + fp8 residue (tir_pack_mlp's OFF_F8 image, multiplied on the block-scaled
+ * fp8 matrix instruction with the scale 2^-17 into the same fp32 accumulators; layer 3 exact).  n_lights <= 8.  Arguments as tir_indirect_fused_fwd without the shadow.  Deviation from the exact decoder on rgb_with_brdf_map:
  * measured per checkpoint by the policy's self-check (profiles/r06_*). */
 int tir_indirect_fused_hp_fwd(const TirField* f, const TirMlp* m, const float* xyz, const int32_t* light_idx,
                               const int32_t* rec_map, int32_t idx_div, int32_t aux_mod, const float* table, float* out,

@@ -90,13 +90,17 @@ constexpr int OFF_FF = OFF_FH + FH_FLOATS;
 // while the rounding of the activations averages out (profiles/r06_decoder_precision_probe.json: 1.8e-5 with fp16 weights
 // whatever the activations' precision, 6.6e-6 with the weights as hi + lo and fp16 activations).  The residue needs only a few
 // bits: |W - fp16(W)| <= 2^-11 |W|, so 2^17 x residue < 448 for |W| < 7 (saturating beyond), four significant bits of it give the
-// weights 15 bits, and its product with the activations runs on v_mfma_f32_32x32x16_fp8_fp8 into a second accumulator set that
-// is folded in with the factor 2^-17 -- half the LDS of a second fp16 plane (a full hi + lo image does not fit next to the
-// gather's tiles).
-constexpr int F8_W0_BYTES = BW0A_ELEMS, F8_W1_BYTES = BW1_ELEMS;          // 18,432 + 16,384 B
+// weights 15 bits, and its product with the activations runs on the fp8 matrix pipe -- half the LDS of a second fp16 plane (a full
+// hi + lo image does not fit next to the gather's tiles).
+// Element order (round 6, second form): the residue product runs on the block-scaled fp8 instruction, K = 64 per issue
+// (v_mfma_scale_f32_32x32x64_f8f6f4 with the A scale 2^-17: it accumulates STRAIGHT into the fp16 product's accumulators -- no
+// second accumulator set, no fold).  A lane's A operand is 32 consecutive bytes = its 8 slots of four consecutive k-blocks:
+// byte ((((j 2 + h) 4 + mt) 32 + row) 32 + (kb % 4) 8 + e) of the layer's section, j = kb / 4 (layer 1: 9 k-blocks padded to 12).
+constexpr int F8_G0 = (KB0A + 3) / 4, F8_G1 = KB1 / 4;                  // groups of four k-blocks: 3, 2
+constexpr int F8_W0_BYTES = F8_G0 * 2 * 4 * 32 * 32, F8_W1_BYTES = F8_G1 * 2 * 4 * 32 * 32;          // 24,576 + 16,384 B
 constexpr int F8_FLOATS = (F8_W0_BYTES + F8_W1_BYTES) / 4;
 constexpr int OFF_F8 = OFF_FF + FH_FLOATS;
-constexpr float F8_SCALE = 131072.0f, F8_INV = 1.0f / 131072.0f;        // 2^17
+constexpr float F8_SCALE = 131072.0f;        // 2^17 (undone by the E8M0 scale 110 = 2^-17 of the matrix instruction)
 constexpr int TOTAL_FLOATS = OFF_F8 + F8_FLOATS;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -181,10 +185,11 @@ __global__ void k_pack_mlp(const float* __restrict__ w0, const float* __restrict
             int idx = (i - OFF_F8) * 4 + t;
             const bool l2 = idx >= F8_W0_BYTES;
             if (l2) idx -= F8_W0_BYTES;
-            const int e = idx % 8, ii = (idx / 8) % 32, mt = (idx / 256) % 4, h = (idx / 1024) % 2, kb = idx / 2048;
-            const int kk = kb * 8 + e;
+            const int e = idx % 8, kl = (idx / 8) % 4, ii = (idx / 32) % 32, mt = (idx / 1024) % 4, h = (idx / 4096) % 2, jg = idx / 8192;
+            const int kb = jg * 4 + kl, kk = kb * 8 + e;
             float wv;
             if (l2) wv = w1[(mt * 32 + ii) * HID + unit_of(kk, h)];
+            else if (kb >= KB0A) wv = 0.0f;                                   // padding k-blocks of the last group
             else { const int in = kperm_f(kk, h); wv = in >= 0 ? w0[(mt * 32 + ii) * IN + in] : 0.0f; }
             const float r = (wv - (float)(_Float16)wv) * F8_SCALE;
             lo[t] = __builtin_amdgcn_fmed3f(r, -448.0f, 448.0f);
@@ -1095,10 +1100,10 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
 //     x = hi + lo in fp16, and are contracted with basis_mat (hi + lo as well) by three v_mfma_f32_32x32x16_f16 per chunk
 //     (hi hi + lo hi + hi lo: ~2^-21 relative per product) -- the features are fp32-grade;
 //   * the decoder reads its activations as fp16 (their rounding is random and averages out over a ray's records and the light
-//     directions) but its WEIGHTS as fp16 + an fp8 residue (F8 image, see OFF_F8): the residue product runs on the fp8 matrix
-//     instruction into a second accumulator set, folded in with 2^-17.  Layer 3 exact as everywhere.
-// LDS: fp16 decoder image (72.9 KB) | fp8 residue image (34.8 KB) | basis_mat^T hi / lo fp16 tiles (18.4 KB) | light rows fp32 |
-// NW x 3 KB product tiles = 151.8 KB with 8 waves (two per SIMD, <= 256 VGPRs).
+//     directions) but its WEIGHTS as fp16 + an fp8 residue (F8 image, see OFF_F8): the residue product runs on the block-scaled fp8
+//     matrix instruction (K = 64, A scale 2^-17) straight into the same accumulators.  Layer 3 exact as everywhere.
+// LDS: fp16 decoder image (72.9 KB) | fp8 residue image (41.0 KB) | basis_mat^T hi / lo fp16 tiles (18.4 KB) | light rows fp32 |
+// NW x 3 KB product tiles = 157.9 KB with 8 waves (two per SIMD, <= 256 VGPRs).
 // ------------------------------------------------------------------------------------------------
 constexpr int HP_XS = 24;                                    // product-tile row stride in halves (16 channels + 8 pad: 48 B)
 constexpr int HP_X_HALVES = 2 * 32 * HP_XS;                  // hi tile + lo tile of one wave
@@ -1127,17 +1132,29 @@ __device__ __forceinline__ float fus_input8(const float (&fo)[16], const float (
     else return fus_input<KK>(fo);
 }
 
-// layer 1 of the high-precision decoder, k-block KB: fp16 product into acc, fp8 residue product into corr
-template <int KB>
-__device__ __forceinline__ void hp_layer1(unsigned whi, unsigned w8, const float (&fo)[16], const float (&fo8)[16], f32x16 (&acc)[4],
-                                          f32x16 (&corr)[4]) {
-    bf16x8 ah[4];
-    long a8[4];
+typedef int hp_i32x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) const u32x4_t lds_u32x4;
+
+// the residue product of one group of four k-blocks: A = 32 bytes per lane from the F8 image (two 16-byte LDS reads), B = the
+// lane's 32 fp8 activations of those k-blocks, A scaled by 2^-17 (E8M0 exponent 110), accumulated into the main accumulators
+__device__ __forceinline__ void hp_residue(unsigned w8, int byte_off, const hp_i32x8& xs, f32x16 (&acc)[4]) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        ah[mt] = lds_tile(whi, KB * 4096 + mt * 512);
-        a8[mt] = lds_tile8(w8, KB * 2048 + mt * 256);
+        const u32x4_t lo = *reinterpret_cast<lds_u32x4*>(w8 + (unsigned)(byte_off + mt * 1024));
+        const u32x4_t hi = *reinterpret_cast<lds_u32x4*>(w8 + (unsigned)(byte_off + mt * 1024 + 16));
+        const hp_i32x8 a = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        acc[mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, xs, acc[mt], 0, 0, 0, 110, 0, 127);
     }
+}
+
+// layer 1 of the high-precision decoder, k-block KB: fp16 product into acc; the fp8 activations of the block are parked in xs and
+// every fourth block (and the last) the residue product of the group follows into the same accumulators
+template <int KB>
+__device__ __forceinline__ void hp_layer1(unsigned whi, unsigned w8, const float (&fo)[16], const float (&fo8)[16], f32x16 (&acc)[4],
+                                          hp_i32x8& xs) {
+    bf16x8 ah[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) ah[mt] = lds_tile(whi, KB * 4096 + mt * 512);
     const float v[8] = {fus_input<KB * 8 + 0>(fo), fus_input<KB * 8 + 1>(fo), fus_input<KB * 8 + 2>(fo), fus_input<KB * 8 + 3>(fo),
                         fus_input<KB * 8 + 4>(fo), fus_input<KB * 8 + 5>(fo), fus_input<KB * 8 + 6>(fo), fus_input<KB * 8 + 7>(fo)};
     const float v8[8] = {fus_input8<KB * 8 + 0>(fo, fo8), fus_input8<KB * 8 + 1>(fo, fo8), fus_input8<KB * 8 + 2>(fo, fo8), fus_input8<KB * 8 + 3>(fo, fo8),
@@ -1145,35 +1162,35 @@ __device__ __forceinline__ void hp_layer1(unsigned whi, unsigned w8, const float
     bf16x8 xh;
     cvt8_f16(v, xh);
     const long x8 = cvt8_fp8(v8);
+    if constexpr (KB % 4 == 0) xs = hp_i32x8{0, 0, 0, 0, 0, 0, 0, 0};       // (padding blocks of the last group: zero activations)
+    xs[2 * (KB % 4)] = (int)(unsigned)(unsigned long)x8;
+    xs[2 * (KB % 4) + 1] = (int)(unsigned)((unsigned long)x8 >> 32);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[mt]), __builtin_bit_cast(f16x8, xh), acc[mt], 0, 0, 0);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) corr[mt] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a8[mt], x8, corr[mt], 0, 0, 0);
+    if constexpr (KB % 4 == 3 || KB + 1 == KB0A) hp_residue(w8, (KB / 4) * 8192, xs, acc);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (KB + 1 < KB0A) hp_layer1<KB + 1>(whi, w8, fo, fo8, acc, corr);
+    if constexpr (KB + 1 < KB0A) hp_layer1<KB + 1>(whi, w8, fo, fo8, acc, xs);
 }
 
 // layer 2 from packed activations: hp[p] = fp16 pair, h8[p] = fp8 quad of relu(h) in accumulator order
 template <int KB>
-__device__ __forceinline__ void hp_layer2(unsigned whi, unsigned w8, const unsigned (&hp)[32], const unsigned (&h8)[16],
-                                          f32x16 (&acc)[4], f32x16 (&corr)[4]) {
+__device__ __forceinline__ void hp_layer2(unsigned whi, unsigned w8, const unsigned (&hp)[32], const unsigned (&h8)[16], f32x16 (&acc)[4]) {
     bf16x8 ah[4];
-    long a8[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        ah[mt] = lds_tile(whi, KB * 4096 + mt * 512);
-        a8[mt] = lds_tile8(w8, KB * 2048 + mt * 256);
-    }
+    for (int mt = 0; mt < 4; ++mt) ah[mt] = lds_tile(whi, KB * 4096 + mt * 512);
     const u32x4_t H = {hp[4 * KB], hp[4 * KB + 1], hp[4 * KB + 2], hp[4 * KB + 3]};
-    const long x8 = (long)(((unsigned long)h8[2 * KB + 1] << 32) | (unsigned long)h8[2 * KB]);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[mt]), __builtin_bit_cast(f16x8, H), acc[mt], 0, 0, 0);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) corr[mt] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a8[mt], x8, corr[mt], 0, 0, 0);
+    if constexpr (KB % 4 == 3) {
+        constexpr int g = KB / 4;
+        const hp_i32x8 xs = {(int)h8[8 * g], (int)h8[8 * g + 1], (int)h8[8 * g + 2], (int)h8[8 * g + 3],
+                             (int)h8[8 * g + 4], (int)h8[8 * g + 5], (int)h8[8 * g + 6], (int)h8[8 * g + 7]};
+        hp_residue(w8, g * 8192, xs, acc);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (KB + 1 < KB1) hp_layer2<KB + 1>(whi, w8, hp, h8, acc, corr);
+    if constexpr (KB + 1 < KB1) hp_layer2<KB + 1>(whi, w8, hp, h8, acc);
 }
 
 // Per record: the taps of the three axes (computed ONCE, shared by the two planes and the line that use each axis -- the
@@ -1293,8 +1310,8 @@ k_indirect_fused_hp(TirField f, const float* __restrict__ packed, const float* _
     const unsigned lane_off = lds0 + BH_FLOATS * 4 + (unsigned)(h * 128 + sl) * 16;
     const unsigned w0hi = opaque(lane_off);
     const unsigned w1hi = opaque(lane_off + BW0A_ELEMS * 2);
-    const unsigned w0f8 = opaque(lds0 + FH_BYTES + (unsigned)(h * 128 + sl) * 8);
-    const unsigned w1f8 = opaque(lds0 + FH_BYTES + F8_W0_BYTES + (unsigned)(h * 128 + sl) * 8);
+    const unsigned w0f8 = opaque(lds0 + FH_BYTES + (unsigned)(h * 4096 + sl * 32));
+    const unsigned w1f8 = opaque(lds0 + FH_BYTES + F8_W0_BYTES + (unsigned)(h * 4096 + sl * 32));
     constexpr int TILE = NW * 32;
     const int64_t n_tiles = (n + TILE - 1) / TILE;
     const UDiv by_div = make_udiv(idx_div), by_mod = make_udiv(aux_mod);
@@ -1322,7 +1339,7 @@ k_indirect_fused_hp(TirField f, const float* __restrict__ packed, const float* _
         f32x16 facc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) facc[r] = 0.0f;
-        f32x16 acc[4], corr[4];
+        f32x16 acc[4];
         auto load_table = [&]() {       // layer 1 starts from the aux-table row of the record's direction (sixteen 16-byte loads per lane)
             const float* tp = table + (size_t)ai * HID + 4 * h;
 #pragma unroll
@@ -1370,21 +1387,19 @@ k_indirect_fused_hp(TirField f, const float* __restrict__ packed, const float* _
         float fo[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) fo[r] = __builtin_amdgcn_fmed3f(facc[r], -65504.0f, 65504.0f);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) corr[mt][r] = 0.0f;
         float fo8[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) fo8[r] = __builtin_amdgcn_fmed3f(fo[r], -448.0f, 448.0f);
-        hp_layer1<0>(w0hi, w0f8, fo, fo8, acc, corr);
+        {
+            hp_i32x8 xs;
+            hp_layer1<0>(w0hi, w0f8, fo, fo8, acc, xs);
+        }
         unsigned hp[32], h8[16];
 #pragma unroll
         for (int q = 0; q < 64; q += 4) {
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                v[e] = __builtin_amdgcn_fmed3f(fmaf(corr[(q + e) >> 4][(q + e) & 15], F8_INV, acc[(q + e) >> 4][(q + e) & 15]), 0.0f, 65504.0f);
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(acc[(q + e) >> 4][(q + e) & 15], 0.0f, 65504.0f);
             const f32x2_t v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
             hp[q >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(v01, fus_f16x2));
             hp[(q >> 1) + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(v23, fus_f16x2));
@@ -1398,9 +1413,9 @@ k_indirect_fused_hp(TirField f, const float* __restrict__ packed, const float* _
         for (int mt = 0; mt < 4; ++mt) {
             const float* bp = lds + BH_B1 + (h * 4 + mt) * 16;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc2[mt][r] = bp[r]; corr[mt][r] = 0.0f; }
+            for (int r = 0; r < 16; ++r) acc2[mt][r] = bp[r];
         }
-        hp_layer2<0>(w1hi, w1f8, hp, h8, acc2, corr);
+        hp_layer2<0>(w1hi, w1f8, hp, h8, acc2);
         f32x4 o4[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) o4[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1413,7 +1428,7 @@ k_indirect_fused_hp(TirField f, const float* __restrict__ packed, const float* _
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int q = 4 * g + e;
-                    const float x = fmaf(corr[q >> 4][q & 15], F8_INV, acc2[q >> 4][q & 15]);
+                    const float x = acc2[q >> 4][q & 15];
                     o4[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[e], x + __builtin_fabsf(x), o4[e], 0, 0, 0);
                 }
             }
@@ -2653,7 +2668,7 @@ extern "C" int tir_indirect_fused_hp_fwd(const TirField* f, const TirMlp* m, con
     if (reinterpret_cast<uintptr_t>(table) % 16 != 0) return TIR_ERR_ARG;
     if (n == 0) return TIR_OK;
     if (n >= (int64_t)1 << 31 || idx_div < 0 || aux_mod < 0) return TIR_ERR_UNSUPPORTED;       // 32-bit record / ray arithmetic in the kernel
-    if (f->n_lights < 1 || f->n_lights > 16) return TIR_ERR_UNSUPPORTED;       // every light row is staged in LDS (576 B each; 16 rows: 159.9 KB in all)
+    if (f->n_lights < 1 || f->n_lights > 8) return TIR_ERR_UNSUPPORTED;        // every light row is staged in LDS (576 B each; 8 rows: 158.2 KB in all)
     const int lt_rows = f->n_lights;
     constexpr int NW = 8;
     const size_t lds = (size_t)FH_BYTES + (size_t)F8_FLOATS * 4 + 2 * (size_t)FUS_WH_BYTES + (size_t)lt_rows * 144 * sizeof(float) +

@@ -594,7 +594,7 @@ def full_indirect_route():
 
 def hp_indirect_route():
     return ("tir_indirect_fused_hp_fwd: fp32 taps, fp16 hi + lo basis contraction, decoder with fp16 activations and fp16 + fp8-residue "
-            "weights, one launch, feature rows in registers")
+            "weights (residue on the block-scaled fp8 matrix instruction), one launch, feature rows in registers")
 
 
 def secondary_app_impl():

@@ -204,7 +204,7 @@ def _secondary(tensoIR, origins, dirs, n_rays, z, org_map, dir_map, active, ligh
                 if kind == "f16" and fh is not None and fusable and ops.fused_indirect() and int(f.n_lights) <= 16:
                     # gather -> basis contraction -> radiance decoder in ONE launch, the feature rows never reach HBM
                     return ops.indirect_fused(f, fh, tensoIR.renderModule.packed(), rec_xyz, light_idx, rec_ray, light_div, dirs, n_dirs, n_dev)
-                if kind == "hp" and fusable and ops.AUX_TABLE and ops.MLP_IMPL == "bf16x3" and int(f.n_lights) <= 16:
+                if kind == "hp" and fusable and ops.AUX_TABLE and ops.MLP_IMPL == "bf16x3" and int(f.n_lights) <= 8:
                     return ops.indirect_fused_hp(f, tensoIR.renderModule.packed(), rec_xyz, light_idx, rec_ray, light_div, dirs, n_dirs, n_dev)
                 return _gather_then_decode(tensoIR, f, fh, rec_xyz, light_idx, rec_ray, light_div, dirs, dir_map, n_dirs, n_dev,
                                            full=kind != "f16")
