@@ -29,23 +29,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-L2_PEAK_GBS = 34500.0          # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate over the 8 XCDs = 256 CUs x 64 B/clk: also the
-                               # rate at which the vector L1s can be filled, the bound of the ray-coherent gathers
-GATHER_BENCH_TAPS = 157e9      # tools/gather_bench.hip (profiles/r01_v5_gather_bench.txt): 192-B taps/s when
-                               # consecutive samples share cells -- the measured ceiling of this access pattern
-F32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
-BF16_MFMA_PEAK_TF = 2500.0     # v_mfma_f32_32x32x16_bf16 / _f16 dense peak
-# VALU issue ceiling: 256 CUs x 4 SIMDs, one wave64 VALU instruction per SIMD every 4 cycles at the 2.4 GHz peak shader clock
-VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 4.0
-# the density gather's arithmetic floor: 3 planes x 16 channels x 7 FMAs per valid sample (4 bilinear + 2 line + 1 product-sum,
-# DESIGN 4.1) = 336 lane operations = 5.25 wave64 instructions per sample (84 per 16-sample gather pass)
-VALU_FLOOR_PER_DENSITY_SAMPLE = 3 * 16 * 7 / 64.0
-# algorithmic bytes per unit of work ("gather-bytes model")
-B_DENSITY_SAMPLE = 1184        # occupancy 8x4 + planes 3x4x16x4 + lines 3x2x16x4
-B_APP_GATHER = 3456            # planes 3x4x48x4 + lines 3x2x48x4
-B_APP_GATHER_H16 = 1728        # the same 18 taps from the fp16 shadow (indirect-light precision policy)
-SETTLE_STEPS = 300             # untimed clock-settle steps before the --warmup steps (stated in the JSON as `settle_steps`)
+# the workloads live in benchlib/ (round 6 split); every name stays reachable as bench.<name> for tests and tools
+from benchlib.common import *  # noqa: E402,F401,F403
+from benchlib.image import bench_image, sharp_scene_line, simulate_ranks  # noqa: E402,F401
+from benchlib.relight import bench_relight, synthetic_hdr_maps  # noqa: E402,F401
+from benchlib.train import (ATOMIC_SEGMENTS_PER_S, FIELD_TENSORS, TRAIN_W, _to_fp64, atomic_segments_after_combining, bench_train,  # noqa: E402,F401
+                            grad_deviation, single_ray_bisect, train_loss, train_parity_and_cpu)
 
 
 def parse():
@@ -103,1351 +92,6 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="single process: create a 1-rank RCCL group anyway and run the multi-rank code path (all-gather per step)")
     return ap.parse_args()
-
-
-def pose_batches(rays, n, rank=0):
-    """`n` distinct ray batches from the base camera batch: the camera orbits the object (azimuth about y, elevation about x;
-    the pose sequence of every rank starts at another angle), same pin-hole, same distance.  The synthetic blob is isotropic
-    (SURVEY 8d), so every pose still sees the whole object; what changes from batch to batch is where the rays walk through
-    the field's planes / lines, the occupancy box and the secondary rays' directions relative to the fixed light grid."""
-    import math
-    out = []
-    for k in range(n):
-        az = 2.0 * math.pi * (k + 0.37 * rank) / max(n, 1)
-        el = 0.35 * math.sin(1.7 * (k + rank))
-        if k == 0 and rank == 0:
-            out.append(rays.clone())                   # batch 0 of rank 0 = the canonical SURVEY 8d camera
-            continue
-        ca, sa, ce, se = math.cos(az), math.sin(az), math.cos(el), math.sin(el)
-        Ry = torch.tensor([[ca, 0.0, sa], [0.0, 1.0, 0.0], [-sa, 0.0, ca]])
-        Rx = torch.tensor([[1.0, 0.0, 0.0], [0.0, ce, -se], [0.0, se, ce]])
-        R = (Ry @ Rx).to(rays.dtype)
-        d = rays[:, 3:] @ R.T
-        out.append(torch.cat([rays[:, :3] @ R.T, d / d.norm(dim=-1, keepdim=True)], dim=-1).contiguous())
-    return out
-
-
-def build_scene(a, device, rank, **blob):
-    import tensoir_amd
-    from tensoir_amd import synth
-    ckpt = synth.make_checkpoint(grid=(a.grid,) * 3, seed=20211202, **blob)
-    model = tensoir_amd.model_from_checkpoint(ckpt, device, envmap_h=a.env_h, envmap_w=a.env_w)
-    with torch.no_grad():
-        import contextlib, io
-        with contextlib.redirect_stdout(io.StringIO()):
-            model.updateAlphaMask((128, 128, 128))
-    side = int(round(a.rays ** 0.5))
-    rays = synth.make_rays(side, a.rays // side)
-    rays = rays.to(device).contiguous()
-    lidx = torch.zeros(rays.shape[0], 1, dtype=torch.int32, device=device)
-    return ckpt, model, rays, lidx
-
-
-# entry points that launch the same kernel as another one (same roofline model, same PMC key)
-ALIAS = {"tir_march_secondary_ids_fwd": "tir_march_secondary_fwd", "tir_shade_integrate_records": "tir_shade_integrate",
-         # one launch for the primary stage's four decoders: the same device code (mlp_bf16_body) as the single-decoder launch
-         "tir_mlp_fwd_multi_bf16x3": "tir_mlp_fwd_bf16x3",
-         # the aux-table variants of both (view-direction columns folded into a per-direction accumulator start, 9 k-blocks):
-         # same decoder, same useful FLOPs per row
-         "tir_mlp_fwd_auxtab_bf16x3": "tir_mlp_fwd_bf16x3", "tir_mlp_fwd_multi_auxtab_bf16x3": "tir_mlp_fwd_bf16x3",
-         # the primary stage's two appearance gathers in one launch: app_mfma_body twice, the grid split between them
-         "tir_vm_app_primary_fwd": "tir_vm_app_fwd", "tir_vm_app_jitter_fwd": "tir_vm_app_fwd"}
-# rocprofv3 kernel names behind each row (the trace under profiles/ lists these)
-ROCPROF_KERNELS = {
-    "tir_mlp_fwd_bf16x3": ["k_mlp_bf16_multi<3> (the four primary-stage decoders in one launch)",
-                           "k_mlp_bf16_auxt<true, false> (one decoder with the aux table; the secondary-ray records when the indirect "
-                           "precision policy is `full`)"],
-    "tir_mlp_fwd_auxtab_f16": ["k_mlp_f16_auxt<true> (radiance decoder of the secondary-ray records, single-product fp16)"],
-    "tir_vm_app_fwd_h16": ["k_vm_app_h16 (radiance features of the secondary-ray records from the fp16 shadow planes)"],
-    "tir_indirect_fused_fwd": ["k_indirect_fused (secondary-ray records: fp16-shadow gather + basis contraction + fp16 radiance decoder in one pass)"],
-    "tir_vm_app_fwd": ["k_vm_app_primary<12> (primary stage: records + jittered records)", "k_vm_app_mfma<12, ...> (fp32 gather)"],
-    "tir_march_secondary_fwd": ["k_march_secondary_lds<4, 3, 512>"],
-    "tir_march_primary_fwd": ["k_march_primary"],
-}
-
-
-def event_bracket_overhead_ms(device, n=300):
-    """What a (record, one-workgroup launch, record) bracket of ops._call reads when the kernel between the events is
-    (next to) empty: the events' own cost on the stream.  Subtracted from every bracketed launch below, so that the sum of
-    the per-kernel durations does not exceed the one-stream step and agrees with a rocprofv3 kernel trace (round 2: the
-    raw brackets summed to 8 % more than the step).  The probe kernel's own ~2 us ride along, i.e. the corrected durations
-    are low by at most that."""
-    from tensoir_amd import ops
-    probe = torch.zeros(64, dtype=torch.int32, device=device)
-    for _ in range(20):
-        ops.exclusive_scan(probe)
-    old, ops.TIMING = ops.TIMING, []
-    for _ in range(n):
-        ops.exclusive_scan(probe)
-    torch.cuda.synchronize()
-    ts = sorted(e0.elapsed_time(e1) for _, e0, e1 in ops.TIMING)
-    ops.TIMING = old
-    return ts[len(ts) // 2]
-
-
-def kernel_table(timing, stats, steps, shapes, overhead_ms=0.0):
-    """Aggregate (name, e0, e1) event pairs into per-kernel totals and roofline figures.  Every roofline row carries an
-    INDEPENDENT ceiling (a hardware rate from MI355X_MICROARCH.md times the algorithm's own work per unit), so frac <= 1."""
-    agg = {}
-    for name, e0, e1 in timing:
-        name = ALIAS.get(name, name)
-        ms = max(e0.elapsed_time(e1) - overhead_ms, 1e-4)
-        k = agg.setdefault(name, {"ms": 0.0, "launches": 0})
-        k["ms"] += ms
-        k["launches"] += 1
-    rows = []
-    for name, k in agg.items():
-        avg_ms = k["ms"] / k["launches"]
-        sec = avg_ms * 1e-3
-        row = {"kernel": name, "launches_per_step": k["launches"] / steps, "avg_ms": avg_ms,
-               "ms_per_step": k["ms"] / steps}
-        units = shapes.get(name)
-        if name in ("tir_march_primary_fwd", "tir_march_secondary_fwd") and stats and name in stats:
-            gathered = int(stats[name].item()) / (k["launches"] / steps)      # counters come from ONE step
-            extra = units["io_bytes"] if units else 0
-            by = gathered * B_DENSITY_SAMPLE + extra
-            # The 70 MB field is cache resident and the march is bound by VALU issue (PMC: SQ_ACTIVE_INST_VALU), so the ceiling
-            # is the VALU issue rate over the FMAs the algorithm needs per valid sample -- not a memory level.
-            peak = VALU_PEAK_WAVE_INSTR / VALU_FLOOR_PER_DENSITY_SAMPLE / 1e9
-            row.update(bound="valu", units=gathered, unit="valid density samples/launch", gather_bytes=by,
-                       achieved=gathered / sec / 1e9, peak=round(peak, 2), runit="G valid density samples/s",
-                       gather_GBps=by / sec / 1e9)
-        elif name in ("tir_vm_app_fwd", "tir_vm_app_fwd_h16", "tir_indirect_fused_fwd") and units and units["n"] > 0:
-            per = B_APP_GATHER if name == "tir_vm_app_fwd" else B_APP_GATHER_H16
-            by = units["n"] / k["launches"] * (per + units["out_bytes"])
-            row.update(bound="l2", units=units["n"] / k["launches"], unit="appearance gathers/launch", gather_bytes=by,
-                       achieved=by / sec / 1e9, peak=L2_PEAK_GBS, runit="GB/s", taps_per_s=units["n"] / k["launches"] * 18 / sec)
-            if name == "tir_indirect_fused_fwd":       # the fused kernel also carries the decoder's matrix work: second reading
-                row["decoder_TFLOPs"] = units["flops"] / k["launches"] / sec / 1e12
-                row["decoder_frac_of_dense_fp16_peak"] = row["decoder_TFLOPs"] / BF16_MFMA_PEAK_TF
-        elif name.startswith("tir_mlp_fwd") and units and units["n"] > 0:
-            fl = units["flops"] / k["launches"]
-            # split-bf16 issues 3 bf16 MFMAs per fp32-equivalent product: price it against the dense bf16 peak / 3; the
-            # single-product fp16 decoder against the dense peak itself; the exact decoder against the fp32 MFMA peak
-            peak = F32_MFMA_PEAK_TF if name == "tir_mlp_fwd" else (BF16_MFMA_PEAK_TF if name.endswith("_f16") else BF16_MFMA_PEAK_TF / 3.0)
-            row.update(bound="mfma", units=units["n"] / k["launches"], unit="decoder rows/launch",
-                       achieved=fl / sec / 1e12, peak=round(peak, 1), runit="TFLOP/s")
-        if "achieved" in row:
-            row["frac"] = row["achieved"] / row["peak"]
-        rows.append(row)
-    rows.sort(key=lambda r: -r["ms_per_step"])
-    return rows
-
-
-def attribute_kernels(run_eager, psteps, io_primary, io_secondary, device, stat_steps=1):
-    """Per-kernel attribution of the inference path: `run_eager()` issues one eager pass (every C call bracketed by events on
-    the launch stream, ops.TIMING); the ops wrappers are instrumented to count the rows each gather / decoder launch really
-    processed (device-side counts), one extra pass reads the counters of gathered density samples.  Returns
-    (rows, gpu_ms_per_step, event_overhead_ms)."""
-    from tensoir_amd import ops
-    # ---- per-kernel attribution: pass 1 brackets every C call with events on the launch stream (no counters),
-    #      pass 2 (one step) reads the device-side counters of gathered density samples ------------------
-    ops.TIMING, ops.STATS = [], None
-    # rows actually processed: min(buffer rows, device-side count) -- the counts are read back after the pass; keyed by the
-    # entry point that really runs (the indirect-light policy sends the secondary records to the h16 gather / f16 decoder)
-    pending = []
-    DEC = lambda o: 2 * (150 * 128 + 128 * 128 + 128 * o)          # useful FLOPs of one decoder row
-    orig = {k: getattr(ops, k) for k in ("vm_app", "vm_app_h16", "mlp", "vm_app_primary", "vm_app_jitter", "mlp_multi", "indirect_fused")}
-
-    def fused_wrap(field, fh, m, xyz, light_idx, rec_map, idx_div, dirs, n_dirs, n_dev=None):
-        pending.append(("tir_indirect_fused_fwd", xyz.shape[0], n_dev, 4 * m.out_dim, DEC(m.out_dim)))
-        return orig["indirect_fused"](field, fh, m, xyz, light_idx, rec_map, idx_div, dirs, n_dirs, n_dev)
-
-    def app_wrap(field, xyz, *args, **kw):
-        n_dev = kw.get("n_dev", args[6] if len(args) > 6 else None)
-        want_rad = kw.get("want_rad", args[2] if len(args) > 2 else True)
-        want_int = kw.get("want_int", args[3] if len(args) > 3 else False)
-        pending.append(("tir_vm_app_fwd", xyz.shape[0], n_dev, 27 * 4 * (int(want_rad) + int(want_int)), 0))
-        return orig["vm_app"](field, xyz, *args, **kw)
-
-    def h16_wrap(field, fh, xyz, *args, **kw):
-        n_dev = kw.get("n_dev", args[3] if len(args) > 3 else None)
-        pending.append(("tir_vm_app_fwd_h16", xyz.shape[0], n_dev, 27 * 4, 0))
-        return orig["vm_app_h16"](field, fh, xyz, *args, **kw)
-
-    def mlp_wrap(m, feat, aux, aux_map=None, impl=None, aux_mod=0, n_dev=None):
-        impl_eff = impl or ops.MLP_IMPL
-        tabled = ops.AUX_TABLE and (aux_map is not None or aux_mod > 0) and aux.shape[0] * 8 <= max(feat.shape[0], 1)
-        key = "tir_mlp_fwd_auxtab_f16" if (impl_eff == "f16" and tabled) else ("tir_mlp_fwd" if impl_eff == "mfma" else "tir_mlp_fwd_bf16x3")
-        pending.append((key, feat.shape[0], n_dev, 0, DEC(m.out_dim)))
-        return orig["mlp"](m, feat, aux, aux_map, impl, aux_mod, n_dev)
-
-    def prim_wrap(field, xyz, *args, **kw):
-        n_dev = kw.get("n_dev", args[4] if len(args) > 4 else None)
-        pending.append(("tir_vm_app_fwd", xyz.shape[0], n_dev, 27 * 4 * 2, 0))              # records: radiance + intrinsic features
-        pending.append(("tir_vm_app_fwd", xyz.shape[0], n_dev, 27 * 4 + 12, 0))             # jittered records: intrinsic features + the points
-        return orig["vm_app_primary"](field, xyz, *args, **kw)
-
-    def jit_wrap(field, xyz, *args, **kw):
-        n_dev = kw.get("n_dev", args[4] if len(args) > 4 else None)
-        pending.append(("tir_vm_app_fwd", xyz.shape[0], n_dev, 27 * 4 + 12, 0))
-        return orig["vm_app_jitter"](field, xyz, *args, **kw)
-
-    def multi_wrap(jobs, n_dev=None):
-        for m, _, _, _ in jobs:
-            pending.append(("tir_mlp_fwd_bf16x3" if ops.MLP_IMPL != "mfma" else "tir_mlp_fwd", jobs[0][1].shape[0], n_dev, 0, DEC(m.out_dim)))
-        return orig["mlp_multi"](jobs, n_dev)
-
-    ops.vm_app, ops.vm_app_h16, ops.mlp = app_wrap, h16_wrap, mlp_wrap
-    ops.vm_app_primary, ops.vm_app_jitter, ops.mlp_multi = prim_wrap, jit_wrap, multi_wrap
-    ops.indirect_fused = fused_wrap
-    try:
-        for _ in range(psteps):
-            run_eager()
-        torch.cuda.synchronize()
-    finally:
-        for k, v in orig.items():
-            setattr(ops, k, v)
-    shapes = {"tir_march_primary_fwd": {"io_bytes": io_primary}, "tir_march_secondary_fwd": {"io_bytes": io_secondary}}
-    for key, rows_, n_dev, out_bytes, flops in pending:
-        n = rows_ if n_dev is None else min(rows_, int(n_dev.item()))
-        e = shapes.setdefault(key, {"n": 0, "out_total": 0.0, "flops": 0.0})
-        e["n"] += n
-        e["out_total"] += n * out_bytes
-        e["flops"] += n * flops
-    for e in shapes.values():
-        if "n" in e:
-            e["out_bytes"] = e["out_total"] / max(1, e["n"])
-    timing = ops.TIMING
-    ops.TIMING, ops.STATS = None, {}
-    for _ in range(stat_steps):                       # counters accumulate over the passes; kernel_table wants them per step
-        run_eager()
-    torch.cuda.synchronize()
-    stats = {k: v.clone() // stat_steps for k, v in ops.STATS.items()}
-    ops.STATS = None
-    ev_over = event_bracket_overhead_ms(device)
-    rows = kernel_table(timing, stats, psteps, shapes, ev_over)
-    return rows, sum(r["ms_per_step"] for r in rows), ev_over
-
-
-def library_info():
-    """Which library the numbers of this run come from: the source hash csrc/build.sh stamps next to the .so it links."""
-    p = os.path.join(ROOT, "tensoir_amd", "libtensoir_hip.so.srchash")
-    try:
-        h = open(p).read().strip()
-    except OSError:
-        h = None
-    return {"so": "tensoir_amd/libtensoir_hip.so", "source_hash": h,
-            "source_hash_of": "sha256 over every csrc/*.hip + tir_common.hpp + include/tensoir_hip.h + compiler flags (csrc/build.sh)"}
-
-
-def load_pmc():
-    """(bytes per launch, issue fractions, meta) from the separate rocprofv3 --pmc passes kept under profiles/ (tools/
-    tools/round_evidence.sh + tools/summarize_prof.py).  The files carry the source hash of the library they were collected with; when it
-    is not the library being timed now, every PMC-derived field of this run is marked `"stale": true`."""
-    out = []
-    for name in ("pmc_traffic.json", "pmc_issue.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        try:
-            out.append(json.load(open(path)))
-        except Exception:
-            out.append({})
-    lib = library_info()["source_hash"]
-    hashes = {d.get("_library_source_hash") for d in out if d}
-    meta = {"library_source_hash": sorted(h for h in hashes if h), "current_library": lib,
-            "stale": not (len(hashes) == 1 and lib is not None and lib in hashes),
-            "source": "profiles/pmc_traffic.json, profiles/pmc_issue.json (separate rocprofv3 --pmc passes of this command)"}
-    return out[0], out[1], meta
-
-
-def roofline_object(r, pmc_traffic, pmc_issue, pmc_meta=None):
-    """One roofline object: achieved / peak with an INDEPENDENT peak (frac <= 1 by construction).
-    bound 'mfma': useful decoder FLOPs vs the matrix-core ceiling of the operand scheme.
-    bound 'l2'  : the appearance gathers read a cache-resident field; the bounding resource is the fill rate of the vector
-                  L1s = the aggregate L2 bandwidth (256 CUs x 64 B/clk): gather bytes (SURVEY 8d model) / launch time vs 34.5 TB/s.
-    bound 'valu': the density march; PMC says VALU issue is the binding pipe, so the ceiling is the VALU issue rate over the
-                  FMAs the algorithm needs per valid sample; the PMC instruction count shows how much of the issued work is that.
-    The SURVEY 8d gather-bytes-over-HBM-peak figure is kept as the labelled `sec8d_hbm_model` (a ratio that exceeds 1 for a
-    cache-resident field -- NOT a roofline fraction), next to the counter-measured HBM traffic."""
-    stale = bool(pmc_meta and pmc_meta.get("stale"))
-    t = pmc_traffic.get(r["kernel"])
-    o = {"kernel": r["kernel"], "bound": r["bound"], "achieved": round(r["achieved"], 3),
-         "peak": r["peak"], "unit": r["runit"], "frac": round(r["frac"], 4),
-         "traffic": t, "avg_launch_ms": round(r["avg_ms"], 4),
-         "units_per_launch": round(r["units"], 1), "unit_of_work": r["unit"]}
-    if t is not None:
-        o["traffic_stale"] = stale
-    if r["kernel"] in ROCPROF_KERNELS:
-        o["rocprof_kernels"] = ROCPROF_KERNELS[r["kernel"]]
-    iss = pmc_issue.get(r["kernel"]) or {}
-    if r["bound"] in ("l2", "valu"):
-        gb = r.get("gather_GBps", r["achieved"]) if r["bound"] == "valu" else r["achieved"]
-        o["sec8d_hbm_model"] = {"gather_bytes_per_launch": round(r["gather_bytes"], 1), "gather_GBps": round(gb, 2),
-                                "hbm_peak_GBps": HBM_PEAK_GBS, "gather_GBps_over_hbm_peak": round(gb / HBM_PEAK_GBS, 3),
-                                "note": "SURVEY 8d gather-bytes model; the field is cache resident, so this ratio is "
-                                        "not bounded by 1 and is not a roofline fraction"}
-        if t:
-            o["hbm_traffic"] = {"bytes_per_launch": t, "GBps": round(t / (r["avg_ms"] * 1e-3) / 1e9, 2),
-                                "frac_of_hbm_peak": round(t / (r["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "stale": stale,
-                                "source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/pmc_traffic.json"}
-    if r["bound"] == "l2":
-        o["peak_source"] = "MI355X_MICROARCH.md L2 aggregate 34.5 TB/s = 256 CUs x 64 B/clk of vector-L1 fill"
-        if "taps_per_s" in r:
-            o["taps_per_s"] = round(r["taps_per_s"], 1)
-    elif r["bound"] == "valu":
-        o["peak_source"] = (f"VALU issue ceiling {VALU_PEAK_WAVE_INSTR / 1e9:.1f} G wave64 instructions/s (256 CUs x 4 SIMDs x 2.4 GHz / 4) over the "
-                            f"algorithm's {VALU_FLOOR_PER_DENSITY_SAMPLE:.2f} FMA instructions per valid sample (3 planes x 16 channels x 7 / 64 lanes)")
-        # the same ceiling if every FMA of the floor were a packed v_pk_fma_f32 (two channels per instruction: the kernel's
-        # interpolation IS packed; the product-sum and everything per sample is not) -- the stricter yardstick (VERDICT r4)
-        o["packed_fma_floor"] = {"peak": round(o["peak"] * 2.0, 2), "frac": round(o["frac"] / 2.0, 4), "unit": o.get("unit"),
-                                 "note": f"{VALU_FLOOR_PER_DENSITY_SAMPLE / 2:.3f} packed instructions per valid sample (42 per 16-sample pass)"}
-        o["l2_model"] = {"bound": "l2", "achieved": round(r["gather_GBps"], 2), "peak": L2_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(r["gather_GBps"] / L2_PEAK_GBS, 4), "note": "gather bytes through the vector L1s (density lines staged in LDS "
-                         "are counted although they never reach the L1)"}
-        if iss.get("valu_instructions_per_launch"):
-            # what the kernel really issues, from the SQ counter pass: VALU instructions per 16-sample gather pass against the
-            # 84 the FMAs need; the rest is index / weight / occupancy / compositing arithmetic -- the headroom of this kernel
-            per_pass = iss["valu_instructions_per_launch"] / max(r["units"] / 16.0, 1.0)
-            o["valu"] = {"valu_per_pass": round(per_pass, 1), "fma_floor_per_pass": 16 * VALU_FLOOR_PER_DENSITY_SAMPLE,
-                         "useful_valu_frac": round(16 * VALU_FLOOR_PER_DENSITY_SAMPLE / per_pass, 4),
-                         "valu_issue_frac": iss.get("valu_issue_frac"), "wait_frac_of_wave_cycles": iss.get("wait_frac_of_wave_cycles"),
-                         "stale": stale, "source": "rocprofv3 --pmc SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES, profiles/pmc_issue.json; "
-                         "pass = 16 valid samples (4 lanes each); units_per_launch of THIS run"}
-    else:
-        o["frac_of_dense_bf16_peak"] = round(r["achieved"] / BF16_MFMA_PEAK_TF, 4)
-        if iss:
-            o["pmc"] = {"mfma_busy_frac": iss.get("mfma_busy_frac"), "valu_issue_frac": iss.get("valu_issue_frac"), "stale": stale}
-        if r["kernel"] == "tir_mlp_fwd_bf16x3":
-            o["aggregation"] = "all launches of this row run the same device code (mlp_bf16_body); avg_launch_ms / units_per_launch are means over them"
-        if r["kernel"].endswith("bf16x3"):
-            o["power_limited"] = {
-                "note": "back-to-back launches of this kernel on random data run at the board power cap: the shader clock "
-                        "settles below the 2.4 GHz the peak assumes; all-zero data (same instructions) runs at 2.39 GHz and "
-                        "15-26 % faster", "board_power_W": "1330-1400", "sustained_sclk_GHz": "1.93-2.07",
-                "frac_at_sustained_clock": round(r["frac"] * 2.4 / 2.0, 4),
-                "bf16_matrix_rate_TF": round(3.0 * r["achieved"], 1),
-                "source": "tools/mlp_power.py -> profiles/r02_mlp_power.txt (rocm-smi polled during the launches)"}
-        o["peak_source"] = ("dense bf16 MFMA 2.5 PF / 3 products of the split-bf16 scheme" if r["kernel"].endswith("bf16x3")
-                            else "dense fp16 MFMA 2.5 PF (single product)" if r["kernel"].endswith("_f16") else "dense f32 MFMA 157.3 TF")
-    return o
-
-
-def dominant_roofline(rows):
-    pmc_traffic, pmc_issue, pmc_meta = load_pmc()
-    dom = next((r for r in rows if "achieved" in r), None)
-    return roofline_object(dom, pmc_traffic, pmc_issue, pmc_meta) if dom else None
-
-
-def trained_300_verdict():
-    """What the auto policy decided on a checkpoint TRAINED to 300^3 through the product API (tools/precision_300.py, run on a
-    GPU box; the JSON is committed evidence, stamped with the library hash it was measured with)."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r06_precision_trained_300.json")))
-        dec = d["policy"]["decision"]
-        return {"mode": dec["mode"], "why": dec["why"], "map_max_abs_f16_vs_full": dec["probe"].get("map_max_abs"), "limit": dec["probe"].get("limit"),
-                "iterations": d.get("iterations"), "grids": d.get("grids"), "library_source_hash": d.get("library_source_hash"),
-                "stale": d.get("library_source_hash") != library_info().get("source_hash"),
-                "worst_map_vs_oracle": max(v["max_rel_floor1"] for v in d["oracle"].values() if isinstance(v, dict) and "max_rel_floor1" in v),
-                "source": "profiles/r06_precision_trained_300.json"}
-    except Exception as e:
-        return {"error": f"{type(e).__name__}: {e}"}
-
-
-def port_vs_reference(port_value):
-    """What is known about the oracle's speed relative to the imported reference's CPU path (which cannot run on the GPU box).
-    profiles/port_over_reference.json is written by oracle/calibrate_port.py in the build container (both implementations, same
-    inputs, same threads); profiles/r03_ref_on_gpu.json holds the one staged run of the reference on the GPU box's host cores."""
-    out = {"note": "no calibration file"}
-    try:
-        cal = json.load(open(os.path.join(ROOT, "profiles", "port_over_reference.json")))
-        out = {"port_over_reference_time": cal["port_over_reference"],
-               "reference_equivalent_rays_per_s": round(port_value * cal["port_over_reference"], 2),
-               "measured": f"oracle/calibrate_port.py in the build container ({cal.get('threads')} threads): reference {cal.get('reference_rays_per_s')} rays/s, "
-                           f"port {cal.get('port_rays_per_s')} rays/s on {cal.get('sample', '?').split(',')[0]}",
-               "caveat": "the ratio depends on thread count and batch size (the CPU path is dominated by per-op overheads and memory "
-                         "traffic, not FLOPs); the staged reference run on THIS kind of box (profiles/r03_ref_on_gpu.json, 128 threads, "
-                         "full batch) measured 361-373 rays/s"}
-    except Exception:
-        pass
-    return out
-
-
-def timed_cpu(fn, warm, calls):
-    """Median wall time of `fn()` on the host cores (warm-ups first, time.perf_counter, no_grad)."""
-    out, ts = None, []
-    with torch.no_grad():
-        for i in range(warm + calls):
-            t0 = time.perf_counter()
-            out = fn()
-            if i >= warm:
-                ts.append(time.perf_counter() - t0)
-    ts.sort()
-    return out, ts[len(ts) // 2], ts
-
-
-def map_parity(got, ref, keys, sel=None, rays=None):
-    """max |hip - oracle| / max(|oracle|, 1) over the named maps (the test metric), per map and worst.  rays (the oracle's rows):
-    rgb_with_brdf_map is compared on the rays where the reference's GGX normal flip is not within fp32 noise of its
-    discontinuity (tests/helpers.py ggx_flip_rays)."""
-    from tests.helpers import ggx_flip_rays, parity_metrics
-    per, worst = {}, 0.0
-    keep = ~ggx_flip_rays(ref["normal_map"], rays) if rays is not None and "normal_map" in ref else None
-    for k in keys:
-        g = got[k].detach().cpu()
-        g = g[sel] if sel is not None else g
-        r = ref[k]
-        if keep is not None and k == "rgb_with_brdf_map":
-            g, r = g[keep], r[keep]
-        m = parity_metrics(g, r)
-        per[k] = {kk: float(f"{vv:.3e}") for kk, vv in m.items()}
-        worst = max(worst, m["max_rel_floor1"])
-    worst_px = max(v["max_rel_pixel"] for v in per.values()) if per else 0.0
-    return {"ok": worst < 1e-4 and worst_px < 1e-4, "tolerance": 1e-4, "max_rel_floor1": float(f"{worst:.3e}"),
-            "max_rel": float(f"{worst_px:.3e}"), "per_map": per,
-            "metric": "both asserted: max |hip - oracle| / max(|oracle|, 1) per map and the true per-pixel relative error "
-                      "||d|| / ||ref|| over pixels with ||ref|| > 1e-2"}
-
-
-MAP_KEYS = ["rgb_map", "depth_map", "normal_map", "albedo_map", "roughness_map", "fresnel_map", "acc_map",
-            "rgb_with_brdf_map", "normals_diff_map", "normals_orientation_loss_map"]
-
-
-def sharp_scene_line(a, device, args):
-    """The same step on a scene whose density rises 3-4x faster across the surface (blob sigma 0.2, gain 2000): the
-    number of appearance samples per ray drops from ~56 to what a trained scene keeps (10-30), which moves the kernel mix
-    from the decoders toward the gathers.  Informative only -- never the headline value."""
-    from tensoir_amd import ops
-    from tensoir_amd.graph import GraphedRenderer
-    _ck, model, rays, lidx = build_scene(a, device, 0, blob_sigma=0.2, blob_gain=2000.0)
-    B = rays.shape[0]
-    gr = GraphedRenderer(model, B, N_samples=a.samples, args=args, device=device)
-    gr.rays.copy_(rays)
-    gr.lidx.copy_(lidx)
-    ret = gr(clone_outputs=False)
-    parity = None
-    if not a.no_cpu_baseline:        # the graph-replay maps of this scene against the oracle on every 32nd ray (default policy)
-        from oracle import tensoir_oracle as O          # checker only
-        from tests.helpers import scene_from_model
-        sc = scene_from_model(_ck, model, a.env_h, a.env_w)
-        stride = max(1, B // 128)
-        with torch.no_grad():
-            ref = O.renderer_train(sc, rays.cpu()[::stride], lidx.cpu()[::stride], n_samples=a.samples, second_n_sample=a.second_samples)
-        got = {k: v.clone() for k, v in ret.items() if torch.is_tensor(v)}
-        parity = map_parity(got, ref, MAP_KEYS, slice(0, None, stride), rays.cpu()[::stride])
-        parity["rays_compared"] = int(ref["rgb_map"].shape[0])
-        parity["indirect_precision"] = model.indirect_precision()
-    for _ in range(5):
-        gr(clone_outputs=False, defer_check=True)
-    torch.cuda.synchronize()
-    n = max(10, a.steps)
-    t0 = time.perf_counter()
-    for _ in range(n):
-        gr(clone_outputs=False, defer_check=True)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    ok = gr.validate()
-    # per-kernel attribution: one eager pass bracketed by events
-    from tensoir_amd import Renderer_TensoIR_train
-    ops.TIMING = []
-    with torch.no_grad():
-        for _ in range(3):
-            Renderer_TensoIR_train(rays, None, lidx, model, N_samples=a.samples, white_bg=True, is_train=False,
-                                   is_relight=True, sample_method="fixed_envirmap", chunk_size=160000, device=device, args=args, _no_graph=True)
-    torch.cuda.synchronize()
-    agg = {}
-    for name, e0, e1 in ops.TIMING:
-        name = ALIAS.get(name, name)
-        agg[name] = agg.get(name, 0.0) + e0.elapsed_time(e1) / 3
-    ops.TIMING = None
-    totals = [int(c[0].item()) for c in gr.checks] if gr.checks else []
-    return {"value": round(B * n / el, 1), "unit": "rays/s", "ms_per_step": round(1e3 * el / n, 4), "capacity_checks_ok": bool(ok),
-            "scene": "blob sigma 0.2, gain 2000 (headline: 0.35 / 20)",
-            "surface_points": int((ret["acc_map"] > 0.5).sum()),
-            "app_samples_per_ray": round(totals[0] / B, 1) if totals else None,
-            "secondary_records": totals[1] if len(totals) > 1 else None, "parity": parity,
-            "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:8]}}
-
-
-def bench_image(a, embed=False):
-    """BASELINE configs[3]: an 800x800 image (640 000 rays in chunks of 4096, light index = pixel mod 3) rendered
-    data-parallel -- every rank its shard of the rays (row tiles or interleaved tiles), ONE all-gather of the 96-B per-ray
-    records per image (renderer.py:225-249 is the reference's sequential chunk loop).  A step = one image; strong scaling."""
-    import contextlib
-    import io
-    import torch.distributed as dist
-    import tensoir_amd
-    from tensoir_amd import _lib, synth
-    from tensoir_amd import dist as tdist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: tensoir_amd has no CPU path")
-    local = local_device(a)
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    if a.tile < 0:      # auto: interleaved chunk-sized tiles as soon as the image is shared (profiles/r05_predicted_scaling.json:
-        a.tile = a.rays if world > 1 else 0          # 8 ranks -> 7.5-7.8x predicted; two chunks 7.5-7.6x, four 7.3x, row tiles 5.6x)
-    assert _lib.lib().tir_device_check() == 0
-    use_dist = world > 1 or a.force_dist
-    ck = synth.make_checkpoint(grid=(a.grid,) * 3, seed=20211202, light_rotation=("000", "120", "240"))
-    model = tensoir_amd.model_from_checkpoint(ck, device, envmap_h=a.env_h, envmap_w=a.env_w)
-    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
-        model.updateAlphaMask((128, 128, 128))
-    args = types.SimpleNamespace(second_nSample=a.second_samples, second_near=0.05, second_far=1.5)
-    side = a.image_side
-    rays = synth.make_rays(side, side, narrow=1.0).to(device)
-    n = rays.shape[0]
-    lidx = (torch.arange(n, device=device) % 3).to(torch.int32).view(-1, 1)
-    fn = tdist.GraphedChunkRenderer(model, a.rays, args, device=device, lanes=max(1, a.in_flight))
-    with torch.no_grad():          # capture + capacity learning on this rank's own shard, BEFORE any RCCL thread exists:
-        mine = tdist.shard_rows(n, rank, world, a.tile).to(device)       # repeat until the captured capacities of every lane
-        for _ in range(4):                                                # hold for the heaviest chunk of the shard
-            tdist._render_chunks(fn, rays, lidx, mine, a.rays)
-            if fn.validate():
-                break
-    if use_dist:
-        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
-            os.environ.setdefault(k, v)               # --force-dist in a bare single process
-        dist.init_process_group(a.backend, **({"device_id": device} if a.backend == "nccl" else {}))
-    gw = world if use_dist else 1
-
-    def one():
-        with torch.no_grad():
-            return tdist.render_sharded_timed(fn, rays, lidx, rank=rank, world=gw, chunk=a.rays, tile=a.tile)
-    for _ in range(3 + a.warmup):      # clock settle + warm-up: a fixed count (every image ends in a collective)
-        one()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    loc, exch = [], []
-    for _ in range(a.steps):
-        img, tl, te = one()
-        loc.append(tl)
-        exch.append(te)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    per_rank = [sum(loc) / len(loc)]
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        pr = torch.zeros((gw,), dtype=torch.float64, device=device)
-        pr[rank] = per_rank[0]
-        dist.all_reduce(pr)
-        per_rank = pr.tolist()
-    sim = None
-    if a.simulate_ranks >= 2 and world == 1:
-        def render_shard(mine):
-            mine = mine.to(device)
-            with torch.no_grad():
-                for _ in range(4):
-                    parts = tdist._render_chunks(fn, rays, lidx, mine, a.rays)
-                    if fn.validate():
-                        break
-                return torch.cat(parts, dim=0) if parts else None
-        sim = simulate_ranks(render_shard, n, a.rays, elapsed / a.steps, tdist.RECORD * 4, a.simulate_ranks,
-                             local_exchange_s=sum(exch) / len(exch))
-    roofline = parity = cpu = kernels = None
-    if rank == 0 and not a.no_cpu_baseline:
-        # dominant kernel, in-run parity and CPU baseline on ONE chunk of the image (the middle one: rays cross the object)
-        from oracle import tensoir_oracle as O          # checker / CPU baseline only
-        from tests.helpers import scene_from_model
-        from tensoir_amd import Renderer_TensoIR_train
-        c0 = (n // a.rays // 2) * a.rays
-        rc, lc = rays[c0:c0 + a.rays].contiguous(), lidx[c0:c0 + a.rays].contiguous()
-
-        def run():
-            with torch.no_grad():
-                return Renderer_TensoIR_train(rc, None, lc, model, N_samples=-1, white_bg=True, is_train=False, is_relight=True,
-                                              sample_method="fixed_envirmap", chunk_size=160000, device=device, args=args, _no_graph=True)
-        ret_c = run()
-        Mc, Dn = int((ret_c["acc_map"] > 0.5).sum()), a.env_h * a.env_w
-        rows, gpu_ms, ev_over = attribute_kernels(run, 2, a.rays * 40 + a.rays * model.nSamples * 4, Mc * Dn * 40, device)
-        roofline = dominant_roofline(rows)
-        kernels = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:6]]
-        sc = scene_from_model(ck, model, a.env_h, a.env_w)
-        stride = max(1, a.rays // 128)
-        r_cpu, l_cpu = rc.cpu()[::stride], lc.cpu()[::stride]
-        ref, med, ts = timed_cpu(lambda: O.renderer_train(sc, r_cpu, l_cpu, n_samples=-1, second_n_sample=a.second_samples), 1, 3)
-        parity = map_parity(ret_c, ref, MAP_KEYS, slice(0, None, stride), r_cpu)
-        parity["rays_compared"] = int(r_cpu.shape[0])
-        cpu = {"value": round(r_cpu.shape[0] / med, 2), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-               "sample": f"every {stride}th ray of the image's middle chunk ({r_cpu.shape[0]} rays x {model.nSamples} samples, "
-                         f"{Dn} dirs x {a.second_samples}), 1 warm-up + {len(ts)} timed calls, median; host nproc={os.cpu_count()}"}
-    if rank == 0:
-        hit = float((img["acc_map"] > 0.5).float().mean())
-        line = {
-            "metric": "full-image primary+secondary rays/sec, one 800x800 image sharded over the GPUs", "value": round(n * a.steps / elapsed, 1),
-            "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 io; decoders split-bf16 x3 (hi/lo operands, 3 MFMA products), fp32 accumulate", "data": "synthetic",
-            "config": {"workload": f"C4: {side}x{side} image = {n} rays in chunks of {a.rays}, VM grid {a.grid}^3, 3 light rotations "
-                                   f"(light index = pixel mod 3), N_samples=-1 ({model.nSamples} per ray), secondary {a.env_h * a.env_w} dirs x "
-                                   f"{a.second_samples}; full field of view ({hit:.2f} of the rays hit the object)",
-                       "sharding": ("contiguous row tiles" if a.tile <= 0 else f"interleaved tiles of {a.tile} rays") +
-                                   f", one all_gather_into_tensor of {tdist.RECORD * 4} B/ray records per image",
-                       "launch": "hip-graph replay per chunk, one capacity check per image", "in_flight": max(1, a.in_flight)},
-            "world_size": gw, "device_count": torch.cuda.device_count(), "backend": a.backend if use_dist else None,
-            "per_rank_render_ms": [round(1e3 * x, 3) for x in per_rank],
-            "load_imbalance": round(max(per_rank) / max(min(per_rank), 1e-9), 3),
-            "exchange_ms": round(1e3 * sum(exch) / len(exch), 3),
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "kernels_middle_chunk": kernels,
-            "roofline_note": "dominant kernel of the image's middle chunk, one eager pass bracketed by events (calibrated)",
-        }
-        if sim is not None:
-            line["simulated_ranks"] = sim
-        if embed:
-            return line
-        print(json.dumps(line), flush=True)
-        if parity is not None and not parity["ok"]:
-            raise SystemExit(f"[bench] PARITY FAILURE vs the oracle (image workload): {parity}")
-    if use_dist:
-        dist.destroy_process_group()
-
-
-def simulate_ranks(render_shard, n_rays, chunk, t1_s, record_bytes, max_world, passes=3, tiles=None, local_exchange_s=0.0):
-    """The multi-GPU row on ONE GPU: for W = 2, 4, ... <= max_world and every sharding (contiguous row
-    tiles; interleaved tiles of 1, 2, 4 chunks) render each rank's shard of the W-rank job ALONE on this GPU -- what rank r would
-    do on its own device, the field being replicated -- and time it (device drained around each shard; best of `passes` after
-    two untimed passes that let the captured capacities settle).  Predicted time of the W-rank job = max_r t_r + exchange, where
-    exchange = the measured local reassembly of the gathered records (`local_exchange_s`, the world = 1 figure) + the wire time
-    of ONE all_gather_into_tensor over xGMI modelled at 60 % of the 153 GB/s per-link peak, every rank receiving (W - 1) shards
-    over W - 1 links in parallel (MI355X_MICROARCH.md: fully connected, 7 links per GPU).  Predicted speed-up = t(1) / that.
-    RCCL itself has still not run with N > 1: this bounds the load-balance part of the scaling curve, not the collective."""
-    from tensoir_amd import dist as tdist
-    if tiles is None:
-        tiles = [0, chunk, 2 * chunk, 4 * chunk]
-    worlds = [w for w in (2, 4, 8, 16) if w <= max_world]
-    out = {"method": simulate_ranks.__doc__.split("\n")[0].strip(), "t1_ms": round(1e3 * t1_s, 3), "record_bytes_per_ray": record_bytes,
-           "link_GBps_assumed": round(0.6 * 153.0, 1), "local_reassembly_ms": round(1e3 * local_exchange_s, 3), "configs": []}
-    for w in worlds:
-        for tile in tiles:
-            per = []
-            for r in range(w):
-                mine = tdist.shard_rows(n_rays, r, w, tile)
-                drain = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)
-                render_shard(mine)                       # untimed, twice: capacities / caches / re-captures of this shard's chunking
-                render_shard(mine)
-                best = None
-                for _ in range(passes):
-                    drain()
-                    t0 = time.perf_counter()
-                    render_shard(mine)
-                    drain()
-                    dt = time.perf_counter() - t0
-                    best = dt if best is None else min(best, dt)
-                per.append(best)
-            wire = (w - 1) / w * n_rays * record_bytes / (0.6 * 153e9 * (w - 1))
-            t_w = max(per) + local_exchange_s + wire
-            out["configs"].append({"world": w, "sharding": "row tiles" if tile <= 0 else f"interleaved tiles of {tile // chunk} chunk(s)",
-                                   "tile": tile, "per_shard_ms": [round(1e3 * x, 3) for x in per], "max_ms": round(1e3 * max(per), 3),
-                                   "mean_ms": round(1e3 * sum(per) / w, 3), "imbalance_max_over_mean": round(max(per) / (sum(per) / w), 3),
-                                   "sum_over_t1": round(sum(per) / t1_s, 3), "exchange_model_ms": round(1e3 * (local_exchange_s + wire), 3),
-                                   "predicted_ms": round(1e3 * t_w, 3), "predicted_speedup": round(t1_s / t_w, 2)})
-    best = {}
-    for c in out["configs"]:
-        if c["world"] not in best or c["predicted_speedup"] > best[c["world"]]["predicted_speedup"]:
-            best[c["world"]] = c
-    out["best_per_world"] = {str(w): {"sharding": c["sharding"], "predicted_speedup": c["predicted_speedup"], "imbalance_max_over_mean": c["imbalance_max_over_mean"]}
-                             for w, c in best.items()}
-    return out
-
-
-def synthetic_hdr_maps(n_maps, H=1024, W=2048):
-    """Seeded 2048x1024 HDR environment maps (tensoir_amd.synth.make_hdr_maps)."""
-    from tensoir_amd import synth
-    return synth.make_hdr_maps([f"env{i}" for i in range(n_maps)], H, W)
-
-
-def bench_relight(a, embed=False):
-    """BASELINE configs[4] (ficus relighting_test): one 800x800 view of the 400^3 field relit under `--maps` 2048x1024 HDR
-    environment maps with 512 importance samples per surface point -- the loop body of scripts/relight_importance.py:93-185.
-    Per 4096-ray chunk one primary pass, then per map: importance sampling + cosine mask on the device, visibility march of
-    the unmasked (point, cell) pairs (96 samples), BRDF x radiance x cosine / pdf, sRGB, background lookup.  Chunks are
-    sharded over the ranks (interleaved tiles), ONE all-gather of the relit colours per view.  A step = one view."""
-    import contextlib
-    import io
-    import torch.distributed as dist
-    import tensoir_amd
-    from tensoir_amd import _lib, ops, relight, synth
-    from tensoir_amd import dist as tdist
-    pair_order = ops.c5_pair_order()
-    world, rank = (int(os.environ.get(k, "0" if k != "WORLD_SIZE" else "1")) for k in ("WORLD_SIZE", "RANK"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: tensoir_amd has no CPU path")
-    local = local_device(a)
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    assert _lib.lib().tir_device_check() == 0
-    grid = a.grid if a.grid != 300 else 400                 # ficus: N_voxel_final = 400^3 (configs/relighting_test/ficus.txt)
-    ck = synth.make_checkpoint(grid=(grid,) * 3, seed=20211202)
-    model = tensoir_amd.model_from_checkpoint(ck, device, envmap_h=a.env_h, envmap_w=a.env_w)
-    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
-        model.updateAlphaMask((128, 128, 128))
-    maps = synthetic_hdr_maps(a.maps)
-    env = relight.Environment_Light(hdr_maps=maps, device=device)
-    side, Ns = a.image_side, 512
-    rays = synth.make_rays(side, side, narrow=1.0).to(device)
-    n = rays.shape[0]
-    lidx = torch.zeros(n, 1, dtype=torch.int32, device=device)
-    use_dist = world > 1 or a.force_dist
-    if use_dist:
-        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
-            os.environ.setdefault(k, v)
-        dist.init_process_group(a.backend, **({"device_id": device} if a.backend == "nccl" else {}))
-    gw = world if use_dist else 1
-    tile = a.rays if (a.tile < 0 and gw > 1) else max(a.tile, 0)
-    mine = tdist.shard_rows(n, rank, gw, tile).to(device)
-
-    @torch.no_grad()
-    def chunk_pass_host(c, names, counts=None):
-        """One chunk the way the reference script drives it (scripts/relight_importance.py:99-113, :166-171): boolean-mask
-        indexing of the hit rows on the host side of the call (a synchronisation + ~12 indexing launches per chunk), per
-        environment map the relit colours, get_light + index_put_ for the background.  --c5-host-masking times this."""
-        r, l = rays[c], lidx[c]
-        out = model(r, l, N_samples=-1)
-        depth, normal, albedo, rough, fres, acc = out[1:7]
-        mask = acc > 0.5
-        surf = (r[:, :3] + depth.unsqueeze(-1) * r[:, 3:])[mask]
-        nrm, alb, rgh, fr, rd = normal[mask], albedo[mask], rough[mask], fres[mask], r[:, 3:][mask]
-        if counts is not None:
-            counts[0] += int(surf.shape[0])
-        cols = []
-        rows_hit = mask.nonzero()[:, 0]
-        for name in names:
-            rgb = relight.relight_importance_sampled(model, env, name, surf, nrm, alb, rgh, fr, rd, num_samples=Ns)
-            img = env.get_light(name, r[:, 3:]).index_put_((rows_hit,), rgb)      # (scripts/relight_importance.py:166-171
-            cols.append(img)                                                          #  tone-maps the background too: host side)
-        return (torch.cat(cols, dim=1) if cols else None), (surf, nrm, alb, rgh, fr, rd, r[mask], l[mask])
-
-    @torch.no_grad()
-    def chunk_pass(c, names, counts=None):
-        """One chunk through the product's chunk call (relight.relight_chunk): primary maps, device-side compaction of the hit
-        rows, per environment map the relit colours, background composed in -- no host round trip between the launches.
-        counts[1] collects the device-side hit counters (summed once per view)."""
-        if a.c5_host_masking:
-            return chunk_pass_host(c, names, counts)
-        r, l = rays[c], lidx[c]
-        out, _prim, cc = relight.relight_chunk(model, env, names, r, l, num_samples=Ns)
-        if counts is not None:
-            counts[1].append(cc["n_hit"])
-        return (out if names else None), cc
-
-    def view(counts=None):
-        if counts is not None:
-            counts[1] = []
-        parts = [chunk_pass(c, list(maps), counts)[0] for c in torch.split(mine, a.rays) if c.numel()]
-        if counts is not None and counts[1]:
-            counts[0] += int(torch.cat(counts[1]).sum().item())       # one read-back per view, after every chunk is queued
-        local_rec = torch.cat(parts, dim=0) if parts else torch.zeros((0, 3 * len(maps)), device=device)
-        return tdist.gather_records(local_rec, n, rank, gw, tile)
-
-    for _ in range(1 + a.warmup):
-        view()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    counts = [0, []]
-    for _ in range(a.steps):
-        img = view(counts)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    per_rank = [elapsed / a.steps]
-    if use_dist:
-        pr = torch.zeros((gw,), dtype=torch.float64, device=device)
-        pr[rank] = elapsed / a.steps
-        dist.all_reduce(pr)
-        per_rank, elapsed = pr.tolist(), float(pr.max().item()) * a.steps
-        cnt = torch.tensor(counts[:1], dtype=torch.float64, device=device)
-        dist.all_reduce(cnt)
-        counts = [int(cnt.item()), []]
-    sim = None
-    if a.simulate_ranks >= 2 and world == 1:
-        def render_shard(mine_r):
-            mine_r = mine_r.to(device)
-            parts = [chunk_pass(c, list(maps))[0] for c in torch.split(mine_r, a.rays) if c.numel()]
-            return torch.cat(parts, dim=0) if parts else None
-        sim = simulate_ranks(render_shard, n, a.rays, elapsed / a.steps, 12 * len(maps), a.simulate_ranks, passes=2, tiles=[0, a.rays])
-    roofline = parity = cpu = kernels = None
-    if rank == 0 and not a.no_cpu_baseline:
-        from oracle import tensoir_oracle as O          # checker / CPU baseline only
-        from tests.helpers import parity_metrics, scene_from_model
-        c0 = (n // a.rays // 2) * a.rays
-        c = torch.arange(c0, c0 + a.rays, device=device)
-        _, (surf, nrm, alb, rgh, fr, rd, r_hit, l_hit) = chunk_pass_host(c, [])
-        M = int(surf.shape[0])
-        rows, gpu_ms, ev_over = attribute_kernels(lambda: chunk_pass(c, list(maps)), 1,
-                                                  a.rays * 40 + a.rays * model.nSamples * 4, 0, device)
-        for r in rows:                                  # the visibility march: launches per step = maps; io = pair bookkeeping
-            if r["kernel"] == "tir_march_secondary_fwd":
-                r["note"] = f"{len(maps)} launches (one per environment map), {M} surface points x {Ns} importance samples each"
-        roofline = dominant_roofline(rows)
-        kernels = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows[:6]]
-        # parity: the fused device path vs the oracle's loop body, fed the cells the device drew (SURVEY 8d), map 0
-        sc = scene_from_model(ck, model, a.env_h, a.env_w)
-        name = next(iter(maps))
-        with torch.no_grad():
-            draws = env._draws
-            cell, _active = env.sample_cells(name, nrm.contiguous(), Ns)
-            env._draws = draws                           # the same draw again inside relight_importance_sampled
-            got = relight.relight_importance_sampled(model, env, name, surf, nrm, alb, rgh, fr, rd, num_samples=Ns)
-            ldir = env.hdr_dir[name].view(-1, 3)[cell.long()]
-            lrgb = env.hdr_rgbs[name].view(-1, 3)[cell.long()]
-            lpdf = env.hdr_pdf_return[name].view(-1)[cell.long()].unsqueeze(-1)
-        sel = slice(0, M, max(1, M // 96))
-        cc = lambda t: t[sel].cpu()
-        pts = int(cc(surf).shape[0])
-        ref, med, ts = timed_cpu(lambda: O.relight_importance(sc, cc(surf), cc(nrm), cc(alb), cc(rgh), cc(fr), cc(rd), cc(ldir), cc(lrgb),
-                                                              cc(lpdf), n_sample=96, near=0.05, far=1.5), 1, 3)
-        m = parity_metrics(cc(got), ref)
-        parity = {"ok": m["max_rel_floor1"] < 1e-4, "tolerance": 1e-4, "relit_rgb": {k: float(f"{v:.3e}") for k, v in m.items()},
-                  "surface_points_compared": pts, "note": "every k-th surface point of the view's middle chunk, environment map 0, the "
-                  "device-drawn cells fed to the oracle's restatement of scripts/relight_importance.py:119-170"}
-        vis_rays = pts * Ns
-        # the same unit as `value` (camera rays/s of a whole view): the oracle's primary pass on the rays of those surface points
-        # + its relight loop body once per environment map; the view's background rays (1 - hit fraction of the rays) are
-        # counted as free for the CPU (their primary pass is a bounding-box miss) -- which can only flatter the CPU figure
-        _, med_p, _ = timed_cpu(lambda: O.forward_primary(sc, cc(r_hit), cc(l_hit).to(torch.int32), -1, True, True, None, None, "aten"), 0, 1)
-        hit_frac = counts[0] / max(1, a.steps) / n
-        cpu = {"value": round((pts / max(hit_frac, 1e-9)) / (med_p + len(maps) * med), 2), "unit": "rays/s", "cores": torch.get_num_threads(),
-               "kind": "port", "sample": f"{pts} surface points of the middle chunk: primary pass of their camera rays ({med_p:.2f} s) + the relight loop "
-               f"body ({Ns} samples x 96 visibility steps, {med:.2f} s per map, 1 warm-up + {len(ts)} timed calls, median) x {len(maps)} maps; scaled "
-               f"to camera rays by the view's hit fraction {hit_frac:.3f} (background rays free); host nproc={os.cpu_count()}",
-               "pairs_per_s": round(vis_rays / med, 1), "gpu_pairs_per_s": round(counts[0] * Ns * len(maps) / elapsed, 1)}
-    if rank == 0:
-        line = {
-            "metric": "relit camera rays/sec: one 800x800 view under 2048x1024 HDR maps, 512 importance samples per surface point",
-            "value": round(n * a.steps / elapsed, 1), "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 io; primary-pass decoders split-bf16 x3, fp32 accumulate; relight integration f32", "data": "synthetic",
-            "config": {"workload": f"C5: {side}x{side} view = {n} rays in chunks of {a.rays}, VM grid {grid}^3, {len(maps)} HDR maps "
-                                   f"2048x1024, {Ns} importance samples per surface point, 96 visibility samples per pair",
-                       "sharding": ("contiguous row tiles" if tile <= 0 else f"interleaved tiles of {tile} rays") +
-                                   f", one all_gather_into_tensor of {12 * len(maps)} B/ray relit colours per view",
-                       "launch": "eager per chunk (primary pass + per-map relight kernels); " + ("host-side masking per chunk as the reference script "
-                                 "does (--c5-host-masking)" if a.c5_host_masking else "relight.relight_chunk: hit rows compacted on the device, no host round "
-                                 "trip per chunk (one hit-count read-back per view)"),
-                       "visibility_pairs": "{} (bins {}x{}, blocks of {} pairs): only the pairs that pass the cosine mask are marched "
-                                           "(scripts/relight_importance.py:127-131); TENSOIR_C5_PAIRS".format(
-                                               pair_order[0], pair_order[1][0], pair_order[1][1], pair_order[2])},
-            "surface_points_per_view": counts[0] // max(1, a.steps),
-            "visibility_pairs_per_s": round(counts[0] * Ns * len(maps) / elapsed, 1),
-            "relit_images_per_s": round(len(maps) * a.steps / elapsed, 3),
-            "world_size": gw, "device_count": torch.cuda.device_count(), "backend": a.backend if use_dist else None,
-            "per_rank_ms_per_step": [round(1e3 * x, 3) for x in per_rank],
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "kernels_middle_chunk": kernels,
-        }
-        if sim is not None:
-            line["simulated_ranks"] = sim
-        if embed:
-            return line
-        print(json.dumps(line), flush=True)
-        if parity is not None and not parity["ok"]:
-            raise SystemExit(f"[bench] PARITY FAILURE vs the oracle (relight workload): {parity}")
-    if use_dist:
-        dist.destroy_process_group()
-
-
-TRAIN_W = dict(rgb_brdf=0.2, normals_diff=0.0005, normals_orientation=0.001, albedo_smoothness=0.001, roughness_smoothness=0.001)
-ATOMIC_SEGMENTS_PER_S = 20.5e9      # tools/atomic_bench.hip (profiles/r01_v4_atomic_bench.txt): L2 fp32 atomics, per 64-B segment
-
-
-def atomic_segments_after_combining(xyz, grid, run=8):
-    """64-B atomic segments k_vm_app_bwd sends to L2 for the records `xyz` [n,3] (normalised coordinates): per VM group, a lane
-    group walks aligned runs of `run` consecutive records and flushes its four plane-tap gradients (3 runs of 16 channels each =
-    12 segments) whenever the plane cell (floor of the unnormalised coordinates, csrc/tir_common.hpp make_tap) changes, and once
-    at the end of the run.  Line and light-row gradients are summed in LDS and are not counted."""
-    n = xyz.shape[0]
-    if n == 0:
-        return 0.0
-    cell = lambda a, size: torch.floor(((xyz[:, a] + 1.0) * 0.5) * float(size - 1)).to(torch.int64)
-    idx = torch.arange(n, device=xyz.device)
-    inside = (idx[1:] % run) != 0                                   # boundaries INSIDE an aligned run
-    total = 0.0
-    for m0, m1 in ((0, 1), (0, 2), (1, 2)):
-        cid = cell(m1, grid[m1]) * int(grid[m0]) + cell(m0, grid[m0])
-        changes = int(((cid[1:] != cid[:-1]) & inside).sum().item())
-        total += ((n + run - 1) // run + changes) * 12.0
-    return total
-
-
-def train_loss(ret, gt, relight):
-    """train_tensoIR.py:262-311 with the config weights of configs/single_light/armadillo.txt (regularisers on the raw
-    parameters -- TV / L1 / ortho -- are PyTorch ops on the parameter tensors, off the per-sample path: not part of the step)."""
-    loss = torch.mean((ret["rgb_map"] - gt) ** 2)
-    if relight:
-        loss = loss + TRAIN_W["rgb_brdf"] * torch.mean((ret["rgb_with_brdf_map"] - gt) ** 2) \
-            + TRAIN_W["normals_diff"] * ret["normals_diff_map"].mean() \
-            + TRAIN_W["normals_orientation"] * ret["normals_orientation_loss_map"].mean() \
-            + TRAIN_W["roughness_smoothness"] * ret["roughness_smoothness_loss"] \
-            + TRAIN_W["albedo_smoothness"] * ret["albedo_smoothness_loss"]
-    return loss
-
-
-def bench_train(a, embed=False):
-    """One training step of train_tensoIR.py:237-317 on the C2 scene: Renderer_TensoIR_train(is_train=True, stratified light
-    directions, is_relight=True) + the loss + total_loss.backward() (hand-written backward kernels) + optimizer.step() (one
-    launch).  Data parallel over ranks: every rank marches its own 4096-ray batch (weak scaling), the parameter gradients are
-    averaged with a bucketed RCCL all-reduce before the optimizer step (the reference never all-reduces: SURVEY 2.1, 8f-4)."""
-    import torch.distributed as dist
-    from tensoir_amd import Renderer_TensoIR_train, _lib, ops, optim
-    from tensoir_amd import dist as tdist
-    world, rank = (int(os.environ.get(k, "0" if k != "WORLD_SIZE" else "1")) for k in ("WORLD_SIZE", "RANK"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: tensoir_amd has no CPU path")
-    local = local_device(a)
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    assert _lib.lib().tir_device_check() == 0
-    ckpt, model, rays, lidx = build_scene(a, device, rank)
-    batches = [b.to(device) for b in pose_batches(rays.cpu(), max(1, a.batches), rank)]
-    model.march_t_stop = 1e-6
-    args = types.SimpleNamespace(second_nSample=a.second_samples, second_near=0.05, second_far=1.5)
-    B = rays.shape[0]
-    # ground-truth colours: the scene's own rendering of each pose, contrast-reduced (0.8 x + 0.1) -- the gradients are real, the
-    # geometry stays put (random colours per pose would teach the field fog, and the record count per step would drift)
-    with torch.no_grad():
-        gts = [(0.8 * Renderer_TensoIR_train(b, None, lidx, model, N_samples=a.samples, white_bg=True, is_train=False, is_relight=True,
-                                             sample_method="fixed_envirmap", device=device, args=args)["rgb_map"] + 0.1).contiguous()
-               for b in batches]
-    opt = optim.Adam(model.get_optparam_groups(0.02, 0.001), betas=(0.9, 0.99))
-    params = [p for g in opt.param_groups for p in g["params"]]
-    use_dist = world > 1 or a.force_dist
-    if use_dist:
-        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
-            os.environ.setdefault(k, v)
-        dist.init_process_group(a.backend, **({"device_id": device} if a.backend == "nccl" else {}))
-    state = {"i": 0, "buckets": 0}
-
-    def step():
-        i = state["i"] % len(batches)
-        state["i"] += 1
-        ret = Renderer_TensoIR_train(batches[i], None, lidx, model, N_samples=a.samples, white_bg=True, is_train=True,
-                                     is_relight=True, sample_method="stratified_sampling", device=device, args=args)
-        loss = train_loss(ret, gts[i], True)
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        if use_dist:
-            state["buckets"] = tdist.allreduce_gradients(params, force=a.force_dist)
-        opt.step()
-        return loss
-
-    l0 = float(step().detach())
-    for _ in range(100):               # untimed, a fixed count: clocks out of the idle state, capacities learnt for every pose
-        step()
-    torch.cuda.synchronize()
-    for _ in range(a.warmup):
-        step()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    mem0 = torch.cuda.memory_allocated(device)
-    torch.cuda.reset_peak_memory_stats(device)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        l1 = step()
-    torch.cuda.synchronize()
-    mem1, mem_peak = torch.cuda.memory_allocated(device), torch.cuda.max_memory_allocated(device)
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    per_rank = [elapsed / a.steps]
-    if use_dist:
-        pr = torch.zeros((dist.get_world_size(),), dtype=torch.float64, device=device)
-        pr[dist.get_rank()] = elapsed / a.steps
-        dist.all_reduce(pr)
-        per_rank, elapsed = pr.tolist(), float(pr.max().item()) * a.steps
-    # ---- per entry point: events around every C call, three steps; rows of the record-bound kernels counted by a wrapper
-    recs, seg_calls = [], []
-    orig_bwd = ops.vm_app_bwd
-
-    def bwd_wrap(f, gd, xyz, *r, **k):
-        recs.append(int(xyz.shape[0]))
-        if len(seg_calls) < 2:                       # the two launches of ONE step: records, jittered records
-            seg_calls.append(atomic_segments_after_combining(xyz.detach(), [int(v) for v in model.gridSize.tolist()]))
-        return orig_bwd(f, gd, xyz, *r, **k)
-    ops.vm_app_bwd = bwd_wrap
-    ops.TIMING = []
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize()
-    ops.vm_app_bwd = orig_bwd
-    ev_over = event_bracket_overhead_ms(device)
-    agg = {}
-    for name, e0, e1 in ops.TIMING:
-        k = agg.setdefault(name, [0.0, 0])
-        k[0] += max(e0.elapsed_time(e1) - ev_over, 1e-4)
-        k[1] += 1
-    ops.TIMING = None
-    rows = sorted(((nm, v[0] / 3, v[1] / 3) for nm, v in agg.items()), key=lambda r: -r[1])
-    A = max(recs[0::2]) if recs else 0           # records (w > 1e-4 samples) of a step: the rows of the decoder / gather backward
-    by = {nm: (ms, cnt) for nm, ms, cnt in rows}
-    roofline = None
-    if "tir_vm_app_bwd" in by and A:
-        # appearance scatter.  What reaches the L2 are the plane-tap atomics AFTER the kernel's run-length combining (a lane group
-        # sums the tap gradients of consecutive records in registers while the plane cell does not change; line and light rows
-        # are summed in LDS): counted here from the record positions with the kernel's own rule (atomic_segments_after_combining),
-        # per step = both launches.  The ceiling is the chip-wide L2 fp32 atomic rate per 64-B segment (micro-benchmark).
-        ms, cnt = by["tir_vm_app_bwd"]
-        seg = float(sum(seg_calls))
-        requested = 3 * A * (3 * (4 * 48 + 2 * 48)) / 16.0
-        roofline = {"kernel": "tir_vm_app_bwd", "bound": "l2-atomics", "achieved": round(seg / (ms * 1e-3) / 1e9, 3),
-                    "peak": ATOMIC_SEGMENTS_PER_S / 1e9, "unit": "G 64-B atomic segments/s",
-                    "frac": round(seg / (ms * 1e-3) / ATOMIC_SEGMENTS_PER_S, 4), "traffic": None,
-                    "avg_launch_ms": round(ms / max(cnt, 1), 4), "units_per_launch": round(seg / max(cnt, 1), 1),
-                    "unit_of_work": "64-B atomic segments issued to L2 per launch (after run-length combining)",
-                    "segments_requested_before_combining": round(requested, 1),
-                    "combining_factor": round(requested / max(seg, 1.0), 3),
-                    "peak_source": "tools/atomic_bench.hip -> profiles/r01_v4_atomic_bench.txt (chip-wide L2 fp32 atomic rate per 64-B "
-                                   "segment, 20.5 G/s); achieved = the atomics the kernel really sends to L2: 12 segments (4 plane taps x 3 "
-                                   "16-channel runs) per lane-group flush, flushes counted from the record positions with the kernel's rule "
-                                   "(aligned runs of 8 consecutive records, a flush whenever the plane cell changes)"}
-    wgrad = None
-    if "tir_mlp_wgrad_multi" in by and A:
-        ms, cnt = by["tir_mlp_wgrad_multi"]
-        nbytes = 4 * A * (128 + 128 + 4 + 128 + 128 + 32 + 3) * 4
-        wgrad = {"kernel": "tir_mlp_wgrad_multi", "bound": "hbm", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                 "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms / max(cnt, 1), 4),
-                 "algorithmic_bytes": "4 decoder invocations x records x (dz1 128 + dz2 128 + dz3 4 + h1 128 + h2 128 + feat 32 + aux 3) fp32"}
-    parity = cpu = None
-    if rank == 0 and not a.no_cpu_baseline:
-        parity, cpu = train_parity_and_cpu(a, ckpt, model, batches[0], lidx, gts[0], args, device)
-    if rank == 0:
-        value = world * B * a.steps / elapsed
-        line = {
-            "metric": "training rays/sec: forward + backward + Adam step at 4096 rays x 512 samples per GPU",
-            "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 io and parameters; decoder forward / backward / weight gradients split-bf16 x3, fp32 accumulate", "data": "synthetic",
-            "config": {"workload": f"train: Renderer_TensoIR_train(is_train=True, is_relight=True, stratified light directions) + loss + "
-                                   f"backward + Adam, {B} rays x {a.samples} samples per GPU, VM grid {a.grid}^3, {a.env_h * a.env_w} dirs x "
-                                   f"{a.second_samples}; the scene trains while it is timed (100 untimed steps first), {len(batches)} camera poses",
-                       "sharding": f"dp{world}: rays[rank-own batch], bucketed all-reduce of the {sum(p.numel() for p in params)} parameter "
-                                   f"gradients per step ({state['buckets']} buckets)" if use_dist else "single GPU",
-                       "records_per_step": A, "launch": "eager; weight-gradient leaves on a second HIP stream"},
-            "it_per_s": round(a.steps / elapsed, 2), "loss_first": l0, "loss_last": float(l1.detach()),
-            "device_memory_MB": {"allocated_before_timed_steps": round(mem0 / 2**20, 1), "allocated_after": round(mem1 / 2**20, 1),
-                                 "peak_during": round(mem_peak / 2**20, 1), "note": "torch caching allocator, this rank; equal "
-                                 "before / after over --steps steps = no per-step growth (run with --steps 3000 as a soak)"},
-            "world_size": (dist.get_world_size() if use_dist else 1), "device_count": torch.cuda.device_count(),
-            "backend": a.backend if use_dist else None, "per_rank_ms_per_step": [round(1e3 * x, 4) for x in per_rank],
-            "roofline": roofline, "roofline_weight_gradients": wgrad, "cpu_baseline": cpu, "parity": parity,
-            "hip_ms_per_step": round(sum(r[1] for r in rows), 3), "event_bracket_overhead_ms": round(ev_over, 5),
-            "entry_points": [{"name": nm, "ms_per_step": round(ms, 4), "launches": c} for nm, ms, c in rows[:14]],
-        }
-        if embed:
-            return line
-        print(json.dumps(line), flush=True)
-        if parity is not None and not parity["ok"]:
-            raise SystemExit(f"[bench] PARITY FAILURE vs the oracle (train workload): {parity}")
-    if use_dist:
-        dist.destroy_process_group()
-
-
-def _to_fp64(x):
-    """A Scene (nested SimpleNamespace / lists / dicts of tensors) with every floating-point tensor in double."""
-    if torch.is_tensor(x):
-        return x.double() if x.is_floating_point() else x
-    if isinstance(x, (list, tuple)):
-        return type(x)(_to_fp64(v) for v in x)
-    if isinstance(x, dict):
-        return {k: _to_fp64(v) for k, v in x.items()}
-    if isinstance(x, types.SimpleNamespace):
-        return type(x)(**{k: _to_fp64(v) for k, v in vars(x).items()})
-    return x
-
-
-FIELD_TENSORS = ("density_plane", "density_line", "app_plane", "app_line")
-
-
-def grad_deviation(gh, gr):
-    """Two {name: gradient} dicts -> the figures of the train parity: max-norm of the dense tensors (relative to the tensor's largest
-    element), relative L2 and outlier share (> 2e-3 of the largest) of the VM planes / lines, and the absolute L2 of the difference."""
-    dense, l2, outl, tot = 0.0, 0.0, 0.0, 0.0
-    for name, ref in gr.items():
-        if name not in gh or float(ref.abs().max()) == 0.0:
-            continue
-        ref = ref.double()
-        d = (gh[name].double() - ref).abs()
-        tot += float(d.pow(2).sum())
-        den = ref.abs().max()
-        if name.split(".")[0] in FIELD_TENSORS:
-            l2, outl = max(l2, float(d.norm() / ref.norm())), max(outl, float((d > 2e-3 * den).double().mean()))
-        else:
-            dense = max(dense, float(d.max() / den))
-    return {"dense": dense, "l2": l2, "outl": outl, "abs": tot ** 0.5}
-
-
-def single_ray_bisect(n, dev_of):
-    """The loss is a mean over rays, so a gradient deviation is a sum of per-ray deviations.  dev_of(index tensor) = grad_deviation of
-    the step restricted to those rays.  Halve the ray set, keep the half that carries more of the deviation (its absolute L2 times its
-    ray count: the weight it has in the full mean), until one ray is left -> (ray, deviation of that ray alone, deviation of all
-    rays but it)."""
-    cur = torch.arange(n)
-    alone = None
-    while cur.numel() > 1:
-        halves = (cur[:cur.numel() // 2], cur[cur.numel() // 2:])
-        devs = [dev_of(h) for h in halves]
-        k = 0 if devs[0]["abs"] * halves[0].numel() >= devs[1]["abs"] * halves[1].numel() else 1
-        cur, alone = halves[k], devs[k]
-    ray = int(cur[0])
-    everyone = torch.arange(n)
-    rest = dev_of(everyone[everyone != ray]) if n > 1 else {"dense": 0.0, "l2": 0.0, "outl": 0.0, "abs": 0.0}
-    return ray, alone, rest
-
-
-def train_parity_and_cpu(a, ckpt, model, rays, lidx, gt, args, device, n_sub=128):
-    """In-run parity of the training kernels at the bench's grid size: ONE step on every k-th ray of the batch (same ray jitter,
-    same BRDF-jitter noise, fixed light grid) -- loss, rendered maps and every parameter gradient against the oracle's autograd
-    (pinned to the reference's loss.backward() by tests/golden/train_grads.npz); the oracle call doubles as the CPU baseline."""
-    from oracle import tensoir_oracle as O          # checker / CPU baseline only
-    from tests.helpers import scene_from_model
-    from tensoir_amd import Renderer_TensoIR_train, ops
-    sc = scene_from_model(ckpt, model, a.env_h, a.env_w)      # the parameters as they are NOW (the scene has been training)
-    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    sc = O.scene_from_state_dict(sd, dict(ckpt["kwargs"]), sc.alpha_volume, sc.alpha_aabb, a.env_h, a.env_w)
-    stride = max(1, rays.shape[0] // n_sub)
-    r, l = rays[::stride].contiguous(), lidx[::stride].contiguous()
-    Bs, S = r.shape[0], a.samples
-    gen = torch.Generator().manual_seed(21)
-    jitter, noise = torch.rand(Bs, 1, generator=gen), torch.randn(Bs, S, 3, generator=gen)
-    # target of the CHECKED step: seeded random colours, not the colours the scene has been fitting.  Near its optimum the
-    # training gradient is a sum of cancelling terms: relative to its largest element the fp32 summation-order noise of two
-    # correct implementations then reaches 1e-3 (measured: 1e-4 ... 4e-3 from run to run, tools/train_parity_repeat.py), which
-    # says nothing about the kernels; with an independent target every gradient is O(1) and well conditioned
-    g = torch.rand(Bs, 3, generator=gen).to(gt.device)
-    w = dict(TRAIN_W)
-    (loss_ref, grads_ref, ret_ref), med, ts = timed_cpu(
-        lambda: O.train_step_grads(sc, r.cpu(), l.cpu(), g.cpu(), is_relight=True, n_samples=S, ray_jitter=jitter, brdf_jitter=noise,
-                                   second_n_sample=a.second_samples, weights=w), 0, 2)
-    model.zero_grad(set_to_none=True)
-    orig_rand, orig_fwd = torch.rand, type(model).forward
-
-    def fake_rand(*aa, **k):
-        if tuple(aa) == (Bs, 1) or (len(aa) == 1 and tuple(aa[0]) == (Bs, 1)):
-            return jitter.clone()
-        return orig_rand(*aa, **k)
-
-    def fwd(self, rr, ll, **k):
-        return orig_fwd(self, rr, ll, _brdf_jitter_dense=noise, **k)
-    torch.rand, type(model).forward = fake_rand, fwd
-    try:
-        ret = Renderer_TensoIR_train(r, None, l, model, N_samples=S, white_bg=True, is_train=True, is_relight=True,
-                                     sample_method="fixed_envirmap", device=device, args=args)
-    finally:
-        torch.rand, type(model).forward = orig_rand, orig_fwd
-    loss = train_loss(ret, g, True)
-    loss.backward()
-    maps = {k: float(f"{float((ret[k].detach().cpu() - ret_ref[k]).abs().max()):.3e}")
-            for k in ("rgb_map", "acc_map", "depth_map", "rgb_with_brdf_map", "normal_map", "albedo_map")}
-    # Gradient figures.  After a few hundred training steps the scene is sharp: sigma x step reaches ~50 at the surface, and the
-    # transmittance T = prod(1 - alpha) amplifies a relative error of sigma ~50-fold.  The HIP march evaluates sigma with its own
-    # summation order and the transcendental-unit softplus (~1e-6 relative; the fp32 oracle: ~1e-7), so the two sides agree on
-    # every threshold decision (identical w > 1e-4 record masks, checked below) and on the maps to 5e-6, but their per-sample
-    # weights differ by up to 6e-5 and single elements of the SPARSE field gradients (a texel of a VM plane collects a handful of
-    # samples) by 1e-3 ... 7e-3 of the tensor's largest element; the well-conditioned unit tests (tests/test_gpu_train.py, golden
-    # scene: max-norm 2e-3, measured 1.6e-4) do not have this amplification.  Round 5 measured both sides against the SAME step in
-    # fp64 (tools/train_parity_repeat.py, `against_fp64_oracle` below): the fp32 oracle stays within ~5e-5 ... 1.5e-4 of fp64,
-    # the HIP backward within 7e-4 ... 3e-3 in most states and 1e-2 in the worst ones -- the deviation is HIP's, not "the
-    # conditioning of the reference's own arithmetic" as earlier rounds wrote here.  Asserted: decoder / basis / light gradients
-    # (sums over EVERY record) max-norm < 2e-3 of the largest element; VM planes and lines relative L2 error < 3e-3 and < 2e-3 of
-    # the elements off by more than 2e-3 of the largest; their max-norm is reported.  (A record whose weight sits AT the 1e-4
-    # threshold and is kept by one side only moves a map by <= 1e-4 and the field gradients by up to 1.4e-2 of their maximum:
-    # seen in about one run in ten; reported as `record_mask_mismatches`.)
-    worst, l2, outl, hip_grads = {}, {}, {}, {}
-    for name, p in model.named_parameters():
-        ref = grads_ref.get(name)
-        if ref is None or float(ref.abs().max()) == 0.0 or p.grad is None:
-            continue
-        hip_grads[name] = p.grad.detach().cpu()
-        d = (hip_grads[name].double() - ref.double()).abs()
-        den = ref.double().abs().max()
-        worst[name] = float(d.max() / den)
-        if name.split(".")[0] in ("density_plane", "density_line", "app_plane", "app_line"):
-            l2[name] = float(d.norm() / ref.double().norm())
-            outl[name] = float((d > 2e-3 * den).double().mean())
-    model.zero_grad(set_to_none=True)
-    # threshold decisions: is some (ray, sample) a record (w > 1e-4) on one side only?  Such a sample moves a map by up to 1e-4 x value
-    # and the sparse field gradients by up to ~1e-2 of their largest element; it is a property of the hard threshold, reported here
-    flips = None
-    try:
-        with torch.no_grad():
-            w_hip = ops.march_primary_train(model.packed_field(), r, jitter.to(device), S, float(model.march_t_stop))[0].cpu()
-            _, aux = O.forward_primary(sc, r.cpu(), l.cpu(), n_samples=S, ray_jitter=jitter, brdf_jitter=noise, return_aux=True)
-        thr = float(sc.weight_thres)
-        flips = int(((w_hip > thr) != (aux.weight > thr)).sum())
-    except Exception as e:
-        print(f"[bench] record-mask comparison skipped ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
-    dense = {k: v for k, v in worst.items() if k not in l2}
-    gmax = max(dense.values()) if dense else 0.0
-    l2max, omax = (max(l2.values()) if l2 else 0.0), (max(outl.values()) if outl else 0.0)
-    parity = {"ok": abs(float(loss) - float(loss_ref)) < 1e-5 and max(maps.values()) < 1e-4 and gmax < 2e-3 and ((l2max < 3e-3 and omax < 2e-3) or bool(flips)),
-              "tolerance": "maps 1e-4 abs; decoder / basis / light gradients: max |hip - ref| / max |ref| per tensor < 2e-3 (the bound of the golden-scene "
-                           "unit tests; typically 2e-5 ... 2e-4 here, 1.6e-4 there); VM plane / line "
-                           "gradients (sparse sums on a sharp, ill-conditioned scene): relative L2 error < 3e-3 (measured 3.4e-4) and < 2e-3 of the elements off by "
-                           "more than 2e-3 of the largest -- waived (and reported) when a sample is a record on one side only (`record_mask_mismatches`); "
-                           "unit tests on the golden scene keep the max-norm.  ONE rule for `ok`: this strict bound on all rays (`ok_strict`), or -- "
-                           "when it is missed -- on all rays but ONE, found by bisection over the rays and reported with its own (bounded) deviation "
-                           "(`single_ray`); the same step against the oracle in fp64 is reported (`against_fp64_oracle`) and decides nothing",
-              "loss_abs_diff": float(f"{abs(float(loss) - float(loss_ref)):.3e}"), "maps_max_abs": maps,
-              "grad_max_rel": float(f"{gmax:.3e}"), "field_grad_rel_l2": float(f"{l2max:.3e}"), "field_grad_outlier_share": float(f"{omax:.3e}"),
-              "field_grad_max_rel": float(f"{max([worst[k] for k in l2] or [0.0]):.3e}"), "grad_tensors_compared": len(worst),
-              "record_mask_mismatches": flips,
-              "worst_tensors": {k: float(f"{v:.3e}") for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:4]},
-              "rays_compared": int(Bs), "note": "one extra step on a strided subsample of the batch against seeded random target colours (well-conditioned "
-                      "gradients), identical jitter draws on both sides; yardstick = the oracle's autograd in fp32"}
-    force64 = os.environ.get("TENSOIR_BENCH_FP64_ARBITRATION", "0") == "1"        # 1: run the fp64 step although the check passed
-    if (not parity["ok"] or force64) and abs(float(loss) - float(loss_ref)) < 1e-5 and max(maps.values()) < 1e-4:
-        # The gradients miss the strict bound although loss and maps agree.  The scene keeps training while it is timed, so every
-        # run ends in another state; in about one state in ten the HIP gradients are 2e-3 ... 1.6e-2 from the oracle's (measured over
-        # 28 runs, profiles/r05_train_parity_states.txt; HIP itself repeats to 5e-7 on a fixed state, so this is accuracy, not a
-        # race).  The SAME step in fp64 says which side is off: the fp32 oracle stays within ~5e-5 of fp64, the HIP backward does
-        # not.  Every miss bisected so far was ONE ray (tools/train_parity_bisect.py), and the oracle does the same against ITSELF when
-        # its decoder weights are perturbed by 1e-5 -- the split-bf16 decoders' distance from fp32 -- (tools/grad_kink_sensitivity.py:
-        # 25 % of 32 scenes above 2e-3): the gradient is discontinuous in the arithmetic, a ReLU mask of a pre-activation within 1e-5 of
-        # zero flips on one side only.  The fp64 figures are reported as measured and decide nothing: `ok` follows the one rule
-        # below (strict on all rays, or on all rays but one).
-        try:
-            _, g64, _ = O.train_step_grads(_to_fp64(sc), r.cpu().double(), l.cpu(), g.cpu().double(), is_relight=True, n_samples=S,
-                                           ray_jitter=jitter.double(), brdf_jitter=noise.double(), second_n_sample=a.second_samples, weights=w)
-
-            def against64(get):
-                dense_m, l2_m, out_m = 0.0, 0.0, 0.0
-                for name in worst:
-                    ref = g64.get(name)
-                    if ref is None or float(ref.abs().max()) == 0.0:
-                        continue
-                    d = (get(name).double() - ref).abs()
-                    den = ref.abs().max()
-                    if name in l2:
-                        l2_m, out_m = max(l2_m, float(d.norm() / ref.norm())), max(out_m, float((d > 2e-3 * den).double().mean()))
-                    else:
-                        dense_m = max(dense_m, float(d.max() / den))
-                return dense_m, l2_m, out_m
-            h = against64(lambda n: hip_grads[n])
-            o = against64(lambda n: grads_ref[n])
-            loose = h[0] < 1e-2 and ((h[1] < 1e-2 and h[2] < 5e-3) or bool(flips))
-            fmt = lambda t: {"grad_max_rel": float(f"{t[0]:.3e}"), "field_grad_rel_l2": float(f"{t[1]:.3e}"), "field_grad_outlier_share": float(f"{t[2]:.3e}")}
-            parity["against_fp64_oracle"] = {"hip": fmt(h), "fp32_oracle": fmt(o),
-                                             "loose_bound": "decoder / basis / light max-norm < 1e-2, VM planes / lines relative L2 < 1e-2 and outlier share < 5e-3, against the fp64 gradients",
-                                             "within_loose_bound": bool(loose)}
-        except Exception as e:
-            parity["against_fp64_oracle"] = {"error": f"{type(e).__name__}: {e}"}
-        parity["ok_strict"] = bool(parity["ok"])
-        if not parity["ok_strict"]:
-            # Every strict miss bisected so far was ONE ray (a ReLU mask of a near-zero pre-activation on a dominant record: the
-            # reference's own gradient jumps the same way, tools/grad_kink_sensitivity.py).  Find it; the other rays must keep the
-            # strict bound -- a defect of a kernel would not sit in one ray.
-            try:
-                def hip_step(idx):
-                    n = int(idx.numel())
-                    jit, noi = jitter[idx], noise[idx]
-                    model.zero_grad(set_to_none=True)
-
-                    def rand_n(*aa, **k):
-                        if tuple(aa) == (n, 1) or (len(aa) == 1 and tuple(aa[0]) == (n, 1)):
-                            return jit.clone()
-                        return orig_rand(*aa, **k)
-
-                    def fwd_n(self, rr, ll, **k):
-                        return orig_fwd(self, rr, ll, _brdf_jitter_dense=noi, **k)
-                    torch.rand, type(model).forward = rand_n, fwd_n
-                    try:
-                        ret_n = Renderer_TensoIR_train(r[idx.to(device)], None, l[idx.to(device)], model, N_samples=S, white_bg=True, is_train=True,
-                                                       is_relight=True, sample_method="fixed_envirmap", device=device, args=args)
-                    finally:
-                        torch.rand, type(model).forward = orig_rand, orig_fwd
-                    train_loss(ret_n, g[idx.to(g.device)], True).backward()
-                    out = {nm: p.grad.detach().cpu() for nm, p in model.named_parameters() if p.grad is not None}
-                    model.zero_grad(set_to_none=True)
-                    return out
-
-                def oracle_step(idx):
-                    return O.train_step_grads(sc, r[idx.to(device)].cpu(), l[idx.to(device)].cpu(), g[idx.to(g.device)].cpu(), is_relight=True, n_samples=S,
-                                              ray_jitter=jitter[idx], brdf_jitter=noise[idx], second_n_sample=a.second_samples, weights=w)[1]
-                ray, alone, rest = single_ray_bisect(Bs, lambda idx: grad_deviation(hip_step(idx), oracle_step(idx)))
-                rest_ok = rest["dense"] < 2e-3 and ((rest["l2"] < 3e-3 and rest["outl"] < 2e-3) or bool(flips))
-                # the excluded ray is bounded too: a flipped ReLU mask moves a ray's own gradient by its unit's share (5 % ... 160 %
-                # observed); anything beyond 2x the ray's gradient is not that mechanism
-                rest_ok = rest_ok and alone is not None and alone["dense"] < 2.0 and alone["l2"] < 2.0
-                short = lambda t: None if t is None else {k: float(f"{v:.3e}") for k, v in t.items() if k != "abs"}
-                parity["single_ray"] = {"ray_of_the_subsample": ray, "that_ray_alone": short(alone), "all_rays_but_it": short(rest),
-                                        "others_keep_the_strict_bound": bool(rest_ok),
-                                        "note": "bisection over the rays (the loss is a mean over rays); DESIGN 5: a ReLU-mask flip on one record"}
-                parity["ok"] = bool(rest_ok)       # THE rule: strict on all rays, or strict on all rays but one (reported, bounded)
-            except Exception as e:
-                parity["single_ray"] = {"error": f"{type(e).__name__}: {e}"}
-    cpu = {"value": round(Bs / med, 2), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"every {stride}th ray of the batch ({Bs} rays x {S} samples, {a.env_h * a.env_w} dirs x {a.second_samples}): forward + "
-                     f"autograd backward of the oracle, {len(ts)} timed calls, median (no optimizer step); host nproc={os.cpu_count()}"}
-    return parity, cpu
-
-
-def local_device(a):
-    """This rank's GPU index: LOCAL_RANK, or LOCAL_RANK modulo the visible devices with --allow-shared-gpu (plumbing runs of
-    several ranks on one device)."""
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.allow_shared_gpu and torch.cuda.is_available() and torch.cuda.device_count() > 0:
-        local %= torch.cuda.device_count()
-    return local
-
-
-def self_launch(a):
-    """`python bench.py --gpus N` with N > 1 and no launcher environment: become the launcher.  Re-executes this command
-    under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU, the
-    reference's own env rendezvous: train_tensoIR.py:22-27 reads RANK / WORLD_SIZE / MASTER_* the same way) and exits with
-    the launcher's return code; rank 0's JSON line is the child's stdout, passed through."""
-    import socket
-    import subprocess
-    if torch.cuda.is_available() and torch.cuda.device_count() < a.gpus and not a.allow_shared_gpu:
-        raise SystemExit(f"[bench] --gpus {a.gpus} but only {torch.cuda.device_count()} visible GPU(s) "
-                         "(--allow-shared-gpu: plumbing runs of several ranks on one device, not a measurement)")
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL across processes needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
-    env["TENSOIR_BENCH_SELF_LAUNCHED"] = "1"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
-    print(f"[bench] --gpus {a.gpus} without a launcher environment: starting {a.gpus} ranks: {' '.join(cmd[1:9])} bench.py ...",
-          file=sys.stderr, flush=True)
-    raise SystemExit(subprocess.call(cmd, env=env))
-
-
-def side_summary(line, wall_s):
-    """The fields of a side workload's full line that the headline run carries in its `workloads` block."""
-    rf, par, cpu = line.get("roofline") or {}, line.get("parity") or {}, line.get("cpu_baseline") or {}
-    worst = {k: par[k] for k in ("max_rel_floor1", "max_rel", "loss_abs_diff", "grad_max_rel", "field_grad_rel_l2", "field_grad_outlier_share",
-                                 "field_grad_max_rel", "record_mask_mismatches") if k in par}
-    if "relit_rgb" in par:
-        worst.update(par["relit_rgb"])
-    if "maps_max_abs" in par:
-        worst["maps_max_abs"] = max(par["maps_max_abs"].values())
-    return {"metric": line["metric"], "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "steps": line["steps"],
-            "warmup": line["warmup"], "scaling": line["scaling"], "workload": line["config"]["workload"],
-            "parity": {"ok": par.get("ok"), **worst},
-            "roofline": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac")} if rf else None,
-            "cpu_baseline": {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "sample")} if cpu else None,
-            "wall_s_incl_setup_and_cpu_checks": round(wall_s, 1)}
-
-
-def check_launch(a):
-    """--gpus N must be the number of ranks actually running, each with a GPU of its own: a scaling
-    line must not be printable from fewer processes or devices than it claims.  A bare `python bench.py --gpus N` (no
-    WORLD_SIZE / RANK in the environment) starts its N ranks itself (self_launch); a launcher environment whose WORLD_SIZE
-    differs from --gpus is refused."""
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
-        self_launch(a)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        raise SystemExit(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU, e.g. python -m "
-                         f"torch.distributed.run --nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} "
-                         f"(or unset WORLD_SIZE / RANK and bench.py starts its ranks itself)")
-    if torch.cuda.is_available() and torch.cuda.device_count() < world and not a.allow_shared_gpu:
-        raise SystemExit(f"[bench] {world} ranks but only {torch.cuda.device_count()} visible GPU(s) "
-                         "(--allow-shared-gpu: plumbing tests of several ranks on one device, not a measurement)")
-    if world > 1:
-        print(f"[bench] rank {os.environ.get('RANK', '0')}/{world} up (local rank {os.environ.get('LOCAL_RANK', '0')}, "
-              f"backend {a.backend})", file=sys.stderr, flush=True)
 
 
 def main():
