@@ -512,7 +512,72 @@ __device__ __forceinline__ float wave_sigma_t(const TirField& f, bool valid, flo
     return sig;
 }
 
-// wave_sigma_t with the density lines in LDS (ll); all 64 lanes call it together
+// ---- wave_sigma_t with the density lines in LDS (ll) and the tap SET-UP once per sample.  The lane that brought a sample builds
+// its three axis taps (make_tap_q: ~45 VALU instructions) and leaves a 9-dword record in the wave's LDS scratch; the C4 gather
+// lanes of a slot read the record and form their 18 addresses with one v_mad_u32_u24 each.  Before, every gather lane repeated
+// the set-up for its slot -- C4 times per sample, and the pass ran at 134 VALU instructions of which 78 were taps and addresses
+// (profiles/r06_march_isa.txt).  Same taps, same addresses, same arithmetic in the same order: bit-identical results.
+// Record: [x: i0 | i1 << 16] [y] [z] [x: w0 w1] [y: w0 w1] [z: w0 w1]; dword 0 receives the slot's feature sum afterwards.
+// Grid sizes < 2^16 (checked where the kernel is chosen).  wl: this wave's scratch, 64 * TIR_TAPREC dwords.
+#define TIR_TAPREC 9
+
+__device__ __forceinline__ unsigned mad_u24(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// 32-bit LDS addresses (device code only: the host pass of hipcc parses these bodies too and has no address space 3)
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+#else
+    return 0;
+#endif
+}
+__device__ __forceinline__ float4 lds_ld4(unsigned addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const __attribute__((address_space(3))) float4*)(uintptr_t)addr;
+#else
+    return float4{};
+#endif
+}
+
+template <int C4>
+__device__ __forceinline__ float density_chunk_rec(const TirField& f, const float* __restrict__ ll, const unsigned* __restrict__ rec, int c) {
+    constexpr unsigned TB = C4 * 16;                     // bytes per texel / line row
+    const unsigned pk[3] = {rec[0], rec[1], rec[2]};
+    const tir_f2 w[3] = {tir_f2{__uint_as_float(rec[3]), __uint_as_float(rec[4])}, tir_f2{__uint_as_float(rec[5]), __uint_as_float(rec[6])},
+                         tir_f2{__uint_as_float(rec[7]), __uint_as_float(rec[8])}};
+    unsigned ix[3][2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { ix[a][0] = pk[a] & 0xffffu; ix[a][1] = pk[a] >> 16; }
+    const unsigned cb = 16u * (unsigned)c;
+    unsigned col[2][2];                                  // this lane's chunk in column x / y of a plane row
+#pragma unroll
+    for (int a = 0; a < 2; ++a) { col[a][0] = mad_u24(ix[a][0], TB, cb); col[a][1] = mad_u24(ix[a][1], TB, cb); }
+    float acc = 0.0f;
+    // LDS byte address of this lane's chunk in row 0 of the current line (a 32-bit LDS address, so that the row offset is the only
+    // thing added per tap: v_mad_u32_u24 straight into ds_read_b128)
+    unsigned laddr = lds_addr(ll) + cb;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int m0 = (i == 2) ? 1 : 0, m1 = (i == 0) ? 1 : 2, vi = 2 - i;
+        const tir_f2 wa = w[m0] * tir_f2{w[m1].x, w[m1].x}, wb = w[m0] * tir_f2{w[m1].y, w[m1].y};
+        const unsigned row_bytes = (unsigned)f.grid[m0] * TB;
+        const float* pl = f.dplane[i];
+        const float4 a = ld4b(pl, mad_u24(ix[m1][0], row_bytes, col[m0][0]));
+        const float4 b = ld4b(pl, mad_u24(ix[m1][0], row_bytes, col[m0][1]));
+        const float4 cc = ld4b(pl, mad_u24(ix[m1][1], row_bytes, col[m0][0]));
+        const float4 d = ld4b(pl, mad_u24(ix[m1][1], row_bytes, col[m0][1]));
+        const float4 e = lds_ld4(mad_u24(ix[vi][0], TB, laddr));
+        const float4 g = lds_ld4(mad_u24(ix[vi][1], TB, laddr));
+        laddr += (unsigned)f.grid[vi] * TB;
+        acc = plane_line_4ch(a, b, cc, d, e, g, wa, wb, w[vi], acc);
+    }
+    return acc;
+}
+
 template <int C4>
 __device__ __forceinline__ float wave_sigma_lds(const TirField& f, const float* __restrict__ ll, bool valid, float x, float y,
                                                 float z, float* wl) {
@@ -521,25 +586,30 @@ __device__ __forceinline__ float wave_sigma_lds(const TirField& f, const float* 
     const int n = __popcll(m);
     if (n == 0) return 0.0f;
     const int rank = __popcll(m & ((1ull << lane) - 1ull));
-    if (valid) { wl[rank * 4] = x; wl[rank * 4 + 1] = y; wl[rank * 4 + 2] = z; }
+    unsigned* const wr = reinterpret_cast<unsigned*>(wl);
+    if (valid) {
+        const TapQ tx = make_tap_q(x, f.grid[0]), ty = make_tap_q(y, f.grid[1]), tz = make_tap_q(z, f.grid[2]);
+        unsigned* r = wr + rank * TIR_TAPREC;
+        r[0] = tx.i0 | (tx.i1 << 16); r[1] = ty.i0 | (ty.i1 << 16); r[2] = tz.i0 | (tz.i1 << 16);
+        r[3] = __float_as_uint(tx.w.x); r[4] = __float_as_uint(tx.w.y);
+        r[5] = __float_as_uint(ty.w.x); r[6] = __float_as_uint(ty.w.y);
+        r[7] = __float_as_uint(tz.w.x); r[8] = __float_as_uint(tz.w.y);
+    }
     __builtin_amdgcn_wave_barrier();
     constexpr int PER = 64 / C4;
     const int slot_in = lane / C4, c = lane % C4;
     for (int base = 0; base < n; base += PER) {
         const int slot = base + slot_in;
         float part = 0.0f;
-        if (slot < n) {
-            const float4 p = *reinterpret_cast<const float4*>(wl + slot * 4);
-            part = density_feature_chunk_lds<C4>(f, ll, p.x, p.y, p.z, c);
-        }
+        if (slot < n) part = density_chunk_rec<C4>(f, ll, wr + slot * TIR_TAPREC, c);
         if (C4 >= 2) part += dpp_f<0xB1, 0xf>(0.0f, part);
         if (C4 >= 4) part += dpp_f<0x4E, 0xf>(0.0f, part);
         if (C4 >= 8) part += dpp_f<0x141, 0xf>(0.0f, part);
-        if (slot < n && c == 0) wl[slot * 4 + 3] = part;
+        if (slot < n && c == 0) wl[slot * TIR_TAPREC] = part;      // (the slot's lanes have read the record: LDS ops of a wave complete in order)
     }
     __builtin_amdgcn_wave_barrier();
     float sig = 0.0f;
-    if (valid) sig = feature2density(f, wl[rank * 4 + 3]);
+    if (valid) sig = feature2density(f, wl[rank * TIR_TAPREC]);
     __builtin_amdgcn_wave_barrier();
     return sig;
 }

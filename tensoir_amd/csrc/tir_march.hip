@@ -717,8 +717,8 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins_a, const int
     float* ll = sl_lds;                                         // [line 0 | line 1 | line 2]
     const int nz = (n_sample + 3) & ~3;
     float* zt = sl_lds + line_floats;
-    float* ws = zt + nz + (threadIdx.x >> 6) * 256;             // this wave's gather scratch
-    int* s_cnt = reinterpret_cast<int*>(zt + nz + (NT / 64) * 256);
+    float* ws = zt + nz + (threadIdx.x >> 6) * (64 * TIR_TAPREC); // this wave's gather scratch: 64 tap records
+    int* s_cnt = reinterpret_cast<int*>(zt + nz + (NT / 64) * (64 * TIR_TAPREC));
     int* s_base = s_cnt + RPB;
     int* s_pid = s_base + RPB;
     __shared__ int s_wtot[2], s_bb, s_fits;
@@ -977,8 +977,8 @@ extern "C" int tir_march_secondary_ids_fwd(const TirField* f, const float* origi
     {
         const int64_t line_floats = (int64_t)(f->grid[0] + f->grid[1] + f->grid[2]) * f->n_dcomp;
         const size_t fixed = ((size_t)line_floats + ((n_sample + 3) & ~3)) * sizeof(float);
-        const size_t lds512 = fixed + (8 * 256 + 3 * 64) * sizeof(float), lds1024 = fixed + (16 * 256 + 3 * 128) * sizeof(float);
-        if (f->tune_lds_lines != 2 && f->n_dcomp == 16 && n_sample <= 96 && lds1024 + 8192 <= 158 * 1024) {
+        const size_t lds512 = fixed + (8 * 64 * TIR_TAPREC + 3 * 64) * sizeof(float), lds1024 = fixed + (16 * 64 * TIR_TAPREC + 3 * 128) * sizeof(float);
+        if (f->tune_lds_lines != 2 && f->n_dcomp == 16 && n_sample <= 96 && f->grid[0] < 65536 && f->grid[1] < 65536 && f->grid[2] < 65536 && lds1024 + 8192 <= 158 * 1024) {
             if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_march_secondary_lds<4, 3, 512>), 80 * 1024)) return rc;
             if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_march_secondary_lds<4, 3, 1024>), 150 * 1024)) return rc;
             const bool small = lds512 + 4096 <= 80 * 1024;          // two 512-thread blocks per CU (4 KB: the kernel's static LDS), else one of 1024
