@@ -547,8 +547,6 @@ template <int C4>
 __device__ __forceinline__ float density_chunk_rec(const TirField& f, const float* __restrict__ ll, const unsigned* __restrict__ rec, int c) {
     constexpr unsigned TB = C4 * 16;                     // bytes per texel / line row
     const unsigned pk[3] = {rec[0], rec[1], rec[2]};
-    const tir_f2 w[3] = {tir_f2{__uint_as_float(rec[3]), __uint_as_float(rec[4])}, tir_f2{__uint_as_float(rec[5]), __uint_as_float(rec[6])},
-                         tir_f2{__uint_as_float(rec[7]), __uint_as_float(rec[8])}};
     unsigned ix[3][2];
 #pragma unroll
     for (int a = 0; a < 3; ++a) { ix[a][0] = pk[a] & 0xffffu; ix[a][1] = pk[a] >> 16; }
@@ -563,7 +561,6 @@ __device__ __forceinline__ float density_chunk_rec(const TirField& f, const floa
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int m0 = (i == 2) ? 1 : 0, m1 = (i == 0) ? 1 : 2, vi = 2 - i;
-        const tir_f2 wa = w[m0] * tir_f2{w[m1].x, w[m1].x}, wb = w[m0] * tir_f2{w[m1].y, w[m1].y};
         const unsigned row_bytes = (unsigned)f.grid[m0] * TB;
         const float* pl = f.dplane[i];
         const float4 a = ld4b(pl, mad_u24(ix[m1][0], row_bytes, col[m0][0]));
@@ -573,7 +570,12 @@ __device__ __forceinline__ float density_chunk_rec(const TirField& f, const floa
         const float4 e = lds_ld4(mad_u24(ix[vi][0], TB, laddr));
         const float4 g = lds_ld4(mad_u24(ix[vi][1], TB, laddr));
         laddr += (unsigned)f.grid[vi] * TB;
-        acc = plane_line_4ch(a, b, cc, d, e, g, wa, wb, w[vi], acc);
+        // (the weights are read behind the taps: they are not needed before the taps arrive)
+        const tir_f2 w0 = {__uint_as_float(rec[3 + 2 * m0]), __uint_as_float(rec[4 + 2 * m0])};
+        const tir_f2 w1 = {__uint_as_float(rec[3 + 2 * m1]), __uint_as_float(rec[4 + 2 * m1])};
+        const tir_f2 wv = {__uint_as_float(rec[3 + 2 * vi]), __uint_as_float(rec[4 + 2 * vi])};
+        const tir_f2 wa = w0 * tir_f2{w1.x, w1.x}, wb = w0 * tir_f2{w1.y, w1.y};
+        acc = plane_line_4ch(a, b, cc, d, e, g, wa, wb, wv, acc);
     }
     return acc;
 }

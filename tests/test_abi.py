@@ -147,3 +147,28 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "tensoir_oracle" in txt:
                     bad.append(f)
     assert not bad, bad
+
+
+def test_hot_kernels_keep_their_register_budget(lib):
+    """DESIGN 4.1's occupancy statements as a build check (no GPU): the kernels of the bench step hold no scratch object and fit the
+    VGPR budget their waves-per-SIMD figure needs (tools/kernel_resources.py reads the gfx950 code object's metadata).  A PE array
+    that became a scratch object cost round 4 0.4 GB of scratch writes per launch; the 1024-thread march spilled one register in
+    the first tap-record version of round 6."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    from tensoir_amd import _lib
+    ks = {k["name"]: k for k in kernel_resources.kernels(_lib.LIB_PATH)}
+    budget = {"k_march_secondary_lds<4, 3, 512>": 128, "k_march_secondary_lds<4, 3, 1024>": 128,      # 4 waves per SIMD
+              "k_indirect_fused<12, true>": 168,                                                         # 3 waves per SIMD
+              "k_indirect_fused_hp<8>": 256, "k_mlp_bf16_multi<3, false>": 256, "k_vm_app_primary<12, false>": 256,
+              "k_march_primary": 256, "k_shade_integrate": 256}
+    for name, vgpr in budget.items():
+        assert name in ks, (name, sorted(ks)[:5])
+        k = ks[name]
+        assert k["scratch"] == 0 and k["vgpr_spill"] == 0, k
+        assert k["vgpr"] + k["agpr"] <= vgpr, k
+    # the only kernels allowed a scratch object: the fp32 VALU fallback decoder, the backward decoders (4 spilled registers), the
+    # rarely used hidden-saving aux-table decoder and the 16-lane scatter of the wide (24 / 96-channel) appearance grids
+    allowed = ("k_mlp_valu", "k_mlp_bwd_bf16", "k_mlp_bf16_auxt<false, true>", "k_mlp_bf16_auxt<true, true>", "k_vm_app_bwd<")
+    bad = [k for k in ks.values() if k["scratch"] and not k["name"].startswith(allowed)]
+    assert not bad, bad
