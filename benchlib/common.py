@@ -365,7 +365,11 @@ def trained_300_verdict():
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r06_precision_trained_300.json")))
         dec = d["policy"]["decision"]
-        return {"mode": dec["mode"], "why": dec["why"], "map_max_abs_f16_vs_full": dec["probe"].get("map_max_abs"), "limit": dec["probe"].get("limit"),
+        probe = dec["probe"]
+        # (a verdict other than f16 carries the rejected f16 measurement under "f16" and the accepted tier's own at the top)
+        f16 = probe.get("f16", probe).get("map_max_abs")
+        return {"mode": dec["mode"], "why": dec["why"], "map_max_abs_f16_vs_full": f16,
+                "map_max_abs_decided_vs_full": probe.get("map_max_abs"), "limit": probe.get("limit"),
                 "iterations": d.get("iterations"), "grids": d.get("grids"), "library_source_hash": d.get("library_source_hash"),
                 "stale": d.get("library_source_hash") != library_info().get("source_hash"),
                 "worst_map_vs_oracle": max(v["max_rel_floor1"] for v in d["oracle"].values() if isinstance(v, dict) and "max_rel_floor1" in v),

@@ -811,6 +811,7 @@ k_mlp_bf16_auxt(const float* __restrict__ packed, const float* __restrict__ feat
 // ------------------------------------------------------------------------------------------------
 constexpr int FUS_XH = 56;                                  // X tile row stride in halves (48 channels + 8)
 constexpr int FUS_WH_BYTES = 3 * 3 * 2 * 32 * 16;           // basis tiles [group][k-step][k-group][row] x 8 halves
+constexpr int FUS_DECODER_PRIO = 3;   // s_setprio of k_indirect_fused's decoder phase
 
 __device__ __forceinline__ int fus_feature_of_row(int row) {      // basis_mat row (feature) behind MFMA output row `row`, -1 = none
     const int kg = (row >> 2) & 1, slot = (row >> 3) * 4 + (row & 3);
@@ -1022,6 +1023,12 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        // The decoder phase runs at a raised wave priority: the waves of a SIMD tend to run the same phase at the same time, and with
+        // equal priorities the arbiter lets the gather-phase VALU work of one wave delay the matrix instructions of another whose
+        // accumulators everything downstream waits for.  Measured: alone on the stream 0.377-0.384 -> 0.370-0.371 ms (priority 3;
+        // 1: nothing), in the bench step 0.941 -> 0.936 ms (three alternating runs each).  The hp kernel gains 3 % alone on the stream
+        // with priority 1 and nothing in the step (two batches in flight): left without.
+        __builtin_amdgcn_s_setprio(FUS_DECODER_PRIO);
         // ---------------- decoder phase: facc[4 i + r] = this half's feature slot 4 i + r  (half 0: features 0..13, half 1: 14..26)
         float fo[16];
 #pragma unroll
@@ -1078,6 +1085,7 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
         float o3 = (o4[0][3] + o4[1][3]) + (o4[2][3] + o4[3][3]);
         o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64);
         o2 += __shfl_xor(o2, 32, 64); o3 += __shfl_xor(o3, 32, 64);
+        __builtin_amdgcn_s_setprio(0);
         if (h == 0 && sd < n) {
             const float* b2 = lds + BH_B2;
             float* op = out + sd * out_dim;
