@@ -351,14 +351,15 @@ def roofline_object(r, pmc_traffic, pmc_issue, pmc_meta=None):
         o["peak_source"] = ("dense bf16 MFMA 2.5 PF / 3 products of the split-bf16 scheme" if r["kernel"].endswith("bf16x3")
                             else "dense fp16 MFMA 2.5 PF (single product)" if r["kernel"].endswith("_f16") else "dense f32 MFMA 157.3 TF")
     if iss.get("valu_issue_frac") is not None and iss.get("mfma_busy_frac") is not None:
-        # On a gfx950 SIMD the VALU and the matrix pipe do not run at the same time: a matrix-only wave and a VALU-only wave sharing a
-        # SIMD take the SUM of their times (tools/mfma_valu_overlap.hip -> profiles/r06_mfma_valu_overlap.txt).  The fraction of the
+        # On a gfx950 SIMD fp32 VALU work and the matrix pipe do not run at the same time: a matrix-only wave and an fp32-VALU-only wave
+        # sharing a SIMD take the SUM of their times; packed-fp16 and integer instructions overlap ~60 % (tools/mfma_valu_overlap.hip ->
+        # profiles/r06_mfma_valu_overlap.txt).  The fraction of the
         # launch in which a SIMD executes one or the other is therefore the sum of the two counters -- the occupancy of the binding
         # resource of a kernel that is neither memory- nor single-pipe-bound.
         o["simd_issue"] = {"valu_issue_frac": iss["valu_issue_frac"], "mfma_busy_frac": iss["mfma_busy_frac"],
                            "sum": round(iss["valu_issue_frac"] + iss["mfma_busy_frac"], 4), "stale": stale,
-                           "note": "VALU and matrix instructions are mutually exclusive on a SIMD (measured: profiles/r06_mfma_valu_overlap.txt); "
-                                   "sum = share of the launch in which the SIMDs execute either"}
+                           "note": "fp32 VALU and matrix instructions are mutually exclusive on a SIMD, packed-fp16 / integer VALU overlap ~60 % (measured: "
+                                   "profiles/r06_mfma_valu_overlap.txt); sum ~ share of the launch in which the SIMDs execute either"}
     return o
 
 
