@@ -92,7 +92,7 @@ ROCPROF_KERNELS = {
     "tir_vm_app_fwd_h16": ["k_vm_app_h16 (radiance features of the secondary-ray records from the fp16 shadow planes)"],
     "tir_indirect_fused_fwd": ["k_indirect_fused (secondary-ray records: fp16-shadow gather + basis contraction + fp16 radiance decoder in one pass)"],
     "tir_vm_app_fwd": ["k_vm_app_primary<12> (primary stage: records + jittered records)", "k_vm_app_mfma<12, ...> (fp32 gather)"],
-    "tir_march_secondary_fwd": ["k_march_secondary_lds<4, 3, 512>"],
+    "tir_march_secondary_fwd": ["k_march_secondary_lds<4, 3, 512, true> (false: the visibility-only launches of a C5 view)"],
     "tir_march_primary_fwd": ["k_march_primary"],
 }
 

@@ -701,7 +701,7 @@ k_march_secondary(TirField f, const float* __restrict__ origins, const int32_t* 
 
 // NT = 512 (two blocks per CU while lines + scratch fit 80 KB: R <= ~370) or 1024 (one block per CU, e.g. the 400^3 field
 // of the ficus config: 76.8 KB of lines); RPB = NT / 8 rays per batch.
-template <int C4, int NSTEP, int NT>
+template <int C4, int NSTEP, int NT, bool REC>
 __global__ void __launch_bounds__(NT, 4)
 k_march_secondary_lds(TirField f, const float* __restrict__ origins_a, const int32_t* __restrict__ org_map_a,
                       const float* __restrict__ dirs_a, const int32_t* __restrict__ dir_map_a,
@@ -731,7 +731,7 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins_a, const int
                     float* vis; float* one_minus_acc; const int32_t* ray_ids; unsigned long long* stats; float occ_lo[3], occ_hi[3]; };
     __shared__ Parked s_park;
     __shared__ __attribute__((aligned(16))) float s_setup[NT / 64][8][12];     // per wave: set-up slots of its 8 rays of a batch
-    const bool want_rec = rec_counter_a != nullptr;
+    // REC = false: the visibility-only instantiation (a C5 view's launches) carries no weight registers, counts or record phase
     if (threadIdx.x == 0) s_park = Parked{rec_counter_a, rec_cap_a, rec_ray_a, rec_w_a, rec_xyz_a, ray_rec_off_a, ray_rec_cnt_a,
                                           origins_a, org_map_a, dirs_a, dir_map_a, active_a, vis_a, one_minus_acc_a, ray_ids_a, stats_a,
                                           {f.occ_lo[0], f.occ_lo[1], f.occ_lo[2]}, {f.occ_hi[0], f.occ_hi[1], f.occ_hi[2]}};
@@ -759,7 +759,7 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins_a, const int
     const float* const sh = sw + ((threadIdx.x >> 5) & 1) * 12;   // group g of this half-wave: sh + 24 g
 
     for (int64_t batch = xr.first; batch < xr.end; batch += xr.stride) {
-        float wreg[4][NSTEP];
+        float wreg[REC ? 4 : 1][REC ? NSTEP : 1];
         int cnts[4];
         // Per-ray set-up ONCE per batch with one lane per ray (lanes 0..7 of the wave), handed to the half-waves through LDS:
         // pair id -> (point, direction) division, the six loads and the slab test were ~160 VALU instructions executed by all
@@ -802,8 +802,10 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins_a, const int
             const int64_t ray = (int64_t)__float_as_int(s2.x);
             const bool in_range = (__float_as_int(s2.y) & 1) != 0, live = (__float_as_int(s2.y) & 2) != 0;
             int cnt = 0;
+            if constexpr (REC) {
 #pragma unroll
-            for (int st = 0; st < NSTEP; ++st) wreg[g][st] = 0.0f;
+                for (int st = 0; st < NSTEP; ++st) wreg[g][st] = 0.0f;
+            }
             if (__any(live)) {
                 const float o[3] = {s0.x, s0.y, s0.z}, d[3] = {s0.w, s1.x, s1.y};
                 const float t_in = s1.z, t_out = s1.w;
@@ -839,10 +841,12 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins_a, const int
                         float incl = scan_prod<32>(v, hl);
                         float excl = shift_up1<32>(incl, hl);
                         w = w * (T * excl);
-                        wreg[g][st] = on ? w : 0.0f;
                         acc += w;
-                        const unsigned long long m = __ballot(w > f.weight_thres);
-                        cnt += __popc((unsigned)(m >> half_shift));
+                        if constexpr (REC) {
+                            wreg[g][st] = on ? w : 0.0f;
+                            const unsigned long long m = __ballot(w > f.weight_thres);
+                            cnt += __popc((unsigned)(m >> half_shift));
+                        }
                         if (stats) n_gather += __popc((unsigned)(__ballot(valid) >> half_shift));
                         T = T * __shfl(incl, 31, 32);
                         if (!done && T < t_stop) done = true;
@@ -865,7 +869,7 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins_a, const int
                 s_pid[rl] = in_range ? (int)ray : -1;
             }
         }
-        if (!want_rec) continue;
+        if constexpr (!REC) continue;
         __syncthreads();
         // one reservation for the batch: inclusive scan of the RPB ray counts (one or two waves), one atomic
         int c = 0, incl = 0;
@@ -919,7 +923,7 @@ k_march_secondary_lds(TirField f, const float* __restrict__ origins_a, const int
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st) {
                 const int k = st * 32 + hl;
-                const float w = wreg[g][st];
+                const float w = wreg[REC ? g : 0][REC ? st : 0];
                 const bool keep = w > f.weight_thres;
                 const unsigned hm = (unsigned)(__ballot(keep) >> half_shift);
                 if (keep) {
@@ -979,23 +983,23 @@ extern "C" int tir_march_secondary_ids_fwd(const TirField* f, const float* origi
         const size_t fixed = ((size_t)line_floats + ((n_sample + 3) & ~3)) * sizeof(float);
         const size_t lds512 = fixed + (8 * 64 * TIR_TAPREC + 3 * 64) * sizeof(float), lds1024 = fixed + (16 * 64 * TIR_TAPREC + 3 * 128) * sizeof(float);
         if (f->tune_lds_lines != 2 && f->n_dcomp == 16 && n_sample <= 96 && f->grid[0] < 65536 && f->grid[1] < 65536 && f->grid[2] < 65536 && lds1024 + 8192 <= 158 * 1024) {
-            if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_march_secondary_lds<4, 3, 512>), 80 * 1024)) return rc;
-            if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_march_secondary_lds<4, 3, 1024>), 150 * 1024)) return rc;
             const bool small = lds512 + 4096 <= 80 * 1024;          // two 512-thread blocks per CU (4 KB: the kernel's static LDS), else one of 1024
             const int rpb = small ? 64 : 128;
             const int64_t n_batches = (n_rays + rpb - 1) / rpb;
             unsigned nblk = (unsigned)std::min<int64_t>(n_batches, small ? 2 * 256 : 256);
             if (xcd_on) nblk = (nblk + 7) / 8 * 8;
-            if (small)
-                hipLaunchKernelGGL((k_march_secondary_lds<4, 3, 512>), dim3(nblk), dim3(512), lds512, tir_stream(stream),
-                                   *f, origins, org_map, dirs, dir_map, active, n_rays, n_dirs, n_sample, z_vals, t_stop, vis,
-                                   one_minus_acc, rec_counter, rec_cap, rec_ray, rec_w, rec_xyz, ray_rec_off, ray_rec_cnt, stats,
-                                   xcd_on, ray_ids, n_ids_dev, (int)line_floats);
-            else
-                hipLaunchKernelGGL((k_march_secondary_lds<4, 3, 1024>), dim3(nblk), dim3(1024), lds1024, tir_stream(stream),
-                                   *f, origins, org_map, dirs, dir_map, active, n_rays, n_dirs, n_sample, z_vals, t_stop, vis,
-                                   one_minus_acc, rec_counter, rec_cap, rec_ray, rec_w, rec_xyz, ray_rec_off, ray_rec_cnt, stats,
-                                   xcd_on, ray_ids, n_ids_dev, (int)line_floats);
+            // (the visibility-only launches of a C5 view run the instantiation without weight registers, counts and record phase)
+#define TIR_LAUNCH_SEC_LDS(NT_, REC_, LDS_, CAP_)                                                                                          \
+            do {                                                                                                                          \
+                if (int rc = tir_allow_dynamic_lds(reinterpret_cast<const void*>(k_march_secondary_lds<4, 3, NT_, REC_>), CAP_)) return rc; \
+                hipLaunchKernelGGL((k_march_secondary_lds<4, 3, NT_, REC_>), dim3(nblk), dim3(NT_), LDS_, tir_stream(stream),             \
+                                   *f, origins, org_map, dirs, dir_map, active, n_rays, n_dirs, n_sample, z_vals, t_stop, vis,            \
+                                   one_minus_acc, rec_counter, rec_cap, rec_ray, rec_w, rec_xyz, ray_rec_off, ray_rec_cnt, stats,         \
+                                   xcd_on, ray_ids, n_ids_dev, (int)line_floats);                                                         \
+            } while (0)
+            if (small) { if (rec_counter) TIR_LAUNCH_SEC_LDS(512, true, lds512, 80 * 1024); else TIR_LAUNCH_SEC_LDS(512, false, lds512, 80 * 1024); }
+            else       { if (rec_counter) TIR_LAUNCH_SEC_LDS(1024, true, lds1024, 150 * 1024); else TIR_LAUNCH_SEC_LDS(1024, false, lds1024, 150 * 1024); }
+#undef TIR_LAUNCH_SEC_LDS
             TIR_CHECK_LAUNCH();
             return TIR_OK;
         }

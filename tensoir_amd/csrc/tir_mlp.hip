@@ -1042,9 +1042,15 @@ k_indirect_fused(TirField f, TirFieldHalf fh, const float* __restrict__ packed, 
             for (int q = 0; q < 64; q += 2) {
                 // (the builtin, not the inline-asm relu_sat16: these reads come straight behind layer 1's last MFMAs, and the hazard
                 //  recogniser does not insert the MFMA -> VALU wait states for inline asm -- that read stale accumulators: 1e-3 errors)
-                const f32x2_t v2 = {__builtin_amdgcn_fmed3f(acc[q >> 4][q & 15], 0.0f, 65504.0f),
-                                    __builtin_amdgcn_fmed3f(acc[(q + 1) >> 4][(q + 1) & 15], 0.0f, 65504.0f)};
-                hp[q >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, fus_f16x2));
+                // Convert first, then ReLU and saturation on the PACKED fp16 pipe (v_pk_max_f16 / v_pk_min_f16): the same values for every
+                // finite input (rounding is monotonic, rnd(0) = 0, an overflow becomes inf and is cut to 65504), 32 fp32-class
+                // instructions instead of 96 -- and packed fp16 instructions run under other waves' matrix instructions, fp32 ones
+                // do not (profiles/r06_mfma_valu_overlap.txt).
+                const f32x2_t v2 = {acc[q >> 4][q & 15], acc[(q + 1) >> 4][(q + 1) & 15]};
+                fus_f16x2 hv = __builtin_convertvector(v2, fus_f16x2);
+                hv = __builtin_elementwise_min(__builtin_elementwise_max(hv, fus_f16x2{(_Float16)0.0f, (_Float16)0.0f}),
+                                               fus_f16x2{(_Float16)65504.0f, (_Float16)65504.0f});
+                hp[q >> 1] = __builtin_bit_cast(unsigned, hv);
             }
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
