@@ -102,6 +102,8 @@ def main():
             f = fam_of(nm)
             num[f] += float((ga[nm] - ref).pow(2).sum()); den[f] += float(ref.pow(2).sum())
         return {f: ((num[f] / den[f]) ** 0.5 if den[f] > 0 else float("nan")) for f in FAM}
+    cap_out = {}
+
     def per_sample():
         """d loss / d density feature per sample, rgb term only: HIP kernel / fp64 re-evaluation of its formula on its inputs / oracle autograd."""
         from tensoir_amd import ops
@@ -142,6 +144,29 @@ def main():
         o_sig, o_gs = cap["or_sigma"], cap["or_gsigma"]
         df_or = o_gs * (-torch.expm1(-o_sig))
         print(f"  sigma: max |hip - oracle| / max {float((sig - o_sig).abs().max() / o_sig.abs().max()):.2e}, rel L2 {float((sig - o_sig).norm() / o_sig.norm()):.2e}", flush=True)
+        # which input carries it: the same fp64 formula on the ORACLE's sigma with HIP's cotangents
+        x2 = o_sig * delta
+        al2 = 1.0 - torch.exp(-x2); v2 = 1.0 - al2 + 1e-10
+        T2 = torch.cumprod(torch.cat([torch.ones(B_, 1, dtype=torch.float64), v2], 1), 1)[:, :-1]
+        a2 = gk * (al2 * T2)
+        sfx2 = torch.flip(torch.cumsum(torch.flip(a2, [1]), 1), [1]) - a2
+        df64_os = (gk * T2 - sfx2 / v2) * delta * torch.exp(-x2) * (-torch.expm1(-o_sig))
+        live = (sig > 0) & (o_sig > 0) & (T > 1e-4)
+        rel = ((sig - o_sig).abs() / o_sig.abs().clamp_min(1e-30))[live]
+        print(f"  sigma where both marched and T > 1e-4 ({int(live.sum())} samples): |hip - oracle| / oracle  max {float(rel.max()):.2e}  rms {float(rel.pow(2).mean().sqrt()):.2e}  median {float(rel.median()):.2e}", flush=True)
+        relf = torch.where(live, (sig - o_sig).abs() / o_sig.abs().clamp_min(1e-30), torch.zeros_like(sig))
+        top = torch.topk(relf.flatten(), 6).indices
+        for ti in top.tolist():
+            r_, k_ = ti // S_, ti % S_
+            print(f"    worst: ray {r_} sample {k_}  sigma hip {float(sig[r_, k_]):.6e} oracle {float(o_sig[r_, k_]):.6e}  T {float(T[r_, k_]):.3e}  neighbours (oracle) {[float(f'{float(v):.3e}') for v in o_sig[r_, max(0, k_ - 2):k_ + 3]]}", flush=True)
+        for lo_, hi_ in ((0, 1e-3), (1e-3, 1e-1), (1e-1, 10), (10, 1e9)):
+            mm = live & (o_sig >= lo_) & (o_sig < hi_)
+            if int(mm.sum()):
+                rr = relf[mm]
+                print(f"    sigma in [{lo_:g}, {hi_:g}): {int(mm.sum())} samples, rel diff rms {float(rr.pow(2).mean().sqrt()):.2e} max {float(rr.max()):.2e}", flush=True)
+        print(f"  fp64(formula) on the ORACLE's sigma + HIP's cotangents - oracle autograd: {float((df64_os - df_or).norm()) / float(df64.norm()):.2e}"
+              f"   (on HIP's sigma: {float((df64 - df_or).norm()) / float(df64.norm()):.2e})  -> the part of the distance that sigma carries", flush=True)
+        cap_out["sig"], cap_out["T"], cap_out["o_sig"] = sig, T, o_sig
         regions = {"in front (T > 0.99)": T > 0.99, "surface (0.01 < T <= 0.99)": (T <= 0.99) & (T > 0.01), "behind (T <= 0.01)": T <= 0.01, "all samples": torch.ones_like(T, dtype=torch.bool)}
         tot = float(df64.norm())
         for name, m in regions.items():
@@ -160,6 +185,26 @@ def main():
             print(f"    {f:22s} |grad| {norm[f]:.3e}   hip-fp32 oracle {a_[f]:.2e}   hip-fp64 oracle {b_[f]:.2e}   fp32-fp64 oracle {c_[f]:.2e}", flush=True)
     print("per-sample d loss / d density feature of the rgb term (march backward):", flush=True)
     per_sample()
+    # the density FEATURE itself on identical normalised coordinates: HIP's gather against the oracle's (fp32 and fp64)
+    with torch.no_grad():
+        pts, z, valid = O.sample_ray(sc, r_all[:, :3].cpu(), r_all[:, 3:6].cpu(), S, jitter)
+        xyz = O.normalize_coord(sc, pts)[valid]
+        f_or = O.density_feature(sc, xyz, "aten").double()
+        f_64 = O.density_feature(sc64, xyz.double(), "aten")
+        f_hip = model.compute_densityfeature(xyz.to(device)).cpu().double()
+        # HIP's MARCH sigma against sigma from HIP's own gather at the ORACLE's sample coordinates: do the march's coordinates differ?
+        sg = torch.zeros_like(cap_out["sig"])
+        sg[valid] = torch.nn.functional.softplus(f_hip + float(sc.density_shift))
+        m2 = (cap_out["sig"] > 0) & (sg > 0) & (cap_out["T"] > 1e-4)
+        r2 = ((cap_out["sig"] - sg).abs() / sg.clamp_min(1e-30))[m2]
+        r3 = ((cap_out["o_sig"] - sg).abs() / sg.clamp_min(1e-30))[m2]
+        print(f"march sigma (HIP) vs softplus(HIP gather at the oracle's coordinates), {int(m2.sum())} samples: rel rms {float(r2.pow(2).mean().sqrt()):.2e} max {float(r2.max()):.2e};"
+              f"   oracle's march sigma vs the same: rms {float(r3.pow(2).mean().sqrt()):.2e} max {float(r3.max()):.2e}", flush=True)
+        near = (f_64 + float(sc.density_shift)) > -12.0          # samples whose sigma is not negligible
+        for nm, m_ in (("all in-box samples", torch.ones_like(near)), ("feature + shift > -12", near)):
+            d_h, d_o = (f_hip - f_64)[m_], (f_or - f_64)[m_]
+            print(f"density feature, {nm} ({int(m_.sum())}): |f| rms {float(f_64[m_].pow(2).mean().sqrt()):.2f}   hip - fp64: rms {float(d_h.pow(2).mean().sqrt()):.2e} max {float(d_h.abs().max()):.2e}"
+                  f"   fp32 oracle - fp64: rms {float(d_o.pow(2).mean().sqrt()):.2e} max {float(d_o.abs().max()):.2e}   hip - fp32 oracle: rms {float((f_hip - f_or)[m_].pow(2).mean().sqrt()):.2e} max {float((f_hip - f_or)[m_].abs().max()):.2e}   (absolute; d sigma / sigma <= this for sigma << 1)", flush=True)
 
 
 if __name__ == "__main__":
