@@ -451,12 +451,27 @@ def main():
         # how many rays carry the worst figure: a decision flip (one secondary sample on the other side of an occupancy-cell
         # boundary because the surface point differs in its last bits) shows up as ONE ray far above the rest
         d_all = (ret["rgb_with_brdf_map"].detach().cpu()[::stride][: a.cpu_rays] - ref["rgb_with_brdf_map"]).abs().max(dim=-1).values
+        # ... and is examined on the ORACLE alone: a ray whose reference colour moves by more than 1e-5 when the oracle's own depth
+        # moves by one or two ulps is a ray on which the reference is discontinuous (tests/helpers.py depth_discontinuity_rays) --
+        # listed with the oracle's own jump, not compared.  Both exemption classes together are capped at max(2, rays / 500).
+        from tests.helpers import depth_discontinuity_rays
+        cand = torch.nonzero(keep & (d_all > 1e-5)).reshape(-1).tolist()
+        jumps = depth_discontinuity_rays(O, sc, ref, r_cpu, l_cpu, cand, a.second_samples) if cand else {}
+        for i_ in jumps:
+            keep[i_] = False
+        if jumps:
+            m = parity_metrics(ret["rgb_with_brdf_map"].detach().cpu()[::stride][: a.cpu_rays][keep], ref["rgb_with_brdf_map"][keep])
+            per_map["rgb_with_brdf_map"] = {kk: float(f"{vv:.3e}") for kk, vv in m.items()}
+            worst = {kk: max(max(v_[kk] for v_ in per_map.values()), 0.0) for kk in worst}
         d_b = d_all[keep]
         top2 = torch.topk(d_b, min(2, d_b.numel())).values.tolist()
-        parity = {"ok": worst["max_rel_floor1"] < 1e-4 and worst["max_rel_pixel"] < 1e-4 and int(flip.sum()) <= max(2, flip.numel() // 500),
+        parity = {"ok": worst["max_rel_floor1"] < 1e-4 and worst["max_rel_pixel"] < 1e-4 and int(flip.sum()) + len(jumps) <= max(2, flip.numel() // 500),
                   "tolerance": 1e-4,
                   "ggx_normal_flip_rays": {"count": int(flip.sum()), "criterion": "|N.V| < 1e-5 for the oracle's composited normal",
                                            "rgb_with_brdf_abs_diff_there": [float(f"{v:.3e}") for v in d_all[flip].tolist()[:8]]},
+                  "depth_discontinuity_rays": {"count": len(jumps), "criterion": "the ORACLE's rgb_with_brdf on its own maps varies by > 1e-5 when its own depth moves by -2 ... +2 ulps "
+                                               "(a secondary sample on an occupancy / box boundary, models/relight_utils.py:433, :683-695); candidates: rays > 1e-5 off",
+                                               "rays": {str(k_): {"oracle_own_jump": float(f"{v_:.3e}"), "hip_abs_diff": float(f"{float(d_all[k_]):.3e}")} for k_, v_ in jumps.items()}},
                   "rgb_with_brdf_rays_over_1e-5": int((d_b > 1e-5).sum()), "rgb_with_brdf_second_worst_abs": float(f"{top2[-1]:.3e}"),
                   "metric": "BOTH asserted < 1e-4: max |hip - oracle| / max(|oracle|, 1) per map (maps live in [0,1], unit normals, "
                             "depth ~4) and max_rel = the true per-pixel relative error ||d|| / ||ref|| over pixels with ||ref|| > 1e-2 "

@@ -99,3 +99,34 @@ def ggx_flip_rays(ref_normal_map, rays, eps=1e-5):
     n = n / n.norm(dim=-1, keepdim=True).clamp(min=1e-6)
     v = -d / d.norm(dim=-1, keepdim=True).clamp(min=1e-6)
     return (n * v).sum(-1).abs() < eps
+
+
+def depth_discontinuity_rays(O, sc, ref, rays, light_idx, candidates, n_sample, tol=1e-5, limit=16):
+    """Rays on which the reference's physically-based colour is DISCONTINUOUS in the ray's own depth: the secondary rays start at
+    rays_o + depth * rays_d (models/relight_utils.py:433), and a secondary sample that sits on an occupancy-cell or bounding-box
+    boundary within the last bits is culled or not (:683-695, :803-815) -- the visibility of that light direction, hence
+    rgb_with_brdf_map, jumps.  The criterion involves the ORACLE only: its own render_with_brdf on its own maps, with its own depth
+    moved by -2 ... +2 ulps, varies by more than `tol` (measured on the headline batch: two rays of 4096 jump by 2.1e-4 and 1.3e-4 for
+    ONE ulp of depth, their neighbours by 1e-7 per ulp; profiles/r06_depth_discontinuity_rays.txt).  Only `candidates` (ray indices into
+    the oracle's rows, at most `limit`) are examined.  -> {ray: the oracle's own spread}."""
+    import numpy as np
+    out = {}
+    rays = torch.as_tensor(rays).detach().cpu().float()
+    light_idx = torch.as_tensor(light_idx).detach().cpu()
+    for i in [int(c) for c in candidates][:limit]:
+        g = lambda k: ref[k][i:i + 1]
+        d0 = g("depth_map").reshape(1).float().numpy()
+        vals = []
+        for u in (-2, -1, 0, 1, 2):
+            d = d0.copy()
+            for _ in range(abs(u)):
+                d = np.nextafter(d, np.float32(np.inf if u > 0 else -np.inf))
+            with torch.no_grad():
+                o = O.render_with_brdf(sc, torch.from_numpy(d), g("normal_map"), g("albedo_map"), g("roughness_map").reshape(1, -1).expand(1, 3),
+                                       g("fresnel_map"), rays[i:i + 1], light_idx[i:i + 1], n_sample=n_sample)
+            vals.append(o.reshape(-1))
+        v = torch.stack(vals)
+        spread = float((v.max(0).values - v.min(0).values).max())
+        if spread > tol:
+            out[i] = spread
+    return out
