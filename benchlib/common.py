@@ -420,13 +420,27 @@ def timed_cpu(fn, warm, calls):
     return out, ts[len(ts) // 2], ts
 
 
-def map_parity(got, ref, keys, sel=None, rays=None):
+def map_parity(got, ref, keys, sel=None, rays=None, disc=None):
     """max |hip - oracle| / max(|oracle|, 1) over the named maps (the test metric), per map and worst.  rays (the oracle's rows):
     rgb_with_brdf_map is compared on the rays where the reference's GGX normal flip is not within fp32 noise of its
-    discontinuity (tests/helpers.py ggx_flip_rays)."""
-    from tests.helpers import ggx_flip_rays, parity_metrics
+    discontinuity (tests/helpers.py ggx_flip_rays).  disc = (oracle module, scene, light_idx rows, secondary samples): rays more
+    than 1e-5 off whose ORACLE colour itself jumps by more than 1e-5 for +-2 ulps of the oracle's own depth are listed, not compared
+    (tests/helpers.py depth_discontinuity_rays; at most max(1, rays / 500) of them)."""
+    from tests.helpers import depth_discontinuity_rays, ggx_flip_rays, parity_metrics
     per, worst = {}, 0.0
     keep = ~ggx_flip_rays(ref["normal_map"], rays) if rays is not None and "normal_map" in ref else None
+    jumps = {}
+    if disc is not None and keep is not None and "rgb_with_brdf_map" in keys:
+        g = got["rgb_with_brdf_map"].detach().cpu()
+        g = g[sel] if sel is not None else g
+        d_all = (g - ref["rgb_with_brdf_map"]).abs().max(dim=-1).values
+        cand = torch.nonzero(keep & (d_all > 1e-5)).reshape(-1).tolist()
+        if cand:
+            O_, sc_, l_rows, n_s = disc
+            jumps = depth_discontinuity_rays(O_, sc_, ref, rays, l_rows, cand, n_s)
+            jumps = dict(list(jumps.items())[: max(1, int(keep.numel()) // 500)])
+            for i_ in jumps:
+                keep[i_] = False
     for k in keys:
         g = got[k].detach().cpu()
         g = g[sel] if sel is not None else g
@@ -439,6 +453,7 @@ def map_parity(got, ref, keys, sel=None, rays=None):
     worst_px = max(v["max_rel_pixel"] for v in per.values()) if per else 0.0
     return {"ok": worst < 1e-4 and worst_px < 1e-4, "tolerance": 1e-4, "max_rel_floor1": float(f"{worst:.3e}"),
             "max_rel": float(f"{worst_px:.3e}"), "per_map": per,
+            "depth_discontinuity_rays": {str(k_): float(f"{v_:.3e}") for k_, v_ in jumps.items()},
             "metric": "both asserted: max |hip - oracle| / max(|oracle|, 1) per map and the true per-pixel relative error "
                       "||d|| / ||ref|| over pixels with ||ref|| > 1e-2"}
 

@@ -37,7 +37,7 @@ def sharp_scene_line(a, device, args):
         with torch.no_grad():
             ref = O.renderer_train(sc, rays.cpu()[::stride], lidx.cpu()[::stride], n_samples=a.samples, second_n_sample=a.second_samples)
         got = {k: v.clone() for k, v in ret.items() if torch.is_tensor(v)}
-        parity = map_parity(got, ref, MAP_KEYS, slice(0, None, stride), rays.cpu()[::stride])
+        parity = map_parity(got, ref, MAP_KEYS, slice(0, None, stride), rays.cpu()[::stride], disc=(O, sc, lidx.cpu()[::stride], a.second_samples))
         parity["rays_compared"] = int(ref["rgb_map"].shape[0])
         parity["indirect_precision"] = model.indirect_precision()
     for _ in range(5):
@@ -176,7 +176,7 @@ def bench_image(a, embed=False):
         stride = max(1, a.rays // 128)
         r_cpu, l_cpu = rc.cpu()[::stride], lc.cpu()[::stride]
         ref, med, ts = timed_cpu(lambda: O.renderer_train(sc, r_cpu, l_cpu, n_samples=-1, second_n_sample=a.second_samples), 1, 3)
-        parity = map_parity(ret_c, ref, MAP_KEYS, slice(0, None, stride), r_cpu)
+        parity = map_parity(ret_c, ref, MAP_KEYS, slice(0, None, stride), r_cpu, disc=(O, sc, l_cpu, a.second_samples))
         parity["rays_compared"] = int(r_cpu.shape[0])
         cpu = {"value": round(r_cpu.shape[0] / med, 2), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
                "sample": f"every {stride}th ray of the image's middle chunk ({r_cpu.shape[0]} rays x {model.nSamples} samples, "
